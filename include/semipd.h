@@ -1,0 +1,271 @@
+/*
+ * semipd.h — C-ABI of libsemipd_hip.so, the MI355X (gfx950) Semi-PD hot path.
+ *
+ * Every entry point takes plain device pointers, sizes and a hipStream_t
+ * (passed as void*, 0 = the legacy default stream).  Nothing here includes a
+ * torch type: the shared library is built with hipcc alone.  All functions
+ * return 0 on success, a positive hipError_t value when the HIP runtime
+ * failed, or a negative SEMIPD_E* code for argument errors.  No entry point
+ * synchronises the stream or allocates memory, so every launch is
+ * hipGraph-capturable (reference requirement: base_attn_backend.py:22-55).
+ *
+ * Each declaration cites the reference interface it replaces
+ * (paths relative to the reference checkout).
+ */
+#ifndef SEMIPD_H_
+#define SEMIPD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* element types of activations / KV rows (a subset of at::ScalarType) */
+enum { SEMIPD_F32 = 0, SEMIPD_F16 = 1, SEMIPD_BF16 = 2 };
+
+/* argument-error codes (negative; HIP errors are returned positive) */
+enum {
+  SEMIPD_EINVAL = -1,      /* bad size / null pointer                */
+  SEMIPD_EDTYPE = -2,      /* unsupported element type               */
+  SEMIPD_ESHAPE = -3,      /* head size / group size not supported   */
+  SEMIPD_EALIGN = -4,      /* pointer or stride not 16-byte aligned  */
+  SEMIPD_ENOTFOUND = -5,   /* IPC mapping not known                  */
+};
+
+/* Library version and last error string (thread-local). */
+int semipd_version(void);
+const char* semipd_last_error(void);
+
+/* ------------------------------------------------------------------ */
+/* a1  RMSNorm                                                         */
+/* ------------------------------------------------------------------ */
+/* out[t,:] = in[t,:] * rsqrt(mean(in[t,:]^2)+eps) * w   (fp32 math)
+ * replaces torch.ops.sgl_kernel.rmsnorm
+ *   (sgl-kernel/csrc/torch_extension.cc:49, python/sgl_kernel/elementwise.py:9-19;
+ *    semantics layers/layernorm.py:59-76).  in_stride/out_stride in elements. */
+int semipd_rmsnorm(void* out, const void* in, const void* weight, int64_t num_tokens,
+                   int64_t hidden, int64_t in_stride, int64_t out_stride, float eps, int dtype,
+                   void* stream);
+
+/* x = in + res (fp32); res = x; in = x*rsqrt(mean(x^2)+eps)*w; both in place.
+ * replaces torch.ops.sgl_kernel.fused_add_rmsnorm
+ *   (torch_extension.cc:52; csrc/elementwise/fused_add_rms_norm_kernel.cu:24-55). */
+int semipd_fused_add_rmsnorm(void* inout, void* residual, const void* weight, int64_t num_tokens,
+                             int64_t hidden, float eps, int dtype, void* stream);
+
+/* ------------------------------------------------------------------ */
+/* activation                                                          */
+/* ------------------------------------------------------------------ */
+/* out[t,:d] = silu(in[t,:d]) * in[t,d:2d]
+ * replaces torch.ops.sgl_kernel.silu_and_mul (torch_extension.cc:61;
+ *   csrc/elementwise/activation.cu:36-50; layers/activation.py:41-51). */
+int semipd_silu_and_mul(void* out, const void* in, int64_t num_tokens, int64_t d, int dtype,
+                        void* stream);
+
+/* ------------------------------------------------------------------ */
+/* a2/a3  RoPE and KV-pool store                                       */
+/* ------------------------------------------------------------------ */
+/* In-place rotary embedding of q [T,Hq,head] and k [T,Hk,head] rows
+ * (row strides in elements), cos_sin_cache fp32 [max_pos, rot_dim]
+ * (cos first half, sin second half), positions int64 [T].
+ * interleave=0 -> neox pairing (i, i+rot/2); 1 -> GPT-J pairing (2i, 2i+1).
+ * replaces torch.ops.sgl_kernel.apply_rope_pos_ids_cos_sin_cache
+ *   (torch_extension.cc:70-73; csrc/elementwise/rope.cu:22-89;
+ *    layers/rotary_embedding.py:113-169). */
+int semipd_rope_inplace(void* q, void* k, const float* cos_sin_cache, const int64_t* positions,
+                        int64_t num_tokens, int num_q_heads, int num_k_heads, int head_size,
+                        int rot_dim, int64_t q_stride, int64_t k_stride, int interleave, int dtype,
+                        void* stream);
+
+/* Fused a2+a3: rotate q in place, rotate k, and scatter rotated k and v into
+ * the paged pool rows k_buf[loc[t]], v_buf[loc[t]] (row = Hk*head elements,
+ * pool row stride in elements).  k itself is also updated in place so callers
+ * that keep k_extend contiguous (extend attention) see rotated keys.
+ * replaces RotaryEmbedding.forward_cuda + MHATokenToKVPool.set_kv_buffer
+ *   (layers/rotary_embedding.py:143-169; mem_cache/memory_pool.py:316-346). */
+int semipd_rope_kv_store(void* q, void* k, const void* v, void* k_buf, void* v_buf,
+                         const int64_t* loc, const float* cos_sin_cache, const int64_t* positions,
+                         int64_t num_tokens, int num_q_heads, int num_k_heads, int head_size,
+                         int v_head_size, int rot_dim, int64_t q_stride, int64_t k_stride,
+                         int64_t v_stride, int64_t kbuf_stride, int64_t vbuf_stride, int interleave,
+                         int dtype, void* stream);
+
+/* buf[loc[t], :row_elems] = src[t, :row_elems]   (byte-exact row scatter)
+ * replaces MHATokenToKVPool.set_kv_buffer / MLATokenToKVPool.set_kv_buffer
+ *   (mem_cache/memory_pool.py:316-346, 439-452). loc is int64 (out_cache_loc). */
+int semipd_kv_store(void* buf, const void* src, const int64_t* loc, int64_t num_tokens,
+                    int64_t row_bytes, int64_t buf_stride_bytes, int64_t src_stride_bytes,
+                    void* stream);
+
+/* ------------------------------------------------------------------ */
+/* a4  kv_indptr / kv_indices                                          */
+/* ------------------------------------------------------------------ */
+/* kv_indptr[0]=0, kv_indptr[b+1]=kv_indptr[b]+lens[b]; kv_indices[kv_indptr[b]+j] =
+ * req_to_token[req_pool_indices[b], start[b]+j], j<lens[b].  start may be NULL.
+ * replaces create_flashinfer_kv_indices_triton + the cumsum around it
+ *   (layers/attention/utils.py:5-39; triton_backend.py:76-200).
+ * req_pool_indices int64 [B]; lens int64 [B] (seq_lens) or int32 selected by lens_is_i64. */
+int semipd_build_kv_indices(const int32_t* req_to_token, int64_t req_to_token_stride,
+                            const int64_t* req_pool_indices, const void* lens, int lens_is_i64,
+                            const int32_t* start, int32_t* kv_indptr, int32_t* kv_indices,
+                            int64_t batch, void* stream);
+
+/* positions / extend_start_loc for an extend batch:
+ * positions[start_loc[b]+j] = prefix_lens[b]+j  (j < extend_lens[b]),
+ * start_loc = exclusive cumsum(extend_lens).
+ * replaces compute_position_triton (model_executor/forward_batch_info.py:393-466). */
+int semipd_compute_positions(const int32_t* prefix_lens, const int32_t* extend_lens,
+                             int64_t* positions, int32_t* extend_start_loc, int64_t batch,
+                             void* stream);
+
+/* ------------------------------------------------------------------ */
+/* a5  paged decode attention (flash-decoding, split-KV)               */
+/* ------------------------------------------------------------------ */
+/* q [B,Hq,Dk] (q_stride = elements between requests), K pool rows [N,Hkv,Dk]
+ * (kbuf_stride = elements per pool row), V pool rows [N,Hkv,Dv]; kv_indptr
+ * int32 [B+1]; kv_indices int32; attn_logits fp32 [B,Hq,num_kv_splits,Dv+1]
+ * scratch (last lane = LSE); out [B,Hq,Dv].  logit_cap<=0 disables the cap.
+ * For MLA pass Hkv=1, Dk=576, Dv=512 and v_buf = k_buf (latent rows).
+ * replaces decode_attention_fwd
+ *   (layers/attention/triton_ops/decode_attention.py:625-670: stage 1 :46-167 /
+ *    :234-390, stage 2 :476-531). */
+int semipd_decode_attention(void* out, const void* q, const void* k_buf, const void* v_buf,
+                            const int32_t* kv_indptr, const int32_t* kv_indices,
+                            float* attn_logits, int64_t batch, int num_q_heads, int num_kv_heads,
+                            int head_dim_k, int head_dim_v, int64_t q_stride, int64_t o_stride,
+                            int64_t kbuf_stride, int64_t vbuf_stride, int num_kv_splits,
+                            float sm_scale, float logit_cap, int dtype, void* stream);
+
+/* ------------------------------------------------------------------ */
+/* a6  batched prefill (extend) attention                              */
+/* ------------------------------------------------------------------ */
+/* q_extend [T,Hq,Dk], k_extend [T,Hkv,Dk], v_extend [T,Hkv,Dv] contiguous rows
+ * (strides in elements per token); paged prefix through kv_indptr/kv_indices
+ * into k_buf/v_buf; qo_indptr int32 [B+1]; causal inside the extend part;
+ * out [T,Hq,Dv].  replaces extend_attention_fwd
+ *   (layers/attention/triton_ops/extend_attention.py:41-288, 291-410);
+ * custom masks are not supported (speculative decoding is off in Semi-PD,
+ * managers/scheduler.py:272-275). */
+int semipd_extend_attention(void* out, const void* q_extend, const void* k_extend,
+                            const void* v_extend, const void* k_buf, const void* v_buf,
+                            const int32_t* qo_indptr, const int32_t* kv_indptr,
+                            const int32_t* kv_indices, int64_t batch, int num_q_heads,
+                            int num_kv_heads, int head_dim_k, int head_dim_v, int64_t q_stride,
+                            int64_t k_stride, int64_t v_stride, int64_t o_stride,
+                            int64_t kbuf_stride, int64_t vbuf_stride, int max_len_extend,
+                            float sm_scale, float logit_cap, int dtype, void* stream);
+
+/* ------------------------------------------------------------------ */
+/* a8/a9  logits post-processing and greedy sampling                   */
+/* ------------------------------------------------------------------ */
+/* rows_out[b,:] = hidden[last_index[b],:]  — last-token gather
+ * (layers/logits_processor.py:232-260). */
+int semipd_gather_rows(void* out, const void* in, const int64_t* index, int64_t num_rows,
+                       int64_t row_bytes, int64_t in_stride_bytes, void* stream);
+
+/* next_token[b] = argmax_v logits[b,v] (lowest index wins ties); logits fp32
+ * or bf16/f16 (upcast), out int32 or int64 selected by out_is_i64.
+ * replaces Sampler greedy branch (layers/sampler.py:72-74). */
+int semipd_argmax(const void* logits, void* out, int64_t batch, int64_t vocab,
+                  int64_t logits_stride, int dtype, int out_is_i64, void* stream);
+
+/* Fused lm_head + greedy: out[b] = argmax_v (hidden[b,:] . W[v,:]) computed with
+ * bf16 MFMA / fp32 accumulate, optionally also writing fp32 logits [B,V]
+ * (logits may be NULL).  W [V,H] row-major (lm_head.weight).
+ * replaces LogitsProcessor._get_logits + Sampler argmax
+ *   (layers/logits_processor.py:394-445; layers/sampler.py:72-74). */
+int semipd_lm_head_argmax(const void* hidden, const void* weight, float* logits, void* out,
+                          void* workspace, int64_t batch, int64_t hidden_size, int64_t vocab,
+                          int dtype, int out_is_i64, void* stream);
+size_t semipd_lm_head_argmax_workspace(int64_t batch, int64_t vocab);
+
+/* ------------------------------------------------------------------ */
+/* a10/a11/a12  MoE                                                    */
+/* ------------------------------------------------------------------ */
+/* softmax + top-k (+renormalise): gating [T,E] (dtype) -> topk_weights fp32 [T,k],
+ * topk_ids int32 [T,k].  replaces fused_topk / vllm topk_softmax
+ *   (layers/moe/topk.py:23-75). */
+int semipd_topk_softmax(const void* gating, float* topk_weights, int32_t* topk_ids,
+                        int64_t num_tokens, int num_experts, int topk, int renormalize, int dtype,
+                        void* stream);
+
+/* Group-limited routing (DeepSeek-V2/V3).  scoring: 0 softmax, 1 sigmoid.
+ * correction_bias (fp32 [E]) may be NULL (grouped_topk, topk.py:79-117);
+ * when given: biased_grouped_topk (topk.py:121-160). */
+int semipd_grouped_topk(const void* gating, const float* correction_bias, float* topk_weights,
+                        int32_t* topk_ids, int64_t num_tokens, int num_experts, int topk,
+                        int num_expert_group, int topk_group, int renormalize, int scoring,
+                        int dtype, void* stream);
+
+/* Counting sort of the T*k expert ids padded per expert to block_size.
+ * replaces torch.ops.sgl_kernel.moe_align_block_size
+ *   (torch_extension.cc:115-118; csrc/moe/moe_align_kernel.cu:27-161).
+ * sorted_token_ids must hold T*k + E*(block_size-1) int32 and is filled with the
+ * sentinel T*k in padding slots; expert_ids holds ceil(that/block_size). */
+int semipd_moe_align_block_size(const int32_t* topk_ids, int64_t numel, int num_experts,
+                                int block_size, int32_t* sorted_token_ids, int32_t* expert_ids,
+                                int32_t* num_tokens_post_pad, int32_t* cumsum_buffer,
+                                int64_t max_sorted, void* stream);
+
+/* Grouped GEMM over expert-sorted rows (bf16 MFMA, fp32 accumulate):
+ *   C[sorted row r, :N] = A[token(r), :K] @ W[expert(block(r)), :N, :K]^T
+ * token(r) = sorted_token_ids[r] / top_k_div (top_k_div=topk for GEMM1 where A is
+ * [T,K]; 1 for GEMM2 where A is [T*k,K]); rows with id >= num_valid are skipped.
+ * mul_routed_weight multiplies each output row by topk_weights[sorted id].
+ * C is [T*k, N] indexed by the sorted id.  block_m must equal the block_size used in
+ * semipd_moe_align_block_size (64).
+ * replaces fused_moe_kernel / invoke_fused_moe_kernel
+ *   (layers/moe/fused_moe_triton/fused_moe.py:54-273, 501-612). */
+int semipd_moe_grouped_gemm(void* c, const void* a, const void* w, const float* topk_weights,
+                            const int32_t* sorted_token_ids, const int32_t* expert_ids,
+                            const int32_t* num_tokens_post_pad, int64_t num_valid, int64_t n,
+                            int64_t k, int64_t max_sorted, int top_k_div, int mul_routed_weight,
+                            int block_m, int dtype, void* stream);
+
+/* out[t,:] = sum_j in[t,j,:]   (vllm moe_sum, fused_moe.py:1144-1148) */
+int semipd_moe_sum(void* out, const void* in, int64_t num_tokens, int topk, int64_t hidden,
+                   int dtype, void* stream);
+
+/* ------------------------------------------------------------------ */
+/* a14  IPC seam (semi-pd-ipc/ipc.cpp:60-97)                           */
+/* ------------------------------------------------------------------ */
+/* handle = hipIpcMemHandle of the allocation that contains dev_ptr (64 bytes),
+ * *offset = dev_ptr - allocation base.  replaces GetIPCMemHandle (ipc.cpp:60-64)
+ * plus the _share_cuda_ offset lookup (semi_pd/utils.py:66-76). */
+int semipd_ipc_get_handle(const void* dev_ptr, uint8_t handle[64], uint64_t* offset);
+/* Open (or re-use: one mapping per handle per process, ref-counted) and return the
+ * mapped allocation base.  replaces ConvertIPCMemHandleToTensor's open
+ * (ipc.cpp:67-85). */
+int semipd_ipc_open(const uint8_t handle[64], int device, void** base);
+/* Drop one reference; unmaps at zero (the reference never closes). */
+int semipd_ipc_close(void* base);
+/* Number of live mappings in this process (diagnostics / tests). */
+int semipd_ipc_num_open(void);
+/* replaces GetDeviceSMCount (ipc.cpp:87-92): CU count of `device`; like the
+ * reference it also makes `device` current. */
+int semipd_device_cu_count(int device, int* num_cus);
+
+/* ------------------------------------------------------------------ */
+/* a16  CU-mask compute isolation (replaces CUDA_MPS_ACTIVE_THREAD_PERCENTAGE,
+ *      entrypoints/engine.py:591-593, 632-634; semi_pd/utils.py:10-11)     */
+/* ------------------------------------------------------------------ */
+/* Fill mask words so that `percent` of the device's CUs are enabled, spread
+ * evenly over the XCDs; from_top selects the complementary (upper) range so a
+ * prefill/decode pair can be disjoint.  words = ceil(num_cus/32). */
+int semipd_cu_mask_fill(int num_cus, int percent, int from_top, uint32_t* mask, int words);
+/* hipExtStreamCreateWithCUMask wrapper; *stream receives a hipStream_t. */
+int semipd_stream_create_cu_mask(int device, const uint32_t* mask, int words, void** stream);
+int semipd_stream_destroy(void* stream);
+/* Read back the mask of a stream (hipExtStreamGetCUMask). */
+int semipd_stream_get_cu_mask(void* stream, uint32_t* mask, int words);
+
+/* Test/diagnostic kernel: every workgroup records the XCC id and CU id it ran on
+ * (out[2*wg], out[2*wg+1]) and spins for `spin_cycles`. */
+int semipd_probe_cu_placement(int32_t* out, int num_workgroups, int64_t spin_cycles, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEMIPD_H_ */

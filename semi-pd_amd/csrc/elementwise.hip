@@ -1,0 +1,676 @@
+// HBM-bound row kernels of the Semi-PD hot path for gfx950:
+// RMSNorm / fused-add RMSNorm, SiLU*mul, RoPE (+ fused KV-pool store, a2/a3),
+// row scatter / gather, kv_indices + positions builders (a4), greedy argmax (a9).
+// All loads/stores are 16-byte vectors when the layout allows; math is fp32.
+#include "common.h"
+
+#include <stdarg.h>
+
+namespace semipd {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// ---------------------------------------------------------------------------
+// RMSNorm: one workgroup per row, the row lives in registers between the
+// sum-of-squares pass and the scale pass (one HBM read, one write).
+// ---------------------------------------------------------------------------
+template <typename T, int MAXV, bool FUSED>
+__global__ void __launch_bounds__(512)
+rmsnorm_vec_kernel(T* __restrict__ out, T* __restrict__ in, T* __restrict__ res,
+                   const T* __restrict__ w, int64_t in_stride, int64_t out_stride, int nvec,
+                   int hidden, float eps) {
+  constexpr int V = Elem<T>::kVec;
+  __shared__ float red[16];
+  const int64_t row = blockIdx.x;
+  T* in_row = in + row * in_stride;
+  T* out_row = out + row * out_stride;
+  T* res_row = FUSED ? res + row * in_stride : nullptr;
+  float x[MAXV][V];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int v = threadIdx.x + i * blockDim.x;
+    if (v < nvec) {
+      Vec16<T> a = load16(in_row + (int64_t)v * V);
+      if (FUSED) {
+        Vec16<T> r = load16(res_row + (int64_t)v * V);
+        Vec16<T> s;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          x[i][j] = Elem<T>::to_f(a.e[j]) + Elem<T>::to_f(r.e[j]);
+          s.e[j] = Elem<T>::from_f(x[i][j]);
+        }
+        store16(res_row + (int64_t)v * V, s);
+      } else {
+#pragma unroll
+        for (int j = 0; j < V; ++j) x[i][j] = Elem<T>::to_f(a.e[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < V; ++j) ss += x[i][j] * x[i][j];
+    }
+  }
+  ss = block_sum(ss, red);
+  const float rs = rsqrtf(ss / (float)hidden + eps);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int v = threadIdx.x + i * blockDim.x;
+    if (v < nvec) {
+      Vec16<T> ww = load16(w + (int64_t)v * V);
+      Vec16<T> o;
+#pragma unroll
+      for (int j = 0; j < V; ++j) o.e[j] = Elem<T>::from_f(x[i][j] * rs * Elem<T>::to_f(ww.e[j]));
+      store16(out_row + (int64_t)v * V, o);
+    }
+  }
+}
+
+// Scalar fallback (hidden not a multiple of the vector width, or unaligned rows).
+template <typename T, bool FUSED>
+__global__ void rmsnorm_scalar_kernel(T* __restrict__ out, T* __restrict__ in, T* __restrict__ res,
+                                      const T* __restrict__ w, int64_t in_stride,
+                                      int64_t out_stride, int hidden, float eps) {
+  __shared__ float red[16];
+  const int64_t row = blockIdx.x;
+  T* in_row = in + row * in_stride;
+  T* out_row = out + row * out_stride;
+  T* res_row = FUSED ? res + row * in_stride : nullptr;
+  float ss = 0.f;
+  for (int i = threadIdx.x; i < hidden; i += blockDim.x) {
+    float x = Elem<T>::to_f(in_row[i]);
+    if (FUSED) {
+      x += Elem<T>::to_f(res_row[i]);
+    }
+    ss += x * x;
+  }
+  ss = block_sum(ss, red);
+  const float rs = rsqrtf(ss / (float)hidden + eps);
+  for (int i = threadIdx.x; i < hidden; i += blockDim.x) {
+    float x = Elem<T>::to_f(in_row[i]);
+    if (FUSED) {
+      x += Elem<T>::to_f(res_row[i]);
+      res_row[i] = Elem<T>::from_f(x);
+    }
+    out_row[i] = Elem<T>::from_f(x * rs * Elem<T>::to_f(w[i]));
+  }
+}
+
+template <typename T, bool FUSED>
+static int launch_rmsnorm(T* out, T* in, T* res, const T* w, int64_t T_rows, int64_t hidden,
+                          int64_t in_stride, int64_t out_stride, float eps, hipStream_t st) {
+  constexpr int V = Elem<T>::kVec;
+  if (T_rows == 0) return 0;
+  const bool vec_ok = (hidden % V == 0) && (in_stride % V == 0) && (out_stride % V == 0) &&
+                      aligned16(out) && aligned16(in) && aligned16(w) && (!FUSED || aligned16(res));
+  const int nvec = (int)(hidden / V);
+  if (vec_ok && nvec <= 512 * 16) {
+    int threads = nvec <= 64 ? 64 : nvec <= 128 ? 128 : nvec <= 1024 ? 256 : 512;
+    // small rows: fewer threads, each with one vector
+    int per = (nvec + threads - 1) / threads;
+    dim3 grid((unsigned)T_rows), block(threads);
+#define RMS_LAUNCH(MV)                                                                        \
+  hipLaunchKernelGGL((rmsnorm_vec_kernel<T, MV, FUSED>), grid, block, 0, st, out, in, res, w, \
+                     in_stride, out_stride, nvec, (int)hidden, eps)
+    if (per <= 1) RMS_LAUNCH(1);
+    else if (per <= 2) RMS_LAUNCH(2);
+    else if (per <= 4) RMS_LAUNCH(4);
+    else if (per <= 8) RMS_LAUNCH(8);
+    else RMS_LAUNCH(16);
+#undef RMS_LAUNCH
+  } else {
+    hipLaunchKernelGGL((rmsnorm_scalar_kernel<T, FUSED>), dim3((unsigned)T_rows), dim3(256), 0, st,
+                       out, in, res, w, in_stride, out_stride, (int)hidden, eps);
+  }
+  return launch_status("rmsnorm");
+}
+
+// ---------------------------------------------------------------------------
+// SiLU * mul
+// ---------------------------------------------------------------------------
+__device__ inline float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+template <typename T>
+__global__ void silu_and_mul_vec_kernel(T* __restrict__ out, const T* __restrict__ in,
+                                        int64_t num_tokens, int dvec) {
+  constexpr int V = Elem<T>::kVec;
+  const int64_t total = num_tokens * dvec;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = i / dvec;
+    const int c = (int)(i - t * dvec);
+    const T* row = in + t * (int64_t)dvec * 2 * V;
+    Vec16<T> a = load16(row + (int64_t)c * V);
+    Vec16<T> b = load16(row + (int64_t)(dvec + c) * V);
+    Vec16<T> o;
+#pragma unroll
+    for (int j = 0; j < V; ++j)
+      o.e[j] = Elem<T>::from_f(silu_f(Elem<T>::to_f(a.e[j])) * Elem<T>::to_f(b.e[j]));
+    store16(out + t * (int64_t)dvec * V + (int64_t)c * V, o);
+  }
+}
+
+template <typename T>
+__global__ void silu_and_mul_scalar_kernel(T* __restrict__ out, const T* __restrict__ in,
+                                           int64_t num_tokens, int64_t d) {
+  const int64_t total = num_tokens * d;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = i / d, c = i - t * d;
+    const float a = Elem<T>::to_f(in[t * 2 * d + c]);
+    const float b = Elem<T>::to_f(in[t * 2 * d + d + c]);
+    out[i] = Elem<T>::from_f(silu_f(a) * b);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// RoPE (in place) and fused RoPE + KV-pool store.
+// Work item = one 16-byte vector of the first rotary half (neox) or of
+// interleaved pairs (GPT-J) of one (token, head).
+// ---------------------------------------------------------------------------
+template <typename T, bool INTERLEAVE>
+__device__ inline void rope_item(T* __restrict__ head_ptr, T* __restrict__ mirror_ptr,
+                                 const float* __restrict__ cs, int rot_dim, int item) {
+  // head_ptr: start of this head's row in place; mirror_ptr: optional second
+  // destination (KV pool row) or nullptr.
+  constexpr int V = Elem<T>::kVec;
+  const int half = rot_dim >> 1;
+  if (!INTERLEAVE) {
+    const int i0 = item * V;  // pair index base, pairs (i, i+half)
+    Vec16<T> a = load16(head_ptr + i0);
+    Vec16<T> b = load16(head_ptr + half + i0);
+    Vec16<T> oa, ob;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const float c = cs[i0 + j], s = cs[half + i0 + j];
+      const float x1 = Elem<T>::to_f(a.e[j]), x2 = Elem<T>::to_f(b.e[j]);
+      oa.e[j] = Elem<T>::from_f(x1 * c - x2 * s);
+      ob.e[j] = Elem<T>::from_f(x2 * c + x1 * s);
+    }
+    store16(head_ptr + i0, oa);
+    store16(head_ptr + half + i0, ob);
+    if (mirror_ptr) {
+      store16(mirror_ptr + i0, oa);
+      store16(mirror_ptr + half + i0, ob);
+    }
+  } else {
+    const int e0 = item * V;  // element base; pairs (e0+2j, e0+2j+1), pair index e0/2+j
+    Vec16<T> a = load16(head_ptr + e0);
+    Vec16<T> o;
+#pragma unroll
+    for (int j = 0; j < V / 2; ++j) {
+      const int p = (e0 >> 1) + j;
+      const float c = cs[p], s = cs[half + p];
+      const float x1 = Elem<T>::to_f(a.e[2 * j]), x2 = Elem<T>::to_f(a.e[2 * j + 1]);
+      o.e[2 * j] = Elem<T>::from_f(x1 * c - x2 * s);
+      o.e[2 * j + 1] = Elem<T>::from_f(x2 * c + x1 * s);
+    }
+    store16(head_ptr + e0, o);
+    if (mirror_ptr) store16(mirror_ptr + e0, o);
+  }
+}
+
+// one workgroup per token; handles q rotate, k rotate(+pool), k pass-through(+pool), v(+pool)
+template <typename T, bool INTERLEAVE, bool STORE>
+__global__ void rope_vec_kernel(T* __restrict__ q, T* __restrict__ k, const T* __restrict__ v,
+                                T* __restrict__ k_buf, T* __restrict__ v_buf,
+                                const int64_t* __restrict__ loc, const float* __restrict__ cache,
+                                const int64_t* __restrict__ positions, int Hq, int Hk, int head,
+                                int vhead, int rot_dim, int64_t q_stride, int64_t k_stride,
+                                int64_t v_stride, int64_t kbuf_stride, int64_t vbuf_stride) {
+  constexpr int V = Elem<T>::kVec;
+  const int64_t t = blockIdx.x;
+  const int64_t pos = positions[t];
+  const float* cs = cache + pos * rot_dim;
+  const int items_per_head = INTERLEAVE ? rot_dim / V : (rot_dim / 2) / V;
+  const int q_items = Hq * items_per_head;
+  const int k_items = Hk * items_per_head;
+  T* q_row = q + t * q_stride;
+  T* k_row = k + t * k_stride;
+  int64_t dst = 0;
+  if (STORE) dst = loc[t];
+  for (int it = threadIdx.x; it < q_items + k_items; it += blockDim.x) {
+    if (it < q_items) {
+      const int h = it / items_per_head, i = it - h * items_per_head;
+      rope_item<T, INTERLEAVE>(q_row + h * head, nullptr, cs, rot_dim, i);
+    } else {
+      const int kk = it - q_items;
+      const int h = kk / items_per_head, i = kk - h * items_per_head;
+      T* mirror = STORE ? k_buf + dst * kbuf_stride + h * head : nullptr;
+      rope_item<T, INTERLEAVE>(k_row + h * head, mirror, cs, rot_dim, i);
+    }
+  }
+  if (STORE) {
+    // pass-through part of k (rot_dim < head) and the whole v row
+    const int pass_vec = (head - rot_dim) / V;
+    for (int it = threadIdx.x; it < Hk * pass_vec; it += blockDim.x) {
+      const int h = it / pass_vec, i = it - h * pass_vec;
+      Vec16<T> a = load16(k_row + h * head + rot_dim + i * V);
+      store16(k_buf + dst * kbuf_stride + h * head + rot_dim + i * V, a);
+    }
+    const int v_vec = Hk * vhead / V;
+    const T* v_row = v + t * v_stride;
+    for (int it = threadIdx.x; it < v_vec; it += blockDim.x) {
+      Vec16<T> a = load16(v_row + it * V);
+      store16(v_buf + dst * vbuf_stride + it * V, a);
+    }
+  }
+}
+
+// scalar fallback: any rot_dim (even), any alignment
+template <typename T, bool STORE>
+__global__ void rope_scalar_kernel(T* __restrict__ q, T* __restrict__ k, const T* __restrict__ v,
+                                   T* __restrict__ k_buf, T* __restrict__ v_buf,
+                                   const int64_t* __restrict__ loc, const float* __restrict__ cache,
+                                   const int64_t* __restrict__ positions, int Hq, int Hk, int head,
+                                   int vhead, int rot_dim, int64_t q_stride, int64_t k_stride,
+                                   int64_t v_stride, int64_t kbuf_stride, int64_t vbuf_stride,
+                                   int interleave) {
+  const int64_t t = blockIdx.x;
+  const int64_t pos = positions[t];
+  const float* cs = cache + pos * rot_dim;
+  const int half = rot_dim >> 1;
+  int64_t dst = 0;
+  if (STORE) dst = loc[t];
+  const int pairs = (Hq + Hk) * half;
+  for (int it = threadIdx.x; it < pairs; it += blockDim.x) {
+    const int h = it / half, p = it - h * half;
+    T* row = h < Hq ? q + t * q_stride + h * head : k + t * k_stride + (h - Hq) * head;
+    const int i1 = interleave ? 2 * p : p, i2 = interleave ? 2 * p + 1 : p + half;
+    const float c = cs[p], s = cs[half + p];
+    const float x1 = Elem<T>::to_f(row[i1]), x2 = Elem<T>::to_f(row[i2]);
+    const T o1 = Elem<T>::from_f(x1 * c - x2 * s), o2 = Elem<T>::from_f(x2 * c + x1 * s);
+    row[i1] = o1;
+    row[i2] = o2;
+    if (STORE && h >= Hq) {
+      T* m = k_buf + dst * kbuf_stride + (h - Hq) * head;
+      m[i1] = o1;
+      m[i2] = o2;
+    }
+  }
+  if (STORE) {
+    const int pass = head - rot_dim;
+    for (int it = threadIdx.x; it < Hk * pass; it += blockDim.x) {
+      const int h = it / pass, i = it - h * pass;
+      k_buf[dst * kbuf_stride + h * head + rot_dim + i] = k[t * k_stride + h * head + rot_dim + i];
+    }
+    for (int it = threadIdx.x; it < Hk * vhead; it += blockDim.x)
+      v_buf[dst * vbuf_stride + it] = v[t * v_stride + it];
+  }
+}
+
+template <typename T, bool STORE>
+static int launch_rope(T* q, T* k, const T* v, T* k_buf, T* v_buf, const int64_t* loc,
+                       const float* cache, const int64_t* positions, int64_t num_tokens, int Hq,
+                       int Hk, int head, int vhead, int rot_dim, int64_t q_stride, int64_t k_stride,
+                       int64_t v_stride, int64_t kbuf_stride, int64_t vbuf_stride, int interleave,
+                       hipStream_t st) {
+  constexpr int V = Elem<T>::kVec;
+  if (num_tokens == 0) return 0;
+  bool vec_ok = aligned16(q) && aligned16(k) && (q_stride % V == 0) && (k_stride % V == 0) &&
+                (head % V == 0) && (interleave ? rot_dim % V == 0 : (rot_dim / 2) % V == 0);
+  if (STORE)
+    vec_ok = vec_ok && aligned16(v) && aligned16(k_buf) && aligned16(v_buf) && (v_stride % V == 0) &&
+             (kbuf_stride % V == 0) && (vbuf_stride % V == 0) && ((head - rot_dim) % V == 0) &&
+             (vhead % V == 0);
+  dim3 grid((unsigned)num_tokens), block(256);
+  if (vec_ok) {
+    if (interleave)
+      hipLaunchKernelGGL((rope_vec_kernel<T, true, STORE>), grid, block, 0, st, q, k, v, k_buf, v_buf,
+                         loc, cache, positions, Hq, Hk, head, vhead, rot_dim, q_stride, k_stride,
+                         v_stride, kbuf_stride, vbuf_stride);
+    else
+      hipLaunchKernelGGL((rope_vec_kernel<T, false, STORE>), grid, block, 0, st, q, k, v, k_buf,
+                         v_buf, loc, cache, positions, Hq, Hk, head, vhead, rot_dim, q_stride,
+                         k_stride, v_stride, kbuf_stride, vbuf_stride);
+  } else {
+    hipLaunchKernelGGL((rope_scalar_kernel<T, STORE>), grid, block, 0, st, q, k, v, k_buf, v_buf, loc,
+                       cache, positions, Hq, Hk, head, vhead, rot_dim, q_stride, k_stride, v_stride,
+                       kbuf_stride, vbuf_stride, interleave);
+  }
+  return launch_status("rope");
+}
+
+// ---------------------------------------------------------------------------
+// row scatter (dst indexed) / gather (src indexed); bytes, 16-byte vectors
+// ---------------------------------------------------------------------------
+template <bool SCATTER, int W>
+__global__ void row_copy_kernel(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src,
+                                const int64_t* __restrict__ index, int64_t rows, int64_t row_units,
+                                int64_t dst_stride, int64_t src_stride) {
+  // W = bytes per unit (16, 4, 2 or 1)
+  const int64_t total = rows * row_units;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / row_units, c = i - r * row_units;
+    const int64_t ix = index[r];
+    const uint8_t* s = src + (SCATTER ? r : ix) * src_stride + c * W;
+    uint8_t* d = dst + (SCATTER ? ix : r) * dst_stride + c * W;
+    if (W == 16) *reinterpret_cast<uint4*>(d) = *reinterpret_cast<const uint4*>(s);
+    else if (W == 4) *reinterpret_cast<uint32_t*>(d) = *reinterpret_cast<const uint32_t*>(s);
+    else if (W == 2) *reinterpret_cast<uint16_t*>(d) = *reinterpret_cast<const uint16_t*>(s);
+    else *d = *s;
+  }
+}
+
+template <bool SCATTER>
+static int launch_row_copy(void* dst, const void* src, const int64_t* index, int64_t rows,
+                           int64_t row_bytes, int64_t dst_stride, int64_t src_stride,
+                           hipStream_t st) {
+  if (rows == 0 || row_bytes == 0) return 0;
+  int W = 1;
+  auto ok = [&](int w) {
+    return row_bytes % w == 0 && dst_stride % w == 0 && src_stride % w == 0 &&
+           (reinterpret_cast<uintptr_t>(dst) % w) == 0 && (reinterpret_cast<uintptr_t>(src) % w) == 0;
+  };
+  if (ok(16)) W = 16; else if (ok(4)) W = 4; else if (ok(2)) W = 2;
+  const int64_t units = row_bytes / W;
+  const int64_t total = rows * units;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  uint8_t* d = (uint8_t*)dst;
+  const uint8_t* s = (const uint8_t*)src;
+#define RC(WW) hipLaunchKernelGGL((row_copy_kernel<SCATTER, WW>), dim3(blocks), dim3(256), 0, st, d, s, index, rows, units, dst_stride, src_stride)
+  if (W == 16) RC(16); else if (W == 4) RC(4); else if (W == 2) RC(2); else RC(1);
+#undef RC
+  return launch_status("row_copy");
+}
+
+// ---------------------------------------------------------------------------
+// kv_indptr / kv_indices, positions
+// ---------------------------------------------------------------------------
+template <typename LT>
+__global__ void build_kv_indices_kernel(const int32_t* __restrict__ req_to_token, int64_t stride,
+                                        const int64_t* __restrict__ req_pool_indices,
+                                        const LT* __restrict__ lens,
+                                        const int32_t* __restrict__ start,
+                                        int32_t* __restrict__ kv_indptr,
+                                        int32_t* __restrict__ kv_indices, int64_t batch) {
+  __shared__ float redf[16];
+  __shared__ int red[16];
+  (void)redf;
+  const int b = blockIdx.x;
+  // exclusive prefix of lens[0..b)
+  int part = 0;
+  for (int i = threadIdx.x; i < b; i += blockDim.x) part += (int)lens[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) red[wid] = part;
+  __syncthreads();
+  int off = 0;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) off += red[i];
+  const int len = (int)lens[b];
+  if (threadIdx.x == 0) {
+    if (b == 0) kv_indptr[0] = 0;
+    kv_indptr[b + 1] = off + len;
+  }
+  const int s0 = start ? start[b] : 0;
+  const int32_t* src = req_to_token + req_pool_indices[b] * stride + s0;
+  for (int i = threadIdx.x; i < len; i += blockDim.x) kv_indices[off + i] = src[i];
+}
+
+__global__ void compute_positions_kernel(const int32_t* __restrict__ prefix_lens,
+                                         const int32_t* __restrict__ extend_lens,
+                                         int64_t* __restrict__ positions,
+                                         int32_t* __restrict__ extend_start_loc, int64_t batch) {
+  __shared__ int red[16];
+  const int b = blockIdx.x;
+  int part = 0;
+  for (int i = threadIdx.x; i < b; i += blockDim.x) part += extend_lens[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) red[wid] = part;
+  __syncthreads();
+  int off = 0;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) off += red[i];
+  if (threadIdx.x == 0 && extend_start_loc) extend_start_loc[b] = off;
+  const int len = extend_lens[b], pre = prefix_lens[b];
+  for (int i = threadIdx.x; i < len; i += blockDim.x) positions[off + i] = (int64_t)(pre + i);
+}
+
+// ---------------------------------------------------------------------------
+// greedy argmax: one workgroup per row; ties -> lowest index
+// ---------------------------------------------------------------------------
+__device__ inline void argmax_combine(float& bv, int64_t& bi, float v, int64_t i) {
+  if (v > bv || (v == bv && i < bi)) {
+    bv = v;
+    bi = i;
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(1024)
+argmax_kernel(const T* __restrict__ logits, void* __restrict__ out, int64_t vocab, int64_t stride,
+              int out_is_i64) {
+  constexpr int V = Elem<T>::kVec;
+  __shared__ float sv[16];
+  __shared__ int64_t si[16];
+  const int64_t row = blockIdx.x;
+  const T* p = logits + row * stride;
+  float bv = -INFINITY;
+  int64_t bi = INT64_MAX;
+  const bool vec_ok = (stride % V == 0) && ((reinterpret_cast<uintptr_t>(logits) & 15u) == 0);
+  const int64_t nvec = vec_ok ? vocab / V : 0;
+  for (int64_t v = threadIdx.x; v < nvec; v += blockDim.x) {
+    Vec16<T> a = load16(p + v * V);
+#pragma unroll
+    for (int j = 0; j < V; ++j) argmax_combine(bv, bi, Elem<T>::to_f(a.e[j]), v * V + j);
+  }
+  for (int64_t i = nvec * V + threadIdx.x; i < vocab; i += blockDim.x)
+    argmax_combine(bv, bi, Elem<T>::to_f(p[i]), i);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(bv, o, 64);
+    const int64_t oi = __shfl_xor(bi, o, 64);
+    argmax_combine(bv, bi, ov, oi);
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) {
+    sv[wid] = bv;
+    si[wid] = bi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) argmax_combine(bv, bi, sv[i], si[i]);
+    if (bi == INT64_MAX) bi = 0;  // all -inf / NaN row
+    if (out_is_i64) reinterpret_cast<int64_t*>(out)[row] = bi;
+    else reinterpret_cast<int32_t*>(out)[row] = (int32_t)bi;
+  }
+}
+
+// moe_sum: out[t,:] = sum_j in[t,j,:]
+template <typename T>
+__global__ void moe_sum_kernel(T* __restrict__ out, const T* __restrict__ in, int64_t num_tokens,
+                               int topk, int hvec) {
+  constexpr int V = Elem<T>::kVec;
+  const int64_t total = num_tokens * hvec;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = i / hvec;
+    const int c = (int)(i - t * hvec);
+    float acc[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] = 0.f;
+    for (int k = 0; k < topk; ++k) {
+      Vec16<T> a = load16(in + ((t * topk + k) * hvec + c) * V);
+#pragma unroll
+      for (int j = 0; j < V; ++j) acc[j] += Elem<T>::to_f(a.e[j]);
+    }
+    Vec16<T> o;
+#pragma unroll
+    for (int j = 0; j < V; ++j) o.e[j] = Elem<T>::from_f(acc[j]);
+    store16(out + (t * hvec + c) * V, o);
+  }
+}
+
+}  // namespace semipd
+
+using namespace semipd;
+
+extern "C" {
+
+int semipd_version(void) { return 100; }
+const char* semipd_last_error(void) { return g_err; }
+
+int semipd_rmsnorm(void* out, const void* in, const void* weight, int64_t num_tokens,
+                   int64_t hidden, int64_t in_stride, int64_t out_stride, float eps, int dtype,
+                   void* stream) {
+  SEMIPD_CHECK_ARG(num_tokens >= 0 && hidden > 0, SEMIPD_EINVAL, "rmsnorm: bad sizes");
+  SEMIPD_CHECK_ARG(num_tokens == 0 || (out && in && weight), SEMIPD_EINVAL, "rmsnorm: null pointer");
+  SEMIPD_CHECK_ARG(num_tokens < (1ll << 31), SEMIPD_EINVAL, "rmsnorm: too many rows");
+  SEMIPD_DISPATCH_DTYPE(dtype, T, return (launch_rmsnorm<T, false>((T*)out, (T*)in, nullptr, (const T*)weight, num_tokens, hidden, in_stride, out_stride, eps, as_stream(stream))));
+  return 0;
+}
+
+int semipd_fused_add_rmsnorm(void* inout, void* residual, const void* weight, int64_t num_tokens,
+                             int64_t hidden, float eps, int dtype, void* stream) {
+  SEMIPD_CHECK_ARG(num_tokens >= 0 && hidden > 0, SEMIPD_EINVAL, "fused_add_rmsnorm: bad sizes");
+  SEMIPD_CHECK_ARG(num_tokens == 0 || (inout && residual && weight), SEMIPD_EINVAL,
+                   "fused_add_rmsnorm: null pointer");
+  SEMIPD_CHECK_ARG(num_tokens < (1ll << 31), SEMIPD_EINVAL, "fused_add_rmsnorm: too many rows");
+  SEMIPD_DISPATCH_DTYPE(dtype, T, return (launch_rmsnorm<T, true>((T*)inout, (T*)inout, (T*)residual, (const T*)weight, num_tokens, hidden, hidden, hidden, eps, as_stream(stream))));
+  return 0;
+}
+
+int semipd_silu_and_mul(void* out, const void* in, int64_t num_tokens, int64_t d, int dtype,
+                        void* stream) {
+  SEMIPD_CHECK_ARG(num_tokens >= 0 && d > 0, SEMIPD_EINVAL, "silu_and_mul: bad sizes");
+  if (num_tokens == 0) return 0;
+  SEMIPD_CHECK_ARG(out && in, SEMIPD_EINVAL, "silu_and_mul: null pointer");
+  hipStream_t st = as_stream(stream);
+  SEMIPD_DISPATCH_DTYPE(dtype, T, {
+    constexpr int V = Elem<T>::kVec;
+    const int64_t total = num_tokens * d;
+    if (d % V == 0 && aligned16(out) && aligned16(in)) {
+      int64_t nv = total / V;
+      int blocks = (int)((nv + 255) / 256);
+      if (blocks > 8192) blocks = 8192;
+      hipLaunchKernelGGL((silu_and_mul_vec_kernel<T>), dim3(blocks), dim3(256), 0, st, (T*)out,
+                         (const T*)in, num_tokens, (int)(d / V));
+    } else {
+      int blocks = (int)((total + 255) / 256);
+      if (blocks > 8192) blocks = 8192;
+      hipLaunchKernelGGL((silu_and_mul_scalar_kernel<T>), dim3(blocks), dim3(256), 0, st, (T*)out,
+                         (const T*)in, num_tokens, d);
+    }
+  });
+  return launch_status("silu_and_mul");
+}
+
+int semipd_rope_inplace(void* q, void* k, const float* cos_sin_cache, const int64_t* positions,
+                        int64_t num_tokens, int num_q_heads, int num_k_heads, int head_size,
+                        int rot_dim, int64_t q_stride, int64_t k_stride, int interleave, int dtype,
+                        void* stream) {
+  SEMIPD_CHECK_ARG(num_tokens >= 0 && head_size > 0 && rot_dim > 0 && rot_dim <= head_size &&
+                       (rot_dim % 2) == 0 && num_q_heads >= 0 && num_k_heads >= 0,
+                   SEMIPD_EINVAL, "rope: bad sizes");
+  if (num_tokens == 0) return 0;
+  SEMIPD_CHECK_ARG(q && k && cos_sin_cache && positions, SEMIPD_EINVAL, "rope: null pointer");
+  SEMIPD_DISPATCH_DTYPE(dtype, T, return (launch_rope<T, false>((T*)q, (T*)k, nullptr, nullptr, nullptr, nullptr, cos_sin_cache, positions, num_tokens, num_q_heads, num_k_heads, head_size, 0, rot_dim, q_stride, k_stride, 0, 0, 0, interleave, as_stream(stream))));
+  return 0;
+}
+
+int semipd_rope_kv_store(void* q, void* k, const void* v, void* k_buf, void* v_buf,
+                         const int64_t* loc, const float* cos_sin_cache, const int64_t* positions,
+                         int64_t num_tokens, int num_q_heads, int num_k_heads, int head_size,
+                         int v_head_size, int rot_dim, int64_t q_stride, int64_t k_stride,
+                         int64_t v_stride, int64_t kbuf_stride, int64_t vbuf_stride, int interleave,
+                         int dtype, void* stream) {
+  SEMIPD_CHECK_ARG(num_tokens >= 0 && head_size > 0 && rot_dim > 0 && rot_dim <= head_size &&
+                       (rot_dim % 2) == 0 && v_head_size > 0,
+                   SEMIPD_EINVAL, "rope_kv_store: bad sizes");
+  if (num_tokens == 0) return 0;
+  SEMIPD_CHECK_ARG(q && k && v && k_buf && v_buf && loc && cos_sin_cache && positions, SEMIPD_EINVAL,
+                   "rope_kv_store: null pointer");
+  SEMIPD_DISPATCH_DTYPE(dtype, T, return (launch_rope<T, true>((T*)q, (T*)k, (const T*)v, (T*)k_buf, (T*)v_buf, loc, cos_sin_cache, positions, num_tokens, num_q_heads, num_k_heads, head_size, v_head_size, rot_dim, q_stride, k_stride, v_stride, kbuf_stride, vbuf_stride, interleave, as_stream(stream))));
+  return 0;
+}
+
+int semipd_kv_store(void* buf, const void* src, const int64_t* loc, int64_t num_tokens,
+                    int64_t row_bytes, int64_t buf_stride_bytes, int64_t src_stride_bytes,
+                    void* stream) {
+  SEMIPD_CHECK_ARG(num_tokens >= 0 && row_bytes >= 0, SEMIPD_EINVAL, "kv_store: bad sizes");
+  if (num_tokens == 0) return 0;
+  SEMIPD_CHECK_ARG(buf && src && loc, SEMIPD_EINVAL, "kv_store: null pointer");
+  return launch_row_copy<true>(buf, src, loc, num_tokens, row_bytes, buf_stride_bytes,
+                               src_stride_bytes, as_stream(stream));
+}
+
+int semipd_gather_rows(void* out, const void* in, const int64_t* index, int64_t num_rows,
+                       int64_t row_bytes, int64_t in_stride_bytes, void* stream) {
+  SEMIPD_CHECK_ARG(num_rows >= 0 && row_bytes >= 0, SEMIPD_EINVAL, "gather_rows: bad sizes");
+  if (num_rows == 0) return 0;
+  SEMIPD_CHECK_ARG(out && in && index, SEMIPD_EINVAL, "gather_rows: null pointer");
+  return launch_row_copy<false>(out, in, index, num_rows, row_bytes, row_bytes, in_stride_bytes,
+                                as_stream(stream));
+}
+
+int semipd_build_kv_indices(const int32_t* req_to_token, int64_t req_to_token_stride,
+                            const int64_t* req_pool_indices, const void* lens, int lens_is_i64,
+                            const int32_t* start, int32_t* kv_indptr, int32_t* kv_indices,
+                            int64_t batch, void* stream) {
+  SEMIPD_CHECK_ARG(batch >= 0 && batch < 65536, SEMIPD_EINVAL, "build_kv_indices: bad batch");
+  if (batch == 0) {
+    if (kv_indptr) SEMIPD_HIP(hipMemsetAsync(kv_indptr, 0, sizeof(int32_t), as_stream(stream)));
+    return 0;
+  }
+  SEMIPD_CHECK_ARG(req_to_token && req_pool_indices && lens && kv_indptr && kv_indices, SEMIPD_EINVAL,
+                   "build_kv_indices: null pointer");
+  if (lens_is_i64)
+    hipLaunchKernelGGL((build_kv_indices_kernel<int64_t>), dim3((unsigned)batch), dim3(256), 0,
+                       as_stream(stream), req_to_token, req_to_token_stride, req_pool_indices,
+                       (const int64_t*)lens, start, kv_indptr, kv_indices, batch);
+  else
+    hipLaunchKernelGGL((build_kv_indices_kernel<int32_t>), dim3((unsigned)batch), dim3(256), 0,
+                       as_stream(stream), req_to_token, req_to_token_stride, req_pool_indices,
+                       (const int32_t*)lens, start, kv_indptr, kv_indices, batch);
+  return launch_status("build_kv_indices");
+}
+
+int semipd_compute_positions(const int32_t* prefix_lens, const int32_t* extend_lens,
+                             int64_t* positions, int32_t* extend_start_loc, int64_t batch,
+                             void* stream) {
+  SEMIPD_CHECK_ARG(batch >= 0 && batch < 65536, SEMIPD_EINVAL, "compute_positions: bad batch");
+  if (batch == 0) return 0;
+  SEMIPD_CHECK_ARG(prefix_lens && extend_lens && positions, SEMIPD_EINVAL,
+                   "compute_positions: null pointer");
+  hipLaunchKernelGGL(compute_positions_kernel, dim3((unsigned)batch), dim3(256), 0, as_stream(stream),
+                     prefix_lens, extend_lens, positions, extend_start_loc, batch);
+  return launch_status("compute_positions");
+}
+
+int semipd_argmax(const void* logits, void* out, int64_t batch, int64_t vocab,
+                  int64_t logits_stride, int dtype, int out_is_i64, void* stream) {
+  SEMIPD_CHECK_ARG(batch >= 0 && vocab > 0, SEMIPD_EINVAL, "argmax: bad sizes");
+  if (batch == 0) return 0;
+  SEMIPD_CHECK_ARG(logits && out, SEMIPD_EINVAL, "argmax: null pointer");
+  const int threads = vocab >= 65536 ? 1024 : vocab >= 4096 ? 512 : 256;
+  SEMIPD_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((argmax_kernel<T>), dim3((unsigned)batch), dim3(threads), 0, as_stream(stream), (const T*)logits, out, vocab, logits_stride, out_is_i64));
+  return launch_status("argmax");
+}
+
+int semipd_moe_sum(void* out, const void* in, int64_t num_tokens, int topk, int64_t hidden,
+                   int dtype, void* stream) {
+  SEMIPD_CHECK_ARG(num_tokens >= 0 && topk > 0 && hidden > 0, SEMIPD_EINVAL, "moe_sum: bad sizes");
+  if (num_tokens == 0) return 0;
+  SEMIPD_CHECK_ARG(out && in, SEMIPD_EINVAL, "moe_sum: null pointer");
+  SEMIPD_DISPATCH_DTYPE(dtype, T, {
+    constexpr int V = Elem<T>::kVec;
+    SEMIPD_CHECK_ARG(hidden % V == 0 && aligned16(out) && aligned16(in), SEMIPD_EALIGN,
+                     "moe_sum: hidden must be a multiple of %d and pointers 16-byte aligned", V);
+    const int64_t nv = num_tokens * (hidden / V);
+    int blocks = (int)((nv + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL((moe_sum_kernel<T>), dim3(blocks), dim3(256), 0, as_stream(stream), (T*)out,
+                       (const T*)in, num_tokens, topk, (int)(hidden / V));
+  });
+  return launch_status("moe_sum");
+}
+
+}  // extern "C"

@@ -1,0 +1,392 @@
+// Batched prefill ("extend") attention for gfx950: flash-attention forward over a
+// paged prefix (gathered through kv_indices) followed by the causal triangle of the new tokens.
+//
+// Workgroup = 4 waves = 128 query rows of one (sequence, q head); each wave owns 32 rows.
+// Everything is computed transposed so that the softmax statistics are lane-local:
+//   S^T[kv,q] = K_tile (A operand, from LDS) x Q^T (B operand, registers)   v_mfma_f32_32x32x16
+//   O^T[dv,q] += V^T_tile (A operand, from LDS) x P^T (B operand = the S^T registers, in place)
+// A lane holds column q = lane&31 of S^T and O^T, so max/sum over kv are in-lane plus one
+// exchange with lane^32, the O rescale factor is one scalar per lane, and P^T needs no
+// cross-lane movement at all to become the B operand of the second MFMA (the kv-slot
+// permutation of the C layout is applied to the V^T fragment addresses instead).
+// K tiles are staged row-major (+16 B row pad: conflict-free ds_read_b128), V tiles are
+// transposed on the way into LDS (+8 B row pad: conflict-free ds_read_b64).
+//
+// Mirrors extend_attention_fwd (layers/attention/triton_ops/extend_attention.py:291-410).
+#include "common.h"
+
+namespace semipd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+
+template <typename T> struct Mfma;
+template <> struct Mfma<bf16_t> {
+  typedef bf16x8_t frag;
+  __device__ static inline f32x16 mma(frag a, frag b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Mfma<f16_t> {
+  typedef f16x8_t frag;
+  __device__ static inline f32x16 mma(frag a, frag b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+union Frag16 {  // 16 bytes viewed as MFMA operand / raw words / elements
+  uint4 u;
+  uint2 h[2];
+  uint16_t e[8];
+  bf16x8_t b;
+  f16x8_t f;
+};
+template <typename T> __device__ inline typename Mfma<T>::frag as_frag(const Frag16& x);
+template <> __device__ inline bf16x8_t as_frag<bf16_t>(const Frag16& x) { return x.b; }
+template <> __device__ inline f16x8_t as_frag<f16_t>(const Frag16& x) { return x.f; }
+
+// Load 8 consecutive elements of a row (zero fill beyond `valid` elements).
+template <typename T>
+__device__ inline Frag16 load_row8(const T* p, int valid, bool vec_ok) {
+  Frag16 r;
+  if (vec_ok && valid >= 8) {
+    r.u = *reinterpret_cast<const uint4*>(p);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r.e[j] = j < valid ? p[j].v : (uint16_t)0;
+  }
+  return r;
+}
+
+template <typename T, int DKP, int DVP>
+__global__ void __launch_bounds__(256)
+extend_attn_kernel(T* __restrict__ out, const T* __restrict__ q_ext, const T* __restrict__ k_ext,
+                   const T* __restrict__ v_ext, const T* __restrict__ k_buf,
+                   const T* __restrict__ v_buf, const int32_t* __restrict__ qo_indptr,
+                   const int32_t* __restrict__ kv_indptr, const int32_t* __restrict__ kv_indices,
+                   int group, int Dk, int Dv, int64_t q_stride, int64_t k_stride, int64_t v_stride,
+                   int64_t o_stride, int64_t kbuf_stride, int64_t vbuf_stride, float sm_scale,
+                   float logit_cap, int vec_ok) {
+  constexpr int BM = 128, BN = 64;
+  constexpr int KS = DKP + 8;  // K tile row stride in elements (16 B pad)
+  constexpr int VS = BN + 4;   // V^T tile row stride in elements (8 B pad)
+  constexpr int KSTEPS = DKP / 16;
+  constexpr int DVT = DVP / 32;
+  __shared__ __attribute__((aligned(16))) uint16_t k_lds[BN * KS];
+  __shared__ __attribute__((aligned(16))) uint16_t vt_lds[DVP * VS];
+
+  const int seq = blockIdx.z, hq = blockIdx.y, q0 = blockIdx.x * BM;
+  const int hk = hq / group;
+  const int q_start = qo_indptr[seq];
+  const int ext_len = qo_indptr[seq + 1] - q_start;
+  if (q0 >= ext_len) return;
+  const int kv_start = kv_indptr[seq];
+  const int pre_len = kv_indptr[seq + 1] - kv_start;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, hi = lane >> 5;
+  const int q_local = q0 + wave * 32 + col;  // this lane's query row inside the extend part
+  const bool q_valid = q_local < ext_len;
+
+  // Q^T fragments (B operand): lane holds Q[q_local][ks*16 + hi*8 .. +8]
+  Frag16 qf[KSTEPS];
+  {
+    const T* qrow = q_ext + (int64_t)(q_start + q_local) * q_stride + (int64_t)hq * Dk;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      const int d0 = ks * 16 + hi * 8;
+      const int valid = q_valid ? min(8, Dk - d0) : 0;
+      qf[ks] = load_row8<T>(qrow + d0, valid, vec_ok);
+    }
+  }
+
+  f32x16 o_acc[DVT];
+#pragma unroll
+  for (int t = 0; t < DVT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o_acc[t][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const float LOG2E = 1.4426950408889634f;
+  const float qk_scale = sm_scale * LOG2E;
+
+  // two phases: 0 = paged prefix (no mask), 1 = extend part (causal)
+  const int ext_end = min(ext_len, q0 + BM);
+  for (int phase = 0; phase < 2; ++phase) {
+    const int n_end = phase == 0 ? pre_len : ext_end;
+    for (int n0 = 0; n0 < n_end; n0 += BN) {
+      __syncthreads();  // previous tile fully consumed
+      // ---- stage K tile: rows n0..n0+63, row-major [kv][d] ----
+      {
+        constexpr int CH = DKP / 8;
+        for (int item = tid; item < BN * CH; item += 256) {
+          const int r = item / CH, c = item - r * CH;
+          const int n = n0 + r;
+          Frag16 x;
+          x.u = make_uint4(0, 0, 0, 0);
+          if (n < n_end) {
+            const T* row = phase == 0
+                               ? k_buf + (int64_t)kv_indices[kv_start + n] * kbuf_stride + (int64_t)hk * Dk
+                               : k_ext + (int64_t)(q_start + n) * k_stride + (int64_t)hk * Dk;
+            x = load_row8<T>(row + c * 8, min(8, Dk - c * 8), vec_ok);
+          }
+          *reinterpret_cast<uint4*>(&k_lds[r * KS + c * 8]) = x.u;
+        }
+      }
+      // ---- stage V tile transposed: vt[dv][kv] ----
+      {
+        constexpr int CH = DVP / 8;
+        for (int item = tid; item < (BN / 4) * CH; item += 256) {
+          const int rg = item / CH, c = item - rg * CH;
+          Frag16 x[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int n = n0 + rg * 4 + i;
+            x[i].u = make_uint4(0, 0, 0, 0);
+            if (n < n_end) {
+              const T* row = phase == 0
+                                 ? v_buf + (int64_t)kv_indices[kv_start + n] * vbuf_stride + (int64_t)hk * Dv
+                                 : v_ext + (int64_t)(q_start + n) * v_stride + (int64_t)hk * Dv;
+              x[i] = load_row8<T>(row + c * 8, min(8, Dv - c * 8), vec_ok);
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            uint2 w;
+            w.x = (uint32_t)x[0].e[j] | ((uint32_t)x[1].e[j] << 16);
+            w.y = (uint32_t)x[2].e[j] | ((uint32_t)x[3].e[j] << 16);
+            *reinterpret_cast<uint2*>(&vt_lds[(c * 8 + j) * VS + rg * 4]) = w;
+          }
+        }
+      }
+      __syncthreads();
+
+      // ---- S^T = K Q^T : two 32-row kv tiles ----
+      f32x16 s_acc[2];
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s_acc[kt][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+          Frag16 a;
+          a.u = *reinterpret_cast<const uint4*>(&k_lds[(kt * 32 + col) * KS + ks * 16 + hi * 8]);
+          s_acc[kt] = Mfma<T>::mma(as_frag<T>(a), as_frag<T>(qf[ks]), s_acc[kt]);
+        }
+      }
+      // ---- mask + online softmax (base-2) ----
+      float mx = m_run;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = n0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          const bool ok = n < n_end && (phase == 0 || n <= q_local);
+          float s = s_acc[kt][r];
+          if (logit_cap > 0.f) s = logit_cap * tanhf(s * sm_scale / logit_cap) * LOG2E;
+          else s *= qk_scale;
+          s = ok ? s : -INFINITY;
+          s_acc[kt][r] = s;
+          mx = fmaxf(mx, s);
+        }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float alpha = (m_run == -INFINITY) ? 0.f : exp2f(m_run - mx);  // mx >= m_run
+      const float m_use = (mx == -INFINITY) ? 0.f : mx;                      // all masked so far
+      float psum = 0.f;
+      Frag16 pf[2][2];
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p = exp2f(s_acc[kt][r] - m_use);  // exp2(-inf) = 0
+          psum += p;
+          pf[kt][r >> 3].e[r & 7] = Elem<T>::from_f(p).v;
+        }
+      }
+      l_run = l_run * alpha + psum;
+      m_run = mx;
+#pragma unroll
+      for (int t = 0; t < DVT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o_acc[t][r] *= alpha;
+      // ---- O^T += V^T P^T ----
+#pragma unroll
+      for (int t = 0; t < DVT; ++t) {
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            Frag16 a;
+            const uint16_t* vrow = &vt_lds[(t * 32 + col) * VS + kt * 32 + s2 * 16 + hi * 4];
+            a.h[0] = *reinterpret_cast<const uint2*>(vrow);
+            a.h[1] = *reinterpret_cast<const uint2*>(vrow + 8);
+            o_acc[t] = Mfma<T>::mma(as_frag<T>(a), as_frag<T>(pf[kt][s2]), o_acc[t]);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: O[q][dv] = O^T / l ----
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+  if (q_valid) {
+    T* orow = out + (int64_t)(q_start + q_local) * o_stride + (int64_t)hq * Dv;
+#pragma unroll
+    for (int t = 0; t < DVT; ++t) {
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int dv0 = t * 32 + 8 * r4 + 4 * hi;
+        if (vec_ok && dv0 + 4 <= Dv) {
+          uint2 w;
+          w.x = (uint32_t)Elem<T>::from_f(o_acc[t][r4 * 4 + 0] * inv).v |
+                ((uint32_t)Elem<T>::from_f(o_acc[t][r4 * 4 + 1] * inv).v << 16);
+          w.y = (uint32_t)Elem<T>::from_f(o_acc[t][r4 * 4 + 2] * inv).v |
+                ((uint32_t)Elem<T>::from_f(o_acc[t][r4 * 4 + 3] * inv).v << 16);
+          *reinterpret_cast<uint2*>(orow + dv0) = w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (dv0 + j < Dv) orow[dv0 + j] = Elem<T>::from_f(o_acc[t][r4 * 4 + j] * inv);
+        }
+      }
+    }
+  }
+}
+
+// Generic fallback (head dims without an MFMA instantiation, e.g. MLA 576/512 with prefix):
+// one wave per (query token, q head).
+template <typename T>
+__global__ void __launch_bounds__(64)
+extend_attn_generic_kernel(T* __restrict__ out, const T* __restrict__ q_ext,
+                           const T* __restrict__ k_ext, const T* __restrict__ v_ext,
+                           const T* __restrict__ k_buf, const T* __restrict__ v_buf,
+                           const int32_t* __restrict__ qo_indptr,
+                           const int32_t* __restrict__ kv_indptr,
+                           const int32_t* __restrict__ kv_indices, int group, int Dk, int Dv,
+                           int64_t q_stride, int64_t k_stride, int64_t v_stride, int64_t o_stride,
+                           int64_t kbuf_stride, int64_t vbuf_stride, float sm_scale,
+                           float logit_cap) {
+  constexpr int MAXR = 9;
+  const int seq = blockIdx.z, hq = blockIdx.y, qi = blockIdx.x;
+  const int hk = hq / group;
+  const int q_start = qo_indptr[seq];
+  const int ext_len = qo_indptr[seq + 1] - q_start;
+  if (qi >= ext_len) return;
+  const int kv_start = kv_indptr[seq];
+  const int pre_len = kv_indptr[seq + 1] - kv_start;
+  const int lane = threadIdx.x;
+  float qf[MAXR], acc[MAXR];
+#pragma unroll
+  for (int r = 0; r < MAXR; ++r) {
+    const int d = lane + r * 64;
+    qf[r] = d < Dk ? Elem<T>::to_f(q_ext[(int64_t)(q_start + qi) * q_stride + (int64_t)hq * Dk + d]) * sm_scale : 0.f;
+    acc[r] = 0.f;
+  }
+  float m = -INFINITY, l = 0.f;
+  const int total = pre_len + qi + 1;
+  for (int t = 0; t < total; ++t) {
+    const T *kr, *vr;
+    if (t < pre_len) {
+      const int64_t idx = kv_indices[kv_start + t];
+      kr = k_buf + idx * kbuf_stride + (int64_t)hk * Dk;
+      vr = v_buf + idx * vbuf_stride + (int64_t)hk * Dv;
+    } else {
+      const int64_t row = q_start + (t - pre_len);
+      kr = k_ext + row * k_stride + (int64_t)hk * Dk;
+      vr = v_ext + row * v_stride + (int64_t)hk * Dv;
+    }
+    float d = 0.f;
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) {
+      const int dd = lane + r * 64;
+      if (dd < Dk) d = fmaf(qf[r], Elem<T>::to_f(kr[dd]), d);
+    }
+    d = wave_sum(d);
+    if (logit_cap > 0.f) d = logit_cap * tanhf(d / logit_cap);
+    const float mn = fmaxf(m, d);
+    const float sc = (m == -INFINITY) ? 0.f : __expf(m - mn);
+    const float p = __expf(d - mn);
+    l = l * sc + p;
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) {
+      const int dd = lane + r * 64;
+      const float vv = dd < Dv ? Elem<T>::to_f(vr[dd]) : 0.f;
+      acc[r] = acc[r] * sc + p * vv;
+    }
+    m = mn;
+  }
+#pragma unroll
+  for (int r = 0; r < MAXR; ++r) {
+    const int dd = lane + r * 64;
+    if (dd < Dv) out[(int64_t)(q_start + qi) * o_stride + (int64_t)hq * Dv + dd] = Elem<T>::from_f(acc[r] / l);
+  }
+}
+
+template <typename T>
+static int run_extend(void* out, const void* q, const void* k, const void* v, const void* k_buf,
+                      const void* v_buf, const int32_t* qo_indptr, const int32_t* kv_indptr,
+                      const int32_t* kv_indices, int64_t batch, int Hq, int Hkv, int Dk, int Dv,
+                      int64_t q_stride, int64_t k_stride, int64_t v_stride, int64_t o_stride,
+                      int64_t kbuf_stride, int64_t vbuf_stride, int max_len_extend, float sm_scale,
+                      float logit_cap, hipStream_t st) {
+  const int group = Hq / Hkv;
+  const int vec_ok = (Dk % 8 == 0 && Dv % 8 == 0 && q_stride % 8 == 0 && k_stride % 8 == 0 &&
+                      v_stride % 8 == 0 && o_stride % 4 == 0 && kbuf_stride % 8 == 0 &&
+                      vbuf_stride % 8 == 0 && aligned16(q) && aligned16(k) && aligned16(v) &&
+                      aligned16(k_buf) && aligned16(v_buf) &&
+                      (reinterpret_cast<uintptr_t>(out) & 7u) == 0)
+                         ? 1
+                         : 0;
+  const int dkp = (Dk + 15) / 16 * 16, dvp = (Dv + 31) / 32 * 32;
+  dim3 grid((unsigned)((max_len_extend + 127) / 128), (unsigned)Hq, (unsigned)batch), block(256);
+#define EXT(DKP, DVP)                                                                              \
+  hipLaunchKernelGGL((extend_attn_kernel<T, DKP, DVP>), grid, block, 0, st, (T*)out, (const T*)q,  \
+                     (const T*)k, (const T*)v, (const T*)k_buf, (const T*)v_buf, qo_indptr,         \
+                     kv_indptr, kv_indices, group, Dk, Dv, q_stride, k_stride, v_stride, o_stride,  \
+                     kbuf_stride, vbuf_stride, sm_scale, logit_cap, vec_ok)
+  if (dkp <= 16 && dvp <= 32) EXT(16, 32);
+  else if (dkp <= 64 && dvp <= 64) EXT(64, 64);
+  else if (dkp <= 96 && dvp <= 96) EXT(96, 96);
+  else if (dkp <= 128 && dvp <= 128) EXT(128, 128);
+  else if (dkp <= 192 && dvp <= 128) EXT(192, 128);
+  else {
+    dim3 g2((unsigned)max_len_extend, (unsigned)Hq, (unsigned)batch);
+    hipLaunchKernelGGL((extend_attn_generic_kernel<T>), g2, dim3(64), 0, st, (T*)out, (const T*)q,
+                       (const T*)k, (const T*)v, (const T*)k_buf, (const T*)v_buf, qo_indptr,
+                       kv_indptr, kv_indices, group, Dk, Dv, q_stride, k_stride, v_stride, o_stride,
+                       kbuf_stride, vbuf_stride, sm_scale, logit_cap);
+  }
+#undef EXT
+  return launch_status("extend_attention");
+}
+
+}  // namespace semipd
+
+using namespace semipd;
+
+extern "C" int semipd_extend_attention(void* out, const void* q_extend, const void* k_extend,
+                                       const void* v_extend, const void* k_buf, const void* v_buf,
+                                       const int32_t* qo_indptr, const int32_t* kv_indptr,
+                                       const int32_t* kv_indices, int64_t batch, int num_q_heads,
+                                       int num_kv_heads, int head_dim_k, int head_dim_v,
+                                       int64_t q_stride, int64_t k_stride, int64_t v_stride,
+                                       int64_t o_stride, int64_t kbuf_stride, int64_t vbuf_stride,
+                                       int max_len_extend, float sm_scale, float logit_cap, int dtype,
+                                       void* stream) {
+  SEMIPD_CHECK_ARG(batch >= 0 && num_q_heads > 0 && num_kv_heads > 0 && head_dim_k > 0 &&
+                       head_dim_v > 0 && max_len_extend >= 0,
+                   SEMIPD_EINVAL, "extend_attention: bad sizes");
+  SEMIPD_CHECK_ARG(num_q_heads % num_kv_heads == 0, SEMIPD_ESHAPE,
+                   "extend_attention: Hq %d not a multiple of Hkv %d", num_q_heads, num_kv_heads);
+  SEMIPD_CHECK_ARG(head_dim_k <= 576 && head_dim_v <= 576, SEMIPD_ESHAPE,
+                   "extend_attention: head dims up to 576 supported");
+  SEMIPD_CHECK_ARG(batch <= 65535 && num_q_heads <= 65535, SEMIPD_EINVAL,
+                   "extend_attention: grid too large");
+  if (batch == 0 || max_len_extend == 0) return 0;
+  SEMIPD_CHECK_ARG(out && q_extend && k_extend && v_extend && qo_indptr && kv_indptr, SEMIPD_EINVAL,
+                   "extend_attention: null pointer");
+  SEMIPD_DISPATCH_HALF(dtype, T, return run_extend<T>(out, q_extend, k_extend, v_extend, k_buf, v_buf, qo_indptr, kv_indptr, kv_indices, batch, num_q_heads, num_kv_heads, head_dim_k, head_dim_v, q_stride, k_stride, v_stride, o_stride, kbuf_stride, vbuf_stride, max_len_extend, sm_scale, logit_cap, as_stream(stream)));
+  return 0;
+}

@@ -1,0 +1,175 @@
+// semi-pd-ipc for ROCm: hipIpcMemHandle export/import with a per-process mapping cache,
+// CU-count query and CU-masked stream creation.
+//
+// Differences from the reference module (semi-pd-ipc/ipc.cpp:60-97), on purpose:
+//  * the handle is always taken on the *allocation base* (hipMemGetAddressRange), and the
+//    byte offset of the tensor inside it is returned alongside, so callers do not need
+//    torch's storage()._share_cuda_() side effects (semi_pd/utils.py:66-76);
+//  * hipIpcOpenMemHandle may be called only once per allocation per process, while PyTorch's
+//    caching allocator packs hundreds of tensors into one allocation: opens are cached by
+//    handle bytes and reference counted, close unmaps at zero (the reference never closes);
+//  * errors are returned, never exit(1) (ipc.cpp:74-79).
+#include "common.h"
+
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+
+namespace semipd {
+
+struct Mapping {
+  void* base;
+  int device;
+  int refs;
+};
+static std::mutex g_ipc_mu;
+static std::map<std::string, Mapping> g_by_handle;
+static std::map<void*, std::string> g_by_base;
+
+__global__ void probe_cu_placement_kernel(int32_t* out, long long spin_cycles) {
+  if (threadIdx.x == 0) {
+    // HW_REG_XCC_ID (id 20): bits [3:0] = XCC id.  HW_REG_HW_ID (id 4): CU id bits [11:8],
+    // SH id bit 12, SE id bits [15:13].
+    const unsigned xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 0xf;
+    const unsigned hw = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4);
+    out[2 * blockIdx.x] = (int32_t)xcc;
+    out[2 * blockIdx.x + 1] = (int32_t)((hw >> 8) & 0xff);  // cu | sh<<4 | se<<5
+  }
+  const long long t0 = clock64();
+  while (clock64() - t0 < spin_cycles) {
+  }
+}
+
+}  // namespace semipd
+
+using namespace semipd;
+
+extern "C" {
+
+int semipd_ipc_get_handle(const void* dev_ptr, uint8_t handle[64], uint64_t* offset) {
+  SEMIPD_CHECK_ARG(dev_ptr && handle && offset, SEMIPD_EINVAL, "ipc_get_handle: null pointer");
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t must be 64 bytes");
+  hipDeviceptr_t base = nullptr;
+  size_t size = 0;
+  SEMIPD_HIP(hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)dev_ptr));
+  hipIpcMemHandle_t h;
+  SEMIPD_HIP(hipIpcGetMemHandle(&h, base));
+  memcpy(handle, &h, 64);
+  *offset = (uint64_t)((const uint8_t*)dev_ptr - (const uint8_t*)base);
+  return 0;
+}
+
+int semipd_ipc_open(const uint8_t handle[64], int device, void** base) {
+  SEMIPD_CHECK_ARG(handle && base, SEMIPD_EINVAL, "ipc_open: null pointer");
+  const std::string key((const char*)handle, 64);
+  std::lock_guard<std::mutex> g(g_ipc_mu);
+  auto it = g_by_handle.find(key);
+  if (it != g_by_handle.end()) {
+    it->second.refs += 1;
+    *base = it->second.base;
+    return 0;
+  }
+  int prev = -1;
+  SEMIPD_HIP(hipGetDevice(&prev));
+  if (device >= 0 && device != prev) SEMIPD_HIP(hipSetDevice(device));
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle, 64);
+  void* p = nullptr;
+  hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+  if (device >= 0 && device != prev) (void)hipSetDevice(prev);
+  if (e != hipSuccess) {
+    set_error("hipIpcOpenMemHandle failed: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  g_by_handle[key] = Mapping{p, device, 1};
+  g_by_base[p] = key;
+  *base = p;
+  return 0;
+}
+
+int semipd_ipc_close(void* base) {
+  std::lock_guard<std::mutex> g(g_ipc_mu);
+  auto it = g_by_base.find(base);
+  SEMIPD_CHECK_ARG(it != g_by_base.end(), SEMIPD_ENOTFOUND, "ipc_close: %p is not an open mapping",
+                   base);
+  Mapping& m = g_by_handle[it->second];
+  if (--m.refs > 0) return 0;
+  hipError_t e = hipIpcCloseMemHandle(base);
+  g_by_handle.erase(it->second);
+  g_by_base.erase(it);
+  if (e != hipSuccess) {
+    set_error("hipIpcCloseMemHandle failed: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
+
+int semipd_ipc_num_open(void) {
+  std::lock_guard<std::mutex> g(g_ipc_mu);
+  return (int)g_by_handle.size();
+}
+
+int semipd_device_cu_count(int device, int* num_cus) {
+  SEMIPD_CHECK_ARG(num_cus, SEMIPD_EINVAL, "device_cu_count: null pointer");
+  SEMIPD_HIP(hipSetDevice(device));  // same side effect as GetDeviceSMCount (ipc.cpp:88)
+  int n = 0;
+  SEMIPD_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device));
+  *num_cus = n;
+  return 0;
+}
+
+int semipd_cu_mask_fill(int num_cus, int percent, int from_top, uint32_t* mask, int words) {
+  SEMIPD_CHECK_ARG(mask && num_cus > 0 && words * 32 >= num_cus && percent > 0 && percent <= 100,
+                   SEMIPD_EINVAL, "cu_mask_fill: bad arguments");
+  // The KFD spreads consecutive mask bits round-robin over the XCDs (and shader engines inside
+  // an XCD), so a contiguous range of logical CU bits is automatically XCD-balanced: bit i lands
+  // on XCD i % 8.  We enable round(num_cus*percent/100) bits, rounded to a multiple of 8 so every
+  // XCD gets the same number of CUs, from the bottom or from the top of the range.
+  int n = (num_cus * percent + 50) / 100;
+  n = (n + 4) / 8 * 8;
+  if (n < 8) n = 8;
+  if (n > num_cus) n = num_cus;
+  for (int w = 0; w < words; ++w) mask[w] = 0;
+  const int lo = from_top ? num_cus - n : 0;
+  for (int i = lo; i < lo + n; ++i) mask[i >> 5] |= (1u << (i & 31));
+  return n;
+}
+
+int semipd_stream_create_cu_mask(int device, const uint32_t* mask, int words, void** stream) {
+  SEMIPD_CHECK_ARG(mask && stream && words > 0, SEMIPD_EINVAL, "stream_create_cu_mask: bad arguments");
+  int prev = -1;
+  SEMIPD_HIP(hipGetDevice(&prev));
+  if (device >= 0 && device != prev) SEMIPD_HIP(hipSetDevice(device));
+  hipStream_t s = nullptr;
+  hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask);
+  if (device >= 0 && device != prev) (void)hipSetDevice(prev);
+  if (e != hipSuccess) {
+    set_error("hipExtStreamCreateWithCUMask failed: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  *stream = (void*)s;
+  return 0;
+}
+
+int semipd_stream_destroy(void* stream) {
+  SEMIPD_CHECK_ARG(stream, SEMIPD_EINVAL, "stream_destroy: null stream");
+  SEMIPD_HIP(hipStreamDestroy(as_stream(stream)));
+  return 0;
+}
+
+int semipd_stream_get_cu_mask(void* stream, uint32_t* mask, int words) {
+  SEMIPD_CHECK_ARG(mask && words > 0, SEMIPD_EINVAL, "stream_get_cu_mask: bad arguments");
+  SEMIPD_HIP(hipExtStreamGetCUMask(as_stream(stream), (uint32_t)words, mask));
+  return 0;
+}
+
+int semipd_probe_cu_placement(int32_t* out, int num_workgroups, int64_t spin_cycles, void* stream) {
+  SEMIPD_CHECK_ARG(out && num_workgroups > 0, SEMIPD_EINVAL, "probe_cu_placement: bad arguments");
+  hipLaunchKernelGGL(probe_cu_placement_kernel, dim3(num_workgroups), dim3(64), 0, as_stream(stream),
+                     out, (long long)spin_cycles);
+  return launch_status("probe_cu_placement");
+}
+
+}  // extern "C"

@@ -1,0 +1,457 @@
+// MoE routing, token alignment and the expert-grouped GEMM for gfx950,
+// plus the lm_head GEMM + greedy argmax that reuses the same MFMA tile (a8/a9).
+#include "common.h"
+
+namespace semipd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+
+union Frag16m {
+  uint4 u;
+  uint16_t e[8];
+  bf16x8_t b;
+  f16x8_t f;
+};
+template <typename T> struct MfmaG;
+template <> struct MfmaG<bf16_t> {
+  __device__ static inline f32x16 mma(const Frag16m& a, const Frag16m& b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.b, b.b, c, 0, 0, 0);
+  }
+};
+template <> struct MfmaG<f16_t> {
+  __device__ static inline f32x16 mma(const Frag16m& a, const Frag16m& b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a.f, b.f, c, 0, 0, 0);
+  }
+};
+
+// ---------------------------------------------------------------------------
+// Routing: one wave per token.  Scores live in LDS (E <= 512).
+// ---------------------------------------------------------------------------
+constexpr int kMaxExperts = 512;
+constexpr int kMaxTopk = 32;
+
+__device__ inline void wave_argmax(float& v, int& i) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(v, o, 64);
+    const int oi = __shfl_xor(i, o, 64);
+    if (ov > v || (ov == v && oi < i)) {
+      v = ov;
+      i = oi;
+    }
+  }
+}
+
+// mode: 0 = plain softmax top-k (fused_topk); 1 = grouped (grouped_topk / biased_grouped_topk)
+template <typename T>
+__global__ void __launch_bounds__(64)
+moe_topk_kernel(const T* __restrict__ gating, const float* __restrict__ bias,
+                float* __restrict__ topk_weights, int32_t* __restrict__ topk_ids, int E, int topk,
+                int num_group, int topk_group, int renormalize, int scoring, int grouped) {
+  __shared__ float score[kMaxExperts];   // unbiased scores (weights come from these)
+  __shared__ float choice[kMaxExperts];  // scores used for selection (biased / masked)
+  __shared__ float gscore[64];
+  __shared__ int gsel[64];
+  const int64_t t = blockIdx.x;
+  const int lane = threadIdx.x;
+  const T* g = gating + t * E;
+  // scores
+  if (scoring == 0) {
+    float mx = -INFINITY;
+    for (int e = lane; e < E; e += 64) mx = fmaxf(mx, Elem<T>::to_f(g[e]));
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int e = lane; e < E; e += 64) {
+      const float x = expf(Elem<T>::to_f(g[e]) - mx);
+      score[e] = x;
+      sum += x;
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    for (int e = lane; e < E; e += 64) score[e] *= inv;
+  } else {
+    for (int e = lane; e < E; e += 64) score[e] = 1.f / (1.f + expf(-Elem<T>::to_f(g[e])));
+  }
+  // grouped_topk / biased_grouped_topk run softmax / sigmoid in the gating dtype (topk.py:91-94,
+  // 132): scores are rounded to T before any comparison so the selection matches bit for bit.
+  if (grouped) {
+    __syncthreads();
+    for (int e = lane; e < E; e += 64) score[e] = Elem<T>::to_f(Elem<T>::from_f(score[e]));
+  }
+  __syncthreads();
+  for (int e = lane; e < E; e += 64) choice[e] = score[e] + (bias ? bias[e] : 0.f);
+  __syncthreads();
+  if (grouped) {
+    const int gs = E / num_group;
+    if (lane < num_group) {
+      float best = -INFINITY, second = -INFINITY;
+      for (int j = 0; j < gs; ++j) {
+        const float x = choice[lane * gs + j];
+        if (x > best) {
+          second = best;
+          best = x;
+        } else if (x > second) {
+          second = x;
+        }
+      }
+      gscore[lane] = bias ? best + second : best;  // topk.py:140-144 vs :98-100
+      gsel[lane] = 0;
+    }
+    __syncthreads();
+    if (lane == 0) {
+      for (int k = 0; k < topk_group; ++k) {
+        float bv = -INFINITY;
+        int bi = -1;
+        for (int j = 0; j < num_group; ++j)
+          if (!gsel[j] && (bi < 0 || gscore[j] > bv)) {
+            bv = gscore[j];
+            bi = j;
+          }
+        if (bi >= 0) gsel[bi] = 1;
+      }
+    }
+    __syncthreads();
+    const float fill = bias ? -INFINITY : 0.f;  // masked_fill value (topk.py:151-153 vs :110)
+    for (int e = lane; e < E; e += 64)
+      if (!gsel[e / gs]) choice[e] = fill;
+    __syncthreads();
+  }
+  // iterative top-k over `choice`
+  float wsum = 0.f;
+  float my_w = 0.f;
+  int my_id = 0;
+  for (int k = 0; k < topk; ++k) {
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int e = lane; e < E; e += 64) {
+      const float x = choice[e];
+      if (x > bv || (x == bv && e < bi)) {
+        bv = x;
+        bi = e;
+      }
+    }
+    wave_argmax(bv, bi);
+    if (bi == 0x7fffffff) bi = 0;
+    const float w = score[bi];
+    wsum += w;
+    if (lane == k) {
+      my_w = w;
+      my_id = bi;
+    }
+    __syncthreads();
+    if (lane == 0) choice[bi] = -INFINITY;
+    __syncthreads();
+  }
+  if (lane < topk) {
+    float wgt = my_w;
+    if (renormalize) {
+      if (grouped) {  // division happens in the gating dtype, then .to(float32) (topk.py:114-117)
+        const float s = Elem<T>::to_f(Elem<T>::from_f(wsum));
+        wgt = Elem<T>::to_f(Elem<T>::from_f(my_w / s));
+      } else {
+        wgt = my_w / wsum;
+      }
+    }
+    topk_weights[t * topk + lane] = wgt;
+    topk_ids[t * topk + lane] = my_id;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// moe_align_block_size
+// ---------------------------------------------------------------------------
+__global__ void fill_i32_kernel(int32_t* p, int64_t n, int32_t v) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    p[i] = v;
+}
+
+// single workgroup: histogram + padded exclusive scan + expert_ids; optionally (FUSED) also the
+// sentinel fill and the scatter, for decode-sized inputs.
+template <bool FUSED>
+__global__ void __launch_bounds__(1024)
+moe_align_kernel(const int32_t* __restrict__ topk_ids, int64_t numel, int E, int block_size,
+                 int32_t* __restrict__ sorted_ids, int32_t* __restrict__ expert_ids,
+                 int32_t* __restrict__ num_post_pad, int32_t* __restrict__ cumsum,
+                 int64_t max_sorted) {
+  __shared__ int hist[kMaxExperts];
+  __shared__ int offs[kMaxExperts + 1];
+  const int tid = threadIdx.x;
+  for (int e = tid; e < E; e += blockDim.x) hist[e] = 0;
+  if (FUSED)
+    for (int64_t i = tid; i < max_sorted; i += blockDim.x) sorted_ids[i] = (int32_t)numel;
+  __syncthreads();
+  for (int64_t i = tid; i < numel; i += blockDim.x) {
+    const int e = topk_ids[i];
+    if (e >= 0 && e < E) atomicAdd(&hist[e], 1);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int e = 0; e < E; ++e) {
+      offs[e] = run;
+      run += (hist[e] + block_size - 1) / block_size * block_size;
+    }
+    offs[E] = run;
+    *num_post_pad = run;
+  }
+  __syncthreads();
+  for (int e = tid; e <= E; e += blockDim.x) cumsum[e] = offs[e];
+  // expert id of every block
+  const int nblocks = offs[E] / block_size;
+  for (int e = tid; e < E; e += blockDim.x)
+    for (int b = offs[e] / block_size; b < offs[e + 1] / block_size; ++b) expert_ids[b] = e;
+  (void)nblocks;
+  if (FUSED) {
+    __syncthreads();
+    for (int e = tid; e < E; e += blockDim.x) hist[e] = offs[e];  // running write cursors
+    __syncthreads();
+    for (int64_t i = tid; i < numel; i += blockDim.x) {
+      const int e = topk_ids[i];
+      if (e >= 0 && e < E) {
+        const int pos = atomicAdd(&hist[e], 1);
+        sorted_ids[pos] = (int32_t)i;
+      }
+    }
+  }
+}
+
+__global__ void moe_scatter_kernel(const int32_t* __restrict__ topk_ids, int64_t numel, int E,
+                                   int32_t* __restrict__ sorted_ids, int32_t* __restrict__ cursor) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int e = topk_ids[i];
+    if (e >= 0 && e < E) {
+      const int pos = atomicAdd(&cursor[e], 1);
+      sorted_ids[pos] = (int32_t)i;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// C[row, n] = sum_k A[arow, k] * W[expert, n, k]      ("NT" GEMM, W row-major [N,K])
+// Workgroup tile 64 x 128, BK = 64, 4 waves each 64 x 32 (two 32x32x16 MFMA row tiles).
+// GROUPED: rows come from sorted_token_ids / expert_ids (fused_moe_kernel semantics);
+// otherwise plain dense rows (lm_head).
+// ---------------------------------------------------------------------------
+template <typename T, typename OutT, bool GROUPED>
+__global__ void __launch_bounds__(256)
+gemm_nt_kernel(OutT* __restrict__ c, const T* __restrict__ a, const T* __restrict__ w,
+               const float* __restrict__ topk_weights, const int32_t* __restrict__ sorted_ids,
+               const int32_t* __restrict__ expert_ids, const int32_t* __restrict__ num_post_pad,
+               int64_t num_valid, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldc,
+               int top_k_div, int mul_routed_weight) {
+  constexpr int BM = 64, BN = 128, BK = 64;
+  constexpr int AS = BK + 8, WS = BK + 8;  // row strides (elements), 16 B pad
+  __shared__ __attribute__((aligned(16))) uint16_t a_lds[BM * AS];
+  __shared__ __attribute__((aligned(16))) uint16_t w_lds[BN * WS];
+  __shared__ int row_id[BM];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, hi = lane >> 5;
+  const int64_t m0 = (int64_t)blockIdx.y * BM;
+  const int64_t n0 = (int64_t)blockIdx.x * BN;
+  int64_t expert = 0;
+  if (GROUPED) {
+    if (m0 >= *num_post_pad) return;
+    expert = expert_ids[blockIdx.y];
+    if (tid < BM) row_id[tid] = sorted_ids[m0 + tid];
+  } else {
+    if (tid < BM) row_id[tid] = (m0 + tid < M) ? (int)(m0 + tid) : -1;
+  }
+  __syncthreads();
+  const T* wbase = w + expert * N * K;
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  const bool k_vec = (K % 8 == 0) && (lda % 8 == 0);
+  for (int64_t k0 = 0; k0 < K; k0 += BK) {
+    __syncthreads();
+    // A tile: 64 rows x 8 chunks of 8 elements = 512 items
+    for (int item = tid; item < BM * (BK / 8); item += 256) {
+      const int r = item >> 3, ch = item & 7;
+      const int rid = row_id[r];
+      Frag16m x;
+      x.u = make_uint4(0, 0, 0, 0);
+      const bool valid = GROUPED ? (rid >= 0 && rid < num_valid) : (rid >= 0);
+      if (valid) {
+        const int64_t arow = GROUPED ? (int64_t)(rid / top_k_div) : (int64_t)rid;
+        const int64_t kk = k0 + ch * 8;
+        const T* p = a + arow * lda + kk;
+        if (k_vec && kk + 8 <= K) {
+          x.u = *reinterpret_cast<const uint4*>(p);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) x.e[j] = (kk + j < K) ? p[j].v : (uint16_t)0;
+        }
+      }
+      *reinterpret_cast<uint4*>(&a_lds[r * AS + ch * 8]) = x.u;
+    }
+    // W tile: 128 rows x 8 chunks = 1024 items
+    for (int item = tid; item < BN * (BK / 8); item += 256) {
+      const int r = item >> 3, ch = item & 7;
+      const int64_t n = n0 + r;
+      Frag16m x;
+      x.u = make_uint4(0, 0, 0, 0);
+      if (n < N) {
+        const int64_t kk = k0 + ch * 8;
+        const T* p = wbase + n * K + kk;
+        if ((K % 8 == 0) && kk + 8 <= K) {
+          x.u = *reinterpret_cast<const uint4*>(p);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) x.e[j] = (kk + j < K) ? p[j].v : (uint16_t)0;
+        }
+      }
+      *reinterpret_cast<uint4*>(&w_lds[r * WS + ch * 8]) = x.u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      Frag16m bf, a0, a1;
+      bf.u = *reinterpret_cast<const uint4*>(&w_lds[(wave * 32 + col) * WS + ks * 16 + hi * 8]);
+      a0.u = *reinterpret_cast<const uint4*>(&a_lds[(col)*AS + ks * 16 + hi * 8]);
+      a1.u = *reinterpret_cast<const uint4*>(&a_lds[(32 + col) * AS + ks * 16 + hi * 8]);
+      acc[0] = MfmaG<T>::mma(a0, bf, acc[0]);
+      acc[1] = MfmaG<T>::mma(a1, bf, acc[1]);
+    }
+  }
+  // epilogue: lane holds C[m = i*32 + (r&3)+8*(r>>2)+4*hi][n = n0 + wave*32 + col]
+  const int64_t n = n0 + wave * 32 + col;
+  if (n < N) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const int rid = row_id[m];
+        const bool valid = GROUPED ? (rid >= 0 && rid < num_valid) : (rid >= 0);
+        if (valid) {
+          float v = acc[i][r];
+          if (GROUPED && mul_routed_weight) v *= topk_weights[rid];
+          OutT* dst = c + (int64_t)rid * ldc + n;
+          if constexpr (sizeof(OutT) == 4) *reinterpret_cast<float*>(dst) = v;
+          else *dst = Elem<OutT>::from_f(v);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace semipd
+
+using namespace semipd;
+
+extern "C" {
+
+int semipd_topk_softmax(const void* gating, float* topk_weights, int32_t* topk_ids,
+                        int64_t num_tokens, int num_experts, int topk, int renormalize, int dtype,
+                        void* stream) {
+  SEMIPD_CHECK_ARG(num_tokens >= 0 && num_experts > 0 && num_experts <= kMaxExperts && topk > 0 &&
+                       topk <= kMaxTopk && topk <= num_experts,
+                   SEMIPD_EINVAL, "topk_softmax: bad sizes (E<=%d, topk<=%d)", kMaxExperts, kMaxTopk);
+  if (num_tokens == 0) return 0;
+  SEMIPD_CHECK_ARG(gating && topk_weights && topk_ids, SEMIPD_EINVAL, "topk_softmax: null pointer");
+  SEMIPD_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((moe_topk_kernel<T>), dim3((unsigned)num_tokens), dim3(64), 0, as_stream(stream), (const T*)gating, (const float*)nullptr, topk_weights, topk_ids, num_experts, topk, 1, 1, renormalize, 0, 0));
+  return launch_status("topk_softmax");
+}
+
+int semipd_grouped_topk(const void* gating, const float* correction_bias, float* topk_weights,
+                        int32_t* topk_ids, int64_t num_tokens, int num_experts, int topk,
+                        int num_expert_group, int topk_group, int renormalize, int scoring,
+                        int dtype, void* stream) {
+  SEMIPD_CHECK_ARG(num_tokens >= 0 && num_experts > 0 && num_experts <= kMaxExperts && topk > 0 &&
+                       topk <= kMaxTopk && topk <= num_experts && num_expert_group > 0 &&
+                       num_expert_group <= 64 && num_experts % num_expert_group == 0 &&
+                       topk_group > 0 && topk_group <= num_expert_group,
+                   SEMIPD_EINVAL, "grouped_topk: bad sizes");
+  if (num_tokens == 0) return 0;
+  SEMIPD_CHECK_ARG(gating && topk_weights && topk_ids, SEMIPD_EINVAL, "grouped_topk: null pointer");
+  const int sc = correction_bias ? 1 : scoring;  // biased_grouped_topk always uses sigmoid
+  SEMIPD_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((moe_topk_kernel<T>), dim3((unsigned)num_tokens), dim3(64), 0, as_stream(stream), (const T*)gating, correction_bias, topk_weights, topk_ids, num_experts, topk, num_expert_group, topk_group, renormalize, sc, 1));
+  return launch_status("grouped_topk");
+}
+
+int semipd_moe_align_block_size(const int32_t* topk_ids, int64_t numel, int num_experts,
+                                int block_size, int32_t* sorted_token_ids, int32_t* expert_ids,
+                                int32_t* num_tokens_post_pad, int32_t* cumsum_buffer,
+                                int64_t max_sorted, void* stream) {
+  SEMIPD_CHECK_ARG(numel >= 0 && num_experts > 0 && num_experts <= kMaxExperts && block_size > 0,
+                   SEMIPD_EINVAL, "moe_align_block_size: bad sizes");
+  SEMIPD_CHECK_ARG(topk_ids && sorted_token_ids && expert_ids && num_tokens_post_pad && cumsum_buffer,
+                   SEMIPD_EINVAL, "moe_align_block_size: null pointer");
+  SEMIPD_CHECK_ARG(max_sorted >= numel + (int64_t)num_experts * (block_size - 1), SEMIPD_EINVAL, "moe_align_block_size: sorted_token_ids too small");
+  hipStream_t st = as_stream(stream);
+  if (numel <= 4096 && max_sorted <= 65536) {
+    hipLaunchKernelGGL((moe_align_kernel<true>), dim3(1), dim3(1024), 0, st, topk_ids, numel,
+                       num_experts, block_size, sorted_token_ids, expert_ids, num_tokens_post_pad,
+                       cumsum_buffer, max_sorted);
+    return launch_status("moe_align(fused)");
+  }
+  int fb = (int)((max_sorted + 255) / 256);
+  if (fb > 2048) fb = 2048;
+  hipLaunchKernelGGL(fill_i32_kernel, dim3(fb), dim3(256), 0, st, sorted_token_ids, max_sorted,
+                     (int32_t)numel);
+  hipLaunchKernelGGL((moe_align_kernel<false>), dim3(1), dim3(1024), 0, st, topk_ids, numel,
+                     num_experts, block_size, sorted_token_ids, expert_ids, num_tokens_post_pad,
+                     cumsum_buffer, max_sorted);
+  int sb = (int)((numel + 255) / 256);
+  if (sb > 2048) sb = 2048;
+  // cumsum_buffer[0..E) doubles as the running write cursor (as in moe_align_kernel.cu:77-95);
+  // after the call it holds the *end* offsets of each expert's real tokens.
+  hipLaunchKernelGGL(moe_scatter_kernel, dim3(sb), dim3(256), 0, st, topk_ids, numel, num_experts,
+                     sorted_token_ids, cumsum_buffer);
+  return launch_status("moe_align");
+}
+
+int semipd_moe_grouped_gemm(void* c, const void* a, const void* w, const float* topk_weights,
+                            const int32_t* sorted_token_ids, const int32_t* expert_ids,
+                            const int32_t* num_tokens_post_pad, int64_t num_valid, int64_t n,
+                            int64_t k, int64_t max_sorted, int top_k_div, int mul_routed_weight,
+                            int block_m, int dtype, void* stream) {
+  SEMIPD_CHECK_ARG(n > 0 && k > 0 && num_valid >= 0 && max_sorted >= 0 && top_k_div > 0,
+                   SEMIPD_EINVAL, "moe_grouped_gemm: bad sizes");
+  SEMIPD_CHECK_ARG(block_m == 64, SEMIPD_ESHAPE, "moe_grouped_gemm: block_m must be 64");
+  if (num_valid == 0 || max_sorted == 0) return 0;
+  SEMIPD_CHECK_ARG(c && a && w && sorted_token_ids && expert_ids && num_tokens_post_pad, SEMIPD_EINVAL,
+                   "moe_grouped_gemm: null pointer");
+  SEMIPD_CHECK_ARG(!mul_routed_weight || topk_weights, SEMIPD_EINVAL,
+                   "moe_grouped_gemm: topk_weights required");
+  SEMIPD_CHECK_ARG(aligned16(a) && aligned16(w), SEMIPD_EALIGN, "moe_grouped_gemm: unaligned pointer");
+  dim3 grid((unsigned)((n + 127) / 128), (unsigned)((max_sorted + 63) / 64));
+  SEMIPD_DISPATCH_HALF(dtype, T, hipLaunchKernelGGL((gemm_nt_kernel<T, T, true>), grid, dim3(256), 0, as_stream(stream), (T*)c, (const T*)a, (const T*)w, topk_weights, sorted_token_ids, expert_ids, num_tokens_post_pad, num_valid, (int64_t)0, n, k, k, n, top_k_div, mul_routed_weight));
+  return launch_status("moe_grouped_gemm");
+}
+
+size_t semipd_lm_head_argmax_workspace(int64_t batch, int64_t vocab) {
+  return (size_t)batch * (size_t)vocab * sizeof(float);
+}
+
+int semipd_argmax(const void* logits, void* out, int64_t batch, int64_t vocab,
+                  int64_t logits_stride, int dtype, int out_is_i64, void* stream);
+
+int semipd_lm_head_argmax(const void* hidden, const void* weight, float* logits, void* out,
+                          void* workspace, int64_t batch, int64_t hidden_size, int64_t vocab,
+                          int dtype, int out_is_i64, void* stream) {
+  SEMIPD_CHECK_ARG(batch >= 0 && hidden_size > 0 && vocab > 0, SEMIPD_EINVAL,
+                   "lm_head_argmax: bad sizes");
+  if (batch == 0) return 0;
+  SEMIPD_CHECK_ARG(hidden && weight && out, SEMIPD_EINVAL, "lm_head_argmax: null pointer");
+  float* lg = logits ? logits : (float*)workspace;
+  SEMIPD_CHECK_ARG(lg, SEMIPD_EINVAL, "lm_head_argmax: logits or workspace required");
+  SEMIPD_CHECK_ARG(aligned16(hidden) && aligned16(weight), SEMIPD_EALIGN,
+                   "lm_head_argmax: unaligned pointer");
+  dim3 grid((unsigned)((vocab + 127) / 128), (unsigned)((batch + 63) / 64));
+  SEMIPD_DISPATCH_HALF(dtype, T, hipLaunchKernelGGL((gemm_nt_kernel<T, float, false>), grid, dim3(256), 0, as_stream(stream), lg, (const T*)hidden, (const T*)weight, (const float*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, (int64_t)0, batch, vocab, hidden_size, hidden_size, vocab, 1, 0));
+  int rc = launch_status("lm_head_gemm");
+  if (rc) return rc;
+  return semipd_argmax(lg, out, batch, vocab, vocab, SEMIPD_F32, out_is_i64, stream);
+}
+
+}  // extern "C"

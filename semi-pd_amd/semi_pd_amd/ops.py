@@ -1,0 +1,364 @@
+"""Host-side operator layer: the reference's op seam, backed by libsemipd_hip.so.
+
+Function names, argument meaning and error behaviour mirror
+  * sgl-kernel/python/sgl_kernel/elementwise.py:9-151 (rmsnorm, fused_add_rmsnorm,
+    silu_and_mul, apply_rope_with_cos_sin_cache_inplace),
+  * sgl-kernel/python/sgl_kernel/moe.py:4-23 (moe_align_block_size),
+  * layers/attention/triton_ops/decode_attention.py:625-636 (decode_attention_fwd),
+  * layers/attention/triton_ops/extend_attention.py:291-307 (extend_attention_fwd),
+  * layers/attention/utils.py:5-39 (create_flashinfer_kv_indices),
+so a parity test written against the reference reads the same here.  Every op
+launches on torch's *current* stream and never synchronises.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import check, current_stream, dtype_code, ptr
+
+
+def _rows(t: torch.Tensor) -> int:
+    return t.numel() // t.shape[-1] if t.numel() else 0
+
+
+def _need_contig_last(t: torch.Tensor, name: str) -> None:
+    if t.stride(-1) != 1:
+        raise RuntimeError(f"{name}: last dimension must be contiguous")
+
+
+# --------------------------------------------------------------------------- norm
+def rmsnorm(input: torch.Tensor, weight: torch.Tensor, eps: float = 1e-6,
+            out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    if input.dim() != 2:
+        raise RuntimeError("rmsnorm: input must be 2-D [tokens, hidden]")
+    if weight.dim() != 1 or weight.shape[0] != input.shape[1]:
+        raise RuntimeError("rmsnorm: weight shape mismatch")
+    if weight.dtype != input.dtype:
+        raise RuntimeError("rmsnorm: weight dtype must match input")
+    _need_contig_last(input, "rmsnorm")
+    if out is None:
+        out = torch.empty_like(input)
+    _need_contig_last(out, "rmsnorm")
+    lib = _lib.load()
+    check(lib.semipd_rmsnorm(ptr(out), ptr(input), ptr(weight), input.shape[0], input.shape[1],
+                             input.stride(0), out.stride(0), eps, dtype_code(input.dtype),
+                             current_stream(input.device)), "rmsnorm")
+    return out
+
+
+def fused_add_rmsnorm(input: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor,
+                      eps: float = 1e-6) -> None:
+    if input.dim() != 2 or residual.shape != input.shape:
+        raise RuntimeError("fused_add_rmsnorm: input/residual must be 2-D and the same shape")
+    if weight.dim() != 1 or weight.shape[0] != input.shape[1]:
+        raise RuntimeError("fused_add_rmsnorm: weight shape mismatch")
+    if not (input.is_contiguous() and residual.is_contiguous()):
+        raise RuntimeError("fused_add_rmsnorm: tensors must be contiguous")
+    if not (weight.dtype == input.dtype == residual.dtype):
+        raise RuntimeError("fused_add_rmsnorm: dtype mismatch")
+    lib = _lib.load()
+    check(lib.semipd_fused_add_rmsnorm(ptr(input), ptr(residual), ptr(weight), input.shape[0],
+                                       input.shape[1], eps, dtype_code(input.dtype),
+                                       current_stream(input.device)), "fused_add_rmsnorm")
+
+
+# --------------------------------------------------------------------------- activation
+def silu_and_mul(input: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    if input.shape[-1] * input.dtype.itemsize % 16 != 0:
+        raise ValueError("The pointers must be multiple of 16 bytes.")
+    d = input.shape[-1] // 2
+    if out is not None:
+        if out.shape[:-1] != input.shape[:-1] or out.shape[-1] * 2 != input.shape[-1]:
+            raise AssertionError(f"{input.shape} vs {out.shape}")
+    else:
+        out = torch.empty(input.shape[:-1] + (d,), device=input.device, dtype=input.dtype)
+    if not (input.is_contiguous() and out.is_contiguous()):
+        raise RuntimeError("silu_and_mul: tensors must be contiguous")
+    lib = _lib.load()
+    check(lib.semipd_silu_and_mul(ptr(out), ptr(input), _rows(input), d, dtype_code(input.dtype),
+                                  current_stream(input.device)), "silu_and_mul")
+    return out
+
+
+# --------------------------------------------------------------------------- rope
+def apply_rope_with_cos_sin_cache_inplace(positions: torch.Tensor, query: torch.Tensor,
+                                          key: torch.Tensor, head_size: int,
+                                          cos_sin_cache: torch.Tensor, is_neox: bool = True) -> None:
+    if cos_sin_cache.dtype != torch.float32:
+        raise ValueError("cos_sin_cache should be float32")
+    if positions.dtype != torch.int64:
+        positions = positions.long()
+    nnz = query.shape[0]
+    q = query.view(nnz, -1, head_size)
+    k = key.view(nnz, -1, head_size)
+    if q.stride(-1) != 1 or k.stride(-1) != 1 or q.stride(1) != head_size or k.stride(1) != head_size:
+        raise RuntimeError("rope: heads must be densely packed")
+    lib = _lib.load()
+    check(lib.semipd_rope_inplace(ptr(q), ptr(k), ptr(cos_sin_cache), ptr(positions), nnz, q.shape[1],
+                                  k.shape[1], head_size, cos_sin_cache.shape[1], q.stride(0),
+                                  k.stride(0), 0 if is_neox else 1, dtype_code(query.dtype),
+                                  current_stream(query.device)), "apply_rope")
+
+
+def rope_and_store_kv(positions: torch.Tensor, query: torch.Tensor, key: torch.Tensor,
+                      value: torch.Tensor, head_size: int, cos_sin_cache: torch.Tensor, is_neox: bool,
+                      k_buffer: torch.Tensor, v_buffer: torch.Tensor, loc: torch.Tensor) -> None:
+    """RoPE on q/k in place fused with set_kv_buffer(loc, k, v)
+    (layers/rotary_embedding.py:143-169 + mem_cache/memory_pool.py:316-346)."""
+    if cos_sin_cache.dtype != torch.float32:
+        raise ValueError("cos_sin_cache should be float32")
+    nnz = query.shape[0]
+    q = query.view(nnz, -1, head_size)
+    k = key.view(nnz, -1, head_size)
+    v = value.view(nnz, k.shape[1], -1)
+    v_head = v.shape[2]
+    if loc.dtype != torch.int64 or positions.dtype != torch.int64:
+        raise RuntimeError("rope_and_store_kv: loc / positions must be int64")
+    if k_buffer.stride(-1) != 1 or v_buffer.stride(-1) != 1:
+        raise RuntimeError("rope_and_store_kv: pool rows must be contiguous")
+    lib = _lib.load()
+    check(lib.semipd_rope_kv_store(ptr(q), ptr(k), ptr(v), ptr(k_buffer), ptr(v_buffer), ptr(loc),
+                                   ptr(cos_sin_cache), ptr(positions), nnz, q.shape[1], k.shape[1],
+                                   head_size, v_head, cos_sin_cache.shape[1], q.stride(0), k.stride(0),
+                                   v.stride(0), k_buffer.stride(0), v_buffer.stride(0),
+                                   0 if is_neox else 1, dtype_code(query.dtype),
+                                   current_stream(query.device)), "rope_kv_store")
+
+
+def store_kv_rows(buffer: torch.Tensor, loc: torch.Tensor, src: torch.Tensor) -> None:
+    """buffer[loc] = src  (memory_pool.py:345-346, 451-452); rows are the trailing dims."""
+    if loc.dtype != torch.int64:
+        loc = loc.long()
+    n = src.shape[0]
+    row_elems = src[0].numel() if n else 0
+    if n and (src[0].numel() != buffer[0].numel()) and False:
+        raise RuntimeError("store_kv_rows: row size mismatch")
+    if n and not src[0].is_contiguous():
+        raise RuntimeError("store_kv_rows: rows must be contiguous")
+    if src.dtype != buffer.dtype:
+        raise RuntimeError("store_kv_rows: dtype mismatch")
+    es = src.element_size()
+    lib = _lib.load()
+    check(lib.semipd_kv_store(ptr(buffer), ptr(src), ptr(loc), n, row_elems * es, buffer.stride(0) * es,
+                              src.stride(0) * es if n else 0, current_stream(src.device)), "kv_store")
+
+
+def gather_rows(src: torch.Tensor, index: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[i] = src[index[i]] for 2-D src (last-token gather, logits_processor.py:232-260)."""
+    if src.dim() != 2 or src.stride(1) != 1:
+        raise RuntimeError("gather_rows: src must be 2-D with contiguous rows")
+    if index.dtype != torch.int64:
+        index = index.long()
+    n = index.shape[0]
+    if out is None:
+        out = torch.empty((n, src.shape[1]), dtype=src.dtype, device=src.device)
+    es = src.element_size()
+    lib = _lib.load()
+    check(lib.semipd_gather_rows(ptr(out), ptr(src), ptr(index), n, src.shape[1] * es,
+                                 src.stride(0) * es, current_stream(src.device)), "gather_rows")
+    return out
+
+
+# --------------------------------------------------------------------------- kv indices
+def create_flashinfer_kv_indices(req_to_token: torch.Tensor, req_pool_indices: torch.Tensor,
+                                 page_kernel_lens: torch.Tensor, kv_indptr: torch.Tensor,
+                                 kv_start_idx: Optional[torch.Tensor], kv_indices: torch.Tensor) -> None:
+    """Fills kv_indptr[:B+1] (cumsum) and kv_indices (layers/attention/utils.py:5-39 plus the
+    torch.cumsum at triton_backend.py:96-97)."""
+    if req_to_token.dtype != torch.int32 or kv_indptr.dtype != torch.int32 or kv_indices.dtype != torch.int32:
+        raise RuntimeError("kv indices must be int32")
+    if req_pool_indices.dtype != torch.int64:
+        req_pool_indices = req_pool_indices.long()
+    if page_kernel_lens.dtype not in (torch.int32, torch.int64):
+        raise RuntimeError("page_kernel_lens must be int32/int64")
+    if kv_start_idx is not None and kv_start_idx.dtype != torch.int32:
+        kv_start_idx = kv_start_idx.int()
+    bs = req_pool_indices.shape[0]
+    lib = _lib.load()
+    check(lib.semipd_build_kv_indices(ptr(req_to_token), req_to_token.stride(0), ptr(req_pool_indices),
+                                      ptr(page_kernel_lens), 1 if page_kernel_lens.dtype == torch.int64 else 0,
+                                      ptr(kv_start_idx), ptr(kv_indptr), ptr(kv_indices), bs,
+                                      current_stream(req_to_token.device)), "build_kv_indices")
+
+
+def compute_position(extend_prefix_lens: torch.Tensor, extend_seq_lens: torch.Tensor,
+                     extend_seq_lens_sum: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """positions, extend_start_loc (model_executor/forward_batch_info.py:393-466)."""
+    bs = extend_seq_lens.shape[0]
+    dev = extend_seq_lens.device
+    positions = torch.empty(extend_seq_lens_sum, dtype=torch.int64, device=dev)
+    start_loc = torch.empty(bs, dtype=torch.int32, device=dev)
+    lib = _lib.load()
+    check(lib.semipd_compute_positions(ptr(extend_prefix_lens.int()), ptr(extend_seq_lens.int()),
+                                       ptr(positions), ptr(start_loc), bs, current_stream(dev)),
+          "compute_positions")
+    return positions, start_loc
+
+
+# --------------------------------------------------------------------------- attention
+def decode_attention_fwd(q: torch.Tensor, k_buffer: torch.Tensor, v_buffer: torch.Tensor,
+                         o: torch.Tensor, kv_indptr: torch.Tensor, kv_indices: torch.Tensor,
+                         attn_logits: Optional[torch.Tensor], num_kv_splits: int, sm_scale: float,
+                         logit_cap: float = 0.0) -> None:
+    """q [B,Hq,Dk]; k_buffer [N,Hkv,Dk]; v_buffer [N,Hkv,Dv]; o [B,Hq,Dv];
+    attn_logits fp32 [B,Hq,num_kv_splits,Dv+1]."""
+    B, Hq, Dk = q.shape
+    Hkv, Dv = v_buffer.shape[1], v_buffer.shape[2]
+    if attn_logits is not None:
+        assert num_kv_splits == attn_logits.shape[2]
+        assert B <= attn_logits.shape[0] and attn_logits.dtype == torch.float32
+        assert attn_logits.shape[3] == Dv + 1 and attn_logits.is_contiguous()
+    assert B <= kv_indptr.shape[0] - 1
+    if q.stride(2) != 1 or q.stride(1) != Dk or o.stride(2) != 1 or o.stride(1) != Dv:
+        raise RuntimeError("decode_attention_fwd: q / o heads must be densely packed")
+    if k_buffer.stride(2) != 1 or k_buffer.stride(1) != Dk or v_buffer.stride(2) != 1 or v_buffer.stride(1) != Dv:
+        # MLA: v_buffer is a [..., :512] view of the latent rows -> stride(1) is the row stride, Hkv == 1
+        if not (Hkv == 1 and k_buffer.stride(2) == 1 and v_buffer.stride(2) == 1):
+            raise RuntimeError("decode_attention_fwd: pool heads must be densely packed")
+    lib = _lib.load()
+    check(lib.semipd_decode_attention(ptr(o), ptr(q), ptr(k_buffer), ptr(v_buffer), ptr(kv_indptr),
+                                      ptr(kv_indices), ptr(attn_logits), B, Hq, Hkv, Dk, Dv,
+                                      q.stride(0), o.stride(0), k_buffer.stride(0), v_buffer.stride(0),
+                                      num_kv_splits, sm_scale, logit_cap, dtype_code(q.dtype),
+                                      current_stream(q.device)), "decode_attention")
+
+
+def extend_attention_fwd(q_extend: torch.Tensor, k_extend: torch.Tensor, v_extend: torch.Tensor,
+                         o_extend: torch.Tensor, k_buffer: Optional[torch.Tensor],
+                         v_buffer: Optional[torch.Tensor], qo_indptr: torch.Tensor,
+                         kv_indptr: torch.Tensor, kv_indices: Optional[torch.Tensor],
+                         custom_mask: Optional[torch.Tensor], mask_indptr: Optional[torch.Tensor],
+                         max_len_extend: int, sm_scale: Optional[float] = None, logit_cap: float = 0.0,
+                         skip_prefix_custom_mask: bool = True) -> None:
+    """q_extend [T,Hq,Dk], k_extend [T,Hkv,Dk], v_extend [T,Hkv,Dv], o_extend [T,Hq,Dv]."""
+    if custom_mask is not None:
+        raise RuntimeError("extend_attention_fwd: custom_mask is not supported (speculative "
+                           "decoding is disabled in Semi-PD mode, managers/scheduler.py:272-275)")
+    T, Hq, Dk = q_extend.shape
+    Hkv, Dv = v_extend.shape[1], v_extend.shape[2]
+    sm_scale = sm_scale or 1.0 / (Dk ** 0.5)
+    for name, t, d in (("q", q_extend, Dk), ("k", k_extend, Dk), ("v", v_extend, Dv), ("o", o_extend, Dv)):
+        if t.stride(2) != 1 or t.stride(1) != d:
+            raise RuntimeError(f"extend_attention_fwd: {name}_extend heads must be densely packed")
+    kb_stride = k_buffer.stride(0) if k_buffer is not None else 0
+    vb_stride = v_buffer.stride(0) if v_buffer is not None else 0
+    B = qo_indptr.shape[0] - 1
+    lib = _lib.load()
+    check(lib.semipd_extend_attention(ptr(o_extend), ptr(q_extend), ptr(k_extend), ptr(v_extend),
+                                      ptr(k_buffer), ptr(v_buffer), ptr(qo_indptr), ptr(kv_indptr),
+                                      ptr(kv_indices), B, Hq, Hkv, Dk, Dv, q_extend.stride(0),
+                                      k_extend.stride(0), v_extend.stride(0), o_extend.stride(0),
+                                      kb_stride, vb_stride, int(max_len_extend), sm_scale, logit_cap,
+                                      dtype_code(q_extend.dtype), current_stream(q_extend.device)),
+          "extend_attention")
+
+
+# --------------------------------------------------------------------------- sampling
+def greedy_argmax(logits: torch.Tensor, out_dtype: torch.dtype = torch.int32) -> torch.Tensor:
+    """Sampler greedy branch: torch.argmax(logits, -1) (layers/sampler.py:72-74)."""
+    if logits.dim() != 2 or logits.stride(1) != 1:
+        raise RuntimeError("greedy_argmax: logits must be 2-D with contiguous rows")
+    out = torch.empty(logits.shape[0], dtype=out_dtype, device=logits.device)
+    lib = _lib.load()
+    check(lib.semipd_argmax(ptr(logits), ptr(out), logits.shape[0], logits.shape[1], logits.stride(0),
+                            dtype_code(logits.dtype), 1 if out_dtype == torch.int64 else 0,
+                            current_stream(logits.device)), "argmax")
+    return out
+
+
+def lm_head_argmax(hidden: torch.Tensor, weight: torch.Tensor, return_logits: bool = True,
+                   out_dtype: torch.dtype = torch.int32):
+    """fp32 logits = hidden @ weight.T (bf16 MFMA, fp32 accumulate) and their argmax
+    (layers/logits_processor.py:394-445 + layers/sampler.py:72-74)."""
+    if hidden.dim() != 2 or weight.dim() != 2 or hidden.shape[1] != weight.shape[1]:
+        raise RuntimeError("lm_head_argmax: shape mismatch")
+    if not (hidden.is_contiguous() and weight.is_contiguous()) or hidden.dtype != weight.dtype:
+        raise RuntimeError("lm_head_argmax: contiguous tensors of one dtype required")
+    B, V = hidden.shape[0], weight.shape[0]
+    logits = torch.empty((B, V), dtype=torch.float32, device=hidden.device)
+    out = torch.empty(B, dtype=out_dtype, device=hidden.device)
+    lib = _lib.load()
+    check(lib.semipd_lm_head_argmax(ptr(hidden), ptr(weight), ptr(logits), ptr(out), None, B,
+                                    hidden.shape[1], V, dtype_code(hidden.dtype),
+                                    1 if out_dtype == torch.int64 else 0,
+                                    current_stream(hidden.device)), "lm_head_argmax")
+    return (logits if return_logits else None), out
+
+
+# --------------------------------------------------------------------------- MoE
+def topk_softmax(gating_output: torch.Tensor, topk: int, renormalize: bool):
+    """fused_topk (layers/moe/topk.py:44-75): fp32 softmax + top-k."""
+    T, E = gating_output.shape
+    w = torch.empty((T, topk), dtype=torch.float32, device=gating_output.device)
+    ids = torch.empty((T, topk), dtype=torch.int32, device=gating_output.device)
+    g = gating_output.contiguous()
+    lib = _lib.load()
+    check(lib.semipd_topk_softmax(ptr(g), ptr(w), ptr(ids), T, E, topk, int(renormalize),
+                                  dtype_code(g.dtype), current_stream(g.device)), "topk_softmax")
+    return w, ids
+
+
+def grouped_topk(gating_output: torch.Tensor, topk: int, renormalize: bool, num_expert_group: int,
+                 topk_group: int, correction_bias: Optional[torch.Tensor] = None,
+                 scoring_func: str = "softmax"):
+    """grouped_topk / biased_grouped_topk (layers/moe/topk.py:79-160)."""
+    if scoring_func not in ("softmax", "sigmoid"):
+        raise ValueError(f"Scoring function '{scoring_func}' is not supported.")
+    T, E = gating_output.shape
+    w = torch.empty((T, topk), dtype=torch.float32, device=gating_output.device)
+    ids = torch.empty((T, topk), dtype=torch.int32, device=gating_output.device)
+    g = gating_output.contiguous()
+    bias = correction_bias.float().contiguous() if correction_bias is not None else None
+    lib = _lib.load()
+    check(lib.semipd_grouped_topk(ptr(g), ptr(bias), ptr(w), ptr(ids), T, E, topk, num_expert_group,
+                                  topk_group, int(renormalize), 1 if scoring_func == "sigmoid" else 0,
+                                  dtype_code(g.dtype), current_stream(g.device)), "grouped_topk")
+    return w, ids
+
+
+def moe_align_block_size(topk_ids: torch.Tensor, num_experts: int, block_size: int,
+                         sorted_token_ids: torch.Tensor, experts_ids: torch.Tensor,
+                         num_tokens_post_pad: torch.Tensor, token_cnts_buffer: Optional[torch.Tensor],
+                         cumsum_buffer: torch.Tensor) -> None:
+    """Same argument list as sgl_kernel.moe_align_block_size (python/sgl_kernel/moe.py:4-23);
+    token_cnts_buffer is accepted and unused (the histogram lives in LDS)."""
+    if topk_ids.dtype != torch.int32:
+        raise RuntimeError("moe_align_block_size: topk_ids must be int32")
+    if cumsum_buffer.numel() < num_experts + 1:
+        raise RuntimeError("moe_align_block_size: cumsum_buffer needs num_experts+1 entries")
+    lib = _lib.load()
+    check(lib.semipd_moe_align_block_size(ptr(topk_ids), topk_ids.numel(), num_experts, block_size,
+                                          ptr(sorted_token_ids), ptr(experts_ids),
+                                          ptr(num_tokens_post_pad), ptr(cumsum_buffer),
+                                          sorted_token_ids.numel(), current_stream(topk_ids.device)),
+          "moe_align_block_size")
+
+
+def moe_grouped_gemm(a: torch.Tensor, w: torch.Tensor, c: torch.Tensor,
+                     topk_weights: Optional[torch.Tensor], sorted_token_ids: torch.Tensor,
+                     expert_ids: torch.Tensor, num_tokens_post_pad: torch.Tensor, num_valid: int,
+                     top_k_div: int, mul_routed_weight: bool, block_m: int = 64) -> None:
+    """invoke_fused_moe_kernel (layers/moe/fused_moe_triton/fused_moe.py:501-612), bf16/f16."""
+    E, N, K = w.shape
+    if a.shape[-1] != K or c.shape[-1] != N or not (a.is_contiguous() and w.is_contiguous() and c.is_contiguous()):
+        raise RuntimeError("moe_grouped_gemm: shape / contiguity mismatch")
+    lib = _lib.load()
+    check(lib.semipd_moe_grouped_gemm(ptr(c), ptr(a), ptr(w), ptr(topk_weights), ptr(sorted_token_ids),
+                                      ptr(expert_ids), ptr(num_tokens_post_pad), num_valid, N, K,
+                                      sorted_token_ids.numel(), top_k_div, int(mul_routed_weight),
+                                      block_m, dtype_code(a.dtype), current_stream(a.device)),
+          "moe_grouped_gemm")
+
+
+def moe_sum(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[t] = x[t].sum(0) for x [T, topk, H] (fused_moe.py:1144-1148)."""
+    T, k, H = x.shape
+    if out is None:
+        out = torch.empty((T, H), dtype=x.dtype, device=x.device)
+    lib = _lib.load()
+    check(lib.semipd_moe_sum(ptr(out), ptr(x.contiguous()), T, k, H, dtype_code(x.dtype),
+                             current_stream(x.device)), "moe_sum")
+    return out

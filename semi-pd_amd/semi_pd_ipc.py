@@ -1,0 +1,129 @@
+"""Drop-in replacement for the reference's `semi_pd_ipc` torch extension
+(semi-pd-ipc/ipc.cpp:94-98): the same three functions with the same signatures, on top of
+the hipIpcMemHandle C-ABI in libsemipd_hip.so (semipd_ipc_get_handle / _open / _close,
+semipd_device_cu_count).
+
+    get_ipc_handle(tensor) -> List[int]                      (len 64, one int per byte)
+    convert_ipc_handle_to_tensor((handle, offset), numel, "at::kBFloat16", device) -> 1-D Tensor
+    get_device_sm_count(rank) -> int                         (CU count on AMD)
+
+Extras (not in the reference): get_ipc_handle_and_offset (no torch `_share_cuda_` needed),
+close_ipc_tensor, num_open_mappings.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Sequence, Tuple
+
+import torch
+
+from semi_pd_amd import _lib
+
+# string <-> dtype table of the reference (semi-pd-ipc/ipc.cpp:28-57, semi_pd/utils.py:40-63)
+ATEN_TO_DTYPE = {
+    "at::kFloat": torch.float32,
+    "at::kDouble": torch.float64,
+    "at::kHalf": torch.float16,
+    "at::kLong": torch.int64,
+    "at::kInt": torch.int32,
+    "at::kShort": torch.int16,
+    "at::kChar": torch.int8,
+    "at::kByte": torch.uint8,
+    "at::kUInt64": torch.uint64,
+    "at::kUInt32": torch.uint32,
+    "at::kUInt16": torch.uint16,
+    "at::kBool": torch.bool,
+    "at::kBFloat16": torch.bfloat16,
+    "at::kComplexHalf": torch.complex32,
+    "at::kComplexFloat": torch.complex64,
+    "at::kComplexDouble": torch.complex128,
+    "at::kFloat8_e4m3fn": torch.float8_e4m3fn,
+    "at::kFloat8_e5m2": torch.float8_e5m2,
+    "at::kFloat8_e4m3fnuz": torch.float8_e4m3fnuz,
+    "at::kFloat8_e5m2fnuz": torch.float8_e5m2fnuz,
+}
+
+
+class _DeviceBytes:
+    """Exposes a raw device range through __cuda_array_interface__ so torch maps it zero-copy."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.ptr = ptr
+        self.nbytes = nbytes
+        self.__cuda_array_interface__ = {
+            "shape": (nbytes,),
+            "typestr": "|u1",
+            "data": (ptr, False),
+            "version": 2,
+            "strides": None,
+        }
+
+
+def get_ipc_handle_and_offset(tensor: torch.Tensor) -> Tuple[List[int], int]:
+    """(64 handle bytes of the allocation that holds `tensor`, byte offset of tensor.data_ptr()
+    inside it).  Replaces get_ipc_handle + storage()._share_cuda_()[3] (semi_pd/utils.py:66-76)."""
+    lib = _lib.load()
+    handle = (C.c_uint8 * 64)()
+    offset = C.c_uint64(0)
+    _lib.check(lib.semipd_ipc_get_handle(_lib.ptr(tensor), C.addressof(handle), C.addressof(offset)),
+               "ipc_get_handle")
+    return [int(b) for b in handle], int(offset.value)
+
+
+def get_ipc_handle(tensor: torch.Tensor) -> List[int]:
+    """GetIPCMemHandle (ipc.cpp:60-64): 64 ints, one per handle byte."""
+    return get_ipc_handle_and_offset(tensor)[0]
+
+
+def _open(handle: Sequence[int], device_index: int) -> int:
+    if len(handle) != 64:
+        raise ValueError(f"IPC handle must have 64 bytes, got {len(handle)}")
+    lib = _lib.load()
+    raw = (C.c_uint8 * 64)(*[int(b) & 0xFF for b in handle])
+    base = C.c_void_p(0)
+    _lib.check(lib.semipd_ipc_open(C.addressof(raw), device_index, C.addressof(base)), "ipc_open")
+    return int(base.value)
+
+
+def convert_ipc_handle_to_tensor(handle_vec_offset, tensor_size: int, dtype_str: str, device) -> torch.Tensor:
+    """ConvertIPCMemHandleToTensor (ipc.cpp:67-85): 1-D tensor of `tensor_size` elements viewing
+    the exporter's memory at allocation base + offset."""
+    handle, offset = handle_vec_offset
+    try:
+        dtype = ATEN_TO_DTYPE[dtype_str]
+    except KeyError:
+        raise ValueError("Unsupported at::ScalarType string: " + dtype_str) from None
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError("convert_ipc_handle_to_tensor: device must be a HIP device")
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    base = _open(handle, index)
+    nbytes = int(tensor_size) * dtype.itemsize
+    mem = _DeviceBytes(base + int(offset), nbytes)
+    with torch.cuda.device(index):
+        flat = torch.as_tensor(mem, device=torch.device("cuda", index))
+    if flat.data_ptr() != base + int(offset):
+        raise RuntimeError("convert_ipc_handle_to_tensor: torch copied the IPC range instead of mapping it")
+    t = flat.view(dtype)
+    t._semipd_ipc_base = base  # keeps the mapping identifiable for close_ipc_tensor
+    return t
+
+
+def close_ipc_tensor(tensor: torch.Tensor) -> None:
+    """Drop the reference this tensor holds on its IPC mapping (unmapped when the last one goes)."""
+    base = getattr(tensor, "_semipd_ipc_base", None)
+    if base is None:
+        raise ValueError("tensor was not created by convert_ipc_handle_to_tensor")
+    _lib.check(_lib.load().semipd_ipc_close(C.c_void_p(base)), "ipc_close")
+    tensor._semipd_ipc_base = None
+
+
+def num_open_mappings() -> int:
+    return int(_lib.load().semipd_ipc_num_open())
+
+
+def get_device_sm_count(rank: int = 0) -> int:
+    """GetDeviceSMCount (ipc.cpp:87-92).  On MI355X this is the CU count (256)."""
+    n = C.c_int(0)
+    _lib.check(_lib.load().semipd_device_cu_count(int(rank), C.addressof(n)), "device_cu_count")
+    return int(n.value)

@@ -1,0 +1,280 @@
+"""Generate tests/golden/*.npz from the REFERENCE itself.
+
+Run only in the build container, where /root/reference exists:
+    TORCHDYNAMO_DISABLE=1 python tests/golden/make_golden.py
+It imports the reference's leaf modules (stubbing the packages that are not installed, SURVEY.md
+Appendix A), runs them on CPU (Triton kernels under TRITON_INTERPRET=1) on seeded inputs and
+stores inputs + outputs.  Only data is written to the repo; no reference source travels.
+bf16 tensors are stored as their uint16 bit patterns (numpy has no bf16).
+"""
+import os
+import sys
+import types
+import importlib.abc
+import importlib.machinery
+
+os.environ["TRITON_INTERPRET"] = "1"
+os.environ.setdefault("TORCHDYNAMO_DISABLE", "1")
+sys.dont_write_bytecode = True
+sys.path.insert(0, "/root/reference/python")
+
+MISSING = {"IPython", "zmq", "setproctitle", "orjson", "uvloop", "decord", "interegular", "llguidance",
+           "xgrammar", "outlines", "torchao", "vllm", "sgl_kernel", "flashinfer", "semi_pd_ipc",
+           "modelscope", "multipart", "torchvision", "aiter"}
+
+
+class _Stub(types.ModuleType):
+    __path__ = []
+
+    def __getattr__(self, name):
+        if name.startswith("__") and name.endswith("__"):
+            raise AttributeError(name)
+        return type(name, (), {"__init__": lambda s, *a, **k: None})
+
+
+class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    def find_spec(self, name, path, target=None):
+        if name.split(".")[0] in MISSING:
+            return importlib.machinery.ModuleSpec(name, self, is_package=True)
+
+    def create_module(self, spec):
+        return _Stub(spec.name)
+
+    def exec_module(self, module):
+        pass
+
+
+sys.meta_path.insert(0, _Finder())
+import triton.runtime.cache as _c  # noqa: E402
+
+for _n in ("default_cache_dir", "default_dump_dir", "default_override_dir"):
+    if not hasattr(_c, _n):
+        setattr(_c, _n, lambda: "/tmp/triton_cache")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import sglang.srt.utils as U  # noqa: E402
+
+U.is_cuda_available = lambda: True
+
+from sglang.srt.layers.layernorm import RMSNorm  # noqa: E402
+from sglang.srt.layers import rotary_embedding as RE  # noqa: E402
+from sglang.srt.layers.attention.triton_ops.decode_attention import decode_attention_fwd  # noqa: E402
+from sglang.srt.layers.attention.triton_ops.extend_attention import extend_attention_fwd  # noqa: E402
+from sglang.srt.layers.attention.utils import create_flashinfer_kv_indices_triton  # noqa: E402
+from sglang.srt.layers.moe import topk as TK  # noqa: E402
+from sglang.srt.mem_cache.memory_pool import ReqToTokenPool, TokenToKVPoolAllocator  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def bits(t: torch.Tensor) -> np.ndarray:
+    t = t.detach()
+    if t.dtype == torch.bfloat16:
+        return t.contiguous().view(torch.int16).numpy().view(np.uint16)
+    return t.contiguous().numpy()
+
+
+def save(name, **arrs):
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrs)
+    print("wrote", name, {k: getattr(v, "shape", None) for k, v in arrs.items()})
+
+
+# ---------------------------------------------------------------- RMSNorm (layernorm.py:59-76)
+def gen_rmsnorm():
+    g = torch.Generator().manual_seed(0)
+    arrs = {}
+    for ci, (T, H, dt) in enumerate([(3, 64, torch.bfloat16), (5, 111, torch.float16), (2, 256, torch.float32),
+                                     (4, 128, torch.bfloat16)]):
+        x = torch.randn(T, H, generator=g).to(dt)
+        r = torch.randn(T, H, generator=g).to(dt)
+        w = (torch.randn(H, generator=g) * 0.5 + 1).to(dt)
+        m = RMSNorm(H, eps=1e-5)
+        m.weight.data = w.clone()
+        y = m.forward_native(x.clone())
+        y2, r2 = m.forward_native(x.clone(), r.clone())
+        tag = f"c{ci}_"
+        arrs.update({tag + "x": bits(x), tag + "r": bits(r), tag + "w": bits(w), tag + "y": bits(y),
+                     tag + "y_fused": bits(y2), tag + "r_fused": bits(r2),
+                     tag + "dtype": np.array(str(dt))})
+    arrs["eps"] = np.array(1e-5)
+    arrs["n"] = np.array(4)
+    save("rmsnorm", **arrs)
+
+
+# ---------------------------------------------------------------- RoPE (rotary_embedding.py)
+def gen_rope():
+    g = torch.Generator().manual_seed(1)
+    arrs = {}
+    cases = []
+    cases.append(("base_neox", RE.RotaryEmbedding(64, 64, 128, 10000, True, torch.float32), 64))
+    cases.append(("base_gptj", RE.RotaryEmbedding(64, 64, 128, 10000, False, torch.float32), 64))
+    cases.append(("partial_neox", RE.RotaryEmbedding(64, 32, 128, 10000, True, torch.float32), 64))
+    cases.append(("llama3", RE.Llama3RotaryEmbedding(128, 128, 256, 500000, True, torch.float32, 8.0, 1.0,
+                                                     4.0, 64), 128))
+    cases.append(("deepseek_yarn", RE.DeepseekScalingRotaryEmbedding(
+        64, 64, 64, 10000, False, 4.0, torch.float32, extrapolation_factor=1, attn_factor=1,
+        beta_fast=32, beta_slow=1, mscale=0.707, mscale_all_dim=0.707, device="cpu"), 64))
+    for name, mod, head in cases:
+        cache = mod.cos_sin_cache.float()
+        T, Hq, Hk = 7, 4, 2
+        pos = torch.randint(0, cache.shape[0], (T,), generator=g)
+        q = torch.randn(T, Hq * head, generator=g)
+        k = torch.randn(T, Hk * head, generator=g)
+        if name == "deepseek_yarn":
+            qo, ko = mod.forward(pos, q.view(T, Hq, head).clone(), k.view(T, Hk, head).clone())
+            qo, ko = qo.reshape(T, -1), ko.reshape(T, -1)
+        else:
+            qo, ko = mod.forward_native(pos, q.clone(), k.clone())
+        arrs.update({f"{name}_cache": cache.numpy(), f"{name}_pos": pos.numpy(), f"{name}_q": q.numpy(),
+                     f"{name}_k": k.numpy(), f"{name}_qo": qo.numpy(), f"{name}_ko": ko.numpy(),
+                     f"{name}_head": np.array(head), f"{name}_neox": np.array(bool(mod.is_neox_style))})
+    arrs["names"] = np.array([c[0] for c in cases])
+    save("rope", **arrs)
+
+
+# ---------------------------------------------------------------- kv pool helpers
+def make_paged(g, B, lens, Hkv, Dk, Dv, dtype, extra=7):
+    total = int(sum(lens))
+    N = total + extra
+    perm = torch.randperm(N - 1, generator=g)[:total] + 1  # slot 0 reserved
+    kv_indptr = torch.zeros(B + 1, dtype=torch.int32)
+    kv_indptr[1:] = torch.cumsum(torch.tensor(lens), 0)
+    kv_indices = perm.to(torch.int32)
+    k_buf = torch.randn(N, Hkv, Dk, generator=g).to(dtype)
+    v_buf = torch.randn(N, Hkv, Dv, generator=g).to(dtype)
+    return k_buf, v_buf, kv_indptr, kv_indices
+
+
+# ---------------------------------------------------------------- decode attention (Triton, interpreter)
+def gen_decode():
+    g = torch.Generator().manual_seed(2)
+    arrs = {}
+    cases = [
+        # name, B, lens, Hq, Hkv, Dk, Dv, splits, logit_cap
+        ("gqa4_d64", 3, [5, 33, 70], 8, 2, 64, 64, 4, 0.0),
+        ("mha_d32", 2, [1, 19], 2, 2, 32, 32, 2, 0.0),
+        ("gqa8_d128_cap", 2, [17, 40], 8, 1, 128, 128, 8, 30.0),
+        ("mla_like", 2, [9, 21], 4, 1, 96, 64, 3, 0.0),
+    ]
+    for name, B, lens, Hq, Hkv, Dk, Dv, splits, cap in cases:
+        dt = torch.float32
+        k_buf, v_buf, kv_indptr, kv_indices = make_paged(g, B, lens, Hkv, Dk, Dv, dt)
+        q = torch.randn(B, Hq, Dk, generator=g).to(dt)
+        o = torch.zeros(B, Hq, Dv, dtype=dt)
+        logits = torch.zeros(B, Hq, splits, Dv + 1, dtype=torch.float32)
+        sm_scale = 1.0 / (Dk ** 0.5)
+        decode_attention_fwd(q, k_buf, v_buf, o, kv_indptr, kv_indices, logits, splits, sm_scale, cap)
+        arrs.update({f"{name}_q": q.numpy(), f"{name}_k": k_buf.numpy(), f"{name}_v": v_buf.numpy(),
+                     f"{name}_indptr": kv_indptr.numpy(), f"{name}_indices": kv_indices.numpy(),
+                     f"{name}_o": o.numpy(), f"{name}_logits": logits.numpy(),
+                     f"{name}_meta": np.array([splits, sm_scale, cap], dtype=np.float64)})
+    arrs["names"] = np.array([c[0] for c in cases])
+    save("decode_attention", **arrs)
+
+
+# ---------------------------------------------------------------- extend attention (Triton, interpreter)
+def gen_extend():
+    g = torch.Generator().manual_seed(3)
+    arrs = {}
+    cases = [
+        # name, prefix lens, extend lens, Hq, Hkv, Dk, Dv, logit_cap
+        ("gqa_d64", [0, 13, 40], [20, 7, 70], 4, 2, 64, 64, 0.0),
+        ("mha_d32_noprefix", [0, 0], [5, 130], 2, 2, 32, 32, 0.0),
+        ("gqa_d128_cap", [9], [33], 4, 1, 128, 128, 25.0),
+        ("dk96_dv64", [6, 0], [10, 3], 2, 1, 96, 64, 0.0),
+    ]
+    for name, pre, ext, Hq, Hkv, Dk, Dv, cap in cases:
+        dt = torch.float32
+        B = len(pre)
+        k_buf, v_buf, kv_indptr, kv_indices = make_paged(g, B, pre, Hkv, Dk, Dv, dt)
+        T = sum(ext)
+        qo_indptr = torch.zeros(B + 1, dtype=torch.int32)
+        qo_indptr[1:] = torch.cumsum(torch.tensor(ext), 0)
+        q = torch.randn(T, Hq, Dk, generator=g).to(dt)
+        k = torch.randn(T, Hkv, Dk, generator=g).to(dt)
+        v = torch.randn(T, Hkv, Dv, generator=g).to(dt)
+        o = torch.zeros(T, Hq, Dv, dtype=dt)
+        sm_scale = 1.0 / (Dk ** 0.5)
+        extend_attention_fwd(q, k, v, o, k_buf, v_buf, qo_indptr, kv_indptr, kv_indices, None, None,
+                             max(ext), sm_scale, cap)
+        arrs.update({f"{name}_q": q.numpy(), f"{name}_k": k.numpy(), f"{name}_v": v.numpy(),
+                     f"{name}_kbuf": k_buf.numpy(), f"{name}_vbuf": v_buf.numpy(),
+                     f"{name}_qo_indptr": qo_indptr.numpy(), f"{name}_kv_indptr": kv_indptr.numpy(),
+                     f"{name}_kv_indices": kv_indices.numpy(), f"{name}_o": o.numpy(),
+                     f"{name}_meta": np.array([sm_scale, cap], dtype=np.float64)})
+    arrs["names"] = np.array([c[0] for c in cases])
+    save("extend_attention", **arrs)
+
+
+# ---------------------------------------------------------------- kv indices (Triton) + pools
+def gen_kv_indices():
+    g = torch.Generator().manual_seed(4)
+    R, C = 9, 40
+    req_to_token = torch.randint(1, 1000, (R, C), generator=g, dtype=torch.int32)
+    req_pool_indices = torch.tensor([3, 0, 7, 5], dtype=torch.int64)
+    lens = torch.tensor([5, 40, 1, 17], dtype=torch.int64)
+    start = torch.tensor([0, 0, 3, 2], dtype=torch.int32)
+    outs = {}
+    for tag, st, ln in (("nostart", None, lens), ("start", start, lens - start.long())):
+        kv_indptr = torch.zeros(5, dtype=torch.int32)
+        kv_indptr[1:] = torch.cumsum(ln, 0)
+        kv_indices = torch.zeros(int(kv_indptr[-1]), dtype=torch.int32)
+        create_flashinfer_kv_indices_triton[(4,)](req_to_token, req_pool_indices, ln, kv_indptr, st,
+                                                  kv_indices, req_to_token.stride(0))
+        outs[tag + "_lens"] = ln.numpy()
+        outs[tag + "_indptr"] = kv_indptr.numpy()
+        outs[tag + "_indices"] = kv_indices.numpy()
+    # pool behaviour (memory_pool.py:46-184): alloc / free ordering
+    pool = ReqToTokenPool(6, 16, "cpu", False)
+    a = pool.alloc(2)
+    b = pool.alloc(3)
+    pool.free(a)
+    c = pool.alloc(3)
+    over = pool.alloc(5)
+    alloc = TokenToKVPoolAllocator(20, torch.bfloat16, "cpu", None)
+    x = alloc.alloc(5)
+    y = alloc.alloc(7)
+    alloc.free(x)
+    z = alloc.alloc(10)
+    w = alloc.alloc(100)
+    save("kv_indices", req_to_token=req_to_token.numpy(), req_pool_indices=req_pool_indices.numpy(),
+         start=start.numpy(), pool_a=np.array(a), pool_b=np.array(b), pool_c=np.array(c),
+         pool_over=np.array(-1 if over is None else 0), alloc_x=x.numpy(), alloc_y=y.numpy(),
+         alloc_z=z.numpy(), alloc_w=np.array(-1 if w is None else 0),
+         alloc_avail=np.array(alloc.available_size()), **outs)
+
+
+# ---------------------------------------------------------------- MoE routing (topk.py)
+def gen_topk():
+    g = torch.Generator().manual_seed(5)
+    arrs = {}
+    T = 9
+    # fused_topk_native: E=8 top2 ; E=64 top6
+    for name, E, k, ren in (("native_e8", 8, 2, True), ("native_e64", 64, 6, False)):
+        gate = torch.randn(T, E, generator=g)
+        w, ids = TK.fused_topk_native(torch.zeros(T, 4), gate, k, ren)
+        arrs.update({name + "_gate": gate.numpy(), name + "_w": w.numpy(), name + "_ids": ids.numpy().astype(np.int32),
+                     name + "_meta": np.array([k, int(ren)])})
+    # grouped_topk: E=64, 8 groups top 3, k=6, softmax & sigmoid, fp32 and bf16 gating
+    for name, dt, scoring in (("grouped_f32", torch.float32, "softmax"), ("grouped_bf16", torch.bfloat16, "softmax"),
+                              ("grouped_sigmoid", torch.float32, "sigmoid")):
+        gate = torch.randn(T, 64, generator=g).to(dt)
+        w, ids = TK.grouped_topk(torch.zeros(T, 4), gate, 6, True, 8, 3, scoring)
+        arrs.update({name + "_gate": bits(gate), name + "_w": w.numpy(), name + "_ids": ids.numpy(),
+                     name + "_meta": np.array([6, 1, 8, 3])})
+    # biased_grouped_topk: E=64, 8 groups top 4, k=8 (DeepSeek-V3 style, scaled down)
+    for name, dt in (("biased_f32", torch.float32), ("biased_bf16", torch.bfloat16)):
+        gate = torch.randn(T, 64, generator=g).to(dt)
+        bias = torch.randn(64, generator=g) * 0.1
+        w, ids = TK.biased_grouped_topk(torch.zeros(T, 4), gate, bias, 8, True, 8, 4)
+        arrs.update({name + "_gate": bits(gate), name + "_bias": bias.numpy(), name + "_w": w.numpy(),
+                     name + "_ids": ids.numpy(), name + "_meta": np.array([8, 1, 8, 4])})
+    save("moe_topk", **arrs)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["rmsnorm", "rope", "kv_indices", "topk", "decode", "extend"]
+    for w in which:
+        {"rmsnorm": gen_rmsnorm, "rope": gen_rope, "kv_indices": gen_kv_indices, "topk": gen_topk,
+         "decode": gen_decode, "extend": gen_extend}[w]()

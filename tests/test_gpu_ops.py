@@ -1,0 +1,506 @@
+"""GPU parity: the HIP kernels (through the C-ABI, via semi_pd_amd.ops) against the CPU oracle on the
+same seeded inputs, and against the golden vectors produced by the reference.  Shapes and
+tolerances follow the reference's own kernel tests (cited per test)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import DTYPES, from_bits, load_golden
+from oracle import ops as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: dict(rtol=1e-5, atol=1e-5), torch.float16: dict(rtol=1e-3, atol=1e-3),
+       torch.bfloat16: dict(rtol=1.6e-2, atol=1e-2)}
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from semi_pd_amd import ops as _ops
+    return _ops
+
+
+def _close(got, want, dtype, **kw):
+    tol = dict(TOL[dtype])
+    tol.update(kw)
+    torch.testing.assert_close(got.detach().cpu().float(), want.detach().cpu().float(), **tol)
+
+
+# ----------------------------------------------------------------------------- RMSNorm
+# sgl-kernel/tests/test_norm.py:52-129 (batch 1/19/99/989, hidden 111..16384, tol 1e-3 fp16)
+@pytest.mark.parametrize("batch", [1, 19, 99, 989])
+@pytest.mark.parametrize("hidden", [111, 500, 1024, 3072, 3584, 4096, 8192, 16384])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_rmsnorm(ops, device, batch, hidden, dtype):
+    torch.manual_seed(batch * 7 + hidden)
+    x = torch.randn(batch, hidden).to(dtype)
+    w = torch.randn(hidden).to(dtype)
+    y = ops.rmsnorm(x.to(device), w.to(device), 1e-6)
+    _close(y, O.rms_norm(x, w, 1e-6), dtype)
+    out = torch.empty_like(x, device=device)
+    ops.rmsnorm(x.to(device), w.to(device), 1e-6, out=out)
+    _close(out, O.rms_norm(x, w, 1e-6), dtype)
+
+
+@pytest.mark.parametrize("batch", [1, 19, 99, 989])
+@pytest.mark.parametrize("hidden", [111, 500, 1024, 3072, 4096, 7168, 8192, 16384])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+def test_fused_add_rmsnorm(ops, device, batch, hidden, dtype):
+    torch.manual_seed(batch * 3 + hidden)
+    x = torch.randn(batch, hidden).to(dtype)
+    r = torch.randn(batch, hidden).to(dtype)
+    w = torch.randn(hidden).to(dtype)
+    xd, rd = x.to(device), r.to(device)
+    ops.fused_add_rmsnorm(xd, rd, w.to(device), 1e-6)
+    y, r2 = O.fused_add_rms_norm(x, r, w, 1e-6)
+    _close(xd, y, dtype)
+    _close(rd, r2, dtype)
+
+
+def test_rmsnorm_golden_bitwise(ops, device):
+    """Golden vectors come from the reference's RMSNorm.forward_native (layers/layernorm.py:59-76);
+    the kernel reproduces them bit for bit on these cases."""
+    g = load_golden("rmsnorm")
+    eps = float(g["eps"])
+    for ci in range(int(g["n"])):
+        tag = f"c{ci}_"
+        dt = DTYPES[str(g[tag + "dtype"])]
+        x, r, w = (from_bits(g[tag + k], dt) for k in ("x", "r", "w"))
+        y = ops.rmsnorm(x.to(device), w.to(device), eps).cpu()
+        _close(y, from_bits(g[tag + "y"], dt), dt)
+        mism = (y.view(torch.int16 if dt != torch.float32 else torch.int32)
+                != from_bits(g[tag + "y"], dt).view(torch.int16 if dt != torch.float32 else torch.int32)).float().mean()
+        assert mism < 0.02, f"case {ci}: {mism:.3f} of elements differ by an ulp"
+        xd, rd = x.to(device), r.to(device)
+        ops.fused_add_rmsnorm(xd, rd, w.to(device), eps)
+        assert torch.equal(rd.cpu(), from_bits(g[tag + "r_fused"], dt))  # the sum is exactly rounded
+        _close(xd, from_bits(g[tag + "y_fused"], dt), dt)
+
+
+def test_rmsnorm_strided_rows(ops, device):
+    x = torch.randn(16, 3 * 256).to(torch.bfloat16)
+    w = torch.randn(256).to(torch.bfloat16)
+    xs = x.to(device)[:, 256:512]  # row stride 768
+    y = ops.rmsnorm(xs, w.to(device), 1e-5)
+    _close(y, O.rms_norm(x[:, 256:512], w, 1e-5), torch.bfloat16)
+
+
+# ----------------------------------------------------------------------------- SiLU*mul
+# sgl-kernel/tests/test_activation.py:8-15 (dim 128..16384, batch 1..16, seq 1..512, tol 1e-3)
+@pytest.mark.parametrize("dim", [128, 256, 1408, 14336])
+@pytest.mark.parametrize("rows", [1, 7, 512])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_silu_and_mul(ops, device, dim, rows, dtype):
+    torch.manual_seed(dim + rows)
+    x = torch.randn(rows, 2 * dim).to(dtype)
+    y = ops.silu_and_mul(x.to(device))
+    _close(y, O.silu_and_mul(x), dtype)
+    x3 = torch.randn(2, rows, 2 * dim).to(dtype)
+    _close(ops.silu_and_mul(x3.to(device)), O.silu_and_mul(x3), dtype)
+
+
+# ----------------------------------------------------------------------------- RoPE
+# sgl-kernel/tests/test_rotary_embedding.py:143-196: (head, rot, max_pos, base, neox, dtype, batch, seq, Hq, Hkv)
+ROPE_CASES = [
+    (64, 64, 32, 8000, True, torch.bfloat16, 32, 32, 1, 1),
+    (256, 128, 4096, 10000, True, torch.bfloat16, 2, 512, 4, 2),
+    (512, 128, 311, 10000, True, torch.bfloat16, 3, 39, 4, 2),
+    (128, 128, 2048, 10000, False, torch.bfloat16, 2, 512, 32, 8),
+    (128, 128, 2048, 10000, False, torch.bfloat16, 2, 512, 16, 4),
+    (512, 128, 311, 10000, False, torch.bfloat16, 3, 39, 4, 2),
+    (64, 20, 311, 10000, True, torch.float16, 3, 5, 4, 2),  # rot not a multiple of 16: scalar path
+]
+
+
+@pytest.mark.parametrize("head,rot,max_pos,base,neox,dtype,batch,seq,Hq,Hk", ROPE_CASES)
+def test_rope(ops, device, head, rot, max_pos, base, neox, dtype, batch, seq, Hq, Hk):
+    torch.manual_seed(head + rot + seq)
+    cache = O.cos_sin_cache_from_inv_freq(O.rope_inv_freq(rot, base), max_pos)
+    T = batch * seq
+    pos = torch.randint(0, max_pos, (T,))
+    q = torch.randn(T, Hq * head).to(dtype)
+    k = torch.randn(T, Hk * head).to(dtype)
+    qd, kd = q.to(device), k.to(device)
+    ops.apply_rope_with_cos_sin_cache_inplace(pos.to(device), qd, kd, head, cache.to(device), neox)
+    qo, ko = O.apply_rope(pos, q, k, head, cache, neox)
+    _close(qd, qo, dtype, rtol=1e-2, atol=1e-2)
+    _close(kd, ko, dtype, rtol=1e-2, atol=1e-2)
+
+
+def test_rope_golden(ops, device):
+    g = load_golden("rope")
+    for name in g["names"]:
+        name = str(name)
+        head, neox = int(g[name + "_head"]), bool(g[name + "_neox"])
+        cache = torch.from_numpy(g[name + "_cache"])
+        pos = torch.from_numpy(g[name + "_pos"])
+        q, k = torch.from_numpy(g[name + "_q"]).to(device), torch.from_numpy(g[name + "_k"]).to(device)
+        ops.apply_rope_with_cos_sin_cache_inplace(pos.to(device), q, k, head, cache.to(device), neox)
+        _close(q, torch.from_numpy(g[name + "_qo"]), torch.float32, rtol=1e-5, atol=1e-5)
+        _close(k, torch.from_numpy(g[name + "_ko"]), torch.float32, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("neox", [True, False])
+@pytest.mark.parametrize("Hq,Hk,head,rot", [(32, 8, 128, 128), (12, 12, 64, 64), (4, 2, 64, 32)])
+def test_rope_kv_store_fused(ops, device, neox, Hq, Hk, head, rot):
+    torch.manual_seed(Hq + head)
+    dtype = torch.bfloat16
+    T, N = 37, 101
+    cache = O.cos_sin_cache_from_inv_freq(O.rope_inv_freq(rot, 10000), 512)
+    pos = torch.randint(0, 512, (T,))
+    loc = (torch.randperm(N - 1)[:T] + 1).long()
+    q = torch.randn(T, Hq * head).to(dtype)
+    k = torch.randn(T, Hk * head).to(dtype)
+    v = torch.randn(T, Hk * head).to(dtype)
+    kbuf = torch.zeros(N, Hk, head, dtype=dtype, device=device)
+    vbuf = torch.zeros(N, Hk, head, dtype=dtype, device=device)
+    qd, kd = q.to(device), k.to(device)
+    ops.rope_and_store_kv(pos.to(device), qd, kd, v.to(device), head, cache.to(device), neox, kbuf, vbuf,
+                          loc.to(device))
+    qo, ko = O.apply_rope(pos, q, k, head, cache, neox)
+    _close(qd, qo, dtype, rtol=1e-2, atol=1e-2)
+    _close(kd, ko, dtype, rtol=1e-2, atol=1e-2)
+    assert torch.equal(kbuf.cpu()[loc].reshape(T, -1), kd.cpu())  # pool holds exactly the rotated keys
+    assert torch.equal(vbuf.cpu()[loc].reshape(T, -1), v)
+    untouched = torch.ones(N, dtype=torch.bool)
+    untouched[loc] = False
+    assert kbuf.cpu()[untouched].abs().sum() == 0 and vbuf.cpu()[untouched].abs().sum() == 0
+
+
+def test_store_kv_rows_and_gather(ops, device):
+    dtype = torch.bfloat16
+    src = torch.randn(50, 8, 128).to(dtype)
+    loc = (torch.randperm(199)[:50] + 1).long()
+    buf = torch.zeros(200, 8, 128, dtype=dtype, device=device)
+    ops.store_kv_rows(buf, loc.to(device), src.to(device))
+    ref = torch.zeros(200, 8, 128, dtype=dtype)
+    ref[loc] = src
+    assert torch.equal(buf.cpu(), ref)
+    # MLA latent rows: 576 elements, 1152 B rows
+    lat = torch.randn(9, 1, 576).to(dtype)
+    buf2 = torch.zeros(32, 1, 576, dtype=dtype, device=device)
+    ops.store_kv_rows(buf2, torch.arange(1, 10).to(device), lat.to(device))
+    assert torch.equal(buf2.cpu()[1:10], lat)
+    hidden = torch.randn(100, 768).to(dtype)
+    idx = torch.tensor([3, 99, 0, 50])
+    assert torch.equal(ops.gather_rows(hidden.to(device), idx.to(device)).cpu(), hidden[idx])
+
+
+# ----------------------------------------------------------------------------- kv indices / positions
+def test_kv_indices_golden_and_random(ops, device):
+    g = load_golden("kv_indices")
+    r2t = torch.from_numpy(g["req_to_token"]).to(device)
+    rpi = torch.from_numpy(g["req_pool_indices"]).to(device)
+    for tag, start in (("nostart", None), ("start", torch.from_numpy(g["start"]).to(device))):
+        lens = torch.from_numpy(g[tag + "_lens"]).to(device)
+        indptr = torch.full((5,), -1, dtype=torch.int32, device=device)
+        ind = torch.full((int(g[tag + "_indptr"][-1]),), -1, dtype=torch.int32, device=device)
+        ops.create_flashinfer_kv_indices(r2t, rpi, lens, indptr, start, ind)
+        assert np.array_equal(indptr.cpu().numpy(), g[tag + "_indptr"])
+        assert np.array_equal(ind.cpu().numpy(), g[tag + "_indices"])
+    # test/srt/test_create_kvindices.py style: random batch against the python loop
+    torch.manual_seed(0)
+    B, C = 257, 700
+    r2t = torch.randint(0, 10000, (300, C), dtype=torch.int32)
+    rpi = torch.randperm(300)[:B].long()
+    lens = torch.randint(1, C, (B,), dtype=torch.int32)
+    want_ptr, want = O.create_kv_indices(r2t, rpi, lens)
+    indptr = torch.empty(B + 1, dtype=torch.int32, device=device)
+    ind = torch.empty(int(want_ptr[-1]), dtype=torch.int32, device=device)
+    ops.create_flashinfer_kv_indices(r2t.to(device), rpi.to(device), lens.to(device), indptr, None, ind)
+    assert torch.equal(indptr.cpu(), want_ptr) and torch.equal(ind.cpu(), want)
+
+
+def test_compute_position(ops, device):
+    pre = torch.tensor([0, 5, 100, 7], dtype=torch.int32)
+    ext = torch.tensor([3, 1, 300, 64], dtype=torch.int32)
+    pos, start = ops.compute_position(pre.to(device), ext.to(device), int(ext.sum()))
+    wp, ws = O.compute_position(pre, ext)
+    assert torch.equal(pos.cpu(), wp) and torch.equal(start.cpu(), ws)
+
+
+# ----------------------------------------------------------------------------- decode attention
+def _paged(B, lens, Hkv, Dk, Dv, dtype, seed, extra=11):
+    g = torch.Generator().manual_seed(seed)
+    total = int(sum(lens))
+    N = total + extra
+    perm = torch.randperm(N - 1, generator=g)[:total] + 1
+    kv_indptr = torch.zeros(B + 1, dtype=torch.int32)
+    kv_indptr[1:] = torch.cumsum(torch.tensor(lens), 0)
+    k_buf = torch.randn(N, Hkv, Dk, generator=g).to(dtype)
+    v_buf = torch.randn(N, Hkv, Dv, generator=g).to(dtype)
+    return k_buf, v_buf, kv_indptr, perm.to(torch.int32)
+
+
+DECODE_CASES = [
+    # B, lens, Hq, Hkv, Dk, Dv, splits, cap
+    (3, [5, 33, 700], 32, 8, 128, 128, 8, 0.0),      # Llama-3-8B heads
+    (2, [1, 257], 8, 1, 128, 128, 16, 0.0),          # 70B/TP8: g = 8
+    (4, [64, 65, 127, 1], 12, 12, 64, 64, 4, 0.0),   # OPT-125m: MHA D=64
+    (2, [300, 17], 16, 2, 128, 128, 1, 0.0),         # g = 8, single split writes o directly
+    (2, [90, 31], 6, 2, 96, 96, 3, 30.0),            # g = 3, D = 96, logit cap
+    (2, [40, 9], 4, 4, 80, 80, 2, 0.0),              # D = 80
+    (3, [50, 3, 128], 32, 2, 64, 64, 5, 0.0),        # g = 16: two head tiles per kv head
+    (2, [33, 70], 16, 1, 576, 512, 4, 0.0),          # MLA latent (generic path)
+    (2, [12, 30], 3, 1, 13, 13, 2, 0.0),             # odd head dim (generic path)
+    (1, [2048], 32, 8, 128, 128, 16, 0.0),
+]
+
+
+@pytest.mark.parametrize("B,lens,Hq,Hkv,Dk,Dv,splits,cap", DECODE_CASES)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_decode_attention(ops, device, B, lens, Hq, Hkv, Dk, Dv, splits, cap, dtype):
+    k_buf, v_buf, indptr, indices = _paged(B, lens, Hkv, Dk, Dv, dtype, seed=Hq * 31 + Dk)
+    if Dk == 576:  # MLA: V is the first 512 columns of the latent K rows (memory_pool.py:430-437)
+        v_buf = k_buf[..., :Dv]
+    torch.manual_seed(B + Hq)
+    q = torch.randn(B, Hq, Dk).to(dtype)
+    sm_scale = 1.0 / (Dk ** 0.5)
+    o = torch.empty(B, Hq, Dv, dtype=dtype, device=device)
+    logits = torch.empty(B, Hq, splits, Dv + 1, dtype=torch.float32, device=device)
+    kd = k_buf.to(device)
+    vd = kd[..., :Dv] if Dk == 576 else v_buf.to(device)
+    ops.decode_attention_fwd(q.to(device), kd, vd, o, indptr.to(device), indices.to(device), logits, splits,
+                             sm_scale, cap)
+    want = O.decode_attention(q, k_buf, v_buf, indptr, indices, sm_scale, cap)
+    # reference bar: cos-sim > 0.99, atol 3e-2 (test_triton_attention_kernels.py:342-347); ours is tighter
+    _close(o, want, dtype, rtol=2e-2, atol=4e-3 if dtype == torch.float16 else 1.5e-2)
+
+
+def test_decode_attention_golden(ops, device):
+    """fp32 golden vectors from the reference Triton kernel, evaluated here in bf16."""
+    g = load_golden("decode_attention")
+    for name in g["names"]:
+        name = str(name)
+        q, k, v = (torch.from_numpy(g[f"{name}_{x}"]).to(torch.bfloat16) for x in ("q", "k", "v"))
+        indptr, indices = torch.from_numpy(g[name + "_indptr"]), torch.from_numpy(g[name + "_indices"])
+        splits, sm_scale, cap = g[name + "_meta"]
+        B, Hq, _ = q.shape
+        Dv = v.shape[2]
+        o = torch.empty(B, Hq, Dv, dtype=torch.bfloat16, device=device)
+        logits = torch.empty(B, Hq, int(splits), Dv + 1, dtype=torch.float32, device=device)
+        ops.decode_attention_fwd(q.to(device), k.to(device), v.to(device), o, indptr.to(device),
+                                 indices.to(device), logits, int(splits), float(sm_scale), float(cap))
+        _close(o, torch.from_numpy(g[name + "_o"]), torch.bfloat16, rtol=3e-2, atol=3e-2)
+
+
+def test_decode_attention_ragged_batch_and_padding(ops, device):
+    """B smaller than the scratch batch (CUDA-graph padding, decode_attention.py:638-640)."""
+    dtype = torch.bfloat16
+    B, Hq, Hkv, D, splits = 5, 8, 2, 128, 4
+    lens = [1, 2, 3, 1000, 64]
+    k_buf, v_buf, indptr, indices = _paged(B, lens, Hkv, D, D, dtype, seed=5)
+    q = torch.randn(B, Hq, D).to(dtype)
+    o = torch.empty(B, Hq, D, dtype=dtype, device=device)
+    logits = torch.empty(16, Hq, splits, D + 1, dtype=torch.float32, device=device)
+    indptr_pad = torch.cat([indptr, indptr[-1:].repeat(11)])
+    ops.decode_attention_fwd(q.to(device), k_buf.to(device), v_buf.to(device), o, indptr_pad.to(device),
+                             indices.to(device), logits, splits, 0.088, 0.0)
+    _close(o, O.decode_attention(q, k_buf, v_buf, indptr, indices, 0.088), dtype, rtol=2e-2, atol=1.5e-2)
+
+
+# ----------------------------------------------------------------------------- extend attention
+EXTEND_CASES = [
+    # prefix lens, extend lens, Hq, Hkv, Dk, Dv, cap
+    ([0, 13, 40], [20, 7, 170], 8, 2, 128, 128, 0.0),
+    ([0, 0], [5, 260], 12, 12, 64, 64, 0.0),
+    ([300], [129], 8, 1, 128, 128, 0.0),
+    ([9, 64, 0], [33, 64, 1], 4, 1, 128, 128, 25.0),
+    ([6, 0], [10, 3], 2, 1, 96, 64, 0.0),
+    ([17], [70], 4, 2, 80, 80, 0.0),
+    ([5, 0], [40, 9], 4, 2, 192, 128, 0.0),      # DeepSeek MHA prefill: qk 128+64, v 128
+    ([3], [20], 3, 3, 13, 13, 0.0),              # test_triton_attention_kernels.py D=13
+    ([11, 2], [6, 14], 4, 1, 576, 512, 0.0),     # MLA absorbed with prefix (generic path)
+]
+
+
+@pytest.mark.parametrize("pre,ext,Hq,Hkv,Dk,Dv,cap", EXTEND_CASES)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_extend_attention(ops, device, pre, ext, Hq, Hkv, Dk, Dv, cap, dtype):
+    B = len(pre)
+    k_buf, v_buf, kv_indptr, kv_indices = _paged(B, pre, Hkv, Dk, Dv, dtype, seed=Hq + Dk)
+    T = sum(ext)
+    qo_indptr = torch.zeros(B + 1, dtype=torch.int32)
+    qo_indptr[1:] = torch.cumsum(torch.tensor(ext), 0)
+    torch.manual_seed(T)
+    q = torch.randn(T, Hq, Dk).to(dtype)
+    k = torch.randn(T, Hkv, Dk).to(dtype)
+    v = torch.randn(T, Hkv, Dv).to(dtype)
+    o = torch.empty(T, Hq, Dv, dtype=dtype, device=device)
+    sm_scale = 1.0 / (Dk ** 0.5)
+    ops.extend_attention_fwd(q.to(device), k.to(device), v.to(device), o, k_buf.to(device), v_buf.to(device),
+                             qo_indptr.to(device), kv_indptr.to(device), kv_indices.to(device), None, None,
+                             max(ext), sm_scale, cap)
+    want = O.extend_attention(q, k, v, k_buf, v_buf, qo_indptr, kv_indptr, kv_indices, sm_scale, cap)
+    # reference bar: allclose(rtol=1e-2) bf16 vs redundant attention (test_triton_attention_kernels.py:168)
+    _close(o, want, dtype, rtol=2e-2, atol=4e-3 if dtype == torch.float16 else 1.5e-2)
+
+
+def test_extend_attention_golden(ops, device):
+    g = load_golden("extend_attention")
+    for name in g["names"]:
+        name = str(name)
+        q, k, v = (torch.from_numpy(g[f"{name}_{x}"]).to(torch.bfloat16) for x in ("q", "k", "v"))
+        kb, vb = (torch.from_numpy(g[f"{name}_{x}"]).to(torch.bfloat16) for x in ("kbuf", "vbuf"))
+        sm_scale, cap = g[name + "_meta"]
+        qo = torch.from_numpy(g[name + "_qo_indptr"])
+        o = torch.empty(q.shape[0], q.shape[1], v.shape[2], dtype=torch.bfloat16, device=device)
+        ext = (qo[1:] - qo[:-1]).max().item()
+        ops.extend_attention_fwd(q.to(device), k.to(device), v.to(device), o, kb.to(device), vb.to(device),
+                                 qo.to(device), torch.from_numpy(g[name + "_kv_indptr"]).to(device),
+                                 torch.from_numpy(g[name + "_kv_indices"]).to(device), None, None, ext,
+                                 float(sm_scale), float(cap))
+        _close(o, torch.from_numpy(g[name + "_o"]), torch.bfloat16, rtol=3e-2, atol=3e-2)
+
+
+def test_extend_equals_decode_on_last_token(ops, device):
+    """Size-independent property at a BASELINE-sized shape (Llama-3-8B heads, ctx 4k): the last query
+    row of an extend over [prefix | new tokens] equals decode attention over the same KV rows."""
+    dtype = torch.bfloat16
+    Hq, Hkv, D = 32, 8, 128
+    pre, ext = 3000, 1096
+    torch.manual_seed(0)
+    N = pre + ext + 5
+    k_all = torch.randn(N, Hkv, D, device=device).to(dtype)
+    v_all = torch.randn(N, Hkv, D, device=device).to(dtype)
+    perm = (torch.randperm(N - 1, device=device) + 1)[:pre + ext].to(torch.int32)
+    q = torch.randn(ext, Hq, D, device=device).to(dtype)
+    k_ext = k_all[perm[pre:].long()].contiguous()
+    v_ext = v_all[perm[pre:].long()].contiguous()
+    o = torch.empty(ext, Hq, D, dtype=dtype, device=device)
+    qo = torch.tensor([0, ext], dtype=torch.int32, device=device)
+    kvp = torch.tensor([0, pre], dtype=torch.int32, device=device)
+    ops.extend_attention_fwd(q, k_ext, v_ext, o, k_all, v_all, qo, kvp, perm[:pre].contiguous(), None, None, ext)
+    od = torch.empty(1, Hq, D, dtype=dtype, device=device)
+    logits = torch.empty(1, Hq, 16, D + 1, dtype=torch.float32, device=device)
+    full = torch.tensor([0, pre + ext], dtype=torch.int32, device=device)
+    ops.decode_attention_fwd(q[-1:].contiguous(), k_all, v_all, od, full, perm, logits, 16, 1.0 / D ** 0.5)
+    _close(o[-1:], od, dtype, rtol=2e-2, atol=8e-3)
+    # and an independent torch check of a middle row
+    row = 517
+    kk = torch.cat([k_all[perm[:pre].long()], k_ext[:row + 1]]).float()
+    vv = torch.cat([v_all[perm[:pre].long()], v_ext[:row + 1]]).float()
+    for h in (0, 13, 31):
+        s = (kk[:, h // 4] @ q[row, h].float()) / D ** 0.5
+        ref = torch.softmax(s, 0) @ vv[:, h // 4]
+        _close(o[row, h], ref, dtype, rtol=2e-2, atol=8e-3)
+
+
+# ----------------------------------------------------------------------------- sampling
+@pytest.mark.parametrize("B,V", [(1, 50272), (32, 128256), (7, 1000), (3, 129280)])
+def test_greedy_argmax(ops, device, B, V):
+    torch.manual_seed(V)
+    x = torch.randn(B, V)
+    x[0, V - 1] = 100.0
+    if B > 1:
+        x[1, 5] = x[1, 77] = 50.0  # tie -> lowest index
+    got = ops.greedy_argmax(x.to(device))
+    assert got.dtype == torch.int32 and got.cpu().tolist() == O.greedy_argmax(x).tolist()
+    got64 = ops.greedy_argmax(x.to(device).to(torch.bfloat16), torch.int64)
+    assert got64.cpu().tolist() == O.greedy_argmax(x.to(torch.bfloat16)).tolist()
+
+
+@pytest.mark.parametrize("B,H,V", [(1, 768, 50272), (5, 4096, 32000), (70, 2048, 1000)])
+def test_lm_head_argmax(ops, device, B, H, V):
+    torch.manual_seed(B + H)
+    h = torch.randn(B, H).to(torch.bfloat16)
+    w = (torch.randn(V, H) * 0.05).to(torch.bfloat16)
+    logits, ids = ops.lm_head_argmax(h.to(device), w.to(device))
+    want = O.logits_last_token(h.float(), None, w.float())
+    _close(logits, want, torch.float32, rtol=1e-3, atol=2e-3)
+    top2 = want.topk(2, dim=-1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 1e-2  # rows whose winner is not a near-tie
+    assert torch.equal(ids.cpu()[safe].long(), want.argmax(-1)[safe])
+
+
+# ----------------------------------------------------------------------------- MoE
+def _same_topk(w, ids, rw, rids, rtol, atol):
+    for t in range(ids.shape[0]):
+        a = sorted(zip(ids[t].tolist(), w[t].tolist()))
+        b = sorted(zip(rids[t].tolist(), rw[t].tolist()))
+        assert [x[0] for x in a] == [x[0] for x in b], (t, a, b)
+        np.testing.assert_allclose([x[1] for x in a], [x[1] for x in b], rtol=rtol, atol=atol)
+
+
+def test_moe_routing_golden(ops, device):
+    g = load_golden("moe_topk")
+    for name in ("native_e8", "native_e64"):
+        k, ren = g[name + "_meta"]
+        w, ids = ops.topk_softmax(torch.from_numpy(g[name + "_gate"]).to(device), int(k), bool(ren))
+        _same_topk(w.cpu().numpy(), ids.cpu().numpy(), g[name + "_w"], g[name + "_ids"], 1e-5, 1e-6)
+    for name, dt, scoring in (("grouped_f32", torch.float32, "softmax"), ("grouped_bf16", torch.bfloat16, "softmax"),
+                              ("grouped_sigmoid", torch.float32, "sigmoid")):
+        k, ren, ng, tg = g[name + "_meta"]
+        w, ids = ops.grouped_topk(from_bits(g[name + "_gate"], dt).to(device), int(k), bool(ren), int(ng), int(tg),
+                                  None, scoring)
+        tol = (1e-5, 1e-6) if dt == torch.float32 else (8e-3, 1e-3)
+        _same_topk(w.cpu().numpy(), ids.cpu().numpy(), g[name + "_w"], g[name + "_ids"], *tol)
+    for name, dt in (("biased_f32", torch.float32), ("biased_bf16", torch.bfloat16)):
+        k, ren, ng, tg = g[name + "_meta"]
+        w, ids = ops.grouped_topk(from_bits(g[name + "_gate"], dt).to(device), int(k), bool(ren), int(ng), int(tg),
+                                  torch.from_numpy(g[name + "_bias"]).to(device))
+        tol = (1e-5, 1e-6) if dt == torch.float32 else (8e-3, 1e-3)
+        _same_topk(w.cpu().numpy(), ids.cpu().numpy(), g[name + "_w"], g[name + "_ids"], *tol)
+
+
+@pytest.mark.parametrize("T,E,k", [(1, 64, 6), (33, 64, 6), (222, 8, 2), (4096, 256, 8)])
+def test_topk_softmax_random(ops, device, T, E, k):
+    torch.manual_seed(T + E)
+    gate = torch.randn(T, E)
+    w, ids = ops.topk_softmax(gate.to(device), k, True)
+    rw, rids = O.fused_topk_native(gate, k, True)
+    _same_topk(w.cpu().numpy(), ids.cpu().numpy(), rw.numpy(), rids.numpy(), 1e-5, 1e-6)
+
+
+@pytest.mark.parametrize("numel_tokens,topk,E,block", [(1, 6, 64, 64), (33, 6, 64, 64), (4096, 8, 256, 64), (5, 2, 8, 64)])
+def test_moe_align_block_size(ops, device, numel_tokens, topk, E, block):
+    """Same comparison as sgl-kernel/tests/test_moe_align.py:151-222 (expert_ids, num_tokens_post_pad),
+    plus the permutation property of sorted_token_ids."""
+    torch.manual_seed(numel_tokens + E)
+    ids = torch.stack([torch.randperm(E)[:topk] for _ in range(numel_tokens)]).to(torch.int32)
+    numel = ids.numel()
+    max_sorted = numel + E * (block - 1)
+    sorted_ids = torch.empty(max_sorted, dtype=torch.int32, device=device)
+    expert_ids = torch.full(((max_sorted + block - 1) // block,), -1, dtype=torch.int32, device=device)
+    npp = torch.empty(1, dtype=torch.int32, device=device)
+    cumsum = torch.empty(E + 1, dtype=torch.int32, device=device)
+    ops.moe_align_block_size(ids.to(device), E, block, sorted_ids, expert_ids, npp, None, cumsum)
+    rs, re_, rn = O.moe_align_block_size(ids, block, E)
+    n = int(npp.item())
+    assert n == int(rn)
+    assert torch.equal(expert_ids.cpu()[: n // block], re_[: n // block])
+    got = sorted_ids.cpu()
+    flat = ids.flatten()
+    for blk in range(n // block):  # same multiset of tokens in every block as the stable oracle
+        assert sorted(got[blk * block:(blk + 1) * block].tolist()) == sorted(rs[blk * block:(blk + 1) * block].tolist())
+    assert (got[n:] == numel).all()
+
+
+@pytest.mark.parametrize("T,N,K,E,topk", [(1, 128, 128, 8, 2), (33, 1024, 511 + 1, 8, 2), (64, 1408, 2048, 64, 6),
+                                           (222, 128, 1024, 64, 6)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_fused_moe_pipeline(ops, device, T, N, K, E, topk, dtype):
+    """align -> grouped GEMM1 -> silu_and_mul -> grouped GEMM2 (x routed weight) -> moe_sum against the
+    reference's naive MoE (test/srt/test_fused_moe.py:46-63, tolerances :31-44)."""
+    torch.manual_seed(T + N)
+    a = (torch.randn(T, K) / 10).to(dtype)
+    w1 = (torch.randn(E, 2 * N, K) / 10).to(dtype)
+    w2 = (torch.randn(E, K, N) / 10).to(dtype)
+    gate = torch.randn(T, E)
+    tw, tid = ops.topk_softmax(gate.to(device), topk, True)
+    block = 64
+    numel = T * topk
+    max_sorted = numel + E * (block - 1)
+    sorted_ids = torch.empty(max_sorted, dtype=torch.int32, device=device)
+    expert_ids = torch.empty((max_sorted + block - 1) // block, dtype=torch.int32, device=device)
+    npp = torch.empty(1, dtype=torch.int32, device=device)
+    cumsum = torch.empty(E + 1, dtype=torch.int32, device=device)
+    ops.moe_align_block_size(tid, E, block, sorted_ids, expert_ids, npp, None, cumsum)
+    c1 = torch.empty(numel, 2 * N, dtype=dtype, device=device)
+    ops.moe_grouped_gemm(a.to(device), w1.to(device), c1, None, sorted_ids, expert_ids, npp, numel, topk, False)
+    c2 = ops.silu_and_mul(c1)
+    c3 = torch.empty(numel, K, dtype=dtype, device=device)
+    ops.moe_grouped_gemm(c2, w2.to(device), c3, tw.flatten().contiguous(), sorted_ids, expert_ids, npp, numel, 1, True)
+    out = ops.moe_sum(c3.view(T, topk, K))
+    want = O.fused_moe(a, w1, w2, tw.cpu(), tid.cpu())
+    _close(out, want, dtype, rtol=1e-1, atol=1e-2)

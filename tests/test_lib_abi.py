@@ -1,0 +1,71 @@
+"""CPU checks of the drop-in boundary: the C-ABI library loads and exports every symbol
+include/semipd.h declares; argument errors come back as RuntimeError; no CPU fallback exists."""
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+from semi_pd_amd import _lib
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "semipd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(semipd_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_is_built_and_loads():
+    assert os.path.exists(_lib.LIB_PATH), "run __graft_entry__.build() first"
+    lib = _lib.load()
+    assert lib.semipd_version() >= 100
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    declared = _declared_symbols()
+    assert len(declared) >= 30
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/semipd.h but not exported"
+    assert sorted(_lib.EXPORTED_SYMBOLS) == declared, "ctypes table and header disagree"
+
+
+def test_argument_errors_are_reported_not_swallowed():
+    lib = _lib.load()
+    rc = lib.semipd_rmsnorm(None, None, None, 4, 0, 0, 0, 1e-6, _lib.BF16, None)  # hidden == 0
+    assert rc == -1
+    assert "rmsnorm" in _lib.last_error()
+    rc = lib.semipd_decode_attention(None, None, None, None, None, None, None, 1, 6, 4, 64, 64, 0, 0, 0, 0, 1,
+                                     1.0, 0.0, _lib.BF16, None)  # Hq % Hkv != 0
+    assert rc == -3
+    with pytest.raises(RuntimeError):
+        _lib.check(rc, "decode_attention")
+
+
+def test_no_cpu_fallback():
+    from semi_pd_amd import ops
+    x = torch.randn(2, 64)
+    with pytest.raises(RuntimeError):
+        ops.rmsnorm(x, torch.ones(64))
+    with pytest.raises(RuntimeError):
+        _lib.dtype_code(torch.float64)
+
+
+def test_cu_mask_fill_is_balanced():
+    import ctypes as C
+    lib = _lib.load()
+    words = 8
+    lo = (C.c_uint32 * words)()
+    hi = (C.c_uint32 * words)()
+    n_lo = lib.semipd_cu_mask_fill(256, 50, 0, C.addressof(lo), words)
+    n_hi = lib.semipd_cu_mask_fill(256, 50, 1, C.addressof(hi), words)
+    assert n_lo == 128 and n_hi == 128
+    bits_lo = [i for i in range(256) if lo[i >> 5] >> (i & 31) & 1]
+    bits_hi = [i for i in range(256) if hi[i >> 5] >> (i & 31) & 1]
+    assert not set(bits_lo) & set(bits_hi) and len(set(bits_lo) | set(bits_hi)) == 256
+    for xcd in range(8):  # logical CU i lands on XCD i % 8
+        assert sum(1 for i in bits_lo if i % 8 == xcd) == 16
+        assert sum(1 for i in bits_hi if i % 8 == xcd) == 16
+    n80 = lib.semipd_cu_mask_fill(256, 80, 0, C.addressof(lo), words)
+    assert n80 == 208 and n80 % 8 == 0
