@@ -1,0 +1,53 @@
+"""HF state_dict -> the product's parameter names (TEST INFRASTRUCTURE ONLY).
+Plays the role of the reference's load_weights stacked-params mapping (models/llama.py:370-420:
+q/k/v -> qkv_proj, gate/up -> gate_up_proj)."""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+
+
+def llama_from_hf(sd: Dict[str, torch.Tensor], num_layers: int, tie: bool = False) -> Dict[str, torch.Tensor]:
+    out = {"model.embed_tokens.weight": sd["model.embed_tokens.weight"], "model.norm.weight": sd["model.norm.weight"]}
+    if not tie:
+        out["lm_head.weight"] = sd["lm_head.weight"]
+    for i in range(num_layers):
+        p = f"model.layers.{i}."
+        out[p + "self_attn.qkv_proj.weight"] = torch.cat(
+            [sd[p + f"self_attn.{x}_proj.weight"] for x in ("q", "k", "v")], 0)
+        out[p + "self_attn.o_proj.weight"] = sd[p + "self_attn.o_proj.weight"]
+        out[p + "mlp.gate_up_proj.weight"] = torch.cat([sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"]], 0)
+        out[p + "mlp.down_proj.weight"] = sd[p + "mlp.down_proj.weight"]
+        out[p + "input_layernorm.weight"] = sd[p + "input_layernorm.weight"]
+        out[p + "post_attention_layernorm.weight"] = sd[p + "post_attention_layernorm.weight"]
+    return out
+
+
+def opt_from_hf(sd: Dict[str, torch.Tensor], num_layers: int) -> Dict[str, torch.Tensor]:
+    d = "model.decoder."
+    out = {"embed_tokens.weight": sd[d + "embed_tokens.weight"],
+           "embed_positions.weight": sd[d + "embed_positions.weight"],
+           "final_layer_norm.weight": sd[d + "final_layer_norm.weight"],
+           "final_layer_norm.bias": sd[d + "final_layer_norm.bias"]}
+    for i in range(num_layers):
+        s, p = d + f"layers.{i}.", f"layers.{i}."
+        for wb in ("weight", "bias"):
+            out[p + f"qkv_proj.{wb}"] = torch.cat([sd[s + f"self_attn.{x}_proj.{wb}"] for x in ("q", "k", "v")], 0)
+            out[p + f"out_proj.{wb}"] = sd[s + f"self_attn.out_proj.{wb}"]
+            out[p + f"self_attn_layer_norm.{wb}"] = sd[s + f"self_attn_layer_norm.{wb}"]
+            out[p + f"fc1.{wb}"] = sd[s + f"fc1.{wb}"]
+            out[p + f"fc2.{wb}"] = sd[s + f"fc2.{wb}"]
+            out[p + f"final_layer_norm.{wb}"] = sd[s + f"final_layer_norm.{wb}"]
+    return out
+
+
+def pad_vocab(sd: Dict[str, torch.Tensor], keys, multiple: int = 64) -> Dict[str, torch.Tensor]:
+    """The product pads vocab-parallel tables to a multiple of 64 rows (zero rows)."""
+    out = dict(sd)
+    for k in keys:
+        w = out[k]
+        pad = (-w.shape[0]) % multiple
+        if pad:
+            out[k] = torch.cat([w, torch.zeros(pad, w.shape[1], dtype=w.dtype)], 0)
+    return out

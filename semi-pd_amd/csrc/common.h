@@ -27,6 +27,7 @@ void set_error(const char* fmt, ...);
     hipError_t _e = (expr);                                                     \
     if (_e != hipSuccess) {                                                     \
       ::semipd::set_error("%s failed: %s", #expr, hipGetErrorString(_e));       \
+      (void)hipGetLastError(); /* do not leave a sticky error for the caller's next launch */ \
       return (int)_e;                                                           \
     }                                                                           \
   } while (0)

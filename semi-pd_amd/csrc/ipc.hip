@@ -81,6 +81,7 @@ int semipd_ipc_open(const uint8_t handle[64], int device, void** base) {
   if (device >= 0 && device != prev) (void)hipSetDevice(prev);
   if (e != hipSuccess) {
     set_error("hipIpcOpenMemHandle failed: %s", hipGetErrorString(e));
+    (void)hipGetLastError();
     return (int)e;
   }
   g_by_handle[key] = Mapping{p, device, 1};

@@ -1,0 +1,110 @@
+"""Tensor-parallel group state and collectives for the hot path.
+
+One process per GPU; device collectives go through torch.distributed's "nccl" backend (= RCCL over
+xGMI on ROCm), scheduler broadcasts through a gloo CPU group — the same split as the reference
+(distributed/parallel_state.py:376-489 GroupCoordinator.all_reduce / all_gather,
+distributed/communication_op.py:11-21, managers/scheduler.py:645-659 broadcast_pyobj).
+Prefill ranks and decode ranks form two independent worlds (separate ports, scheduler.py:249-259).
+
+On CPU tensors the same code runs over gloo, which is how tests cover world_size 2 without GPUs.
+"""
+from __future__ import annotations
+
+import pickle
+from typing import Any, List, Optional
+
+import torch
+import torch.distributed as dist
+
+_TP_RANK = 0
+_TP_SIZE = 1
+_DEVICE_GROUP: Optional[dist.ProcessGroup] = None
+_CPU_GROUP: Optional[dist.ProcessGroup] = None
+
+
+def init_distributed_environment(world_size: int, rank: int, distributed_init_method: str,
+                                 backend: str = "nccl", device: Optional[torch.device] = None,
+                                 timeout_s: int = 600) -> None:
+    """model_runner.py:285-344 init_torch_distributed: one device group + one gloo group."""
+    global _TP_RANK, _TP_SIZE, _DEVICE_GROUP, _CPU_GROUP
+    _TP_RANK, _TP_SIZE = rank, world_size
+    if world_size == 1:
+        _DEVICE_GROUP = _CPU_GROUP = None
+        return
+    import datetime
+    if not dist.is_initialized():
+        kwargs = {}
+        if backend == "nccl" and device is not None:
+            kwargs["device_id"] = device
+        dist.init_process_group(backend=backend, init_method=distributed_init_method, world_size=world_size,
+                                rank=rank, timeout=datetime.timedelta(seconds=timeout_s), **kwargs)
+    _DEVICE_GROUP = dist.group.WORLD
+    _CPU_GROUP = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=timeout_s)) \
+        if backend != "gloo" else dist.group.WORLD
+
+
+def destroy_distributed_environment() -> None:
+    global _TP_RANK, _TP_SIZE, _DEVICE_GROUP, _CPU_GROUP
+    if dist.is_initialized():
+        dist.destroy_process_group()
+    _TP_RANK, _TP_SIZE, _DEVICE_GROUP, _CPU_GROUP = 0, 1, None, None
+
+
+def get_tensor_model_parallel_rank() -> int:
+    return _TP_RANK
+
+
+def get_tensor_model_parallel_world_size() -> int:
+    return _TP_SIZE
+
+
+def get_tp_cpu_group():
+    return _CPU_GROUP
+
+
+def tensor_model_parallel_all_reduce(input_: torch.Tensor) -> torch.Tensor:
+    """SUM all-reduce of [T, hidden] after o_proj / down_proj / experts (layers/linear.py:1266)."""
+    if _TP_SIZE == 1:
+        return input_
+    dist.all_reduce(input_, group=_DEVICE_GROUP)
+    return input_
+
+
+def tensor_model_parallel_all_gather(input_: torch.Tensor, dim: int = -1) -> torch.Tensor:
+    """All-gather along `dim` (logits [B, V/tp] -> [B, V], layers/logits_processor.py:426-427;
+    parallel_state.py:438-489)."""
+    if _TP_SIZE == 1:
+        return input_
+    if dim < 0:
+        dim += input_.dim()
+    input_ = input_.contiguous()
+    out = torch.empty((_TP_SIZE,) + tuple(input_.shape), dtype=input_.dtype, device=input_.device)
+    dist.all_gather_into_tensor(out, input_, group=_DEVICE_GROUP) if input_.is_cuda else \
+        dist.all_gather(list(out.unbind(0)), input_, group=_DEVICE_GROUP)
+    out = out.movedim(0, dim)
+    shape = list(input_.shape)
+    shape[dim] = shape[dim] * _TP_SIZE
+    return out.reshape(shape)
+
+
+def broadcast_pyobj(data: List[Any], rank: int, group, src: int = 0) -> List[Any]:
+    """Pickle broadcast on the CPU group (utils.broadcast_pyobj, scheduler.py:645-659)."""
+    if group is None or _TP_SIZE == 1:
+        return data
+    if rank == src:
+        payload = pickle.dumps(data)
+        size = torch.tensor([len(payload)], dtype=torch.long)
+        dist.broadcast(size, src=src, group=group)
+        buf = torch.frombuffer(bytearray(payload), dtype=torch.uint8)
+        dist.broadcast(buf, src=src, group=group)
+        return data
+    size = torch.tensor([0], dtype=torch.long)
+    dist.broadcast(size, src=src, group=group)
+    buf = torch.empty(int(size.item()), dtype=torch.uint8)
+    dist.broadcast(buf, src=src, group=group)
+    return pickle.loads(bytes(buf.numpy()))
+
+
+def barrier_cpu() -> None:
+    if _CPU_GROUP is not None and _TP_SIZE > 1:
+        dist.barrier(group=_CPU_GROUP)

@@ -1,0 +1,328 @@
+"""Norm / RoPE / activation / linear / logits / sampler layers of the hot path, each a thin
+torch.nn.Module over the HIP operators (semi_pd_amd.ops).  Class names follow the reference:
+  RMSNorm                     layers/layernorm.py:37-76
+  RotaryEmbedding / get_rope  layers/rotary_embedding.py:61-169, 633-795, 993-1170
+  SiluAndMul                  layers/activation.py:41-51
+  Column/Row/QKV/MergedColumn parallel linear, VocabParallelEmbedding, ParallelLMHead
+                              layers/linear.py:296-460, 725-1100, 1103-1280; vocab_parallel_embedding.py:174-500
+  LogitsProcessor             layers/logits_processor.py:220-445
+  Sampler                     layers/sampler.py:29-171 (greedy branch)
+Dense GEMMs stay on hipBLASLt through F.linear (SURVEY §2.2 "TP linear").
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Any, Dict, Optional, Tuple, Union
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from semi_pd_amd import ops
+from semi_pd_amd.distributed import (get_tensor_model_parallel_rank, get_tensor_model_parallel_world_size,
+                                     tensor_model_parallel_all_gather, tensor_model_parallel_all_reduce)
+
+
+# --------------------------------------------------------------------------- norm / activation
+class RMSNorm(nn.Module):
+    def __init__(self, hidden_size: int, eps: float = 1e-6):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(hidden_size), requires_grad=False)
+        self.variance_epsilon = eps
+
+    def forward(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None):
+        if residual is not None:
+            ops.fused_add_rmsnorm(x, residual, self.weight.data, self.variance_epsilon)
+            return x, residual
+        return ops.rmsnorm(x, self.weight.data, self.variance_epsilon)
+
+
+class SiluAndMul(nn.Module):
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return ops.silu_and_mul(x)
+
+
+# --------------------------------------------------------------------------- rotary embedding
+class RotaryEmbedding(nn.Module):
+    """cos/sin cache [max_pos, rot] in fp32 (rotary_embedding.py:78-82 keeps fp32 on the kernel path),
+    applied in place by the HIP kernel; optionally fused with the KV-pool store."""
+
+    def __init__(self, head_size: int, rotary_dim: int, max_position_embeddings: int, base: float,
+                 is_neox_style: bool, dtype: torch.dtype):
+        super().__init__()
+        self.head_size, self.rotary_dim = head_size, rotary_dim
+        self.max_position_embeddings, self.base = max_position_embeddings, base
+        self.is_neox_style, self.dtype = is_neox_style, dtype
+        self.register_buffer("cos_sin_cache", self._compute_cos_sin_cache(), persistent=False)
+
+    def _compute_inv_freq(self, base: float) -> torch.Tensor:
+        return 1.0 / (base ** (torch.arange(0, self.rotary_dim, 2, dtype=torch.float) / self.rotary_dim))
+
+    def _compute_cos_sin_cache(self) -> torch.Tensor:
+        inv_freq = self._compute_inv_freq(self.base)
+        t = torch.arange(self.max_position_embeddings, dtype=torch.float)
+        freqs = torch.einsum("i,j -> ij", t, inv_freq)
+        return torch.cat((freqs.cos(), freqs.sin()), dim=-1)
+
+    def forward(self, positions: torch.Tensor, query: torch.Tensor, key: torch.Tensor):
+        ops.apply_rope_with_cos_sin_cache_inplace(positions, query, key, self.head_size, self.cos_sin_cache,
+                                                  self.is_neox_style)
+        return query, key
+
+    def forward_and_store(self, positions, query, key, value, k_buffer, v_buffer, loc):
+        ops.rope_and_store_kv(positions, query, key, value, self.head_size, self.cos_sin_cache,
+                              self.is_neox_style, k_buffer, v_buffer, loc)
+        return query, key
+
+
+class Llama3RotaryEmbedding(RotaryEmbedding):
+    def __init__(self, head_size, rotary_dim, max_position_embeddings, base, is_neox_style, dtype,
+                 scaling_factor: float, low_freq_factor: float, high_freq_factor: float, orig_max_position: int):
+        self.scaling_factor, self.low_freq_factor = scaling_factor, low_freq_factor
+        self.high_freq_factor, self.orig_max_position = high_freq_factor, orig_max_position
+        super().__init__(head_size, rotary_dim, max_position_embeddings, base, is_neox_style, dtype)
+
+    def _compute_inv_freq(self, base: float) -> torch.Tensor:
+        inv_freqs = super()._compute_inv_freq(base)
+        low_freq_wavelen = self.orig_max_position / self.low_freq_factor
+        high_freq_wavelen = self.orig_max_position / self.high_freq_factor
+        wave_len = 2 * math.pi / inv_freqs
+        if self.low_freq_factor != self.high_freq_factor:
+            smooth = (self.orig_max_position / wave_len - self.low_freq_factor) / (
+                self.high_freq_factor - self.low_freq_factor)
+        else:
+            smooth = 0
+        return torch.where(
+            wave_len < high_freq_wavelen, inv_freqs,
+            torch.where(wave_len > low_freq_wavelen, inv_freqs / self.scaling_factor,
+                        (1 - smooth) * inv_freqs / self.scaling_factor + smooth * inv_freqs))
+
+
+def yarn_get_mscale(scale: float = 1, mscale: float = 1) -> float:
+    if scale <= 1:
+        return 1.0
+    return 0.1 * mscale * math.log(scale) + 1.0
+
+
+class DeepseekScalingRotaryEmbedding(RotaryEmbedding):
+    """YaRN cache with mscale baked in (rotary_embedding.py:633-708)."""
+
+    def __init__(self, head_size, rotary_dim, max_position_embeddings, base, is_neox_style, scaling_factor,
+                 dtype, *, extrapolation_factor: float = 1, attn_factor: float = 1, beta_fast: int = 32,
+                 beta_slow: int = 1, mscale: float = 1, mscale_all_dim: float = 0):
+        self.scaling_factor, self.extrapolation_factor = scaling_factor, extrapolation_factor
+        self.attn_factor, self.beta_fast, self.beta_slow = attn_factor, beta_fast, beta_slow
+        self.mscale = float(yarn_get_mscale(scaling_factor, float(mscale))
+                            / yarn_get_mscale(scaling_factor, float(mscale_all_dim)) * attn_factor)
+        super().__init__(head_size, rotary_dim, max_position_embeddings, base, is_neox_style, dtype)
+
+    def _compute_cos_sin_cache(self) -> torch.Tensor:
+        dim, base, mp = self.rotary_dim, self.base, self.max_position_embeddings
+
+        def corr_dim(num_rot):
+            return (dim * math.log(mp / (num_rot * 2 * math.pi))) / (2 * math.log(base))
+
+        low = max(math.floor(corr_dim(self.beta_fast)), 0)
+        high = min(math.ceil(corr_dim(self.beta_slow)), dim - 1)
+        if low == high:
+            high += 0.001
+        ramp = torch.clamp((torch.arange(dim // 2, dtype=torch.float) - low) / (high - low), 0, 1)
+        pos_freqs = base ** (torch.arange(0, dim, 2, dtype=torch.float) / dim)
+        inv_extra, inv_inter = 1.0 / pos_freqs, 1.0 / (self.scaling_factor * pos_freqs)
+        mask = (1 - ramp) * self.extrapolation_factor
+        inv_freq = inv_inter * (1 - mask) + inv_extra * mask
+        t = torch.arange(mp * self.scaling_factor, dtype=torch.float32)
+        freqs = torch.einsum("i,j -> ij", t, inv_freq)
+        return torch.cat((freqs.cos() * self.mscale, freqs.sin() * self.mscale), dim=-1)
+
+
+_ROPE_DICT: Dict[Tuple, RotaryEmbedding] = {}
+
+
+def get_rope(head_size: int, rotary_dim: int, max_position: int, base: float, is_neox_style: bool = True,
+             rope_scaling: Optional[Dict[str, Any]] = None, dtype: Optional[torch.dtype] = None) -> RotaryEmbedding:
+    """Subset of get_rope (rotary_embedding.py:993-1170): default, llama3, deepseek_yarn."""
+    dtype = dtype or torch.get_default_dtype()
+    key = (head_size, rotary_dim, max_position, base, is_neox_style,
+           tuple(sorted((k, str(v)) for k, v in rope_scaling.items())) if rope_scaling else None, dtype)
+    if key in _ROPE_DICT:
+        return _ROPE_DICT[key]
+    if rope_scaling is None:
+        rope = RotaryEmbedding(head_size, rotary_dim, max_position, base, is_neox_style, dtype)
+    else:
+        kind = rope_scaling.get("rope_type", rope_scaling.get("type"))
+        if kind == "llama3":
+            rope = Llama3RotaryEmbedding(head_size, rotary_dim, max_position, base, is_neox_style, dtype,
+                                         rope_scaling["factor"], rope_scaling["low_freq_factor"],
+                                         rope_scaling["high_freq_factor"],
+                                         rope_scaling["original_max_position_embeddings"])
+        elif kind == "deepseek_yarn":
+            extra = {k: v for k, v in rope_scaling.items()
+                     if k in ("extrapolation_factor", "attn_factor", "beta_fast", "beta_slow", "mscale",
+                              "mscale_all_dim")}
+            rope = DeepseekScalingRotaryEmbedding(head_size, rotary_dim,
+                                                  rope_scaling["original_max_position_embeddings"], base,
+                                                  is_neox_style, rope_scaling["factor"], dtype, **extra)
+        elif kind in (None, "default"):
+            rope = RotaryEmbedding(head_size, rotary_dim, max_position, base, is_neox_style, dtype)
+        else:
+            raise ValueError(f"Unknown RoPE scaling type {kind}")
+    _ROPE_DICT[key] = rope
+    return rope
+
+
+# --------------------------------------------------------------------------- tensor-parallel linear
+def _shard(n: int, tp: int) -> int:
+    assert n % tp == 0, f"{n} is not divisible by tp={tp}"
+    return n // tp
+
+
+class ColumnParallelLinear(nn.Module):
+    """Y = X W^T with W [out/tp, in] (layers/linear.py:296-460)."""
+
+    def __init__(self, input_size: int, output_size: int, bias: bool = False, params_dtype=None):
+        super().__init__()
+        tp = get_tensor_model_parallel_world_size()
+        self.output_size_per_partition = _shard(output_size, tp)
+        self.weight = nn.Parameter(torch.empty(self.output_size_per_partition, input_size, dtype=params_dtype),
+                                   requires_grad=False)
+        self.bias = nn.Parameter(torch.zeros(self.output_size_per_partition, dtype=params_dtype),
+                                 requires_grad=False) if bias else None
+
+    def forward(self, x):
+        return F.linear(x, self.weight, self.bias)
+
+
+class MergedColumnParallelLinear(ColumnParallelLinear):
+    """gate_up_proj: the per-rank shard is [gate/tp ; up/tp] (linear.py:463-722)."""
+
+    def __init__(self, input_size: int, output_sizes, bias: bool = False, params_dtype=None):
+        self.output_sizes = list(output_sizes)
+        super().__init__(input_size, sum(output_sizes), bias, params_dtype)
+
+
+class QKVParallelLinear(ColumnParallelLinear):
+    """Fused q/k/v projection; kv heads are replicated when Hkv < tp (linear.py:725-1100,
+    models/llama.py:115-131)."""
+
+    def __init__(self, hidden_size: int, head_size: int, total_num_heads: int, total_num_kv_heads: int,
+                 bias: bool = False, params_dtype=None):
+        tp = get_tensor_model_parallel_world_size()
+        self.head_size = head_size
+        self.num_heads = _shard(total_num_heads, tp)
+        if total_num_kv_heads >= tp:
+            self.num_kv_heads = _shard(total_num_kv_heads, tp)
+            self.num_kv_head_replicas = 1
+        else:
+            self.num_kv_heads = 1
+            self.num_kv_head_replicas = _shard(tp, total_num_kv_heads)
+        out = (self.num_heads + 2 * self.num_kv_heads) * tp * head_size
+        super().__init__(hidden_size, out, bias, params_dtype)
+
+
+class RowParallelLinear(nn.Module):
+    """Y = all_reduce(X_shard W_shard^T) with W [out, in/tp] (layers/linear.py:1103-1280, reduce :1266)."""
+
+    def __init__(self, input_size: int, output_size: int, bias: bool = False, reduce_results: bool = True,
+                 params_dtype=None):
+        super().__init__()
+        tp = get_tensor_model_parallel_world_size()
+        self.input_size_per_partition = _shard(input_size, tp)
+        self.reduce_results = reduce_results
+        self.weight = nn.Parameter(torch.empty(output_size, self.input_size_per_partition, dtype=params_dtype),
+                                   requires_grad=False)
+        self.bias = nn.Parameter(torch.zeros(output_size, dtype=params_dtype), requires_grad=False) if bias else None
+
+    def forward(self, x):
+        # bias is added on rank 0 only so that the sum over ranks adds it once (linear.py:1258-1262)
+        bias = self.bias if (self.bias is not None and get_tensor_model_parallel_rank() == 0) else None
+        out = F.linear(x, self.weight, bias)
+        if self.reduce_results and get_tensor_model_parallel_world_size() > 1:
+            out = tensor_model_parallel_all_reduce(out)
+        return out
+
+
+class VocabParallelEmbedding(nn.Module):
+    """Embedding rows sharded over ranks; out-of-shard ids contribute zeros, then all-reduce
+    (layers/vocab_parallel_embedding.py:174-500, reduce :487)."""
+
+    def __init__(self, num_embeddings: int, embedding_dim: int, params_dtype=None, pad_to: int = 64):
+        super().__init__()
+        tp = get_tensor_model_parallel_world_size()
+        rank = get_tensor_model_parallel_rank()
+        self.org_vocab_size = num_embeddings
+        padded = -(-num_embeddings // (pad_to * tp)) * (pad_to * tp)
+        self.num_embeddings_padded = padded
+        self.num_embeddings_per_partition = padded // tp
+        self.vocab_start_index = rank * self.num_embeddings_per_partition
+        self.vocab_end_index = self.vocab_start_index + self.num_embeddings_per_partition
+        self.tp_size = tp
+        self.weight = nn.Parameter(torch.empty(self.num_embeddings_per_partition, embedding_dim,
+                                               dtype=params_dtype), requires_grad=False)
+
+    def forward(self, input_ids: torch.Tensor):
+        if self.tp_size == 1:
+            return F.embedding(input_ids, self.weight)
+        mask = (input_ids >= self.vocab_start_index) & (input_ids < self.vocab_end_index)
+        local = torch.where(mask, input_ids - self.vocab_start_index, torch.zeros_like(input_ids))
+        out = F.embedding(local, self.weight)
+        out = out * mask.unsqueeze(-1).to(out.dtype)
+        return tensor_model_parallel_all_reduce(out)
+
+
+class ParallelLMHead(VocabParallelEmbedding):
+    pass
+
+
+# --------------------------------------------------------------------------- logits / sampler
+@dataclass
+class LogitsProcessorOutput:
+    next_token_logits: Optional[torch.Tensor]
+    next_token_ids: Optional[torch.Tensor] = None
+    hidden_states: Optional[torch.Tensor] = None
+
+
+class LogitsProcessor(nn.Module):
+    """Last-token gather + lm_head + all-gather + fp32 (logits_processor.py:220-445).  With TP=1 and a
+    greedy batch the argmax is produced by the same HIP call (ops.lm_head_argmax); with TP>1 the
+    local shard of the logits is computed, gathered and then reduced with ops.greedy_argmax."""
+
+    def __init__(self, vocab_size: int, final_logit_softcapping: Optional[float] = None):
+        super().__init__()
+        self.vocab_size = vocab_size
+        self.final_logit_softcapping = final_logit_softcapping
+
+    def forward(self, input_ids, hidden_states: torch.Tensor, lm_head: VocabParallelEmbedding,
+                forward_batch) -> LogitsProcessorOutput:
+        if forward_batch.forward_mode.is_extend():
+            last_index = torch.cumsum(forward_batch.extend_seq_lens, dim=0, dtype=torch.int64) - 1
+            pruned = ops.gather_rows(hidden_states, last_index)
+        else:
+            pruned = hidden_states
+        if get_tensor_model_parallel_world_size() == 1 and self.final_logit_softcapping is None:
+            # rows >= vocab_size are padding (vocab_parallel_embedding.py pads to a multiple of 64)
+            logits, ids = ops.lm_head_argmax(pruned.contiguous(), lm_head.weight[: self.vocab_size],
+                                             return_logits=True)
+            return LogitsProcessorOutput(logits, next_token_ids=ids)
+        logits = torch.matmul(pruned, lm_head.weight.T)
+        logits = tensor_model_parallel_all_gather(logits)
+        logits = logits[:, : self.vocab_size].float()
+        if self.final_logit_softcapping:
+            logits = self.final_logit_softcapping * torch.tanh(logits / self.final_logit_softcapping)
+        return LogitsProcessorOutput(logits)
+
+
+class Sampler(nn.Module):
+    """Greedy sampling (sampler.py:72-74): argmax over fp32 logits -> int32 ids.  Non-greedy
+    sampling is a §8(f) "next" row."""
+
+    def forward(self, logits_output: LogitsProcessorOutput, sampling_info=None) -> torch.Tensor:
+        if sampling_info is not None and not getattr(sampling_info, "is_all_greedy", True):
+            raise NotImplementedError("only greedy sampling (temperature 0) is implemented in this round")
+        if logits_output.next_token_ids is not None:
+            return logits_output.next_token_ids
+        logits = logits_output.next_token_logits
+        if not logits.is_contiguous():
+            logits = logits.contiguous()
+        return ops.greedy_argmax(logits)

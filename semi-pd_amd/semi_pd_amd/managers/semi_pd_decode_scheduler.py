@@ -1,0 +1,183 @@
+"""SemiPDDecodeScheduler: the decode instance owns every allocation.  It answers the prefill
+instance's "which of these rids may I prefill?" by running the real PrefillAdder, allocating the
+request slot and the KV slots and writing them into the shared req_to_token table; later it merges
+the prefilled batch into its running decode batch.  Reference:
+managers/semi_pd_decode_scheduler.py:44-377."""
+from __future__ import annotations
+
+import logging
+import os
+import time
+from typing import List, Optional
+
+import torch
+
+from semi_pd_amd.distributed import barrier_cpu
+from semi_pd_amd.managers.io_struct import (BatchProcessPrefillResultReq, GetNextPrefillBatchInput,
+                                            GetNextPrefillBatchOutput, TokenizedGenerateReqInput)
+from semi_pd_amd.managers.schedule_batch import AddReqResult, Req, ScheduleBatch
+from semi_pd_amd.managers.scheduler import SchedulerBase
+from semi_pd_amd.semi_pd.utils import InstanceRole
+
+logger = logging.getLogger(__name__)
+
+TEST_RETRACT = os.environ.get("SGLANG_TEST_RETRACT", "0").lower() in ("1", "true")
+
+
+class SemiPDDecodeScheduler(SchedulerBase):
+    def __init__(self, server_args, model_runner, tp_rank, recv_socket, send_to_detokenizer, bridge_socket,
+                 send_to_p_instance):
+        super().__init__(server_args, model_runner, tp_rank, recv_socket, send_to_detokenizer, InstanceRole.DECODE)
+        # requests handed to the prefill instance whose result has not come back yet
+        self.scheduled_prefill_batches: List[ScheduleBatch] = []
+        self.bridge_socket = bridge_socket            # PUSH -> P (replies to GetNextPrefillBatchInput)
+        self.send_to_p_instance = send_to_p_instance  # PUSH -> P's input socket (retracted requests)
+
+    # ---------------------------------------------------------------------------- dispatch
+    def dispatch(self, recv_req):
+        if isinstance(recv_req, GetNextPrefillBatchInput):
+            self.get_next_prefill_batch(recv_req)
+        elif isinstance(recv_req, BatchProcessPrefillResultReq):
+            self.process_prefill_result(recv_req)
+        else:
+            super().dispatch(recv_req)
+
+    def add_to_waiting_queue(self, req: Req):
+        if req.is_retracted:
+            return  # D re-queued it itself when it retracted it (semi_pd_decode_scheduler.py:137)
+        self.waiting_queue.append(req)
+
+    # ---------------------------------------------------------------------------- decode side
+    def on_retract(self, retracted: List[Req]):
+        """semi_pd_decode_scheduler.py:117-139: a retracted request goes back to the front of D's
+        queue and is re-sent to P with its generated tokens appended to the prompt."""
+        for req in retracted:
+            message = TokenizedGenerateReqInput(
+                rid=req.rid, input_text=None, input_ids=req.origin_input_ids + req.output_ids,
+                sampling_params=req.sampling_params, is_retracted=True)
+            self.waiting_queue.insert(0, req)
+            if self.tp_rank == 0:
+                self.send_to_p_instance.send_pyobj(message)
+
+    def forced_retractions(self, batch: ScheduleBatch) -> int:
+        """SGLANG_TEST_RETRACT (semi_pd_decode_scheduler.py:42-43, 103-105): retract although memory is
+        available, to exercise the D -> P re-send path."""
+        return 2 if (TEST_RETRACT and batch.batch_size() > 10) else 0
+
+    def get_next_batch_to_run(self) -> Optional[ScheduleBatch]:
+        """semi_pd_decode_scheduler.py:141-153: D only ever runs decode batches."""
+        if not self.running_batch.is_empty():
+            self.running_batch = self.update_running_batch(self.running_batch)
+            return self.running_batch if not self.running_batch.is_empty() else None
+        return None
+
+    # ---------------------------------------------------------------------------- prefill admission
+    def get_new_batch_prefill(self, rids: List[str]) -> Optional[ScheduleBatch]:
+        """semi_pd_decode_scheduler.py:155-308 (radix / LoRA / hierarchical-cache branches do not exist
+        in Semi-PD mode)."""
+        if (self.running_batch.batch_is_full or len(self.waiting_queue) == 0) and self.chunked_req is None:
+            return None
+        pending = sum(len(b.reqs) for b in self.scheduled_prefill_batches)
+        running_bs = len(self.running_batch.reqs) + pending
+        if running_bs >= self.max_running_requests:
+            self.running_batch.batch_is_full = True
+            return None
+        adder = self.build_prefill_adder()
+        for b in self.scheduled_prefill_batches:  # tokens promised to in-flight prefills are spoken for
+            for r in b.reqs:
+                adder.rem_total_tokens -= min(r.sampling_params.max_new_tokens, 4096) * self.new_token_ratio
+        if self.chunked_req is not None:
+            self.chunked_req.init_next_round_input()
+            self.chunked_req = adder.add_chunked_req(self.chunked_req)
+        rid_set = set(rids)
+        for req in self.waiting_queue:
+            if req.rid not in rid_set:
+                continue
+            if running_bs + len(adder.can_run_list) >= self.max_running_requests:
+                self.running_batch.batch_is_full = True
+                break
+            req.init_next_round_input()
+            res = adder.add_one_req(req)
+            if res != AddReqResult.CONTINUE:
+                if res == AddReqResult.NO_TOKEN:
+                    self.running_batch.batch_is_full = True
+                break
+        can_run_list = adder.can_run_list
+        if len(can_run_list) == 0:
+            return None
+        chosen = set(id(x) for x in can_run_list)
+        self.waiting_queue = [x for x in self.waiting_queue if id(x) not in chosen]
+        if adder.new_chunked_req is not None:
+            assert self.chunked_req is None
+            self.chunked_req = adder.new_chunked_req
+        if self.chunked_req:
+            self.chunked_req.is_chunked += 1
+        new_batch = ScheduleBatch.init_new(can_run_list, self.req_to_token_pool, self.token_to_kv_pool_allocator,
+                                           self.tree_cache, self.device)
+        new_batch.prepare_for_extend()
+        self.scheduled_prefill_batches.append(new_batch)
+        new_batch.decoding_reqs = None
+        return new_batch
+
+    def get_next_prefill_batch(self, recv_req: GetNextPrefillBatchInput):
+        """semi_pd_decode_scheduler.py:310-337."""
+        if self.chunked_req:
+            if self.scheduled_prefill_batches:
+                # the previous chunk is still running in P: answer "nothing yet"
+                self._reply_empty()
+                return
+            self.tree_cache.cache_unfinished_req(self.chunked_req)
+            self.req_to_token_pool.free(self.chunked_req.req_pool_idx)
+        batch = self.get_new_batch_prefill(recv_req.rids)
+        if batch is None:
+            self._reply_empty()
+            return
+        # the shared table must be complete in HBM before P reads it (the reference relies on timing)
+        if torch.device(self.device).type == "cuda":
+            torch.cuda.current_stream().synchronize()
+        if self.tp_rank == 0:
+            self.bridge_socket.send_pyobj(GetNextPrefillBatchOutput(
+                rids=[r.rid for r in batch.reqs],
+                chunked_rid=(self.chunked_req.rid if self.chunked_req else None),
+                req_pool_indices=[r.req_pool_idx for r in batch.reqs],
+                prefix_lens=[len(r.prefix_indices) for r in batch.reqs],
+                extend_input_lens=[r.extend_input_len for r in batch.reqs]))
+
+    def _reply_empty(self):
+        if self.tp_rank == 0:
+            self.bridge_socket.send_pyobj(GetNextPrefillBatchOutput(
+                rids=[], chunked_rid=(self.chunked_req.rid if self.chunked_req else None),
+                req_pool_indices=[], prefix_lens=[], extend_input_lens=[]))
+
+    def process_prefill_result(self, recv_req: BatchProcessPrefillResultReq):
+        """semi_pd_decode_scheduler.py:339-377."""
+        batch = self.scheduled_prefill_batches.pop(0)
+        assert len(batch.reqs) == len(recv_req.next_token_ids)
+        if self.tp_size > 1:
+            barrier_cpu()
+        batch.output_ids = torch.tensor(recv_req.next_token_ids, dtype=torch.int64, device=self.device)
+        self.process_batch_result_prefill(batch, recv_req.next_token_ids)
+        batch.filter_batch(chunked_req_to_exclude=self.chunked_req)
+        if not batch.is_empty():
+            if self.running_batch.is_empty():
+                self.running_batch = batch
+            else:
+                self.running_batch.merge_batch(batch)
+
+    # ---------------------------------------------------------------------------- loop
+    def step(self) -> bool:
+        recv = self.recv_requests()
+        self.process_input_requests(recv)
+        batch = self.get_next_batch_to_run()
+        if batch is None:
+            return bool(recv)
+        _, next_token_ids = self.run_batch(batch)
+        batch.output_ids = next_token_ids
+        self.process_batch_result_decode(batch, next_token_ids.tolist())
+        return True
+
+    def event_loop_normal(self):
+        while not self._shutdown:
+            if not self.step():
+                self.check_watchdog()
+                self.idle_sleep()

@@ -1,0 +1,120 @@
+"""SemiPDPrefillScheduler: the prefill instance never allocates.  It proposes request ids to the
+decode instance, receives (rids, req_pool_indices, prefix_lens, extend_input_lens), reads its
+out_cache_loc from the *shared* req_to_token table, runs the prefill forward and ships the sampled
+token ids back.  Reference: managers/semi_pd_prefill_scheduler.py:40-176."""
+from __future__ import annotations
+
+import logging
+from typing import List, Optional
+
+import torch
+
+from semi_pd_amd.distributed import broadcast_pyobj
+from semi_pd_amd.managers.io_struct import (BatchProcessPrefillResultReq, GetNextPrefillBatchInput,
+                                            GetNextPrefillBatchOutput)
+from semi_pd_amd.managers.schedule_batch import ScheduleBatch
+from semi_pd_amd.managers.scheduler import SchedulerBase
+from semi_pd_amd.semi_pd.utils import InstanceRole
+
+logger = logging.getLogger(__name__)
+
+
+class SemiPDPrefillScheduler(SchedulerBase):
+    def __init__(self, server_args, model_runner, tp_rank, recv_socket, send_to_d_instance, bridge_socket,
+                 send_stats_to=None):
+        # send_stats_to: only StatsReq answers go there; tokens are streamed by the decode instance
+        super().__init__(server_args, model_runner, tp_rank, recv_socket, send_stats_to, InstanceRole.PREFILL)
+        self.enable_overlap = False
+        self.chunked_rid: Optional[str] = None
+        self.send_to_d_instance = send_to_d_instance  # PUSH -> D's input socket (rank 0 only)
+        self.bridge_socket = bridge_socket            # PULL <- D's replies (rank 0 only)
+
+    def add_to_waiting_queue(self, req):
+        if req.is_retracted:
+            # retracted requests jump the queue, like the decode side does (semi_pd_decode_scheduler.py:137)
+            self.waiting_queue.insert(0, req)
+        else:
+            self.waiting_queue.append(req)
+
+    def to_extend_batch(self, resp: GetNextPrefillBatchOutput) -> ScheduleBatch:
+        """semi_pd_prefill_scheduler.py:74-118."""
+        can_run_list = [r for r in self.waiting_queue if r.rid in resp.rids]
+        can_run_list.sort(key=lambda r: resp.rids.index(r.rid))
+        if self.chunked_rid != resp.chunked_rid:
+            # the last chunked request has finished prefilling: drop it from the waiting queue
+            new_waiting_queue = []
+            for r in self.waiting_queue:
+                if r.rid == self.chunked_rid:
+                    continue
+                if r.rid in resp.rids and r.rid != resp.chunked_rid:
+                    continue
+                new_waiting_queue.append(r)
+            self.waiting_queue = new_waiting_queue
+            self.chunked_rid = resp.chunked_rid
+        else:
+            self.waiting_queue = [r for r in self.waiting_queue
+                                  if r.rid not in resp.rids or r.rid == resp.chunked_rid]
+        table = self.req_to_token_pool.req_to_token
+        for i, r in enumerate(can_run_list):
+            assert r.rid == resp.rids[i]
+            r.extend_input_len = resp.extend_input_lens[i]
+            pre_len = resp.prefix_lens[i]
+            r.prefix_indices = table[resp.req_pool_indices[i], :pre_len].to(torch.int64)
+            r.fill_ids = r.origin_input_ids[: pre_len + r.extend_input_len]
+        batch = ScheduleBatch.init_new(can_run_list, self.req_to_token_pool, self.token_to_kv_pool_allocator,
+                                       self.tree_cache, self.device)
+        batch.prepare_for_extend(pre_allocated_req_pool_indices=resp.req_pool_indices)
+        return batch
+
+    def get_next_batch_to_run(self) -> Optional[ScheduleBatch]:
+        """semi_pd_prefill_scheduler.py:120-157."""
+        resp = None
+        if self.waiting_queue and self.tp_rank == 0:
+            n_prefill_tokens = 0
+            candidates: List[str] = []
+            for r in self.waiting_queue:
+                if n_prefill_tokens > self.chunked_prefill_size:
+                    break
+                n_prefill_tokens += len(r.origin_input_ids)
+                candidates.append(r.rid)
+            self.send_to_d_instance.send_pyobj(GetNextPrefillBatchInput(rids=candidates))
+            # the reference blocks forever here (semi_pd_prefill_scheduler.py:134); we bound the wait
+            resp = self.bridge_socket.recv_pyobj(timeout=self.server_args.watchdog_timeout)
+            assert isinstance(resp, GetNextPrefillBatchOutput), f"unexpected bridge message {type(resp)}"
+        if self.tp_size > 1:
+            resp = broadcast_pyobj([resp], self.tp_rank, self.tp_cpu_group, src=0)[0]
+        if resp and len(resp.rids) > 0:
+            return self.to_extend_batch(resp)
+        if resp is not None:
+            self._rejected = True  # the decode instance has no room right now: back off a little
+        return None
+
+    def process_batch_result_prefill(self, batch: ScheduleBatch, next_token_ids: torch.Tensor):
+        """semi_pd_prefill_scheduler.py:159-173.  `.tolist()` synchronises the stream, so every KV row
+        this batch wrote is in HBM before the decode instance hears about it (SURVEY §3.2 hazard)."""
+        ids = next_token_ids.tolist()
+        self.stats["prefill_batches"] += 1
+        self.stats["prefill_tokens"] += batch.extend_num_tokens
+        if self.tp_rank == 0:
+            self.send_to_d_instance.send_pyobj(BatchProcessPrefillResultReq(next_token_ids=ids))
+
+    def step(self) -> bool:
+        self.process_input_requests(self.recv_requests())
+        batch = self.get_next_batch_to_run()
+        if batch is None:
+            return False
+        _, next_token_ids = self.run_batch(batch)
+        self.process_batch_result_prefill(batch, next_token_ids)
+        import time
+        self.last_progress = time.monotonic()
+        return True
+
+    def event_loop_normal(self):
+        import time
+        while not self._shutdown:
+            self._rejected = False
+            if not self.step():
+                if self._rejected:
+                    time.sleep(0.0005)
+                else:
+                    self.idle_sleep()

@@ -1,0 +1,179 @@
+"""Request/token/KV pools of the Semi-PD hot path.
+
+Same roles and method names as the reference pools (mem_cache/memory_pool.py:46-96 ReqToTokenPool,
+:124-184 TokenToKVPoolAllocator, :187-346 MHATokenToKVPool, :379-452 MLATokenToKVPool), with the
+layout chosen for one 288 GB HBM3E device:
+
+ * all layers' K and V rows live in ONE slab  kv[L, 2, N+1, Hkv, D]  (MLA: kv[L, N+1, 1, 576]);
+   per-layer buffers are views, so a single hipIpcMemHandle covers the whole cache and the
+   prefill process maps it once (bypass_create_buffers=True leaves the views empty until
+   share_params_from_ipc fills them, model_runner.py:563-624);
+ * page size is 1 (token-granular), slot 0 is the dummy slot for padded tokens
+   (memory_pool.py:172-176);
+ * the free list stays on the host: the decode process is the only allocator
+   (semi_pd_decode_scheduler.py:166-337) and never needs it on the device.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple, Union
+
+import torch
+
+from semi_pd_amd import ops
+
+
+class ReqToTokenPool:
+    """Maps a request slot to the KV-pool slots of its tokens: int32 [size, max_context_len]."""
+
+    def __init__(self, size: int, max_context_len: int, device: str, bypass_create_buffers: bool = False):
+        self.size = size
+        self.max_context_len = max_context_len
+        self.device = device
+        self.req_to_token: Optional[torch.Tensor] = None
+        if not bypass_create_buffers:
+            self.req_to_token = torch.zeros((size, max_context_len), dtype=torch.int32, device=device)
+        self.free_slots = list(range(size))
+
+    def write(self, indices, values):
+        self.req_to_token[indices] = values
+
+    def available_size(self):
+        return len(self.free_slots)
+
+    def alloc(self, need_size: int) -> Optional[List[int]]:
+        if need_size > len(self.free_slots):
+            return None
+        select_index = self.free_slots[:need_size]
+        self.free_slots = self.free_slots[need_size:]
+        return select_index
+
+    def free(self, free_index: Union[int, List[int]]):
+        if isinstance(free_index, int):
+            self.free_slots.append(free_index)
+        else:
+            self.free_slots.extend(free_index)
+
+    def clear(self):
+        self.free_slots = list(range(self.size))
+
+
+class TokenToKVPoolAllocator:
+    """Free list of KV slots 1..size (int64, FIFO like the reference's tensor slicing)."""
+
+    def __init__(self, size: int, dtype: torch.dtype, device: str, kvcache):
+        self.size = size
+        self.dtype = dtype
+        self.device = device
+        self.page_size = 1
+        self._kvcache = kvcache
+        self.is_not_in_free_group = True
+        self.free_group: List[torch.Tensor] = []
+        self.clear()
+
+    def available_size(self):
+        return len(self.free_slots)
+
+    def get_kvcache(self):
+        return self._kvcache
+
+    def alloc(self, need_size: int) -> Optional[torch.Tensor]:
+        if need_size > len(self.free_slots):
+            return None
+        select_index = self.free_slots[:need_size]
+        self.free_slots = self.free_slots[need_size:]
+        return select_index
+
+    def free(self, free_index: torch.Tensor):
+        if free_index.numel() == 0:
+            return
+        free_index = free_index.to("cpu", torch.int64)
+        if self.is_not_in_free_group:
+            self.free_slots = torch.concat((self.free_slots, free_index))
+        else:
+            self.free_group.append(free_index)
+
+    def free_group_begin(self):
+        self.is_not_in_free_group = False
+        self.free_group = []
+
+    def free_group_end(self):
+        self.is_not_in_free_group = True
+        if self.free_group:
+            self.free(torch.concat(self.free_group))
+
+    def clear(self):
+        # slot 0 is reserved for dummy writes of padded tokens
+        self.free_slots = torch.arange(1, self.size + 1, dtype=torch.int64)
+        self.is_not_in_free_group = True
+        self.free_group = []
+
+
+class MHATokenToKVPool:
+    def __init__(self, size: int, page_size: int, dtype: torch.dtype, head_num: int, head_dim: int,
+                 layer_num: int, device: str, bypass_create_buffers: bool = False):
+        assert page_size == 1, "Semi-PD runs with token-granular pages (schedule_batch.py:937)"
+        self.size, self.page_size, self.dtype = size, page_size, dtype
+        self.head_num, self.head_dim, self.layer_num, self.device = head_num, head_dim, layer_num, device
+        self.k_buffer: List[torch.Tensor] = []
+        self.v_buffer: List[torch.Tensor] = []
+        self.slab: Optional[torch.Tensor] = None
+        if not bypass_create_buffers:
+            self._create_buffers()
+
+    def _create_buffers(self):
+        # [L, 2, N+page, Hkv, D]: one allocation, one IPC handle
+        self.slab = torch.zeros((self.layer_num, 2, self.size + self.page_size, self.head_num, self.head_dim),
+                                dtype=self.dtype, device=self.device)
+        self.k_buffer = [self.slab[i, 0] for i in range(self.layer_num)]
+        self.v_buffer = [self.slab[i, 1] for i in range(self.layer_num)]
+
+    def get_kv_size_bytes(self):
+        n = (self.size + self.page_size) * self.head_num * self.head_dim * self.dtype.itemsize * self.layer_num
+        return n, n
+
+    def get_key_buffer(self, layer_id: int):
+        return self.k_buffer[layer_id]
+
+    def get_value_buffer(self, layer_id: int):
+        return self.v_buffer[layer_id]
+
+    def get_kv_buffer(self, layer_id: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        return self.k_buffer[layer_id], self.v_buffer[layer_id]
+
+    def set_kv_buffer(self, layer, loc: torch.Tensor, cache_k: torch.Tensor, cache_v: torch.Tensor):
+        layer_id = layer.layer_id
+        if cache_k.dtype != self.dtype:
+            cache_k, cache_v = cache_k.to(self.dtype), cache_v.to(self.dtype)
+        ops.store_kv_rows(self.k_buffer[layer_id], loc, cache_k.view(-1, self.head_num, self.head_dim))
+        ops.store_kv_rows(self.v_buffer[layer_id], loc, cache_v.view(-1, self.head_num, self.head_dim))
+
+
+class MLATokenToKVPool:
+    """Latent KV rows [N+page, 1, kv_lora_rank + qk_rope_head_dim] per layer; the value buffer is
+    the first kv_lora_rank columns of the same rows (memory_pool.py:379-452)."""
+
+    def __init__(self, size: int, page_size: int, dtype: torch.dtype, kv_lora_rank: int,
+                 qk_rope_head_dim: int, layer_num: int, device: str, bypass_create_buffers: bool = False):
+        assert page_size == 1
+        self.size, self.page_size, self.dtype = size, page_size, dtype
+        self.kv_lora_rank, self.qk_rope_head_dim = kv_lora_rank, qk_rope_head_dim
+        self.layer_num, self.device = layer_num, device
+        self.kv_buffer: List[torch.Tensor] = []
+        self.slab: Optional[torch.Tensor] = None
+        if not bypass_create_buffers:
+            self.slab = torch.zeros((layer_num, size + page_size, 1, kv_lora_rank + qk_rope_head_dim),
+                                    dtype=dtype, device=device)
+            self.kv_buffer = [self.slab[i] for i in range(layer_num)]
+
+    def get_key_buffer(self, layer_id: int):
+        return self.kv_buffer[layer_id]
+
+    def get_value_buffer(self, layer_id: int):
+        return self.kv_buffer[layer_id][..., : self.kv_lora_rank]
+
+    def get_kv_buffer(self, layer_id: int):
+        return self.get_key_buffer(layer_id), self.get_value_buffer(layer_id)
+
+    def set_kv_buffer(self, layer, loc: torch.Tensor, cache_k: torch.Tensor, cache_v: torch.Tensor = None):
+        ops.store_kv_rows(self.kv_buffer[layer.layer_id], loc,
+                          cache_k.view(-1, 1, self.kv_lora_rank + self.qk_rope_head_dim))

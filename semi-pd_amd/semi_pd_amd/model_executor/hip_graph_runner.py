@@ -1,0 +1,90 @@
+"""Decode hipGraph runner (reference: model_executor/cuda_graph_runner.py:109-150 batch-size list,
+:455-531 replay with padding).  One graph per batch-size bucket; the graph contains the metadata
+kernels (kv_indptr / kv_indices), every layer and the lm_head + argmax, so a decode step is one
+hipGraphLaunch.  Padded slots use seq_len = 1 and write their KV to the dummy slot 0."""
+from __future__ import annotations
+
+import bisect
+from typing import Dict, List, Tuple
+
+import torch
+
+from semi_pd_amd.model_executor.forward_batch_info import ForwardBatch, ForwardMode
+
+
+def get_batch_sizes_to_capture(max_bs: int) -> List[int]:
+    """cuda_graph_runner.py:109-150: [1, 2, 4] + multiples of 8 up to 160 (HIP: up to 256)."""
+    bs = [1, 2, 4] + [8 * i for i in range(1, 33)]
+    return [b for b in bs if b <= max_bs]
+
+
+class HipGraphRunner:
+    def __init__(self, model_runner):
+        self.mr = model_runner
+        dev = model_runner.device
+        self.capture_bs = get_batch_sizes_to_capture(min(model_runner.cuda_graph_max_bs,
+                                                         model_runner.max_running_requests))
+        self.max_bs = max(self.capture_bs)
+        self.seq_len_fill_value = model_runner.attn_backend.get_cuda_graph_seq_len_fill_value()
+        with torch.device(dev):
+            self.input_ids = torch.zeros(self.max_bs, dtype=torch.int64)
+            self.req_pool_indices = torch.zeros(self.max_bs, dtype=torch.int64)
+            self.seq_lens = torch.full((self.max_bs,), self.seq_len_fill_value, dtype=torch.int64)
+            self.out_cache_loc = torch.zeros(self.max_bs, dtype=torch.int64)
+            self.positions = torch.zeros(self.max_bs, dtype=torch.int64)
+        model_runner.attn_backend.init_cuda_graph_state(self.max_bs)
+        self.graphs: Dict[int, torch.cuda.CUDAGraph] = {}
+        self.outputs: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
+        self.pool = None
+        self.stream = torch.cuda.Stream(device=dev)
+        for bs in reversed(self.capture_bs):
+            self._capture_one(bs)
+
+    def _capture_one(self, bs: int):
+        mr = self.mr
+        fb = ForwardBatch(
+            forward_mode=ForwardMode.DECODE, batch_size=bs, input_ids=self.input_ids[:bs],
+            req_pool_indices=self.req_pool_indices[:bs], seq_lens=self.seq_lens[:bs],
+            out_cache_loc=self.out_cache_loc[:bs], seq_lens_sum=bs, positions=self.positions[:bs],
+            req_to_token_pool=mr.req_to_token_pool, token_to_kv_pool=mr.token_to_kv_pool,
+            attn_backend=mr.attn_backend)
+
+        def run_once():
+            torch.clamp(self.seq_lens[:bs] - 1, min=0, out=self.positions[:bs])
+            mr.attn_backend.init_forward_metadata_capture_cuda_graph(
+                bs, bs, self.req_pool_indices[:bs], self.seq_lens[:bs], None, ForwardMode.DECODE, None)
+            out = mr.model.forward(fb.input_ids, fb.positions, fb)
+            ids = out.next_token_ids if out.next_token_ids is not None else mr.sampler(out)
+            return out.next_token_logits, ids
+
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            for _ in range(2):  # warm up allocator / hipBLASLt heuristics outside the capture
+                run_once()
+        torch.cuda.current_stream().wait_stream(self.stream)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=self.pool, stream=self.stream):
+            out = run_once()
+        self.pool = self.pool or g.pool()
+        self.graphs[bs] = g
+        self.outputs[bs] = out
+
+    def can_run(self, forward_batch: ForwardBatch) -> bool:
+        return forward_batch.forward_mode.is_decode() and forward_batch.batch_size <= self.max_bs
+
+    def replay(self, forward_batch: ForwardBatch):
+        from semi_pd_amd.layers.basic import LogitsProcessorOutput
+        raw_bs = forward_batch.batch_size
+        bs = self.capture_bs[bisect.bisect_left(self.capture_bs, raw_bs)]
+        if bs != raw_bs:
+            self.seq_lens.fill_(self.seq_len_fill_value)
+            self.out_cache_loc.zero_()
+            self.req_pool_indices.zero_()
+        self.input_ids[:raw_bs].copy_(forward_batch.input_ids)
+        self.req_pool_indices[:raw_bs].copy_(forward_batch.req_pool_indices)
+        self.seq_lens[:raw_bs].copy_(forward_batch.seq_lens)
+        self.out_cache_loc[:raw_bs].copy_(forward_batch.out_cache_loc)
+        self.graphs[bs].replay()
+        logits, ids = self.outputs[bs]
+        return LogitsProcessorOutput(logits[:raw_bs] if logits is not None else None, next_token_ids=ids[:raw_bs])

@@ -1,0 +1,296 @@
+"""ModelRunner: owns the model, the KV pools and the attention backend of ONE process
+(prefill or decode) and implements the weight / KV-cache sharing of Semi-PD.
+
+Reference: model_executor/model_runner.py — initialize :180-230, get_ipc_info :346-479,
+share_params_from_ipc :481-624, init_memory_pool :972-1092, init_attention_backend :1127-1172,
+forward / sample :1225-1325; decode graphs: cuda_graph_runner.py:109-150, 455-531.
+
+The decode instance (role DECODE) loads the weights, allocates the KV slab and req_to_token and
+exports one (hipIpcMemHandle, byte offset) per tensor.  The prefill instance (role PREFILL) builds
+the same module tree on the `meta` device and maps every tensor from those handles, so weights and
+KV cache exist once in HBM.
+"""
+from __future__ import annotations
+
+import hashlib
+import logging
+from typing import Dict, List, Optional
+
+import torch
+from torch import nn
+
+from semi_pd_amd import ops
+from semi_pd_amd.distributed import (get_tensor_model_parallel_rank, get_tensor_model_parallel_world_size,
+                                     init_distributed_environment)
+from semi_pd_amd.layers.attention_backend import HipAttnBackend
+from semi_pd_amd.layers.basic import Sampler
+from semi_pd_amd.mem_cache.memory_pool import (MHATokenToKVPool, MLATokenToKVPool, ReqToTokenPool,
+                                               TokenToKVPoolAllocator)
+from semi_pd_amd.model_executor.forward_batch_info import ForwardBatch, ForwardMode
+from semi_pd_amd.semi_pd.utils import (InstanceRole, IPCInfo, convert_ipc_handle_to_tensor, get_device_sm_count,
+                                       get_ipc_handle)
+
+logger = logging.getLogger(__name__)
+
+
+def build_model(model_config, dtype):
+    arch = model_config.architectures[0]
+    if arch == "LlamaForCausalLM":
+        from semi_pd_amd.models.llama import LlamaForCausalLM
+        return LlamaForCausalLM(model_config, dtype)
+    if arch == "OPTForCausalLM":
+        from semi_pd_amd.models.opt import OPTForCausalLM
+        return OPTForCausalLM(model_config, dtype)
+    if arch in ("DeepseekV2ForCausalLM", "DeepseekV3ForCausalLM"):
+        from semi_pd_amd.models.deepseek_v2 import DeepseekV2ForCausalLM
+        return DeepseekV2ForCausalLM(model_config, dtype)
+    raise ValueError(f"unsupported architecture {arch}")
+
+
+def _seed_of(name: str, seed: int) -> int:
+    return int.from_bytes(hashlib.sha256(f"{seed}:{name}".encode()).digest()[:7], "little")
+
+
+@torch.no_grad()
+def dummy_init_weights(model: nn.Module, device: torch.device, seed: int = 0, std: float = 0.02):
+    """`--load-format dummy` (model_loader/loader.py: DummyModelLoader): deterministic random weights.
+    Every parameter is drawn on the device from a generator seeded by its *name*, norm weights are 1,
+    so two processes (or a unified and a Semi-PD engine) build bit-identical models."""
+    for name, p in model.named_parameters():
+        if p.device.type == "meta":
+            continue
+        leaf = name.rsplit(".", 2)[-2] if "." in name else name
+        if "norm" in leaf and name.endswith("weight"):
+            p.fill_(1.0)
+        elif "norm" in leaf and name.endswith("bias"):
+            p.zero_()
+        else:
+            g = torch.Generator(device=device)
+            g.manual_seed(_seed_of(name, seed))
+            p.copy_(torch.randn(p.shape, generator=g, device=device, dtype=torch.float32).mul_(std).to(p.dtype))
+
+
+class ModelRunner:
+    def __init__(self, model_config, *, gpu_id: int = 0, tp_rank: int = 0, tp_size: int = 1,
+                 dtype: torch.dtype = torch.bfloat16, context_length: int = 4096,
+                 max_running_requests: int = 256, mem_fraction_static: float = 0.8,
+                 max_total_tokens: Optional[int] = None, nccl_init_method: Optional[str] = None,
+                 dist_backend: str = "nccl", instance_role: InstanceRole = InstanceRole.OTHER,
+                 bypass_load_weight: bool = False, seed: int = 0, cu_percent: int = 100,
+                 disable_cuda_graph: bool = False, cuda_graph_max_bs: int = 256,
+                 load_state_dict: Optional[Dict[str, torch.Tensor]] = None):
+        self.model_config = model_config
+        self.gpu_id, self.tp_rank, self.tp_size = gpu_id, tp_rank, tp_size
+        self.dtype = dtype
+        self.max_context_len = context_length
+        self.max_running_requests = max_running_requests
+        self.mem_fraction_static = mem_fraction_static
+        self.instance_role = instance_role
+        self.bypass_load_weight = bypass_load_weight
+        self.disable_cuda_graph = disable_cuda_graph
+        self.cuda_graph_max_bs = cuda_graph_max_bs
+        self.device = torch.device("cuda", gpu_id)
+        torch.cuda.set_device(self.device)
+        if tp_size > 1:
+            init_distributed_environment(tp_size, tp_rank, nccl_init_method, dist_backend, self.device)
+        else:
+            init_distributed_environment(1, 0, "", dist_backend)
+        self.num_cus = get_device_sm_count(gpu_id)
+        self.num_cus_owned = max(8, self.num_cus * cu_percent // 100)
+
+        # ---- model -------------------------------------------------------------------------
+        torch.set_default_dtype(dtype)
+        try:
+            if bypass_load_weight:
+                # prefill instance: structure only, tensors arrive through IPC (model_runner.py:663-675)
+                with torch.device("meta"):
+                    self.model = build_model(model_config, dtype)
+            else:
+                with torch.device(self.device):
+                    self.model = build_model(model_config, dtype)
+                if load_state_dict is not None:
+                    missing = self.model.load_state_dict(load_state_dict, strict=False)
+                    assert not missing.unexpected_keys, missing
+                else:
+                    dummy_init_weights(self.model, self.device, seed)
+        finally:
+            torch.set_default_dtype(torch.float32)
+        self.model.eval()
+        geo = self.model.kv_geometry
+        self.kv_geometry = geo
+        self.num_attention_heads_local = geo["num_heads"]
+        self.num_kv_heads_local = geo["num_kv_heads"]
+        self.v_head_dim = geo["v_head_dim"]
+        self.sampler = Sampler()
+
+        # ---- pools ---------------------------------------------------------------------------
+        self.init_memory_pool(max_total_tokens)
+        self.attn_backend = None
+        self.graph_runner = None
+
+    # ------------------------------------------------------------------------------------ memory
+    def profile_max_num_token(self) -> int:
+        """model_runner.py:930-966: tokens that fit in mem_fraction_static of what is free now."""
+        free, total = torch.cuda.mem_get_info(self.device)
+        geo = self.kv_geometry
+        if geo["kind"] == "mla":
+            cell = (geo["kv_lora_rank"] + geo["qk_rope_head_dim"]) * geo["num_layers"] * self.dtype.itemsize
+        else:
+            cell = geo["num_kv_heads"] * (geo["head_dim"] + geo["v_head_dim"]) * geo["num_layers"] * self.dtype.itemsize
+        rest = free - total * (1 - self.mem_fraction_static)
+        return max(int(rest // cell), 0)
+
+    def init_memory_pool(self, max_total_tokens: Optional[int]):
+        bypass = self.bypass_load_weight
+        if max_total_tokens is None:
+            if bypass:
+                raise ValueError("the prefill instance needs the decode instance's max_total_tokens "
+                                 "(model_runner.py:972-978)")
+            max_total_tokens = self.profile_max_num_token()
+            cap = self.max_running_requests * self.max_context_len
+            max_total_tokens = min(max_total_tokens, cap)
+        if max_total_tokens <= 0:
+            raise RuntimeError("Not enough memory. Please try to increase --mem-fraction-static.")
+        self.max_total_num_tokens = int(max_total_tokens)
+        geo = self.kv_geometry
+        dev = str(self.device)
+        # +4 columns like the reference (model_runner.py:1040: max_context_len + 4)
+        self.req_to_token_pool = ReqToTokenPool(self.max_running_requests + 1, self.max_context_len + 4, dev,
+                                                bypass_create_buffers=bypass)
+        if geo["kind"] == "mla":
+            self.token_to_kv_pool = MLATokenToKVPool(self.max_total_num_tokens, 1, self.dtype,
+                                                     geo["kv_lora_rank"], geo["qk_rope_head_dim"],
+                                                     geo["num_layers"], dev, bypass_create_buffers=bypass)
+        else:
+            self.token_to_kv_pool = MHATokenToKVPool(self.max_total_num_tokens, 1, self.dtype,
+                                                     geo["num_kv_heads"], geo["head_dim"], geo["num_layers"],
+                                                     dev, bypass_create_buffers=bypass)
+        self.token_to_kv_pool_allocator = TokenToKVPoolAllocator(self.max_total_num_tokens, self.dtype, dev,
+                                                                 self.token_to_kv_pool)
+
+    # ------------------------------------------------------------------------------------ IPC export
+    def get_ipc_info(self) -> IPCInfo:
+        """model_runner.py:346-479.  One (handle, offset) per parameter / buffer / KV layer /
+        req_to_token; zero-size tensors are "BYPASS"."""
+        params_info, weight_handles, buffer_handles = {}, {}, {}
+
+        def describe(t: torch.Tensor):
+            return {"shape": tuple(t.shape), "dtype": t.dtype, "stride": tuple(t.stride()),
+                    "numel": t.numel(), "contiguous": t.is_contiguous()}
+
+        for name, p in self.model.named_parameters(remove_duplicate=False):
+            params_info[name] = describe(p)
+            weight_handles[name] = "BYPASS" if p.numel() == 0 else get_ipc_handle(p.data)
+        for name, b in self.model.named_buffers(remove_duplicate=False):
+            params_info["buffer::" + name] = describe(b)
+            buffer_handles[name] = "BYPASS" if b.numel() == 0 else get_ipc_handle(b)
+        pool = self.token_to_kv_pool
+        kv_handles: List[list] = []
+        if isinstance(pool, MHATokenToKVPool):
+            for i in range(pool.layer_num):
+                kv_handles.append([get_ipc_handle(pool.k_buffer[i]), get_ipc_handle(pool.v_buffer[i])])
+            kv_info = {"kind": "mha", "shape": tuple(pool.k_buffer[0].shape), "dtype": pool.dtype,
+                       "numel": pool.k_buffer[0].numel(), "layer_num": pool.layer_num}
+        else:
+            for i in range(pool.layer_num):
+                kv_handles.append([get_ipc_handle(pool.kv_buffer[i])])
+            kv_info = {"kind": "mla", "shape": tuple(pool.kv_buffer[0].shape), "dtype": pool.dtype,
+                       "numel": pool.kv_buffer[0].numel(), "layer_num": pool.layer_num}
+        kv_info["max_total_num_tokens"] = self.max_total_num_tokens
+        r2t = self.req_to_token_pool.req_to_token
+        return IPCInfo(params_info=params_info, weight_handles=weight_handles,
+                       register_buffer_handles=buffer_handles, kv_cache_handles=kv_handles,
+                       kvcache_info=kv_info, req_to_token_handle=list(get_ipc_handle(r2t)),
+                       req_to_token_info={"shape": tuple(r2t.shape), "dtype": r2t.dtype, "numel": r2t.numel()})
+
+    # ------------------------------------------------------------------------------------ IPC import
+    def _import(self, handle, info) -> torch.Tensor:
+        flat = convert_ipc_handle_to_tensor(tuple(handle), info["numel"], info["dtype"], self.device)
+        if info.get("contiguous", True):
+            return flat.view(info["shape"])
+        return torch.as_strided(flat, info["shape"], info["stride"])
+
+    @staticmethod
+    def _set_by_path(root: nn.Module, name: str, value, is_buffer: bool):
+        mod = root
+        parts = name.split(".")
+        for p in parts[:-1]:
+            mod = getattr(mod, p)
+        if is_buffer:
+            mod._buffers[parts[-1]] = value
+        else:
+            mod._parameters[parts[-1]] = nn.Parameter(value, requires_grad=False)
+
+    def share_params_from_ipc(self, ipc_info: IPCInfo):
+        """model_runner.py:481-624: re-materialise every tensor from the decode instance's handles."""
+        cache: Dict[tuple, torch.Tensor] = {}
+
+        def imp(handle, info):
+            if handle == "BYPASS":
+                return torch.empty(info["shape"], dtype=info["dtype"], device=self.device)
+            key = (tuple(handle[0]), handle[1], info["dtype"], info["shape"])
+            if key not in cache:  # tied weights: one tensor, several names
+                cache[key] = self._import(handle, info)
+            return cache[key]
+
+        for name, handle in ipc_info.weight_handles.items():
+            self._set_by_path(self.model, name, imp(handle, ipc_info.params_info[name]), False)
+        for name, handle in ipc_info.register_buffer_handles.items():
+            self._set_by_path(self.model, name, imp(handle, ipc_info.params_info["buffer::" + name]), True)
+        left = [n for n, p in self.model.named_parameters() if p.device.type == "meta"]
+        left += [n for n, b in self.model.named_buffers() if b.device.type == "meta"]
+        if left:
+            raise RuntimeError(f"tensors not covered by the IPC info: {left[:5]}")
+        kvi = ipc_info.kvcache_info
+        info = {"numel": kvi["numel"], "dtype": kvi["dtype"], "shape": kvi["shape"], "contiguous": True}
+        pool = self.token_to_kv_pool
+        if kvi["kind"] == "mha":
+            pool.k_buffer = [self._import(h[0], info) for h in ipc_info.kv_cache_handles]
+            pool.v_buffer = [self._import(h[1], info) for h in ipc_info.kv_cache_handles]
+        else:
+            pool.kv_buffer = [self._import(h[0], info) for h in ipc_info.kv_cache_handles]
+        ri = ipc_info.req_to_token_info
+        self.req_to_token_pool.req_to_token = self._import(
+            ipc_info.req_to_token_handle, {"numel": ri["numel"], "dtype": ri["dtype"], "shape": ri["shape"]})
+
+    # ------------------------------------------------------------------------------------ backend / graphs
+    def init_attention_backend(self):
+        self.attn_backend = HipAttnBackend(self)
+
+    def init_cuda_graphs(self):
+        """Decode hipGraphs (cuda_graph_runner.py): only the decode instance captures
+        (semi_pd_scheduler.py:409-411)."""
+        if self.disable_cuda_graph:
+            return
+        from semi_pd_amd.model_executor.hip_graph_runner import HipGraphRunner
+        self.graph_runner = HipGraphRunner(self)
+
+    # ------------------------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(self, forward_batch: ForwardBatch):
+        kt = getattr(self, "kernel_timing", None)
+        sampled = kt.begin_step() if kt is not None else False
+        try:
+            if forward_batch.forward_mode.is_decode():
+                # a sampled step runs eagerly so that HIP events can bracket the attention launches
+                if (not sampled and self.graph_runner is not None
+                        and self.graph_runner.can_run(forward_batch)):
+                    return self.graph_runner.replay(forward_batch)
+                return self.forward_decode(forward_batch)
+            if forward_batch.forward_mode.is_extend():
+                return self.forward_extend(forward_batch)
+            raise ValueError(f"Invalid forward mode: {forward_batch.forward_mode}")
+        finally:
+            if kt is not None:
+                kt.end_step()
+
+    def forward_decode(self, forward_batch: ForwardBatch):
+        self.attn_backend.init_forward_metadata(forward_batch)
+        return self.model.forward(forward_batch.input_ids, forward_batch.positions, forward_batch)
+
+    def forward_extend(self, forward_batch: ForwardBatch):
+        self.attn_backend.init_forward_metadata(forward_batch)
+        return self.model.forward(forward_batch.input_ids, forward_batch.positions, forward_batch)
+
+    def sample(self, logits_output, forward_batch=None) -> torch.Tensor:
+        return self.sampler(logits_output, None)

@@ -1,0 +1,114 @@
+"""Mirror of python/sglang/semi_pd/utils.py (IPCInfo, InstanceRole, AggregatedSocket, dtype table,
+compute-share knobs) for the MI355X build.
+
+The reference partitions the GPU with CUDA MPS (env CUDA_MPS_ACTIVE_THREAD_PERCENTAGE set before
+each fork, entrypoints/engine.py:591-593, 632-634) and has no AMD path.  Here the same two knobs
+    SEMI_PD_PREFILL_SM_PERCENTILE / SEMI_PD_DECODE_SM_PERCENTILE   (semi_pd/utils.py:10-11)
+become CU masks: `cu_mask_env()` yields the environment for a child process (process-wide mask,
+covers every stream, hipGraph and RCCL kernel of that process), `cu_masked_stream()` builds a
+hipExtStreamCreateWithCUMask stream inside a process.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+from enum import Enum
+from typing import Dict, List
+
+import torch
+
+import semi_pd_ipc
+from semi_pd_amd import _lib
+
+PREFILL_ENGINE_SM_PERCENTILE = int(os.getenv("SEMI_PD_PREFILL_SM_PERCENTILE", 80))
+DECODE_ENGINE_SM_PERCENTILE = int(os.getenv("SEMI_PD_DECODE_SM_PERCENTILE", 100))
+
+
+@dataclass
+class IPCInfo:
+    """Same fields as the reference dataclass (semi_pd/utils.py:14-23)."""
+    params_info: dict
+    weight_handles: dict
+    register_buffer_handles: dict
+    kv_cache_handles: list
+    kvcache_info: dict
+    req_to_token_handle: list
+    req_to_token_info: dict
+
+
+class InstanceRole(Enum):
+    PREFILL = 0
+    DECODE = 1
+    OTHER = 2
+
+
+class AggregatedSocket:
+    """Fan-out sender (semi_pd/utils.py:31-37): the tokenizer sends every request to D first, then P."""
+
+    def __init__(self, sockets: List):
+        self.sockets = sockets
+
+    def send_pyobj(self, obj):
+        for socket in self.sockets:
+            socket.send_pyobj(obj)
+
+
+DTYPE_TO_ATEN = {v: k for k, v in semi_pd_ipc.ATEN_TO_DTYPE.items()}
+
+
+def get_ipc_handle(tensor: torch.Tensor):
+    """(handle, storage_offset_bytes) like the reference helper (semi_pd/utils.py:66-76) — the offset
+    comes from hipMemGetAddressRange instead of storage()._share_cuda_()."""
+    return semi_pd_ipc.get_ipc_handle_and_offset(tensor)
+
+
+def convert_ipc_handle_to_tensor(ipc_handle, size, dtype, device):
+    return semi_pd_ipc.convert_ipc_handle_to_tensor(ipc_handle, size, DTYPE_TO_ATEN[dtype], device)
+
+
+def get_device_sm_count(rank: int = 0):
+    return semi_pd_ipc.get_device_sm_count(rank)
+
+
+# --------------------------------------------------------------------------- CU masks
+def cu_mask_words(num_cus: int, percent: int, from_top: bool) -> List[int]:
+    lib = _lib.load()
+    words = (num_cus + 31) // 32
+    buf = (C.c_uint32 * words)()
+    n = lib.semipd_cu_mask_fill(num_cus, int(percent), 1 if from_top else 0, C.addressof(buf), words)
+    if n <= 0:
+        raise RuntimeError(f"cu_mask_fill failed: {_lib.last_error()}")
+    return [int(w) for w in buf]
+
+
+def cu_mask_env(gpu_id: int, num_cus: int, percent: int, from_top: bool) -> Dict[str, str]:
+    """Environment that confines a *process* to `percent` of the CUs of `gpu_id`.
+    ROCr reads HSA_CU_MASK ("<gpu>:<cu list>") when the process creates its queues; a 100 % share
+    needs no mask."""
+    if percent >= 100:
+        return {}
+    words = cu_mask_words(num_cus, percent, from_top)
+    bits = [i for i in range(num_cus) if words[i >> 5] >> (i & 31) & 1]
+    # compress into ranges
+    ranges, start, prev = [], bits[0], bits[0]
+    for b in bits[1:]:
+        if b != prev + 1:
+            ranges.append((start, prev))
+            start = b
+        prev = b
+    ranges.append((start, prev))
+    spec = ",".join(f"{a}-{b}" if a != b else f"{a}" for a, b in ranges)
+    return {"HSA_CU_MASK": f"{gpu_id}:{spec}"}
+
+
+def cu_masked_stream(device_index: int, percent: int, from_top: bool) -> torch.cuda.Stream:
+    """torch stream backed by hipExtStreamCreateWithCUMask (semipd_stream_create_cu_mask)."""
+    lib = _lib.load()
+    n = get_device_sm_count(device_index)
+    words = cu_mask_words(n, percent, from_top)
+    arr = (C.c_uint32 * len(words))(*words)
+    s = C.c_void_p(0)
+    _lib.check(lib.semipd_stream_create_cu_mask(device_index, C.addressof(arr), len(words), C.addressof(s)),
+               "stream_create_cu_mask")
+    return torch.cuda.ExternalStream(int(s.value), device=torch.device("cuda", device_index))

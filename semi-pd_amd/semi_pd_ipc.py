@@ -105,17 +105,25 @@ def convert_ipc_handle_to_tensor(handle_vec_offset, tensor_size: int, dtype_str:
     if flat.data_ptr() != base + int(offset):
         raise RuntimeError("convert_ipc_handle_to_tensor: torch copied the IPC range instead of mapping it")
     t = flat.view(dtype)
-    t._semipd_ipc_base = base  # keeps the mapping identifiable for close_ipc_tensor
+    _OPEN_RANGES.setdefault(base + int(offset), []).append(base)  # for close_ipc_tensor
     return t
 
 
+# data_ptr of an imported tensor -> [mapping base, ...] (one entry per convert call)
+_OPEN_RANGES = {}
+
+
 def close_ipc_tensor(tensor: torch.Tensor) -> None:
-    """Drop the reference this tensor holds on its IPC mapping (unmapped when the last one goes)."""
-    base = getattr(tensor, "_semipd_ipc_base", None)
-    if base is None:
+    """Drop the reference this tensor (or any view that starts at the same address) holds on its
+    IPC mapping; the allocation is unmapped when the last reference goes.  The caller must not
+    touch the tensor afterwards."""
+    bases = _OPEN_RANGES.get(tensor.data_ptr())
+    if not bases:
         raise ValueError("tensor was not created by convert_ipc_handle_to_tensor")
+    base = bases.pop()
+    if not bases:
+        del _OPEN_RANGES[tensor.data_ptr()]
     _lib.check(_lib.load().semipd_ipc_close(C.c_void_p(base)), "ipc_close")
-    tensor._semipd_ipc_base = None
 
 
 def num_open_mappings() -> int:

@@ -77,6 +77,7 @@ def test_ipc_roundtrip_between_processes(device):
     assert float(a.sum().item()) == 7000.0  # child's write is visible here
     parent.send("ok")
     after = parent.recv()
+    assert "error" not in after, after.get("error")
     assert after["mappings_after_close"] == 0
     p.join(30)
     assert p.exitcode == 0

@@ -1,0 +1,199 @@
+"""CPU test of the P<->D protocol — host logic only, no kernels.
+
+The prefill and decode schedulers run in one process against in-memory sockets and a *shared*
+req_to_token tensor (standing in for the hipIpcMemHandle mapping).  A toy "model" stores token ids
+in a fake KV array at out_cache_loc and derives the next token from the tokens it gathers through
+req_to_token — so any mistake in slot allocation, in the shared table, in chunked prefill or in the
+retract path changes the generated ids.  Expected ids come from the full token history alone, and
+must also equal what the unified scheduler produces (the invariant that pins Semi-PD)."""
+import collections
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+from semi_pd_amd.managers.io_struct import SamplingParams, TokenizedGenerateReqInput
+from semi_pd_amd.managers.schedule_batch import ScheduleBatch
+from semi_pd_amd.managers.scheduler import Scheduler
+from semi_pd_amd.managers.semi_pd_decode_scheduler import SemiPDDecodeScheduler
+from semi_pd_amd.managers.semi_pd_prefill_scheduler import SemiPDPrefillScheduler
+from semi_pd_amd.managers.transport import NOTHING
+from semi_pd_amd.mem_cache.memory_pool import ReqToTokenPool, TokenToKVPoolAllocator
+from semi_pd_amd.server_args import ServerArgs
+
+VOCAB = 997
+
+
+def toy_next(history):
+    return (sum((i + 1) * t for i, t in enumerate(history)) * 31 + len(history)) % VOCAB
+
+
+def expected(prompt, n):
+    h = list(prompt)
+    out = []
+    for _ in range(n):
+        t = toy_next(h)
+        out.append(t)
+        h.append(t)
+    return out
+
+
+class Q:
+    """In-memory PUSH/PULL pair."""
+
+    def __init__(self, pump=None):
+        self.q = collections.deque()
+        self.pump = pump
+
+    def send_pyobj(self, obj):
+        self.q.append(obj)
+
+    def recv_pyobj_nowait(self):
+        return self.q.popleft() if self.q else NOTHING
+
+    def recv_pyobj(self, timeout=None):
+        for _ in range(10000):
+            if self.q:
+                return self.q.popleft()
+            self.pump()  # let the peer scheduler run (stands in for the other process)
+        raise TimeoutError
+
+
+class FakeWorker:
+    def __init__(self, runner, kv_store):
+        self.runner, self.kv = runner, kv_store
+
+    def forward_batch_generation(self, mwb):
+        table = self.runner.req_to_token_pool.req_to_token
+        self.kv[mwb.out_cache_loc.long()] = mwb.input_ids
+        ids = []
+        for rp, sl in zip(mwb.req_pool_indices.tolist(), mwb.seq_lens.tolist()):
+            slots = table[rp, :sl].long()
+            assert (slots > 0).all(), "a sequence points at the dummy slot 0"
+            assert len(set(slots.tolist())) == sl, "two tokens of one sequence share a KV slot"
+            ids.append(toy_next(self.kv[slots].tolist()))
+        return None, torch.tensor(ids, dtype=torch.int32)
+
+
+def make_runner(shared=None, size=4000, max_reqs=32, ctx=512):
+    if shared is None:
+        r2t = ReqToTokenPool(max_reqs + 1, ctx + 4, "cpu")
+    else:
+        r2t = ReqToTokenPool(max_reqs + 1, ctx + 4, "cpu", bypass_create_buffers=True)
+        r2t.req_to_token = shared.req_to_token_pool.req_to_token  # the IPC mapping
+    alloc = TokenToKVPoolAllocator(size, torch.bfloat16, "cpu", None)
+    return SimpleNamespace(device=torch.device("cpu"), req_to_token_pool=r2t,
+                           token_to_kv_pool_allocator=alloc, max_total_num_tokens=size)
+
+
+def args(**kw):
+    base = dict(model_config=None, context_length=512, max_running_requests=32, max_total_tokens=4000,
+                chunked_prefill_size=8192, enable_semi_pd=True, watchdog_timeout=5.0)
+    base.update(kw)
+    return ServerArgs(**base)
+
+
+def run_semi_pd(prompts, max_new, sa, size=4000, force_retract=0, interleave=True):
+    d_runner = make_runner(size=size)
+    p_runner = make_runner(shared=d_runner, size=size)
+    kv = torch.zeros(size + 1, dtype=torch.int64)
+    d_in, p_in, out = Q(), Q(), Q()
+    holder = {}
+    bridge = Q(pump=lambda: holder["d"].step())
+    d = SemiPDDecodeScheduler(sa, d_runner, 0, d_in, out, bridge, p_in)
+    p = SemiPDPrefillScheduler(sa, p_runner, 0, p_in, d_in, bridge)
+    holder["d"] = d
+    d.tp_worker, p.tp_worker = FakeWorker(d_runner, kv), FakeWorker(p_runner, kv)
+    if force_retract:
+        d.forced_retractions = lambda batch: force_retract if batch.batch_size() > 4 else 0
+    got = {}
+    reqs = [TokenizedGenerateReqInput(f"r{i}", None, list(pr), SamplingParams(max_new_tokens=max_new, ignore_eos=True))
+            for i, pr in enumerate(prompts)]
+    pending = collections.deque(reqs)
+    for it in range(20000):
+        if pending and (not interleave or it % 3 == 0):
+            r = pending.popleft()
+            d_in.send_pyobj(r)   # D first, then P (tokenizer_manager.py:149-160)
+            p_in.send_pyobj(r)
+        p.step()
+        d.step()
+        while out.q:
+            o = out.q.popleft()
+            for rid, toks in zip(o.rids, o.output_ids):
+                got.setdefault(rid, []).extend(toks)
+        if not pending and len(got) == len(reqs) and all(len(v) >= max_new for v in got.values()):
+            break
+    # nothing leaks: every KV slot and request slot is back in the decode instance's pools
+    assert d_runner.token_to_kv_pool_allocator.available_size() == size
+    assert d_runner.req_to_token_pool.available_size() == d_runner.req_to_token_pool.size
+    assert p_runner.token_to_kv_pool_allocator.available_size() == size, "the prefill instance allocated KV"
+    assert not d.scheduled_prefill_batches and not d.waiting_queue and not p.waiting_queue
+    return [got[f"r{i}"] for i in range(len(reqs))], d, p
+
+
+def run_unified(prompts, max_new, sa):
+    runner = make_runner()
+    kv = torch.zeros(4001, dtype=torch.int64)
+    inbox, out = Q(), Q()
+    s = Scheduler(sa, runner, 0, inbox, out)
+    s.tp_worker = FakeWorker(runner, kv)
+    for i, pr in enumerate(prompts):
+        inbox.send_pyobj(TokenizedGenerateReqInput(f"r{i}", None, list(pr),
+                                                   SamplingParams(max_new_tokens=max_new, ignore_eos=True)))
+    got = {}
+    for _ in range(20000):
+        if not s.step() and len(got) == len(prompts) and all(len(v) >= max_new for v in got.values()):
+            break
+        while out.q:
+            o = out.q.popleft()
+            for rid, toks in zip(o.rids, o.output_ids):
+                got.setdefault(rid, []).extend(toks)
+    assert runner.token_to_kv_pool_allocator.available_size() == 4000
+    return [got[f"r{i}"] for i in range(len(prompts))]
+
+
+def prompts_of(lens, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randint(1, VOCAB, (n,), generator=g).tolist() for n in lens]
+
+
+def test_semi_pd_equals_unified_equals_history_rule():
+    prompts = prompts_of([5, 40, 128, 1, 77, 33, 64, 12])
+    want = [expected(p, 9) for p in prompts]
+    assert run_unified(prompts, 9, args(enable_semi_pd=False)) == want
+    got, d, p = run_semi_pd(prompts, 9, args())
+    assert got == want
+    assert p.stats["prefill_tokens"] == sum(len(x) for x in prompts)
+    assert d.stats["decode_tokens"] == 8 * len(prompts)
+
+
+def test_chunked_prefill_across_p_and_d():
+    prompts = prompts_of([150, 20, 200, 9, 77, 130], seed=1)
+    want = [expected(p, 6) for p in prompts]
+    assert run_unified(prompts, 6, args(enable_semi_pd=False, chunked_prefill_size=64)) == want
+    got, d, p = run_semi_pd(prompts, 6, args(chunked_prefill_size=64))
+    assert got == want
+    assert p.stats["prefill_batches"] > len(prompts)  # the long prompts really were split
+
+
+def test_retracted_requests_are_re_prefilled():
+    prompts = prompts_of([30, 8, 51, 17, 23, 40, 12, 9], seed=2)
+    want = [expected(p, 12) for p in prompts]
+    got, d, p = run_semi_pd(prompts, 12, args(), force_retract=2, interleave=False)
+    assert got == want
+    assert p.stats["prefill_tokens"] > sum(len(x) for x in prompts), "no request was re-prefilled"
+
+
+def test_memory_pressure_retract_and_admission_control():
+    # pool of 300 slots: admission control (PrefillAdder budget) and OOM retraction must both hold
+    prompts = prompts_of([60, 70, 50, 40, 65, 30], seed=3)
+    want = [expected(p, 20) for p in prompts]
+    got, d, p = run_semi_pd(prompts, 20, args(max_total_tokens=300), size=300, interleave=False)
+    assert got == want
+
+
+def test_single_token_requests_finish_at_prefill():
+    prompts = prompts_of([10, 3, 25], seed=4)
+    got, d, p = run_semi_pd(prompts, 1, args())
+    assert got == [expected(p_, 1) for p_ in prompts]
+    assert d.stats["decode_tokens"] == 0
