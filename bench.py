@@ -1,0 +1,276 @@
+#!/usr/bin/env python
+"""Semi-PD serving benchmark (BASELINE.json metric: output tokens/s + p50 TTFT / TBT, Semi-PD mode).
+
+A "step" is one wave of synthetic fixed-length requests with Poisson arrivals served end to end by
+the Semi-PD engine (prefill process + decode process per GPU, shared weights / KV, CU split).
+Client-side timing follows python/sglang/bench_serving.py:884-970 (TTFT = first token - send,
+ITL = gaps between tokens, output tok/s = sum(out) / duration); request generation follows
+:771-782 (ids[i][j] = (o_i + i + j) mod vocab) and :896-899 (exponential inter-arrival times).
+
+    python bench.py --gpus 1 --steps 1 --warmup 1
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (TP = N)
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "semi-pd_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+MFMA_BF16_PEAK_TFLOPS = 2500.0
+
+
+def model_config(name: str):
+    from semi_pd_amd.models.llama import LLAMA3_8B, LLAMA3_70B, LlamaConfig
+    from semi_pd_amd.models.opt import OPT_125M
+    if name == "llama3-8b":
+        return LLAMA3_8B
+    if name == "llama3-70b":
+        return LLAMA3_70B
+    if name == "opt-125m":
+        return OPT_125M
+    if name == "llama-tiny":
+        return LlamaConfig(vocab_size=32000, hidden_size=1024, intermediate_size=2816, num_hidden_layers=4,
+                           num_attention_heads=8, num_key_value_heads=2, max_position_embeddings=8192)
+    raise ValueError(name)
+
+
+def make_requests(num, input_len, vocab, seed):
+    """bench_serving.py:771-782 random-ids rule."""
+    rs = np.random.RandomState(seed)
+    offsets = rs.randint(0, vocab, size=num)
+    return [[int((offsets[i] + i + j) % vocab) for j in range(input_len)] for i in range(num)]
+
+
+def arrival_times(num, rate, seed):
+    if rate <= 0 or rate == float("inf"):
+        return np.zeros(num)
+    rs = np.random.RandomState(seed + 1)
+    return np.cumsum(rs.exponential(1.0 / rate, size=num)) - 0.0
+
+
+def run_wave(engine, prompts, arrivals, output_len):
+    """Send requests on their Poisson schedule, stream tokens, return per-request records."""
+    from semi_pd_amd.managers.io_struct import SamplingParams
+    t0 = time.time()
+    rids = []
+    nxt = 0
+    n = len(prompts)
+    done = 0
+    while done < n:
+        now = time.time() - t0
+        while nxt < n and arrivals[nxt] <= now:
+            rids.append(engine.add_request(prompts[nxt], SamplingParams(max_new_tokens=output_len, ignore_eos=True)))
+            nxt += 1
+        wait = 0.0005 if nxt >= n else min(0.0005, max(0.0, arrivals[nxt] - now))
+        if not engine.poll(timeout=wait):
+            engine.check_children()
+        done = sum(1 for r in rids if engine._finished[r] is not None)
+    dur = time.time() - t0
+    recs = [engine.request_record(r) for r in rids]
+    return recs, dur
+
+
+def summarize(records, duration):
+    ttft, itl, out_tokens = [], [], 0
+    for r in records:
+        tt = r["token_times"]
+        out_tokens += len(r["output_ids"])
+        if tt:
+            ttft.append(tt[0] - r["send"])
+            itl.extend(np.diff(tt).tolist())
+    return {"output_tokens": out_tokens, "duration_s": duration,
+            "output_tok_s": out_tokens / duration if duration > 0 else 0.0,
+            "p50_ttft_ms": float(np.median(ttft) * 1e3) if ttft else None,
+            "p99_ttft_ms": float(np.percentile(ttft, 99) * 1e3) if ttft else None,
+            "p50_tbt_ms": float(np.median(itl) * 1e3) if itl else None,
+            "p99_tbt_ms": float(np.percentile(itl, 99) * 1e3) if itl else None}
+
+
+def cpu_baseline(cfg, input_len, output_len, budget_s=25.0):
+    """The CPU oracle (oracle/model.py, a port of the reference's torch_native path) timed on this
+    host, on a bounded sample of the same workload: ONE transformer layer of the model's real shape
+    (x num_layers) + embedding + lm_head, 2 requests of the same input length, 4 decode steps, fp32,
+    driven like bench_one_batch.py (one prefill, then decode steps)."""
+    from oracle.model import OracleLlama
+    import copy
+    cores = len(os.sched_getaffinity(0))
+    torch.set_num_threads(cores)
+    c1 = copy.copy(cfg)
+    c1.num_hidden_layers = 1
+    g = torch.Generator().manual_seed(0)
+    H, I, D = cfg.hidden_size, cfg.intermediate_size, cfg.head_size
+    sd = {"model.embed_tokens.weight": torch.randn(cfg.vocab_size, H, generator=g) * 0.02,
+          "lm_head.weight": torch.randn(cfg.vocab_size, H, generator=g) * 0.02,
+          "model.norm.weight": torch.ones(H),
+          "model.layers.0.input_layernorm.weight": torch.ones(H),
+          "model.layers.0.post_attention_layernorm.weight": torch.ones(H),
+          "model.layers.0.self_attn.qkv_proj.weight": torch.randn((cfg.num_attention_heads + 2 * cfg.num_key_value_heads) * D, H, generator=g) * 0.02,
+          "model.layers.0.self_attn.o_proj.weight": torch.randn(H, cfg.num_attention_heads * D, generator=g) * 0.02,
+          "model.layers.0.mlp.gate_up_proj.weight": torch.randn(2 * I, H, generator=g) * 0.02,
+          "model.layers.0.mlp.down_proj.weight": torch.randn(H, I, generator=g) * 0.02}
+    oracle = OracleLlama(c1, sd)
+    nreq, steps = 2, 4
+    prompts = make_requests(nreq, input_len, cfg.vocab_size, 3)
+    t0 = time.time()
+    logits, kv, lens = oracle.prefill(prompts)
+    t_prefill = time.time() - t0
+    lens = list(lens)
+    cur = [int(torch.argmax(l)) for l in logits]
+    t0 = time.time()
+    for _ in range(steps):
+        logits = oracle.decode_step(cur, kv, lens)
+        cur = [int(torch.argmax(l)) for l in logits]
+    t_decode = (time.time() - t0) / steps
+    # head (embedding + final norm + lm_head) cost, measured separately so that it is not multiplied
+    h = torch.randn(nreq, H)
+    t0 = time.time()
+    for _ in range(3):
+        oracle._logits(h)
+    t_head = (time.time() - t0) / 3
+    L = cfg.num_hidden_layers
+    full_prefill = (t_prefill - t_head) * L + t_head
+    full_decode = (t_decode - t_head) * L + t_head
+    total = full_prefill + full_decode * (output_len - 1)
+    return {"value": nreq * output_len / total, "unit": "output tokens/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/model.py OracleLlama fp32: 1 of {L} layers timed and scaled x{L} + lm_head; "
+                      f"{nreq} requests in={input_len}, prefill + {steps} decode steps extrapolated to out={output_len}; "
+                      f"measured prefill {t_prefill:.2f}s, decode step {t_decode * 1e3:.0f}ms, head {t_head * 1e3:.0f}ms"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model", default="llama3-8b")
+    ap.add_argument("--num-requests", type=int, default=64)
+    ap.add_argument("--input-len", type=int, default=1024)
+    ap.add_argument("--output-len", type=int, default=128)
+    ap.add_argument("--request-rate", type=float, default=16.0, help="Poisson arrivals per second (0 = all at once)")
+    ap.add_argument("--mode", choices=["semi-pd", "unified"], default="semi-pd")
+    ap.add_argument("--prefill-cu", type=int, default=50)
+    ap.add_argument("--decode-cu", type=int, default=50)
+    ap.add_argument("--cu-mask-mode", default="env")
+    ap.add_argument("--context-length", type=int, default=0)
+    ap.add_argument("--max-running-requests", type=int, default=256)
+    ap.add_argument("--mem-fraction-static", type=float, default=None)
+    ap.add_argument("--max-total-tokens", type=int, default=None)
+    ap.add_argument("--disable-cuda-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)  # launcher-level barrier / max only
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+
+    from semi_pd_amd.entrypoints.engine import Engine
+    from semi_pd_amd.server_args import ServerArgs
+    cfg = model_config(args.model)
+    ctx = args.context_length or (args.input_len + args.output_len + 8)
+    port_base = int(os.environ.get("MASTER_PORT", "29500")) + 100
+    sa = ServerArgs(model_config=cfg, context_length=ctx, tp_size=world, enable_semi_pd=(args.mode == "semi-pd"),
+                    max_running_requests=args.max_running_requests, mem_fraction_static=args.mem_fraction_static,
+                    max_total_tokens=args.max_total_tokens, prefill_cu_percent=args.prefill_cu,
+                    decode_cu_percent=args.decode_cu, cu_mask_mode=args.cu_mask_mode,
+                    disable_cuda_graph=args.disable_cuda_graph, nccl_port_base=port_base,
+                    collect_kernel_timing=not args.no_kernel_timing, random_seed=args.seed,
+                    dist_init_addr=os.environ.get("MASTER_ADDR", "127.0.0.1"), watchdog_timeout=600.0)
+    if args.mode == "unified" and world > 1:
+        raise SystemExit("unified mode is single-GPU only in this round")
+    engine = Engine(sa, local_tp_ranks=[rank], gpu_ids={rank: local_rank})
+    prompts = make_requests(args.num_requests, args.input_len, cfg.vocab_size, args.seed)
+    arrivals = arrival_times(args.num_requests, args.request_rate, args.seed)
+
+    try:
+        for _ in range(args.warmup):
+            barrier()
+            if rank == 0:
+                run_wave(engine, prompts, arrivals, args.output_len)
+        if rank == 0 and not args.no_kernel_timing:
+            engine.get_stats(reset=True)
+        barrier()
+        t0 = time.time()
+        all_records, wave_summaries = [], []
+        for _ in range(args.steps):
+            if rank == 0:
+                recs, dur = run_wave(engine, prompts, arrivals, args.output_len)
+                all_records.extend(recs)
+                wave_summaries.append(summarize(recs, dur))
+        barrier()
+        elapsed = time.time() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        stats = engine.get_stats() if (rank == 0 and not args.no_kernel_timing) else []
+    finally:
+        engine.shutdown()
+
+    if rank != 0:
+        return
+    summ = summarize(all_records, elapsed)
+    roofline = None
+    extra = {}
+    for s in stats:
+        kt = s.get("kernel_timing") or {}
+        if "decode_attention" in kt:
+            k = kt["decode_attention"]
+            roofline = {"bound": "hbm", "kernel": "decode_stage1_kernel (+stage2)", "achieved": round(k["gbps"], 1),
+                        "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(k["gbps"] / HBM_PEAK_GBPS, 4),
+                        "traffic": None, "avg_launch_us": round(k["avg_us"], 2),
+                        "algorithmic_bytes_per_launch": int(k["bytes_per_launch"]), "launches_sampled": k["launches"]}
+        if "extend_attention" in kt:
+            k = kt["extend_attention"]
+            extra["extend_attention"] = {"bound": "mfma", "achieved": round(k["tflops"], 1),
+                                         "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                         "frac": round(k["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4),
+                                         "avg_launch_us": round(k["avg_us"], 1), "launches_sampled": k["launches"]}
+    cpu = None
+    if not args.no_cpu_baseline and hasattr(cfg, "rms_norm_eps"):
+        try:
+            cpu = cpu_baseline(cfg, args.input_len, args.output_len)
+        except Exception as e:  # the baseline must never take the measured number down with it
+            cpu = {"error": repr(e)}
+    out = {
+        "metric": "output tokens/s (Semi-PD mode; with p50 TTFT / TBT)" if args.mode == "semi-pd" else "output tokens/s (unified engine)",
+        "value": round(summ["output_tok_s"], 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / max(args.steps, 1), 2),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "p50_ttft_ms": summ["p50_ttft_ms"], "p50_tbt_ms": summ["p50_tbt_ms"],
+        "p99_ttft_ms": summ["p99_ttft_ms"], "p99_tbt_ms": summ["p99_tbt_ms"],
+        "config": {"workload": f"{args.model} bf16 TP={world} {args.mode}, CU split P{args.prefill_cu}/D{args.decode_cu} "
+                               f"({args.cu_mask_mode}), {args.num_requests} synthetic requests in={args.input_len} "
+                               f"out={args.output_len}, Poisson {args.request_rate} req/s, dummy weights",
+                   "num_requests": args.num_requests, "input_len": args.input_len, "output_len": args.output_len,
+                   "request_rate": args.request_rate, "parallelism": f"tp{world}", "mode": args.mode},
+        "roofline": roofline, "roofline_extra": extra, "cpu_baseline": cpu,
+    }
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
