@@ -1,0 +1,115 @@
+"""Kernel micro-benchmarks at the SURVEY §8d shapes (run on the GPU box).  Prints one line per case with
+the achieved fraction of the HBM / MFMA roofline.  Usage: python tools/kbench.py [decode|extend|norm|moe|all]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "semi-pd_amd")]
+import torch  # noqa: E402
+
+from semi_pd_amd import ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+HBM, MFMA = 8000.0, 2500.0
+
+
+def timeit(fn, iters=20, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e-3  # seconds
+
+
+def bench_decode():
+    print("# decode attention: B, ctx, Hq, Hkv, D, splits -> us, GB/s, frac of 8 TB/s")
+    for (Hq, Hkv, D) in [(32, 8, 128), (8, 1, 128), (12, 12, 64)]:
+        for B in (1, 32, 128, 256):
+            for ctx in (1024, 8192):
+                if B * ctx > 2_200_000:
+                    continue
+                N = B * ctx + 1
+                kb = torch.randn(N, Hkv, D, device=dev, dtype=torch.bfloat16)
+                vb = torch.randn(N, Hkv, D, device=dev, dtype=torch.bfloat16)
+                q = torch.randn(B, Hq, D, device=dev, dtype=torch.bfloat16)
+                o = torch.empty_like(q)
+                indptr = (torch.arange(B + 1, device=dev, dtype=torch.int32) * ctx)
+                idx = (torch.randperm(N - 1, device=dev)[: B * ctx] + 1).to(torch.int32)
+                best = None
+                for splits in (1, 2, 4, 8, 16, 32):
+                    if ctx // splits < 64:
+                        continue
+                    lg = torch.empty(B, Hq, splits, D + 1, device=dev, dtype=torch.float32)
+                    t = timeit(lambda: ops.decode_attention_fwd(q, kb, vb, o, indptr, idx, lg, splits, D ** -0.5))
+                    if best is None or t < best[0]:
+                        best = (t, splits)
+                t, splits = best
+                nbytes = B * ctx * Hkv * 2 * D * 2 + 2 * B * Hq * D * 2
+                print(f"decode B={B:4d} ctx={ctx:5d} Hq={Hq} Hkv={Hkv} D={D} splits={splits:2d}: {t * 1e6:8.1f} us "
+                      f"{nbytes / t / 1e9:7.0f} GB/s  {nbytes / t / 1e9 / HBM:.3f}")
+                del kb, vb
+
+
+def bench_extend():
+    print("# extend attention: B, ext, prefix, Hq, Hkv, D -> us, TFLOP/s, frac of 2.5 PF")
+    for (Hq, Hkv, D) in [(32, 8, 128), (12, 12, 64)]:
+        for B, ext, pre in [(1, 1024, 0), (8, 1024, 0), (1, 8192, 0), (4, 2048, 0), (8, 128, 1024), (32, 128, 0), (2, 1024, 1024)]:
+            T = B * ext
+            N = B * pre + 8
+            q = torch.randn(T, Hq, D, device=dev, dtype=torch.bfloat16)
+            k = torch.randn(T, Hkv, D, device=dev, dtype=torch.bfloat16)
+            v = torch.randn(T, Hkv, D, device=dev, dtype=torch.bfloat16)
+            o = torch.empty_like(q)
+            kb = torch.randn(N, Hkv, D, device=dev, dtype=torch.bfloat16)
+            vb = torch.randn(N, Hkv, D, device=dev, dtype=torch.bfloat16)
+            qo = torch.arange(B + 1, device=dev, dtype=torch.int32) * ext
+            kvp = torch.arange(B + 1, device=dev, dtype=torch.int32) * pre
+            idx = (torch.randperm(N - 1, device=dev)[: max(B * pre, 1)] + 1).to(torch.int32)
+            t = timeit(lambda: ops.extend_attention_fwd(q, k, v, o, kb, vb, qo, kvp, idx, None, None, ext), iters=10)
+            flops = 4.0 * Hq * D * B * ext * (pre + (ext + 1) / 2)
+            print(f"extend B={B:3d} ext={ext:5d} pre={pre:5d} Hq={Hq} Hkv={Hkv} D={D}: {t * 1e6:9.1f} us "
+                  f"{flops / t / 1e12:7.1f} TF/s  {flops / t / 1e12 / MFMA:.3f}")
+
+
+def bench_norm():
+    print("# fused_add_rmsnorm / rmsnorm / silu_and_mul / rope_kv_store: T, H -> us, GB/s")
+    for H in (4096, 8192):
+        for T in (32, 256, 8192):
+            x = torch.randn(T, H, device=dev, dtype=torch.bfloat16)
+            r = torch.randn(T, H, device=dev, dtype=torch.bfloat16)
+            w = torch.ones(H, device=dev, dtype=torch.bfloat16)
+            t = timeit(lambda: ops.fused_add_rmsnorm(x, r, w, 1e-5))
+            print(f"fused_add_rmsnorm T={T:5d} H={H}: {t * 1e6:7.1f} us {4 * T * H * 2 / t / 1e9:7.0f} GB/s")
+    for T in (32, 8192):
+        x = torch.randn(T, 2 * 14336, device=dev, dtype=torch.bfloat16)
+        t = timeit(lambda: ops.silu_and_mul(x))
+        print(f"silu_and_mul T={T:5d} d=14336: {t * 1e6:7.1f} us {3 * T * 14336 * 2 / t / 1e9:7.0f} GB/s")
+
+
+def bench_lm_head():
+    print("# lm_head_argmax: B, H, V -> us, GB/s of weight stream")
+    for B in (1, 32, 256):
+        H, V = 4096, 128256
+        h = torch.randn(B, H, device=dev, dtype=torch.bfloat16)
+        w = torch.randn(V, H, device=dev, dtype=torch.bfloat16) * 0.02
+        t = timeit(lambda: ops.lm_head_argmax(h, w), iters=5)
+        t2 = timeit(lambda: torch.matmul(h, w.T).float().argmax(-1), iters=5)
+        print(f"lm_head_argmax B={B:3d}: {t * 1e6:8.1f} us {V * H * 2 / t / 1e9:6.0f} GB/s   (torch matmul+argmax {t2 * 1e6:8.1f} us)")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which in ("decode", "all"):
+        bench_decode()
+    if which in ("extend", "all"):
+        bench_extend()
+    if which in ("norm", "all"):
+        bench_norm()
+    if which in ("lm_head", "all"):
+        bench_lm_head()
