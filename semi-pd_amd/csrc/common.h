@@ -56,15 +56,10 @@ template <> struct Elem<float> {
 template <> struct Elem<bf16_t> {
   static constexpr int kVec = 8;
   __device__ static inline float to_f(bf16_t x) { return __uint_as_float(((uint32_t)x.v) << 16); }
-  __device__ static inline bf16_t from_f(float f) {  // round-to-nearest-even, NaN preserved
-    uint32_t u = __float_as_uint(f);
+  __device__ static inline bf16_t from_f(float f) {  // round-to-nearest-even: v_cvt_pk_bf16_f32
+    const __bf16 h = (__bf16)f;
     bf16_t r;
-    if ((u & 0x7fffffffu) > 0x7f800000u) {
-      r.v = (uint16_t)((u >> 16) | 0x40u);
-    } else {
-      u += 0x7fffu + ((u >> 16) & 1u);
-      r.v = (uint16_t)(u >> 16);
-    }
+    r.v = __builtin_bit_cast(uint16_t, h);
     return r;
   }
 };

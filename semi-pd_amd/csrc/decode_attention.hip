@@ -353,6 +353,13 @@ static int launch_stage1(T* out, const T* q, const T* k_buf, const T* v_buf, con
   return launch_status("decode_stage1");
 }
 
+// defined in decode_attention_mfma.hip
+template <typename T>
+int launch_decode_mfma(T* out, const T* q, const T* k_buf, const T* v_buf, const int32_t* kv_indptr,
+                       const int32_t* kv_indices, float* attn_logits, int64_t batch, int Hq, int Hkv, int D,
+                       int64_t q_stride, int64_t o_stride, int64_t kbuf_stride, int64_t vbuf_stride,
+                       int splits, float sm_scale, float logit_cap, hipStream_t st);
+
 template <typename T>
 static int run_decode(void* out, const void* q, const void* k_buf, const void* v_buf,
                       const int32_t* kv_indptr, const int32_t* kv_indices, float* attn_logits,
@@ -364,7 +371,16 @@ static int run_decode(void* out, const void* q, const void* k_buf, const void* v
                     aligned16(q) && aligned16(k_buf) && aligned16(v_buf) && q_stride % 8 == 0 &&
                     kbuf_stride % 8 == 0 && vbuf_stride % 8 == 0;
   int rc = 0;
-  if (fast) {
+  const int group = num_q_heads / num_kv_heads;
+  const bool mfma = fast && group >= 2 &&
+                    (head_dim_k == 64 || head_dim_k == 96 || head_dim_k == 128) &&
+                    o_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 7u) == 0;
+  if (mfma) {
+    // GQA / MQA: matrix-core kernel (decode_attention_mfma.hip)
+    rc = launch_decode_mfma<T>((T*)out, (const T*)q, (const T*)k_buf, (const T*)v_buf, kv_indptr, kv_indices,
+                               attn_logits, batch, num_q_heads, num_kv_heads, head_dim_k, q_stride, o_stride,
+                               kbuf_stride, vbuf_stride, num_kv_splits, sm_scale, logit_cap, st);
+  } else if (fast) {
     const int D = head_dim_k;
     if (D <= 64)
       rc = launch_stage1<T, 8>((T*)out, (const T*)q, (const T*)k_buf, (const T*)v_buf, kv_indptr,

@@ -9,8 +9,11 @@
 // exchange with lane^32, the O rescale factor is one scalar per lane, and P^T needs no
 // cross-lane movement at all to become the B operand of the second MFMA (the kv-slot
 // permutation of the C layout is applied to the V^T fragment addresses instead).
-// K tiles are staged row-major (+16 B row pad: conflict-free ds_read_b128), V tiles are
-// transposed on the way into LDS (+8 B row pad: conflict-free ds_read_b64).
+// K tiles are staged row-major (+16 B row pad: conflict-free ds_read_b128); V tiles are staged
+// row-major too and transposed by the LDS itself on the way out (ds_read_b64_tr_b16).  The next
+// KV tile is prefetched into registers while the current one is multiplied.  Masking code only
+// runs on boundary tiles; the vector / logit-cap variants are separate instantiations so the hot
+// loop carries no dead branches.
 //
 // Mirrors extend_attention_fwd (layers/attention/triton_ops/extend_attention.py:291-410).
 #include "common.h"
@@ -20,6 +23,7 @@ namespace semipd {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 template <typename T> struct Mfma;
 template <> struct Mfma<bf16_t> {
@@ -37,7 +41,8 @@ template <> struct Mfma<f16_t> {
 
 union Frag16 {  // 16 bytes viewed as MFMA operand / raw words / elements
   uint4 u;
-  uint2 h[2];
+  uint32_t w[4];
+  s16x4 s[2];
   uint16_t e[8];
   bf16x8_t b;
   f16x8_t f;
@@ -46,12 +51,17 @@ template <typename T> __device__ inline typename Mfma<T>::frag as_frag(const Fra
 template <> __device__ inline bf16x8_t as_frag<bf16_t>(const Frag16& x) { return x.b; }
 template <> __device__ inline f16x8_t as_frag<f16_t>(const Frag16& x) { return x.f; }
 
-// Load 8 consecutive elements of a row (zero fill beyond `valid` elements).
-template <typename T>
-__device__ inline Frag16 load_row8(const T* p, int valid, bool vec_ok) {
+template <typename T> __device__ inline uint32_t pack2(float a, float b) {
+  return (uint32_t)Elem<T>::from_f(a).v | ((uint32_t)Elem<T>::from_f(b).v << 16);
+}
+
+// 8 consecutive elements of a row.  VEC: one 16-byte load (the chunk is either whole or absent);
+// otherwise element-wise with zero fill beyond `valid`.
+template <typename T, bool VEC>
+__device__ inline Frag16 load_row8(const T* p, int valid) {
   Frag16 r;
-  if (vec_ok && valid >= 8) {
-    r.u = *reinterpret_cast<const uint4*>(p);
+  if (VEC) {
+    r.u = valid > 0 ? *reinterpret_cast<const uint4*>(p) : make_uint4(0, 0, 0, 0);
   } else {
 #pragma unroll
     for (int j = 0; j < 8; ++j) r.e[j] = j < valid ? p[j].v : (uint16_t)0;
@@ -59,7 +69,7 @@ __device__ inline Frag16 load_row8(const T* p, int valid, bool vec_ok) {
   return r;
 }
 
-template <typename T, int DKP, int DVP>
+template <typename T, int DKP, int DVP, bool VEC, bool CAP>
 __global__ void __launch_bounds__(256)
 extend_attn_kernel(T* __restrict__ out, const T* __restrict__ q_ext, const T* __restrict__ k_ext,
                    const T* __restrict__ v_ext, const T* __restrict__ k_buf,
@@ -67,14 +77,16 @@ extend_attn_kernel(T* __restrict__ out, const T* __restrict__ q_ext, const T* __
                    const int32_t* __restrict__ kv_indptr, const int32_t* __restrict__ kv_indices,
                    int group, int Dk, int Dv, int64_t q_stride, int64_t k_stride, int64_t v_stride,
                    int64_t o_stride, int64_t kbuf_stride, int64_t vbuf_stride, float sm_scale,
-                   float logit_cap, int vec_ok) {
+                   float logit_cap) {
   constexpr int BM = 128, BN = 64;
   constexpr int KS = DKP + 8;  // K tile row stride in elements (16 B pad)
-  constexpr int VS = BN + 4;   // V^T tile row stride in elements (8 B pad)
+  // V tile row stride in elements: row bytes == 64 (mod 128), i.e. 16 or 48 dwords (mod 64), which
+  // makes the 4-row ds_read_b64_tr_b16 blocks conflict-free
+  constexpr int VS = DVP + (((DVP / 2) % 32 == 16) ? 0 : 32);
   constexpr int KSTEPS = DKP / 16;
   constexpr int DVT = DVP / 32;
   __shared__ __attribute__((aligned(16))) uint16_t k_lds[BN * KS];
-  __shared__ __attribute__((aligned(16))) uint16_t vt_lds[DVP * VS];
+  __shared__ __attribute__((aligned(16))) uint16_t v_lds[BN * VS];
 
   const int seq = blockIdx.z, hq = blockIdx.y, q0 = blockIdx.x * BM;
   const int hk = hq / group;
@@ -96,8 +108,7 @@ extend_attn_kernel(T* __restrict__ out, const T* __restrict__ q_ext, const T* __
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
       const int d0 = ks * 16 + hi * 8;
-      const int valid = q_valid ? min(8, Dk - d0) : 0;
-      qf[ks] = load_row8<T>(qrow + d0, valid, vec_ok);
+      qf[ks] = load_row8<T, VEC>(qrow + d0, q_valid ? min(8, Dk - d0) : 0);
     }
   }
 
@@ -106,123 +117,201 @@ extend_attn_kernel(T* __restrict__ out, const T* __restrict__ q_ext, const T* __
   for (int t = 0; t < DVT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o_acc[t][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;  // running max in the log2 domain
   const float LOG2E = 1.4426950408889634f;
   const float qk_scale = sm_scale * LOG2E;
 
-  // two phases: 0 = paged prefix (no mask), 1 = extend part (causal)
+  // KV tiles: first the paged prefix (no mask), then the extend part (causal).  Tile i+1 is
+  // fetched into registers while tile i is computed from LDS (issue early / write late).
   const int ext_end = min(ext_len, q0 + BM);
-  for (int phase = 0; phase < 2; ++phase) {
-    const int n_end = phase == 0 ? pre_len : ext_end;
-    for (int n0 = 0; n0 < n_end; n0 += BN) {
-      __syncthreads();  // previous tile fully consumed
-      // ---- stage K tile: rows n0..n0+63, row-major [kv][d] ----
-      {
-        constexpr int CH = DKP / 8;
-        for (int item = tid; item < BN * CH; item += 256) {
-          const int r = item / CH, c = item - r * CH;
-          const int n = n0 + r;
-          Frag16 x;
-          x.u = make_uint4(0, 0, 0, 0);
-          if (n < n_end) {
-            const T* row = phase == 0
-                               ? k_buf + (int64_t)kv_indices[kv_start + n] * kbuf_stride + (int64_t)hk * Dk
-                               : k_ext + (int64_t)(q_start + n) * k_stride + (int64_t)hk * Dk;
-            x = load_row8<T>(row + c * 8, min(8, Dk - c * 8), vec_ok);
-          }
-          *reinterpret_cast<uint4*>(&k_lds[r * KS + c * 8]) = x.u;
-        }
-      }
-      // ---- stage V tile transposed: vt[dv][kv] ----
-      {
-        constexpr int CH = DVP / 8;
-        for (int item = tid; item < (BN / 4) * CH; item += 256) {
-          const int rg = item / CH, c = item - rg * CH;
-          Frag16 x[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int n = n0 + rg * 4 + i;
-            x[i].u = make_uint4(0, 0, 0, 0);
-            if (n < n_end) {
-              const T* row = phase == 0
-                                 ? v_buf + (int64_t)kv_indices[kv_start + n] * vbuf_stride + (int64_t)hk * Dv
-                                 : v_ext + (int64_t)(q_start + n) * v_stride + (int64_t)hk * Dv;
-              x[i] = load_row8<T>(row + c * 8, min(8, Dv - c * 8), vec_ok);
-            }
-          }
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            uint2 w;
-            w.x = (uint32_t)x[0].e[j] | ((uint32_t)x[1].e[j] << 16);
-            w.y = (uint32_t)x[2].e[j] | ((uint32_t)x[3].e[j] << 16);
-            *reinterpret_cast<uint2*>(&vt_lds[(c * 8 + j) * VS + rg * 4]) = w;
-          }
-        }
-      }
-      __syncthreads();
+  const int n_pre_tiles = (pre_len + BN - 1) / BN;
+  const int n_ext_tiles = (ext_end + BN - 1) / BN;
+  const int n_tiles = n_pre_tiles + n_ext_tiles;
+  constexpr int CHK = DKP / 8, CHV = DVP / 8;
+  constexpr int NKI = (BN * CHK + 255) / 256, NVI = (BN * CHV + 255) / 256;
+  Frag16 kreg[NKI], vreg[NVI];
+  const T* k_head = k_buf + (int64_t)hk * Dk;
+  const T* v_head = v_buf + (int64_t)hk * Dv;
+  const T* ke_head = k_ext + (int64_t)q_start * k_stride + (int64_t)hk * Dk;
+  const T* ve_head = v_ext + (int64_t)q_start * v_stride + (int64_t)hk * Dv;
+  const int32_t* idx_base = kv_indices + kv_start;
 
-      // ---- S^T = K Q^T : two 32-row kv tiles ----
-      f32x16 s_acc[2];
+  // Per-thread staging slots: item = tid + i*256 -> (row r, 16-byte chunk c) of the tile.
+  // The pool-slot indices of a prefix tile are loaded ONE ITERATION before its rows so that the
+  // dependent index -> row address chain never stalls the wave in front of the MFMAs.
+  int32_t idxk[NKI], idxv[NVI];
+  auto load_idx = [&](int it) __attribute__((always_inline)) {
+    if (it < n_pre_tiles) {
+      const int n0 = it * BN;
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s_acc[kt][r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-          Frag16 a;
-          a.u = *reinterpret_cast<const uint4*>(&k_lds[(kt * 32 + col) * KS + ks * 16 + hi * 8]);
-          s_acc[kt] = Mfma<T>::mma(as_frag<T>(a), as_frag<T>(qf[ks]), s_acc[kt]);
-        }
+      for (int i = 0; i < NKI; ++i) {
+        const int n = n0 + (tid + i * 256) / CHK;
+        idxk[i] = n < pre_len ? idx_base[n] : 0;
       }
-      // ---- mask + online softmax (base-2) ----
-      float mx = m_run;
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
+      for (int i = 0; i < NVI; ++i) {
+        const int n = n0 + (tid + i * 256) / CHV;
+        idxv[i] = n < pre_len ? idx_base[n] : 0;
+      }
+    }
+  };
+  auto fetch = [&](int it) __attribute__((always_inline)) {
+    if (it < n_pre_tiles) {  // paged prefix: rows through the indices loaded one iteration ago
+      const int n0 = it * BN;
+#pragma unroll
+      for (int i = 0; i < NKI; ++i) {
+        const int item = tid + i * 256;
+        const int r = item / CHK, c = item - r * CHK;
+        kreg[i].u = make_uint4(0, 0, 0, 0);
+        if ((BN * CHK % 256 == 0 || item < BN * CHK) && n0 + r < pre_len)
+          kreg[i] = load_row8<T, VEC>(k_head + (int64_t)idxk[i] * kbuf_stride + c * 8, min(8, Dk - c * 8));
+      }
+#pragma unroll
+      for (int i = 0; i < NVI; ++i) {
+        const int item = tid + i * 256;
+        const int r = item / CHV, c = item - r * CHV;
+        vreg[i].u = make_uint4(0, 0, 0, 0);  // rows past the end stay zero: 0 * garbage could be NaN
+        if ((BN * CHV % 256 == 0 || item < BN * CHV) && n0 + r < pre_len)
+          vreg[i] = load_row8<T, VEC>(v_head + (int64_t)idxv[i] * vbuf_stride + c * 8, min(8, Dv - c * 8));
+      }
+    } else {  // the new tokens: contiguous rows
+      const int n0 = (it - n_pre_tiles) * BN;
+#pragma unroll
+      for (int i = 0; i < NKI; ++i) {
+        const int item = tid + i * 256;
+        const int r = item / CHK, c = item - r * CHK;
+        kreg[i].u = make_uint4(0, 0, 0, 0);
+        if ((BN * CHK % 256 == 0 || item < BN * CHK) && n0 + r < ext_end)
+          kreg[i] = load_row8<T, VEC>(ke_head + (int64_t)(n0 + r) * k_stride + c * 8, min(8, Dk - c * 8));
+      }
+#pragma unroll
+      for (int i = 0; i < NVI; ++i) {
+        const int item = tid + i * 256;
+        const int r = item / CHV, c = item - r * CHV;
+        vreg[i].u = make_uint4(0, 0, 0, 0);
+        if ((BN * CHV % 256 == 0 || item < BN * CHV) && n0 + r < ext_end)
+          vreg[i] = load_row8<T, VEC>(ve_head + (int64_t)(n0 + r) * v_stride + c * 8, min(8, Dv - c * 8));
+      }
+    }
+  };
+
+  // 16-lane group g = lane >> 4 of the transposing read: dv block (g & 1) * 16 of a 32-wide tile,
+  // kv rows 4*hi + ...; lane i of the group supplies row (i >> 2), columns 4*(i & 3) .. +3 and
+  // receives column i.
+  const int gi = lane & 15;
+  const uint16_t* vbase = &v_lds[(hi * 4 + (gi >> 2)) * VS + ((lane >> 4) & 1) * 16 + (gi & 3) * 4];
+  const uint16_t* kbase = &k_lds[col * KS + hi * 8];
+
+  load_idx(0);
+  if (n_tiles > 0) fetch(0);
+  load_idx(1);
+  for (int it = 0; it < n_tiles; ++it) {
+    const bool pre = it < n_pre_tiles;
+    const int n0 = (pre ? it : it - n_pre_tiles) * BN;
+    const int n_end = pre ? pre_len : ext_end;
+    __syncthreads();  // previous tile fully consumed
+#pragma unroll
+    for (int i = 0; i < NKI; ++i) {
+      const int item = tid + i * 256;
+      const int r = item / CHK, c = item - r * CHK;
+      if (BN * CHK % 256 == 0 || item < BN * CHK)
+        *reinterpret_cast<uint4*>(&k_lds[r * KS + c * 8]) = kreg[i].u;
+    }
+#pragma unroll
+    for (int i = 0; i < NVI; ++i) {
+      const int item = tid + i * 256;
+      const int r = item / CHV, c = item - r * CHV;
+      if (BN * CHV % 256 == 0 || item < BN * CHV)
+        *reinterpret_cast<uint4*>(&v_lds[r * VS + c * 8]) = vreg[i].u;
+    }
+    __syncthreads();
+    if (it + 1 < n_tiles) fetch(it + 1);  // in flight during the MFMAs below
+    load_idx(it + 2);
+
+    // this wave's rows are q0 + wave*32 .. +31: a causal tile entirely above them is all masked
+    const int w_row0 = q0 + wave * 32;
+    if (!pre && n0 > w_row0 + 31) continue;
+
+    // ---- S^T = K Q^T : two 32-row kv tiles ----
+    f32x16 s_acc[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s_acc[kt][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        Frag16 a;
+        a.u = *reinterpret_cast<const uint4*>(kbase + kt * 32 * KS + ks * 16);
+        s_acc[kt] = Mfma<T>::mma(as_frag<T>(a), as_frag<T>(qf[ks]), s_acc[kt]);
+      }
+    }
+    // ---- scale (+cap) and mask; masking only on boundary tiles (wave-uniform test) ----
+    const bool need_mask = (n0 + BN > n_end) || (!pre && n0 + BN - 1 > w_row0);
+    if (CAP && logit_cap > 0.f) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          s_acc[kt][r] = logit_cap * tanhf(s_acc[kt][r] * sm_scale / logit_cap) * LOG2E;
+    } else {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s_acc[kt][r] *= qk_scale;
+    }
+    if (need_mask) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int n = n0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          const bool ok = n < n_end && (phase == 0 || n <= q_local);
-          float s = s_acc[kt][r];
-          if (logit_cap > 0.f) s = logit_cap * tanhf(s * sm_scale / logit_cap) * LOG2E;
-          else s *= qk_scale;
-          s = ok ? s : -INFINITY;
-          s_acc[kt][r] = s;
-          mx = fmaxf(mx, s);
+          const bool ok = n < n_end && (pre || n <= q_local);
+          s_acc[kt][r] = ok ? s_acc[kt][r] : -INFINITY;
         }
-      }
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float alpha = (m_run == -INFINITY) ? 0.f : exp2f(m_run - mx);  // mx >= m_run
-      const float m_use = (mx == -INFINITY) ? 0.f : mx;                      // all masked so far
-      float psum = 0.f;
-      Frag16 pf[2][2];
+    }
+    float mx = -INFINITY;
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
+    for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float p = exp2f(s_acc[kt][r] - m_use);  // exp2(-inf) = 0
-          psum += p;
-          pf[kt][r >> 3].e[r & 7] = Elem<T>::from_f(p).v;
-        }
-      }
-      l_run = l_run * alpha + psum;
-      m_run = mx;
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s_acc[kt][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    // ---- online softmax (base 2) ----
+    const float m_new = fmaxf(m_run, mx);
+    if (__any(m_new > m_run)) {
+      const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
 #pragma unroll
       for (int t = 0; t < DVT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o_acc[t][r] *= alpha;
-      // ---- O^T += V^T P^T ----
+      m_run = m_new;
+    }
+    const float m_use = (m_run == -INFINITY) ? 0.f : m_run;  // everything masked so far
+    float psum = 0.f;
+    Frag16 pf[2][2];
 #pragma unroll
-      for (int t = 0; t < DVT; ++t) {
+    for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
+      for (int r = 0; r < 16; r += 2) {
+        const float p0 = __builtin_amdgcn_exp2f(s_acc[kt][r] - m_use);  // exp2(-inf) = 0
+        const float p1 = __builtin_amdgcn_exp2f(s_acc[kt][r + 1] - m_use);
+        psum += p0 + p1;
+        pf[kt][r >> 3].w[(r & 7) >> 1] = pack2<T>(p0, p1);
+      }
+    }
+    l_run += psum;
+    // ---- O^T += V^T P^T : V^T fragments through the transposing LDS read ----
 #pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2) {
-            Frag16 a;
-            const uint16_t* vrow = &vt_lds[(t * 32 + col) * VS + kt * 32 + s2 * 16 + hi * 4];
-            a.h[0] = *reinterpret_cast<const uint2*>(vrow);
-            a.h[1] = *reinterpret_cast<const uint2*>(vrow + 8);
-            o_acc[t] = Mfma<T>::mma(as_frag<T>(a), as_frag<T>(pf[kt][s2]), o_acc[t]);
-          }
+    for (int t = 0; t < DVT; ++t) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          Frag16 a;
+          const uint16_t* vp = vbase + (kt * 32 + s2 * 16) * VS + t * 32;
+          a.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp));
+          a.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp + 8 * VS));
+          o_acc[t] = Mfma<T>::mma(as_frag<T>(a), as_frag<T>(pf[kt][s2]), o_acc[t]);
         }
       }
     }
@@ -238,13 +327,13 @@ extend_attn_kernel(T* __restrict__ out, const T* __restrict__ q_ext, const T* __
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
         const int dv0 = t * 32 + 8 * r4 + 4 * hi;
-        if (vec_ok && dv0 + 4 <= Dv) {
-          uint2 w;
-          w.x = (uint32_t)Elem<T>::from_f(o_acc[t][r4 * 4 + 0] * inv).v |
-                ((uint32_t)Elem<T>::from_f(o_acc[t][r4 * 4 + 1] * inv).v << 16);
-          w.y = (uint32_t)Elem<T>::from_f(o_acc[t][r4 * 4 + 2] * inv).v |
-                ((uint32_t)Elem<T>::from_f(o_acc[t][r4 * 4 + 3] * inv).v << 16);
-          *reinterpret_cast<uint2*>(orow + dv0) = w;
+        if (VEC) {
+          if (dv0 < Dv) {
+            uint2 w;
+            w.x = pack2<T>(o_acc[t][r4 * 4 + 0] * inv, o_acc[t][r4 * 4 + 1] * inv);
+            w.y = pack2<T>(o_acc[t][r4 * 4 + 2] * inv, o_acc[t][r4 * 4 + 3] * inv);
+            *reinterpret_cast<uint2*>(orow + dv0) = w;
+          }
         } else {
 #pragma unroll
           for (int j = 0; j < 4; ++j)
@@ -324,6 +413,30 @@ extend_attn_generic_kernel(T* __restrict__ out, const T* __restrict__ q_ext,
   }
 }
 
+template <typename T, bool VEC, bool CAP>
+static int launch_extend_variant(void* out, const void* q, const void* k, const void* v, const void* k_buf,
+                                 const void* v_buf, const int32_t* qo_indptr, const int32_t* kv_indptr,
+                                 const int32_t* kv_indices, int64_t batch, int Hq, int group, int Dk, int Dv,
+                                 int64_t q_stride, int64_t k_stride, int64_t v_stride, int64_t o_stride,
+                                 int64_t kbuf_stride, int64_t vbuf_stride, int max_len_extend, float sm_scale,
+                                 float logit_cap, hipStream_t st) {
+  const int dkp = (Dk + 15) / 16 * 16, dvp = (Dv + 31) / 32 * 32;
+  dim3 grid((unsigned)((max_len_extend + 127) / 128), (unsigned)Hq, (unsigned)batch), block(256);
+#define EXT(DKP, DVP)                                                                              \
+  hipLaunchKernelGGL((extend_attn_kernel<T, DKP, DVP, VEC, CAP>), grid, block, 0, st, (T*)out,     \
+                     (const T*)q, (const T*)k, (const T*)v, (const T*)k_buf, (const T*)v_buf,       \
+                     qo_indptr, kv_indptr, kv_indices, group, Dk, Dv, q_stride, k_stride, v_stride, \
+                     o_stride, kbuf_stride, vbuf_stride, sm_scale, logit_cap)
+  if (dkp <= 16 && dvp <= 32) EXT(16, 32);
+  else if (dkp <= 64 && dvp <= 64) EXT(64, 64);
+  else if (dkp <= 96 && dvp <= 96) EXT(96, 96);
+  else if (dkp <= 128 && dvp <= 128) EXT(128, 128);
+  else if (dkp <= 192 && dvp <= 128) EXT(192, 128);
+  else return 1;  // no MFMA instantiation
+#undef EXT
+  return 0;
+}
+
 template <typename T>
 static int run_extend(void* out, const void* q, const void* k, const void* v, const void* k_buf,
                       const void* v_buf, const int32_t* qo_indptr, const int32_t* kv_indptr,
@@ -332,33 +445,26 @@ static int run_extend(void* out, const void* q, const void* k, const void* v, co
                       int64_t kbuf_stride, int64_t vbuf_stride, int max_len_extend, float sm_scale,
                       float logit_cap, hipStream_t st) {
   const int group = Hq / Hkv;
-  const int vec_ok = (Dk % 8 == 0 && Dv % 8 == 0 && q_stride % 8 == 0 && k_stride % 8 == 0 &&
+  const bool vec_ok = Dk % 8 == 0 && Dv % 8 == 0 && q_stride % 8 == 0 && k_stride % 8 == 0 &&
                       v_stride % 8 == 0 && o_stride % 4 == 0 && kbuf_stride % 8 == 0 &&
                       vbuf_stride % 8 == 0 && aligned16(q) && aligned16(k) && aligned16(v) &&
-                      aligned16(k_buf) && aligned16(v_buf) &&
-                      (reinterpret_cast<uintptr_t>(out) & 7u) == 0)
-                         ? 1
-                         : 0;
-  const int dkp = (Dk + 15) / 16 * 16, dvp = (Dv + 31) / 32 * 32;
-  dim3 grid((unsigned)((max_len_extend + 127) / 128), (unsigned)Hq, (unsigned)batch), block(256);
-#define EXT(DKP, DVP)                                                                              \
-  hipLaunchKernelGGL((extend_attn_kernel<T, DKP, DVP>), grid, block, 0, st, (T*)out, (const T*)q,  \
-                     (const T*)k, (const T*)v, (const T*)k_buf, (const T*)v_buf, qo_indptr,         \
-                     kv_indptr, kv_indices, group, Dk, Dv, q_stride, k_stride, v_stride, o_stride,  \
-                     kbuf_stride, vbuf_stride, sm_scale, logit_cap, vec_ok)
-  if (dkp <= 16 && dvp <= 32) EXT(16, 32);
-  else if (dkp <= 64 && dvp <= 64) EXT(64, 64);
-  else if (dkp <= 96 && dvp <= 96) EXT(96, 96);
-  else if (dkp <= 128 && dvp <= 128) EXT(128, 128);
-  else if (dkp <= 192 && dvp <= 128) EXT(192, 128);
-  else {
+                      aligned16(k_buf) && aligned16(v_buf) && (reinterpret_cast<uintptr_t>(out) & 7u) == 0;
+  int miss;
+#define VARIANT(V, C)                                                                                 \
+  launch_extend_variant<T, V, C>(out, q, k, v, k_buf, v_buf, qo_indptr, kv_indptr, kv_indices, batch, Hq, \
+                                 group, Dk, Dv, q_stride, k_stride, v_stride, o_stride, kbuf_stride,      \
+                                 vbuf_stride, max_len_extend, sm_scale, logit_cap, st)
+  if (vec_ok && !(logit_cap > 0.f)) miss = VARIANT(true, false);
+  else if (vec_ok) miss = VARIANT(true, true);
+  else miss = VARIANT(false, true);
+#undef VARIANT
+  if (miss) {
     dim3 g2((unsigned)max_len_extend, (unsigned)Hq, (unsigned)batch);
     hipLaunchKernelGGL((extend_attn_generic_kernel<T>), g2, dim3(64), 0, st, (T*)out, (const T*)q,
                        (const T*)k, (const T*)v, (const T*)k_buf, (const T*)v_buf, qo_indptr,
                        kv_indptr, kv_indices, group, Dk, Dv, q_stride, k_stride, v_stride, o_stride,
                        kbuf_stride, vbuf_stride, sm_scale, logit_cap);
   }
-#undef EXT
   return launch_status("extend_attention");
 }
 
