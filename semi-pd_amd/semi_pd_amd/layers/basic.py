@@ -189,6 +189,22 @@ class ColumnParallelLinear(nn.Module):
                                    requires_grad=False)
         self.bias = nn.Parameter(torch.zeros(self.output_size_per_partition, dtype=params_dtype),
                                  requires_grad=False) if bias else None
+        self._tag_shards(input_size, output_size)
+
+    def _row_ranges(self, output_size: int):
+        """Row ranges of the full [out, in] weight owned by this rank (weight_loader semantics,
+        layers/linear.py:350-400)."""
+        tp, rank = get_tensor_model_parallel_world_size(), get_tensor_model_parallel_rank()
+        n = output_size // tp
+        return [(rank * n, (rank + 1) * n)]
+
+    def _tag_shards(self, input_size: int, output_size: int):
+        ranges = self._row_ranges(output_size)
+        self.weight.tp_full_shape = (output_size, input_size)
+        self.weight.tp_shard = lambda full: torch.cat([full[a:b] for a, b in ranges], 0)
+        if self.bias is not None:
+            self.bias.tp_full_shape = (output_size,)
+            self.bias.tp_shard = lambda full: torch.cat([full[a:b] for a, b in ranges], 0)
 
     def forward(self, x):
         return F.linear(x, self.weight, self.bias)
@@ -200,6 +216,15 @@ class MergedColumnParallelLinear(ColumnParallelLinear):
     def __init__(self, input_size: int, output_sizes, bias: bool = False, params_dtype=None):
         self.output_sizes = list(output_sizes)
         super().__init__(input_size, sum(output_sizes), bias, params_dtype)
+
+    def _row_ranges(self, output_size: int):
+        tp, rank = get_tensor_model_parallel_world_size(), get_tensor_model_parallel_rank()
+        out, base = [], 0
+        for size in self.output_sizes:
+            n = size // tp
+            out.append((base + rank * n, base + (rank + 1) * n))
+            base += size
+        return out
 
 
 class QKVParallelLinear(ColumnParallelLinear):
@@ -217,8 +242,25 @@ class QKVParallelLinear(ColumnParallelLinear):
         else:
             self.num_kv_heads = 1
             self.num_kv_head_replicas = _shard(tp, total_num_kv_heads)
+        self.total_num_heads, self.total_num_kv_heads = total_num_heads, total_num_kv_heads
         out = (self.num_heads + 2 * self.num_kv_heads) * tp * head_size
         super().__init__(hidden_size, out, bias, params_dtype)
+
+    def _row_ranges(self, output_size: int):
+        # full layout: [q heads | k heads | v heads] (linear.py:880-960 shard ids "q","k","v")
+        rank = get_tensor_model_parallel_rank()
+        d = self.head_size
+        q0 = rank * self.num_heads * d
+        kv_rank = rank // self.num_kv_head_replicas
+        k_base = self.total_num_heads * d
+        v_base = k_base + self.total_num_kv_heads * d
+        kn = self.num_kv_heads * d
+        return [(q0, q0 + self.num_heads * d), (k_base + kv_rank * kn, k_base + (kv_rank + 1) * kn),
+                (v_base + kv_rank * kn, v_base + (kv_rank + 1) * kn)]
+
+    def _tag_shards(self, input_size: int, output_size: int):
+        full_out = (self.total_num_heads + 2 * self.total_num_kv_heads) * self.head_size
+        super()._tag_shards(input_size, full_out)
 
 
 class RowParallelLinear(nn.Module):
@@ -233,6 +275,9 @@ class RowParallelLinear(nn.Module):
         self.weight = nn.Parameter(torch.empty(output_size, self.input_size_per_partition, dtype=params_dtype),
                                    requires_grad=False)
         self.bias = nn.Parameter(torch.zeros(output_size, dtype=params_dtype), requires_grad=False) if bias else None
+        rank, n = get_tensor_model_parallel_rank(), self.input_size_per_partition
+        self.weight.tp_full_shape = (output_size, input_size)
+        self.weight.tp_shard = lambda full: full[:, rank * n:(rank + 1) * n].contiguous()
 
     def forward(self, x):
         # bias is added on rank 0 only so that the sum over ranks adds it once (linear.py:1258-1262)
@@ -260,6 +305,17 @@ class VocabParallelEmbedding(nn.Module):
         self.tp_size = tp
         self.weight = nn.Parameter(torch.empty(self.num_embeddings_per_partition, embedding_dim,
                                                dtype=params_dtype), requires_grad=False)
+        a, b, org = self.vocab_start_index, self.vocab_end_index, num_embeddings
+        self.weight.tp_full_shape = (num_embeddings, embedding_dim)
+
+        def shard(full):  # rows of the real vocabulary, zero rows for the padding
+            out = torch.zeros(b - a, full.shape[1], dtype=full.dtype, device=full.device)
+            hi = min(b, org)
+            if hi > a:
+                out[: hi - a] = full[a:hi]
+            return out
+
+        self.weight.tp_shard = shard
 
     def forward(self, input_ids: torch.Tensor):
         if self.tp_size == 1:

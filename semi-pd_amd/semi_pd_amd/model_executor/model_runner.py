@@ -67,7 +67,27 @@ def dummy_init_weights(model: nn.Module, device: torch.device, seed: int = 0, st
         else:
             g = torch.Generator(device=device)
             g.manual_seed(_seed_of(name, seed))
-            p.copy_(torch.randn(p.shape, generator=g, device=device, dtype=torch.float32).mul_(std).to(p.dtype))
+            # tensor-parallel shards are slices of ONE full-size draw, so TP=n computes the same model
+            # as TP=1 (weight_loader semantics of layers/linear.py)
+            full_shape = getattr(p, "tp_full_shape", tuple(p.shape))
+            full = torch.randn(full_shape, generator=g, device=device, dtype=torch.float32).mul_(std).to(p.dtype)
+            p.copy_(p.tp_shard(full) if hasattr(p, "tp_shard") else full)
+
+
+@torch.no_grad()
+def load_full_state_dict(model: nn.Module, full_sd: Dict[str, torch.Tensor]):
+    """Load an unsharded state_dict (product parameter names): each rank keeps its shard."""
+    params = dict(model.named_parameters(remove_duplicate=False))
+    bufs = dict(model.named_buffers(remove_duplicate=False))
+    for name, full in full_sd.items():
+        if name in params:
+            p = params[name]
+            src = full.to(p.device, p.dtype)
+            p.copy_(p.tp_shard(src) if (hasattr(p, "tp_shard") and tuple(src.shape) != tuple(p.shape)) else src)
+        elif name in bufs:
+            bufs[name].copy_(full.to(bufs[name].device, bufs[name].dtype))
+        else:
+            raise KeyError(f"unexpected parameter {name}")
 
 
 class ModelRunner:
@@ -109,8 +129,7 @@ class ModelRunner:
                 with torch.device(self.device):
                     self.model = build_model(model_config, dtype)
                 if load_state_dict is not None:
-                    missing = self.model.load_state_dict(load_state_dict, strict=False)
-                    assert not missing.unexpected_keys, missing
+                    load_full_state_dict(self.model, load_state_dict)
                 else:
                     dummy_init_weights(self.model, self.device, seed)
         finally:

@@ -1,0 +1,212 @@
+"""world_size-2 tests of the N>1 path on CPU over gloo (the GPU boxes available to the build are
+single-GPU): TP linear / embedding / logits sharding + all-reduce / all-gather against the unsharded
+computation, scheduler-message broadcast, and the Semi-PD P<->D protocol with two TP ranks per
+instance (rank 0 owns the sockets, rank 1 follows the broadcasts; semi_pd_prefill_scheduler.py:140-147,
+semi_pd_decode_scheduler.py:363-364)."""
+import multiprocessing as mp
+import os
+import socket
+import sys
+import traceback
+
+import pytest
+import torch
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(rank, world, port, fn_name, q, paths):
+    try:
+        for p in paths:
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        torch.set_num_threads(1)
+        from semi_pd_amd import distributed as D
+        D.init_distributed_environment(world, rank, f"tcp://127.0.0.1:{port}", backend="gloo")
+        out = globals()[fn_name](rank, world)
+        q.put((rank, "ok", out))
+        D.destroy_distributed_environment()
+    except Exception:
+        q.put((rank, "error", traceback.format_exc()))
+
+
+def _spawn(fn_name, world=2, timeout=120):
+    from conftest import PKG, ROOT
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_run, args=(r, world, port, fn_name, q, [ROOT, PKG, os.path.join(ROOT, "tests")]))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    results = {}
+    for _ in range(world):
+        rank, status, out = q.get(timeout=timeout)
+        assert status == "ok", f"rank {rank}:\n{out}"
+        results[rank] = out
+    for p in procs:
+        p.join(30)
+    return results
+
+
+# ------------------------------------------------------------------------------ worker bodies
+def _tp_layers(rank, world):
+    import torch.nn.functional as F
+    from semi_pd_amd.layers.basic import (MergedColumnParallelLinear, QKVParallelLinear, RowParallelLinear,
+                                          VocabParallelEmbedding)
+    from semi_pd_amd.distributed import tensor_model_parallel_all_gather
+    g = torch.Generator().manual_seed(0)
+    H, Hq, Hkv, D, I, V = 64, 4, 2, 16, 96, 100
+    x = torch.randn(7, H, generator=g)
+    full = {"qkv": torch.randn((Hq + 2 * Hkv) * D, H, generator=g), "o": torch.randn(H, Hq * D, generator=g),
+            "gu": torch.randn(2 * I, H, generator=g), "down": torch.randn(H, I, generator=g),
+            "emb": torch.randn(V, H, generator=g), "ids": torch.randint(0, V, (7,), generator=g)}
+    qkv = QKVParallelLinear(H, D, Hq, Hkv, params_dtype=torch.float32)
+    o = RowParallelLinear(Hq * D, H, params_dtype=torch.float32)
+    gu = MergedColumnParallelLinear(H, [I, I], params_dtype=torch.float32)
+    down = RowParallelLinear(I, H, params_dtype=torch.float32)
+    emb = VocabParallelEmbedding(V, H, params_dtype=torch.float32)
+    for layer, key in ((qkv, "qkv"), (o, "o"), (gu, "gu"), (down, "down"), (emb, "emb")):
+        layer.weight.data.copy_(layer.weight.tp_shard(full[key]))
+    # attention-less block: per-head "attention" = identity on v, so q/k shards only need the right shape
+    y = qkv(x)
+    q, k, v = y.split([qkv.num_heads * D, qkv.num_kv_heads * D, qkv.num_kv_heads * D], dim=-1)
+    rep = qkv.num_heads // qkv.num_kv_heads
+    attn = v.view(7, qkv.num_kv_heads, 1, D).expand(7, qkv.num_kv_heads, rep, D).reshape(7, -1) + q
+    h = o(attn)
+    a = gu(h)
+    h2 = down(F.silu(a[:, : a.shape[1] // 2]) * a[:, a.shape[1] // 2:])
+    e = emb(full["ids"])
+    logits = tensor_model_parallel_all_gather(torch.matmul(h2, emb.weight.T))[:, :V]
+    # unsharded reference
+    yq, yk, yv = (x @ full["qkv"].T).split([Hq * D, Hkv * D, Hkv * D], dim=-1)
+    attn_f = yv.view(7, Hkv, 1, D).expand(7, Hkv, Hq // Hkv, D).reshape(7, -1) + yq
+    h_f = attn_f @ full["o"].T
+    a_f = h_f @ full["gu"].T
+    h2_f = (F.silu(a_f[:, :I]) * a_f[:, I:]) @ full["down"].T
+    torch.testing.assert_close(h, h_f, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(h2, h2_f, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(e, full["emb"][full["ids"]], rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(logits, h2_f @ full["emb"].T, rtol=1e-4, atol=1e-2)
+    return True
+
+
+def _broadcast(rank, world):
+    from semi_pd_amd.distributed import barrier_cpu, broadcast_pyobj, get_tp_cpu_group
+    data = [{"rids": ["a", "b"], "x": list(range(1000))}] if rank == 0 else []
+    got = broadcast_pyobj(data, rank, get_tp_cpu_group(), src=0)
+    barrier_cpu()
+    return got[0]["rids"] == ["a", "b"] and len(got[0]["x"]) == 1000
+
+
+def _sched_proc(role, rank, port, r2t, kv, names, q, paths):
+    """One scheduler process of the 4-process topology (P0, P1, D0, D1): two gloo worlds (one per
+    role, like the separate NCCL worlds of scheduler.py:249-259), AF_UNIX PUSH/PULL sockets on rank 0,
+    req_to_token / fake-KV tensors shared between P_r and D_r (standing in for hipIpcMemHandle)."""
+    try:
+        for p in paths:
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        torch.set_num_threads(1)
+        import test_semi_pd_protocol_cpu as T
+        from semi_pd_amd import distributed as D
+        from semi_pd_amd.managers.semi_pd_decode_scheduler import SemiPDDecodeScheduler
+        from semi_pd_amd.managers.semi_pd_prefill_scheduler import SemiPDPrefillScheduler
+        from semi_pd_amd.managers.transport import PullSocket, PushSocket
+        from semi_pd_amd.mem_cache.memory_pool import ReqToTokenPool, TokenToKVPoolAllocator
+        from types import SimpleNamespace
+        D.init_distributed_environment(2, rank, f"tcp://127.0.0.1:{port}", backend="gloo")
+        pool = ReqToTokenPool(r2t.shape[0], r2t.shape[1], "cpu", bypass_create_buffers=True)
+        pool.req_to_token = r2t
+        runner = SimpleNamespace(device=torch.device("cpu"), req_to_token_pool=pool,
+                                 token_to_kv_pool_allocator=TokenToKVPoolAllocator(4000, torch.bfloat16, "cpu", None),
+                                 max_total_num_tokens=4000)
+        sa = T.args(tp_size=2, watchdog_timeout=30.0)
+        r0 = rank == 0
+        if role == "D":
+            s = SemiPDDecodeScheduler(sa, runner, rank, PullSocket(names["d_in"]) if r0 else None,
+                                      PushSocket(names["tok"]) if r0 else None,
+                                      PushSocket(names["bridge"]) if r0 else None,
+                                      PushSocket(names["p_in"]) if r0 else None)
+        else:
+            s = SemiPDPrefillScheduler(sa, runner, rank, PullSocket(names["p_in"]) if r0 else None,
+                                       PushSocket(names["d_in"]) if r0 else None,
+                                       PullSocket(names["bridge"]) if r0 else None)
+        s.tp_worker = T.FakeWorker(runner, kv)
+        q.put((role, rank, "ready", None))
+        s.event_loop_normal()
+        q.put((role, rank, "done", runner.token_to_kv_pool_allocator.available_size()))
+        D.destroy_distributed_environment()
+    except Exception:
+        q.put((role, rank, "error", traceback.format_exc()))
+
+
+# ------------------------------------------------------------------------------ tests
+def test_tp2_layers_match_unsharded():
+    assert all(_spawn("_tp_layers").values())
+
+
+def test_tp2_broadcast_pyobj():
+    assert all(_spawn("_broadcast").values())
+
+
+def test_tp2_semi_pd_protocol_four_processes(tmp_path):
+    import time
+    import test_semi_pd_protocol_cpu as T
+    from conftest import PKG, ROOT
+    from semi_pd_amd.managers.io_struct import SamplingParams, ShutdownReq, TokenizedGenerateReqInput
+    from semi_pd_amd.managers.transport import NOTHING, PullSocket, PushSocket
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    names = {k: str(tmp_path / k) for k in ("d_in", "p_in", "bridge", "tok")}
+    ports = {"P": _free_port(), "D": _free_port()}
+    paths = [ROOT, PKG, os.path.join(ROOT, "tests")]
+    shared = {r: (torch.zeros(33, 516, dtype=torch.int32).share_memory_(),
+                  torch.zeros(4001, dtype=torch.int64).share_memory_()) for r in (0, 1)}
+    tok = PullSocket(names["tok"])
+    procs = [ctx.Process(target=_sched_proc, args=(role, r, ports[role], shared[r][0], shared[r][1], names, q, paths))
+             for role in ("D", "P") for r in (0, 1)]
+    for p in procs:
+        p.start()
+    try:
+        for _ in range(4):
+            role, rank, status, info = q.get(timeout=120)
+            assert status == "ready", f"{role}{rank}:\n{info}"
+        d_in, p_in = PushSocket(names["d_in"]), PushSocket(names["p_in"])
+        prompts = T.prompts_of([5, 40, 150, 12, 33, 90], seed=9)
+        for i, pr in enumerate(prompts):
+            req = TokenizedGenerateReqInput(f"r{i}", None, list(pr), SamplingParams(max_new_tokens=7, ignore_eos=True))
+            d_in.send_pyobj(req)  # D first, then P
+            p_in.send_pyobj(req)
+        got = {}
+        deadline = time.time() + 60
+        while time.time() < deadline and not (len(got) == len(prompts) and all(len(v) >= 7 for v in got.values())):
+            o = tok.recv_pyobj_nowait()
+            if o is NOTHING:
+                time.sleep(0.002)
+                continue
+            for rid, toks in zip(o.rids, o.output_ids):
+                got.setdefault(rid, []).extend(toks)
+        assert [got.get(f"r{i}") for i in range(len(prompts))] == [T.expected(pr, 7) for pr in prompts]
+        d_in.send_pyobj(ShutdownReq())
+        p_in.send_pyobj(ShutdownReq())
+        done = {}
+        for _ in range(4):
+            role, rank, status, info = q.get(timeout=60)
+            assert status == "done", f"{role}{rank}:\n{info}"
+            done[(role, rank)] = info
+        # both TP ranks of the decode instance mirrored every allocation and freed everything
+        assert done[("D", 0)] == 4000 and done[("D", 1)] == 4000
+        assert done[("P", 0)] == 4000 and done[("P", 1)] == 4000  # the prefill instance never allocates
+    finally:
+        for p in procs:
+            p.join(10)
+            if p.is_alive():
+                p.terminate()
+        tok.close()
