@@ -39,6 +39,9 @@ def model_config(name: str):
         return LLAMA3_70B
     if name == "opt-125m":
         return OPT_125M
+    if name == "deepseek-v2-lite":
+        from semi_pd_amd.models.deepseek_v2 import DEEPSEEK_V2_LITE
+        return DEEPSEEK_V2_LITE
     if name == "llama-tiny":
         return LlamaConfig(vocab_size=32000, hidden_size=1024, intermediate_size=2816, num_hidden_layers=4,
                            num_attention_heads=8, num_key_value_heads=2, max_position_embeddings=8192)
@@ -250,7 +253,7 @@ def main():
                                          "frac": round(k["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4),
                                          "avg_launch_us": round(k["avg_us"], 1), "launches_sampled": k["launches"]}
     cpu = None
-    if not args.no_cpu_baseline and hasattr(cfg, "rms_norm_eps"):
+    if not args.no_cpu_baseline and cfg.architectures[0] == "LlamaForCausalLM":
         try:
             cpu = cpu_baseline(cfg, args.input_len, args.output_len)
         except Exception as e:  # the baseline must never take the measured number down with it

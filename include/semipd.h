@@ -79,6 +79,15 @@ int semipd_rope_inplace(void* q, void* k, const float* cos_sin_cache, const int6
                         int rot_dim, int64_t q_stride, int64_t k_stride, int interleave, int dtype,
                         void* stream);
 
+/* Same rotation on head slices that are not densely packed: q / k point at the first rotary element
+ * of head 0, token and head strides in elements.  Used by MLA, where q_pe = q[..., 128:] (head stride
+ * 192) and k_pe = latent[..., 512:] (one 64-wide "head" in a 576-wide row), GPT-J pairing
+ * (replaces DeepseekScalingRotaryEmbedding.forward, layers/rotary_embedding.py:710-748). */
+int semipd_rope_inplace_strided(void* q, void* k, const float* cos_sin_cache, const int64_t* positions,
+                                int64_t num_tokens, int num_q_heads, int num_k_heads, int rot_dim,
+                                int64_t q_token_stride, int64_t q_head_stride, int64_t k_token_stride,
+                                int64_t k_head_stride, int interleave, int dtype, void* stream);
+
 /* Fused a2+a3: rotate q in place, rotate k, and scatter rotated k and v into
  * the paged pool rows k_buf[loc[t]], v_buf[loc[t]] (row = Hk*head elements,
  * pool row stride in elements).  k itself is also updated in place so callers

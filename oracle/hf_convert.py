@@ -51,3 +51,28 @@ def pad_vocab(sd: Dict[str, torch.Tensor], keys, multiple: int = 64) -> Dict[str
         if pad:
             out[k] = torch.cat([w, torch.zeros(pad, w.shape[1], dtype=w.dtype)], 0)
     return out
+
+
+def deepseek_v2_from_hf(sd: Dict[str, torch.Tensor], cfg) -> Dict[str, torch.Tensor]:
+    """HF DeepseekV2ForCausalLM names -> product names (models/deepseek_v2.py load_weights mapping:
+    gate/up -> gate_up_proj, experts -> w13_weight / w2_weight)."""
+    out = {"model.embed_tokens.weight": sd["model.embed_tokens.weight"], "model.norm.weight": sd["model.norm.weight"],
+           "lm_head.weight": sd["lm_head.weight"]}
+    for i in range(cfg.num_hidden_layers):
+        p = f"model.layers.{i}."
+        for k in ("self_attn.q_proj.weight", "self_attn.kv_a_proj_with_mqa.weight", "self_attn.kv_a_layernorm.weight",
+                  "self_attn.kv_b_proj.weight", "self_attn.o_proj.weight", "input_layernorm.weight",
+                  "post_attention_layernorm.weight"):
+            out[p + k] = sd[p + k]
+        if p + "mlp.gate.weight" in sd:
+            out[p + "mlp.gate.weight"] = sd[p + "mlp.gate.weight"]
+            out[p + "mlp.experts.w13_weight"] = sd[p + "mlp.experts.gate_up_proj"]
+            out[p + "mlp.experts.w2_weight"] = sd[p + "mlp.experts.down_proj"]
+            sp = p + "mlp.shared_experts."
+            if sp + "gate_proj.weight" in sd:
+                out[sp + "gate_up_proj.weight"] = torch.cat([sd[sp + "gate_proj.weight"], sd[sp + "up_proj.weight"]], 0)
+                out[sp + "down_proj.weight"] = sd[sp + "down_proj.weight"]
+        else:
+            out[p + "mlp.gate_up_proj.weight"] = torch.cat([sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"]], 0)
+            out[p + "mlp.down_proj.weight"] = sd[p + "mlp.down_proj.weight"]
+    return out

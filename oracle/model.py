@@ -204,3 +204,97 @@ class OracleOPT:
         return self._logits(hidden)
 
     generate = OracleLlama.generate
+
+
+class OracleDeepseekV2:
+    """DeepSeek-V2(-Lite) forward in the *non-absorbed* form for every step (models/deepseek_v2.py
+    forward_normal :591-631 generalised to cached tokens): per-head K/V are re-expanded from the cached
+    latent with kv_b_proj, attention is plain MHA.  Mathematically equal to forward_absorb (:633-706),
+    so it checks the engine's absorbed decode path independently.  MoE: MoEGate + grouped_topk /
+    biased_grouped_topk + naive experts (deepseek_v2.py:119-210, layers/moe/topk.py:79-160,
+    fused_moe_native.py:58-131)."""
+
+    def __init__(self, config, state_dict, act_dtype=torch.float32):
+        self.cfg = config
+        self.w = {k: v.detach().to("cpu") for k, v in state_dict.items()}
+        self.act = act_dtype
+        c = config
+        self.H = c.num_attention_heads
+        self.nope, self.rope, self.vd, self.lora = c.qk_nope_head_dim, c.qk_rope_head_dim, c.v_head_dim, c.kv_lora_rank
+        self.scaling = (self.nope + self.rope) ** -0.5
+        rs = c.rope_scaling
+        if rs:
+            extra = {k: rs[k] for k in ("beta_fast", "beta_slow", "mscale", "mscale_all_dim") if k in rs}
+            self.cache = O.deepseek_yarn_cos_sin_cache(self.rope, rs["original_max_position_embeddings"],
+                                                       c.rope_theta, rs["factor"], **extra)
+            m = O.yarn_get_mscale(rs["factor"], float(rs.get("mscale_all_dim", False)))
+            self.scaling = self.scaling * m * m
+        else:
+            self.cache = O.cos_sin_cache_from_inv_freq(O.rope_inv_freq(self.rope, c.rope_theta),
+                                                       c.max_position_embeddings)
+
+    def _lin(self, x, name):
+        return (x.float() @ self.w[name].float().T).to(self.act)
+
+    def _mlp(self, x, prefix):
+        return self._lin(O.silu_and_mul(self._lin(x, prefix + "gate_up_proj.weight")), prefix + "down_proj.weight")
+
+    def _moe(self, x, p):
+        c = self.cfg
+        logits = self._lin(x, p + "gate.weight")
+        bias = self.w.get(p + "gate.e_score_correction_bias")
+        if bias is not None:
+            tw, ti = O.biased_grouped_topk(logits, bias.float(), c.num_experts_per_tok, c.norm_topk_prob,
+                                           c.n_group, c.topk_group)
+        else:
+            tw, ti = O.grouped_topk(logits, c.num_experts_per_tok, c.norm_topk_prob, c.n_group, c.topk_group)
+        out = O.fused_moe(x, self.w[p + "experts.w13_weight"], self.w[p + "experts.w2_weight"], tw, ti)
+        out = out * c.routed_scaling_factor
+        if c.n_shared_experts is not None:
+            out = out + self._mlp(x, p + "shared_experts.").float()
+        return out.to(self.act)
+
+    def _layers(self, h, positions, lens, kv):
+        c = self.cfg
+        res = None
+        starts = [0]
+        for n in lens:
+            starts.append(starts[-1] + n)
+        for l in range(c.num_hidden_layers):
+            p = f"model.layers.{l}."
+            if res is None:
+                res = h
+                x = O.rms_norm(h, self.w[p + "input_layernorm.weight"], c.rms_norm_eps)
+            else:
+                x, res = O.fused_add_rms_norm(h, res, self.w[p + "input_layernorm.weight"], c.rms_norm_eps)
+            T = x.shape[0]
+            q = self._lin(x, p + "self_attn.q_proj.weight").view(T, self.H, self.nope + self.rope)
+            latent = self._lin(x, p + "self_attn.kv_a_proj_with_mqa.weight")
+            kv_a = O.rms_norm(latent[:, : self.lora], self.w[p + "self_attn.kv_a_layernorm.weight"], c.rms_norm_eps)
+            q_pe, k_pe = O.apply_rope(positions, q[..., self.nope:].reshape(T, -1), latent[:, self.lora:],
+                                      self.rope, self.cache, False)
+            q = torch.cat([q[..., : self.nope], q_pe.view(T, self.H, self.rope)], -1)
+            kvb = self._lin(kv_a, p + "self_attn.kv_b_proj.weight").view(T, self.H, self.nope + self.vd)
+            k = torch.cat([kvb[..., : self.nope], k_pe.view(T, 1, self.rope).expand(T, self.H, self.rope)], -1)
+            v = kvb[..., self.nope:]
+            outs = []
+            for b, n in enumerate(lens):
+                sl = slice(starts[b], starts[b + 1])
+                kv.append(l, b, k[sl], v[sl])
+                kk, vv = kv.k[l][b], kv.v[l][b]
+                s = torch.einsum("qhd,khd->hqk", q[sl].float(), kk.float()) * self.scaling
+                Tk = kk.shape[0]
+                if n > 1:
+                    s = s.masked_fill(~torch.ones(n, Tk, dtype=torch.bool).tril(diagonal=Tk - n), float("-inf"))
+                outs.append(torch.einsum("hqk,khd->qhd", torch.softmax(s, -1), vv.float()).reshape(n, -1))
+            h = self._lin(torch.cat(outs, 0).to(self.act), p + "self_attn.o_proj.weight")
+            x, res = O.fused_add_rms_norm(h, res, self.w[p + "post_attention_layernorm.weight"], c.rms_norm_eps)
+            is_moe = (c.n_routed_experts is not None and l >= c.first_k_dense_replace and l % c.moe_layer_freq == 0)
+            h = self._moe(x, p + "mlp.") if is_moe else self._mlp(x, p + "mlp.")
+        x, _ = O.fused_add_rms_norm(h, res, self.w["model.norm.weight"], c.rms_norm_eps)
+        return x
+
+    _logits = OracleLlama._logits
+    prefill = OracleLlama.prefill
+    decode_step = OracleLlama.decode_step
+    generate = OracleLlama.generate

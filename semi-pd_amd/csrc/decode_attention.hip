@@ -360,6 +360,12 @@ int launch_decode_mfma(T* out, const T* q, const T* k_buf, const T* v_buf, const
                        int64_t q_stride, int64_t o_stride, int64_t kbuf_stride, int64_t vbuf_stride,
                        int splits, float sm_scale, float logit_cap, hipStream_t st);
 
+// defined in mla_decode_attention.hip
+template <typename T>
+int launch_mla_decode(T* out, const T* q, const T* kv_buf, const int32_t* kv_indptr, const int32_t* kv_indices,
+                      float* attn_logits, int64_t batch, int Hq, int64_t q_stride, int64_t o_stride,
+                      int64_t kvbuf_stride, int splits, float sm_scale, float logit_cap, hipStream_t st);
+
 template <typename T>
 static int run_decode(void* out, const void* q, const void* k_buf, const void* v_buf,
                       const int32_t* kv_indptr, const int32_t* kv_indices, float* attn_logits,
@@ -375,7 +381,14 @@ static int run_decode(void* out, const void* q, const void* k_buf, const void* v
   const bool mfma = fast && group >= 2 &&
                     (head_dim_k == 64 || head_dim_k == 96 || head_dim_k == 128) &&
                     o_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 7u) == 0;
-  if (mfma) {
+  const bool mla = head_dim_k == 576 && head_dim_v == 512 && num_kv_heads == 1 && k_buf == v_buf &&
+                   kbuf_stride == vbuf_stride && kbuf_stride % 8 == 0 && q_stride % 8 == 0 && aligned16(q) &&
+                   aligned16(k_buf) && o_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 7u) == 0;
+  if (mla) {
+    // DeepSeek latent rows shared by all heads (mla_decode_attention.hip)
+    rc = launch_mla_decode<T>((T*)out, (const T*)q, (const T*)k_buf, kv_indptr, kv_indices, attn_logits, batch,
+                              num_q_heads, q_stride, o_stride, kbuf_stride, num_kv_splits, sm_scale, logit_cap, st);
+  } else if (mfma) {
     // GQA / MQA: matrix-core kernel (decode_attention_mfma.hip)
     rc = launch_decode_mfma<T>((T*)out, (const T*)q, (const T*)k_buf, (const T*)v_buf, kv_indptr, kv_indices,
                                attn_logits, batch, num_q_heads, num_kv_heads, head_dim_k, q_stride, o_stride,

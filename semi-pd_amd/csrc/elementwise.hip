@@ -303,6 +303,55 @@ __global__ void rope_scalar_kernel(T* __restrict__ q, T* __restrict__ k, const T
   }
 }
 
+// RoPE on head slices that are not densely packed (MLA: q_pe = q[..., 128:], head stride 192;
+// k_pe = latent[..., 512:], one "head" of 64 inside a 576-wide row).  q / k point at the first
+// rotary element of head 0; strides in elements.
+template <typename T, bool INTERLEAVE, bool VECT>
+__global__ void rope_strided_kernel(T* __restrict__ q, T* __restrict__ k, const float* __restrict__ cache,
+                                    const int64_t* __restrict__ positions, int Hq, int Hk, int rot_dim,
+                                    int64_t q_ts, int64_t q_hs, int64_t k_ts, int64_t k_hs) {
+  constexpr int V = Elem<T>::kVec;
+  const int64_t t = blockIdx.x;
+  const float* cs = cache + positions[t] * rot_dim;
+  const int half = rot_dim >> 1;
+  if (VECT) {
+    const int iph = INTERLEAVE ? rot_dim / V : half / V;
+    for (int it = threadIdx.x; it < (Hq + Hk) * iph; it += blockDim.x) {
+      const int h = it / iph, i = it - h * iph;
+      T* hp = h < Hq ? q + t * q_ts + h * q_hs : k + t * k_ts + (h - Hq) * k_hs;
+      rope_item<T, INTERLEAVE>(hp, nullptr, cs, rot_dim, i);
+    }
+  } else {
+    for (int it = threadIdx.x; it < (Hq + Hk) * half; it += blockDim.x) {
+      const int h = it / half, p = it - h * half;
+      T* hp = h < Hq ? q + t * q_ts + h * q_hs : k + t * k_ts + (h - Hq) * k_hs;
+      const int i1 = INTERLEAVE ? 2 * p : p, i2 = INTERLEAVE ? 2 * p + 1 : p + half;
+      const float c = cs[p], s = cs[half + p];
+      const float x1 = Elem<T>::to_f(hp[i1]), x2 = Elem<T>::to_f(hp[i2]);
+      hp[i1] = Elem<T>::from_f(x1 * c - x2 * s);
+      hp[i2] = Elem<T>::from_f(x2 * c + x1 * s);
+    }
+  }
+}
+
+template <typename T>
+static int launch_rope_strided(T* q, T* k, const float* cache, const int64_t* positions, int64_t num_tokens,
+                               int Hq, int Hk, int rot_dim, int64_t q_ts, int64_t q_hs, int64_t k_ts,
+                               int64_t k_hs, int interleave, hipStream_t st) {
+  constexpr int V = Elem<T>::kVec;
+  const bool vec = aligned16(q) && aligned16(k) && q_ts % V == 0 && q_hs % V == 0 && k_ts % V == 0 &&
+                   k_hs % V == 0 && (interleave ? rot_dim % V == 0 : (rot_dim / 2) % V == 0);
+  dim3 grid((unsigned)num_tokens), block(128);
+  if (interleave) {
+    if (vec) hipLaunchKernelGGL((rope_strided_kernel<T, true, true>), grid, block, 0, st, q, k, cache, positions, Hq, Hk, rot_dim, q_ts, q_hs, k_ts, k_hs);
+    else hipLaunchKernelGGL((rope_strided_kernel<T, true, false>), grid, block, 0, st, q, k, cache, positions, Hq, Hk, rot_dim, q_ts, q_hs, k_ts, k_hs);
+  } else {
+    if (vec) hipLaunchKernelGGL((rope_strided_kernel<T, false, true>), grid, block, 0, st, q, k, cache, positions, Hq, Hk, rot_dim, q_ts, q_hs, k_ts, k_hs);
+    else hipLaunchKernelGGL((rope_strided_kernel<T, false, false>), grid, block, 0, st, q, k, cache, positions, Hq, Hk, rot_dim, q_ts, q_hs, k_ts, k_hs);
+  }
+  return launch_status("rope_strided");
+}
+
 template <typename T, bool STORE>
 static int launch_rope(T* q, T* k, const T* v, T* k_buf, T* v_buf, const int64_t* loc,
                        const float* cache, const int64_t* positions, int64_t num_tokens, int Hq,
@@ -573,6 +622,18 @@ int semipd_rope_inplace(void* q, void* k, const float* cos_sin_cache, const int6
   if (num_tokens == 0) return 0;
   SEMIPD_CHECK_ARG(q && k && cos_sin_cache && positions, SEMIPD_EINVAL, "rope: null pointer");
   SEMIPD_DISPATCH_DTYPE(dtype, T, return (launch_rope<T, false>((T*)q, (T*)k, nullptr, nullptr, nullptr, nullptr, cos_sin_cache, positions, num_tokens, num_q_heads, num_k_heads, head_size, 0, rot_dim, q_stride, k_stride, 0, 0, 0, interleave, as_stream(stream))));
+  return 0;
+}
+
+int semipd_rope_inplace_strided(void* q, void* k, const float* cos_sin_cache, const int64_t* positions,
+                                int64_t num_tokens, int num_q_heads, int num_k_heads, int rot_dim,
+                                int64_t q_token_stride, int64_t q_head_stride, int64_t k_token_stride,
+                                int64_t k_head_stride, int interleave, int dtype, void* stream) {
+  SEMIPD_CHECK_ARG(num_tokens >= 0 && rot_dim > 0 && (rot_dim % 2) == 0 && num_q_heads >= 0 && num_k_heads >= 0,
+                   SEMIPD_EINVAL, "rope_strided: bad sizes");
+  if (num_tokens == 0) return 0;
+  SEMIPD_CHECK_ARG(q && k && cos_sin_cache && positions, SEMIPD_EINVAL, "rope_strided: null pointer");
+  SEMIPD_DISPATCH_DTYPE(dtype, T, return (launch_rope_strided<T>((T*)q, (T*)k, cos_sin_cache, positions, num_tokens, num_q_heads, num_k_heads, rot_dim, q_token_stride, q_head_stride, k_token_stride, k_head_stride, interleave, as_stream(stream))));
   return 0;
 }
 

@@ -35,6 +35,7 @@ _SIGNATURES = {
     "semipd_fused_add_rmsnorm": [_vp, _vp, _vp, _i64, _i64, _f32, _i32, _vp],
     "semipd_silu_and_mul": [_vp, _vp, _i64, _i64, _i32, _vp],
     "semipd_rope_inplace": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i64, _i64, _i32, _i32, _vp],
+    "semipd_rope_inplace_strided": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _i32, _i32, _vp],
     "semipd_rope_kv_store": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32,
                              _i64, _i64, _i64, _i64, _i64, _i32, _i32, _vp],
     "semipd_kv_store": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp],

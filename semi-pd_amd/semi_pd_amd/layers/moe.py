@@ -1,0 +1,86 @@
+"""MoE routing + fused experts on the HIP kernels.
+
+Reference: layers/moe/topk.py:162-220 (`select_experts`), layers/moe/fused_moe_triton/fused_moe.py
+:409-498 (`moe_align_block_size`), :961-1165 (`fused_experts_impl`: align -> GEMM1 -> SiLU*mul ->
+GEMM2 x routed weight -> sum over top-k), layers/moe/fused_moe_triton/layer.py:239-641 (`FusedMoE`,
+weights w13 [E, 2N, K] and w2 [E, K, N], TP all-reduce :637-638).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import nn
+
+from semi_pd_amd import ops
+from semi_pd_amd.distributed import (get_tensor_model_parallel_rank, get_tensor_model_parallel_world_size,
+                                     tensor_model_parallel_all_reduce)
+
+MOE_BLOCK_M = 64  # rows per expert block = M tile of the grouped GEMM
+
+
+def select_experts(hidden_states: torch.Tensor, router_logits: torch.Tensor, top_k: int,
+                   use_grouped_topk: bool, renormalize: bool, topk_group: Optional[int] = None,
+                   num_expert_group: Optional[int] = None, correction_bias: Optional[torch.Tensor] = None):
+    """topk.py:162-220: grouped_topk / biased_grouped_topk when use_grouped_topk, else fused_topk."""
+    if use_grouped_topk:
+        assert topk_group is not None and num_expert_group is not None
+        return ops.grouped_topk(router_logits, top_k, renormalize, num_expert_group, topk_group, correction_bias)
+    return ops.topk_softmax(router_logits, top_k, renormalize)
+
+
+def fused_experts(hidden_states: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, topk_weights: torch.Tensor,
+                  topk_ids: torch.Tensor) -> torch.Tensor:
+    """fused_experts_impl (fused_moe.py:961-1165), bf16/f16 path.  hidden [T, K]; w1 [E, 2N, K];
+    w2 [E, K, N]; returns [T, K]."""
+    T, K = hidden_states.shape
+    E, N2, _ = w1.shape
+    topk = topk_ids.shape[1]
+    dev, dt = hidden_states.device, hidden_states.dtype
+    numel = T * topk
+    max_sorted = numel + E * (MOE_BLOCK_M - 1)
+    sorted_ids = torch.empty(max_sorted, dtype=torch.int32, device=dev)
+    expert_ids = torch.empty((max_sorted + MOE_BLOCK_M - 1) // MOE_BLOCK_M, dtype=torch.int32, device=dev)
+    num_post_pad = torch.empty(1, dtype=torch.int32, device=dev)
+    cumsum = torch.empty(E + 1, dtype=torch.int32, device=dev)
+    ops.moe_align_block_size(topk_ids, E, MOE_BLOCK_M, sorted_ids, expert_ids, num_post_pad, None, cumsum)
+    c1 = torch.empty((numel, N2), dtype=dt, device=dev)
+    ops.moe_grouped_gemm(hidden_states, w1, c1, None, sorted_ids, expert_ids, num_post_pad, numel, topk, False)
+    c2 = ops.silu_and_mul(c1)
+    c3 = torch.empty((numel, K), dtype=dt, device=dev)
+    ops.moe_grouped_gemm(c2, w2, c3, topk_weights.reshape(-1), sorted_ids, expert_ids, num_post_pad, numel, 1, True)
+    return ops.moe_sum(c3.view(T, topk, K))
+
+
+class FusedMoE(nn.Module):
+    def __init__(self, num_experts: int, top_k: int, hidden_size: int, intermediate_size: int,
+                 renormalize: bool = True, use_grouped_topk: bool = False, num_expert_group: Optional[int] = None,
+                 topk_group: Optional[int] = None, correction_bias: Optional[torch.Tensor] = None,
+                 reduce_results: bool = False, params_dtype=None):
+        super().__init__()
+        tp, rank = get_tensor_model_parallel_world_size(), get_tensor_model_parallel_rank()
+        assert intermediate_size % tp == 0
+        n = intermediate_size // tp
+        self.top_k, self.renormalize = top_k, renormalize
+        self.use_grouped_topk, self.num_expert_group, self.topk_group = use_grouped_topk, num_expert_group, topk_group
+        self.correction_bias = correction_bias
+        self.reduce_results = reduce_results
+        self.w13_weight = nn.Parameter(torch.empty(num_experts, 2 * n, hidden_size, dtype=params_dtype),
+                                       requires_grad=False)
+        self.w2_weight = nn.Parameter(torch.empty(num_experts, hidden_size, n, dtype=params_dtype),
+                                      requires_grad=False)
+        inter = intermediate_size
+        self.w13_weight.tp_full_shape = (num_experts, 2 * inter, hidden_size)
+        self.w13_weight.tp_shard = lambda full: torch.cat(
+            [full[:, rank * n:(rank + 1) * n], full[:, inter + rank * n: inter + (rank + 1) * n]], 1).contiguous()
+        self.w2_weight.tp_full_shape = (num_experts, hidden_size, inter)
+        self.w2_weight.tp_shard = lambda full: full[:, :, rank * n:(rank + 1) * n].contiguous()
+
+    def forward(self, hidden_states: torch.Tensor, router_logits: torch.Tensor) -> torch.Tensor:
+        topk_weights, topk_ids = select_experts(hidden_states, router_logits, self.top_k, self.use_grouped_topk,
+                                                self.renormalize, self.topk_group, self.num_expert_group,
+                                                self.correction_bias)
+        out = fused_experts(hidden_states, self.w13_weight, self.w2_weight, topk_weights, topk_ids)
+        if self.reduce_results and get_tensor_model_parallel_world_size() > 1:
+            out = tensor_model_parallel_all_reduce(out)
+        return out

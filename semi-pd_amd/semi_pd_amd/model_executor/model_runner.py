@@ -132,6 +132,10 @@ class ModelRunner:
                     load_full_state_dict(self.model, load_state_dict)
                 else:
                     dummy_init_weights(self.model, self.device, seed)
+                if hasattr(self.model, "post_load_weights"):
+                    # e.g. MLA's W_kc / W_vc buffers (deepseek_v2.py:1228-1249); the prefill instance
+                    # receives them through IPC like any other buffer
+                    self.model.post_load_weights()
         finally:
             torch.set_default_dtype(torch.float32)
         self.model.eval()

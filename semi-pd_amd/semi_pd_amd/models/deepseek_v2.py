@@ -1,0 +1,293 @@
+"""DeepSeek-V2 / V2-Lite (MLA attention + MoE) on the HIP hot-path operators.
+
+Reference: models/deepseek_v2.py — MoEGate :119-138, DeepseekV2MoE :141-210, DeepseekV2AttentionMLA
+:393-850 (forward_normal :591-631 for a prefill without prefix, forward_absorb :633-706 for decode and
+for prefill over a prefix), decoder layer / model :853-1060, w_kc / w_vc construction :1215-1249.
+
+MLA keeps ONE latent row [kv_lora_rank + qk_rope_head_dim] per token and layer in the KV pool.
+* no prefix (forward_normal): expand the latent to per-head K/V with kv_b_proj and run ordinary MHA
+  attention (Dk = 192, Dv = 128) over the new tokens only;
+* otherwise (forward_absorb): fold W_kc into the query and W_vc into the output, so attention is MQA
+  over the 576-wide latent rows (Dv = 512), straight out of the paged pool.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Any, Dict, Optional
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from semi_pd_amd import ops
+from semi_pd_amd.distributed import (get_tensor_model_parallel_world_size, tensor_model_parallel_all_reduce)
+from semi_pd_amd.layers.attention_backend import RadixAttention
+from semi_pd_amd.layers.basic import (ColumnParallelLinear, LogitsProcessor, MergedColumnParallelLinear,
+                                      ParallelLMHead, RMSNorm, RowParallelLinear, SiluAndMul,
+                                      VocabParallelEmbedding, get_rope, yarn_get_mscale)
+from semi_pd_amd.layers.moe import FusedMoE
+
+
+@dataclass
+class DeepseekV2Config:
+    """HF DeepseekV2Config fields read by the reference; defaults = DeepSeek-V2-Lite."""
+    vocab_size: int = 102400
+    hidden_size: int = 2048
+    intermediate_size: int = 10944
+    moe_intermediate_size: int = 1408
+    num_hidden_layers: int = 27
+    num_attention_heads: int = 16
+    n_shared_experts: Optional[int] = 2
+    n_routed_experts: int = 64
+    num_experts_per_tok: int = 6
+    routed_scaling_factor: float = 1.0
+    topk_method: str = "greedy"
+    n_group: int = 1
+    topk_group: int = 1
+    norm_topk_prob: bool = False
+    first_k_dense_replace: int = 1
+    moe_layer_freq: int = 1
+    kv_lora_rank: int = 512
+    q_lora_rank: Optional[int] = None
+    qk_rope_head_dim: int = 64
+    qk_nope_head_dim: int = 128
+    v_head_dim: int = 128
+    rms_norm_eps: float = 1e-6
+    rope_theta: float = 10000.0
+    rope_scaling: Optional[Dict[str, Any]] = field(default_factory=lambda: {
+        "type": "yarn", "factor": 40, "beta_fast": 32, "beta_slow": 1, "mscale": 0.707,
+        "mscale_all_dim": 0.707, "original_max_position_embeddings": 4096})
+    max_position_embeddings: int = 163840
+    tie_word_embeddings: bool = False
+    architectures: tuple = ("DeepseekV2ForCausalLM",)
+
+
+DEEPSEEK_V2_LITE = DeepseekV2Config()
+
+
+class DeepseekV2MLP(nn.Module):
+    def __init__(self, hidden_size: int, intermediate_size: int, dtype, reduce_results: bool = True):
+        super().__init__()
+        self.gate_up_proj = MergedColumnParallelLinear(hidden_size, [intermediate_size] * 2, params_dtype=dtype)
+        self.down_proj = RowParallelLinear(intermediate_size, hidden_size, reduce_results=reduce_results,
+                                           params_dtype=dtype)
+        self.act_fn = SiluAndMul()
+
+    def forward(self, x):
+        return self.down_proj(self.act_fn(self.gate_up_proj(x)))
+
+
+class MoEGate(nn.Module):
+    def __init__(self, config: DeepseekV2Config, dtype):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(config.n_routed_experts, config.hidden_size, dtype=dtype),
+                                   requires_grad=False)
+        if config.topk_method == "noaux_tc":
+            self.e_score_correction_bias = nn.Parameter(torch.zeros(config.n_routed_experts, dtype=torch.float32),
+                                                        requires_grad=False)
+        else:
+            self.e_score_correction_bias = None
+
+    def forward(self, hidden_states):
+        return F.linear(hidden_states, self.weight, None)
+
+
+class DeepseekV2MoE(nn.Module):
+    def __init__(self, config: DeepseekV2Config, dtype):
+        super().__init__()
+        self.tp_size = get_tensor_model_parallel_world_size()
+        self.routed_scaling_factor = config.routed_scaling_factor
+        self.n_shared_experts = config.n_shared_experts
+        self.gate = MoEGate(config, dtype)
+        self.experts = FusedMoE(config.n_routed_experts, config.num_experts_per_tok, config.hidden_size,
+                                config.moe_intermediate_size, renormalize=config.norm_topk_prob,
+                                use_grouped_topk=True, num_expert_group=config.n_group,
+                                topk_group=config.topk_group, correction_bias=self.gate.e_score_correction_bias,
+                                params_dtype=dtype)
+        self.shared_experts = None
+        if config.n_shared_experts is not None:
+            self.shared_experts = DeepseekV2MLP(config.hidden_size,
+                                                config.moe_intermediate_size * config.n_shared_experts, dtype,
+                                                reduce_results=False)
+
+    def forward(self, hidden_states: torch.Tensor) -> torch.Tensor:
+        shared_output = self.shared_experts(hidden_states) if self.shared_experts is not None else None
+        router_logits = self.gate(hidden_states)
+        out = self.experts(hidden_states, router_logits)
+        if self.routed_scaling_factor != 1.0:
+            out = out * self.routed_scaling_factor
+        if shared_output is not None:
+            out = out + shared_output
+        if self.tp_size > 1:
+            out = tensor_model_parallel_all_reduce(out)
+        return out
+
+
+class DeepseekV2AttentionMLA(nn.Module):
+    def __init__(self, config: DeepseekV2Config, layer_id: int, dtype):
+        super().__init__()
+        tp = get_tensor_model_parallel_world_size()
+        self.layer_id = layer_id
+        self.qk_nope_head_dim, self.qk_rope_head_dim = config.qk_nope_head_dim, config.qk_rope_head_dim
+        self.qk_head_dim = self.qk_nope_head_dim + self.qk_rope_head_dim
+        self.v_head_dim, self.kv_lora_rank, self.q_lora_rank = config.v_head_dim, config.kv_lora_rank, config.q_lora_rank
+        assert config.num_attention_heads % tp == 0
+        self.num_local_heads = config.num_attention_heads // tp
+        H = config.num_attention_heads
+        if self.q_lora_rank is not None:
+            self.q_a_proj = nn.Linear(config.hidden_size, self.q_lora_rank, bias=False, dtype=dtype)
+            self.q_a_layernorm = RMSNorm(self.q_lora_rank, eps=config.rms_norm_eps)
+            self.q_b_proj = ColumnParallelLinear(self.q_lora_rank, H * self.qk_head_dim, params_dtype=dtype)
+        else:
+            self.q_proj = ColumnParallelLinear(config.hidden_size, H * self.qk_head_dim, params_dtype=dtype)
+        self.kv_a_proj_with_mqa = nn.Linear(config.hidden_size, self.kv_lora_rank + self.qk_rope_head_dim,
+                                            bias=False, dtype=dtype)
+        self.kv_a_layernorm = RMSNorm(self.kv_lora_rank, eps=config.rms_norm_eps)
+        self.kv_b_proj = ColumnParallelLinear(self.kv_lora_rank, H * (self.qk_nope_head_dim + self.v_head_dim),
+                                              params_dtype=dtype)
+        self.o_proj = RowParallelLinear(H * self.v_head_dim, config.hidden_size, params_dtype=dtype)
+        rope_scaling = dict(config.rope_scaling) if config.rope_scaling else None
+        self.scaling = self.qk_head_dim ** -0.5
+        if rope_scaling:
+            rope_scaling["rope_type"] = "deepseek_yarn"
+            mscale = yarn_get_mscale(rope_scaling["factor"], float(rope_scaling.get("mscale_all_dim", False)))
+            self.scaling = self.scaling * mscale * mscale
+        self.rotary_emb = get_rope(self.qk_rope_head_dim, self.qk_rope_head_dim, config.max_position_embeddings,
+                                   config.rope_theta, False, rope_scaling, dtype)
+        self.attn_mqa = RadixAttention(self.num_local_heads, self.kv_lora_rank + self.qk_rope_head_dim, self.scaling,
+                                       num_kv_heads=1, layer_id=layer_id, v_head_dim=self.kv_lora_rank)
+        self.attn_mha = RadixAttention(self.num_local_heads, self.qk_head_dim, self.scaling,
+                                       num_kv_heads=self.num_local_heads, layer_id=layer_id,
+                                       v_head_dim=self.v_head_dim)
+        # Semi-PD: buffers so that they are exported / imported through IPC (deepseek_v2.py:532-536)
+        self.register_buffer("w_kc", torch.empty(0, dtype=dtype), persistent=False)
+        self.register_buffer("w_vc", torch.empty(0, dtype=dtype), persistent=False)
+
+    def post_load_weights(self):
+        """deepseek_v2.py:1228-1249: W_kc [H,128,512] and W_vc [H,512,128] out of kv_b_proj."""
+        w = self.kv_b_proj.weight
+        w_kc, w_vc = w.unflatten(0, (-1, self.qk_nope_head_dim + self.v_head_dim)).split(
+            [self.qk_nope_head_dim, self.v_head_dim], dim=1)
+        self.w_kc = w_kc.contiguous()                    # [H, 128, 512]
+        self.w_vc = w_vc.transpose(1, 2).contiguous()    # [H, 512, 128]
+
+    def _q(self, hidden_states):
+        if self.q_lora_rank is not None:
+            q = self.q_b_proj(self.q_a_layernorm(self.q_a_proj(hidden_states)))
+        else:
+            q = self.q_proj(hidden_states)
+        return q.view(-1, self.num_local_heads, self.qk_head_dim)
+
+    def _latent(self, hidden_states, positions, q):
+        """kv_a_proj -> RMSNorm on the 512 latent dims -> RoPE on the 64 rope dims (and on q_pe);
+        returns the finished latent rows [T, 1, 576]."""
+        latent = self.kv_a_proj_with_mqa(hidden_states)  # [T, 576]
+        kv_a = ops.rmsnorm(latent[:, : self.kv_lora_rank], self.kv_a_layernorm.weight.data,
+                           self.kv_a_layernorm.variance_epsilon, out=latent[:, : self.kv_lora_rank])
+        del kv_a
+        latent = latent.unsqueeze(1)
+        ops.apply_rope_strided_inplace(positions, q[..., self.qk_nope_head_dim:], latent[..., self.kv_lora_rank:],
+                                       self.rotary_emb.cos_sin_cache, False)
+        return latent
+
+    def forward(self, positions, hidden_states, forward_batch):
+        no_absorb = forward_batch.forward_mode.is_extend() and sum(forward_batch.extend_prefix_lens_cpu) == 0
+        if no_absorb:
+            return self.forward_normal(positions, hidden_states, forward_batch)
+        return self.forward_absorb(positions, hidden_states, forward_batch)
+
+    def forward_normal(self, positions, hidden_states, forward_batch):
+        q = self._q(hidden_states)
+        latent = self._latent(hidden_states, positions, q)
+        forward_batch.token_to_kv_pool.set_kv_buffer(self.attn_mha, forward_batch.out_cache_loc, latent, None)
+        kv = self.kv_b_proj(latent[:, 0, : self.kv_lora_rank])
+        kv = kv.view(-1, self.num_local_heads, self.qk_nope_head_dim + self.v_head_dim)
+        k = torch.empty_like(q)
+        k[..., : self.qk_nope_head_dim] = kv[..., : self.qk_nope_head_dim]
+        k[..., self.qk_nope_head_dim:] = latent[..., self.kv_lora_rank:]
+        v = kv[..., self.qk_nope_head_dim:].contiguous()
+        attn_output = self.attn_mha(q.reshape(q.shape[0], -1), k.view(k.shape[0], -1), v.view(v.shape[0], -1),
+                                    forward_batch, save_kv_cache=False)
+        return self.o_proj(attn_output)
+
+    def forward_absorb(self, positions, hidden_states, forward_batch):
+        q = self._q(hidden_states)
+        T = q.shape[0]
+        latent = self._latent(hidden_states, positions, q)
+        q_input = torch.empty((T, self.num_local_heads, self.kv_lora_rank + self.qk_rope_head_dim),
+                              dtype=q.dtype, device=q.device)
+        q_nope_out = torch.bmm(q[..., : self.qk_nope_head_dim].transpose(0, 1), self.w_kc)  # [H, T, 512]
+        q_input[..., : self.kv_lora_rank] = q_nope_out.transpose(0, 1)
+        q_input[..., self.kv_lora_rank:] = q[..., self.qk_nope_head_dim:]
+        forward_batch.token_to_kv_pool.set_kv_buffer(self.attn_mqa, forward_batch.out_cache_loc, latent, None)
+        attn_output = self.attn_mqa(q_input.view(T, -1), latent.view(T, -1), latent[..., : self.kv_lora_rank],
+                                    forward_batch, save_kv_cache=False)
+        attn_output = attn_output.view(T, self.num_local_heads, self.kv_lora_rank)
+        out = torch.bmm(attn_output.transpose(0, 1), self.w_vc)  # [H, T, 128]
+        return self.o_proj(out.transpose(0, 1).reshape(T, -1))
+
+
+class DeepseekV2DecoderLayer(nn.Module):
+    def __init__(self, config: DeepseekV2Config, layer_id: int, dtype):
+        super().__init__()
+        self.self_attn = DeepseekV2AttentionMLA(config, layer_id, dtype)
+        is_moe = (config.n_routed_experts is not None and layer_id >= config.first_k_dense_replace
+                  and layer_id % config.moe_layer_freq == 0)
+        self.mlp = DeepseekV2MoE(config, dtype) if is_moe else DeepseekV2MLP(config.hidden_size,
+                                                                           config.intermediate_size, dtype)
+        self.input_layernorm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+        self.post_attention_layernorm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+
+    def forward(self, positions, hidden_states, forward_batch, residual):
+        if residual is None:
+            residual = hidden_states
+            hidden_states = self.input_layernorm(hidden_states)
+        else:
+            hidden_states, residual = self.input_layernorm(hidden_states, residual)
+        hidden_states = self.self_attn(positions, hidden_states, forward_batch)
+        hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
+        hidden_states = self.mlp(hidden_states)
+        return hidden_states, residual
+
+
+class DeepseekV2Model(nn.Module):
+    def __init__(self, config: DeepseekV2Config, dtype):
+        super().__init__()
+        self.embed_tokens = VocabParallelEmbedding(config.vocab_size, config.hidden_size, params_dtype=dtype)
+        self.layers = nn.ModuleList([DeepseekV2DecoderLayer(config, i, dtype)
+                                     for i in range(config.num_hidden_layers)])
+        self.norm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+
+    def forward(self, input_ids, positions, forward_batch):
+        hidden_states = self.embed_tokens(input_ids)
+        residual = None
+        for layer in self.layers:
+            hidden_states, residual = layer(positions, hidden_states, forward_batch, residual)
+        hidden_states, _ = self.norm(hidden_states, residual)
+        return hidden_states
+
+
+class DeepseekV2ForCausalLM(nn.Module):
+    def __init__(self, config: DeepseekV2Config, dtype=torch.bfloat16):
+        super().__init__()
+        self.config = config
+        self.model = DeepseekV2Model(config, dtype)
+        self.lm_head = ParallelLMHead(config.vocab_size, config.hidden_size, params_dtype=dtype)
+        self.logits_processor = LogitsProcessor(config.vocab_size)
+
+    @property
+    def kv_geometry(self):
+        a = self.model.layers[0].self_attn
+        return dict(kind="mla", num_kv_heads=1, num_heads=a.num_local_heads,
+                    head_dim=a.kv_lora_rank + a.qk_rope_head_dim, v_head_dim=a.kv_lora_rank,
+                    kv_lora_rank=a.kv_lora_rank, qk_rope_head_dim=a.qk_rope_head_dim,
+                    num_layers=len(self.model.layers))
+
+    def post_load_weights(self):
+        for layer in self.model.layers:
+            layer.self_attn.post_load_weights()
+
+    @torch.no_grad()
+    def forward(self, input_ids, positions, forward_batch):
+        hidden_states = self.model(input_ids, positions, forward_batch)
+        return self.logits_processor(input_ids, hidden_states, self.lm_head, forward_batch)

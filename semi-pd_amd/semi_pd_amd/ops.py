@@ -103,6 +103,25 @@ def apply_rope_with_cos_sin_cache_inplace(positions: torch.Tensor, query: torch.
                                   current_stream(query.device)), "apply_rope")
 
 
+def apply_rope_strided_inplace(positions: torch.Tensor, q_rot: torch.Tensor, k_rot: torch.Tensor,
+                               cos_sin_cache: torch.Tensor, is_neox: bool) -> None:
+    """In-place RoPE on views q_rot [T, Hq, rot] / k_rot [T, Hk, rot] whose heads are strided slices
+    of larger rows (MLA: DeepseekScalingRotaryEmbedding.forward, rotary_embedding.py:710-748)."""
+    if cos_sin_cache.dtype != torch.float32:
+        raise ValueError("cos_sin_cache should be float32")
+    if positions.dtype != torch.int64:
+        positions = positions.long()
+    T, Hq, rot = q_rot.shape
+    Hk = k_rot.shape[1]
+    if q_rot.stride(2) != 1 or k_rot.stride(2) != 1 or rot != cos_sin_cache.shape[1] or k_rot.shape[2] != rot:
+        raise RuntimeError("apply_rope_strided_inplace: bad layout")
+    lib = _lib.load()
+    check(lib.semipd_rope_inplace_strided(ptr(q_rot), ptr(k_rot), ptr(cos_sin_cache), ptr(positions), T, Hq, Hk,
+                                          rot, q_rot.stride(0), q_rot.stride(1), k_rot.stride(0),
+                                          k_rot.stride(1), 0 if is_neox else 1, dtype_code(q_rot.dtype),
+                                          current_stream(q_rot.device)), "rope_strided")
+
+
 def rope_and_store_kv(positions: torch.Tensor, query: torch.Tensor, key: torch.Tensor,
                       value: torch.Tensor, head_size: int, cos_sin_cache: torch.Tensor, is_neox: bool,
                       k_buffer: torch.Tensor, v_buffer: torch.Tensor, loc: torch.Tensor) -> None:
@@ -241,7 +260,8 @@ def extend_attention_fwd(q_extend: torch.Tensor, k_extend: torch.Tensor, v_exten
     Hkv, Dv = v_extend.shape[1], v_extend.shape[2]
     sm_scale = sm_scale or 1.0 / (Dk ** 0.5)
     for name, t, d in (("q", q_extend, Dk), ("k", k_extend, Dk), ("v", v_extend, Dv), ("o", o_extend, Dv)):
-        if t.stride(2) != 1 or t.stride(1) != d:
+        # a single-head tensor may be a column slice of wider rows (MLA: v = latent[..., :512])
+        if t.stride(2) != 1 or (t.shape[1] > 1 and t.stride(1) != d):
             raise RuntimeError(f"extend_attention_fwd: {name}_extend heads must be densely packed")
     kb_stride = k_buffer.stride(0) if k_buffer is not None else 0
     vb_stride = v_buffer.stride(0) if v_buffer is not None else 0

@@ -242,6 +242,8 @@ DECODE_CASES = [
     (2, [40, 9], 4, 4, 80, 80, 2, 0.0),              # D = 80
     (3, [50, 3, 128], 32, 2, 64, 64, 5, 0.0),        # g = 16: two head tiles per kv head
     (2, [33, 70], 16, 1, 576, 512, 4, 0.0),          # MLA latent (generic path)
+    (3, [300, 1, 65], 40, 1, 576, 512, 1, 0.0),      # MLA, 3 head tiles (last partial), single split
+    (2, [129, 1000], 128, 1, 576, 512, 8, 20.0),     # MLA, DeepSeek-V3 head count, logit cap
     (2, [12, 30], 3, 1, 13, 13, 2, 0.0),             # odd head dim (generic path)
     (1, [2048], 32, 8, 128, 128, 16, 0.0),
 ]

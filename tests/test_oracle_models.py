@@ -64,3 +64,24 @@ def test_oracle_opt_matches_hf():
         want_toks, want_logits = _hf_greedy(hf, p, 6)
         assert toks[b] == want_toks
         torch.testing.assert_close(logits[b], want_logits, rtol=1e-4, atol=1e-4)
+
+
+def test_oracle_deepseek_v2_matches_hf():
+    from oracle.hf_convert import deepseek_v2_from_hf
+    from oracle.model import OracleDeepseekV2
+    from semi_pd_amd.models.deepseek_v2 import DeepseekV2Config
+    torch.manual_seed(2)
+    kw = dict(vocab_size=300, hidden_size=64, intermediate_size=96, moe_intermediate_size=32, num_hidden_layers=3,
+              num_attention_heads=4, n_shared_experts=2, n_routed_experts=8, num_experts_per_tok=3, kv_lora_rank=32,
+              q_lora_rank=None, qk_rope_head_dim=16, qk_nope_head_dim=16, v_head_dim=16, first_k_dense_replace=1,
+              n_group=1, topk_group=1, topk_method="greedy", norm_topk_prob=False, routed_scaling_factor=1.0,
+              max_position_embeddings=256, rms_norm_eps=1e-6)
+    hf = transformers.DeepseekV2ForCausalLM(transformers.DeepseekV2Config(num_key_value_heads=4, **kw)).eval()
+    cfg = DeepseekV2Config(rope_scaling=None, rope_theta=10000.0, **kw)
+    oracle = OracleDeepseekV2(cfg, deepseek_v2_from_hf(hf.state_dict(), cfg))
+    prompts = _prompts(300)
+    toks, logits = oracle.generate(prompts, 5)
+    for b, p in enumerate(prompts):
+        want_toks, want_logits = _hf_greedy(hf, p, 5)
+        assert toks[b] == want_toks
+        torch.testing.assert_close(logits[b], want_logits, rtol=2e-4, atol=2e-4)

@@ -56,6 +56,31 @@ def bench_decode():
                 del kb, vb
 
 
+def bench_mla():
+    print("# MLA decode attention (latent 576/512): B, ctx, H, splits -> us, GB/s, frac of 8 TB/s")
+    for H in (16, 128):
+        for B in (1, 32, 128):
+            for ctx in (1024, 8192):
+                N = B * ctx + 1
+                kv = torch.randn(N, 1, 576, device=dev, dtype=torch.bfloat16)
+                q = torch.randn(B, H, 576, device=dev, dtype=torch.bfloat16)
+                o = torch.empty(B, H, 512, device=dev, dtype=torch.bfloat16)
+                indptr = (torch.arange(B + 1, device=dev, dtype=torch.int32) * ctx)
+                idx = (torch.randperm(N - 1, device=dev)[: B * ctx] + 1).to(torch.int32)
+                best = None
+                for splits in (1, 2, 4, 8, 16, 32, 64):
+                    if ctx // splits < 64:
+                        continue
+                    lg = torch.empty(B, H, splits, 513, device=dev, dtype=torch.float32)
+                    t = timeit(lambda: ops.decode_attention_fwd(q, kv, kv[..., :512], o, indptr, idx, lg, splits, 0.1))
+                    if best is None or t < best[0]:
+                        best = (t, splits)
+                t, splits = best
+                nbytes = B * ctx * 576 * 2 + B * H * (576 + 512) * 2
+                print(f"mla B={B:4d} ctx={ctx:5d} H={H:3d} splits={splits:2d}: {t * 1e6:8.1f} us "
+                      f"{nbytes / t / 1e9:7.0f} GB/s  {nbytes / t / 1e9 / HBM:.3f}")
+
+
 def bench_extend():
     print("# extend attention: B, ext, prefix, Hq, Hkv, D -> us, TFLOP/s, frac of 2.5 PF")
     for (Hq, Hkv, D) in [(32, 8, 128), (12, 12, 64)]:
@@ -107,6 +132,8 @@ if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     if which in ("decode", "all"):
         bench_decode()
+    if which in ("mla", "all"):
+        bench_mla()
     if which in ("extend", "all"):
         bench_extend()
     if which in ("norm", "all"):
