@@ -64,7 +64,9 @@ def choose_kv_splits(batch: int, num_kv_heads: int, max_seq_len: int, num_cus: i
     """Split-KV factor: enough workgroups (batch x kv-head tiles x splits) to fill the CUs this
     process owns a few times over, never cutting below ~64 tokens per split.  (The reference uses a
     fixed --triton-attention-num-kv-splits, 16 on HIP: server_args.py:321-323.)"""
-    target = 4 * num_cus
+    # one work item = one wave (4 per workgroup); 2 waves per SIMD fit, so ~16 items per CU keep
+    # every CU fully occupied with a second round to balance the tail
+    target = 16 * num_cus
     base = max(1, batch * num_kv_heads)
     want = max(1, -(-target // base))
     by_len = max(1, max_seq_len // 64)
