@@ -232,19 +232,25 @@ __global__ void moe_scatter_kernel(const int32_t* __restrict__ topk_ids, int64_t
 
 // ---------------------------------------------------------------------------
 // C[row, n] = sum_k A[arow, k] * W[expert, n, k]      ("NT" GEMM, W row-major [N,K])
-// Workgroup tile 64 x 128, BK = 64, 4 waves each 64 x 32 (two 32x32x16 MFMA row tiles).
-// GROUPED: rows come from sorted_token_ids / expert_ids (fused_moe_kernel semantics);
-// otherwise plain dense rows (lm_head).
+// Workgroup tile 64 x 256, BK = 64, 4 waves each 64 x 64 (2 x 2 tiles of v_mfma_f32_32x32x16).
+// The next K-tile (A rows gathered through the sorted token ids, W rows of the block's expert) is
+// fetched into registers while the current one is multiplied out of LDS (issue early / write late),
+// so a decode-sized call streams the expert weights once at HBM rate and a prefill-sized call keeps
+// the matrix pipes fed.  GROUPED: rows come from sorted_token_ids / expert_ids (fused_moe_kernel
+// semantics, fused_moe.py:54-273); otherwise plain dense rows (lm_head).
 // ---------------------------------------------------------------------------
-template <typename T, typename OutT, bool GROUPED>
+template <typename T, typename OutT, bool GROUPED, int BN>
 __global__ void __launch_bounds__(256)
 gemm_nt_kernel(OutT* __restrict__ c, const T* __restrict__ a, const T* __restrict__ w,
                const float* __restrict__ topk_weights, const int32_t* __restrict__ sorted_ids,
                const int32_t* __restrict__ expert_ids, const int32_t* __restrict__ num_post_pad,
                int64_t num_valid, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldc,
                int top_k_div, int mul_routed_weight) {
-  constexpr int BM = 64, BN = 128, BK = 64;
-  constexpr int AS = BK + 8, WS = BK + 8;  // row strides (elements), 16 B pad
+  constexpr int BM = 64, BK = 64;
+  constexpr int NJ = BN / 128;              // 32-column tiles per wave (wave owns BN/4 columns)
+  constexpr int AS = BK + 8, WS = BK + 8;  // row strides (elements), 16 B pad: conflict-free ds_read_b128
+  constexpr int NA = BM * (BK / 8) / 256;  // 2 A chunks per thread per K-tile
+  constexpr int NW = BN * (BK / 8) / 256;  // 8 W chunks per thread per K-tile
   __shared__ __attribute__((aligned(16))) uint16_t a_lds[BM * AS];
   __shared__ __attribute__((aligned(16))) uint16_t w_lds[BN * WS];
   __shared__ int row_id[BM];
@@ -257,83 +263,114 @@ gemm_nt_kernel(OutT* __restrict__ c, const T* __restrict__ a, const T* __restric
   if (GROUPED) {
     if (m0 >= *num_post_pad) return;
     expert = expert_ids[blockIdx.y];
-    if (tid < BM) row_id[tid] = sorted_ids[m0 + tid];
+    if (tid < BM) {
+      const int sid = sorted_ids[m0 + tid];
+      row_id[tid] = (sid >= 0 && sid < num_valid) ? sid : -1;
+    }
   } else {
     if (tid < BM) row_id[tid] = (m0 + tid < M) ? (int)(m0 + tid) : -1;
   }
   __syncthreads();
   const T* wbase = w + expert * N * K;
 
-  f32x16 acc[2];
+  // this thread's staging slots: chunk ch = tid & 7 (8 elements) of rows (tid >> 3) + 32*i
+  const int ch = tid & 7, r0 = tid >> 3;
+  const T* a_ptr[NA];
+  bool a_ok[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int rid = row_id[r0 + 32 * i];
+    a_ok[i] = rid >= 0;
+    const int64_t arow = GROUPED ? (int64_t)(rid / top_k_div) : (int64_t)rid;
+    a_ptr[i] = a + (a_ok[i] ? arow : 0) * lda + ch * 8;
+  }
+  const T* w_ptr[NW];
+  bool w_ok[NW];
+#pragma unroll
+  for (int i = 0; i < NW; ++i) {
+    const int64_t n = n0 + r0 + 32 * i;
+    w_ok[i] = n < N;
+    w_ptr[i] = wbase + (w_ok[i] ? n : 0) * K + ch * 8;
+  }
+  const bool k_vec = (K % 8 == 0) && (lda % 8 == 0);
+
+  Frag16m areg[NA], wreg[NW];
+  auto fetch = [&](int64_t k0) __attribute__((always_inline)) {
+    const int64_t kk = k0 + ch * 8;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      areg[i].u = make_uint4(0, 0, 0, 0);
+      if (a_ok[i]) {
+        if (k_vec && kk + 8 <= K) {
+          areg[i].u = *reinterpret_cast<const uint4*>(a_ptr[i] + k0);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) areg[i].e[j] = (kk + j < K) ? a_ptr[i][k0 + j].v : (uint16_t)0;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      wreg[i].u = make_uint4(0, 0, 0, 0);
+      if (w_ok[i]) {
+        if (k_vec && kk + 8 <= K) {
+          wreg[i].u = *reinterpret_cast<const uint4*>(w_ptr[i] + k0);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) wreg[i].e[j] = (kk + j < K) ? w_ptr[i][k0 + j].v : (uint16_t)0;
+        }
+      }
+    }
+  };
+
+  f32x16 acc[2][NJ];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const bool k_vec = (K % 8 == 0) && (lda % 8 == 0);
+  const uint16_t* a_rd = &a_lds[col * AS + hi * 8];
+  const uint16_t* w_rd = &w_lds[(wave * (BN / 4) + col) * WS + hi * 8];
+  fetch(0);
   for (int64_t k0 = 0; k0 < K; k0 += BK) {
-    __syncthreads();
-    // A tile: 64 rows x 8 chunks of 8 elements = 512 items
-    for (int item = tid; item < BM * (BK / 8); item += 256) {
-      const int r = item >> 3, ch = item & 7;
-      const int rid = row_id[r];
-      Frag16m x;
-      x.u = make_uint4(0, 0, 0, 0);
-      const bool valid = GROUPED ? (rid >= 0 && rid < num_valid) : (rid >= 0);
-      if (valid) {
-        const int64_t arow = GROUPED ? (int64_t)(rid / top_k_div) : (int64_t)rid;
-        const int64_t kk = k0 + ch * 8;
-        const T* p = a + arow * lda + kk;
-        if (k_vec && kk + 8 <= K) {
-          x.u = *reinterpret_cast<const uint4*>(p);
-        } else {
+    __syncthreads();  // previous tile consumed
 #pragma unroll
-          for (int j = 0; j < 8; ++j) x.e[j] = (kk + j < K) ? p[j].v : (uint16_t)0;
-        }
-      }
-      *reinterpret_cast<uint4*>(&a_lds[r * AS + ch * 8]) = x.u;
-    }
-    // W tile: 128 rows x 8 chunks = 1024 items
-    for (int item = tid; item < BN * (BK / 8); item += 256) {
-      const int r = item >> 3, ch = item & 7;
-      const int64_t n = n0 + r;
-      Frag16m x;
-      x.u = make_uint4(0, 0, 0, 0);
-      if (n < N) {
-        const int64_t kk = k0 + ch * 8;
-        const T* p = wbase + n * K + kk;
-        if ((K % 8 == 0) && kk + 8 <= K) {
-          x.u = *reinterpret_cast<const uint4*>(p);
-        } else {
+    for (int i = 0; i < NA; ++i)
+      *reinterpret_cast<uint4*>(&a_lds[(r0 + 32 * i) * AS + ch * 8]) = areg[i].u;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) x.e[j] = (kk + j < K) ? p[j].v : (uint16_t)0;
-        }
-      }
-      *reinterpret_cast<uint4*>(&w_lds[r * WS + ch * 8]) = x.u;
-    }
+    for (int i = 0; i < NW; ++i)
+      *reinterpret_cast<uint4*>(&w_lds[(r0 + 32 * i) * WS + ch * 8]) = wreg[i].u;
     __syncthreads();
+    if (k0 + BK < K) fetch(k0 + BK);  // in flight during the MFMAs
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
-      Frag16m bf, a0, a1;
-      bf.u = *reinterpret_cast<const uint4*>(&w_lds[(wave * 32 + col) * WS + ks * 16 + hi * 8]);
-      a0.u = *reinterpret_cast<const uint4*>(&a_lds[(col)*AS + ks * 16 + hi * 8]);
-      a1.u = *reinterpret_cast<const uint4*>(&a_lds[(32 + col) * AS + ks * 16 + hi * 8]);
-      acc[0] = MfmaG<T>::mma(a0, bf, acc[0]);
-      acc[1] = MfmaG<T>::mma(a1, bf, acc[1]);
+      Frag16m a0, a1;
+      a0.u = *reinterpret_cast<const uint4*>(a_rd + ks * 16);
+      a1.u = *reinterpret_cast<const uint4*>(a_rd + 32 * AS + ks * 16);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        Frag16m b;
+        b.u = *reinterpret_cast<const uint4*>(w_rd + j * 32 * WS + ks * 16);
+        acc[0][j] = MfmaG<T>::mma(a0, b, acc[0][j]);
+        acc[1][j] = MfmaG<T>::mma(a1, b, acc[1][j]);
+      }
     }
   }
-  // epilogue: lane holds C[m = i*32 + (r&3)+8*(r>>2)+4*hi][n = n0 + wave*32 + col]
-  const int64_t n = n0 + wave * 32 + col;
-  if (n < N) {
+  // epilogue: lane holds C[m = i*32 + (r&3)+8*(r>>2)+4*hi][n = n0 + wave*(BN/4) + j*32 + col]
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int64_t n = n0 + wave * (BN / 4) + j * 32 + col;
+    if (n >= N) continue;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
         const int rid = row_id[m];
-        const bool valid = GROUPED ? (rid >= 0 && rid < num_valid) : (rid >= 0);
-        if (valid) {
-          float v = acc[i][r];
+        if (rid >= 0) {
+          float v = acc[i][j][r];
           if (GROUPED && mul_routed_weight) v *= topk_weights[rid];
           OutT* dst = c + (int64_t)rid * ldc + n;
           if constexpr (sizeof(OutT) == 4) *reinterpret_cast<float*>(dst) = v;
@@ -424,8 +461,15 @@ int semipd_moe_grouped_gemm(void* c, const void* a, const void* w, const float* 
   SEMIPD_CHECK_ARG(!mul_routed_weight || topk_weights, SEMIPD_EINVAL,
                    "moe_grouped_gemm: topk_weights required");
   SEMIPD_CHECK_ARG(aligned16(a) && aligned16(w), SEMIPD_EALIGN, "moe_grouped_gemm: unaligned pointer");
-  dim3 grid((unsigned)((n + 127) / 128), (unsigned)((max_sorted + 63) / 64));
-  SEMIPD_DISPATCH_HALF(dtype, T, hipLaunchKernelGGL((gemm_nt_kernel<T, T, true>), grid, dim3(256), 0, as_stream(stream), (T*)c, (const T*)a, (const T*)w, topk_weights, sorted_token_ids, expert_ids, num_tokens_post_pad, num_valid, (int64_t)0, n, k, k, n, top_k_div, mul_routed_weight));
+  // decode-sized calls stream each expert's weights once: narrow tiles = more workgroups in flight;
+  // prefill-sized calls are MFMA-bound: wide tiles halve the LDS traffic per MFMA
+  const bool wide = num_valid >= 2048;
+  dim3 grid((unsigned)((n + (wide ? 255 : 127)) / (wide ? 256 : 128)), (unsigned)((max_sorted + 63) / 64));
+  if (wide) {
+    SEMIPD_DISPATCH_HALF(dtype, T, hipLaunchKernelGGL((gemm_nt_kernel<T, T, true, 256>), grid, dim3(256), 0, as_stream(stream), (T*)c, (const T*)a, (const T*)w, topk_weights, sorted_token_ids, expert_ids, num_tokens_post_pad, num_valid, (int64_t)0, n, k, k, n, top_k_div, mul_routed_weight));
+  } else {
+    SEMIPD_DISPATCH_HALF(dtype, T, hipLaunchKernelGGL((gemm_nt_kernel<T, T, true, 128>), grid, dim3(256), 0, as_stream(stream), (T*)c, (const T*)a, (const T*)w, topk_weights, sorted_token_ids, expert_ids, num_tokens_post_pad, num_valid, (int64_t)0, n, k, k, n, top_k_div, mul_routed_weight));
+  }
   return launch_status("moe_grouped_gemm");
 }
 
@@ -448,7 +492,7 @@ int semipd_lm_head_argmax(const void* hidden, const void* weight, float* logits,
   SEMIPD_CHECK_ARG(aligned16(hidden) && aligned16(weight), SEMIPD_EALIGN,
                    "lm_head_argmax: unaligned pointer");
   dim3 grid((unsigned)((vocab + 127) / 128), (unsigned)((batch + 63) / 64));
-  SEMIPD_DISPATCH_HALF(dtype, T, hipLaunchKernelGGL((gemm_nt_kernel<T, float, false>), grid, dim3(256), 0, as_stream(stream), lg, (const T*)hidden, (const T*)weight, (const float*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, (int64_t)0, batch, vocab, hidden_size, hidden_size, vocab, 1, 0));
+  SEMIPD_DISPATCH_HALF(dtype, T, hipLaunchKernelGGL((gemm_nt_kernel<T, float, false, 128>), grid, dim3(256), 0, as_stream(stream), lg, (const T*)hidden, (const T*)weight, (const float*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, (int64_t)0, batch, vocab, hidden_size, hidden_size, vocab, 1, 0));
   int rc = launch_status("lm_head_gemm");
   if (rc) return rc;
   return semipd_argmax(lg, out, batch, vocab, vocab, SEMIPD_F32, out_is_i64, stream);

@@ -200,3 +200,38 @@ def test_semi_pd_chunked_prefill_and_retract(unified_llama):
         check_against_oracle(oracle, prompts, outs)
     finally:
         eng.shutdown()
+
+
+def test_opt_125m_semi_pd_baseline_config1(device):
+    """BASELINE.json configs[0]: OPT-125m TP=1 --enable-semi-pd, 32 synthetic requests (in=128, out=64),
+    greedy — run on the HIP path and checked token by token (tie margin) against the CPU oracle, which
+    is pinned to HF OPTForCausalLM (tests/test_oracle_models.py)."""
+    import numpy as np
+    from semi_pd_amd.entrypoints.engine import Engine
+    from semi_pd_amd.managers.io_struct import SamplingParams
+    from semi_pd_amd.model_executor.model_runner import build_model, dummy_init_weights
+    from semi_pd_amd.models.opt import OPT_125M
+    cfg = OPT_125M
+    rs = np.random.RandomState(1)
+    offs = rs.randint(0, cfg.vocab_size, size=32)
+    prompts = [[int((offs[i] + i + j) % cfg.vocab_size) for j in range(128)] for i in range(32)]  # bench_serving.py:771-782
+    sa = server_args(cfg, enable_semi_pd=True, context_length=256, max_running_requests=48, max_total_tokens=12000,
+                     cuda_graph_max_bs=32, prefill_cu_percent=50, decode_cu_percent=50)
+    eng = Engine(sa)
+    try:
+        outs = eng.generate(prompts, SamplingParams(max_new_tokens=64, ignore_eos=True), timeout=600)
+    finally:
+        eng.shutdown()
+    assert all(len(o) == 64 for o in outs)
+    # the same seeded weights, rebuilt here for the oracle
+    torch.set_default_dtype(torch.bfloat16)
+    try:
+        with torch.device(device):
+            model = build_model(cfg, torch.bfloat16)
+    finally:
+        torch.set_default_dtype(torch.float32)
+    dummy_init_weights(model, device, sa.random_seed)
+    sd = {k: v.float().cpu() for k, v in model.state_dict().items()}
+    oracle = OracleOPT(cfg, sd)
+    frac = check_against_oracle(oracle, prompts[:8], outs[:8], margin=6e-2)
+    assert frac > 0.8

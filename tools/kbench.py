@@ -117,6 +117,22 @@ def bench_norm():
         print(f"silu_and_mul T={T:5d} d=14336: {t * 1e6:7.1f} us {3 * T * 14336 * 2 / t / 1e9:7.0f} GB/s")
 
 
+def bench_moe():
+    print("# fused MoE (align + GEMM1 + silu*mul + GEMM2 + sum): T, E, k, K, N -> us, TFLOP/s, weight GB/s")
+    from semi_pd_amd.layers.moe import fused_experts
+    E, k, K, N = 64, 6, 2048, 1408
+    w1 = torch.randn(E, 2 * N, K, device=dev, dtype=torch.bfloat16) * 0.02
+    w2 = torch.randn(E, K, N, device=dev, dtype=torch.bfloat16) * 0.02
+    for T in (1, 32, 256, 1024, 4096):
+        x = torch.randn(T, K, device=dev, dtype=torch.bfloat16)
+        tw, ti = ops.topk_softmax(torch.randn(T, E, device=dev), k, True)
+        t = timeit(lambda: fused_experts(x, w1, w2, tw, ti), iters=10)
+        flops = 2.0 * T * k * 3 * N * K
+        wbytes = min(E, T * k) * 3 * N * K * 2
+        print(f"moe T={T:5d} E={E} k={k} K={K} N={N}: {t * 1e6:9.1f} us {flops / t / 1e12:7.1f} TF/s "
+              f"{wbytes / t / 1e9:7.0f} GB/s(weights)")
+
+
 def bench_lm_head():
     print("# lm_head_argmax: B, H, V -> us, GB/s of weight stream")
     for B in (1, 32, 256):
@@ -138,5 +154,7 @@ if __name__ == "__main__":
         bench_extend()
     if which in ("norm", "all"):
         bench_norm()
+    if which in ("moe", "all"):
+        bench_moe()
     if which in ("lm_head", "all"):
         bench_lm_head()
