@@ -286,7 +286,17 @@ class ModelRunner:
         if self.disable_cuda_graph:
             return
         from semi_pd_amd.model_executor.hip_graph_runner import HipGraphRunner
-        self.graph_runner = HipGraphRunner(self)
+        if self.tp_size == 1:
+            self.graph_runner = HipGraphRunner(self)
+            return
+        # TP > 1: the graphs contain RCCL all-reduces.  If this RCCL build refuses stream capture the
+        # decode instance keeps running the same HIP kernels eagerly instead of dying at start-up.
+        try:
+            self.graph_runner = HipGraphRunner(self)
+        except Exception as e:  # pragma: no cover (needs a multi-GPU node)
+            logger.warning("decode hipGraph capture failed with TP=%d (%s); running decode eagerly", self.tp_size, e)
+            self.graph_runner = None
+            torch.cuda.synchronize()
 
     # ------------------------------------------------------------------------------------ forward
     @torch.no_grad()

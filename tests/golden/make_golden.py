@@ -214,7 +214,7 @@ def gen_kv_indices():
     req_to_token = torch.randint(1, 1000, (R, C), generator=g, dtype=torch.int32)
     req_pool_indices = torch.tensor([3, 0, 7, 5], dtype=torch.int64)
     lens = torch.tensor([5, 40, 1, 17], dtype=torch.int64)
-    start = torch.tensor([0, 0, 3, 2], dtype=torch.int32)
+    start = torch.tensor([0, 3, 0, 2], dtype=torch.int32)  # start <= len for every request
     outs = {}
     for tag, st, ln in (("nostart", None, lens), ("start", start, lens - start.long())):
         kv_indptr = torch.zeros(5, dtype=torch.int32)

@@ -1,0 +1,35 @@
+"""One fixed launch shape of the dominant kernels, for rocprofv3 --pmc passes (HBM traffic check).
+Usage: python tools/pmc_target.py [decode|mla|extend]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "semi-pd_amd")]
+import torch
+from semi_pd_amd import ops
+dev = torch.device("cuda:0")
+which = sys.argv[1] if len(sys.argv) > 1 else "decode"
+torch.manual_seed(0)
+if which == "decode":
+    B, ctx, Hq, Hkv, D, splits = 128, 4096, 32, 8, 128, 1
+    N = B * ctx + 1
+    kb = torch.randn(N, Hkv, D, device=dev, dtype=torch.bfloat16)
+    vb = torch.randn(N, Hkv, D, device=dev, dtype=torch.bfloat16)
+    q = torch.randn(B, Hq, D, device=dev, dtype=torch.bfloat16)
+    o = torch.empty_like(q)
+    indptr = torch.arange(B + 1, device=dev, dtype=torch.int32) * ctx
+    idx = (torch.randperm(N - 1, device=dev)[: B * ctx] + 1).to(torch.int32)
+    for _ in range(5):
+        ops.decode_attention_fwd(q, kb, vb, o, indptr, idx, None, splits, D ** -0.5)
+    print("algorithmic_bytes_per_launch", B * ctx * Hkv * 2 * D * 2 + 2 * B * Hq * D * 2)
+elif which == "mla":
+    B, ctx, H, splits = 128, 8192, 16, 4
+    N = B * ctx + 1
+    kv = torch.randn(N, 1, 576, device=dev, dtype=torch.bfloat16)
+    q = torch.randn(B, H, 576, device=dev, dtype=torch.bfloat16)
+    o = torch.empty(B, H, 512, device=dev, dtype=torch.bfloat16)
+    indptr = torch.arange(B + 1, device=dev, dtype=torch.int32) * ctx
+    idx = (torch.randperm(N - 1, device=dev)[: B * ctx] + 1).to(torch.int32)
+    lg = torch.empty(B, H, splits, 513, device=dev, dtype=torch.float32)
+    for _ in range(5):
+        ops.decode_attention_fwd(q, kv, kv[..., :512], o, indptr, idx, lg, splits, 0.1)
+    print("algorithmic_bytes_per_launch", B * ctx * 576 * 2 + B * H * (576 + 512) * 2)
+torch.cuda.synchronize()
