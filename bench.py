@@ -239,6 +239,12 @@ def main():
     roofline = None
     extra = {}
     for s in stats:
+        if s.get("role") == "DECODE" and s.get("decode_steps"):
+            n = s["decode_steps"]
+            extra["decode_step_ms"] = {"steps": int(n), "avg_batch": round(s["decode_tokens"] / n, 1),
+                                       "schedule": round(1e3 * s.get("t_schedule_s", 0) / n, 3),
+                                       "forward_and_sync": round(1e3 * s.get("t_forward_s", 0) / n, 3),
+                                       "output": round(1e3 * s.get("t_output_s", 0) / n, 3)}
         kt = s.get("kernel_timing") or {}
         if "decode_attention" in kt:
             k = kt["decode_attention"]

@@ -381,6 +381,14 @@ gemm_nt_kernel(OutT* __restrict__ c, const T* __restrict__ a, const T* __restric
   }
 }
 
+// defined in skinny_gemm.hip
+bool skinny_gemm_ok(int64_t K, int64_t lda, const void* a, const void* w);
+template <typename T, typename OutT, bool GROUPED>
+int launch_skinny_gemm(OutT* c, const T* a, const T* w, const float* topk_weights, const int32_t* sorted_ids,
+                       const int32_t* expert_ids, const int32_t* num_post_pad, int64_t num_valid, int64_t M,
+                       int64_t N, int64_t K, int64_t lda, int64_t ldc, int64_t m_blocks, int top_k_div,
+                       int mul_routed_weight, hipStream_t st);
+
 }  // namespace semipd
 
 using namespace semipd;
@@ -461,7 +469,10 @@ int semipd_moe_grouped_gemm(void* c, const void* a, const void* w, const float* 
   SEMIPD_CHECK_ARG(!mul_routed_weight || topk_weights, SEMIPD_EINVAL,
                    "moe_grouped_gemm: topk_weights required");
   SEMIPD_CHECK_ARG(aligned16(a) && aligned16(w), SEMIPD_EALIGN, "moe_grouped_gemm: unaligned pointer");
-  // decode-sized calls stream each expert's weights once: narrow tiles = more workgroups in flight;
+  // decode-sized calls are bound by streaming each expert's weights once: weight-streaming kernel
+  if (num_valid <= 2048 && skinny_gemm_ok(k, k, a, w) && n % 4 == 0) {
+    SEMIPD_DISPATCH_HALF(dtype, T, return (launch_skinny_gemm<T, T, true>((T*)c, (const T*)a, (const T*)w, topk_weights, sorted_token_ids, expert_ids, num_tokens_post_pad, num_valid, (int64_t)0, n, k, k, n, (max_sorted + 63) / 64, top_k_div, mul_routed_weight, as_stream(stream))));
+  }
   // prefill-sized calls are MFMA-bound: wide tiles halve the LDS traffic per MFMA
   const bool wide = num_valid >= 2048;
   dim3 grid((unsigned)((n + (wide ? 255 : 127)) / (wide ? 256 : 128)), (unsigned)((max_sorted + 63) / 64));
@@ -491,6 +502,12 @@ int semipd_lm_head_argmax(const void* hidden, const void* weight, float* logits,
   SEMIPD_CHECK_ARG(lg, SEMIPD_EINVAL, "lm_head_argmax: logits or workspace required");
   SEMIPD_CHECK_ARG(aligned16(hidden) && aligned16(weight), SEMIPD_EALIGN,
                    "lm_head_argmax: unaligned pointer");
+  if (batch <= 64 && skinny_gemm_ok(hidden_size, hidden_size, hidden, weight) && vocab % 4 == 0) {
+    int rc0 = 0;
+    SEMIPD_DISPATCH_HALF(dtype, T, rc0 = (launch_skinny_gemm<T, float, false>(lg, (const T*)hidden, (const T*)weight, nullptr, nullptr, nullptr, nullptr, (int64_t)0, batch, vocab, hidden_size, hidden_size, vocab, (int64_t)1, 1, 0, as_stream(stream))));
+    if (rc0) return rc0;
+    return semipd_argmax(lg, out, batch, vocab, vocab, SEMIPD_F32, out_is_i64, stream);
+  }
   dim3 grid((unsigned)((vocab + 127) / 128), (unsigned)((batch + 63) / 64));
   SEMIPD_DISPATCH_HALF(dtype, T, hipLaunchKernelGGL((gemm_nt_kernel<T, float, false, 128>), grid, dim3(256), 0, as_stream(stream), lg, (const T*)hidden, (const T*)weight, (const float*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, (int64_t)0, batch, vocab, hidden_size, hidden_size, vocab, 1, 0));
   int rc = launch_status("lm_head_gemm");

@@ -1,0 +1,217 @@
+// Weight-streaming "skinny" NT GEMM for gfx950: C[m, n] = sum_k A[m, k] * W[e, n, k] with at most 64
+// rows of A per block (decode-sized MoE expert blocks, lm_head at decode batch sizes).
+//
+// These calls are bound by reading W once from HBM, so the kernel is built like the decode-attention
+// kernel rather than like a tiled GEMM:
+//   * a wave owns 16 rows of W (output columns) and streams them straight from HBM in MFMA A-operand
+//     layout (lane l: row l & 15, 16 bytes at k-block l >> 4), one K-chunk of 256 ahead in registers;
+//   * the <= 64 activation rows of the block are staged per K-chunk in LDS (shared by the 4 waves,
+//     +16 B row pad, conflict-free ds_read_b128) and used as the B operand: C^T[n, m] tiles of
+//     v_mfma_f32_16x16x32, up to four m-tiles, empty m-tiles skipped;
+//   * a lane ends up with 4 consecutive n of one row m, so the stores are 8 / 16 bytes wide.
+// GROUPED = fused_moe_kernel semantics (rows through sorted_token_ids, weights of expert_ids[block],
+// optional routed-weight multiply; layers/moe/fused_moe_triton/fused_moe.py:54-273).
+#include "common.h"
+
+namespace semipd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+
+union FragS {
+  uint4 u;
+  uint16_t e[8];
+  bf16x8_t b;
+  f16x8_t f;
+};
+template <typename T> struct MfmaS;
+template <> struct MfmaS<bf16_t> {
+  __device__ static inline f32x4 mma(const FragS& a, const FragS& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.b, b.b, c, 0, 0, 0);
+  }
+};
+template <> struct MfmaS<f16_t> {
+  __device__ static inline f32x4 mma(const FragS& a, const FragS& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a.f, b.f, c, 0, 0, 0);
+  }
+};
+
+template <typename T, typename OutT, bool GROUPED>
+__global__ void __launch_bounds__(256, 2)
+skinny_gemm_kernel(OutT* __restrict__ c, const T* __restrict__ a, const T* __restrict__ w,
+                   const float* __restrict__ topk_weights, const int32_t* __restrict__ sorted_ids,
+                   const int32_t* __restrict__ expert_ids, const int32_t* __restrict__ num_post_pad,
+                   int64_t num_valid, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldc,
+                   int top_k_div, int mul_routed_weight) {
+  constexpr int BM = 64, BNW = 16, KC = 256;     // rows of A per block, W rows per wave, K chunk
+  constexpr int AS = KC + 8;                      // LDS row stride (elements)
+  constexpr int KSC = KC / 32;                    // 8 MFMA k-steps per chunk
+  constexpr int NA = BM * (KC / 8) / 256;         // 8 A chunks of 16 B per thread per K-chunk
+  __shared__ __attribute__((aligned(16))) uint16_t a_lds[BM * AS];
+  __shared__ int row_id[BM];
+  __shared__ int n_rows;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c16 = lane & 15, q4 = lane >> 4;
+  const int64_t m0 = (int64_t)blockIdx.y * BM;
+  const int64_t n0 = (int64_t)blockIdx.x * (4 * BNW) + wave * BNW;
+  int64_t expert = 0;
+  if (GROUPED) {
+    if (m0 >= *num_post_pad) return;
+    expert = expert_ids[blockIdx.y];
+    if (tid < BM) {
+      const int sid = sorted_ids[m0 + tid];
+      row_id[tid] = (sid >= 0 && sid < num_valid) ? sid : -1;
+    }
+  } else {
+    if (tid < BM) row_id[tid] = (m0 + tid < M) ? (int)(m0 + tid) : -1;
+  }
+  if (tid == 0) n_rows = 0;
+  __syncthreads();
+  if (tid < BM && row_id[tid] >= 0) atomicMax(&n_rows, tid + 1);
+  __syncthreads();
+  const int m_tiles = (n_rows + 15) >> 4;  // real rows are packed at the front of a block
+  if (m_tiles == 0) return;
+
+  // ---- A staging slots: chunk ch (16 B) of rows r0 + 8*i ----
+  const int ch = tid & 31, r0 = tid >> 5;  // 32 chunks per 256-wide row, 8 rows per pass
+  const T* a_ptr[NA];
+  bool a_ok[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int rid = row_id[r0 + 8 * i];
+    a_ok[i] = rid >= 0;
+    const int64_t arow = GROUPED ? (int64_t)(rid / top_k_div) : (int64_t)rid;
+    a_ptr[i] = a + (a_ok[i] ? arow : 0) * lda + ch * 8;
+  }
+  // ---- W rows of this wave: lane = row c16, 16 bytes at k = q4*8 (+32 per k-step) ----
+  const bool w_ok = (n0 + c16) < N;
+  const T* w_ptr = w + expert * N * K + (w_ok ? (n0 + c16) : 0) * K + q4 * 8;
+
+  FragS areg[NA];
+  FragS wreg[2][KSC];
+  auto fetch_a = [&](int64_t k0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      areg[i].u = make_uint4(0, 0, 0, 0);
+      if (a_ok[i] && k0 + ch * 8 < K) areg[i].u = *reinterpret_cast<const uint4*>(a_ptr[i] + k0);
+    }
+  };
+  auto fetch_w = [&](FragS (&r)[KSC], int64_t k0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ks = 0; ks < KSC; ++ks) {
+      r[ks].u = make_uint4(0, 0, 0, 0);
+      if (w_ok && k0 + ks * 32 + q4 * 8 < K) r[ks].u = *reinterpret_cast<const uint4*>(w_ptr + k0 + ks * 32);
+    }
+  };
+
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const uint16_t* a_rd = &a_lds[c16 * AS + q4 * 8];
+
+  auto compute = [&](FragS (&r)[KSC]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ks = 0; ks < KSC; ++ks) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (t < m_tiles) {
+          FragS b;
+          b.u = *reinterpret_cast<const uint4*>(a_rd + t * 16 * AS + ks * 32);
+          acc[t] = MfmaS<T>::mma(r[ks], b, acc[t]);
+        }
+      }
+    }
+  };
+
+  fetch_a(0);
+  fetch_w(wreg[0], 0);
+  for (int64_t k0 = 0; k0 < K; k0 += 2 * KC) {
+    // ---- even chunk ----
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+      *reinterpret_cast<uint4*>(&a_lds[(r0 + 8 * i) * AS + ch * 8]) = areg[i].u;
+    __syncthreads();
+    if (k0 + KC < K) {
+      fetch_a(k0 + KC);
+      fetch_w(wreg[1], k0 + KC);
+    }
+    compute(wreg[0]);
+    // ---- odd chunk ----
+    if (k0 + KC < K) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+        *reinterpret_cast<uint4*>(&a_lds[(r0 + 8 * i) * AS + ch * 8]) = areg[i].u;
+      __syncthreads();
+      if (k0 + 2 * KC < K) {
+        fetch_a(k0 + 2 * KC);
+        fetch_w(wreg[0], k0 + 2 * KC);
+      }
+      compute(wreg[1]);
+    }
+  }
+
+  // ---- epilogue: lane holds C^T[n = n0 + q4*4 + r][m = t*16 + c16] ----
+  const int64_t nb = n0 + q4 * 4;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    if (t >= m_tiles) continue;
+    const int rid = row_id[t * 16 + c16];
+    if (rid < 0 || nb >= N) continue;
+    float v[4];
+    const float scale = (GROUPED && mul_routed_weight) ? topk_weights[rid] : 1.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = acc[t][r] * scale;
+    OutT* dst = c + (int64_t)rid * ldc + nb;
+    if (nb + 4 <= N && (ldc % 4 == 0)) {
+      if constexpr (sizeof(OutT) == 4) {
+        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        uint2 p;
+        p.x = (uint32_t)Elem<OutT>::from_f(v[0]).v | ((uint32_t)Elem<OutT>::from_f(v[1]).v << 16);
+        p.y = (uint32_t)Elem<OutT>::from_f(v[2]).v | ((uint32_t)Elem<OutT>::from_f(v[3]).v << 16);
+        *reinterpret_cast<uint2*>(dst) = p;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (nb + r < N) {
+          if constexpr (sizeof(OutT) == 4) *reinterpret_cast<float*>(dst + r) = v[r];
+          else dst[r] = Elem<OutT>::from_f(v[r]);
+        }
+      }
+    }
+  }
+}
+
+// usable when K is a multiple of 32 (whole MFMA k-steps) and rows are 16-byte aligned
+bool skinny_gemm_ok(int64_t K, int64_t lda, const void* a, const void* w) {
+  return K % 32 == 0 && lda % 8 == 0 && aligned16(a) && aligned16(w);
+}
+
+template <typename T, typename OutT, bool GROUPED>
+int launch_skinny_gemm(OutT* c, const T* a, const T* w, const float* topk_weights, const int32_t* sorted_ids,
+                       const int32_t* expert_ids, const int32_t* num_post_pad, int64_t num_valid, int64_t M,
+                       int64_t N, int64_t K, int64_t lda, int64_t ldc, int64_t m_blocks, int top_k_div,
+                       int mul_routed_weight, hipStream_t st) {
+  dim3 grid((unsigned)((N + 63) / 64), (unsigned)m_blocks);
+  hipLaunchKernelGGL((skinny_gemm_kernel<T, OutT, GROUPED>), grid, dim3(256), 0, st, c, a, w, topk_weights,
+                     sorted_ids, expert_ids, num_post_pad, num_valid, M, N, K, lda, ldc, top_k_div,
+                     mul_routed_weight);
+  return launch_status("skinny_gemm");
+}
+
+#define SKINNY_INST(T, OutT, G)                                                                        \
+  template int launch_skinny_gemm<T, OutT, G>(OutT*, const T*, const T*, const float*, const int32_t*, \
+                                              const int32_t*, const int32_t*, int64_t, int64_t, int64_t, \
+                                              int64_t, int64_t, int64_t, int64_t, int, int, hipStream_t);
+SKINNY_INST(bf16_t, bf16_t, true)
+SKINNY_INST(f16_t, f16_t, true)
+SKINNY_INST(bf16_t, float, false)
+SKINNY_INST(f16_t, float, false)
+#undef SKINNY_INST
+
+}  // namespace semipd

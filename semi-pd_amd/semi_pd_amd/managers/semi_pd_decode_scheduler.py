@@ -166,14 +166,23 @@ class SemiPDDecodeScheduler(SchedulerBase):
 
     # ---------------------------------------------------------------------------- loop
     def step(self) -> bool:
+        t0 = time.perf_counter()
         recv = self.recv_requests()
         self.process_input_requests(recv)
         batch = self.get_next_batch_to_run()
         if batch is None:
             return bool(recv)
+        t1 = time.perf_counter()
         _, next_token_ids = self.run_batch(batch)
         batch.output_ids = next_token_ids
-        self.process_batch_result_decode(batch, next_token_ids.tolist())
+        ids = next_token_ids.tolist()  # the only device sync of a decode step
+        t2 = time.perf_counter()
+        self.process_batch_result_decode(batch, ids)
+        t3 = time.perf_counter()
+        st = self.stats
+        st["t_schedule_s"] = st.get("t_schedule_s", 0.0) + (t1 - t0)
+        st["t_forward_s"] = st.get("t_forward_s", 0.0) + (t2 - t1)
+        st["t_output_s"] = st.get("t_output_s", 0.0) + (t3 - t2)
         return True
 
     def event_loop_normal(self):
