@@ -190,6 +190,34 @@ int semipd_lm_head_argmax(const void* hidden, const void* weight, float* logits,
                           int dtype, int out_is_i64, void* stream);
 size_t semipd_lm_head_argmax_workspace(int64_t batch, int64_t vocab);
 
+/* Stochastic branch of Sampler.forward (layers/sampler.py:77-136).  All rows fp32, contiguous
+ * [batch, vocab]; per-row parameter arrays may be NULL, then the scalar *_val applies to every row.
+ *
+ * logits <- softmax(logits / temperature[b]) in place (sampler.py:78-81). */
+int semipd_softmax_temperature(float* logits, const float* temperatures, int64_t batch, int64_t vocab,
+                               void* stream);
+/* Joint top-k / top-p rejection sampling with uniform_samples [rounds, batch]; out_ids int32 [batch],
+ * success uint8 [batch] (may be NULL).  replaces torch.ops.sgl_kernel.top_k_top_p_sampling_from_probs
+ * with filter_apply_order="joint" (sgl-kernel/csrc/torch_extension.cc:166-170;
+ * python/sgl_kernel/sampling.py:106-165; pinned by sgl-kernel/tests/test_sampling.py:8-52). */
+int semipd_top_k_top_p_sampling_from_probs(const float* probs, const float* uniform_samples,
+                                           const int32_t* top_ks, int32_t top_k_val, const float* top_ps,
+                                           float top_p_val, int32_t* out_ids, uint8_t* success, int64_t batch,
+                                           int64_t vocab, int rounds, void* stream);
+/* Sample among probs >= min_p[b] * max_v probs[b,v] with uniform_samples [batch].
+ * replaces min_p_sampling_from_probs (torch_extension.cc:160-164; tests/test_sampling.py:112-141). */
+int semipd_min_p_sampling_from_probs(const float* probs, const float* uniform_samples, const float* min_ps,
+                                     float min_p_val, int32_t* out_ids, int64_t batch, int64_t vocab,
+                                     void* stream);
+/* out = probs restricted to the top-k entries (ties at the k-th value kept), renormalised.
+ * replaces top_k_renorm_probs_wrapper (torch_extension.cc:156-158; tests/test_sampling.py:84-109). */
+int semipd_top_k_renorm_prob(const float* probs, float* out, const int32_t* top_ks, int32_t top_k_val,
+                             int64_t batch, int64_t vocab, void* stream);
+/* out = probs restricted to the smallest set of largest entries with mass >= top_p, renormalised.
+ * replaces top_p_renorm_probs (torch_extension.cc:152-154; tests/test_sampling.py:57-81). */
+int semipd_top_p_renorm_prob(const float* probs, float* out, const float* top_ps, float top_p_val,
+                             int64_t batch, int64_t vocab, void* stream);
+
 /* ------------------------------------------------------------------ */
 /* a10/a11/a12  MoE                                                    */
 /* ------------------------------------------------------------------ */

@@ -49,6 +49,11 @@ _SIGNATURES = {
     "semipd_argmax": [_vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp],
     "semipd_lm_head_argmax": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp],
     "semipd_lm_head_argmax_workspace": [_i64, _i64],
+    "semipd_softmax_temperature": [_vp, _vp, _i64, _i64, _vp],
+    "semipd_top_k_top_p_sampling_from_probs": [_vp, _vp, _vp, _i32, _vp, _f32, _vp, _vp, _i64, _i64, _i32, _vp],
+    "semipd_min_p_sampling_from_probs": [_vp, _vp, _vp, _f32, _vp, _i64, _i64, _vp],
+    "semipd_top_k_renorm_prob": [_vp, _vp, _vp, _i32, _i64, _i64, _vp],
+    "semipd_top_p_renorm_prob": [_vp, _vp, _vp, _f32, _i64, _i64, _vp],
     "semipd_topk_softmax": [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp],
     "semipd_grouped_topk": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "semipd_moe_align_block_size": [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp],

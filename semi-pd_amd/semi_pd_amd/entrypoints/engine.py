@@ -312,7 +312,10 @@ class Engine:
     def generate(self, prompts: Sequence[Sequence[int]], sampling_params: SamplingParams,
                  timeout: float = 3600.0) -> List[List[int]]:
         import copy
-        rids = [self.add_request(p, copy.deepcopy(sampling_params)) for p in prompts]
+        per_req = sampling_params if isinstance(sampling_params, (list, tuple)) else [sampling_params] * len(prompts)
+        if len(per_req) != len(prompts):
+            raise ValueError("generate: one SamplingParams per prompt (or a single one for all) expected")
+        rids = [self.add_request(p, copy.deepcopy(sp)) for p, sp in zip(prompts, per_req)]
         self.wait(rids, timeout)
         return [self._outputs[r] for r in rids]
 

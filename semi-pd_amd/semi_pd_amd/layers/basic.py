@@ -370,15 +370,36 @@ class LogitsProcessor(nn.Module):
 
 
 class Sampler(nn.Module):
-    """Greedy sampling (sampler.py:72-74): argmax over fp32 logits -> int32 ids.  Non-greedy
-    sampling is a §8(f) "next" row."""
+    """layers/sampler.py:38-171.  Greedy batches: argmax over fp32 logits -> int32 ids (:72-74; already
+    produced by the fused lm_head call when it ran).  Otherwise logits / T -> softmax -> joint
+    top-k / top-p rejection sampling, or top-k renorm -> top-p renorm -> min-p sampling when a request
+    asks for min_p (:77-107), all in HIP (csrc/sampling.hip)."""
+
+    MAX_TOP_K_ROUND = 32  # sampler.py:92
 
     def forward(self, logits_output: LogitsProcessorOutput, sampling_info=None) -> torch.Tensor:
-        if sampling_info is not None and not getattr(sampling_info, "is_all_greedy", True):
-            raise NotImplementedError("only greedy sampling (temperature 0) is implemented in this round")
-        if logits_output.next_token_ids is not None:
-            return logits_output.next_token_ids
+        if sampling_info is None or getattr(sampling_info, "is_all_greedy", True):
+            if logits_output.next_token_ids is not None:
+                return logits_output.next_token_ids
+            logits = logits_output.next_token_logits
+            if not logits.is_contiguous():
+                logits = logits.contiguous()
+            return ops.greedy_argmax(logits)
         logits = logits_output.next_token_logits
-        if not logits.is_contiguous():
-            logits = logits.contiguous()
-        return ops.greedy_argmax(logits)
+        if logits is None:
+            raise RuntimeError("Sampler: stochastic sampling needs the fp32 logits")
+        if logits.dtype != torch.float32 or not logits.is_contiguous():
+            logits = logits.float().contiguous()
+        batch = logits.shape[0]
+        if len(sampling_info) != batch:
+            raise RuntimeError(f"Sampler: {len(sampling_info)} sampling params for {batch} logit rows")
+        probs = ops.softmax_temperature_(logits, sampling_info.temperatures)  # in place, like the reference
+        uniform_samples = torch.rand((self.MAX_TOP_K_ROUND, batch), device=probs.device)
+        if sampling_info.need_min_p_sampling:
+            probs = ops.top_k_renorm_prob(probs, sampling_info.top_ks)
+            probs = ops.top_p_renorm_prob(probs, sampling_info.top_ps)
+            ids = ops.min_p_sampling_from_probs(probs, uniform_samples, sampling_info.min_ps)
+        else:
+            ids, _ = ops.top_k_top_p_sampling_from_probs(probs, uniform_samples, sampling_info.top_ks,
+                                                         sampling_info.top_ps, filter_apply_order="joint")
+        return ids

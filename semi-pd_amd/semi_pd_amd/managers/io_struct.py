@@ -9,15 +9,45 @@ from typing import Any, List, Optional
 
 @dataclass
 class SamplingParams:
-    """Subset of sampling/sampling_params.py used by the greedy configs."""
+    """sampling/sampling_params.py:27-110 (the fields the Semi-PD path consumes).  The default
+    temperature here is 0 (the benchmark configs are greedy); the HTTP layer applies the reference's
+    default of 1.0 when a request does not specify one."""
     max_new_tokens: int = 128
     temperature: float = 0.0
+    top_p: float = 1.0
+    top_k: int = -1
+    min_p: float = 0.0
     ignore_eos: bool = False
     stop_token_ids: Optional[List[int]] = None
 
+    def __post_init__(self):
+        self.verify()
+        self.normalize()
+
+    def normalize(self):
+        """sampling_params.py:78-85: temperature ~ 0 means greedy == top_k 1; top_k -1 = whole vocab."""
+        if self.temperature < 1e-6:
+            self.temperature = 1.0
+            self.top_k = 1
+        if self.top_k == -1:
+            self.top_k = 1 << 30
+
+    def verify(self):
+        """sampling_params.py:87-110."""
+        if self.temperature < 0.0:
+            raise ValueError(f"temperature must be non-negative, got {self.temperature}.")
+        if not 0.0 < self.top_p <= 1.0:
+            raise ValueError(f"top_p must be in (0, 1], got {self.top_p}.")
+        if not 0.0 <= self.min_p <= 1.0:
+            raise ValueError(f"min_p must be in [0, 1], got {self.min_p}.")
+        if self.top_k < -1 or self.top_k == 0:
+            raise ValueError(f"top_k must be -1 (disable), or at least 1, got {self.top_k}.")
+        if self.max_new_tokens is not None and self.max_new_tokens < 0:
+            raise ValueError(f"max_new_tokens must be at least 0, got {self.max_new_tokens}.")
+
     @property
     def is_greedy(self) -> bool:
-        return self.temperature == 0.0
+        return self.top_k <= 1
 
 
 @dataclass

@@ -15,6 +15,7 @@ from typing import List, Optional
 import torch
 
 from semi_pd_amd.managers.io_struct import SamplingParams
+from semi_pd_amd.sampling_batch_info import SamplingBatchInfo
 from semi_pd_amd.model_executor.forward_batch_info import ForwardMode
 
 CLIP_MAX_NEW_TOKENS_ESTIMATION = 4096  # schedule_policy.py:36-40
@@ -100,6 +101,7 @@ class ModelWorkerBatch:
     extend_num_tokens: Optional[int] = None
     extend_seq_lens: Optional[List[int]] = None
     extend_prefix_lens: Optional[List[int]] = None
+    sampling_info: Optional[SamplingBatchInfo] = None
 
 
 class ScheduleBatch:
@@ -257,7 +259,8 @@ class ScheduleBatch:
             seq_lens=self.seq_lens, out_cache_loc=self.out_cache_loc, seq_lens_sum=self.seq_lens_sum,
             extend_num_tokens=self.extend_num_tokens if ext else None,
             extend_seq_lens=self.extend_lens if ext else None,
-            extend_prefix_lens=self.prefix_lens if ext else None)
+            extend_prefix_lens=self.prefix_lens if ext else None,
+            sampling_info=SamplingBatchInfo.from_reqs(self.reqs, getattr(self, "vocab_size", 0), self.device))
 
 
 class AddReqResult(Enum):

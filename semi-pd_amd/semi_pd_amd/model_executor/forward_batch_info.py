@@ -47,6 +47,7 @@ class ForwardBatch:
     req_to_token_pool: object = None
     token_to_kv_pool: object = None
     attn_backend: object = None
+    sampling_info: object = None
 
     @classmethod
     def init_new(cls, batch, model_runner) -> "ForwardBatch":
@@ -75,4 +76,5 @@ class ForwardBatch:
         ret.req_to_token_pool = model_runner.req_to_token_pool
         ret.token_to_kv_pool = model_runner.token_to_kv_pool
         ret.attn_backend = model_runner.attn_backend
+        ret.sampling_info = getattr(batch, "sampling_info", None)
         return ret

@@ -17,6 +17,7 @@ class KernelTiming:
     def __init__(self, sample_every: int = 16, max_pending: int = 4096):
         self.sample_every = sample_every
         self.max_pending = max_pending
+        self.gate_cycles = 0  # calibrated on first use (see start())
         self._step = 0
         self.active = False
         self._pending: List[Tuple[str, torch.cuda.Event, torch.cuda.Event, float, float]] = []
@@ -31,7 +32,27 @@ class KernelTiming:
     def end_step(self):
         self.active = False
 
+    @staticmethod
+    def _calibrate_gate(target_us: float = 25.0) -> int:
+        """Ticks of torch.cuda._sleep that spin for ~target_us (the tick unit differs per platform)."""
+        probe = 20_000
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(probe)
+        torch.cuda.synchronize()
+        s.record()
+        torch.cuda._sleep(probe)
+        e.record()
+        torch.cuda.synchronize()
+        us = max(s.elapsed_time(e) * 1e3, 1.0)
+        return max(int(probe * target_us / us), 1)
+
     def start(self) -> torch.cuda.Event:
+        # An eager step is CPU-bound: without a gate the start event retires before the kernel packet
+        # has even been submitted and the pair measures launch latency, not the kernel.  A short
+        # device-side spin (~20 us) lets the CPU queue start-event, kernel(s) and stop-event first.
+        if self.gate_cycles == 0:
+            self.gate_cycles = self._calibrate_gate()
+        torch.cuda._sleep(self.gate_cycles)
         e = torch.cuda.Event(enable_timing=True)
         e.record(torch.cuda.current_stream())
         return e

@@ -326,4 +326,4 @@ class ModelRunner:
         return self.model.forward(forward_batch.input_ids, forward_batch.positions, forward_batch)
 
     def sample(self, logits_output, forward_batch=None) -> torch.Tensor:
-        return self.sampler(logits_output, None)
+        return self.sampler(logits_output, getattr(forward_batch, "sampling_info", None))

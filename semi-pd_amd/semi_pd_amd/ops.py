@@ -308,6 +308,94 @@ def lm_head_argmax(hidden: torch.Tensor, weight: torch.Tensor, return_logits: bo
     return (logits if return_logits else None), out
 
 
+# --------------------------------------------------------------------------- stochastic sampling
+def _probs_2d(probs: torch.Tensor, name: str) -> Tuple[int, int]:
+    if probs.dim() != 2 or probs.dtype != torch.float32 or not probs.is_contiguous():
+        raise RuntimeError(f"{name}: probs must be a contiguous fp32 [batch, vocab] tensor")
+    return probs.shape[0], probs.shape[1]
+
+
+def _per_row(value, batch: int, dtype: torch.dtype, device, name: str):
+    """(tensor-or-None, scalar): the reference ops accept a python scalar or a [batch] tensor."""
+    if isinstance(value, torch.Tensor):
+        if value.numel() != batch:
+            raise RuntimeError(f"{name}: expected {batch} per-row values, got {value.numel()}")
+        return value.to(device=device, dtype=dtype).contiguous(), 0
+    return None, value
+
+
+def softmax_temperature_(logits: torch.Tensor, temperatures: Optional[torch.Tensor]) -> torch.Tensor:
+    """logits.div_(temperatures); logits[:] = softmax(logits, -1) in one pass set (sampler.py:78-81)."""
+    B, V = _probs_2d(logits, "softmax_temperature_")
+    t = None
+    if temperatures is not None:
+        t = temperatures.reshape(-1).to(torch.float32).contiguous()
+        if t.numel() != B:
+            raise RuntimeError("softmax_temperature_: one temperature per row required")
+    check(_lib.load().semipd_softmax_temperature(ptr(logits), ptr(t) if t is not None else None, B, V,
+                                                 current_stream(logits.device)), "softmax_temperature")
+    return logits
+
+
+def top_k_top_p_sampling_from_probs(probs: torch.Tensor, uniform_samples: torch.Tensor, top_k, top_p,
+                                    filter_apply_order: str = "joint"):
+    """sgl_kernel.top_k_top_p_sampling_from_probs (python/sgl_kernel/sampling.py:139-165):
+    returns (samples int32 [batch], success bool [batch])."""
+    if filter_apply_order != "joint":
+        raise RuntimeError("top_k_top_p_sampling_from_probs: only filter_apply_order='joint' is implemented")
+    B, V = _probs_2d(probs, "top_k_top_p_sampling_from_probs")
+    if uniform_samples.dim() != 2 or uniform_samples.shape[1] != B or uniform_samples.dtype != torch.float32 \
+            or not uniform_samples.is_contiguous():
+        raise RuntimeError("top_k_top_p_sampling_from_probs: uniform_samples must be fp32 [rounds, batch]")
+    ks, k_val = _per_row(top_k, B, torch.int32, probs.device, "top_k")
+    ps, p_val = _per_row(top_p, B, torch.float32, probs.device, "top_p")
+    out = torch.empty(B, dtype=torch.int32, device=probs.device)
+    success = torch.empty(B, dtype=torch.uint8, device=probs.device)
+    check(_lib.load().semipd_top_k_top_p_sampling_from_probs(
+        ptr(probs), ptr(uniform_samples), ptr(ks) if ks is not None else None, int(k_val),
+        ptr(ps) if ps is not None else None, float(p_val), ptr(out), ptr(success), B, V,
+        uniform_samples.shape[0], current_stream(probs.device)), "top_k_top_p_sampling_from_probs")
+    return out, success.bool()
+
+
+def min_p_sampling_from_probs(probs: torch.Tensor, uniform_samples: torch.Tensor, min_p) -> torch.Tensor:
+    """sgl_kernel.min_p_sampling_from_probs (python/sgl_kernel/sampling.py:194-210)."""
+    B, V = _probs_2d(probs, "min_p_sampling_from_probs")
+    u = uniform_samples
+    if u.dim() == 2:  # the sampler hands over [rounds, batch]; only the first round is consumed
+        u = u[0]
+    if u.numel() != B or u.dtype != torch.float32 or not u.is_contiguous():
+        raise RuntimeError("min_p_sampling_from_probs: uniform_samples must be fp32 [batch]")
+    ms, m_val = _per_row(min_p, B, torch.float32, probs.device, "min_p")
+    out = torch.empty(B, dtype=torch.int32, device=probs.device)
+    check(_lib.load().semipd_min_p_sampling_from_probs(
+        ptr(probs), ptr(u), ptr(ms) if ms is not None else None, float(m_val), ptr(out), B, V,
+        current_stream(probs.device)), "min_p_sampling_from_probs")
+    return out
+
+
+def top_k_renorm_prob(probs: torch.Tensor, top_k) -> torch.Tensor:
+    """sgl_kernel.top_k_renorm_prob (python/sgl_kernel/sampling.py:25-32)."""
+    B, V = _probs_2d(probs, "top_k_renorm_prob")
+    ks, k_val = _per_row(top_k, B, torch.int32, probs.device, "top_k")
+    out = torch.empty_like(probs)
+    check(_lib.load().semipd_top_k_renorm_prob(ptr(probs), ptr(out), ptr(ks) if ks is not None else None,
+                                               int(k_val), B, V, current_stream(probs.device)),
+          "top_k_renorm_prob")
+    return out
+
+
+def top_p_renorm_prob(probs: torch.Tensor, top_p) -> torch.Tensor:
+    """sgl_kernel.top_p_renorm_prob (python/sgl_kernel/sampling.py:53-60)."""
+    B, V = _probs_2d(probs, "top_p_renorm_prob")
+    ps, p_val = _per_row(top_p, B, torch.float32, probs.device, "top_p")
+    out = torch.empty_like(probs)
+    check(_lib.load().semipd_top_p_renorm_prob(ptr(probs), ptr(out), ptr(ps) if ps is not None else None,
+                                               float(p_val), B, V, current_stream(probs.device)),
+          "top_p_renorm_prob")
+    return out
+
+
 # --------------------------------------------------------------------------- MoE
 def topk_softmax(gating_output: torch.Tensor, topk: int, renormalize: bool):
     """fused_topk (layers/moe/topk.py:44-75): fp32 softmax + top-k."""

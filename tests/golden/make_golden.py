@@ -273,8 +273,50 @@ def gen_topk():
     save("moe_topk", **arrs)
 
 
+def _reference_sampler_functions():
+    """layers/sampler.py cannot be imported here (its module imports pull the scheduler), but the two
+    torch-native helpers it defines are self-contained: compile just those two function definitions
+    from the reference file at generation time (nothing of it is stored)."""
+    import ast
+    path = "/root/reference/python/sglang/srt/layers/sampler.py"
+    tree = ast.parse(open(path).read())
+    want = {"top_k_top_p_min_p_sampling_from_probs_torch", "top_p_normalize_probs_torch"}
+    mod = ast.Module(body=[n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in want],
+                     type_ignores=[])
+    ns = {"torch": torch}
+    exec(compile(mod, path, "exec"), ns)
+    return ns["top_k_top_p_min_p_sampling_from_probs_torch"], ns["top_p_normalize_probs_torch"]
+
+
+def gen_sampling():
+    """Empirical token counts of the reference's torch-native sampler (sampler.py:207-243) and the
+    output of top_p_normalize_probs_torch, on small seeded distributions."""
+    sample_fn, top_p_norm = _reference_sampler_functions()
+    g = torch.Generator().manual_seed(11)
+    B, V, draws = 6, 48, 4000
+    logits = torch.randn(B, V, generator=g) * 2.0
+    temps = torch.tensor([1.0, 0.7, 1.3, 1.0, 0.5, 2.0]).view(-1, 1)
+    probs = torch.softmax(logits / temps, dim=-1)
+    top_ks = torch.tensor([1 << 30, 5, 12, 1, 1 << 30, 20], dtype=torch.int32)
+    top_ps = torch.tensor([1.0, 1.0, 0.8, 1.0, 0.6, 0.95])
+    min_ps = torch.tensor([0.0, 0.0, 0.0, 0.0, 0.0, 0.0])
+    min_ps2 = torch.tensor([0.05, 0.2, 0.0, 0.0, 0.1, 0.02])
+    arrs = {"logits": logits.numpy(), "temperatures": temps.numpy(), "probs": probs.numpy(),
+            "top_ks": top_ks.numpy(), "top_ps": top_ps.numpy(), "min_ps": min_ps2.numpy(),
+            "draws": np.array([draws])}
+    torch.manual_seed(5)
+    for name, mp, need in (("counts", min_ps, False), ("counts_min_p", min_ps2, True)):
+        counts = torch.zeros(B, V, dtype=torch.int64)
+        for _ in range(draws):
+            ids = sample_fn(probs.clone(), top_ks, top_ps, mp, need)
+            counts[torch.arange(B), ids.long()] += 1
+        arrs[name] = counts.numpy()
+    arrs["top_p_normalized"] = top_p_norm(probs.clone(), top_ps).numpy()
+    save("sampling", **arrs)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rmsnorm", "rope", "kv_indices", "topk", "decode", "extend"]
+    which = sys.argv[1:] or ["rmsnorm", "rope", "kv_indices", "topk", "decode", "extend", "sampling"]
     for w in which:
         {"rmsnorm": gen_rmsnorm, "rope": gen_rope, "kv_indices": gen_kv_indices, "topk": gen_topk,
-         "decode": gen_decode, "extend": gen_extend}[w]()
+         "decode": gen_decode, "extend": gen_extend, "sampling": gen_sampling}[w]()

@@ -235,3 +235,34 @@ def test_opt_125m_semi_pd_baseline_config1(device):
     oracle = OracleOPT(cfg, sd)
     frac = check_against_oracle(oracle, prompts[:8], outs[:8], margin=6e-2)
     assert frac > 0.8
+
+
+def test_semi_pd_stochastic_sampling_stays_in_oracle_top_k(unified_llama):
+    """Mixed greedy / stochastic requests through P and D (first token sampled in P, the rest in D,
+    decode logits coming out of the hipGraph): greedy rows equal the unified engine's greedy output;
+    every stochastic token lies in the oracle's top-k set (tie margin on the k-th logit)."""
+    from semi_pd_amd.entrypoints.engine import Engine
+    from semi_pd_amd.managers.io_struct import SamplingParams
+    cfg, sd, prompts, outs, _ = unified_llama
+    k = 4
+    sps = [SamplingParams(max_new_tokens=12, ignore_eos=True) if i % 2 == 0 else
+           SamplingParams(max_new_tokens=12, ignore_eos=True, temperature=0.9, top_k=k, top_p=0.95)
+           for i in range(len(prompts))]
+    eng = Engine(server_args(cfg, enable_semi_pd=True, prefill_cu_percent=50, decode_cu_percent=50))
+    try:
+        a = eng.generate(prompts, sps, timeout=300)
+        b = eng.generate(prompts, sps, timeout=300)
+    finally:
+        eng.shutdown()
+    oracle = OracleLlama(cfg, sd)
+    for run in (a, b):
+        assert all(len(o) == 12 for o in run)
+        _, logits = oracle.generate(prompts, 12, forced=run)
+        for i, toks in enumerate(run):
+            for s, t in enumerate(toks):
+                row = logits[i, s]
+                kk = 1 if i % 2 == 0 else k
+                kth = float(torch.topk(row, kk).values[-1])
+                assert float(row[t]) >= kth - MARGIN, f"request {i} step {s}: token {t} outside the top-{kk}"
+    # stochastic rows differ between the two runs somewhere (the RNG advances), greedy rows do not
+    assert any(a[i] != b[i] for i in range(1, len(prompts), 2))

@@ -157,3 +157,47 @@ def test_fused_moe_staged_close_to_naive():
 def test_greedy_argmax_first_max():
     x = torch.tensor([[0.0, 3.0, 3.0, -1.0], [5.0, 1.0, 5.0, 5.0]])
     assert O.greedy_argmax(x).tolist() == [1, 0]
+
+
+def _check_counts(counts: np.ndarray, dist: torch.Tensor, draws: int):
+    """Empirical counts of the reference sampler vs the oracle distribution: same support, and every
+    frequency within 5 binomial standard deviations (+1 count)."""
+    dist = dist.double().numpy()
+    assert ((counts > 0) <= (dist > 0)).all(), "reference sampled a token outside the oracle support"
+    sigma = np.sqrt(draws * dist * (1 - dist))
+    assert (np.abs(counts - draws * dist) <= 5 * sigma + 1).all()
+    # tokens the oracle keeps with >= 1 % probability must have been seen
+    assert (counts[dist >= 0.01] > 0).all()
+
+
+def test_sampling_distribution_matches_reference_counts():
+    g = load_golden("sampling")
+    probs = torch.from_numpy(g["probs"])
+    top_ks, top_ps, min_ps = (torch.from_numpy(g[k]) for k in ("top_ks", "top_ps", "min_ps"))
+    draws = int(g["draws"][0])
+    torch.testing.assert_close(O.softmax_temperature(torch.from_numpy(g["logits"]), torch.from_numpy(g["temperatures"])),
+                               probs, rtol=1e-6, atol=1e-7)
+    d = O.top_k_top_p_min_p_filter(probs, top_ks, top_ps, torch.zeros_like(min_ps), False)
+    _check_counts(g["counts"], d, draws)
+    d = O.top_k_top_p_min_p_filter(probs, top_ks, top_ps, min_ps, True)
+    _check_counts(g["counts_min_p"], d, draws)
+    torch.testing.assert_close(O.top_p_normalize_probs(probs, top_ps), torch.from_numpy(g["top_p_normalized"]),
+                               rtol=1e-6, atol=1e-7)
+
+
+def test_sampling_renorm_formulas_agree():
+    """The two statements of top-p renormalisation the reference holds (sampler.py:234-243 and
+    sgl-kernel/tests/test_sampling.py:57-81) and the top-k one agree on continuous random rows."""
+    g = torch.Generator().manual_seed(2)
+    probs = torch.rand(5, 200, generator=g)
+    probs = probs / probs.sum(-1, keepdim=True)
+    for p in (0.1, 0.5, 0.9):
+        torch.testing.assert_close(O.top_p_renorm_prob(probs, p), O.top_p_normalize_probs(probs, torch.full((5,), p)),
+                                   rtol=1e-5, atol=1e-7)
+    for k in (1, 10, 200):
+        kept = (O.top_k_renorm_prob(probs, k) > 0).sum(-1)
+        assert (kept == k).all()
+    m = O.top_k_top_p_joint_mask(probs, 20, 0.5)
+    d = O.top_k_top_p_min_p_filter(probs, torch.full((5,), 20, dtype=torch.int32), torch.full((5,), 0.5),
+                                   torch.zeros(5), False)
+    assert ((d > 0).int() <= m).all()
