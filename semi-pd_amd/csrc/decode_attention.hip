@@ -306,24 +306,20 @@ __global__ void decode_stage2_kernel(T* __restrict__ out, const float* __restric
   const int seq_len = kv_indptr[b + 1] - kv_indptr[b];
   const int per_split = (seq_len + num_kv_splits - 1) / num_kv_splits;
   const float* base = attn_logits + ((int64_t)b * num_q_heads + hq) * num_kv_splits * (Dv + 1);
+  // splits [0, n_valid) are non-empty.  Two passes so that the loads of the second one are independent
+  // of each other (the running-max form of the reference serialises every split behind an exp).
+  const int n_valid = per_split > 0 ? min(num_kv_splits, (seq_len + per_split - 1) / per_split) : 0;
+  float e_max = -INFINITY;
+  for (int s = 0; s < n_valid; ++s) e_max = fmaxf(e_max, base[(int64_t)s * (Dv + 1) + Dv]);
+  float e_sum = 0.f;
+  for (int s = 0; s < n_valid; ++s) e_sum += __expf(base[(int64_t)s * (Dv + 1) + Dv] - e_max);
+  const float inv = e_sum > 0.f ? 1.f / e_sum : 0.f;
   for (int d = threadIdx.x; d < Dv; d += blockDim.x) {
-    float e_max = -INFINITY, e_sum = 0.f, acc = 0.f;
-    for (int s = 0; s < num_kv_splits; ++s) {
-      const int sb = per_split * s;
-      const int se = min(sb + per_split, seq_len);
-      if (se > sb) {
-        const float tv = base[(int64_t)s * (Dv + 1) + d];
-        const float tl = base[(int64_t)s * (Dv + 1) + Dv];
-        const float n_max = fmaxf(tl, e_max);
-        const float old_scale = safe_exp_diff(e_max, n_max);
-        const float e = __expf(tl - n_max);
-        acc = acc * old_scale + e * tv;
-        e_sum = e_sum * old_scale + e;
-        e_max = n_max;
-      }
-    }
-    out[(int64_t)b * o_stride + (int64_t)hq * Dv + d] =
-        Elem<T>::from_f(e_sum > 0.f ? acc / e_sum : 0.f);
+    float acc = 0.f;
+#pragma unroll 4
+    for (int s = 0; s < n_valid; ++s)
+      acc += __expf(base[(int64_t)s * (Dv + 1) + Dv] - e_max) * base[(int64_t)s * (Dv + 1) + d];
+    out[(int64_t)b * o_stride + (int64_t)hq * Dv + d] = Elem<T>::from_f(acc * inv);
   }
 }
 

@@ -79,7 +79,9 @@ def tensor_model_parallel_all_gather(input_: torch.Tensor, dim: int = -1) -> tor
         dim += input_.dim()
     input_ = input_.contiguous()
     out = torch.empty((_TP_SIZE,) + tuple(input_.shape), dtype=input_.dtype, device=input_.device)
-    dist.all_gather_into_tensor(out, input_, group=_DEVICE_GROUP) if input_.is_cuda else \
+    if dist.get_backend(_DEVICE_GROUP) == "nccl":
+        dist.all_gather_into_tensor(out, input_, group=_DEVICE_GROUP)
+    else:
         dist.all_gather(list(out.unbind(0)), input_, group=_DEVICE_GROUP)
     out = out.movedim(0, dim)
     shape = list(input_.shape)

@@ -39,6 +39,7 @@ def _build_runner(server_args: ServerArgs, gpu_id: int, tp_rank: int, role: Inst
         max_running_requests=server_args.max_running_requests,
         mem_fraction_static=server_args.mem_fraction_static, max_total_tokens=max_total_tokens,
         nccl_init_method=f"tcp://{server_args.dist_init_addr}:{nccl_port}", instance_role=role,
+        dist_backend=server_args.dist_backend,
         bypass_load_weight=bypass_load_weight, seed=server_args.random_seed, cu_percent=cu_percent,
         disable_cuda_graph=server_args.disable_cuda_graph, cuda_graph_max_bs=server_args.cuda_graph_max_bs)
     if server_args.collect_kernel_timing:
@@ -91,7 +92,7 @@ def run_scheduler_process(server_args: ServerArgs, port_args: SemiPDPortArgs, gp
         torch.cuda.synchronize()
         pipe_writer.send({"status": "ready", "max_total_num_tokens": mr.max_total_num_tokens,
                           "max_req_input_len": sched.max_req_input_len, "role": role.name,
-                          "hsa_cu_mask": os.environ.get("HSA_CU_MASK", "")})
+                          "tp_rank": tp_rank, "hsa_cu_mask": os.environ.get("HSA_CU_MASK", "")})
         sched.event_loop_normal()
     except Exception:
         msg = traceback.format_exc()

@@ -42,6 +42,7 @@ class ServerArgs:
     cu_mask_mode: str = "env"                # "env" (process-wide HSA_CU_MASK) | "none"
     dist_init_addr: str = "127.0.0.1"
     nccl_port_base: Optional[int] = None
+    dist_backend: str = "nccl"               # "nccl" = RCCL over xGMI; "gloo" only for single-GPU TP tests
     collect_kernel_timing: bool = False
 
     def __post_init__(self):

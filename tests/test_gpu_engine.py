@@ -266,3 +266,28 @@ def test_semi_pd_stochastic_sampling_stays_in_oracle_top_k(unified_llama):
                 assert float(row[t]) >= kth - MARGIN, f"request {i} step {s}: token {t} outside the top-{kk}"
     # stochastic rows differ between the two runs somewhere (the RNG advances), greedy rows do not
     assert any(a[i] != b[i] for i in range(1, len(prompts), 2))
+
+
+def test_semi_pd_tp2_on_one_gpu_matches_oracle(unified_llama):
+    """Tensor parallel 2 with both ranks on the one GPU of the test box (gloo instead of RCCL, which
+    refuses two ranks per device): 2 prefill + 2 decode processes, per-rank weight shards and KV pools
+    shared P<->D through per-rank IPC handles, scheduler decisions broadcast from rank 0, all-reduce after
+    o_proj / down_proj, all-gather of the vocab-parallel logits.  Tokens must agree with the fp32 oracle
+    of the unsharded model."""
+    from semi_pd_amd.entrypoints.engine import Engine
+    from semi_pd_amd.managers.io_struct import SamplingParams
+    cfg, sd, prompts, outs, _ = unified_llama
+    eng = Engine(server_args(cfg, tp_size=2, enable_semi_pd=True, prefill_cu_percent=50, decode_cu_percent=50,
+                             dist_backend="gloo", disable_cuda_graph=True),
+                 gpu_ids={0: 0, 1: 0})
+    try:
+        assert sorted((i["role"], i["tp_rank"]) for i in eng.ready_infos) == [
+            ("DECODE", 0), ("DECODE", 1), ("PREFILL", 0), ("PREFILL", 1)]
+        semi = eng.generate(prompts, SamplingParams(max_new_tokens=12, ignore_eos=True), timeout=600)
+        assert all(len(o) == 12 for o in semi)
+        oracle = OracleLlama(cfg, sd)
+        check_against_oracle(oracle, prompts, semi)
+        if semi != outs:
+            _explain_mismatch(oracle, prompts, semi, outs)
+    finally:
+        eng.shutdown()
