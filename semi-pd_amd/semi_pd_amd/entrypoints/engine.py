@@ -39,7 +39,8 @@ def _build_runner(server_args: ServerArgs, gpu_id: int, tp_rank: int, role: Inst
         max_running_requests=server_args.max_running_requests,
         mem_fraction_static=server_args.mem_fraction_static, max_total_tokens=max_total_tokens,
         nccl_init_method=f"tcp://{server_args.dist_init_addr}:{nccl_port}", instance_role=role,
-        dist_backend=server_args.dist_backend,
+        dist_backend=server_args.dist_backend, model_path=server_args.model_path,
+        load_format=server_args.load_format,
         bypass_load_weight=bypass_load_weight, seed=server_args.random_seed, cu_percent=cu_percent,
         disable_cuda_graph=server_args.disable_cuda_graph, cuda_graph_max_bs=server_args.cuda_graph_max_bs)
     if server_args.collect_kernel_timing:

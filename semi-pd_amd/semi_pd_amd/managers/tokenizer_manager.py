@@ -1,0 +1,246 @@
+"""TokenizerManager: the asyncio front of the engine.  Tokenises a request, hands it to the decode
+scheduler first and then to the prefill scheduler (the Semi-PD fan-out of
+managers/tokenizer_manager.py:149-160, done inside Engine.add_request), collects the streamed token
+ids and detokenises them incrementally (the reference runs the detokeniser as its own process,
+managers/detokenizer_manager.py; here it shares the front-end process).
+
+Output dictionaries follow tokenizer_manager.py:907-980:
+  {"text": <cumulative text>, "meta_info": {"id", "finish_reason", "prompt_tokens",
+   "completion_tokens", "cached_tokens", "e2e_latency"}}            (or "output_ids" when the server
+runs with --skip-tokenizer-init)."""
+from __future__ import annotations
+
+import asyncio
+import threading
+import time
+import uuid
+from typing import Any, AsyncIterator, Dict, List, Optional, Union
+
+from semi_pd_amd.managers.io_struct import SamplingParams
+
+_SAMPLING_KEYS = ("max_new_tokens", "temperature", "top_p", "top_k", "min_p", "ignore_eos", "stop_token_ids")
+
+
+def get_tokenizer(path: str):
+    """hf_transformers_utils.get_tokenizer: a local HF tokenizer directory (there is no network)."""
+    from transformers import AutoTokenizer
+    return AutoTokenizer.from_pretrained(path, local_files_only=True)
+
+
+def sampling_params_from_dict(d: Optional[dict]) -> SamplingParams:
+    """sampling/sampling_params.py:33-58: defaults of the HTTP surface (temperature 1.0, 128 new tokens)."""
+    d = dict(d or {})
+    unknown = [k for k in d if k not in _SAMPLING_KEYS and k not in (
+        "stop", "n", "skip_special_tokens", "spaces_between_special_tokens", "no_stop_trim",
+        "frequency_penalty", "presence_penalty", "repetition_penalty", "min_new_tokens", "json_schema", "regex",
+        "ebnf", "custom_params", "max_tokens")]
+    if unknown:
+        raise ValueError(f"unknown sampling parameters: {unknown}")
+    for k in ("frequency_penalty", "presence_penalty"):
+        if d.get(k):
+            raise ValueError(f"{k} is not supported")
+    if d.get("repetition_penalty", 1.0) != 1.0:
+        raise ValueError("repetition_penalty is not supported")
+    if d.get("n", 1) != 1:
+        raise ValueError("n > 1 is not supported")
+    for k in ("json_schema", "regex", "ebnf"):
+        if d.get(k):
+            raise ValueError("structured output is not supported")
+    if d.get("stop"):
+        raise ValueError("stop strings are not supported; use stop_token_ids")
+    kw = {k: d[k] for k in _SAMPLING_KEYS if k in d and d[k] is not None}
+    kw.setdefault("temperature", 1.0)
+    kw.setdefault("max_new_tokens", 128)
+    return SamplingParams(**kw)
+
+
+class _ReqState:
+    def __init__(self, rid: str, prompt_tokens: int, loop: asyncio.AbstractEventLoop):
+        self.rid = rid
+        self.prompt_tokens = prompt_tokens
+        self.event = asyncio.Event()
+        self.loop = loop
+        self.created = time.time()
+        self.seen = 0
+
+
+class TokenizerManager:
+    def __init__(self, engine, server_args, tokenizer=None):
+        self.engine = engine
+        self.server_args = server_args
+        self.tokenizer = tokenizer
+        if tokenizer is None and not server_args.skip_tokenizer_init:
+            self.tokenizer = get_tokenizer(server_args.tokenizer_path)
+        self.states: Dict[str, _ReqState] = {}
+        self._lock = threading.Lock()
+        self._stop = False
+        self._pump_error: Optional[BaseException] = None
+        self.last_receive_tstamp = time.time()
+        self._thread = threading.Thread(target=self._pump, name="semipd-output-pump", daemon=True)
+        self._thread.start()
+
+    # ------------------------------------------------------------------------------ output pump
+    def _pump(self):
+        eng = self.engine
+        if getattr(eng, "model_runner", None) is not None:  # in-process (unified) engine steps here
+            import torch
+            torch.cuda.set_device(eng.model_runner.device)
+        try:
+            while not self._stop:
+                progressed = eng.poll(timeout=0.02)
+                if not progressed:
+                    if eng.scheduler is not None:
+                        time.sleep(0.001)
+                    else:
+                        eng.check_children()
+                    continue
+                self.last_receive_tstamp = time.time()
+                with self._lock:
+                    states = list(self.states.values())
+                for st in states:
+                    n = len(eng._outputs.get(st.rid, ()))
+                    if n != st.seen or eng._finished.get(st.rid) is not None:
+                        st.seen = n
+                        st.loop.call_soon_threadsafe(st.event.set)
+        except BaseException as e:  # surface scheduler death to every waiting request
+            self._pump_error = e
+            with self._lock:
+                for st in self.states.values():
+                    st.loop.call_soon_threadsafe(st.event.set)
+
+    def shutdown(self):
+        self._stop = True
+        self._thread.join(timeout=5)
+
+    # ------------------------------------------------------------------------------ requests
+    def _tokenize(self, text: Optional[str], input_ids: Optional[List[int]]) -> List[int]:
+        if input_ids is not None:
+            return [int(t) for t in input_ids]
+        if text is None:
+            raise ValueError("either text or input_ids must be given")
+        if self.tokenizer is None:
+            raise ValueError("the server runs with --skip-tokenizer-init: send input_ids, not text")
+        return self.tokenizer.encode(text)
+
+    def _validate(self, ids: List[int], sp: SamplingParams):
+        ctx = self.server_args.context_length
+        if len(ids) == 0:
+            raise ValueError("empty prompt")
+        if len(ids) >= ctx:
+            raise ValueError(f"The input ({len(ids)} tokens) is longer than the model's context length ({ctx} tokens).")
+        vocab = self.server_args.model_config.vocab_size
+        if max(ids) >= vocab or min(ids) < 0:
+            raise ValueError("input_ids out of the vocabulary range")
+        if sp.max_new_tokens is None or len(ids) + sp.max_new_tokens > ctx:
+            sp.max_new_tokens = ctx - len(ids)  # tokenizer_manager.py: clipped to the context window
+
+    @staticmethod
+    def _finish_dict(reason: Optional[str], completion_tokens: int, last_token: Optional[int]):
+        if reason is None:
+            return None
+        if reason == "length":
+            return {"type": "length", "length": completion_tokens}
+        if reason == "stop":
+            return {"type": "stop", "matched": last_token}
+        return {"type": "abort", "message": str(reason)}
+
+    def _out_dict(self, st: _ReqState, ids: List[int], fin: Optional[str], skip_special_tokens: bool) -> dict:
+        meta = {"id": st.rid, "finish_reason": self._finish_dict(fin, len(ids), ids[-1] if ids else None),
+                "prompt_tokens": st.prompt_tokens, "completion_tokens": len(ids), "cached_tokens": 0}
+        if fin is not None:
+            meta["e2e_latency"] = time.time() - st.created
+        if self.tokenizer is None:
+            return {"output_ids": list(ids), "meta_info": meta}
+        shown = ids[:-1] if (fin == "stop" and ids) else ids  # the matched stop / EOS token is not rendered
+        text = self.tokenizer.decode(shown, skip_special_tokens=skip_special_tokens)
+        if fin is None and text.endswith("�"):
+            text = text[:-1]  # an incomplete multi-byte character: wait for the next token
+        return {"text": text, "output_ids": list(ids), "meta_info": meta}
+
+    async def _one(self, text, input_ids, sampling: dict, stream: bool, rid: Optional[str]) -> AsyncIterator[dict]:
+        sp = sampling_params_from_dict(sampling)
+        ids = self._tokenize(text, input_ids)
+        self._validate(ids, sp)
+        skip_special = bool((sampling or {}).get("skip_special_tokens", True))
+        rid = rid or uuid.uuid4().hex
+        st = _ReqState(rid, len(ids), asyncio.get_running_loop())
+        with self._lock:
+            if rid in self.states:
+                raise ValueError(f"duplicate request id {rid}")
+            self.states[rid] = st
+            self.engine.add_request(ids, sp, rid=rid)
+        try:
+            sent = -1
+            while True:
+                await st.event.wait()
+                st.event.clear()
+                if self._pump_error is not None:
+                    raise RuntimeError(f"scheduler failed: {self._pump_error}")
+                out_ids = list(self.engine._outputs[rid])
+                fin = self.engine._finished[rid]
+                if fin is not None:
+                    yield self._out_dict(st, out_ids, fin, skip_special)
+                    return
+                if stream and len(out_ids) != sent:
+                    sent = len(out_ids)
+                    yield self._out_dict(st, out_ids, None, skip_special)
+        finally:
+            with self._lock:
+                self.states.pop(rid, None)
+            for d in (self.engine._outputs, self.engine._finished, self.engine._token_times, self.engine._send_time):
+                d.pop(rid, None)
+
+    async def generate_request(self, obj: Dict[str, Any]) -> AsyncIterator[Union[dict, List[dict]]]:
+        """obj follows GenerateReqInput (managers/io_struct.py:36-120): text | input_ids (single or batch),
+        sampling_params (dict or list), stream, rid."""
+        text, input_ids = obj.get("text"), obj.get("input_ids")
+        stream = bool(obj.get("stream", False))
+        sampling = obj.get("sampling_params") or {}
+        rid = obj.get("rid")
+        if obj.get("return_logprob"):
+            raise ValueError("return_logprob is not supported")
+        is_batch = isinstance(text, list) or (isinstance(input_ids, list) and input_ids
+                                               and isinstance(input_ids[0], list))
+        if not is_batch:
+            async for out in self._one(text, input_ids, sampling, stream, rid):
+                yield out
+            return
+        n = len(text) if isinstance(text, list) else len(input_ids)
+        texts = text if isinstance(text, list) else [None] * n
+        idss = input_ids if isinstance(input_ids, list) and input_ids and isinstance(input_ids[0], list) else [None] * n
+        samplings = sampling if isinstance(sampling, list) else [sampling] * n
+        rids = rid if isinstance(rid, list) else [None] * n
+        if not (len(texts) == len(idss) == len(samplings) == len(rids) == n):
+            raise ValueError("batch fields have different lengths")
+        gens = [self._one(texts[i], idss[i], samplings[i], stream, rids[i]) for i in range(n)]
+        if not stream:
+            results = await asyncio.gather(*[g.__anext__() for g in gens])
+            for g in gens:
+                await g.aclose()
+            yield list(results)
+            return
+        queue: asyncio.Queue = asyncio.Queue()
+
+        async def drain(i, g):
+            try:
+                async for out in g:
+                    out["index"] = i
+                    await queue.put(out)
+            except Exception as e:  # noqa: BLE001
+                await queue.put(e)
+            await queue.put(None)
+
+        tasks = [asyncio.create_task(drain(i, g)) for i, g in enumerate(gens)]
+        done = 0
+        try:
+            while done < n:
+                item = await queue.get()
+                if item is None:
+                    done += 1
+                elif isinstance(item, Exception):
+                    raise item
+                else:
+                    yield item
+        finally:
+            for t in tasks:
+                t.cancel()

@@ -98,7 +98,8 @@ class ModelRunner:
                  dist_backend: str = "nccl", instance_role: InstanceRole = InstanceRole.OTHER,
                  bypass_load_weight: bool = False, seed: int = 0, cu_percent: int = 100,
                  disable_cuda_graph: bool = False, cuda_graph_max_bs: int = 256,
-                 load_state_dict: Optional[Dict[str, torch.Tensor]] = None):
+                 load_state_dict: Optional[Dict[str, torch.Tensor]] = None, model_path: Optional[str] = None,
+                 load_format: str = "dummy"):
         self.model_config = model_config
         self.gpu_id, self.tp_rank, self.tp_size = gpu_id, tp_rank, tp_size
         self.dtype = dtype
@@ -130,6 +131,12 @@ class ModelRunner:
                     self.model = build_model(model_config, dtype)
                 if load_state_dict is not None:
                     load_full_state_dict(self.model, load_state_dict)
+                elif load_format != "dummy":
+                    # --load-format auto: HF safetensors under --model-path (model_loader/loader.py)
+                    from semi_pd_amd.model_loader import load_weights, safetensors_weights_iterator
+                    if not model_path:
+                        raise ValueError("load_format=%r needs a model_path" % load_format)
+                    load_weights(self.model, model_config, safetensors_weights_iterator(model_path))
                 else:
                     dummy_init_weights(self.model, self.device, seed)
                 if hasattr(self.model, "post_load_weights"):

@@ -15,8 +15,15 @@ from semi_pd_amd.semi_pd.utils import DECODE_ENGINE_SM_PERCENTILE, PREFILL_ENGIN
 
 @dataclasses.dataclass
 class ServerArgs:
-    model_config: Any = None                 # LlamaConfig / OPTConfig / DeepseekV2Config (dummy weights)
-    load_format: str = "dummy"
+    model_config: Any = None                 # LlamaConfig / OPTConfig / DeepseekV2Config; read from
+    #                                          <model_path>/config.json when not given
+    model_path: Optional[str] = None
+    tokenizer_path: Optional[str] = None
+    skip_tokenizer_init: bool = False
+    served_model_name: Optional[str] = None
+    host: str = "127.0.0.1"
+    port: int = 30000
+    load_format: str = "dummy"               # "dummy" (seeded random weights) | "auto" (HF safetensors)
     dtype: str = "bfloat16"
     context_length: int = 4096
     tp_size: int = 1
@@ -46,6 +53,13 @@ class ServerArgs:
     collect_kernel_timing: bool = False
 
     def __post_init__(self):
+        if self.model_config is None and self.model_path:
+            from semi_pd_amd.model_loader import load_hf_config
+            self.model_config = load_hf_config(self.model_path)
+        if self.tokenizer_path is None:
+            self.tokenizer_path = self.model_path
+        if self.served_model_name is None:
+            self.served_model_name = self.model_path or type(self.model_config).__name__
         if self.mem_fraction_static is None:
             self.mem_fraction_static = 0.88 if self.tp_size == 1 else 0.85
             if self.enable_semi_pd:
@@ -79,3 +93,80 @@ class SemiPDPortArgs:
             d_scheduler_input_ipc_name=os.path.join(d, "d_in"),
             bridge_ipc_name=os.path.join(d, "bridge"),
             p_nccl_port=base + 1, d_nccl_port=base + 2)
+
+
+# ------------------------------------------------------------------------------------- CLI
+def add_cli_args(parser):
+    """The subset of server_args.py:380-1195 add_cli_args the Semi-PD path reads, same flag names.
+    Flags the reference accepts but that have no effect here are still parsed, so that its launch
+    commands (evaluation/benchmark_*_semi_pd.sh:14-16) run unchanged."""
+    p = parser
+    p.add_argument("--model-path", "--model", type=str, required=True)
+    p.add_argument("--tokenizer-path", type=str, default=None)
+    p.add_argument("--host", type=str, default="127.0.0.1")
+    p.add_argument("--port", type=int, default=30000)
+    p.add_argument("--skip-tokenizer-init", action="store_true")
+    p.add_argument("--load-format", type=str, default="auto", choices=["auto", "safetensors", "dummy"])
+    p.add_argument("--dtype", type=str, default="auto", choices=["auto", "half", "float16", "bfloat16"])
+    p.add_argument("--context-length", type=int, default=None)
+    p.add_argument("--served-model-name", type=str, default=None)
+    p.add_argument("--mem-fraction-static", type=float, default=None)
+    p.add_argument("--max-running-requests", type=int, default=256)
+    p.add_argument("--max-total-tokens", type=int, default=None)
+    p.add_argument("--chunked-prefill-size", type=int, default=8192)
+    p.add_argument("--max-prefill-tokens", type=int, default=16384)
+    p.add_argument("--schedule-conservativeness", type=float, default=1.0)
+    p.add_argument("--tensor-parallel-size", "--tp-size", "--tp", dest="tp_size", type=int, default=1)
+    p.add_argument("--base-gpu-id", type=int, default=0)
+    p.add_argument("--random-seed", type=int, default=0)
+    p.add_argument("--watchdog-timeout", type=float, default=300.0)
+    p.add_argument("--dist-init-addr", "--nccl-init-addr", dest="dist_init_addr", type=str, default="127.0.0.1")
+    p.add_argument("--nccl-port", type=int, default=None)
+    p.add_argument("--disable-cuda-graph", action="store_true")
+    p.add_argument("--cuda-graph-max-bs", type=int, default=256)
+    p.add_argument("--enable-semi-pd", action="store_true", help="prefill and decode instance on the same GPUs")
+    p.add_argument("--prefill-cu-percent", type=int, default=PREFILL_ENGINE_SM_PERCENTILE,
+                   help="share of the CUs given to the prefill instance (SEMI_PD_PREFILL_SM_PERCENTILE)")
+    p.add_argument("--decode-cu-percent", type=int, default=DECODE_ENGINE_SM_PERCENTILE,
+                   help="share of the CUs given to the decode instance (SEMI_PD_DECODE_SM_PERCENTILE)")
+    p.add_argument("--attention-backend", type=str, default="hip")
+    p.add_argument("--sampling-backend", type=str, default="hip")
+    p.add_argument("--log-level", type=str, default="info")
+    # accepted for command-line compatibility; no effect on this path
+    for flag in ("--trust-remote-code", "--disable-radix-cache", "--enable-metrics", "--disable-overlap-schedule",
+                 "--enable-mixed-chunk", "--show-time-cost"):
+        p.add_argument(flag, action="store_true")
+    p.add_argument("--dist-timeout", type=int, default=None)
+    p.add_argument("--stream-interval", type=int, default=1)
+    return p
+
+
+def from_cli_args(args) -> ServerArgs:
+    dtype = "bfloat16" if args.dtype == "auto" else args.dtype
+    sa = ServerArgs(
+        model_path=args.model_path, tokenizer_path=args.tokenizer_path, host=args.host, port=args.port,
+        skip_tokenizer_init=args.skip_tokenizer_init,
+        load_format="dummy" if args.load_format == "dummy" else "auto", dtype=dtype,
+        served_model_name=args.served_model_name, mem_fraction_static=args.mem_fraction_static,
+        max_running_requests=args.max_running_requests, max_total_tokens=args.max_total_tokens,
+        chunked_prefill_size=args.chunked_prefill_size, max_prefill_tokens=args.max_prefill_tokens,
+        schedule_conservativeness=args.schedule_conservativeness, tp_size=args.tp_size,
+        base_gpu_id=args.base_gpu_id, random_seed=args.random_seed, watchdog_timeout=args.watchdog_timeout,
+        dist_init_addr=args.dist_init_addr, nccl_port_base=args.nccl_port,
+        disable_cuda_graph=args.disable_cuda_graph, cuda_graph_max_bs=args.cuda_graph_max_bs,
+        enable_semi_pd=args.enable_semi_pd, prefill_cu_percent=args.prefill_cu_percent,
+        decode_cu_percent=args.decode_cu_percent, attention_backend=args.attention_backend,
+        sampling_backend=args.sampling_backend)
+    ctx = args.context_length or getattr(sa.model_config, "max_position_embeddings", 4096)
+    sa.context_length = int(ctx)
+    eos = getattr(sa, "eos_token_ids", None)
+    if eos is None:
+        try:
+            import json
+            with open(os.path.join(args.model_path, "config.json")) as f:
+                e = json.load(f).get("eos_token_id")
+            if e is not None:
+                sa.eos_token_ids = [int(x) for x in (e if isinstance(e, list) else [e])]
+        except OSError:
+            pass
+    return sa

@@ -291,3 +291,72 @@ def test_semi_pd_tp2_on_one_gpu_matches_oracle(unified_llama):
             _explain_mismatch(oracle, prompts, semi, outs)
     finally:
         eng.shutdown()
+
+
+def test_launch_server_semi_pd_http(unified_llama, tmp_path):
+    """`python -m sglang.launch_server --model-path <dir> --enable-semi-pd` (the reference's launch line,
+    served here by the alias module) with dummy weights: greedy /generate and /v1/completions return the
+    tokens of the in-process engine built from the same config; a stochastic request streams."""
+    import dataclasses
+    import json
+    import subprocess
+    import sys
+    import time
+    import urllib.request
+    cfg, sd, prompts, outs, _ = unified_llama
+    d = {k: v for k, v in dataclasses.asdict(cfg).items() if k != "architectures"}
+    d["architectures"] = ["LlamaForCausalLM"]
+    (tmp_path / "config.json").write_text(json.dumps(d))
+    port = 31000 + os.getpid() % 2000
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=os.path.join(root, "semi-pd_amd") + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    log = open(tmp_path / "server.log", "w")
+    proc = subprocess.Popen(
+        [sys.executable, "-m", "sglang.launch_server", "--model-path", str(tmp_path), "--load-format", "dummy",
+         "--skip-tokenizer-init", "--enable-semi-pd", "--prefill-cu-percent", "50", "--decode-cu-percent", "50",
+         "--port", str(port), "--context-length", "384", "--max-running-requests", "24", "--max-total-tokens", "6000",
+         "--cuda-graph-max-bs", "16", "--trust-remote-code", "--disable-radix-cache"],
+        env=env, stdout=log, stderr=subprocess.STDOUT)
+    base = f"http://127.0.0.1:{port}"
+
+    def post(path, body, timeout=120):
+        req = urllib.request.Request(base + path, data=json.dumps(body).encode(),
+                                     headers={"Content-Type": "application/json"})
+        return urllib.request.urlopen(req, timeout=timeout)
+
+    try:
+        deadline = time.time() + 240
+        while True:
+            assert proc.poll() is None, "server exited:\n" + open(tmp_path / "server.log").read()[-3000:]
+            try:
+                if urllib.request.urlopen(base + "/health", timeout=2).status == 200:
+                    break
+            except OSError:
+                assert time.time() < deadline, "server did not come up:\n" + open(tmp_path / "server.log").read()[-3000:]
+                time.sleep(1.0)
+        greedy = {"max_new_tokens": 12, "temperature": 0, "ignore_eos": True}
+        r = json.load(post("/generate", {"input_ids": prompts, "sampling_params": greedy}))
+        got = [o["output_ids"] for o in r]
+        assert all(o["meta_info"]["finish_reason"] == {"type": "length", "length": 12} for o in r)
+        oracle = OracleLlama(cfg, sd)
+        check_against_oracle(oracle, prompts, got)
+        if got != outs:
+            _explain_mismatch(oracle, prompts, got, outs)
+        r = json.load(post("/v1/completions", {"prompt": prompts[1], "max_tokens": 5, "temperature": 0, "ignore_eos": True}))
+        assert r["usage"] == {"prompt_tokens": len(prompts[1]), "completion_tokens": 5,
+                              "total_tokens": len(prompts[1]) + 5}
+        resp = post("/generate", {"input_ids": prompts[2], "stream": True,
+                                  "sampling_params": {"max_new_tokens": 6, "temperature": 0.8, "top_k": 5, "ignore_eos": True}})
+        events = [json.loads(l[6:]) for l in resp.read().decode().splitlines() if l.startswith("data: {")]
+        assert events[-1]["meta_info"]["completion_tokens"] == 6 and len(events) >= 2
+        assert all(0 <= t < cfg.vocab_size for t in events[-1]["output_ids"])
+        assert urllib.request.urlopen(base + "/health_generate", timeout=60).status == 200
+        info = json.load(urllib.request.urlopen(base + "/get_server_info", timeout=10))
+        assert info["enable_semi_pd"] and {i["role"] for i in info["ready_infos"]} == {"PREFILL", "DECODE"}
+    finally:
+        proc.terminate()
+        try:
+            proc.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            proc.kill()
+        log.close()

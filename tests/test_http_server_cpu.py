@@ -1,0 +1,201 @@
+"""The HTTP surface (native /generate + OpenAI-compatible routes) on CPU, against a scripted engine:
+request parsing, sampling-parameter defaults, batch and SSE streaming shapes, finish reasons and
+usage accounting follow the reference (entrypoints/http_server.py:228-262, 491-515;
+managers/tokenizer_manager.py:907-980; openai_api/adapter.py)."""
+import json
+import threading
+import time
+
+import pytest
+
+pytest.importorskip("fastapi")
+pytest.importorskip("httpx")
+from fastapi.testclient import TestClient
+
+from semi_pd_amd.entrypoints.http_server import build_app
+from semi_pd_amd.managers.tokenizer_manager import TokenizerManager, sampling_params_from_dict
+from semi_pd_amd.models.llama import LlamaConfig
+from semi_pd_amd.server_args import ServerArgs
+
+WORDS = ["<eos>", "alpha", "beta", "gamma", "delta", "epsilon", "zeta", "eta", "theta", "iota", "user:", "assistant:"]
+
+
+class WordTokenizer:
+    """Whitespace word-level tokenizer with the three methods the server uses."""
+    eos_token_id = 0
+    chat_template = None
+
+    def encode(self, text):
+        return [WORDS.index(w) for w in text.split()]
+
+    def decode(self, ids, skip_special_tokens=True):
+        return " ".join(WORDS[i] for i in ids if not (skip_special_tokens and i == 0))
+
+
+class ScriptedEngine:
+    """Emits token (last_prompt_token + step) % len(WORDS) one per poll; token 0 is EOS."""
+    scheduler = None
+
+    def __init__(self):
+        self._outputs, self._finished, self._token_times, self._send_time = {}, {}, {}, {}
+        self._live = {}
+        self.requests = []
+        self._lock = threading.Lock()
+
+    def add_request(self, input_ids, sampling_params, rid=None):
+        with self._lock:
+            self._outputs[rid], self._finished[rid], self._token_times[rid] = [], None, []
+            self._send_time[rid] = time.time()
+            self._live[rid] = (list(input_ids), sampling_params)
+            self.requests.append((rid, list(input_ids), sampling_params))
+        return rid
+
+    def poll(self, timeout=0.0):
+        with self._lock:
+            if not self._live:
+                pass
+            else:
+                for rid in list(self._live):
+                    ids, sp = self._live[rid]
+                    if rid not in self._outputs:
+                        del self._live[rid]
+                        continue
+                    tok = (ids[-1] + len(self._outputs[rid]) + 1) % len(WORDS)
+                    self._outputs[rid].append(tok)
+                    if tok == 0 and not sp.ignore_eos:
+                        self._finished[rid] = "stop"
+                    elif len(self._outputs[rid]) >= sp.max_new_tokens:
+                        self._finished[rid] = "length"
+                    if self._finished[rid] is not None:
+                        del self._live[rid]
+                return True
+        time.sleep(min(timeout, 0.005))
+        return False
+
+    def check_children(self):
+        pass
+
+    def shutdown(self):
+        pass
+
+
+@pytest.fixture()
+def client():
+    cfg = LlamaConfig(vocab_size=len(WORDS), hidden_size=64, intermediate_size=64, num_hidden_layers=1,
+                      num_attention_heads=2, num_key_value_heads=2)
+    sa = ServerArgs(model_config=cfg, context_length=64, served_model_name="word-model")
+    eng = ScriptedEngine()
+    tm = TokenizerManager(eng, sa, tokenizer=WordTokenizer())
+    with TestClient(build_app(tm, sa)) as c:
+        c.engine = eng
+        yield c
+
+
+def _sse_events(resp):
+    out = []
+    for line in resp.iter_lines():
+        if line.startswith("data: "):
+            out.append(line[6:])
+    assert out[-1] == "[DONE]"
+    return [json.loads(x) for x in out[:-1]]
+
+
+def test_generate_text_and_ids(client):
+    r = client.post("/generate", json={"text": "alpha beta", "sampling_params": {"max_new_tokens": 3}})
+    assert r.status_code == 200
+    body = r.json()
+    # prompt ends with id 2 -> tokens 3, 4, 5
+    assert body["output_ids"] == [3, 4, 5] and body["text"] == "gamma delta epsilon"
+    meta = body["meta_info"]
+    assert meta["finish_reason"] == {"type": "length", "length": 3}
+    assert (meta["prompt_tokens"], meta["completion_tokens"], meta["cached_tokens"]) == (2, 3, 0)
+    r = client.post("/generate", json={"input_ids": [1, 9], "sampling_params": {"max_new_tokens": 8}})
+    body = r.json()  # 10, 11, 0 = EOS -> stop, EOS not rendered
+    assert body["output_ids"] == [10, 11, 0] and body["text"] == "user: assistant:"
+    assert body["meta_info"]["finish_reason"] == {"type": "stop", "matched": 0}
+    # HTTP defaults of the reference: temperature 1.0, 128 new tokens (clipped to the context window)
+    sp = client.engine.requests[-1][2]
+    assert sp.temperature == 1.0 and sp.top_k == 1 << 30 and not sp.is_greedy
+
+
+def test_generate_batch_and_stream(client):
+    r = client.post("/generate", json={"text": ["alpha", "gamma delta"],
+                                       "sampling_params": [{"max_new_tokens": 2}, {"max_new_tokens": 1, "temperature": 0}]})
+    out = r.json()
+    assert [o["output_ids"] for o in out] == [[2, 3], [5]]
+    assert client.engine.requests[-1][2].is_greedy and not client.engine.requests[-2][2].is_greedy
+    with client.stream("POST", "/generate", json={"text": "alpha", "stream": True,
+                                                  "sampling_params": {"max_new_tokens": 4, "ignore_eos": True}}) as resp:
+        ev = _sse_events(resp)
+    assert ev[-1]["output_ids"] == [2, 3, 4, 5] and ev[-1]["meta_info"]["finish_reason"]["type"] == "length"
+    assert all(e["meta_info"]["finish_reason"] is None for e in ev[:-1])
+    lens = [len(e["output_ids"]) for e in ev]
+    assert lens == sorted(lens) and ev[-1]["text"].startswith(ev[0]["text"])  # cumulative text
+
+
+def test_generate_errors(client):
+    assert client.post("/generate", json={"sampling_params": {}}).status_code == 400
+    assert client.post("/generate", json={"input_ids": [99]}).status_code == 400            # outside the vocabulary
+    assert client.post("/generate", json={"input_ids": list(range(1, 12)) * 7}).status_code == 400  # > context
+    r = client.post("/generate", json={"text": "alpha", "sampling_params": {"top_p": 0.0}})
+    assert r.status_code == 400 and "top_p" in r.json()["error"]["message"]
+    r = client.post("/generate", json={"text": "alpha", "sampling_params": {"stop": ["x"]}})
+    assert r.status_code == 400
+    with pytest.raises(ValueError):
+        sampling_params_from_dict({"temperatur": 1})
+
+
+def test_openai_completions(client):
+    r = client.post("/v1/completions", json={"model": "word-model", "prompt": "alpha beta", "max_tokens": 2,
+                                             "temperature": 0})
+    body = r.json()
+    assert body["object"] == "text_completion" and body["model"] == "word-model"
+    assert body["choices"][0]["text"] == "gamma delta" and body["choices"][0]["finish_reason"] == "length"
+    assert body["usage"] == {"prompt_tokens": 2, "completion_tokens": 2, "total_tokens": 4}
+    # OpenAI default max_tokens = 16; batch of prompts; echo
+    r = client.post("/v1/completions", json={"prompt": ["alpha", "eta"], "echo": True, "ignore_eos": True})
+    body = r.json()
+    assert len(body["choices"]) == 2 and body["usage"]["completion_tokens"] == 32
+    assert body["choices"][0]["text"].startswith("alpha" + "beta gamma")  # echo = prompt text + completion text
+    with client.stream("POST", "/v1/completions", json={"prompt": [1, 2], "max_tokens": 3, "stream": True}) as resp:
+        ev = _sse_events(resp)
+    assert "".join(e["choices"][0]["text"] for e in ev).split() == ["gamma", "delta", "epsilon"]
+    assert ev[-1]["choices"][0]["finish_reason"] == "length" and ev[-1]["usage"]["total_tokens"] == 5
+
+
+def test_openai_chat_and_models(client):
+    r = client.post("/v1/chat/completions", json={"messages": [{"role": "user", "content": "alpha beta"}],
+                                                  "max_tokens": 2})
+    body = r.json()
+    # fallback template "user: alpha beta\nassistant:" -> last prompt token 11 -> tokens 0 (EOS): stop
+    assert body["object"] == "chat.completion"
+    assert body["choices"][0]["message"] == {"role": "assistant", "content": ""}
+    assert body["choices"][0]["finish_reason"] == "stop" and body["usage"]["prompt_tokens"] == 4
+    with client.stream("POST", "/v1/chat/completions",
+                       json={"messages": [{"role": "user", "content": "alpha"}], "max_tokens": 3, "stream": True,
+                             "ignore_eos": True}) as resp:
+        ev = _sse_events(resp)
+    assert ev[0]["choices"][0]["delta"]["role"] == "assistant"
+    assert ev[-1]["choices"][0]["finish_reason"] == "length"
+    assert client.get("/v1/models").json()["data"][0]["id"] == "word-model"
+    assert client.get("/health").status_code == 200
+    assert client.get("/health_generate").status_code == 200
+    assert client.get("/get_model_info").json()["is_generation"] is True
+    assert client.post("/flush_cache").status_code == 200
+
+
+def test_cli_flags_of_the_reference_parse(tmp_path):
+    """The reference's own launch line (evaluation/benchmark_deepseek_v2_lite_semi_pd.sh:14-16)."""
+    import argparse
+    from semi_pd_amd.server_args import add_cli_args, from_cli_args
+    (tmp_path / "config.json").write_text(json.dumps({
+        "architectures": ["LlamaForCausalLM"], "vocab_size": 320, "hidden_size": 64, "intermediate_size": 96,
+        "num_hidden_layers": 2, "num_attention_heads": 4, "num_key_value_heads": 2, "max_position_embeddings": 256,
+        "eos_token_id": 7, "torch_dtype": "bfloat16"}))
+    argv = ["--model-path", str(tmp_path), "--trust-remote-code", "--context-length", "10240",
+            "--watchdog-timeout", "60000", "--dist-timeout", "3600", "--enable-metrics", "--disable-radix-cache",
+            "--served-model-name", "deepseek", "--mem-fraction-static", "0.82", "--tp", "1", "--enable-semi-pd"]
+    sa = from_cli_args(add_cli_args(argparse.ArgumentParser()).parse_args(argv))
+    assert sa.enable_semi_pd and sa.disable_radix_cache and sa.tp_size == 1 and sa.context_length == 10240
+    assert sa.mem_fraction_static == 0.82 and sa.served_model_name == "deepseek" and sa.load_format == "auto"
+    assert sa.model_config.num_key_value_heads == 2 and sa.eos_token_ids == [7]

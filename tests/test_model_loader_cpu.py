@@ -1,0 +1,91 @@
+"""`--load-format auto` on CPU: a seeded HF model saved with save_pretrained (config.json +
+safetensors) must load into the product model exactly as the oracle's HF-name conversion lays it
+out (reference: model_loader/loader.py + models/*.py load_weights stacked-parameter mappings)."""
+import pytest
+import torch
+
+transformers = pytest.importorskip("transformers")
+pytest.importorskip("safetensors")
+
+from oracle.hf_convert import deepseek_v2_from_hf, llama_from_hf, opt_from_hf
+from semi_pd_amd.model_loader import (config_from_hf_dict, load_hf_config, load_weights,
+                                      safetensors_weights_iterator)
+from semi_pd_amd.model_executor.model_runner import build_model
+
+
+def _load(tmp_path, hf):
+    hf.save_pretrained(tmp_path, safe_serialization=True)
+    cfg = load_hf_config(str(tmp_path))
+    model = build_model(cfg, torch.float32)
+    loaded = load_weights(model, cfg, safetensors_weights_iterator(str(tmp_path)))
+    assert len(loaded) == len(set(loaded))
+    return cfg, model
+
+
+def _compare(model, want):
+    got = dict(model.named_parameters())
+    for k, w in want.items():
+        g = got[k]
+        if g.shape != w.shape:  # vocab rows padded to a multiple of 64 with zeros
+            assert g.shape[0] >= w.shape[0] and torch.count_nonzero(g[w.shape[0]:]) == 0
+            g = g[: w.shape[0]]
+        assert torch.equal(g, w.to(g.dtype)), k
+    assert set(got) <= set(want) | {"lm_head.weight"}
+
+
+def test_llama_checkpoint(tmp_path):
+    torch.manual_seed(0)
+    hf = transformers.LlamaForCausalLM(transformers.LlamaConfig(
+        vocab_size=320, hidden_size=64, intermediate_size=96, num_hidden_layers=2, num_attention_heads=4,
+        num_key_value_heads=2, max_position_embeddings=256, rms_norm_eps=1e-5, rope_theta=10000.0,
+        tie_word_embeddings=False))
+    cfg, model = _load(tmp_path, hf)
+    assert (cfg.num_key_value_heads, cfg.intermediate_size, cfg.vocab_size) == (2, 96, 320)
+    _compare(model, llama_from_hf(hf.state_dict(), 2))
+
+
+def test_opt_checkpoint(tmp_path):
+    torch.manual_seed(1)
+    hf = transformers.OPTForCausalLM(transformers.OPTConfig(
+        vocab_size=272, hidden_size=64, ffn_dim=128, num_hidden_layers=2, num_attention_heads=4,
+        max_position_embeddings=128, word_embed_proj_dim=64, do_layer_norm_before=True))
+    cfg, model = _load(tmp_path, hf)
+    assert cfg.ffn_dim == 128
+    _compare(model, opt_from_hf(hf.state_dict(), 2))
+
+
+def test_deepseek_v2_checkpoint(tmp_path):
+    torch.manual_seed(2)
+    kw = dict(vocab_size=300, hidden_size=64, intermediate_size=96, moe_intermediate_size=32, num_hidden_layers=3,
+              num_attention_heads=4, n_shared_experts=2, n_routed_experts=8, num_experts_per_tok=3, kv_lora_rank=32,
+              q_lora_rank=None, qk_rope_head_dim=16, qk_nope_head_dim=16, v_head_dim=16, first_k_dense_replace=1,
+              n_group=1, topk_group=1, topk_method="greedy", norm_topk_prob=False, routed_scaling_factor=1.0,
+              max_position_embeddings=256, rms_norm_eps=1e-6)
+    hf = transformers.DeepseekV2ForCausalLM(transformers.DeepseekV2Config(num_key_value_heads=4, **kw))
+    cfg, model = _load(tmp_path, hf)
+    assert cfg.n_routed_experts == 8 and cfg.kv_lora_rank == 32
+    _compare(model, deepseek_v2_from_hf(hf.state_dict(), cfg))
+
+
+def test_per_expert_names_are_stacked():
+    """Hub checkpoints store experts one by one (models/deepseek_v2.py:1170-1200 expert_params_mapping)."""
+    from semi_pd_amd.model_loader import product_items
+    from semi_pd_amd.models.deepseek_v2 import DeepseekV2Config
+    cfg = DeepseekV2Config(n_routed_experts=3, moe_intermediate_size=4, hidden_size=6)
+    g = torch.Generator().manual_seed(0)
+    ws = {}
+    for e in (2, 0, 1):
+        for which, shape in (("gate_proj", (4, 6)), ("up_proj", (4, 6)), ("down_proj", (6, 4))):
+            ws[f"model.layers.1.mlp.experts.{e}.{which}.weight"] = torch.randn(shape, generator=g)
+    out = dict(product_items(cfg, ws.items()))
+    assert set(out) == {"model.layers.1.mlp.experts.w13_weight", "model.layers.1.mlp.experts.w2_weight"}
+    w13 = out["model.layers.1.mlp.experts.w13_weight"]
+    assert w13.shape == (3, 8, 6)
+    assert torch.equal(w13[1, :4], ws["model.layers.1.mlp.experts.1.gate_proj.weight"])
+    assert torch.equal(w13[2, 4:], ws["model.layers.1.mlp.experts.2.up_proj.weight"])
+    assert torch.equal(out["model.layers.1.mlp.experts.w2_weight"][0], ws["model.layers.1.mlp.experts.0.down_proj.weight"])
+
+
+def test_unsupported_architecture_is_rejected():
+    with pytest.raises(ValueError):
+        config_from_hf_dict({"architectures": ["GPT2LMHeadModel"], "hidden_size": 8})
