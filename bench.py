@@ -173,6 +173,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--rate-sweep", default="", help="comma-separated Poisson rates; one extra (untimed for "
+                    "`value`) wave per rate after the timed steps, reported under qps_sweep (BASELINE config 2)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -230,6 +232,15 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         stats = engine.get_stats() if (rank == 0 and not args.no_kernel_timing) else []
+        sweep = []
+        for rate in [float(x) for x in args.rate_sweep.split(",") if x]:
+            barrier()
+            if rank == 0:
+                recs, dur = run_wave(engine, prompts, arrival_times(args.num_requests, rate, args.seed), args.output_len)
+                sm = summarize(recs, dur)
+                sweep.append({"request_rate": rate, **{k: (round(v, 2) if isinstance(v, float) else v)
+                                                       for k, v in sm.items()}})
+        barrier()
     finally:
         engine.shutdown()
 
@@ -248,7 +259,7 @@ def main():
         kt = s.get("kernel_timing") or {}
         if "decode_attention" in kt:
             k = kt["decode_attention"]
-            roofline = {"bound": "hbm", "kernel": "decode_stage1_kernel (+stage2)", "achieved": round(k["gbps"], 1),
+            roofline = {"bound": "hbm", "kernel": "decode_mfma_kernel + decode_stage2_kernel (one decode_attention call)", "achieved": round(k["gbps"], 1),
                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(k["gbps"] / HBM_PEAK_GBPS, 4),
                         "traffic": None, "avg_launch_us": round(k["avg_us"], 2),
                         "algorithmic_bytes_per_launch": int(k["bytes_per_launch"]), "launches_sampled": k["launches"]}
@@ -278,6 +289,8 @@ def main():
                    "request_rate": args.request_rate, "parallelism": f"tp{world}", "mode": args.mode},
         "roofline": roofline, "roofline_extra": extra, "cpu_baseline": cpu,
     }
+    if sweep:
+        out["qps_sweep"] = sweep
     print(json.dumps(out), flush=True)
 
 

@@ -69,8 +69,10 @@ __device__ inline Frag16 load_row8(const T* p, int valid) {
   return r;
 }
 
+// Two workgroups per CU (2 waves / SIMD, <= 256 VGPRs) wherever that fits without spilling: the second
+// wave hides the LDS / softmax latency of the first.
 template <typename T, int DKP, int DVP, bool VEC, bool CAP>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, (VEC && !CAP && DKP <= 128) ? 2 : 1)
 extend_attn_kernel(T* __restrict__ out, const T* __restrict__ q_ext, const T* __restrict__ k_ext,
                    const T* __restrict__ v_ext, const T* __restrict__ k_buf,
                    const T* __restrict__ v_buf, const int32_t* __restrict__ qo_indptr,
@@ -88,7 +90,7 @@ extend_attn_kernel(T* __restrict__ out, const T* __restrict__ q_ext, const T* __
   __shared__ __attribute__((aligned(16))) uint16_t k_lds[BN * KS];
   __shared__ __attribute__((aligned(16))) uint16_t v_lds[BN * VS];
 
-  const int seq = blockIdx.z, hq = blockIdx.y, q0 = blockIdx.x * BM;
+  const int seq = blockIdx.z, hq = blockIdx.x, q0 = (int)(gridDim.y - 1 - blockIdx.y) * BM;
   const int hk = hq / group;
   const int q_start = qo_indptr[seq];
   const int ext_len = qo_indptr[seq + 1] - q_start;
@@ -421,7 +423,9 @@ static int launch_extend_variant(void* out, const void* q, const void* k, const 
                                  int64_t kbuf_stride, int64_t vbuf_stride, int max_len_extend, float sm_scale,
                                  float logit_cap, hipStream_t st) {
   const int dkp = (Dk + 15) / 16 * 16, dvp = (Dv + 31) / 32 * 32;
-  dim3 grid((unsigned)((max_len_extend + 127) / 128), (unsigned)Hq, (unsigned)batch), block(256);
+  // x = head (fastest), y = query tile: dispatch order is x-major, so every head of the longest
+  // (last, causal) query tile starts first and the short tiles fill the tail
+  dim3 grid((unsigned)Hq, (unsigned)((max_len_extend + 127) / 128), (unsigned)batch), block(256);
 #define EXT(DKP, DVP)                                                                              \
   hipLaunchKernelGGL((extend_attn_kernel<T, DKP, DVP, VEC, CAP>), grid, block, 0, st, (T*)out,     \
                      (const T*)q, (const T*)k, (const T*)v, (const T*)k_buf, (const T*)v_buf,       \
