@@ -190,6 +190,18 @@ int semipd_lm_head_argmax(const void* hidden, const void* weight, float* logits,
                           int dtype, int out_is_i64, void* stream);
 size_t semipd_lm_head_argmax_workspace(int64_t batch, int64_t vocab);
 
+/* Dense layer at decode batch sizes: out[rows, n] = x[rows, k] . weight[n, k]^T (bf16/f16, fp32
+ * accumulate), rows <= 256, written for the regime where the call is bound by streaming `weight` once
+ * from HBM (weight rows go straight into MFMA operand registers; split-K over `num_cus` compute units
+ * with fp32 partial planes summed in a fixed order by a second small launch).  `workspace` (up to
+ * semipd_linear_workspace bytes, reused by every call on one stream) enables split-K; NULL = no split.
+ * num_cus = compute units this process may use (its CU-mask share), 0 = whole device.
+ * replaces UnquantizedLinearMethod.apply -> F.linear for decode batches (layers/linear.py:165-172). */
+size_t semipd_linear_workspace(int64_t max_rows, int64_t max_n);
+int semipd_linear(void* out, const void* x, const void* weight, void* workspace, size_t workspace_bytes,
+                  int64_t rows, int64_t n, int64_t k, int64_t ldx, int64_t ldo, int num_cus, int dtype,
+                  void* stream);
+
 /* Stochastic branch of Sampler.forward (layers/sampler.py:77-136).  All rows fp32, contiguous
  * [batch, vocab]; per-row parameter arrays may be NULL, then the scalar *_val applies to every row.
  *

@@ -387,7 +387,8 @@ template <typename T, typename OutT, bool GROUPED>
 int launch_skinny_gemm(OutT* c, const T* a, const T* w, const float* topk_weights, const int32_t* sorted_ids,
                        const int32_t* expert_ids, const int32_t* num_post_pad, int64_t num_valid, int64_t M,
                        int64_t N, int64_t K, int64_t lda, int64_t ldc, int64_t m_blocks, int top_k_div,
-                       int mul_routed_weight, hipStream_t st);
+                       int mul_routed_weight, hipStream_t st, int ksplit, float* partial_ws);
+int skinny_pick_ksplit(int64_t rows, int64_t N, int64_t K, int64_t m_blocks, int num_cus);
 
 }  // namespace semipd
 
@@ -471,7 +472,7 @@ int semipd_moe_grouped_gemm(void* c, const void* a, const void* w, const float* 
   SEMIPD_CHECK_ARG(aligned16(a) && aligned16(w), SEMIPD_EALIGN, "moe_grouped_gemm: unaligned pointer");
   // decode-sized calls are bound by streaming each expert's weights once: weight-streaming kernel
   if (num_valid <= 2048 && skinny_gemm_ok(k, k, a, w) && n % 4 == 0) {
-    SEMIPD_DISPATCH_HALF(dtype, T, return (launch_skinny_gemm<T, T, true>((T*)c, (const T*)a, (const T*)w, topk_weights, sorted_token_ids, expert_ids, num_tokens_post_pad, num_valid, (int64_t)0, n, k, k, n, (max_sorted + 63) / 64, top_k_div, mul_routed_weight, as_stream(stream))));
+    SEMIPD_DISPATCH_HALF(dtype, T, return (launch_skinny_gemm<T, T, true>((T*)c, (const T*)a, (const T*)w, topk_weights, sorted_token_ids, expert_ids, num_tokens_post_pad, num_valid, (int64_t)0, n, k, k, n, (max_sorted + 63) / 64, top_k_div, mul_routed_weight, as_stream(stream), 1, nullptr)));
   }
   // prefill-sized calls are MFMA-bound: wide tiles halve the LDS traffic per MFMA
   const bool wide = num_valid >= 2048;
@@ -504,7 +505,7 @@ int semipd_lm_head_argmax(const void* hidden, const void* weight, float* logits,
                    "lm_head_argmax: unaligned pointer");
   if (batch <= 64 && skinny_gemm_ok(hidden_size, hidden_size, hidden, weight) && vocab % 4 == 0) {
     int rc0 = 0;
-    SEMIPD_DISPATCH_HALF(dtype, T, rc0 = (launch_skinny_gemm<T, float, false>(lg, (const T*)hidden, (const T*)weight, nullptr, nullptr, nullptr, nullptr, (int64_t)0, batch, vocab, hidden_size, hidden_size, vocab, (int64_t)1, 1, 0, as_stream(stream))));
+    SEMIPD_DISPATCH_HALF(dtype, T, rc0 = (launch_skinny_gemm<T, float, false>(lg, (const T*)hidden, (const T*)weight, nullptr, nullptr, nullptr, nullptr, (int64_t)0, batch, vocab, hidden_size, hidden_size, vocab, (int64_t)1, 1, 0, as_stream(stream), 1, nullptr)));
     if (rc0) return rc0;
     return semipd_argmax(lg, out, batch, vocab, vocab, SEMIPD_F32, out_is_i64, stream);
   }
@@ -513,6 +514,35 @@ int semipd_lm_head_argmax(const void* hidden, const void* weight, float* logits,
   int rc = launch_status("lm_head_gemm");
   if (rc) return rc;
   return semipd_argmax(lg, out, batch, vocab, vocab, SEMIPD_F32, out_is_i64, stream);
+}
+
+// ---- dense linear at decode batch sizes ---------------------------------------------------------
+size_t semipd_linear_workspace(int64_t max_rows, int64_t max_n) {
+  // 16 split-K partial planes of [rows rounded to 64, n] fp32
+  const int64_t rows = (max_rows + 63) / 64 * 64;
+  return (size_t)(16 * rows * max_n * 4);
+}
+
+int semipd_linear(void* out, const void* x, const void* weight, void* workspace, size_t workspace_bytes,
+                  int64_t rows, int64_t n, int64_t k, int64_t ldx, int64_t ldo, int num_cus, int dtype,
+                  void* stream) {
+  SEMIPD_CHECK_ARG(rows >= 0 && n > 0 && k > 0 && ldx >= k && ldo >= n, SEMIPD_EINVAL, "linear: bad sizes");
+  if (rows == 0) return 0;
+  SEMIPD_CHECK_ARG(out && x && weight, SEMIPD_EINVAL, "linear: null pointer");
+  SEMIPD_CHECK_ARG(rows <= 256, SEMIPD_ESHAPE,
+                   "linear: %lld rows; this entry point is the weight-streaming path for decode batches (<= 256)",
+                   (long long)rows);
+  SEMIPD_CHECK_ARG(skinny_gemm_ok(k, ldx, x, weight) && n % 4 == 0 && ldo % 4 == 0 && aligned16(out), SEMIPD_EALIGN,
+                   "linear: k %% 32, n %% 4, 16-byte aligned rows required");
+  const int64_t m_blocks = (rows + 63) / 64;
+  int ksplit = 1;
+  if (workspace && aligned16(workspace)) {
+    ksplit = skinny_pick_ksplit(rows, n, k, m_blocks, num_cus);
+    const size_t plane = (size_t)(m_blocks * 64) * n * 4;
+    while (ksplit > 1 && (size_t)ksplit * plane > workspace_bytes) --ksplit;
+  }
+  SEMIPD_DISPATCH_HALF(dtype, T, return (launch_skinny_gemm<T, T, false>((T*)out, (const T*)x, (const T*)weight, nullptr, nullptr, nullptr, nullptr, (int64_t)0, rows, n, k, ldx, ldo, m_blocks, 1, 0, as_stream(stream), ksplit, ksplit > 1 ? (float*)workspace : nullptr)));
+  return 0;
 }
 
 }  // extern "C"

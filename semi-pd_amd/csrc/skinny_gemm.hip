@@ -43,7 +43,7 @@ skinny_gemm_kernel(OutT* __restrict__ c, const T* __restrict__ a, const T* __res
                    const float* __restrict__ topk_weights, const int32_t* __restrict__ sorted_ids,
                    const int32_t* __restrict__ expert_ids, const int32_t* __restrict__ num_post_pad,
                    int64_t num_valid, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldc,
-                   int top_k_div, int mul_routed_weight) {
+                   int top_k_div, int mul_routed_weight, int chunks_per_split, float* __restrict__ partial_ws) {
   constexpr int BM = 64, BNW = 16, KC = 256;     // rows of A per block, W rows per wave, K chunk
   constexpr int AS = KC + 8;                      // LDS row stride (elements)
   constexpr int KSC = KC / 32;                    // 8 MFMA k-steps per chunk
@@ -89,20 +89,24 @@ skinny_gemm_kernel(OutT* __restrict__ c, const T* __restrict__ a, const T* __res
   const bool w_ok = (n0 + c16) < N;
   const T* w_ptr = w + expert * N * K + (w_ok ? (n0 + c16) : 0) * K + q4 * 8;
 
+  // split-K: blockIdx.z owns K-chunks [z * chunks_per_split, (z + 1) * chunks_per_split)
+  const int64_t k_begin = (int64_t)blockIdx.z * chunks_per_split * KC;
+  const int64_t k_end = min(K, k_begin + (int64_t)chunks_per_split * KC);
+
   FragS areg[NA];
   FragS wreg[2][KSC];
   auto fetch_a = [&](int64_t k0) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       areg[i].u = make_uint4(0, 0, 0, 0);
-      if (a_ok[i] && k0 + ch * 8 < K) areg[i].u = *reinterpret_cast<const uint4*>(a_ptr[i] + k0);
+      if (a_ok[i] && k0 + ch * 8 < k_end) areg[i].u = *reinterpret_cast<const uint4*>(a_ptr[i] + k0);
     }
   };
   auto fetch_w = [&](FragS (&r)[KSC], int64_t k0) __attribute__((always_inline)) {
 #pragma unroll
     for (int ks = 0; ks < KSC; ++ks) {
       r[ks].u = make_uint4(0, 0, 0, 0);
-      if (w_ok && k0 + ks * 32 + q4 * 8 < K) r[ks].u = *reinterpret_cast<const uint4*>(w_ptr + k0 + ks * 32);
+      if (w_ok && k0 + ks * 32 + q4 * 8 < k_end) r[ks].u = *reinterpret_cast<const uint4*>(w_ptr + k0 + ks * 32);
     }
   };
 
@@ -125,28 +129,28 @@ skinny_gemm_kernel(OutT* __restrict__ c, const T* __restrict__ a, const T* __res
     }
   };
 
-  fetch_a(0);
-  fetch_w(wreg[0], 0);
-  for (int64_t k0 = 0; k0 < K; k0 += 2 * KC) {
+  fetch_a(k_begin);
+  fetch_w(wreg[0], k_begin);
+  for (int64_t k0 = k_begin; k0 < k_end; k0 += 2 * KC) {
     // ---- even chunk ----
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < NA; ++i)
       *reinterpret_cast<uint4*>(&a_lds[(r0 + 8 * i) * AS + ch * 8]) = areg[i].u;
     __syncthreads();
-    if (k0 + KC < K) {
+    if (k0 + KC < k_end) {
       fetch_a(k0 + KC);
       fetch_w(wreg[1], k0 + KC);
     }
     compute(wreg[0]);
     // ---- odd chunk ----
-    if (k0 + KC < K) {
+    if (k0 + KC < k_end) {
       __syncthreads();
 #pragma unroll
       for (int i = 0; i < NA; ++i)
         *reinterpret_cast<uint4*>(&a_lds[(r0 + 8 * i) * AS + ch * 8]) = areg[i].u;
       __syncthreads();
-      if (k0 + 2 * KC < K) {
+      if (k0 + 2 * KC < k_end) {
         fetch_a(k0 + 2 * KC);
         fetch_w(wreg[0], k0 + 2 * KC);
       }
@@ -156,6 +160,26 @@ skinny_gemm_kernel(OutT* __restrict__ c, const T* __restrict__ a, const T* __res
 
   // ---- epilogue: lane holds C^T[n = n0 + q4*4 + r][m = t*16 + c16] ----
   const int64_t nb = n0 + q4 * 4;
+  if (!GROUPED && gridDim.z > 1) {
+    // split-K: fp32 partials [z][m_block * 64 + row][N], summed in z order by splitk_reduce_kernel.
+    // (An in-kernel "last workgroup reduces" needs agent-scope fences, which write back / invalidate
+    // the whole XCD L2 per workgroup on gfx950: measured 10x slower than this second launch.)
+    const int64_t rows_total = (int64_t)gridDim.y * BM;
+    float* ws = partial_ws + ((int64_t)blockIdx.z * rows_total + m0) * N;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (t >= m_tiles || nb >= N) continue;
+      float* dst = ws + (int64_t)(t * 16 + c16) * N + nb;
+      if (nb + 4 <= N && (N % 4 == 0)) {
+        *reinterpret_cast<float4*>(dst) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (nb + r < N) dst[r] = acc[t][r];
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     if (t >= m_tiles) continue;
@@ -192,26 +216,91 @@ bool skinny_gemm_ok(int64_t K, int64_t lda, const void* a, const void* w) {
   return K % 32 == 0 && lda % 8 == 0 && aligned16(a) && aligned16(w);
 }
 
+// c[m, n] = sum_z partial[z][m][n] (z ascending: deterministic), 4 consecutive n per thread
+template <typename OutT>
+__global__ void __launch_bounds__(256)
+splitk_reduce_kernel(OutT* __restrict__ c, const float* __restrict__ partial, int ksplit, int64_t M, int64_t N,
+                     int64_t plane_rows, int64_t ldc) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t n4 = N / 4;
+  if (i >= M * n4) return;
+  const int64_t m = i / n4, n = (i - m * n4) * 4;
+  const float* src = partial + m * N + n;
+  f32x4 acc = *reinterpret_cast<const f32x4*>(src);
+  for (int z = 1; z < ksplit; ++z) acc += *reinterpret_cast<const f32x4*>(src + (int64_t)z * plane_rows * N);
+  OutT* dst = c + m * ldc + n;
+  if constexpr (sizeof(OutT) == 4) {
+    *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  } else {
+    uint2 p;
+    p.x = (uint32_t)Elem<OutT>::from_f(acc[0]).v | ((uint32_t)Elem<OutT>::from_f(acc[1]).v << 16);
+    p.y = (uint32_t)Elem<OutT>::from_f(acc[2]).v | ((uint32_t)Elem<OutT>::from_f(acc[3]).v << 16);
+    *reinterpret_cast<uint2*>(dst) = p;
+  }
+}
+
 template <typename T, typename OutT, bool GROUPED>
 int launch_skinny_gemm(OutT* c, const T* a, const T* w, const float* topk_weights, const int32_t* sorted_ids,
                        const int32_t* expert_ids, const int32_t* num_post_pad, int64_t num_valid, int64_t M,
                        int64_t N, int64_t K, int64_t lda, int64_t ldc, int64_t m_blocks, int top_k_div,
-                       int mul_routed_weight, hipStream_t st) {
-  dim3 grid((unsigned)((N + 63) / 64), (unsigned)m_blocks);
+                       int mul_routed_weight, hipStream_t st, int ksplit, float* partial_ws) {
+  const int chunks = (int)((K + 255) / 256);
+  if (GROUPED || ksplit < 1 || !partial_ws || N % 4 != 0 || ldc % 4 != 0) ksplit = 1;
+  const int cps = (chunks + ksplit - 1) / ksplit;
+  ksplit = (chunks + cps - 1) / cps;  // no empty splits
+  dim3 grid((unsigned)((N + 63) / 64), (unsigned)m_blocks, (unsigned)ksplit);
   hipLaunchKernelGGL((skinny_gemm_kernel<T, OutT, GROUPED>), grid, dim3(256), 0, st, c, a, w, topk_weights,
                      sorted_ids, expert_ids, num_post_pad, num_valid, M, N, K, lda, ldc, top_k_div,
-                     mul_routed_weight);
-  return launch_status("skinny_gemm");
+                     mul_routed_weight, cps, partial_ws);
+  int rc = launch_status("skinny_gemm");
+  if (rc || ksplit == 1) return rc;
+  const int64_t items = M * (N / 4);
+  hipLaunchKernelGGL((splitk_reduce_kernel<OutT>), dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, c,
+                     (const float*)partial_ws, ksplit, M, N, m_blocks * 64, ldc);
+  return launch_status("splitk_reduce");
+}
+
+// Split-K factor for a weight-streaming call on `num_cus` compute units: fill every workgroup slot
+// (3 workgroups per CU at 152 VGPRs) in whole rounds, keep >= 2 K-chunks per split.
+int skinny_pick_ksplit(int64_t rows, int64_t N, int64_t K, int64_t m_blocks, int num_cus) {
+  const int chunks = (int)((K + 255) / 256);
+  const double tiles = (double)((N + 63) / 64) * (double)m_blocks;
+  const double slots = (double)(num_cus > 0 ? num_cus : 256) * 3.0;
+  // time model: weight bytes at ~20 GB/s per resident workgroup slot in use (5 TB/s over a full chip),
+  // scaled by how evenly the rounds fill the slots and the K-chunks fill the splits; a split adds
+  // the reduction launch (~3 us) and its partial traffic
+  const double bytes = (double)N * (double)K * 2.0;
+  int best = 1;
+  double best_t = 1e30;
+  for (int s : {1, 2, 3, 4, 6, 8, 12, 16}) {
+    if (s > 1 && chunks / s < 2) break;
+    const int cps = (chunks + s - 1) / s;
+    const int s_eff = (chunks + cps - 1) / cps;
+    const double wgs = tiles * s_eff;
+    const double rounds = wgs / slots;
+    const double full_rounds = (double)(int64_t)(rounds + 0.999999);
+    const double balance = (double)chunks / ((double)s_eff * cps);
+    double t = bytes * full_rounds / (rounds * balance) / (20e9 * (rounds < 1.0 ? wgs : slots));
+    if (s_eff > 1) t += 3e-6 + (double)s_eff * (double)rows * (double)N * 8.0 / 2e12;
+    if (t < best_t * 0.97) {
+      best_t = t;
+      best = s_eff;
+    }
+  }
+  return best;
 }
 
 #define SKINNY_INST(T, OutT, G)                                                                        \
   template int launch_skinny_gemm<T, OutT, G>(OutT*, const T*, const T*, const float*, const int32_t*, \
                                               const int32_t*, const int32_t*, int64_t, int64_t, int64_t, \
-                                              int64_t, int64_t, int64_t, int64_t, int, int, hipStream_t);
+                                              int64_t, int64_t, int64_t, int64_t, int, int, hipStream_t, \
+                                              int, float*);
 SKINNY_INST(bf16_t, bf16_t, true)
 SKINNY_INST(f16_t, f16_t, true)
 SKINNY_INST(bf16_t, float, false)
 SKINNY_INST(f16_t, float, false)
+SKINNY_INST(bf16_t, bf16_t, false)
+SKINNY_INST(f16_t, f16_t, false)
 #undef SKINNY_INST
 
 }  // namespace semipd

@@ -49,6 +49,8 @@ _SIGNATURES = {
     "semipd_argmax": [_vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp],
     "semipd_lm_head_argmax": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp],
     "semipd_lm_head_argmax_workspace": [_i64, _i64],
+    "semipd_linear_workspace": [_i64, _i64],
+    "semipd_linear": [_vp, _vp, _vp, _vp, _sz, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _vp],
     "semipd_softmax_temperature": [_vp, _vp, _i64, _i64, _vp],
     "semipd_top_k_top_p_sampling_from_probs": [_vp, _vp, _vp, _i32, _vp, _f32, _vp, _vp, _i64, _i64, _i32, _vp],
     "semipd_min_p_sampling_from_probs": [_vp, _vp, _vp, _f32, _vp, _i64, _i64, _vp],
@@ -71,7 +73,8 @@ _SIGNATURES = {
     "semipd_stream_get_cu_mask": [_vp, _vp, _i32],
     "semipd_probe_cu_placement": [_vp, _i32, _i64, _vp],
 }
-_RESTYPES = {"semipd_last_error": C.c_char_p, "semipd_lm_head_argmax_workspace": _sz}
+_RESTYPES = {"semipd_last_error": C.c_char_p, "semipd_lm_head_argmax_workspace": _sz,
+             "semipd_linear_workspace": _sz}
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

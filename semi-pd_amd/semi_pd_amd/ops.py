@@ -308,6 +308,46 @@ def lm_head_argmax(hidden: torch.Tensor, weight: torch.Tensor, return_logits: bo
     return (logits if return_logits else None), out
 
 
+# --------------------------------------------------------------------------- decode-sized dense layers
+_LINEAR_WS = {}
+_LINEAR_WS_BYTES = 64 << 20  # split-K partial planes + tile counters, shared by every layer of a process
+
+
+def _linear_workspace(device: torch.device) -> torch.Tensor:
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    ws = _LINEAR_WS.get(key)
+    if ws is None:
+        ws = torch.zeros(_LINEAR_WS_BYTES, dtype=torch.uint8, device=device)  # counters must start at zero
+        _LINEAR_WS[key] = ws
+    return ws
+
+
+def linear_is_supported(x: torch.Tensor, weight: torch.Tensor, max_rows: int = 256) -> bool:
+    return (x.is_cuda and x.dim() == 2 and weight.dim() == 2 and 0 < x.shape[0] <= max_rows
+            and x.dtype == weight.dtype and x.dtype in (torch.bfloat16, torch.float16)
+            and x.stride(1) == 1 and weight.is_contiguous() and x.shape[1] == weight.shape[1]
+            and weight.shape[1] % 32 == 0 and weight.shape[0] % 4 == 0 and x.stride(0) % 8 == 0
+            and x.data_ptr() % 16 == 0)
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, num_cus: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x @ weight.T for decode batches (UnquantizedLinearMethod.apply, layers/linear.py:165-172) with the
+    weight-streaming split-K kernel.  num_cus = compute units of this process's CU-mask share."""
+    if not linear_is_supported(x, weight):
+        raise RuntimeError("linear: unsupported shapes / dtypes / strides for the weight-streaming kernel")
+    M, K = x.shape
+    N = weight.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    elif out.shape != (M, N) or out.dtype != x.dtype or out.stride(1) != 1:
+        raise RuntimeError("linear: bad out tensor")
+    ws = _linear_workspace(x.device)
+    check(_lib.load().semipd_linear(ptr(out), ptr(x), ptr(weight), ptr(ws), ws.numel(), M, N, K, x.stride(0),
+                                    out.stride(0), int(num_cus), dtype_code(x.dtype), current_stream(x.device)),
+          "linear")
+    return out
+
+
 # --------------------------------------------------------------------------- stochastic sampling
 def _probs_2d(probs: torch.Tensor, name: str) -> Tuple[int, int]:
     if probs.dim() != 2 or probs.dtype != torch.float32 or not probs.is_contiguous():

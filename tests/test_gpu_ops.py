@@ -517,3 +517,32 @@ def test_fused_moe_pipeline(ops, device, T, N, K, E, topk, dtype):
     out = ops.moe_sum(c3.view(T, topk, K))
     want = O.fused_moe(a, w1, w2, tw.cpu(), tid.cpu())
     _close(out, want, dtype, rtol=1e-1, atol=1e-2)
+
+
+# ----------------------------------------------------------------------------- decode-sized dense layers
+# UnquantizedLinearMethod.apply = F.linear (layers/linear.py:165-172); bf16 tolerance of the fused-MoE
+# GEMM test (test/srt/test_fused_moe.py:31-44)
+@pytest.mark.parametrize("M", [1, 7, 16, 33, 64, 130])
+@pytest.mark.parametrize("N,K", [(4096, 4096), (6144, 4096), (28672, 4096), (4096, 14336), (1000, 512), (64, 96)])
+@pytest.mark.parametrize("num_cus", [0, 128])
+def test_linear_split_k(ops, device, M, N, K, num_cus):
+    torch.manual_seed(M + N + K)
+    x = torch.randn(M, K).to(torch.bfloat16)
+    w = (torch.randn(N, K) * 0.05).to(torch.bfloat16)
+    want = x.float() @ w.float().T
+    got = ops.linear(x.to(device), w.to(device), num_cus=num_cus)
+    torch.testing.assert_close(got.cpu().float(), want, rtol=2e-2, atol=2e-2 * float(want.abs().max()))
+    # deterministic (fixed-order split-K reduction) and the counters are left clean for the next call
+    again = ops.linear(x.to(device), w.to(device), num_cus=num_cus)
+    assert torch.equal(got, again)
+
+
+def test_linear_strided_rows_and_f16(ops, device):
+    torch.manual_seed(5)
+    big = torch.randn(9, 2 * 512).to(torch.float16)
+    w = (torch.randn(256, 512) * 0.05).to(torch.float16)
+    x = big.to(device)[:, 512:]  # row stride 1024, 16-byte aligned start
+    got = ops.linear(x, w.to(device))
+    torch.testing.assert_close(got.cpu().float(), big[:, 512:].float() @ w.float().T, rtol=2e-3, atol=2e-2)
+    with pytest.raises(RuntimeError):
+        ops.linear(torch.randn(300, 512, device=device, dtype=torch.float16), w.to(device))

@@ -144,8 +144,41 @@ def bench_lm_head():
         print(f"lm_head_argmax B={B:3d}: {t * 1e6:8.1f} us {V * H * 2 / t / 1e9:6.0f} GB/s   (torch matmul+argmax {t2 * 1e6:8.1f} us)")
 
 
+def bench_linear():
+    """Decode-sized dense layers of Llama-3-8B: hipBLASLt (F.linear) vs the weight-streaming split-K kernel
+    (ops.linear; KBENCH_NUM_CUS = compute units assumed by its split heuristic)."""
+    print("# decode linear M x [N, K]: hipBLASLt us / GB/s   ops.linear us / GB/s   HSA_CU_MASK=%s"
+          % os.environ.get("HSA_CU_MASK", "-"))
+    import torch.nn.functional as F
+    for M in (1, 16, 32, 64):
+        for (N, K) in ((28672, 4096), (4096, 14336), (6144, 4096), (4096, 4096)):
+            # rotate over several weight copies so that the 4 MB L2 / 256 MB MALL do not serve re-reads
+            copies = max(2, int(1.2e9 // (N * K * 2)))
+            ws = [torch.randn(N, K, device=dev, dtype=torch.bfloat16) * 0.02 for _ in range(copies)]
+            x = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
+            it = [0]
+
+            def f1():
+                it[0] += 1
+                return F.linear(x, ws[it[0] % copies])
+
+            ncu = int(os.environ.get("KBENCH_NUM_CUS", "0"))
+
+            def f2():
+                it[0] += 1
+                return ops.linear(x, ws[it[0] % copies], num_cus=ncu)
+            t1 = timeit(f1, iters=3 * copies)
+            t2 = timeit(f2, iters=3 * copies)
+            by = N * K * 2
+            print(f"linear M={M:3d} N={N:6d} K={K:6d}: blaslt {t1 * 1e6:7.1f} us {by / t1 / 1e9:6.0f} GB/s   "
+                  f"skinny {t2 * 1e6:7.1f} us {by / t2 / 1e9:6.0f} GB/s")
+            del ws
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which == "linear":
+        bench_linear()
     if which in ("decode", "all"):
         bench_decode()
     if which in ("mla", "all"):
