@@ -262,6 +262,8 @@ def main():
             roofline = {"bound": "hbm", "kernel": "decode_mfma_kernel + decode_stage2_kernel (one decode_attention call)", "achieved": round(k["gbps"], 1),
                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(k["gbps"] / HBM_PEAK_GBPS, 4),
                         "traffic": None, "avg_launch_us": round(k["avg_us"], 2),
+                        "avg_launch_us_minus_event_overhead": round(k.get("avg_us_minus_event_overhead", k["avg_us"]), 2),
+                        "event_pair_overhead_us": kt.get("_event_pair_overhead_us"),
                         "algorithmic_bytes_per_launch": int(k["bytes_per_launch"]), "launches_sampled": k["launches"]}
         if "extend_attention" in kt:
             k = kt["extend_attention"]

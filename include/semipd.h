@@ -314,6 +314,10 @@ int semipd_stream_get_cu_mask(void* stream, uint32_t* mask, int words);
  * (out[2*wg], out[2*wg+1]) and spins for `spin_cycles`. */
 int semipd_probe_cu_placement(int32_t* out, int num_workgroups, int64_t spin_cycles, void* stream);
 
+/* Measurement aid: enqueue `count` empty kernels.  bench.py brackets them with the same pair of HIP
+ * events it uses around a hot kernel to calibrate the dispatch + completion overhead the pair adds. */
+int semipd_launch_noop(int count, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,6 +46,10 @@ __global__ void probe_cu_placement_kernel(int32_t* out, long long spin_cycles) {
 
 using namespace semipd;
 
+namespace semipd {
+__global__ void noop_kernel() {}
+}  // namespace semipd
+
 extern "C" {
 
 int semipd_ipc_get_handle(const void* dev_ptr, uint8_t handle[64], uint64_t* offset) {
@@ -171,6 +175,12 @@ int semipd_probe_cu_placement(int32_t* out, int num_workgroups, int64_t spin_cyc
   hipLaunchKernelGGL(probe_cu_placement_kernel, dim3(num_workgroups), dim3(64), 0, as_stream(stream),
                      out, (long long)spin_cycles);
   return launch_status("probe_cu_placement");
+}
+
+int semipd_launch_noop(int count, void* stream) {
+  SEMIPD_CHECK_ARG(count >= 0 && count <= 1024, SEMIPD_EINVAL, "launch_noop: bad count");
+  for (int i = 0; i < count; ++i) hipLaunchKernelGGL(noop_kernel, dim3(1), dim3(64), 0, as_stream(stream));
+  return launch_status("noop");
 }
 
 }  // extern "C"

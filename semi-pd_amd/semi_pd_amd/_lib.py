@@ -72,6 +72,7 @@ _SIGNATURES = {
     "semipd_stream_destroy": [_vp],
     "semipd_stream_get_cu_mask": [_vp, _vp, _i32],
     "semipd_probe_cu_placement": [_vp, _i32, _i64, _vp],
+    "semipd_launch_noop": [_i32, _vp],
 }
 _RESTYPES = {"semipd_last_error": C.c_char_p, "semipd_lm_head_argmax_workspace": _sz,
              "semipd_linear_workspace": _sz}

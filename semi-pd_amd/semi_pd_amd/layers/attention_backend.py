@@ -205,7 +205,7 @@ class HipAttnBackend(AttentionBackend):
             o.view(B, layer.tp_q_head_num, layer.v_head_dim),
             md.kv_indptr, md.kv_indices, md.attn_logits, md.num_kv_splits, layer.scaling, layer.logit_cap)
         if kt:
-            kt.stop("decode_attention", t0, *self._algo)
+            kt.stop("decode_attention", t0, *self._algo, n_kernels=2 if md.num_kv_splits > 1 else 1)
         return o
 
 
