@@ -263,8 +263,9 @@ int semipd_moe_align_block_size(const int32_t* topk_ids, int64_t numel, int num_
  * token(r) = sorted_token_ids[r] / top_k_div (top_k_div=topk for GEMM1 where A is
  * [T,K]; 1 for GEMM2 where A is [T*k,K]); rows with id >= num_valid are skipped.
  * mul_routed_weight multiplies each output row by topk_weights[sorted id].
- * C is [T*k, N] indexed by the sorted id.  block_m must equal the block_size used in
- * semipd_moe_align_block_size (64).
+ * C is [T*k, N] indexed by the sorted id.  block_m (64 or 128) must equal the block_size used in
+ * semipd_moe_align_block_size: 64 for decode batches, 128 for prefill chunks (one pass over an
+ * expert's weights per block_m rows routed to it).
  * replaces fused_moe_kernel / invoke_fused_moe_kernel
  *   (layers/moe/fused_moe_triton/fused_moe.py:54-273, 501-612). */
 int semipd_moe_grouped_gemm(void* c, const void* a, const void* w, const float* topk_weights,

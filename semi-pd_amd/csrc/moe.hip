@@ -383,7 +383,7 @@ gemm_nt_kernel(OutT* __restrict__ c, const T* __restrict__ a, const T* __restric
 
 // defined in skinny_gemm.hip
 bool skinny_gemm_ok(int64_t K, int64_t lda, const void* a, const void* w);
-template <typename T, typename OutT, bool GROUPED>
+template <typename T, typename OutT, bool GROUPED, int BM = 64>
 int launch_skinny_gemm(OutT* c, const T* a, const T* w, const float* topk_weights, const int32_t* sorted_ids,
                        const int32_t* expert_ids, const int32_t* num_post_pad, int64_t num_valid, int64_t M,
                        int64_t N, int64_t K, int64_t lda, int64_t ldc, int64_t m_blocks, int top_k_div,
@@ -463,18 +463,25 @@ int semipd_moe_grouped_gemm(void* c, const void* a, const void* w, const float* 
                             int block_m, int dtype, void* stream) {
   SEMIPD_CHECK_ARG(n > 0 && k > 0 && num_valid >= 0 && max_sorted >= 0 && top_k_div > 0,
                    SEMIPD_EINVAL, "moe_grouped_gemm: bad sizes");
-  SEMIPD_CHECK_ARG(block_m == 64, SEMIPD_ESHAPE, "moe_grouped_gemm: block_m must be 64");
+  SEMIPD_CHECK_ARG(block_m == 64 || block_m == 128, SEMIPD_ESHAPE, "moe_grouped_gemm: block_m must be 64 or 128");
   if (num_valid == 0 || max_sorted == 0) return 0;
   SEMIPD_CHECK_ARG(c && a && w && sorted_token_ids && expert_ids && num_tokens_post_pad, SEMIPD_EINVAL,
                    "moe_grouped_gemm: null pointer");
   SEMIPD_CHECK_ARG(!mul_routed_weight || topk_weights, SEMIPD_EINVAL,
                    "moe_grouped_gemm: topk_weights required");
   SEMIPD_CHECK_ARG(aligned16(a) && aligned16(w), SEMIPD_EALIGN, "moe_grouped_gemm: unaligned pointer");
-  // decode-sized calls are bound by streaming each expert's weights once: weight-streaming kernel
-  if (num_valid <= 2048 && skinny_gemm_ok(k, k, a, w) && n % 4 == 0) {
-    SEMIPD_DISPATCH_HALF(dtype, T, return (launch_skinny_gemm<T, T, true>((T*)c, (const T*)a, (const T*)w, topk_weights, sorted_token_ids, expert_ids, num_tokens_post_pad, num_valid, (int64_t)0, n, k, k, n, (max_sorted + 63) / 64, top_k_div, mul_routed_weight, as_stream(stream), 1, nullptr)));
+  // Up to a few hundred rows per expert the call is bound by streaming the expert weights (one pass per
+  // block of block_m rows), not by MFMA: weight-streaming kernel, 64-row blocks for decode, 128-row
+  // blocks for prefill chunks
+  if (skinny_gemm_ok(k, k, a, w) && n % 4 == 0) {
+    if (block_m == 128) {
+      SEMIPD_DISPATCH_HALF(dtype, T, return (launch_skinny_gemm<T, T, true, 128>((T*)c, (const T*)a, (const T*)w, topk_weights, sorted_token_ids, expert_ids, num_tokens_post_pad, num_valid, (int64_t)0, n, k, k, n, (max_sorted + 127) / 128, top_k_div, mul_routed_weight, as_stream(stream), 1, nullptr)));
+    }
+    SEMIPD_DISPATCH_HALF(dtype, T, return (launch_skinny_gemm<T, T, true, 64>((T*)c, (const T*)a, (const T*)w, topk_weights, sorted_token_ids, expert_ids, num_tokens_post_pad, num_valid, (int64_t)0, n, k, k, n, (max_sorted + 63) / 64, top_k_div, mul_routed_weight, as_stream(stream), 1, nullptr)));
   }
-  // prefill-sized calls are MFMA-bound: wide tiles halve the LDS traffic per MFMA
+  SEMIPD_CHECK_ARG(block_m == 64, SEMIPD_ESHAPE,
+                   "moe_grouped_gemm: block_m 128 needs k %% 32 == 0, n %% 4 == 0 and 16-byte aligned rows");
+  // general tiled kernel for the shapes the streaming kernel does not take
   const bool wide = num_valid >= 2048;
   dim3 grid((unsigned)((n + (wide ? 255 : 127)) / (wide ? 256 : 128)), (unsigned)((max_sorted + 63) / 64));
   if (wide) {

@@ -37,17 +37,18 @@ template <> struct MfmaS<f16_t> {
   }
 };
 
-template <typename T, typename OutT, bool GROUPED>
+template <typename T, typename OutT, bool GROUPED, int BM>
 __global__ void __launch_bounds__(256, 2)
 skinny_gemm_kernel(OutT* __restrict__ c, const T* __restrict__ a, const T* __restrict__ w,
                    const float* __restrict__ topk_weights, const int32_t* __restrict__ sorted_ids,
                    const int32_t* __restrict__ expert_ids, const int32_t* __restrict__ num_post_pad,
                    int64_t num_valid, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldc,
                    int top_k_div, int mul_routed_weight, int chunks_per_split, float* __restrict__ partial_ws) {
-  constexpr int BM = 64, BNW = 16, KC = 256;     // rows of A per block, W rows per wave, K chunk
+  constexpr int BNW = 16, KC = 256;              // W rows per wave, K chunk (BM = rows of A per block)
+  constexpr int MT = BM / 16;                     // m-tiles of 16 rows
   constexpr int AS = KC + 8;                      // LDS row stride (elements)
   constexpr int KSC = KC / 32;                    // 8 MFMA k-steps per chunk
-  constexpr int NA = BM * (KC / 8) / 256;         // 8 A chunks of 16 B per thread per K-chunk
+  constexpr int NA = BM * (KC / 8) / 256;         // A chunks of 16 B per thread per K-chunk (8 or 16)
   __shared__ __attribute__((aligned(16))) uint16_t a_lds[BM * AS];
   __shared__ int row_id[BM];
   __shared__ int n_rows;
@@ -76,14 +77,12 @@ skinny_gemm_kernel(OutT* __restrict__ c, const T* __restrict__ a, const T* __res
 
   // ---- A staging slots: chunk ch (16 B) of rows r0 + 8*i ----
   const int ch = tid & 31, r0 = tid >> 5;  // 32 chunks per 256-wide row, 8 rows per pass
-  const T* a_ptr[NA];
-  bool a_ok[NA];
+  int64_t a_off[NA];  // element offset of the chunk at k = 0, -1 = no such row
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     const int rid = row_id[r0 + 8 * i];
-    a_ok[i] = rid >= 0;
     const int64_t arow = GROUPED ? (int64_t)(rid / top_k_div) : (int64_t)rid;
-    a_ptr[i] = a + (a_ok[i] ? arow : 0) * lda + ch * 8;
+    a_off[i] = rid >= 0 ? arow * lda + ch * 8 : -1;
   }
   // ---- W rows of this wave: lane = row c16, 16 bytes at k = q4*8 (+32 per k-step) ----
   const bool w_ok = (n0 + c16) < N;
@@ -99,7 +98,7 @@ skinny_gemm_kernel(OutT* __restrict__ c, const T* __restrict__ a, const T* __res
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       areg[i].u = make_uint4(0, 0, 0, 0);
-      if (a_ok[i] && k0 + ch * 8 < k_end) areg[i].u = *reinterpret_cast<const uint4*>(a_ptr[i] + k0);
+      if (a_off[i] >= 0 && k0 + ch * 8 < k_end) areg[i].u = *reinterpret_cast<const uint4*>(a + a_off[i] + k0);
     }
   };
   auto fetch_w = [&](FragS (&r)[KSC], int64_t k0) __attribute__((always_inline)) {
@@ -110,16 +109,16 @@ skinny_gemm_kernel(OutT* __restrict__ c, const T* __restrict__ a, const T* __res
     }
   };
 
-  f32x4 acc[4];
+  f32x4 acc[MT];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   const uint16_t* a_rd = &a_lds[c16 * AS + q4 * 8];
 
   auto compute = [&](FragS (&r)[KSC]) __attribute__((always_inline)) {
 #pragma unroll
     for (int ks = 0; ks < KSC; ++ks) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
+      for (int t = 0; t < MT; ++t) {
         if (t < m_tiles) {
           FragS b;
           b.u = *reinterpret_cast<const uint4*>(a_rd + t * 16 * AS + ks * 32);
@@ -167,7 +166,7 @@ skinny_gemm_kernel(OutT* __restrict__ c, const T* __restrict__ a, const T* __res
     const int64_t rows_total = (int64_t)gridDim.y * BM;
     float* ws = partial_ws + ((int64_t)blockIdx.z * rows_total + m0) * N;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < MT; ++t) {
       if (t >= m_tiles || nb >= N) continue;
       float* dst = ws + (int64_t)(t * 16 + c16) * N + nb;
       if (nb + 4 <= N && (N % 4 == 0)) {
@@ -181,7 +180,7 @@ skinny_gemm_kernel(OutT* __restrict__ c, const T* __restrict__ a, const T* __res
     return;
   }
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
+  for (int t = 0; t < MT; ++t) {
     if (t >= m_tiles) continue;
     const int rid = row_id[t * 16 + c16];
     if (rid < 0 || nb >= N) continue;
@@ -239,7 +238,7 @@ splitk_reduce_kernel(OutT* __restrict__ c, const float* __restrict__ partial, in
   }
 }
 
-template <typename T, typename OutT, bool GROUPED>
+template <typename T, typename OutT, bool GROUPED, int BM = 64>
 int launch_skinny_gemm(OutT* c, const T* a, const T* w, const float* topk_weights, const int32_t* sorted_ids,
                        const int32_t* expert_ids, const int32_t* num_post_pad, int64_t num_valid, int64_t M,
                        int64_t N, int64_t K, int64_t lda, int64_t ldc, int64_t m_blocks, int top_k_div,
@@ -249,14 +248,14 @@ int launch_skinny_gemm(OutT* c, const T* a, const T* w, const float* topk_weight
   const int cps = (chunks + ksplit - 1) / ksplit;
   ksplit = (chunks + cps - 1) / cps;  // no empty splits
   dim3 grid((unsigned)((N + 63) / 64), (unsigned)m_blocks, (unsigned)ksplit);
-  hipLaunchKernelGGL((skinny_gemm_kernel<T, OutT, GROUPED>), grid, dim3(256), 0, st, c, a, w, topk_weights,
+  hipLaunchKernelGGL((skinny_gemm_kernel<T, OutT, GROUPED, BM>), grid, dim3(256), 0, st, c, a, w, topk_weights,
                      sorted_ids, expert_ids, num_post_pad, num_valid, M, N, K, lda, ldc, top_k_div,
                      mul_routed_weight, cps, partial_ws);
   int rc = launch_status("skinny_gemm");
   if (rc || ksplit == 1) return rc;
   const int64_t items = M * (N / 4);
   hipLaunchKernelGGL((splitk_reduce_kernel<OutT>), dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, c,
-                     (const float*)partial_ws, ksplit, M, N, m_blocks * 64, ldc);
+                     (const float*)partial_ws, ksplit, M, N, m_blocks * BM, ldc);
   return launch_status("splitk_reduce");
 }
 
@@ -290,17 +289,19 @@ int skinny_pick_ksplit(int64_t rows, int64_t N, int64_t K, int64_t m_blocks, int
   return best;
 }
 
-#define SKINNY_INST(T, OutT, G)                                                                        \
-  template int launch_skinny_gemm<T, OutT, G>(OutT*, const T*, const T*, const float*, const int32_t*, \
-                                              const int32_t*, const int32_t*, int64_t, int64_t, int64_t, \
-                                              int64_t, int64_t, int64_t, int64_t, int, int, hipStream_t, \
-                                              int, float*);
-SKINNY_INST(bf16_t, bf16_t, true)
-SKINNY_INST(f16_t, f16_t, true)
-SKINNY_INST(bf16_t, float, false)
-SKINNY_INST(f16_t, float, false)
-SKINNY_INST(bf16_t, bf16_t, false)
-SKINNY_INST(f16_t, f16_t, false)
+#define SKINNY_INST(T, OutT, G, BM)                                                                        \
+  template int launch_skinny_gemm<T, OutT, G, BM>(OutT*, const T*, const T*, const float*, const int32_t*, \
+                                                  const int32_t*, const int32_t*, int64_t, int64_t, int64_t, \
+                                                  int64_t, int64_t, int64_t, int64_t, int, int, hipStream_t, \
+                                                  int, float*);
+SKINNY_INST(bf16_t, bf16_t, true, 64)
+SKINNY_INST(f16_t, f16_t, true, 64)
+SKINNY_INST(bf16_t, bf16_t, true, 128)
+SKINNY_INST(f16_t, f16_t, true, 128)
+SKINNY_INST(bf16_t, float, false, 64)
+SKINNY_INST(f16_t, float, false, 64)
+SKINNY_INST(bf16_t, bf16_t, false, 64)
+SKINNY_INST(f16_t, f16_t, false, 64)
 #undef SKINNY_INST
 
 }  // namespace semipd

@@ -38,17 +38,22 @@ def fused_experts(hidden_states: torch.Tensor, w1: torch.Tensor, w2: torch.Tenso
     topk = topk_ids.shape[1]
     dev, dt = hidden_states.device, hidden_states.dtype
     numel = T * topk
-    max_sorted = numel + E * (MOE_BLOCK_M - 1)
+    # rows per block: every block streams its expert's weights once, so prefill chunks use the taller
+    # block (fused_moe.py:614-700 get_default_config picks BLOCK_SIZE_M by M the same way)
+    block_m = MOE_BLOCK_M if numel <= 2048 else 2 * MOE_BLOCK_M
+    max_sorted = numel + E * (block_m - 1)
     sorted_ids = torch.empty(max_sorted, dtype=torch.int32, device=dev)
-    expert_ids = torch.empty((max_sorted + MOE_BLOCK_M - 1) // MOE_BLOCK_M, dtype=torch.int32, device=dev)
+    expert_ids = torch.empty((max_sorted + block_m - 1) // block_m, dtype=torch.int32, device=dev)
     num_post_pad = torch.empty(1, dtype=torch.int32, device=dev)
     cumsum = torch.empty(E + 1, dtype=torch.int32, device=dev)
-    ops.moe_align_block_size(topk_ids, E, MOE_BLOCK_M, sorted_ids, expert_ids, num_post_pad, None, cumsum)
+    ops.moe_align_block_size(topk_ids, E, block_m, sorted_ids, expert_ids, num_post_pad, None, cumsum)
     c1 = torch.empty((numel, N2), dtype=dt, device=dev)
-    ops.moe_grouped_gemm(hidden_states, w1, c1, None, sorted_ids, expert_ids, num_post_pad, numel, topk, False)
+    ops.moe_grouped_gemm(hidden_states, w1, c1, None, sorted_ids, expert_ids, num_post_pad, numel, topk, False,
+                         block_m)
     c2 = ops.silu_and_mul(c1)
     c3 = torch.empty((numel, K), dtype=dt, device=dev)
-    ops.moe_grouped_gemm(c2, w2, c3, topk_weights.reshape(-1), sorted_ids, expert_ids, num_post_pad, numel, 1, True)
+    ops.moe_grouped_gemm(c2, w2, c3, topk_weights.reshape(-1), sorted_ids, expert_ids, num_post_pad, numel, 1, True,
+                         block_m)
     return ops.moe_sum(c3.view(T, topk, K))
 
 

@@ -492,7 +492,8 @@ def test_moe_align_block_size(ops, device, numel_tokens, topk, E, block):
 @pytest.mark.parametrize("T,N,K,E,topk", [(1, 128, 128, 8, 2), (33, 1024, 511 + 1, 8, 2), (64, 1408, 2048, 64, 6),
                                            (222, 128, 1024, 64, 6)])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_fused_moe_pipeline(ops, device, T, N, K, E, topk, dtype):
+@pytest.mark.parametrize("block", [64, 128])
+def test_fused_moe_pipeline(ops, device, T, N, K, E, topk, dtype, block):
     """align -> grouped GEMM1 -> silu_and_mul -> grouped GEMM2 (x routed weight) -> moe_sum against the
     reference's naive MoE (test/srt/test_fused_moe.py:46-63, tolerances :31-44)."""
     torch.manual_seed(T + N)
@@ -501,7 +502,6 @@ def test_fused_moe_pipeline(ops, device, T, N, K, E, topk, dtype):
     w2 = (torch.randn(E, K, N) / 10).to(dtype)
     gate = torch.randn(T, E)
     tw, tid = ops.topk_softmax(gate.to(device), topk, True)
-    block = 64
     numel = T * topk
     max_sorted = numel + E * (block - 1)
     sorted_ids = torch.empty(max_sorted, dtype=torch.int32, device=device)
@@ -510,13 +510,30 @@ def test_fused_moe_pipeline(ops, device, T, N, K, E, topk, dtype):
     cumsum = torch.empty(E + 1, dtype=torch.int32, device=device)
     ops.moe_align_block_size(tid, E, block, sorted_ids, expert_ids, npp, None, cumsum)
     c1 = torch.empty(numel, 2 * N, dtype=dtype, device=device)
-    ops.moe_grouped_gemm(a.to(device), w1.to(device), c1, None, sorted_ids, expert_ids, npp, numel, topk, False)
+    ops.moe_grouped_gemm(a.to(device), w1.to(device), c1, None, sorted_ids, expert_ids, npp, numel, topk, False, block)
     c2 = ops.silu_and_mul(c1)
     c3 = torch.empty(numel, K, dtype=dtype, device=device)
-    ops.moe_grouped_gemm(c2, w2.to(device), c3, tw.flatten().contiguous(), sorted_ids, expert_ids, npp, numel, 1, True)
+    ops.moe_grouped_gemm(c2, w2.to(device), c3, tw.flatten().contiguous(), sorted_ids, expert_ids, npp, numel, 1, True, block)
     out = ops.moe_sum(c3.view(T, topk, K))
     want = O.fused_moe(a, w1, w2, tw.cpu(), tid.cpu())
     _close(out, want, dtype, rtol=1e-1, atol=1e-2)
+
+
+def test_fused_experts_layer_prefill_sized(ops, device):
+    """layers.moe.fused_experts above the decode threshold (T * topk > 2048 -> 128-row blocks): many rows
+    per expert, several blocks per expert, ragged last blocks."""
+    from semi_pd_amd.layers.moe import fused_experts
+    torch.manual_seed(3)
+    T, N, K, E, topk = 700, 256, 512, 8, 4
+    a = (torch.randn(T, K) / 10).to(torch.bfloat16)
+    w1 = (torch.randn(E, 2 * N, K) / 10).to(torch.bfloat16)
+    w2 = (torch.randn(E, K, N) / 10).to(torch.bfloat16)
+    gate = torch.randn(T, E)
+    gate[:, 0] += 2.0  # skewed routing: expert 0 gets most tokens
+    tw, tid = ops.topk_softmax(gate.to(device), topk, True)
+    out = fused_experts(a.to(device), w1.to(device), w2.to(device), tw, tid)
+    want = O.fused_moe(a, w1, w2, tw.cpu(), tid.cpu())
+    _close(out, want, torch.bfloat16, rtol=1e-1, atol=1e-2)
 
 
 # ----------------------------------------------------------------------------- decode-sized dense layers
