@@ -259,7 +259,8 @@ def main():
         kt = s.get("kernel_timing") or {}
         if "decode_attention" in kt:
             k = kt["decode_attention"]
-            roofline = {"bound": "hbm", "kernel": "decode_mfma_kernel + decode_stage2_kernel (one decode_attention call)", "achieved": round(k["gbps"], 1),
+            kname = ("mla_decode_kernel" if "Deepseek" in cfg.architectures[0] else "decode_mfma_kernel")
+            roofline = {"bound": "hbm", "kernel": kname + " + decode_stage2_kernel (one decode_attention call)", "achieved": round(k["gbps"], 1),
                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(k["gbps"] / HBM_PEAK_GBPS, 4),
                         "traffic": None, "avg_launch_us": round(k["avg_us"], 2),
                         "avg_launch_us_minus_event_overhead": round(k.get("avg_us_minus_event_overhead", k["avg_us"]), 2),
