@@ -64,11 +64,13 @@ def choose_kv_splits(batch: int, num_kv_heads: int, max_seq_len: int, num_cus: i
     """Split-KV factor: enough workgroups (batch x kv-head tiles x splits) to fill the CUs this
     process owns a few times over, never cutting below ~64 tokens per split.  (The reference uses a
     fixed --triton-attention-num-kv-splits, 16 on HIP: server_args.py:321-323.)"""
-    # one work item = one wave (4 per workgroup); 2 waves per SIMD fit, so ~16 items per CU keep
-    # every CU fully occupied with a second round to balance the tail
-    target = 16 * num_cus
+    # One work item = one wave of decode_mfma_kernel; 2 waves per SIMD fit, i.e. 8 per CU.  Measured
+    # on 128 and 256 CUs at ctx ~ 1.1 k (profiles/r01_kbench_decode_small_batches.txt): the best split
+    # puts ONE full round of waves on the CUs the process owns (B x Hkv x splits ~ 8 x CUs); a second
+    # round costs more in per-wave prologue and stage-2 work than it gains in balance.
+    target = 8 * num_cus
     base = max(1, batch * num_kv_heads)
-    want = max(1, -(-target // base))
+    want = max(1, target // base)
     by_len = max(1, max_seq_len // 64)
     return int(max(1, min(cap, want, by_len)))
 

@@ -56,6 +56,29 @@ def bench_decode():
                 del kb, vb
 
 
+def bench_decode_small():
+    """Serving-run regime: small decode batches, ctx ~ 1.1 k, every split factor (pick with HSA_CU_MASK)."""
+    print("# decode attention, small batches: B, ctx, splits -> us (stage1+stage2), GB/s   HSA_CU_MASK=%s"
+          % os.environ.get("HSA_CU_MASK", "-"))
+    Hq, Hkv, D = 32, 8, 128
+    for B in (4, 8, 16, 32, 64):
+        ctx = 1100
+        N = B * ctx + 1
+        kb = torch.randn(N, Hkv, D, device=dev, dtype=torch.bfloat16)
+        vb = torch.randn(N, Hkv, D, device=dev, dtype=torch.bfloat16)
+        q = torch.randn(B, Hq, D, device=dev, dtype=torch.bfloat16)
+        o = torch.empty_like(q)
+        indptr = (torch.arange(B + 1, device=dev, dtype=torch.int32) * ctx)
+        idx = (torch.randperm(N - 1, device=dev)[: B * ctx] + 1).to(torch.int32)
+        nbytes = B * ctx * Hkv * 2 * D * 2 + 2 * B * Hq * D * 2
+        row = []
+        for splits in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32):
+            lg = torch.empty(B, Hq, splits, D + 1, device=dev, dtype=torch.float32)
+            t = timeit(lambda: ops.decode_attention_fwd(q, kb, vb, o, indptr, idx, lg, splits, D ** -0.5), iters=50)
+            row.append(f"{splits}:{t * 1e6:.1f}us/{nbytes / t / 1e9:.0f}")
+        print(f"B={B:3d} ctx={ctx}: " + "  ".join(row))
+
+
 def bench_mla():
     print("# MLA decode attention (latent 576/512): B, ctx, H, splits -> us, GB/s, frac of 8 TB/s")
     for H in (16, 128):
@@ -179,6 +202,8 @@ if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     if which == "linear":
         bench_linear()
+    if which == "decode_small":
+        bench_decode_small()
     if which in ("decode", "all"):
         bench_decode()
     if which in ("mla", "all"):
