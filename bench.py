@@ -157,10 +157,10 @@ def main():
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--model", default="llama3-8b")
-    ap.add_argument("--num-requests", type=int, default=64)
+    ap.add_argument("--num-requests", type=int, default=256)
     ap.add_argument("--input-len", type=int, default=1024)
     ap.add_argument("--output-len", type=int, default=128)
-    ap.add_argument("--request-rate", type=float, default=16.0, help="Poisson arrivals per second (0 = all at once)")
+    ap.add_argument("--request-rate", type=float, default=32.0, help="Poisson arrivals per second (0 = all at once)")
     ap.add_argument("--mode", choices=["semi-pd", "unified"], default="semi-pd")
     ap.add_argument("--prefill-cu", type=int, default=50)
     ap.add_argument("--decode-cu", type=int, default=50)
