@@ -107,7 +107,9 @@ def cpu_baseline(cfg, input_len, output_len, budget_s=25.0):
     driven like bench_one_batch.py (one prefill, then decode steps)."""
     from oracle.model import OracleLlama
     import copy
-    cores = len(os.sched_getaffinity(0))
+    # torch's intra-op pool stops scaling (and with 256 hardware threads collapses: 3.2 s per decode
+    # step of ONE layer) well before a big host's core count: use at most 32 threads and say so
+    cores = min(len(os.sched_getaffinity(0)), 32)
     torch.set_num_threads(cores)
     c1 = copy.copy(cfg)
     c1.num_hidden_layers = 1
