@@ -175,6 +175,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--fixed-load", action="store_true", help="N > 1: do not scale requests / rate with N")
     ap.add_argument("--rate-sweep", default="", help="comma-separated Poisson rates; one extra (untimed for "
                     "`value`) wave per rate after the timed steps, reported under qps_sweep (BASELINE config 2)")
     args = ap.parse_args()
@@ -183,6 +184,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # N > 1 = tensor parallel over N GPUs serving N times the offered load: the request
+    # count and the Poisson rate are per GPU ("scaling": "weak"); a fixed offered load would cap the
+    # output rate by construction.  --fixed-load keeps the N = 1 load (strong scaling of latency).
+    if world > 1 and not args.fixed_load:
+        args.num_requests *= world
+        args.request_rate *= world
+        args.max_running_requests *= world
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -284,7 +292,7 @@ def main():
         "metric": "output tokens/s (Semi-PD mode; with p50 TTFT / TBT)" if args.mode == "semi-pd" else "output tokens/s (unified engine)",
         "value": round(summ["output_tok_s"], 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / max(args.steps, 1), 2),
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "higher_is_better": True, "scaling": ("strong" if args.fixed_load else "weak"), "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "p50_ttft_ms": summ["p50_ttft_ms"], "p50_tbt_ms": summ["p50_tbt_ms"],
         "p99_ttft_ms": summ["p99_ttft_ms"], "p99_tbt_ms": summ["p99_tbt_ms"],
         "config": {"workload": f"{args.model} bf16 TP={world} {args.mode}, CU split P{args.prefill_cu}/D{args.decode_cu} "

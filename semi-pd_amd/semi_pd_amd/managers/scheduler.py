@@ -79,6 +79,8 @@ class SchedulerBase:
         self.stats: Dict[str, float] = {"prefill_batches": 0, "prefill_tokens": 0, "decode_steps": 0,
                                         "decode_tokens": 0}
         self._shutdown = False
+        self._deferred_out: List[BatchTokenIDOut] = []
+        self.defer_decode_stream = False  # the Semi-PD decode loop turns this on
 
     # ---------------------------------------------------------------------------- input
     def recv_requests(self) -> list:
@@ -174,10 +176,14 @@ class SchedulerBase:
         self.token_to_kv_pool_allocator.free_group_end()
         self.stats["decode_steps"] += 1
         self.stats["decode_tokens"] += len(batch.reqs)
-        self.stream_output(batch.reqs)
+        self.stream_output(batch.reqs, defer=self.defer_decode_stream)
         self.last_progress = time.monotonic()
 
-    def stream_output(self, reqs: List[Req]):
+    def stream_output(self, reqs: List[Req], defer: bool = False):
+        """Send the tokens produced since the last message.  With defer=True the message is built now
+        but pickled and sent by flush_stream_output(), which the decode loop calls right after it has
+        launched the NEXT step, so that the host cost hides behind GPU work (the role of the overlap
+        thread of the reference, managers/tp_worker_overlap_thread.py, for the output path)."""
         if self.tp_rank != 0 or self.send_to_detokenizer is None or not reqs:
             return
         now = time.time()
@@ -191,7 +197,18 @@ class SchedulerBase:
             fins.append(r.finished_reason)
             outs.append(new)
         if rids:
-            self.send_to_detokenizer.send_pyobj(BatchTokenIDOut(rids, fins, outs, [now] * len(rids)))
+            msg = BatchTokenIDOut(rids, fins, outs, [now] * len(rids))
+            if defer:
+                self._deferred_out.append(msg)
+            else:
+                self.flush_stream_output()  # keep per-request order
+                self.send_to_detokenizer.send_pyobj(msg)
+
+    def flush_stream_output(self):
+        if self._deferred_out:
+            pending, self._deferred_out = self._deferred_out, []
+            for msg in pending:
+                self.send_to_detokenizer.send_pyobj(msg)
 
     # ---------------------------------------------------------------------------- decode helpers
     def update_running_batch(self, batch: ScheduleBatch) -> ScheduleBatch:

@@ -30,6 +30,7 @@ class SemiPDDecodeScheduler(SchedulerBase):
         super().__init__(server_args, model_runner, tp_rank, recv_socket, send_to_detokenizer, InstanceRole.DECODE)
         # requests handed to the prefill instance whose result has not come back yet
         self.scheduled_prefill_batches: List[ScheduleBatch] = []
+        self.defer_decode_stream = True               # see step(): outputs go out behind the next launch
         self.bridge_socket = bridge_socket            # PUSH -> P (replies to GetNextPrefillBatchInput)
         self.send_to_p_instance = send_to_p_instance  # PUSH -> P's input socket (retracted requests)
 
@@ -171,10 +172,12 @@ class SemiPDDecodeScheduler(SchedulerBase):
         self.process_input_requests(recv)
         batch = self.get_next_batch_to_run()
         if batch is None:
+            self.flush_stream_output()
             return bool(recv)
         t1 = time.perf_counter()
-        _, next_token_ids = self.run_batch(batch)
+        _, next_token_ids = self.run_batch(batch)  # asynchronous: one hipGraph launch
         batch.output_ids = next_token_ids
+        self.flush_stream_output()     # tokens of the previous step: pickle + send while the GPU works
         ids = next_token_ids.tolist()  # the only device sync of a decode step
         t2 = time.perf_counter()
         self.process_batch_result_decode(batch, ids)
