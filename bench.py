@@ -172,6 +172,8 @@ def main():
     ap.add_argument("--mem-fraction-static", type=float, default=None)
     ap.add_argument("--max-total-tokens", type=int, default=None)
     ap.add_argument("--disable-cuda-graph", action="store_true")
+    ap.add_argument("--kv-cache-dtype", default="auto", choices=["auto", "fp8_e5m2", "fp8_e4m3"],
+                    help="KV pool rows: activation type (the measured default) or OCP fp8")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
@@ -212,6 +214,7 @@ def main():
                     max_total_tokens=args.max_total_tokens, prefill_cu_percent=args.prefill_cu,
                     decode_cu_percent=args.decode_cu, cu_mask_mode=args.cu_mask_mode,
                     disable_cuda_graph=args.disable_cuda_graph, nccl_port_base=port_base,
+                    kv_cache_dtype=args.kv_cache_dtype,
                     collect_kernel_timing=not args.no_kernel_timing, random_seed=args.seed,
                     dist_init_addr=os.environ.get("MASTER_ADDR", "127.0.0.1"), watchdog_timeout=600.0)
     if args.mode == "unified" and world > 1:
@@ -297,9 +300,11 @@ def main():
         "p99_ttft_ms": summ["p99_ttft_ms"], "p99_tbt_ms": summ["p99_tbt_ms"],
         "config": {"workload": f"{args.model} bf16 TP={world} {args.mode}, CU split P{args.prefill_cu}/D{args.decode_cu} "
                                f"({args.cu_mask_mode}), {args.num_requests} synthetic requests in={args.input_len} "
-                               f"out={args.output_len}, Poisson {args.request_rate} req/s, dummy weights",
+                               f"out={args.output_len}, Poisson {args.request_rate} req/s, dummy weights"
+                               + ("" if args.kv_cache_dtype == "auto" else f", KV cache {args.kv_cache_dtype}"),
                    "num_requests": args.num_requests, "input_len": args.input_len, "output_len": args.output_len,
-                   "request_rate": args.request_rate, "parallelism": f"tp{world}", "mode": args.mode},
+                   "request_rate": args.request_rate, "parallelism": f"tp{world}", "mode": args.mode,
+                   "kv_cache_dtype": args.kv_cache_dtype},
         "roofline": roofline, "roofline_extra": extra, "cpu_baseline": cpu,
     }
     if sweep:

@@ -22,8 +22,12 @@
 extern "C" {
 #endif
 
-/* element types of activations / KV rows (a subset of at::ScalarType) */
-enum { SEMIPD_F32 = 0, SEMIPD_F16 = 1, SEMIPD_BF16 = 2 };
+/* element types of activations / KV rows (a subset of at::ScalarType).  The two fp8 types are
+ * KV-POOL STORAGE types only (OCP e5m2 / e4m3fn = torch.float8_e5m2 / float8_e4m3fn,
+ * `--kv-cache-dtype fp8_e5m2|fp8_e4m3`, mem_cache/memory_pool.py:205-209): rows are rounded to nearest
+ * even when stored and expanded exactly to the activation type when read; all arithmetic stays in the
+ * activation type.  Entry points that touch the pool take `kv_dtype` (== dtype for plain rows). */
+enum { SEMIPD_F32 = 0, SEMIPD_F16 = 1, SEMIPD_BF16 = 2, SEMIPD_F8E5M2 = 3, SEMIPD_F8E4M3 = 4 };
 
 /* argument-error codes (negative; HIP errors are returned positive) */
 enum {
@@ -99,7 +103,7 @@ int semipd_rope_kv_store(void* q, void* k, const void* v, void* k_buf, void* v_b
                          int64_t num_tokens, int num_q_heads, int num_k_heads, int head_size,
                          int v_head_size, int rot_dim, int64_t q_stride, int64_t k_stride,
                          int64_t v_stride, int64_t kbuf_stride, int64_t vbuf_stride, int interleave,
-                         int dtype, void* stream);
+                         int dtype, int kv_dtype, void* stream);
 
 /* buf[loc[t], :row_elems] = src[t, :row_elems]   (byte-exact row scatter)
  * replaces MHATokenToKVPool.set_kv_buffer / MLATokenToKVPool.set_kv_buffer
@@ -107,6 +111,10 @@ int semipd_rope_kv_store(void* q, void* k, const void* v, void* k_buf, void* v_b
 int semipd_kv_store(void* buf, const void* src, const int64_t* loc, int64_t num_tokens,
                     int64_t row_bytes, int64_t buf_stride_bytes, int64_t src_stride_bytes,
                     void* stream);
+/* Same scatter into an fp8 pool: buf[loc[t], :row_elems] = fp8(src[t, :row_elems]); strides in elements.
+ * replaces `cache_k.to(self.dtype)` + index_put of set_kv_buffer (mem_cache/memory_pool.py:326-346). */
+int semipd_kv_store_cvt(void* buf, const void* src, const int64_t* loc, int64_t num_tokens, int64_t row_elems,
+                        int64_t buf_stride, int64_t src_stride, int dtype, int kv_dtype, void* stream);
 
 /* ------------------------------------------------------------------ */
 /* a4  kv_indptr / kv_indices                                          */
@@ -145,7 +153,7 @@ int semipd_decode_attention(void* out, const void* q, const void* k_buf, const v
                             float* attn_logits, int64_t batch, int num_q_heads, int num_kv_heads,
                             int head_dim_k, int head_dim_v, int64_t q_stride, int64_t o_stride,
                             int64_t kbuf_stride, int64_t vbuf_stride, int num_kv_splits,
-                            float sm_scale, float logit_cap, int dtype, void* stream);
+                            float sm_scale, float logit_cap, int dtype, int kv_dtype, void* stream);
 
 /* ------------------------------------------------------------------ */
 /* a6  batched prefill (extend) attention                              */
@@ -164,7 +172,8 @@ int semipd_extend_attention(void* out, const void* q_extend, const void* k_exten
                             int num_kv_heads, int head_dim_k, int head_dim_v, int64_t q_stride,
                             int64_t k_stride, int64_t v_stride, int64_t o_stride,
                             int64_t kbuf_stride, int64_t vbuf_stride, int max_len_extend,
-                            float sm_scale, float logit_cap, int dtype, void* stream);
+                            float sm_scale, float logit_cap, int dtype, int kv_dtype,
+                            void* stream);
 
 /* ------------------------------------------------------------------ */
 /* a8/a9  logits post-processing and greedy sampling                   */

@@ -48,12 +48,16 @@ class _KVCache:
 
 
 class OracleLlama:
-    def __init__(self, config, state_dict: Dict[str, torch.Tensor], act_dtype=torch.float32):
+    def __init__(self, config, state_dict: Dict[str, torch.Tensor], act_dtype=torch.float32, kv_cache_dtype=None):
         """act_dtype=torch.float32: exact-arithmetic oracle; torch.bfloat16: rounds activations where
-        the engine materialises them (closer to the GPU bit pattern)."""
+        the engine materialises them (closer to the GPU bit pattern).  kv_cache_dtype = torch.float8_e5m2 /
+        float8_e4m3fn: rows go through `.to(fp8)` when they enter the cache and `.to(act)` when read
+        (mem_cache/memory_pool.py:205-209, 326-336); the tokens of the running forward attend to each
+        other unquantised, as extend_attention_fwd reads them from k_extend / v_extend."""
         self.cfg = config
         self.w = {k: v.detach().to("cpu") for k, v in state_dict.items()}
         self.act = act_dtype
+        self.kv_cache_dtype = kv_cache_dtype
         self.D = config.head_size
         self.Hq, self.Hkv = config.num_attention_heads, config.num_key_value_heads
         self.g = self.Hq // self.Hkv
@@ -87,9 +91,15 @@ class OracleLlama:
             outs = []
             for b, n in enumerate(lens):
                 sl = slice(starts[b], starts[b + 1])
-                kv.append(l, b, k[sl].view(n, self.Hkv, self.D), v[sl].view(n, self.Hkv, self.D))
-                outs.append(_sdpa_per_request(q[sl].view(n, self.Hq, self.D), kv.k[l][b], kv.v[l][b], self.g,
+                kc, vc = k[sl].view(n, self.Hkv, self.D), v[sl].view(n, self.Hkv, self.D)
+                k_all = kc if kv.k[l][b] is None else torch.cat([kv.k[l][b], kc], 0)
+                v_all = vc if kv.v[l][b] is None else torch.cat([kv.v[l][b], vc], 0)
+                outs.append(_sdpa_per_request(q[sl].view(n, self.Hq, self.D), k_all, v_all, self.g,
                                               self.D ** -0.5).reshape(n, -1))
+                if self.kv_cache_dtype is not None:
+                    kc, vc = (O.kv_cache_round_trip(kc, self.kv_cache_dtype),
+                              O.kv_cache_round_trip(vc, self.kv_cache_dtype))
+                kv.append(l, b, kc, vc)
             attn = torch.cat(outs, 0).to(self.act)
             h = self._lin(attn, p + "self_attn.o_proj.weight")
             x, res = O.fused_add_rms_norm(h, res, self.w[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps)

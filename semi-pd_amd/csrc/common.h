@@ -86,6 +86,80 @@ template <typename T> __device__ inline void store16(T* p, const Vec16<T>& v) {
   *reinterpret_cast<Vec16<T>*>(p) = v;
 }
 
+// ---- fp8 KV-cache storage (OCP e5m2 / e4m3fn, gfx950 conversion instructions) -------------------
+// The reference stores the cache as `cache_k.to(torch.float8_e5m2)` and the attention kernels load it
+// with `.to(q.dtype)` (mem_cache/memory_pool.py:205-209, 326-336): round-to-nearest-even on the way
+// in, exact on the way out, all arithmetic in the activation type.
+struct f8e5m2_t { uint8_t v; };
+struct f8e4m3_t { uint8_t v; };
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+template <typename F8> struct F8Cvt;
+template <> struct F8Cvt<f8e5m2_t> {
+  template <bool HI> __device__ static inline uint32_t pack2(float a, float b, uint32_t old) {
+    return (uint32_t)__builtin_amdgcn_cvt_pk_bf8_f32(a, b, (int)old, HI);
+  }
+  template <bool HI> __device__ static inline f32x2_t unpack2(uint32_t w) {
+    return __builtin_amdgcn_cvt_pk_f32_bf8((int)w, HI);
+  }
+};
+template <> struct F8Cvt<f8e4m3_t> {
+  template <bool HI> __device__ static inline uint32_t pack2(float a, float b, uint32_t old) {
+    return (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, (int)old, HI);
+  }
+  template <bool HI> __device__ static inline f32x2_t unpack2(uint32_t w) {
+    return __builtin_amdgcn_cvt_pk_f32_fp8((int)w, HI);
+  }
+};
+
+// 8 sixteen-bit elements (one 16-byte vector) <-> 8 fp8 bytes
+template <typename F8, typename T> __device__ inline uint2 to_f8x8(const Vec16<T>& a) {
+  static_assert(Elem<T>::kVec == 8, "fp8 KV storage needs 16-bit activations");
+  uint2 w;
+  w.x = F8Cvt<F8>::template pack2<false>(Elem<T>::to_f(a.e[0]), Elem<T>::to_f(a.e[1]), 0u);
+  w.x = F8Cvt<F8>::template pack2<true>(Elem<T>::to_f(a.e[2]), Elem<T>::to_f(a.e[3]), w.x);
+  w.y = F8Cvt<F8>::template pack2<false>(Elem<T>::to_f(a.e[4]), Elem<T>::to_f(a.e[5]), 0u);
+  w.y = F8Cvt<F8>::template pack2<true>(Elem<T>::to_f(a.e[6]), Elem<T>::to_f(a.e[7]), w.y);
+  return w;
+}
+template <typename F8, typename T> __device__ inline uint4 from_f8x8(uint2 w) {
+  static_assert(Elem<T>::kVec == 8, "fp8 KV storage needs 16-bit activations");
+  const f32x2_t a = F8Cvt<F8>::template unpack2<false>(w.x), b = F8Cvt<F8>::template unpack2<true>(w.x);
+  const f32x2_t c = F8Cvt<F8>::template unpack2<false>(w.y), d = F8Cvt<F8>::template unpack2<true>(w.y);
+  uint4 o;
+  o.x = (uint32_t)Elem<T>::from_f(a.x).v | ((uint32_t)Elem<T>::from_f(a.y).v << 16);
+  o.y = (uint32_t)Elem<T>::from_f(b.x).v | ((uint32_t)Elem<T>::from_f(b.y).v << 16);
+  o.z = (uint32_t)Elem<T>::from_f(c.x).v | ((uint32_t)Elem<T>::from_f(c.y).v << 16);
+  o.w = (uint32_t)Elem<T>::from_f(d.x).v | ((uint32_t)Elem<T>::from_f(d.y).v << 16);
+  return o;
+}
+
+template <typename F8, typename T> __device__ inline F8 to_f8(T x) {
+  F8 r;
+  r.v = (uint8_t)(F8Cvt<F8>::template pack2<false>(Elem<T>::to_f(x), 0.f, 0u) & 0xffu);
+  return r;
+}
+
+// KV-pool storage traits: KV == T (rows in the activation type) or an fp8 type
+template <typename T, typename KV> struct KVTraits {          // fp8 storage
+  static constexpr bool kF8 = true;
+  using Raw = uint2;                                           // 8 elements in flight
+  __device__ static inline Raw load8(const KV* p) { return *reinterpret_cast<const uint2*>(p); }
+  __device__ static inline Raw zero() { return make_uint2(0u, 0u); }
+  __device__ static inline uint4 expand(Raw r) { return from_f8x8<KV, T>(r); }
+  __device__ static inline void store8(KV* p, const Vec16<T>& a) { *reinterpret_cast<uint2*>(p) = to_f8x8<KV, T>(a); }
+  __device__ static inline void store1(KV* p, T x) { *p = to_f8<KV, T>(x); }
+};
+template <typename T> struct KVTraits<T, T> {                 // same type: byte-exact
+  static constexpr bool kF8 = false;
+  using Raw = uint4;
+  __device__ static inline Raw load8(const T* p) { return *reinterpret_cast<const uint4*>(p); }
+  __device__ static inline Raw zero() { return make_uint4(0u, 0u, 0u, 0u); }
+  __device__ static inline uint4 expand(Raw r) { return r; }
+  __device__ static inline void store8(T* p, const Vec16<T>& a) { *reinterpret_cast<Vec16<T>*>(p) = a; }
+  __device__ static inline void store1(T* p, T x) { *p = x; }
+};
+
 // ---- wave / block reductions ----------------------------------------------
 __device__ inline float wave_sum(float v) {
 #pragma unroll

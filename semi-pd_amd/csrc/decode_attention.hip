@@ -350,8 +350,8 @@ static int launch_stage1(T* out, const T* q, const T* k_buf, const T* v_buf, con
 }
 
 // defined in decode_attention_mfma.hip
-template <typename T>
-int launch_decode_mfma(T* out, const T* q, const T* k_buf, const T* v_buf, const int32_t* kv_indptr,
+template <typename T, typename KV>
+int launch_decode_mfma(T* out, const T* q, const KV* k_buf, const KV* v_buf, const int32_t* kv_indptr,
                        const int32_t* kv_indices, float* attn_logits, int64_t batch, int Hq, int Hkv, int D,
                        int64_t q_stride, int64_t o_stride, int64_t kbuf_stride, int64_t vbuf_stride,
                        int splits, float sm_scale, float logit_cap, hipStream_t st);
@@ -368,7 +368,8 @@ static int run_decode(void* out, const void* q, const void* k_buf, const void* v
                       int64_t batch, int num_q_heads, int num_kv_heads, int head_dim_k,
                       int head_dim_v, int64_t q_stride, int64_t o_stride, int64_t kbuf_stride,
                       int64_t vbuf_stride, int num_kv_splits, float sm_scale, float logit_cap,
-                      hipStream_t st) {
+                      int dtype, int kv_dtype, hipStream_t st) {
+  const bool kv_f8 = kv_dtype != dtype;
   const bool fast = head_dim_k == head_dim_v && head_dim_k % 8 == 0 && head_dim_k <= 256 &&
                     aligned16(q) && aligned16(k_buf) && aligned16(v_buf) && q_stride % 8 == 0 &&
                     kbuf_stride % 8 == 0 && vbuf_stride % 8 == 0;
@@ -380,13 +381,30 @@ static int run_decode(void* out, const void* q, const void* k_buf, const void* v
   const bool mla = head_dim_k == 576 && head_dim_v == 512 && num_kv_heads == 1 && k_buf == v_buf &&
                    kbuf_stride == vbuf_stride && kbuf_stride % 8 == 0 && q_stride % 8 == 0 && aligned16(q) &&
                    aligned16(k_buf) && o_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 7u) == 0;
-  if (mla) {
+  if (kv_f8) {
+    // fp8 pool rows (mem_cache/memory_pool.py:205-209): the GQA / MQA matrix-core kernel expands them
+    // on the way from HBM to the MFMA operands; the other kernels only read rows of the activation type
+    SEMIPD_CHECK_ARG(kv_dtype == SEMIPD_F8E5M2 || kv_dtype == SEMIPD_F8E4M3, SEMIPD_EDTYPE,
+                     "decode_attention: unsupported kv_dtype %d", kv_dtype);
+    SEMIPD_CHECK_ARG(mfma && !mla, SEMIPD_ESHAPE,
+                     "decode_attention: fp8 KV rows need the GQA / MQA kernel (group >= 2, head dim 64 / 96 / 128)");
+    if (kv_dtype == SEMIPD_F8E5M2)
+      rc = launch_decode_mfma<T, f8e5m2_t>((T*)out, (const T*)q, (const f8e5m2_t*)k_buf, (const f8e5m2_t*)v_buf,
+                                           kv_indptr, kv_indices, attn_logits, batch, num_q_heads, num_kv_heads,
+                                           head_dim_k, q_stride, o_stride, kbuf_stride, vbuf_stride, num_kv_splits,
+                                           sm_scale, logit_cap, st);
+    else
+      rc = launch_decode_mfma<T, f8e4m3_t>((T*)out, (const T*)q, (const f8e4m3_t*)k_buf, (const f8e4m3_t*)v_buf,
+                                           kv_indptr, kv_indices, attn_logits, batch, num_q_heads, num_kv_heads,
+                                           head_dim_k, q_stride, o_stride, kbuf_stride, vbuf_stride, num_kv_splits,
+                                           sm_scale, logit_cap, st);
+  } else if (mla) {
     // DeepSeek latent rows shared by all heads (mla_decode_attention.hip)
     rc = launch_mla_decode<T>((T*)out, (const T*)q, (const T*)k_buf, kv_indptr, kv_indices, attn_logits, batch,
                               num_q_heads, q_stride, o_stride, kbuf_stride, num_kv_splits, sm_scale, logit_cap, st);
   } else if (mfma) {
     // GQA / MQA: matrix-core kernel (decode_attention_mfma.hip)
-    rc = launch_decode_mfma<T>((T*)out, (const T*)q, (const T*)k_buf, (const T*)v_buf, kv_indptr, kv_indices,
+    rc = launch_decode_mfma<T, T>((T*)out, (const T*)q, (const T*)k_buf, (const T*)v_buf, kv_indptr, kv_indices,
                                attn_logits, batch, num_q_heads, num_kv_heads, head_dim_k, q_stride, o_stride,
                                kbuf_stride, vbuf_stride, num_kv_splits, sm_scale, logit_cap, st);
   } else if (fast) {
@@ -434,7 +452,7 @@ extern "C" int semipd_decode_attention(void* out, const void* q, const void* k_b
                                        int num_kv_heads, int head_dim_k, int head_dim_v,
                                        int64_t q_stride, int64_t o_stride, int64_t kbuf_stride,
                                        int64_t vbuf_stride, int num_kv_splits, float sm_scale,
-                                       float logit_cap, int dtype, void* stream) {
+                                       float logit_cap, int dtype, int kv_dtype, void* stream) {
   SEMIPD_CHECK_ARG(batch >= 0 && num_q_heads > 0 && num_kv_heads > 0 && head_dim_k > 0 &&
                        head_dim_v > 0 && num_kv_splits > 0,
                    SEMIPD_EINVAL, "decode_attention: bad sizes");
@@ -449,6 +467,6 @@ extern "C" int semipd_decode_attention(void* out, const void* q, const void* k_b
                    "decode_attention: null pointer");
   SEMIPD_CHECK_ARG(num_kv_splits == 1 || attn_logits, SEMIPD_EINVAL,
                    "decode_attention: attn_logits scratch required when num_kv_splits > 1");
-  SEMIPD_DISPATCH_HALF(dtype, T, return run_decode<T>(out, q, k_buf, v_buf, kv_indptr, kv_indices, attn_logits, batch, num_q_heads, num_kv_heads, head_dim_k, head_dim_v, q_stride, o_stride, kbuf_stride, vbuf_stride, num_kv_splits, sm_scale, logit_cap, as_stream(stream)));
+  SEMIPD_DISPATCH_HALF(dtype, T, return run_decode<T>(out, q, k_buf, v_buf, kv_indptr, kv_indices, attn_logits, batch, num_q_heads, num_kv_heads, head_dim_k, head_dim_v, q_stride, o_stride, kbuf_stride, vbuf_stride, num_kv_splits, sm_scale, logit_cap, dtype, kv_dtype, as_stream(stream)));
   return 0;
 }

@@ -43,19 +43,23 @@ template <> struct Mfma16<f16_t> {
   }
 };
 
-template <int D> struct KRegs {  // K fragments of one 32-token tile (A operands of S^T = K Q^T)
-  FragD k[2][D / 32];
+// K fragments of one 32-token tile (A operands of S^T = K Q^T) as they travel from HBM: 16 bytes per
+// lane for pool rows in the activation type, 8 bytes for fp8 rows (expanded right before the MFMA)
+template <int D, typename Raw> struct KRegs {
+  Raw k[2][D / 32];
 };
 
-template <typename T, int D>
+template <typename T, int D, typename KV>
 __global__ void __launch_bounds__(256, 2)
-decode_mfma_kernel(T* __restrict__ out, const T* __restrict__ q, const T* __restrict__ k_buf,
-                   const T* __restrict__ v_buf, const int32_t* __restrict__ kv_indptr,
+decode_mfma_kernel(T* __restrict__ out, const T* __restrict__ q, const KV* __restrict__ k_buf,
+                   const KV* __restrict__ v_buf, const int32_t* __restrict__ kv_indptr,
                    const int32_t* __restrict__ kv_indices, float* __restrict__ attn_logits,
                    int num_q_heads, int num_kv_heads, int group, int tiles_per_kv, int64_t q_stride,
                    int64_t o_stride, int64_t kbuf_stride, int64_t vbuf_stride, int num_kv_splits,
                    int64_t total_items, float sm_scale, float logit_cap) {
   constexpr int KS = D / 32, DT = D / 16, CPR = D / 8, NV = CPR / 2;
+  using KVT = KVTraits<T, KV>;
+  using Raw = typename KVT::Raw;
   constexpr int PAD = ((D / 2) % 32 == 16) ? 0 : 64;  // row stride == 16 or 48 dwords (mod 64):
   constexpr int RS = D * 2 + PAD;                     // conflict-free ds_read_b64_tr_b16
   __shared__ __attribute__((aligned(16))) uint8_t v_lds_all[4][32 * RS];
@@ -113,16 +117,16 @@ decode_mfma_kernel(T* __restrict__ out, const T* __restrict__ q, const T* __rest
     const int tok = s_begin + ti * 32 + (lane & 31);
     return (ti < n_tiles && tok < s_end) ? idx_base[tok] : 0;
   };
-  auto issue_k = [&](KRegs<D>& r, int32_t idx_reg) {
+  auto issue_k = [&](KRegs<D, Raw>& r, int32_t idx_reg) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int64_t row = (int64_t)__shfl(idx_reg, t * 16 + c16, 64) * kbuf_stride + k_head_off;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
-        r.k[t][ks].u = *reinterpret_cast<const uint4*>(k_buf + row + ks * 32);
+        r.k[t][ks] = KVT::load8(k_buf + row + ks * 32);
     }
   };
-  FragD vreg[NV];  // V rows of the NEXT tile, in flight while the current tile is computed
+  Raw vreg[NV];  // V rows of the NEXT tile, in flight while the current tile is computed
   auto issue_v = [&](int32_t idx_reg, int ti) {
     const int base_tok = s_begin + ti * 32;
 #pragma unroll
@@ -130,21 +134,21 @@ decode_mfma_kernel(T* __restrict__ out, const T* __restrict__ q, const T* __rest
       const int it = j * 64 + lane;
       const int tok = it / CPR, ch = it - tok * CPR;
       const int64_t row = (int64_t)__shfl(idx_reg, tok, 64) * vbuf_stride + v_head_off;
-      vreg[j].u = make_uint4(0, 0, 0, 0);
+      vreg[j] = KVT::zero();
       if (base_tok + tok < s_end)  // rows past the end must be zero: 0 * garbage could be NaN
-        vreg[j].u = *reinterpret_cast<const uint4*>(v_buf + row + ch * 8);
+        vreg[j] = KVT::load8(v_buf + row + ch * 8);
     }
   };
 
   // compute tile ti from K registers `r` and the V registers; as soon as the V registers are in
   // LDS they are re-used for the loads of tile ti+1 (idx_v = its indices)
-  auto compute = [&](KRegs<D>& r, int ti, int32_t idx_v) {
+  auto compute = [&](KRegs<D, Raw>& r, int ti, int32_t idx_v) {
     // ---- V rows -> LDS (row-major, this wave's private tile) ----
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
       const int it = j * 64 + lane;
       const int tok = it / CPR, ch = it - tok * CPR;
-      *reinterpret_cast<uint4*>(v_lds + tok * RS + ch * 16) = vreg[j].u;
+      *reinterpret_cast<uint4*>(v_lds + tok * RS + ch * 16) = KVT::expand(vreg[j]);
     }
     if (ti + 1 < n_tiles) issue_v(idx_v, ti + 1);
     // ---- S^T = K Q^T ----
@@ -153,7 +157,11 @@ decode_mfma_kernel(T* __restrict__ out, const T* __restrict__ q, const T* __rest
     for (int t = 0; t < 2; ++t) {
       s_acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) s_acc[t] = Mfma16<T>::mma(r.k[t][ks], qf[ks], s_acc[t]);
+      for (int ks = 0; ks < KS; ++ks) {
+        FragD kf;
+        kf.u = KVT::expand(r.k[t][ks]);
+        s_acc[t] = Mfma16<T>::mma(kf, qf[ks], s_acc[t]);
+      }
     }
     // ---- online softmax: lane = head c16, tokens t*16 + q4*4 + r ----
     const int base_tok = s_begin + ti * 32;
@@ -207,7 +215,7 @@ decode_mfma_kernel(T* __restrict__ out, const T* __restrict__ q, const T* __rest
     }
   };
 
-  KRegs<D> ra, rb;
+  KRegs<D, Raw> ra, rb;
   int32_t idx_cur = load_idx(0);
   issue_k(ra, idx_cur);
   issue_v(idx_cur, 0);
@@ -251,8 +259,8 @@ decode_mfma_kernel(T* __restrict__ out, const T* __restrict__ q, const T* __rest
   }
 }
 
-template <typename T>
-int launch_decode_mfma(T* out, const T* q, const T* k_buf, const T* v_buf, const int32_t* kv_indptr,
+template <typename T, typename KV>
+int launch_decode_mfma(T* out, const T* q, const KV* k_buf, const KV* v_buf, const int32_t* kv_indptr,
                        const int32_t* kv_indices, float* attn_logits, int64_t batch, int Hq, int Hkv, int D,
                        int64_t q_stride, int64_t o_stride, int64_t kbuf_stride, int64_t vbuf_stride,
                        int splits, float sm_scale, float logit_cap, hipStream_t st) {
@@ -261,7 +269,7 @@ int launch_decode_mfma(T* out, const T* q, const T* k_buf, const T* v_buf, const
   const int64_t total = batch * Hkv * tiles * splits;
   dim3 grid((unsigned)((total + 3) / 4)), block(256);
 #define DM(DD)                                                                                      \
-  hipLaunchKernelGGL((decode_mfma_kernel<T, DD>), grid, block, 0, st, out, q, k_buf, v_buf, kv_indptr, \
+  hipLaunchKernelGGL((decode_mfma_kernel<T, DD, KV>), grid, block, 0, st, out, q, k_buf, v_buf, kv_indptr, \
                      kv_indices, attn_logits, Hq, Hkv, group, tiles, q_stride, o_stride, kbuf_stride,  \
                      vbuf_stride, splits, total, sm_scale, logit_cap)
   switch (D) {
@@ -275,11 +283,16 @@ int launch_decode_mfma(T* out, const T* q, const T* k_buf, const T* v_buf, const
   return launch_status("decode_mfma");
 }
 
-template int launch_decode_mfma<bf16_t>(bf16_t*, const bf16_t*, const bf16_t*, const bf16_t*, const int32_t*,
-                                        const int32_t*, float*, int64_t, int, int, int, int64_t, int64_t,
-                                        int64_t, int64_t, int, float, float, hipStream_t);
-template int launch_decode_mfma<f16_t>(f16_t*, const f16_t*, const f16_t*, const f16_t*, const int32_t*,
-                                       const int32_t*, float*, int64_t, int, int, int, int64_t, int64_t, int64_t,
-                                       int64_t, int, float, float, hipStream_t);
+#define DM_INST(T, KV)                                                                                  \
+  template int launch_decode_mfma<T, KV>(T*, const T*, const KV*, const KV*, const int32_t*, const int32_t*, \
+                                         float*, int64_t, int, int, int, int64_t, int64_t, int64_t, int64_t,   \
+                                         int, float, float, hipStream_t);
+DM_INST(bf16_t, bf16_t)
+DM_INST(f16_t, f16_t)
+DM_INST(bf16_t, f8e5m2_t)
+DM_INST(bf16_t, f8e4m3_t)
+DM_INST(f16_t, f8e5m2_t)
+DM_INST(f16_t, f8e4m3_t)
+#undef DM_INST
 
 }  // namespace semipd

@@ -172,8 +172,8 @@ __global__ void silu_and_mul_scalar_kernel(T* __restrict__ out, const T* __restr
 // Work item = one 16-byte vector of the first rotary half (neox) or of
 // interleaved pairs (GPT-J) of one (token, head).
 // ---------------------------------------------------------------------------
-template <typename T, bool INTERLEAVE>
-__device__ inline void rope_item(T* __restrict__ head_ptr, T* __restrict__ mirror_ptr,
+template <typename T, bool INTERLEAVE, typename KV = T>
+__device__ inline void rope_item(T* __restrict__ head_ptr, KV* __restrict__ mirror_ptr,
                                  const float* __restrict__ cs, int rot_dim, int item) {
   // head_ptr: start of this head's row in place; mirror_ptr: optional second
   // destination (KV pool row) or nullptr.
@@ -194,8 +194,8 @@ __device__ inline void rope_item(T* __restrict__ head_ptr, T* __restrict__ mirro
     store16(head_ptr + i0, oa);
     store16(head_ptr + half + i0, ob);
     if (mirror_ptr) {
-      store16(mirror_ptr + i0, oa);
-      store16(mirror_ptr + half + i0, ob);
+      KVTraits<T, KV>::store8(mirror_ptr + i0, oa);
+      KVTraits<T, KV>::store8(mirror_ptr + half + i0, ob);
     }
   } else {
     const int e0 = item * V;  // element base; pairs (e0+2j, e0+2j+1), pair index e0/2+j
@@ -210,14 +210,14 @@ __device__ inline void rope_item(T* __restrict__ head_ptr, T* __restrict__ mirro
       o.e[2 * j + 1] = Elem<T>::from_f(x2 * c + x1 * s);
     }
     store16(head_ptr + e0, o);
-    if (mirror_ptr) store16(mirror_ptr + e0, o);
+    if (mirror_ptr) KVTraits<T, KV>::store8(mirror_ptr + e0, o);
   }
 }
 
 // one workgroup per token; handles q rotate, k rotate(+pool), k pass-through(+pool), v(+pool)
-template <typename T, bool INTERLEAVE, bool STORE>
+template <typename T, bool INTERLEAVE, bool STORE, typename KV = T>
 __global__ void rope_vec_kernel(T* __restrict__ q, T* __restrict__ k, const T* __restrict__ v,
-                                T* __restrict__ k_buf, T* __restrict__ v_buf,
+                                KV* __restrict__ k_buf, KV* __restrict__ v_buf,
                                 const int64_t* __restrict__ loc, const float* __restrict__ cache,
                                 const int64_t* __restrict__ positions, int Hq, int Hk, int head,
                                 int vhead, int rot_dim, int64_t q_stride, int64_t k_stride,
@@ -236,12 +236,12 @@ __global__ void rope_vec_kernel(T* __restrict__ q, T* __restrict__ k, const T* _
   for (int it = threadIdx.x; it < q_items + k_items; it += blockDim.x) {
     if (it < q_items) {
       const int h = it / items_per_head, i = it - h * items_per_head;
-      rope_item<T, INTERLEAVE>(q_row + h * head, nullptr, cs, rot_dim, i);
+      rope_item<T, INTERLEAVE, KV>(q_row + h * head, (KV*)nullptr, cs, rot_dim, i);
     } else {
       const int kk = it - q_items;
       const int h = kk / items_per_head, i = kk - h * items_per_head;
-      T* mirror = STORE ? k_buf + dst * kbuf_stride + h * head : nullptr;
-      rope_item<T, INTERLEAVE>(k_row + h * head, mirror, cs, rot_dim, i);
+      KV* mirror = STORE ? k_buf + dst * kbuf_stride + h * head : nullptr;
+      rope_item<T, INTERLEAVE, KV>(k_row + h * head, mirror, cs, rot_dim, i);
     }
   }
   if (STORE) {
@@ -250,21 +250,21 @@ __global__ void rope_vec_kernel(T* __restrict__ q, T* __restrict__ k, const T* _
     for (int it = threadIdx.x; it < Hk * pass_vec; it += blockDim.x) {
       const int h = it / pass_vec, i = it - h * pass_vec;
       Vec16<T> a = load16(k_row + h * head + rot_dim + i * V);
-      store16(k_buf + dst * kbuf_stride + h * head + rot_dim + i * V, a);
+      KVTraits<T, KV>::store8(k_buf + dst * kbuf_stride + h * head + rot_dim + i * V, a);
     }
     const int v_vec = Hk * vhead / V;
     const T* v_row = v + t * v_stride;
     for (int it = threadIdx.x; it < v_vec; it += blockDim.x) {
       Vec16<T> a = load16(v_row + it * V);
-      store16(v_buf + dst * vbuf_stride + it * V, a);
+      KVTraits<T, KV>::store8(v_buf + dst * vbuf_stride + it * V, a);
     }
   }
 }
 
 // scalar fallback: any rot_dim (even), any alignment
-template <typename T, bool STORE>
+template <typename T, bool STORE, typename KV = T>
 __global__ void rope_scalar_kernel(T* __restrict__ q, T* __restrict__ k, const T* __restrict__ v,
-                                   T* __restrict__ k_buf, T* __restrict__ v_buf,
+                                   KV* __restrict__ k_buf, KV* __restrict__ v_buf,
                                    const int64_t* __restrict__ loc, const float* __restrict__ cache,
                                    const int64_t* __restrict__ positions, int Hq, int Hk, int head,
                                    int vhead, int rot_dim, int64_t q_stride, int64_t k_stride,
@@ -287,19 +287,20 @@ __global__ void rope_scalar_kernel(T* __restrict__ q, T* __restrict__ k, const T
     row[i1] = o1;
     row[i2] = o2;
     if (STORE && h >= Hq) {
-      T* m = k_buf + dst * kbuf_stride + (h - Hq) * head;
-      m[i1] = o1;
-      m[i2] = o2;
+      KV* m = k_buf + dst * kbuf_stride + (h - Hq) * head;
+      KVTraits<T, KV>::store1(m + i1, o1);
+      KVTraits<T, KV>::store1(m + i2, o2);
     }
   }
   if (STORE) {
     const int pass = head - rot_dim;
     for (int it = threadIdx.x; it < Hk * pass; it += blockDim.x) {
       const int h = it / pass, i = it - h * pass;
-      k_buf[dst * kbuf_stride + h * head + rot_dim + i] = k[t * k_stride + h * head + rot_dim + i];
+      KVTraits<T, KV>::store1(k_buf + dst * kbuf_stride + h * head + rot_dim + i,
+                              k[t * k_stride + h * head + rot_dim + i]);
     }
     for (int it = threadIdx.x; it < Hk * vhead; it += blockDim.x)
-      v_buf[dst * vbuf_stride + it] = v[t * v_stride + it];
+      KVTraits<T, KV>::store1(v_buf + dst * vbuf_stride + it, v[t * v_stride + it]);
   }
 }
 
@@ -319,7 +320,7 @@ __global__ void rope_strided_kernel(T* __restrict__ q, T* __restrict__ k, const 
     for (int it = threadIdx.x; it < (Hq + Hk) * iph; it += blockDim.x) {
       const int h = it / iph, i = it - h * iph;
       T* hp = h < Hq ? q + t * q_ts + h * q_hs : k + t * k_ts + (h - Hq) * k_hs;
-      rope_item<T, INTERLEAVE>(hp, nullptr, cs, rot_dim, i);
+      rope_item<T, INTERLEAVE, T>(hp, (T*)nullptr, cs, rot_dim, i);
     }
   } else {
     for (int it = threadIdx.x; it < (Hq + Hk) * half; it += blockDim.x) {
@@ -352,8 +353,8 @@ static int launch_rope_strided(T* q, T* k, const float* cache, const int64_t* po
   return launch_status("rope_strided");
 }
 
-template <typename T, bool STORE>
-static int launch_rope(T* q, T* k, const T* v, T* k_buf, T* v_buf, const int64_t* loc,
+template <typename T, bool STORE, typename KV = T>
+static int launch_rope(T* q, T* k, const T* v, KV* k_buf, KV* v_buf, const int64_t* loc,
                        const float* cache, const int64_t* positions, int64_t num_tokens, int Hq,
                        int Hk, int head, int vhead, int rot_dim, int64_t q_stride, int64_t k_stride,
                        int64_t v_stride, int64_t kbuf_stride, int64_t vbuf_stride, int interleave,
@@ -362,22 +363,22 @@ static int launch_rope(T* q, T* k, const T* v, T* k_buf, T* v_buf, const int64_t
   if (num_tokens == 0) return 0;
   bool vec_ok = aligned16(q) && aligned16(k) && (q_stride % V == 0) && (k_stride % V == 0) &&
                 (head % V == 0) && (interleave ? rot_dim % V == 0 : (rot_dim / 2) % V == 0);
-  if (STORE)
+  if (STORE)  // pool rows: 8 elements per vector store = 16 bytes, or 8 bytes for fp8 rows
     vec_ok = vec_ok && aligned16(v) && aligned16(k_buf) && aligned16(v_buf) && (v_stride % V == 0) &&
-             (kbuf_stride % V == 0) && (vbuf_stride % V == 0) && ((head - rot_dim) % V == 0) &&
-             (vhead % V == 0);
+             (kbuf_stride % 16 == 0) && (vbuf_stride % 16 == 0) && ((head - rot_dim) % V == 0) &&
+             (vhead % V == 0) && (KVTraits<T, KV>::kF8 ? V == 8 : true);
   dim3 grid((unsigned)num_tokens), block(256);
   if (vec_ok) {
     if (interleave)
-      hipLaunchKernelGGL((rope_vec_kernel<T, true, STORE>), grid, block, 0, st, q, k, v, k_buf, v_buf,
+      hipLaunchKernelGGL((rope_vec_kernel<T, true, STORE, KV>), grid, block, 0, st, q, k, v, k_buf, v_buf,
                          loc, cache, positions, Hq, Hk, head, vhead, rot_dim, q_stride, k_stride,
                          v_stride, kbuf_stride, vbuf_stride);
     else
-      hipLaunchKernelGGL((rope_vec_kernel<T, false, STORE>), grid, block, 0, st, q, k, v, k_buf,
+      hipLaunchKernelGGL((rope_vec_kernel<T, false, STORE, KV>), grid, block, 0, st, q, k, v, k_buf,
                          v_buf, loc, cache, positions, Hq, Hk, head, vhead, rot_dim, q_stride,
                          k_stride, v_stride, kbuf_stride, vbuf_stride);
   } else {
-    hipLaunchKernelGGL((rope_scalar_kernel<T, STORE>), grid, block, 0, st, q, k, v, k_buf, v_buf, loc,
+    hipLaunchKernelGGL((rope_scalar_kernel<T, STORE, KV>), grid, block, 0, st, q, k, v, k_buf, v_buf, loc,
                        cache, positions, Hq, Hk, head, vhead, rot_dim, q_stride, k_stride, v_stride,
                        kbuf_stride, vbuf_stride, interleave);
   }
@@ -558,6 +559,73 @@ __global__ void moe_sum_kernel(T* __restrict__ out, const T* __restrict__ in, in
   }
 }
 
+// ---- KV rows of the activation type -> fp8 pool rows (scatter by loc) ----------------------------
+template <typename T, typename KV>
+__global__ void kv_store_cvt_kernel(KV* __restrict__ buf, const T* __restrict__ src, const int64_t* __restrict__ loc,
+                                    int64_t num_tokens, int64_t row_elems, int64_t buf_stride, int64_t src_stride,
+                                    int vec) {
+  const int64_t per_row = vec ? row_elems / 8 : row_elems;
+  const int64_t total = num_tokens * per_row;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = i / per_row, c = i - t * per_row;
+    const int64_t dst = loc[t];
+    if (vec) KVTraits<T, KV>::store8(buf + dst * buf_stride + c * 8, load16(src + t * src_stride + c * 8));
+    else KVTraits<T, KV>::store1(buf + dst * buf_stride + c, src[t * src_stride + c]);
+  }
+}
+
+template <typename T, typename KV>
+static int launch_kv_store_cvt(void* buf, const void* src, const int64_t* loc, int64_t num_tokens, int64_t row_elems,
+                               int64_t buf_stride, int64_t src_stride, hipStream_t st) {
+  const int vec = (row_elems % 8 == 0 && buf_stride % 8 == 0 && src_stride % 8 == 0 && aligned16(src) &&
+                   (reinterpret_cast<uintptr_t>(buf) & 7u) == 0) ? 1 : 0;
+  const int64_t total = num_tokens * (vec ? row_elems / 8 : row_elems);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL((kv_store_cvt_kernel<T, KV>), dim3(blocks), dim3(256), 0, st, (KV*)buf, (const T*)src, loc,
+                     num_tokens, row_elems, buf_stride, src_stride, vec);
+  return launch_status("kv_store_cvt");
+}
+
+// fp8 pool rows are only defined for 16-bit activations
+template <typename T>
+static int kv_store_cvt_dispatch(void* buf, const void* src, const int64_t* loc, int64_t num_tokens,
+                                 int64_t row_elems, int64_t buf_stride, int64_t src_stride, int kv_dtype,
+                                 hipStream_t st) {
+  if constexpr (Elem<T>::kVec == 8) {
+    if (kv_dtype == SEMIPD_F8E5M2)
+      return launch_kv_store_cvt<T, f8e5m2_t>(buf, src, loc, num_tokens, row_elems, buf_stride, src_stride, st);
+    if (kv_dtype == SEMIPD_F8E4M3)
+      return launch_kv_store_cvt<T, f8e4m3_t>(buf, src, loc, num_tokens, row_elems, buf_stride, src_stride, st);
+  }
+  set_error("kv_store_cvt: unsupported kv_dtype %d for this activation type", kv_dtype);
+  return SEMIPD_EDTYPE;
+}
+
+template <typename T>
+static int rope_kv_store_dispatch(void* q, void* k, const void* v, void* k_buf, void* v_buf, const int64_t* loc,
+                                  const float* cache, const int64_t* positions, int64_t num_tokens, int Hq, int Hk,
+                                  int head, int vhead, int rot_dim, int64_t q_stride, int64_t k_stride,
+                                  int64_t v_stride, int64_t kbuf_stride, int64_t vbuf_stride, int interleave,
+                                  int dtype, int kv_dtype, hipStream_t st) {
+  if (kv_dtype == dtype)
+    return launch_rope<T, true, T>((T*)q, (T*)k, (const T*)v, (T*)k_buf, (T*)v_buf, loc, cache, positions, num_tokens,
+                                   Hq, Hk, head, vhead, rot_dim, q_stride, k_stride, v_stride, kbuf_stride,
+                                   vbuf_stride, interleave, st);
+  if constexpr (Elem<T>::kVec == 8) {
+    if (kv_dtype == SEMIPD_F8E5M2)
+      return launch_rope<T, true, f8e5m2_t>((T*)q, (T*)k, (const T*)v, (f8e5m2_t*)k_buf, (f8e5m2_t*)v_buf, loc, cache,
+                                            positions, num_tokens, Hq, Hk, head, vhead, rot_dim, q_stride, k_stride,
+                                            v_stride, kbuf_stride, vbuf_stride, interleave, st);
+    if (kv_dtype == SEMIPD_F8E4M3)
+      return launch_rope<T, true, f8e4m3_t>((T*)q, (T*)k, (const T*)v, (f8e4m3_t*)k_buf, (f8e4m3_t*)v_buf, loc, cache,
+                                            positions, num_tokens, Hq, Hk, head, vhead, rot_dim, q_stride, k_stride,
+                                            v_stride, kbuf_stride, vbuf_stride, interleave, st);
+  }
+  set_error("rope_kv_store: unsupported kv_dtype %d for activation dtype %d", kv_dtype, dtype);
+  return SEMIPD_EDTYPE;
+}
+
 }  // namespace semipd
 
 using namespace semipd;
@@ -621,7 +689,7 @@ int semipd_rope_inplace(void* q, void* k, const float* cos_sin_cache, const int6
                    SEMIPD_EINVAL, "rope: bad sizes");
   if (num_tokens == 0) return 0;
   SEMIPD_CHECK_ARG(q && k && cos_sin_cache && positions, SEMIPD_EINVAL, "rope: null pointer");
-  SEMIPD_DISPATCH_DTYPE(dtype, T, return (launch_rope<T, false>((T*)q, (T*)k, nullptr, nullptr, nullptr, nullptr, cos_sin_cache, positions, num_tokens, num_q_heads, num_k_heads, head_size, 0, rot_dim, q_stride, k_stride, 0, 0, 0, interleave, as_stream(stream))));
+  SEMIPD_DISPATCH_DTYPE(dtype, T, return (launch_rope<T, false, T>((T*)q, (T*)k, (const T*)nullptr, (T*)nullptr, (T*)nullptr, nullptr, cos_sin_cache, positions, num_tokens, num_q_heads, num_k_heads, head_size, 0, rot_dim, q_stride, k_stride, 0, 0, 0, interleave, as_stream(stream))));
   return 0;
 }
 
@@ -642,14 +710,23 @@ int semipd_rope_kv_store(void* q, void* k, const void* v, void* k_buf, void* v_b
                          int64_t num_tokens, int num_q_heads, int num_k_heads, int head_size,
                          int v_head_size, int rot_dim, int64_t q_stride, int64_t k_stride,
                          int64_t v_stride, int64_t kbuf_stride, int64_t vbuf_stride, int interleave,
-                         int dtype, void* stream) {
+                         int dtype, int kv_dtype, void* stream) {
   SEMIPD_CHECK_ARG(num_tokens >= 0 && head_size > 0 && rot_dim > 0 && rot_dim <= head_size &&
                        (rot_dim % 2) == 0 && v_head_size > 0,
                    SEMIPD_EINVAL, "rope_kv_store: bad sizes");
   if (num_tokens == 0) return 0;
   SEMIPD_CHECK_ARG(q && k && v && k_buf && v_buf && loc && cos_sin_cache && positions, SEMIPD_EINVAL,
                    "rope_kv_store: null pointer");
-  SEMIPD_DISPATCH_DTYPE(dtype, T, return (launch_rope<T, true>((T*)q, (T*)k, (const T*)v, (T*)k_buf, (T*)v_buf, loc, cos_sin_cache, positions, num_tokens, num_q_heads, num_k_heads, head_size, v_head_size, rot_dim, q_stride, k_stride, v_stride, kbuf_stride, vbuf_stride, interleave, as_stream(stream))));
+  SEMIPD_DISPATCH_DTYPE(dtype, T, return (rope_kv_store_dispatch<T>(q, k, v, k_buf, v_buf, loc, cos_sin_cache, positions, num_tokens, num_q_heads, num_k_heads, head_size, v_head_size, rot_dim, q_stride, k_stride, v_stride, kbuf_stride, vbuf_stride, interleave, dtype, kv_dtype, as_stream(stream))));
+  return 0;
+}
+
+int semipd_kv_store_cvt(void* buf, const void* src, const int64_t* loc, int64_t num_tokens, int64_t row_elems,
+                        int64_t buf_stride, int64_t src_stride, int dtype, int kv_dtype, void* stream) {
+  SEMIPD_CHECK_ARG(num_tokens >= 0 && row_elems >= 0, SEMIPD_EINVAL, "kv_store_cvt: bad sizes");
+  if (num_tokens == 0 || row_elems == 0) return 0;
+  SEMIPD_CHECK_ARG(buf && src && loc, SEMIPD_EINVAL, "kv_store_cvt: null pointer");
+  SEMIPD_DISPATCH_DTYPE(dtype, T, return (kv_store_cvt_dispatch<T>(buf, src, loc, num_tokens, row_elems, buf_stride, src_stride, kv_dtype, as_stream(stream))));
   return 0;
 }
 

@@ -71,11 +71,11 @@ __device__ inline Frag16 load_row8(const T* p, int valid) {
 
 // Two workgroups per CU (2 waves / SIMD, <= 256 VGPRs) wherever that fits without spilling: the second
 // wave hides the LDS / softmax latency of the first.
-template <typename T, int DKP, int DVP, bool VEC, bool CAP>
+template <typename T, int DKP, int DVP, bool VEC, bool CAP, typename KV = T>
 __global__ void __launch_bounds__(256, (VEC && !CAP && DKP <= 128) ? 2 : 1)
 extend_attn_kernel(T* __restrict__ out, const T* __restrict__ q_ext, const T* __restrict__ k_ext,
-                   const T* __restrict__ v_ext, const T* __restrict__ k_buf,
-                   const T* __restrict__ v_buf, const int32_t* __restrict__ qo_indptr,
+                   const T* __restrict__ v_ext, const KV* __restrict__ k_buf,
+                   const KV* __restrict__ v_buf, const int32_t* __restrict__ qo_indptr,
                    const int32_t* __restrict__ kv_indptr, const int32_t* __restrict__ kv_indices,
                    int group, int Dk, int Dv, int64_t q_stride, int64_t k_stride, int64_t v_stride,
                    int64_t o_stride, int64_t kbuf_stride, int64_t vbuf_stride, float sm_scale,
@@ -132,8 +132,11 @@ extend_attn_kernel(T* __restrict__ out, const T* __restrict__ q_ext, const T* __
   constexpr int CHK = DKP / 8, CHV = DVP / 8;
   constexpr int NKI = (BN * CHK + 255) / 256, NVI = (BN * CHV + 255) / 256;
   Frag16 kreg[NKI], vreg[NVI];
-  const T* k_head = k_buf + (int64_t)hk * Dk;
-  const T* v_head = v_buf + (int64_t)hk * Dv;
+  // paged prefix rows: activation type, or fp8 (8 bytes per 8 elements in flight, expanded when the
+  // tile is written to LDS so that the loads stay in flight during the MFMAs)
+  constexpr bool F8 = KVTraits<T, KV>::kF8;
+  const KV* k_head = k_buf + (int64_t)hk * Dk;
+  const KV* v_head = v_buf + (int64_t)hk * Dv;
   const T* ke_head = k_ext + (int64_t)q_start * k_stride + (int64_t)hk * Dk;
   const T* ve_head = v_ext + (int64_t)q_start * v_stride + (int64_t)hk * Dv;
   const int32_t* idx_base = kv_indices + kv_start;
@@ -165,16 +168,30 @@ extend_attn_kernel(T* __restrict__ out, const T* __restrict__ q_ext, const T* __
         const int item = tid + i * 256;
         const int r = item / CHK, c = item - r * CHK;
         kreg[i].u = make_uint4(0, 0, 0, 0);
-        if ((BN * CHK % 256 == 0 || item < BN * CHK) && n0 + r < pre_len)
-          kreg[i] = load_row8<T, VEC>(k_head + (int64_t)idxk[i] * kbuf_stride + c * 8, min(8, Dk - c * 8));
+        if ((BN * CHK % 256 == 0 || item < BN * CHK) && n0 + r < pre_len) {
+          if constexpr (F8) {
+            const uint2 w = *reinterpret_cast<const uint2*>(k_head + (int64_t)idxk[i] * kbuf_stride + c * 8);
+            kreg[i].u = make_uint4(w.x, w.y, 0u, 0u);
+          } else {
+            kreg[i] = load_row8<T, VEC>(reinterpret_cast<const T*>(k_head) + (int64_t)idxk[i] * kbuf_stride + c * 8,
+                                        min(8, Dk - c * 8));
+          }
+        }
       }
 #pragma unroll
       for (int i = 0; i < NVI; ++i) {
         const int item = tid + i * 256;
         const int r = item / CHV, c = item - r * CHV;
         vreg[i].u = make_uint4(0, 0, 0, 0);  // rows past the end stay zero: 0 * garbage could be NaN
-        if ((BN * CHV % 256 == 0 || item < BN * CHV) && n0 + r < pre_len)
-          vreg[i] = load_row8<T, VEC>(v_head + (int64_t)idxv[i] * vbuf_stride + c * 8, min(8, Dv - c * 8));
+        if ((BN * CHV % 256 == 0 || item < BN * CHV) && n0 + r < pre_len) {
+          if constexpr (F8) {
+            const uint2 w = *reinterpret_cast<const uint2*>(v_head + (int64_t)idxv[i] * vbuf_stride + c * 8);
+            vreg[i].u = make_uint4(w.x, w.y, 0u, 0u);
+          } else {
+            vreg[i] = load_row8<T, VEC>(reinterpret_cast<const T*>(v_head) + (int64_t)idxv[i] * vbuf_stride + c * 8,
+                                        min(8, Dv - c * 8));
+          }
+        }
       }
     } else {  // the new tokens: contiguous rows
       const int n0 = (it - n_pre_tiles) * BN;
@@ -216,15 +233,25 @@ extend_attn_kernel(T* __restrict__ out, const T* __restrict__ q_ext, const T* __
     for (int i = 0; i < NKI; ++i) {
       const int item = tid + i * 256;
       const int r = item / CHK, c = item - r * CHK;
-      if (BN * CHK % 256 == 0 || item < BN * CHK)
-        *reinterpret_cast<uint4*>(&k_lds[r * KS + c * 8]) = kreg[i].u;
+      if (BN * CHK % 256 == 0 || item < BN * CHK) {
+        uint4 u = kreg[i].u;
+        if constexpr (F8) {
+          if (pre) u = from_f8x8<KV, T>(make_uint2(u.x, u.y));
+        }
+        *reinterpret_cast<uint4*>(&k_lds[r * KS + c * 8]) = u;
+      }
     }
 #pragma unroll
     for (int i = 0; i < NVI; ++i) {
       const int item = tid + i * 256;
       const int r = item / CHV, c = item - r * CHV;
-      if (BN * CHV % 256 == 0 || item < BN * CHV)
-        *reinterpret_cast<uint4*>(&v_lds[r * VS + c * 8]) = vreg[i].u;
+      if (BN * CHV % 256 == 0 || item < BN * CHV) {
+        uint4 u = vreg[i].u;
+        if constexpr (F8) {
+          if (pre) u = from_f8x8<KV, T>(make_uint2(u.x, u.y));
+        }
+        *reinterpret_cast<uint4*>(&v_lds[r * VS + c * 8]) = u;
+      }
     }
     __syncthreads();
     if (it + 1 < n_tiles) fetch(it + 1);  // in flight during the MFMAs below
@@ -415,7 +442,7 @@ extend_attn_generic_kernel(T* __restrict__ out, const T* __restrict__ q_ext,
   }
 }
 
-template <typename T, bool VEC, bool CAP>
+template <typename T, bool VEC, bool CAP, typename KV = T>
 static int launch_extend_variant(void* out, const void* q, const void* k, const void* v, const void* k_buf,
                                  const void* v_buf, const int32_t* qo_indptr, const int32_t* kv_indptr,
                                  const int32_t* kv_indices, int64_t batch, int Hq, int group, int Dk, int Dv,
@@ -427,16 +454,18 @@ static int launch_extend_variant(void* out, const void* q, const void* k, const 
   // (last, causal) query tile starts first and the short tiles fill the tail
   dim3 grid((unsigned)Hq, (unsigned)((max_len_extend + 127) / 128), (unsigned)batch), block(256);
 #define EXT(DKP, DVP)                                                                              \
-  hipLaunchKernelGGL((extend_attn_kernel<T, DKP, DVP, VEC, CAP>), grid, block, 0, st, (T*)out,     \
-                     (const T*)q, (const T*)k, (const T*)v, (const T*)k_buf, (const T*)v_buf,       \
+  hipLaunchKernelGGL((extend_attn_kernel<T, DKP, DVP, VEC, CAP, KV>), grid, block, 0, st, (T*)out, \
+                     (const T*)q, (const T*)k, (const T*)v, (const KV*)k_buf, (const KV*)v_buf,     \
                      qo_indptr, kv_indptr, kv_indices, group, Dk, Dv, q_stride, k_stride, v_stride, \
                      o_stride, kbuf_stride, vbuf_stride, sm_scale, logit_cap)
   if (dkp <= 16 && dvp <= 32) EXT(16, 32);
   else if (dkp <= 64 && dvp <= 64) EXT(64, 64);
   else if (dkp <= 96 && dvp <= 96) EXT(96, 96);
   else if (dkp <= 128 && dvp <= 128) EXT(128, 128);
-  else if (dkp <= 192 && dvp <= 128) EXT(192, 128);
-  else return 1;  // no MFMA instantiation
+  else if (dkp <= 192 && dvp <= 128) {
+    if constexpr (KVTraits<T, KV>::kF8) return 1;  // MLA prefill keeps its rows in the activation type
+    else EXT(192, 128);
+  } else return 1;  // no MFMA instantiation
 #undef EXT
   return 0;
 }
@@ -447,12 +476,32 @@ static int run_extend(void* out, const void* q, const void* k, const void* v, co
                       const int32_t* kv_indices, int64_t batch, int Hq, int Hkv, int Dk, int Dv,
                       int64_t q_stride, int64_t k_stride, int64_t v_stride, int64_t o_stride,
                       int64_t kbuf_stride, int64_t vbuf_stride, int max_len_extend, float sm_scale,
-                      float logit_cap, hipStream_t st) {
+                      float logit_cap, int dtype, int kv_dtype, hipStream_t st) {
   const int group = Hq / Hkv;
   const bool vec_ok = Dk % 8 == 0 && Dv % 8 == 0 && q_stride % 8 == 0 && k_stride % 8 == 0 &&
                       v_stride % 8 == 0 && o_stride % 4 == 0 && kbuf_stride % 8 == 0 &&
                       vbuf_stride % 8 == 0 && aligned16(q) && aligned16(k) && aligned16(v) &&
                       aligned16(k_buf) && aligned16(v_buf) && (reinterpret_cast<uintptr_t>(out) & 7u) == 0;
+  if (kv_dtype != dtype) {
+    // fp8 prefix rows (mem_cache/memory_pool.py:205-209): vectorised, cap-free instantiations only
+    SEMIPD_CHECK_ARG(kv_dtype == SEMIPD_F8E5M2 || kv_dtype == SEMIPD_F8E4M3, SEMIPD_EDTYPE,
+                     "extend_attention: unsupported kv_dtype %d", kv_dtype);
+    SEMIPD_CHECK_ARG(vec_ok && !(logit_cap > 0.f) && Dk <= 128 && Dv <= 128, SEMIPD_ESHAPE,
+                     "extend_attention: fp8 KV rows need 8-element aligned heads up to 128 and no logit cap");
+    int miss8;
+    if (kv_dtype == SEMIPD_F8E5M2)
+      miss8 = launch_extend_variant<T, true, false, f8e5m2_t>(out, q, k, v, k_buf, v_buf, qo_indptr, kv_indptr,
+                                                              kv_indices, batch, Hq, group, Dk, Dv, q_stride, k_stride,
+                                                              v_stride, o_stride, kbuf_stride, vbuf_stride,
+                                                              max_len_extend, sm_scale, logit_cap, st);
+    else
+      miss8 = launch_extend_variant<T, true, false, f8e4m3_t>(out, q, k, v, k_buf, v_buf, qo_indptr, kv_indptr,
+                                                              kv_indices, batch, Hq, group, Dk, Dv, q_stride, k_stride,
+                                                              v_stride, o_stride, kbuf_stride, vbuf_stride,
+                                                              max_len_extend, sm_scale, logit_cap, st);
+    SEMIPD_CHECK_ARG(!miss8, SEMIPD_ESHAPE, "extend_attention: no fp8 instantiation for these head sizes");
+    return launch_status("extend_attention");
+  }
   int miss;
 #define VARIANT(V, C)                                                                                 \
   launch_extend_variant<T, V, C>(out, q, k, v, k_buf, v_buf, qo_indptr, kv_indptr, kv_indices, batch, Hq, \
@@ -484,7 +533,7 @@ extern "C" int semipd_extend_attention(void* out, const void* q_extend, const vo
                                        int64_t q_stride, int64_t k_stride, int64_t v_stride,
                                        int64_t o_stride, int64_t kbuf_stride, int64_t vbuf_stride,
                                        int max_len_extend, float sm_scale, float logit_cap, int dtype,
-                                       void* stream) {
+                                       int kv_dtype, void* stream) {
   SEMIPD_CHECK_ARG(batch >= 0 && num_q_heads > 0 && num_kv_heads > 0 && head_dim_k > 0 &&
                        head_dim_v > 0 && max_len_extend >= 0,
                    SEMIPD_EINVAL, "extend_attention: bad sizes");
@@ -497,6 +546,6 @@ extern "C" int semipd_extend_attention(void* out, const void* q_extend, const vo
   if (batch == 0 || max_len_extend == 0) return 0;
   SEMIPD_CHECK_ARG(out && q_extend && k_extend && v_extend && qo_indptr && kv_indptr, SEMIPD_EINVAL,
                    "extend_attention: null pointer");
-  SEMIPD_DISPATCH_HALF(dtype, T, return run_extend<T>(out, q_extend, k_extend, v_extend, k_buf, v_buf, qo_indptr, kv_indptr, kv_indices, batch, num_q_heads, num_kv_heads, head_dim_k, head_dim_v, q_stride, k_stride, v_stride, o_stride, kbuf_stride, vbuf_stride, max_len_extend, sm_scale, logit_cap, as_stream(stream)));
+  SEMIPD_DISPATCH_HALF(dtype, T, return run_extend<T>(out, q_extend, k_extend, v_extend, k_buf, v_buf, qo_indptr, kv_indptr, kv_indices, batch, num_q_heads, num_kv_heads, head_dim_k, head_dim_v, q_stride, k_stride, v_stride, o_stride, kbuf_stride, vbuf_stride, max_len_extend, sm_scale, logit_cap, dtype, kv_dtype, as_stream(stream)));
   return 0;
 }

@@ -58,7 +58,17 @@ int semipd_ipc_get_handle(const void* dev_ptr, uint8_t handle[64], uint64_t* off
   hipDeviceptr_t base = nullptr;
   size_t size = 0;
   SEMIPD_HIP(hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)dev_ptr));
+  // ROCm 7.2 / dmabuf IPC: hipIpcOpenMemHandle in the importing process never returns when the
+  // allocation size modulo 4 GiB is 2 GiB or more (measured: 2.5 GiB and 6.1 GiB hang; 1.9, 5.0, 9.5, 20,
+  // 40 GiB map in < 1 ms; tools/ipc_big_probe.py).  Refuse to export such an allocation instead of
+  // hanging the importer; large buffers meant for sharing are sized around it (memory_pool.py).
+  SEMIPD_CHECK_ARG(((uint64_t)size & 0xffffffffull) < 0x80000000ull, SEMIPD_EINVAL,
+                   "ipc_get_handle: allocation of %zu bytes cannot be imported by another process on this ROCm "
+                   "(size mod 4 GiB >= 2 GiB hangs hipIpcOpenMemHandle); allocate it with ipc-safe padding",
+                   size);
   hipIpcMemHandle_t h;
+  memset(&h, 0, sizeof(h));  // the runtime fills only part of the 64 bytes; the importer's mapping cache
+                             // is keyed by all of them, so the rest must not be stack garbage
   SEMIPD_HIP(hipIpcGetMemHandle(&h, base));
   memcpy(handle, &h, 64);
   *offset = (uint64_t)((const uint8_t*)dev_ptr - (const uint8_t*)base);

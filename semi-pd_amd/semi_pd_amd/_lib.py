@@ -19,8 +19,10 @@ LIB_PATH = os.environ.get(
     "SEMIPD_HIP_LIB", os.path.join(os.path.dirname(_PKG_DIR), "lib", "libsemipd_hip.so")
 )
 
-F32, F16, BF16 = 0, 1, 2
+F32, F16, BF16, F8E5M2, F8E4M3 = 0, 1, 2, 3, 4
 _DTYPE_CODE = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
+_KV_DTYPE_CODE = {torch.float16: F16, torch.bfloat16: BF16, torch.float32: F32,
+                  torch.float8_e5m2: F8E5M2, torch.float8_e4m3fn: F8E4M3}
 
 _lock = threading.Lock()
 _lib: Optional[C.CDLL] = None
@@ -37,14 +39,15 @@ _SIGNATURES = {
     "semipd_rope_inplace": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i64, _i64, _i32, _i32, _vp],
     "semipd_rope_inplace_strided": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _i32, _i32, _vp],
     "semipd_rope_kv_store": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32,
-                             _i64, _i64, _i64, _i64, _i64, _i32, _i32, _vp],
+                             _i64, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _vp],
     "semipd_kv_store": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp],
+    "semipd_kv_store_cvt": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _vp],
     "semipd_build_kv_indices": [_vp, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _vp],
     "semipd_compute_positions": [_vp, _vp, _vp, _vp, _i64, _vp],
     "semipd_decode_attention": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i64,
-                                _i64, _i64, _i64, _i32, _f32, _f32, _i32, _vp],
+                                _i64, _i64, _i64, _i32, _f32, _f32, _i32, _i32, _vp],
     "semipd_extend_attention": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32,
-                                _i64, _i64, _i64, _i64, _i64, _i64, _i32, _f32, _f32, _i32, _vp],
+                                _i64, _i64, _i64, _i64, _i64, _i64, _i32, _f32, _f32, _i32, _i32, _vp],
     "semipd_gather_rows": [_vp, _vp, _vp, _i64, _i64, _i64, _vp],
     "semipd_argmax": [_vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp],
     "semipd_lm_head_argmax": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp],
@@ -118,6 +121,14 @@ def dtype_code(dtype: torch.dtype) -> int:
         return _DTYPE_CODE[dtype]
     except KeyError:
         raise RuntimeError(f"unsupported dtype {dtype} (float32 / float16 / bfloat16 only)") from None
+
+
+def kv_dtype_code(dtype: torch.dtype) -> int:
+    """Storage type of KV-pool rows: the activation type or one of the two OCP fp8 types."""
+    try:
+        return _KV_DTYPE_CODE[dtype]
+    except KeyError:
+        raise RuntimeError(f"unsupported KV-cache dtype {dtype}") from None
 
 
 def ptr(t: Optional[torch.Tensor]) -> Optional[int]:

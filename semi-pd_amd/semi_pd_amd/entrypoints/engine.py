@@ -40,7 +40,7 @@ def _build_runner(server_args: ServerArgs, gpu_id: int, tp_rank: int, role: Inst
         mem_fraction_static=server_args.mem_fraction_static, max_total_tokens=max_total_tokens,
         nccl_init_method=f"tcp://{server_args.dist_init_addr}:{nccl_port}", instance_role=role,
         dist_backend=server_args.dist_backend, model_path=server_args.model_path,
-        load_format=server_args.load_format,
+        load_format=server_args.load_format, kv_cache_dtype=server_args.kv_cache_dtype,
         bypass_load_weight=bypass_load_weight, seed=server_args.random_seed, cu_percent=cu_percent,
         disable_cuda_graph=server_args.disable_cuda_graph, cuda_graph_max_bs=server_args.cuda_graph_max_bs)
     if server_args.collect_kernel_timing:
@@ -56,6 +56,8 @@ def run_scheduler_process(server_args: ServerArgs, port_args: SemiPDPortArgs, gp
         if p not in sys.path:
             sys.path.insert(0, p)
     faulthandler.enable()
+    if os.environ.get("SEMIPD_DUMP_TRACEBACK_AFTER"):  # debugging aid: where does a start-up hang?
+        faulthandler.dump_traceback_later(float(os.environ["SEMIPD_DUMP_TRACEBACK_AFTER"]), repeat=False)
     logging.basicConfig(level=os.environ.get("SEMIPD_LOGLEVEL", "WARNING"),
                         format=f"[%(asctime)s {role.name} TP{tp_rank}] %(message)s")
     parent = os.getppid()

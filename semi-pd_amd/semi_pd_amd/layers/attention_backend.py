@@ -107,7 +107,8 @@ class HipAttnBackend(AttentionBackend):
             self.forward_metadata = ForwardMetadata(attn_logits, kv_indptr, kv_indices, None, 0, splits)
             # sum_len * Hkv * (Dk + Dv) * s  +  2 * B * Hq * D * s   per layer
             es = 2
-            self._algo = (forward_batch.seq_lens_sum * self.num_kv_head * self._kv_row_elems() * es
+            es_kv = getattr(self.model_runner, "kv_cache_dtype", torch.bfloat16).itemsize  # 1 for fp8 rows
+            self._algo = (forward_batch.seq_lens_sum * self.num_kv_head * self._kv_row_elems() * es_kv
                           + 2 * bs * self.num_head * self.v_head_dim * es, 0.0)
         else:
             prefix_sum = int(sum(forward_batch.extend_prefix_lens_cpu))

@@ -108,6 +108,22 @@ class TokenToKVPoolAllocator:
         self.free_group = []
 
 
+def ipc_safe_zeros(shape, dtype: torch.dtype, device) -> torch.Tensor:
+    """torch.zeros(shape, dtype) inside an allocation another process can import: on this ROCm
+    hipIpcOpenMemHandle hangs when the allocation size modulo 4 GiB is >= 2 GiB (see csrc/ipc.hip), so
+    the backing allocation is padded up to the next multiple of 4 GiB in that case (< 2 GiB of 288).
+    The caching allocator rounds large requests up to 2 MiB, which is what the check looks at."""
+    numel = 1
+    for d in shape:
+        numel *= int(d)
+    nbytes = numel * dtype.itemsize
+    alloc = -(-nbytes // (2 << 20)) * (2 << 20)
+    if (alloc & 0xFFFFFFFF) >= (1 << 31):
+        alloc = -(-alloc // (1 << 32)) * (1 << 32)
+    raw = torch.zeros(alloc, dtype=torch.uint8, device=device)
+    return raw[:nbytes].view(dtype).view(*shape)
+
+
 class MHATokenToKVPool:
     def __init__(self, size: int, page_size: int, dtype: torch.dtype, head_num: int, head_dim: int,
                  layer_num: int, device: str, bypass_create_buffers: bool = False):
@@ -122,8 +138,8 @@ class MHATokenToKVPool:
 
     def _create_buffers(self):
         # [L, 2, N+page, Hkv, D]: one allocation, one IPC handle
-        self.slab = torch.zeros((self.layer_num, 2, self.size + self.page_size, self.head_num, self.head_dim),
-                                dtype=self.dtype, device=self.device)
+        self.slab = ipc_safe_zeros((self.layer_num, 2, self.size + self.page_size, self.head_num, self.head_dim),
+                                   self.dtype, self.device)
         self.k_buffer = [self.slab[i, 0] for i in range(self.layer_num)]
         self.v_buffer = [self.slab[i, 1] for i in range(self.layer_num)]
 
@@ -142,7 +158,9 @@ class MHATokenToKVPool:
 
     def set_kv_buffer(self, layer, loc: torch.Tensor, cache_k: torch.Tensor, cache_v: torch.Tensor):
         layer_id = layer.layer_id
-        if cache_k.dtype != self.dtype:
+        # an fp8 pool (--kv-cache-dtype fp8_e5m2 / fp8_e4m3, memory_pool.py:205-209, 326-336) converts
+        # inside the scatter kernel; any other mismatch is converted here like the reference does
+        if cache_k.dtype != self.dtype and self.dtype not in (torch.float8_e5m2, torch.float8_e4m3fn):
             cache_k, cache_v = cache_k.to(self.dtype), cache_v.to(self.dtype)
         ops.store_kv_rows(self.k_buffer[layer_id], loc, cache_k.view(-1, self.head_num, self.head_dim))
         ops.store_kv_rows(self.v_buffer[layer_id], loc, cache_v.view(-1, self.head_num, self.head_dim))
@@ -161,8 +179,8 @@ class MLATokenToKVPool:
         self.kv_buffer: List[torch.Tensor] = []
         self.slab: Optional[torch.Tensor] = None
         if not bypass_create_buffers:
-            self.slab = torch.zeros((layer_num, size + page_size, 1, kv_lora_rank + qk_rope_head_dim),
-                                    dtype=dtype, device=device)
+            self.slab = ipc_safe_zeros((layer_num, size + page_size, 1, kv_lora_rank + qk_rope_head_dim), dtype,
+                                       device)
             self.kv_buffer = [self.slab[i] for i in range(layer_num)]
 
     def get_key_buffer(self, layer_id: int):

@@ -99,10 +99,17 @@ class ModelRunner:
                  bypass_load_weight: bool = False, seed: int = 0, cu_percent: int = 100,
                  disable_cuda_graph: bool = False, cuda_graph_max_bs: int = 256,
                  load_state_dict: Optional[Dict[str, torch.Tensor]] = None, model_path: Optional[str] = None,
-                 load_format: str = "dummy"):
+                 load_format: str = "dummy", kv_cache_dtype: str = "auto"):
         self.model_config = model_config
         self.gpu_id, self.tp_rank, self.tp_size = gpu_id, tp_rank, tp_size
         self.dtype = dtype
+        # --kv-cache-dtype (server_args.py kv_cache_dtype; model_runner.py:690-710): pool rows in the
+        # activation type or in OCP fp8
+        try:
+            self.kv_cache_dtype = {"auto": dtype, "fp8_e5m2": torch.float8_e5m2,
+                                   "fp8_e4m3": torch.float8_e4m3fn}[kv_cache_dtype]
+        except KeyError:
+            raise ValueError(f"unsupported kv_cache_dtype {kv_cache_dtype!r}") from None
         self.max_context_len = context_length
         self.max_running_requests = max_running_requests
         self.mem_fraction_static = mem_fraction_static
@@ -145,6 +152,10 @@ class ModelRunner:
                     self.model.post_load_weights()
         finally:
             torch.set_default_dtype(torch.float32)
+        # give the initialisation temporaries (fp32 draws of full-size tensors) back to the driver: later
+        # allocations that are exported through IPC (KV slab, req_to_token) must not be carved out of a
+        # cached block whose size the importer cannot map (see csrc/ipc.hip)
+        torch.cuda.empty_cache()
         self.model.eval()
         geo = self.model.kv_geometry
         self.kv_geometry = geo
@@ -164,9 +175,10 @@ class ModelRunner:
         free, total = torch.cuda.mem_get_info(self.device)
         geo = self.kv_geometry
         if geo["kind"] == "mla":
-            cell = (geo["kv_lora_rank"] + geo["qk_rope_head_dim"]) * geo["num_layers"] * self.dtype.itemsize
+            cell = (geo["kv_lora_rank"] + geo["qk_rope_head_dim"]) * geo["num_layers"] * self.kv_cache_dtype.itemsize
         else:
-            cell = geo["num_kv_heads"] * (geo["head_dim"] + geo["v_head_dim"]) * geo["num_layers"] * self.dtype.itemsize
+            cell = (geo["num_kv_heads"] * (geo["head_dim"] + geo["v_head_dim"]) * geo["num_layers"]
+                    * self.kv_cache_dtype.itemsize)
         rest = free - total * (1 - self.mem_fraction_static)
         return max(int(rest // cell), 0)
 
@@ -188,14 +200,16 @@ class ModelRunner:
         self.req_to_token_pool = ReqToTokenPool(self.max_running_requests + 1, self.max_context_len + 4, dev,
                                                 bypass_create_buffers=bypass)
         if geo["kind"] == "mla":
+            if self.kv_cache_dtype != self.dtype:
+                raise NotImplementedError("fp8 KV cache is implemented for MHA / GQA pools, not for MLA latent rows")
             self.token_to_kv_pool = MLATokenToKVPool(self.max_total_num_tokens, 1, self.dtype,
                                                      geo["kv_lora_rank"], geo["qk_rope_head_dim"],
                                                      geo["num_layers"], dev, bypass_create_buffers=bypass)
         else:
-            self.token_to_kv_pool = MHATokenToKVPool(self.max_total_num_tokens, 1, self.dtype,
+            self.token_to_kv_pool = MHATokenToKVPool(self.max_total_num_tokens, 1, self.kv_cache_dtype,
                                                      geo["num_kv_heads"], geo["head_dim"], geo["num_layers"],
                                                      dev, bypass_create_buffers=bypass)
-        self.token_to_kv_pool_allocator = TokenToKVPoolAllocator(self.max_total_num_tokens, self.dtype, dev,
+        self.token_to_kv_pool_allocator = TokenToKVPoolAllocator(self.max_total_num_tokens, self.kv_cache_dtype, dev,
                                                                  self.token_to_kv_pool)
 
     # ------------------------------------------------------------------------------------ IPC export

@@ -144,7 +144,8 @@ def rope_and_store_kv(positions: torch.Tensor, query: torch.Tensor, key: torch.T
                                    head_size, v_head, cos_sin_cache.shape[1], q.stride(0), k.stride(0),
                                    v.stride(0), k_buffer.stride(0), v_buffer.stride(0),
                                    0 if is_neox else 1, dtype_code(query.dtype),
-                                   current_stream(query.device)), "rope_kv_store")
+                                   _lib.kv_dtype_code(k_buffer.dtype), current_stream(query.device)),
+          "rope_kv_store")
 
 
 def store_kv_rows(buffer: torch.Tensor, loc: torch.Tensor, src: torch.Tensor) -> None:
@@ -157,10 +158,16 @@ def store_kv_rows(buffer: torch.Tensor, loc: torch.Tensor, src: torch.Tensor) ->
         raise RuntimeError("store_kv_rows: row size mismatch")
     if n and not src[0].is_contiguous():
         raise RuntimeError("store_kv_rows: rows must be contiguous")
+    lib = _lib.load()
+    if buffer.dtype in (torch.float8_e5m2, torch.float8_e4m3fn):
+        # fp8 pool: `cache_k.to(self.dtype)` of set_kv_buffer happens inside the scatter
+        check(lib.semipd_kv_store_cvt(ptr(buffer), ptr(src), ptr(loc), n, row_elems, buffer.stride(0),
+                                      src.stride(0) if n else 0, dtype_code(src.dtype),
+                                      _lib.kv_dtype_code(buffer.dtype), current_stream(src.device)), "kv_store_cvt")
+        return
     if src.dtype != buffer.dtype:
         raise RuntimeError("store_kv_rows: dtype mismatch")
     es = src.element_size()
-    lib = _lib.load()
     check(lib.semipd_kv_store(ptr(buffer), ptr(src), ptr(loc), n, row_elems * es, buffer.stride(0) * es,
                               src.stride(0) * es if n else 0, current_stream(src.device)), "kv_store")
 
@@ -242,7 +249,8 @@ def decode_attention_fwd(q: torch.Tensor, k_buffer: torch.Tensor, v_buffer: torc
                                       ptr(kv_indices), ptr(attn_logits), B, Hq, Hkv, Dk, Dv,
                                       q.stride(0), o.stride(0), k_buffer.stride(0), v_buffer.stride(0),
                                       num_kv_splits, sm_scale, logit_cap, dtype_code(q.dtype),
-                                      current_stream(q.device)), "decode_attention")
+                                      _lib.kv_dtype_code(k_buffer.dtype), current_stream(q.device)),
+          "decode_attention")
 
 
 def extend_attention_fwd(q_extend: torch.Tensor, k_extend: torch.Tensor, v_extend: torch.Tensor,
@@ -272,7 +280,9 @@ def extend_attention_fwd(q_extend: torch.Tensor, k_extend: torch.Tensor, v_exten
                                       ptr(kv_indices), B, Hq, Hkv, Dk, Dv, q_extend.stride(0),
                                       k_extend.stride(0), v_extend.stride(0), o_extend.stride(0),
                                       kb_stride, vb_stride, int(max_len_extend), sm_scale, logit_cap,
-                                      dtype_code(q_extend.dtype), current_stream(q_extend.device)),
+                                      dtype_code(q_extend.dtype),
+                                      _lib.kv_dtype_code(k_buffer.dtype if k_buffer is not None else q_extend.dtype),
+                                      current_stream(q_extend.device)),
           "extend_attention")
 
 

@@ -25,6 +25,7 @@ class ServerArgs:
     port: int = 30000
     load_format: str = "dummy"               # "dummy" (seeded random weights) | "auto" (HF safetensors)
     dtype: str = "bfloat16"
+    kv_cache_dtype: str = "auto"             # "auto" | "fp8_e5m2" | "fp8_e4m3" (MHA / GQA pools)
     context_length: int = 4096
     tp_size: int = 1
     base_gpu_id: int = 0
@@ -108,6 +109,7 @@ def add_cli_args(parser):
     p.add_argument("--skip-tokenizer-init", action="store_true")
     p.add_argument("--load-format", type=str, default="auto", choices=["auto", "safetensors", "dummy"])
     p.add_argument("--dtype", type=str, default="auto", choices=["auto", "half", "float16", "bfloat16"])
+    p.add_argument("--kv-cache-dtype", type=str, default="auto", choices=["auto", "fp8_e5m2", "fp8_e4m3"])
     p.add_argument("--context-length", type=int, default=None)
     p.add_argument("--served-model-name", type=str, default=None)
     p.add_argument("--mem-fraction-static", type=float, default=None)
@@ -147,6 +149,7 @@ def from_cli_args(args) -> ServerArgs:
         model_path=args.model_path, tokenizer_path=args.tokenizer_path, host=args.host, port=args.port,
         skip_tokenizer_init=args.skip_tokenizer_init,
         load_format="dummy" if args.load_format == "dummy" else "auto", dtype=dtype,
+        kv_cache_dtype=args.kv_cache_dtype,
         served_model_name=args.served_model_name, mem_fraction_static=args.mem_fraction_static,
         max_running_requests=args.max_running_requests, max_total_tokens=args.max_total_tokens,
         chunked_prefill_size=args.chunked_prefill_size, max_prefill_tokens=args.max_prefill_tokens,

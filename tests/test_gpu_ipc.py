@@ -136,3 +136,23 @@ def test_cu_masked_stream_confines_workgroups(device):
         assert len({x for x, _ in slots}) == len({x for x, _ in full}), "mask is not spread over all XCDs"
         _lib.check(lib.semipd_stream_destroy(s), "destroy")
     assert not (seen[0] & seen[1]), "prefill and decode CU sets overlap"
+
+
+def test_export_refuses_allocation_sizes_the_importer_cannot_map(device):
+    """ROCm 7.2 dmabuf IPC: hipIpcOpenMemHandle never returns when the allocation size modulo 4 GiB is
+    >= 2 GiB (tools/ipc_big_probe.py).  The exporter must fail loudly instead of hanging the prefill
+    instance at start-up, and the pools must size their slabs around it."""
+    import semi_pd_ipc
+    from semi_pd_amd.mem_cache.memory_pool import ipc_safe_zeros
+    bad = torch.empty(int(2.5 * (1 << 30)), dtype=torch.uint8, device=device)
+    with pytest.raises(RuntimeError, match="cannot be imported"):
+        semi_pd_ipc.get_ipc_handle_and_offset(bad)
+    del bad
+    torch.cuda.empty_cache()
+    # the same number of payload bytes through the pool allocator: padded to 4 GiB, exportable
+    t = ipc_safe_zeros((32, 2, 40001, 8, 128), torch.float8_e5m2, device)
+    assert t.numel() == 32 * 2 * 40001 * 8 * 128 and t.dtype == torch.float8_e5m2
+    handle, off = semi_pd_ipc.get_ipc_handle_and_offset(t[3, 1])
+    assert len(handle) == 64 and off == t[3, 1].data_ptr() - t.data_ptr()
+    h2, _ = semi_pd_ipc.get_ipc_handle_and_offset(t[5, 0])
+    assert h2 == handle  # one allocation, one handle: the importer's mapping cache depends on it

@@ -37,7 +37,7 @@ def test_argument_errors_are_reported_not_swallowed():
     assert rc == -1
     assert "rmsnorm" in _lib.last_error()
     rc = lib.semipd_decode_attention(None, None, None, None, None, None, None, 1, 6, 4, 64, 64, 0, 0, 0, 0, 1,
-                                     1.0, 0.0, _lib.BF16, None)  # Hq % Hkv != 0
+                                     1.0, 0.0, _lib.BF16, _lib.BF16, None)  # Hq % Hkv != 0
     assert rc == -3
     with pytest.raises(RuntimeError):
         _lib.check(rc, "decode_attention")

@@ -61,7 +61,7 @@ def bench_decode_small():
     print("# decode attention, small batches: B, ctx, splits -> us (stage1+stage2), GB/s   HSA_CU_MASK=%s"
           % os.environ.get("HSA_CU_MASK", "-"))
     Hq, Hkv, D = 32, 8, 128
-    for B in (4, 8, 16, 32, 64):
+    for B in (4, 8, 16, 32, 64, 256):
         ctx = 1100
         N = B * ctx + 1
         kb = torch.randn(N, Hkv, D, device=dev, dtype=torch.bfloat16)
@@ -71,12 +71,17 @@ def bench_decode_small():
         indptr = (torch.arange(B + 1, device=dev, dtype=torch.int32) * ctx)
         idx = (torch.randperm(N - 1, device=dev)[: B * ctx] + 1).to(torch.int32)
         nbytes = B * ctx * Hkv * 2 * D * 2 + 2 * B * Hq * D * 2
+        kvd = os.environ.get("KBENCH_KV", "")
+        if kvd:  # fp8 pool rows: half the bytes
+            fd = torch.float8_e5m2 if kvd == "fp8_e5m2" else torch.float8_e4m3fn
+            kb, vb = kb.to(fd), vb.to(fd)
+            nbytes = B * ctx * Hkv * 2 * D * 1 + 2 * B * Hq * D * 2
         row = []
         for splits in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32):
             lg = torch.empty(B, Hq, splits, D + 1, device=dev, dtype=torch.float32)
             t = timeit(lambda: ops.decode_attention_fwd(q, kb, vb, o, indptr, idx, lg, splits, D ** -0.5), iters=50)
             row.append(f"{splits}:{t * 1e6:.1f}us/{nbytes / t / 1e9:.0f}")
-        print(f"B={B:3d} ctx={ctx}: " + "  ".join(row))
+        print(f"B={B:3d} ctx={ctx} kv={kvd or 'bf16'}: " + "  ".join(row))
 
 
 def bench_mla():
