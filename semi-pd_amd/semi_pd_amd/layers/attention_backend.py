@@ -60,18 +60,22 @@ class ForwardMetadata:
     num_kv_splits: int
 
 
-def choose_kv_splits(batch: int, num_kv_heads: int, max_seq_len: int, num_cus: int, cap: int) -> int:
-    """Split-KV factor: enough workgroups (batch x kv-head tiles x splits) to fill the CUs this
-    process owns a few times over, never cutting below ~64 tokens per split.  (The reference uses a
-    fixed --triton-attention-num-kv-splits, 16 on HIP: server_args.py:321-323.)"""
-    # One work item = one wave of decode_mfma_kernel; 2 waves per SIMD fit, i.e. 8 per CU.  Measured
-    # on 128 and 256 CUs at ctx ~ 1.1 k (profiles/r01_kbench_decode_small_batches.txt): the best split
-    # puts ONE full round of waves on the CUs the process owns (B x Hkv x splits ~ 8 x CUs); a second
-    # round costs more in per-wave prologue and stage-2 work than it gains in balance.
-    target = 8 * num_cus
+def choose_kv_splits(batch: int, num_kv_heads: int, max_seq_len: int, num_cus: int, cap: int,
+                     mla: bool = False) -> int:
+    """Split-KV factor: one full round of work items on the CUs this process owns, never cutting a
+    split too short.  (The reference uses a fixed --triton-attention-num-kv-splits, 16 on HIP:
+    server_args.py:321-323.)"""
+    # GQA / MQA: one work item = one wave of decode_mfma_kernel; 2 waves per SIMD fit, i.e. 8 per CU.
+    # Measured on 128 and 256 CUs at ctx ~ 1.1 k (profiles/r01_kbench_decode_small_batches.txt): the
+    # best split puts ONE full round of waves on the CUs (B x Hkv x splits ~ 8 x CUs); a second round
+    # costs more in per-wave prologue and stage-2 work than it gains in balance.
+    # MLA: one work item = one 4-wave workgroup of mla_decode_kernel (the waves share the latent tile in
+    # LDS), 2 per CU, and a split below ~128 tokens does not amortise staging Q for 16 heads
+    # (profiles/r01_kbench_mla_small_batches.txt: best B x splits = 1 .. 2 x CUs).
+    target = (2 if mla else 8) * num_cus
     base = max(1, batch * num_kv_heads)
     want = max(1, target // base)
-    by_len = max(1, max_seq_len // 64)
+    by_len = max(1, max_seq_len // (128 if mla else 64))
     return int(max(1, min(cap, want, by_len)))
 
 
@@ -84,6 +88,7 @@ class HipAttnBackend(AttentionBackend):
         self.req_to_token = model_runner.req_to_token_pool.req_to_token
         self.max_context_len = model_runner.max_context_len
         self.num_cus = model_runner.num_cus_owned
+        self.is_mla = model_runner.kv_geometry["kind"] == "mla"
         self.num_kv_splits_cap = num_kv_splits_cap
         self.forward_metadata: Optional[ForwardMetadata] = None
         self.cuda_graph_attn_logits = None
@@ -101,7 +106,8 @@ class HipAttnBackend(AttentionBackend):
                                              forward_batch.seq_lens, kv_indptr, None, kv_indices)
             max_len = self.max_context_len if forward_batch.seq_lens_sum is None else max(
                 1, forward_batch.seq_lens_sum // max(bs, 1))
-            splits = choose_kv_splits(bs, self.num_kv_head, max_len, self.num_cus, self.num_kv_splits_cap)
+            splits = choose_kv_splits(bs, self.num_kv_head, max_len, self.num_cus, self.num_kv_splits_cap,
+                                      mla=self.is_mla)
             attn_logits = torch.empty((bs, self.num_head, splits, self.v_head_dim + 1), dtype=torch.float32,
                                       device=dev) if splits > 1 else None
             self.forward_metadata = ForwardMetadata(attn_logits, kv_indptr, kv_indices, None, 0, splits)
@@ -144,7 +150,7 @@ class HipAttnBackend(AttentionBackend):
         the static req_pool_indices / seq_lens buffers on every replay."""
         assert forward_mode.is_decode()
         splits = num_kv_splits or choose_kv_splits(bs, self.num_kv_head, self.max_context_len, self.num_cus,
-                                                   self.num_kv_splits_cap)
+                                                   self.num_kv_splits_cap, mla=self.is_mla)
         kv_indptr = self.cuda_graph_kv_indptr[: bs + 1]
         ops.create_flashinfer_kv_indices(self.req_to_token, req_pool_indices, seq_lens, kv_indptr, None,
                                          self.cuda_graph_kv_indices)

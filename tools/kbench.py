@@ -109,6 +109,27 @@ def bench_mla():
                       f"{nbytes / t / 1e9:7.0f} GB/s  {nbytes / t / 1e9 / HBM:.3f}")
 
 
+def bench_mla_small():
+    """Serving-run regime for MLA decode: small batches, ctx ~ 1.1 k, H = 16, every split factor."""
+    print("# MLA decode, small batches: B, ctx, splits -> us (stage1+stage2) / GB/s   HSA_CU_MASK=%s"
+          % os.environ.get("HSA_CU_MASK", "-"))
+    H, ctx = 16, 1100
+    for B in (4, 8, 16, 32, 64, 128):
+        N = B * ctx + 1
+        kv = torch.randn(N, 1, 576, device=dev, dtype=torch.bfloat16)
+        q = torch.randn(B, H, 576, device=dev, dtype=torch.bfloat16)
+        o = torch.empty(B, H, 512, device=dev, dtype=torch.bfloat16)
+        indptr = (torch.arange(B + 1, device=dev, dtype=torch.int32) * ctx)
+        idx = (torch.randperm(N - 1, device=dev)[: B * ctx] + 1).to(torch.int32)
+        nbytes = B * ctx * 576 * 2 + B * H * (576 + 512) * 2
+        row = []
+        for splits in (1, 2, 3, 4, 6, 8, 12, 16):
+            lg = torch.empty(B, H, splits, 513, device=dev, dtype=torch.float32)
+            t = timeit(lambda: ops.decode_attention_fwd(q, kv, kv[..., :512], o, indptr, idx, lg, splits, 0.1), iters=50)
+            row.append(f"{splits}:{t * 1e6:.1f}us/{nbytes / t / 1e9:.0f}")
+        print(f"B={B:3d} ctx={ctx}: " + "  ".join(row))
+
+
 def bench_extend():
     print("# extend attention: B, ext, prefix, Hq, Hkv, D -> us, TFLOP/s, frac of 2.5 PF")
     for (Hq, Hkv, D) in [(32, 8, 128), (12, 12, 64)]:
@@ -209,6 +230,8 @@ if __name__ == "__main__":
         bench_linear()
     if which == "decode_small":
         bench_decode_small()
+    if which == "mla_small":
+        bench_mla_small()
     if which in ("decode", "all"):
         bench_decode()
     if which in ("mla", "all"):
