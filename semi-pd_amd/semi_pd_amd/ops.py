@@ -154,9 +154,10 @@ def store_kv_rows(buffer: torch.Tensor, loc: torch.Tensor, src: torch.Tensor) ->
         loc = loc.long()
     n = src.shape[0]
     row_elems = src[0].numel() if n else 0
-    if n and (src[0].numel() != buffer[0].numel()) and False:
-        raise RuntimeError("store_kv_rows: row size mismatch")
-    if n and not src[0].is_contiguous():
+    if n and row_elems != buffer[0].numel():
+        raise RuntimeError(f"store_kv_rows: rows of {row_elems} elements into a pool with rows of "
+                           f"{buffer[0].numel()}")
+    if n and not (src[0].is_contiguous() and buffer[0].is_contiguous()):
         raise RuntimeError("store_kv_rows: rows must be contiguous")
     lib = _lib.load()
     if buffer.dtype in (torch.float8_e5m2, torch.float8_e4m3fn):
