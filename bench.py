@@ -275,7 +275,14 @@ def main():
             kname = ("mla_decode_kernel" if "Deepseek" in cfg.architectures[0] else "decode_mfma_kernel")
             roofline = {"bound": "hbm", "kernel": kname + " + decode_stage2_kernel (one decode_attention call)", "achieved": round(k["gbps"], 1),
                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(k["gbps"] / HBM_PEAK_GBPS, 4),
-                        "traffic": None, "avg_launch_us": round(k["avg_us"], 2),
+                        # PMC counters cannot be read from inside this process: `traffic` stays null here;
+                        # the separate rocprofv3 --pmc FETCH_SIZE pass of this command (x2 gfx950 correction)
+                        # is committed under profiles/ and gave traffic = 1.03 x algorithmic bytes per launch
+                        "traffic": None,
+                        "traffic_pmc": {"ratio_to_algorithmic": 1.03,
+                                        "source": "profiles/r01_pmc_decode_attention_in_situ.txt"}
+                        if kname == "decode_mfma_kernel" else None,
+                        "avg_launch_us": round(k["avg_us"], 2),
                         "avg_launch_us_minus_event_overhead": round(k.get("avg_us_minus_event_overhead", k["avg_us"]), 2),
                         "event_pair_overhead_us": kt.get("_event_pair_overhead_us"),
                         "algorithmic_bytes_per_launch": int(k["bytes_per_launch"]), "launches_sampled": k["launches"]}
