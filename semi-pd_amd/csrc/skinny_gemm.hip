@@ -44,11 +44,20 @@ skinny_gemm_kernel(OutT* __restrict__ c, const T* __restrict__ a, const T* __res
                    const int32_t* __restrict__ expert_ids, const int32_t* __restrict__ num_post_pad,
                    int64_t num_valid, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldc,
                    int top_k_div, int mul_routed_weight, int chunks_per_split, float* __restrict__ partial_ws) {
-  constexpr int BNW = 16, KC = 256;              // W rows per wave, K chunk (BM = rows of A per block)
+  // BM = 64 (decode blocks, dense calls): a wave owns 16 W rows, K chunks of 256.
+  // BM = 128 (prefill chunks of a grouped GEMM): a wave owns TWO groups of 16 W rows and the K chunk
+  // shrinks to 128, so the registers in flight stay the same while every staged activation fragment
+  // feeds two MFMAs and every activation row is re-read by half as many workgroups (with 64 W rows per
+  // workgroup the 44x re-read of the activations through L2, not the weights, bounded the prefill call).
+  constexpr int NG = (BM == 128) ? 2 : 1;         // groups of 16 W rows per wave
+  constexpr int KC = 256 / NG;                    // K chunk staged per barrier pair
+  constexpr int BNW = 16 * NG;                    // W rows per wave
   constexpr int MT = BM / 16;                     // m-tiles of 16 rows
   constexpr int AS = KC + 8;                      // LDS row stride (elements)
-  constexpr int KSC = KC / 32;                    // 8 MFMA k-steps per chunk
-  constexpr int NA = BM * (KC / 8) / 256;         // A chunks of 16 B per thread per K-chunk (8 or 16)
+  constexpr int KSC = KC / 32;                    // MFMA k-steps per chunk
+  constexpr int CPRW = KC / 8;                    // 16-byte chunks per staged row
+  constexpr int RPP = 256 / CPRW;                 // rows staged per pass of the 256 threads
+  constexpr int NA = BM / RPP;                    // A chunks of 16 B per thread per K-chunk (8)
   __shared__ __attribute__((aligned(16))) uint16_t a_lds[BM * AS];
   __shared__ int row_id[BM];
   __shared__ int n_rows;
@@ -75,25 +84,30 @@ skinny_gemm_kernel(OutT* __restrict__ c, const T* __restrict__ a, const T* __res
   const int m_tiles = (n_rows + 15) >> 4;  // real rows are packed at the front of a block
   if (m_tiles == 0) return;
 
-  // ---- A staging slots: chunk ch (16 B) of rows r0 + 8*i ----
-  const int ch = tid & 31, r0 = tid >> 5;  // 32 chunks per 256-wide row, 8 rows per pass
+  // ---- A staging slots: chunk ch (16 B) of rows r0 + RPP*i ----
+  const int ch = tid % CPRW, r0 = tid / CPRW;
   int64_t a_off[NA];  // element offset of the chunk at k = 0, -1 = no such row
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
-    const int rid = row_id[r0 + 8 * i];
+    const int rid = row_id[r0 + RPP * i];
     const int64_t arow = GROUPED ? (int64_t)(rid / top_k_div) : (int64_t)rid;
     a_off[i] = rid >= 0 ? arow * lda + ch * 8 : -1;
   }
-  // ---- W rows of this wave: lane = row c16, 16 bytes at k = q4*8 (+32 per k-step) ----
-  const bool w_ok = (n0 + c16) < N;
-  const T* w_ptr = w + expert * N * K + (w_ok ? (n0 + c16) : 0) * K + q4 * 8;
+  // ---- W rows of this wave: group g, lane = row c16, 16 bytes at k = q4*8 (+32 per k-step) ----
+  bool w_ok[NG];
+  const T* w_ptr[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    w_ok[g] = (n0 + g * 16 + c16) < N;
+    w_ptr[g] = w + expert * N * K + (w_ok[g] ? (n0 + g * 16 + c16) : 0) * K + q4 * 8;
+  }
 
-  // split-K: blockIdx.z owns K-chunks [z * chunks_per_split, (z + 1) * chunks_per_split)
-  const int64_t k_begin = (int64_t)blockIdx.z * chunks_per_split * KC;
-  const int64_t k_end = min(K, k_begin + (int64_t)chunks_per_split * KC);
+  // split-K: blockIdx.z owns [z * chunks_per_split, (z + 1) * chunks_per_split) in units of 256 k
+  const int64_t k_begin = (int64_t)blockIdx.z * chunks_per_split * 256;
+  const int64_t k_end = min(K, k_begin + (int64_t)chunks_per_split * 256);
 
   FragS areg[NA];
-  FragS wreg[2][KSC];
+  FragS wreg[2][NG][KSC];
   auto fetch_a = [&](int64_t k0) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
@@ -101,20 +115,31 @@ skinny_gemm_kernel(OutT* __restrict__ c, const T* __restrict__ a, const T* __res
       if (a_off[i] >= 0 && k0 + ch * 8 < k_end) areg[i].u = *reinterpret_cast<const uint4*>(a + a_off[i] + k0);
     }
   };
-  auto fetch_w = [&](FragS (&r)[KSC], int64_t k0) __attribute__((always_inline)) {
+  auto fetch_w = [&](FragS (&r)[NG][KSC], int64_t k0) __attribute__((always_inline)) {
 #pragma unroll
-    for (int ks = 0; ks < KSC; ++ks) {
-      r[ks].u = make_uint4(0, 0, 0, 0);
-      if (w_ok && k0 + ks * 32 + q4 * 8 < k_end) r[ks].u = *reinterpret_cast<const uint4*>(w_ptr + k0 + ks * 32);
+    for (int g = 0; g < NG; ++g) {
+#pragma unroll
+      for (int ks = 0; ks < KSC; ++ks) {
+        r[g][ks].u = make_uint4(0, 0, 0, 0);
+        if (w_ok[g] && k0 + ks * 32 + q4 * 8 < k_end)
+          r[g][ks].u = *reinterpret_cast<const uint4*>(w_ptr[g] + k0 + ks * 32);
+      }
     }
   };
-
-  f32x4 acc[MT];
+  auto stage_a = [&]() __attribute__((always_inline)) {
 #pragma unroll
-  for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NA; ++i)
+      *reinterpret_cast<uint4*>(&a_lds[(r0 + RPP * i) * AS + ch * 8]) = areg[i].u;
+  };
+
+  f32x4 acc[NG][MT];
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[g][t] = f32x4{0.f, 0.f, 0.f, 0.f};
   const uint16_t* a_rd = &a_lds[c16 * AS + q4 * 8];
 
-  auto compute = [&](FragS (&r)[KSC]) __attribute__((always_inline)) {
+  auto compute = [&](FragS (&r)[NG][KSC]) __attribute__((always_inline)) {
 #pragma unroll
     for (int ks = 0; ks < KSC; ++ks) {
 #pragma unroll
@@ -122,7 +147,8 @@ skinny_gemm_kernel(OutT* __restrict__ c, const T* __restrict__ a, const T* __res
         if (t < m_tiles) {
           FragS b;
           b.u = *reinterpret_cast<const uint4*>(a_rd + t * 16 * AS + ks * 32);
-          acc[t] = MfmaS<T>::mma(r[ks], b, acc[t]);
+#pragma unroll
+          for (int g = 0; g < NG; ++g) acc[g][t] = MfmaS<T>::mma(r[g][ks], b, acc[g][t]);
         }
       }
     }
@@ -133,9 +159,7 @@ skinny_gemm_kernel(OutT* __restrict__ c, const T* __restrict__ a, const T* __res
   for (int64_t k0 = k_begin; k0 < k_end; k0 += 2 * KC) {
     // ---- even chunk ----
     __syncthreads();
-#pragma unroll
-    for (int i = 0; i < NA; ++i)
-      *reinterpret_cast<uint4*>(&a_lds[(r0 + 8 * i) * AS + ch * 8]) = areg[i].u;
+    stage_a();
     __syncthreads();
     if (k0 + KC < k_end) {
       fetch_a(k0 + KC);
@@ -145,9 +169,7 @@ skinny_gemm_kernel(OutT* __restrict__ c, const T* __restrict__ a, const T* __res
     // ---- odd chunk ----
     if (k0 + KC < k_end) {
       __syncthreads();
-#pragma unroll
-      for (int i = 0; i < NA; ++i)
-        *reinterpret_cast<uint4*>(&a_lds[(r0 + 8 * i) * AS + ch * 8]) = areg[i].u;
+      stage_a();
       __syncthreads();
       if (k0 + 2 * KC < k_end) {
         fetch_a(k0 + 2 * KC);
@@ -157,53 +179,56 @@ skinny_gemm_kernel(OutT* __restrict__ c, const T* __restrict__ a, const T* __res
     }
   }
 
-  // ---- epilogue: lane holds C^T[n = n0 + q4*4 + r][m = t*16 + c16] ----
-  const int64_t nb = n0 + q4 * 4;
-  if (!GROUPED && gridDim.z > 1) {
-    // split-K: fp32 partials [z][m_block * 64 + row][N], summed in z order by splitk_reduce_kernel.
-    // (An in-kernel "last workgroup reduces" needs agent-scope fences, which write back / invalidate
-    // the whole XCD L2 per workgroup on gfx950: measured 10x slower than this second launch.)
-    const int64_t rows_total = (int64_t)gridDim.y * BM;
-    float* ws = partial_ws + ((int64_t)blockIdx.z * rows_total + m0) * N;
+  // ---- epilogue: lane holds C^T[n = n0 + g*16 + q4*4 + r][m = t*16 + c16] ----
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const int64_t nb = n0 + g * 16 + q4 * 4;
+    if (!GROUPED && gridDim.z > 1) {
+      // split-K: fp32 partials [z][m_block * BM + row][N], summed in z order by splitk_reduce_kernel.
+      // (An in-kernel "last workgroup reduces" needs agent-scope fences, which write back / invalidate
+      // the whole XCD L2 per workgroup on gfx950: measured 10x slower than this second launch.)
+      const int64_t rows_total = (int64_t)gridDim.y * BM;
+      float* ws = partial_ws + ((int64_t)blockIdx.z * rows_total + m0) * N;
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        if (t >= m_tiles || nb >= N) continue;
+        float* dst = ws + (int64_t)(t * 16 + c16) * N + nb;
+        if (nb + 4 <= N && (N % 4 == 0)) {
+          *reinterpret_cast<float4*>(dst) = make_float4(acc[g][t][0], acc[g][t][1], acc[g][t][2], acc[g][t][3]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (nb + r < N) dst[r] = acc[g][t][r];
+        }
+      }
+      continue;
+    }
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
-      if (t >= m_tiles || nb >= N) continue;
-      float* dst = ws + (int64_t)(t * 16 + c16) * N + nb;
-      if (nb + 4 <= N && (N % 4 == 0)) {
-        *reinterpret_cast<float4*>(dst) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+      if (t >= m_tiles) continue;
+      const int rid = row_id[t * 16 + c16];
+      if (rid < 0 || nb >= N) continue;
+      float v[4];
+      const float scale = (GROUPED && mul_routed_weight) ? topk_weights[rid] : 1.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[g][t][r] * scale;
+      OutT* dst = c + (int64_t)rid * ldc + nb;
+      if (nb + 4 <= N && (ldc % 4 == 0)) {
+        if constexpr (sizeof(OutT) == 4) {
+          *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          uint2 p;
+          p.x = (uint32_t)Elem<OutT>::from_f(v[0]).v | ((uint32_t)Elem<OutT>::from_f(v[1]).v << 16);
+          p.y = (uint32_t)Elem<OutT>::from_f(v[2]).v | ((uint32_t)Elem<OutT>::from_f(v[3]).v << 16);
+          *reinterpret_cast<uint2*>(dst) = p;
+        }
       } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (nb + r < N) dst[r] = acc[t][r];
-      }
-    }
-    return;
-  }
-#pragma unroll
-  for (int t = 0; t < MT; ++t) {
-    if (t >= m_tiles) continue;
-    const int rid = row_id[t * 16 + c16];
-    if (rid < 0 || nb >= N) continue;
-    float v[4];
-    const float scale = (GROUPED && mul_routed_weight) ? topk_weights[rid] : 1.f;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = acc[t][r] * scale;
-    OutT* dst = c + (int64_t)rid * ldc + nb;
-    if (nb + 4 <= N && (ldc % 4 == 0)) {
-      if constexpr (sizeof(OutT) == 4) {
-        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-      } else {
-        uint2 p;
-        p.x = (uint32_t)Elem<OutT>::from_f(v[0]).v | ((uint32_t)Elem<OutT>::from_f(v[1]).v << 16);
-        p.y = (uint32_t)Elem<OutT>::from_f(v[2]).v | ((uint32_t)Elem<OutT>::from_f(v[3]).v << 16);
-        *reinterpret_cast<uint2*>(dst) = p;
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (nb + r < N) {
-          if constexpr (sizeof(OutT) == 4) *reinterpret_cast<float*>(dst + r) = v[r];
-          else dst[r] = Elem<OutT>::from_f(v[r]);
+        for (int r = 0; r < 4; ++r) {
+          if (nb + r < N) {
+            if constexpr (sizeof(OutT) == 4) *reinterpret_cast<float*>(dst + r) = v[r];
+            else dst[r] = Elem<OutT>::from_f(v[r]);
+          }
         }
       }
     }
@@ -247,7 +272,8 @@ int launch_skinny_gemm(OutT* c, const T* a, const T* w, const float* topk_weight
   if (GROUPED || ksplit < 1 || !partial_ws || N % 4 != 0 || ldc % 4 != 0) ksplit = 1;
   const int cps = (chunks + ksplit - 1) / ksplit;
   ksplit = (chunks + cps - 1) / cps;  // no empty splits
-  dim3 grid((unsigned)((N + 63) / 64), (unsigned)m_blocks, (unsigned)ksplit);
+  constexpr int64_t kRowsPerWg = (BM == 128) ? 128 : 64;  // W rows per workgroup (see NG in the kernel)
+  dim3 grid((unsigned)((N + kRowsPerWg - 1) / kRowsPerWg), (unsigned)m_blocks, (unsigned)ksplit);
   hipLaunchKernelGGL((skinny_gemm_kernel<T, OutT, GROUPED, BM>), grid, dim3(256), 0, st, c, a, w, topk_weights,
                      sorted_ids, expert_ids, num_post_pad, num_valid, M, N, K, lda, ldc, top_k_div,
                      mul_routed_weight, cps, partial_ws);
