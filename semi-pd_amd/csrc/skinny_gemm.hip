@@ -45,11 +45,12 @@ skinny_gemm_kernel(OutT* __restrict__ c, const T* __restrict__ a, const T* __res
                    int64_t num_valid, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldc,
                    int top_k_div, int mul_routed_weight, int chunks_per_split, float* __restrict__ partial_ws) {
   // BM = 64 (decode blocks, dense calls): a wave owns 16 W rows, K chunks of 256.
-  // BM = 128 (prefill chunks of a grouped GEMM): a wave owns TWO groups of 16 W rows and the K chunk
-  // shrinks to 128, so the registers in flight stay the same while every staged activation fragment
-  // feeds two MFMAs and every activation row is re-read by half as many workgroups (with 64 W rows per
-  // workgroup the 44x re-read of the activations through L2, not the weights, bounded the prefill call).
-  constexpr int NG = (BM == 128) ? 2 : 1;         // groups of 16 W rows per wave
+  // BM = 128 (prefill chunks of a grouped GEMM): a wave owns FOUR groups of 16 W rows (256 W rows per
+  // workgroup) and the K chunk shrinks to 64, so the registers in flight stay the same while every staged
+  // activation fragment feeds four MFMAs and every activation row is re-read by a quarter as many
+  // workgroups.  With 64 W rows per workgroup the 44x re-read of the activations through L2, not the
+  // weights, bounded the prefill call (profiles/r01_kbench_moe_v*.txt: 327 -> 505 TFLOP/s at T = 8192).
+  constexpr int NG = (BM == 128) ? 4 : 1;         // groups of 16 W rows per wave
   constexpr int KC = 256 / NG;                    // K chunk staged per barrier pair
   constexpr int BNW = 16 * NG;                    // W rows per wave
   constexpr int MT = BM / 16;                     // m-tiles of 16 rows
@@ -272,7 +273,7 @@ int launch_skinny_gemm(OutT* c, const T* a, const T* w, const float* topk_weight
   if (GROUPED || ksplit < 1 || !partial_ws || N % 4 != 0 || ldc % 4 != 0) ksplit = 1;
   const int cps = (chunks + ksplit - 1) / ksplit;
   ksplit = (chunks + cps - 1) / cps;  // no empty splits
-  constexpr int64_t kRowsPerWg = (BM == 128) ? 128 : 64;  // W rows per workgroup (see NG in the kernel)
+  constexpr int64_t kRowsPerWg = (BM == 128) ? 256 : 64;  // W rows per workgroup (see NG in the kernel)
   dim3 grid((unsigned)((N + kRowsPerWg - 1) / kRowsPerWg), (unsigned)m_blocks, (unsigned)ksplit);
   hipLaunchKernelGGL((skinny_gemm_kernel<T, OutT, GROUPED, BM>), grid, dim3(256), 0, st, c, a, w, topk_weights,
                      sorted_ids, expert_ids, num_post_pad, num_valid, M, N, K, lda, ldc, top_k_div,
