@@ -15,6 +15,7 @@ layout chosen for one 288 GB HBM3E device:
 """
 from __future__ import annotations
 
+import collections
 from typing import List, Optional, Tuple, Union
 
 import torch
@@ -58,7 +59,10 @@ class ReqToTokenPool:
 
 
 class TokenToKVPoolAllocator:
-    """Free list of KV slots 1..size (int64, FIFO like the reference's tensor slicing)."""
+    """Free list of KV slots 1..size (int64, FIFO like the reference's tensor slicing,
+    mem_cache/memory_pool.py:130-190).  The list is kept as a deque of chunks: allocation takes from the
+    head, a free appends one chunk at the tail, so neither is O(pool size) (the reference re-concatenates
+    the whole free tensor on every free)."""
 
     def __init__(self, size: int, dtype: torch.dtype, device: str, kvcache):
         self.size = size
@@ -71,24 +75,36 @@ class TokenToKVPoolAllocator:
         self.clear()
 
     def available_size(self):
-        return len(self.free_slots)
+        return self._avail
 
     def get_kvcache(self):
         return self._kvcache
 
     def alloc(self, need_size: int) -> Optional[torch.Tensor]:
-        if need_size > len(self.free_slots):
+        if need_size > self._avail:
             return None
-        select_index = self.free_slots[:need_size]
-        self.free_slots = self.free_slots[need_size:]
-        return select_index
+        parts, need = [], int(need_size)
+        while need > 0:
+            head = self._chunks[0]
+            if head.numel() <= need:
+                parts.append(self._chunks.popleft())
+                need -= head.numel()
+            else:
+                parts.append(head[:need])
+                self._chunks[0] = head[need:]
+                need = 0
+        self._avail -= int(need_size)
+        if not parts:
+            return torch.empty(0, dtype=torch.int64)
+        return parts[0] if len(parts) == 1 else torch.cat(parts)
 
     def free(self, free_index: torch.Tensor):
         if free_index.numel() == 0:
             return
         free_index = free_index.to("cpu", torch.int64)
         if self.is_not_in_free_group:
-            self.free_slots = torch.concat((self.free_slots, free_index))
+            self._chunks.append(free_index)
+            self._avail += free_index.numel()
         else:
             self.free_group.append(free_index)
 
@@ -101,9 +117,15 @@ class TokenToKVPoolAllocator:
         if self.free_group:
             self.free(torch.concat(self.free_group))
 
+    @property
+    def free_slots(self) -> torch.Tensor:
+        """The free list in allocation order (diagnostics / tests)."""
+        return torch.cat(list(self._chunks)) if self._chunks else torch.empty(0, dtype=torch.int64)
+
     def clear(self):
         # slot 0 is reserved for dummy writes of padded tokens
-        self.free_slots = torch.arange(1, self.size + 1, dtype=torch.int64)
+        self._chunks = collections.deque([torch.arange(1, self.size + 1, dtype=torch.int64)])
+        self._avail = self.size
         self.is_not_in_free_group = True
         self.free_group = []
 
