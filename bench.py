@@ -214,7 +214,7 @@ def main():
                     max_total_tokens=args.max_total_tokens, prefill_cu_percent=args.prefill_cu,
                     decode_cu_percent=args.decode_cu, cu_mask_mode=args.cu_mask_mode,
                     disable_cuda_graph=args.disable_cuda_graph, nccl_port_base=port_base,
-                    kv_cache_dtype=args.kv_cache_dtype,
+                    kv_cache_dtype=args.kv_cache_dtype, cuda_graph_max_bs=min(1024, 256 * world),
                     collect_kernel_timing=not args.no_kernel_timing, random_seed=args.seed,
                     dist_init_addr=os.environ.get("MASTER_ADDR", "127.0.0.1"), watchdog_timeout=600.0)
     if args.mode == "unified" and world > 1:

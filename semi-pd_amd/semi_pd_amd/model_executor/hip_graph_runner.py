@@ -13,8 +13,10 @@ from semi_pd_amd.model_executor.forward_batch_info import ForwardBatch, ForwardM
 
 
 def get_batch_sizes_to_capture(max_bs: int) -> List[int]:
-    """cuda_graph_runner.py:109-150: [1, 2, 4] + multiples of 8 up to 160 (HIP: up to 256)."""
-    bs = [1, 2, 4] + [8 * i for i in range(1, 33)]
+    """cuda_graph_runner.py:109-150: [1, 2, 4] + multiples of 8 up to 160 (HIP: up to 256); above that
+    (large TP groups serving many requests) coarser steps up to 1024 so that a burst does not fall off
+    the graphs into eager launches."""
+    bs = [1, 2, 4] + [8 * i for i in range(1, 33)] + list(range(288, 513, 32)) + list(range(576, 1025, 64))
     return [b for b in bs if b <= max_bs]
 
 
