@@ -185,7 +185,8 @@ def build_app(tokenizer_manager, server_args) -> FastAPI:
             raise ValueError("chat completions need a tokenizer (server runs with --skip-tokenizer-init)")
         if getattr(tok, "chat_template", None):
             ids = tok.apply_chat_template(messages, tokenize=True, add_generation_prompt=True)
-            return list(ids["input_ids"] if isinstance(ids, dict) else ids)
+            # transformers 4 returns the id list, transformers 5 a BatchEncoding (a Mapping, not a dict)
+            return [int(t) for t in (ids["input_ids"] if hasattr(ids, "keys") else ids)]
         text = "".join(f"{m['role']}: {m['content']}\n" for m in messages) + "assistant:"
         return tok.encode(text)
 
