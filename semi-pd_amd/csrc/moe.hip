@@ -2,6 +2,8 @@
 // plus the lm_head GEMM + greedy argmax that reuses the same MFMA tile (a8/a9).
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace semipd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -383,12 +385,12 @@ gemm_nt_kernel(OutT* __restrict__ c, const T* __restrict__ a, const T* __restric
 
 // defined in skinny_gemm.hip
 bool skinny_gemm_ok(int64_t K, int64_t lda, const void* a, const void* w);
-template <typename T, typename OutT, bool GROUPED, int BM = 64>
+template <typename T, typename OutT, bool GROUPED, int BM = 64, int NG = (BM == 128 ? 4 : 1)>
 int launch_skinny_gemm(OutT* c, const T* a, const T* w, const float* topk_weights, const int32_t* sorted_ids,
                        const int32_t* expert_ids, const int32_t* num_post_pad, int64_t num_valid, int64_t M,
                        int64_t N, int64_t K, int64_t lda, int64_t ldc, int64_t m_blocks, int top_k_div,
                        int mul_routed_weight, hipStream_t st, int ksplit, float* partial_ws);
-int skinny_pick_ksplit(int64_t rows, int64_t N, int64_t K, int64_t m_blocks, int num_cus);
+int skinny_pick_ksplit(int64_t rows, int64_t N, int64_t K, int64_t m_blocks, int num_cus, int rows_per_wg);
 
 }  // namespace semipd
 
@@ -542,13 +544,24 @@ int semipd_linear(void* out, const void* x, const void* weight, void* workspace,
   SEMIPD_CHECK_ARG(skinny_gemm_ok(k, ldx, x, weight) && n % 4 == 0 && ldo % 4 == 0 && aligned16(out), SEMIPD_EALIGN,
                    "linear: k %% 32, n %% 4, 16-byte aligned rows required");
   const int64_t m_blocks = (rows + 63) / 64;
+  // W rows per workgroup (64 x NG): wide workgroups for wide layers keep the launch within ONE round of
+  // workgroup slots on the CUs the process owns (no tail), narrow ones + split-K for the square layers
+  int ng = n >= 16384 ? 2 : 1;
+  if (const char* e = getenv("SEMIPD_LINEAR_NG")) ng = atoi(e) == 4 ? 4 : atoi(e) == 2 ? 2 : 1;
   int ksplit = 1;
   if (workspace && aligned16(workspace)) {
-    ksplit = skinny_pick_ksplit(rows, n, k, m_blocks, num_cus);
+    ksplit = skinny_pick_ksplit(rows, n, k, m_blocks, num_cus, 64 * ng);
+    if (const char* e = getenv("SEMIPD_LINEAR_KSPLIT")) ksplit = atoi(e) > 0 ? atoi(e) : ksplit;
     const size_t plane = (size_t)(m_blocks * 64) * n * 4;
     while (ksplit > 1 && (size_t)ksplit * plane > workspace_bytes) --ksplit;
   }
-  SEMIPD_DISPATCH_HALF(dtype, T, return (launch_skinny_gemm<T, T, false>((T*)out, (const T*)x, (const T*)weight, nullptr, nullptr, nullptr, nullptr, (int64_t)0, rows, n, k, ldx, ldo, m_blocks, 1, 0, as_stream(stream), ksplit, ksplit > 1 ? (float*)workspace : nullptr)));
+  float* ws = ksplit > 1 ? (float*)workspace : nullptr;
+  if (ng == 4) {
+    SEMIPD_DISPATCH_HALF(dtype, T, return (launch_skinny_gemm<T, T, false, 64, 4>((T*)out, (const T*)x, (const T*)weight, nullptr, nullptr, nullptr, nullptr, (int64_t)0, rows, n, k, ldx, ldo, m_blocks, 1, 0, as_stream(stream), ksplit, ws)));
+  } else if (ng == 2) {
+    SEMIPD_DISPATCH_HALF(dtype, T, return (launch_skinny_gemm<T, T, false, 64, 2>((T*)out, (const T*)x, (const T*)weight, nullptr, nullptr, nullptr, nullptr, (int64_t)0, rows, n, k, ldx, ldo, m_blocks, 1, 0, as_stream(stream), ksplit, ws)));
+  }
+  SEMIPD_DISPATCH_HALF(dtype, T, return (launch_skinny_gemm<T, T, false, 64, 1>((T*)out, (const T*)x, (const T*)weight, nullptr, nullptr, nullptr, nullptr, (int64_t)0, rows, n, k, ldx, ldo, m_blocks, 1, 0, as_stream(stream), ksplit, ws)));
   return 0;
 }
 

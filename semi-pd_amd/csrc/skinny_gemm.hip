@@ -37,7 +37,7 @@ template <> struct MfmaS<f16_t> {
   }
 };
 
-template <typename T, typename OutT, bool GROUPED, int BM>
+template <typename T, typename OutT, bool GROUPED, int BM, int NG>
 __global__ void __launch_bounds__(256, 2)
 skinny_gemm_kernel(OutT* __restrict__ c, const T* __restrict__ a, const T* __restrict__ w,
                    const float* __restrict__ topk_weights, const int32_t* __restrict__ sorted_ids,
@@ -50,7 +50,7 @@ skinny_gemm_kernel(OutT* __restrict__ c, const T* __restrict__ a, const T* __res
   // activation fragment feeds four MFMAs and every activation row is re-read by a quarter as many
   // workgroups.  With 64 W rows per workgroup the 44x re-read of the activations through L2, not the
   // weights, bounded the prefill call (profiles/r01_kbench_moe_v*.txt: 327 -> 505 TFLOP/s at T = 8192).
-  constexpr int NG = (BM == 128) ? 4 : 1;         // groups of 16 W rows per wave
+  static_assert(NG == 1 || NG == 2 || NG == 4, "NG = groups of 16 W rows per wave");
   constexpr int KC = 256 / NG;                    // K chunk staged per barrier pair
   constexpr int BNW = 16 * NG;                    // W rows per wave
   constexpr int MT = BM / 16;                     // m-tiles of 16 rows
@@ -264,7 +264,7 @@ splitk_reduce_kernel(OutT* __restrict__ c, const float* __restrict__ partial, in
   }
 }
 
-template <typename T, typename OutT, bool GROUPED, int BM = 64>
+template <typename T, typename OutT, bool GROUPED, int BM = 64, int NG = (BM == 128 ? 4 : 1)>
 int launch_skinny_gemm(OutT* c, const T* a, const T* w, const float* topk_weights, const int32_t* sorted_ids,
                        const int32_t* expert_ids, const int32_t* num_post_pad, int64_t num_valid, int64_t M,
                        int64_t N, int64_t K, int64_t lda, int64_t ldc, int64_t m_blocks, int top_k_div,
@@ -273,9 +273,9 @@ int launch_skinny_gemm(OutT* c, const T* a, const T* w, const float* topk_weight
   if (GROUPED || ksplit < 1 || !partial_ws || N % 4 != 0 || ldc % 4 != 0) ksplit = 1;
   const int cps = (chunks + ksplit - 1) / ksplit;
   ksplit = (chunks + cps - 1) / cps;  // no empty splits
-  constexpr int64_t kRowsPerWg = (BM == 128) ? 256 : 64;  // W rows per workgroup (see NG in the kernel)
+  constexpr int64_t kRowsPerWg = 64 * NG;  // W rows per workgroup: 4 waves x NG groups of 16
   dim3 grid((unsigned)((N + kRowsPerWg - 1) / kRowsPerWg), (unsigned)m_blocks, (unsigned)ksplit);
-  hipLaunchKernelGGL((skinny_gemm_kernel<T, OutT, GROUPED, BM>), grid, dim3(256), 0, st, c, a, w, topk_weights,
+  hipLaunchKernelGGL((skinny_gemm_kernel<T, OutT, GROUPED, BM, NG>), grid, dim3(256), 0, st, c, a, w, topk_weights,
                      sorted_ids, expert_ids, num_post_pad, num_valid, M, N, K, lda, ldc, top_k_div,
                      mul_routed_weight, cps, partial_ws);
   int rc = launch_status("skinny_gemm");
@@ -288,9 +288,9 @@ int launch_skinny_gemm(OutT* c, const T* a, const T* w, const float* topk_weight
 
 // Split-K factor for a weight-streaming call on `num_cus` compute units: fill every workgroup slot
 // (3 workgroups per CU at 152 VGPRs) in whole rounds, keep >= 2 K-chunks per split.
-int skinny_pick_ksplit(int64_t rows, int64_t N, int64_t K, int64_t m_blocks, int num_cus) {
+int skinny_pick_ksplit(int64_t rows, int64_t N, int64_t K, int64_t m_blocks, int num_cus, int rows_per_wg) {
   const int chunks = (int)((K + 255) / 256);
-  const double tiles = (double)((N + 63) / 64) * (double)m_blocks;
+  const double tiles = (double)((N + rows_per_wg - 1) / rows_per_wg) * (double)m_blocks;
   const double slots = (double)(num_cus > 0 ? num_cus : 256) * 3.0;
   // time model: weight bytes at ~20 GB/s per resident workgroup slot in use (5 TB/s over a full chip),
   // scaled by how evenly the rounds fill the slots and the K-chunks fill the splits; a split adds
@@ -316,19 +316,23 @@ int skinny_pick_ksplit(int64_t rows, int64_t N, int64_t K, int64_t m_blocks, int
   return best;
 }
 
-#define SKINNY_INST(T, OutT, G, BM)                                                                        \
-  template int launch_skinny_gemm<T, OutT, G, BM>(OutT*, const T*, const T*, const float*, const int32_t*, \
-                                                  const int32_t*, const int32_t*, int64_t, int64_t, int64_t, \
-                                                  int64_t, int64_t, int64_t, int64_t, int, int, hipStream_t, \
-                                                  int, float*);
-SKINNY_INST(bf16_t, bf16_t, true, 64)
-SKINNY_INST(f16_t, f16_t, true, 64)
-SKINNY_INST(bf16_t, bf16_t, true, 128)
-SKINNY_INST(f16_t, f16_t, true, 128)
-SKINNY_INST(bf16_t, float, false, 64)
-SKINNY_INST(f16_t, float, false, 64)
-SKINNY_INST(bf16_t, bf16_t, false, 64)
-SKINNY_INST(f16_t, f16_t, false, 64)
+#define SKINNY_INST(T, OutT, G, BM, NG)                                                                        \
+  template int launch_skinny_gemm<T, OutT, G, BM, NG>(OutT*, const T*, const T*, const float*, const int32_t*, \
+                                                      const int32_t*, const int32_t*, int64_t, int64_t, int64_t, \
+                                                      int64_t, int64_t, int64_t, int64_t, int, int, hipStream_t, \
+                                                      int, float*);
+SKINNY_INST(bf16_t, bf16_t, true, 64, 1)
+SKINNY_INST(f16_t, f16_t, true, 64, 1)
+SKINNY_INST(bf16_t, bf16_t, true, 128, 4)
+SKINNY_INST(f16_t, f16_t, true, 128, 4)
+SKINNY_INST(bf16_t, float, false, 64, 1)
+SKINNY_INST(f16_t, float, false, 64, 1)
+SKINNY_INST(bf16_t, bf16_t, false, 64, 1)
+SKINNY_INST(f16_t, f16_t, false, 64, 1)
+SKINNY_INST(bf16_t, bf16_t, false, 64, 2)
+SKINNY_INST(f16_t, f16_t, false, 64, 2)
+SKINNY_INST(bf16_t, bf16_t, false, 64, 4)
+SKINNY_INST(f16_t, f16_t, false, 64, 4)
 #undef SKINNY_INST
 
 }  // namespace semipd

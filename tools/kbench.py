@@ -224,8 +224,47 @@ def bench_linear():
             del ws
 
 
+def bench_linear_sweep():
+    """ops.linear with every (NG, ksplit) forced through SEMIPD_LINEAR_NG / SEMIPD_LINEAR_KSPLIT vs hipBLASLt."""
+    import torch.nn.functional as F
+    print("# decode linear sweep: M, N, K: hipBLASLt us | best (NG, ksplit) us | all   HSA_CU_MASK=%s"
+          % os.environ.get("HSA_CU_MASK", "-"))
+    ncu = int(os.environ.get("KBENCH_NUM_CUS", "0"))
+    for M in (16, 48):
+        for (N, K) in ((28672, 4096), (4096, 14336), (6144, 4096), (4096, 4096)):
+            copies = max(2, int(1.2e9 // (N * K * 2)))
+            ws = [torch.randn(N, K, device=dev, dtype=torch.bfloat16) * 0.02 for _ in range(copies)]
+            x = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
+            it = [0]
+
+            def f1():
+                it[0] += 1
+                return F.linear(x, ws[it[0] % copies])
+
+            def f2():
+                it[0] += 1
+                return ops.linear(x, ws[it[0] % copies], num_cus=ncu)
+            t1 = timeit(f1, iters=3 * copies)
+            res = {}
+            for ng in (1, 2, 4):
+                for ks in (1, 2, 3, 4, 6, 8):
+                    if ks > 1 and (K // 256) // ks < 2:
+                        continue
+                    os.environ["SEMIPD_LINEAR_NG"], os.environ["SEMIPD_LINEAR_KSPLIT"] = str(ng), str(ks)
+                    res[(ng, ks)] = timeit(f2, iters=2 * copies) * 1e6
+            os.environ.pop("SEMIPD_LINEAR_NG"), os.environ.pop("SEMIPD_LINEAR_KSPLIT")
+            t_auto = timeit(f2, iters=3 * copies) * 1e6
+            best = min(res, key=res.get)
+            row = " ".join(f"{ng}/{ks}:{t:.0f}" for (ng, ks), t in sorted(res.items()))
+            print(f"M={M:3d} N={N:6d} K={K:6d}: blaslt {t1 * 1e6:6.1f} | best NG={best[0]} ks={best[1]} {res[best]:6.1f} "
+                  f"| auto {t_auto:6.1f} | {row}")
+            del ws
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which == "linear_sweep":
+        bench_linear_sweep()
     if which == "linear":
         bench_linear()
     if which == "decode_small":
