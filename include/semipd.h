@@ -238,6 +238,11 @@ int semipd_top_k_renorm_prob(const float* probs, float* out, const int32_t* top_
  * replaces top_p_renorm_probs (torch_extension.cc:152-154; tests/test_sampling.py:57-81). */
 int semipd_top_p_renorm_prob(const float* probs, float* out, const float* top_ps, float top_p_val,
                              int64_t batch, int64_t vocab, void* stream);
+/* out[b] = log_softmax(logits[b])[ids[b]] (fp32), lse[b] = logsumexp(logits[b]) (may be NULL).
+ * replaces the return_logprob branch of Sampler.forward on greedy batches: log_softmax + gather
+ *   (layers/sampler.py:74-75, 139-155). */
+int semipd_token_logprobs(const float* logits, const int32_t* ids, float* out, float* lse, int64_t batch,
+                          int64_t vocab, void* stream);
 
 /* ------------------------------------------------------------------ */
 /* a10/a11/a12  MoE                                                    */

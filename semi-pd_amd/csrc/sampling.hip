@@ -330,6 +330,29 @@ renorm_kernel(const float* __restrict__ probs, float* __restrict__ out, const in
   }
 }
 
+// out[b] = log_softmax(logits[b])[ids[b]] and lse[b] = logsumexp(logits[b])  (Sampler.forward with
+// return_logprob on a greedy batch: layers/sampler.py:74-75, 139-155); the top-k logprobs are
+// topk(logits) - lse on the host side of the op.
+template <bool VEC>
+__global__ void __launch_bounds__(kST)
+token_logprob_kernel(const float* __restrict__ logits, const int32_t* __restrict__ ids, float* __restrict__ out,
+                     float* __restrict__ lse, int V) {
+  __shared__ SampLds s;
+  const float* row = logits + (int64_t)blockIdx.x * V;
+  float m = -INFINITY;
+  visit_row<VEC>(row, V, [&](float x, int) { m = fmaxf(m, x); });
+  m = block_max_f(m, s);
+  float acc[1] = {0.f};
+  visit_row<VEC>(row, V, [&](float x, int) { acc[0] += expf(x - m); });
+  block_sum_n<1>(acc, s);
+  if (threadIdx.x == 0) {
+    const float l = m + logf(acc[0]);
+    if (lse) lse[blockIdx.x] = l;
+    const int id = ids[blockIdx.x];
+    out[blockIdx.x] = (id >= 0 && id < V) ? row[id] - l : -INFINITY;
+  }
+}
+
 static bool rows_vec_ok(const void* p, int64_t V) { return V % 4 == 0 && aligned16(p); }
 
 }  // namespace semipd
@@ -398,6 +421,20 @@ int semipd_top_k_renorm_prob(const float* probs, float* out, const int32_t* top_
     hipLaunchKernelGGL((renorm_kernel<false, false>), dim3((unsigned)batch), dim3(kST), 0, as_stream(stream),
                        probs, out, top_ks, top_k_val, (const float*)nullptr, 0.f, (int)vocab);
   return launch_status("top_k_renorm_prob");
+}
+
+int semipd_token_logprobs(const float* logits, const int32_t* ids, float* out, float* lse, int64_t batch,
+                          int64_t vocab, void* stream) {
+  SEMIPD_CHECK_ARG(logits && ids && out && batch >= 0 && vocab > 0 && vocab < (1ll << 30), SEMIPD_EINVAL,
+                   "token_logprobs: bad arguments");
+  if (batch == 0) return 0;
+  if (rows_vec_ok(logits, vocab))
+    hipLaunchKernelGGL((token_logprob_kernel<true>), dim3((unsigned)batch), dim3(kST), 0, as_stream(stream), logits,
+                       ids, out, lse, (int)vocab);
+  else
+    hipLaunchKernelGGL((token_logprob_kernel<false>), dim3((unsigned)batch), dim3(kST), 0, as_stream(stream), logits,
+                       ids, out, lse, (int)vocab);
+  return launch_status("token_logprobs");
 }
 
 int semipd_top_p_renorm_prob(const float* probs, float* out, const float* top_ps, float top_p_val,

@@ -59,6 +59,7 @@ _SIGNATURES = {
     "semipd_min_p_sampling_from_probs": [_vp, _vp, _vp, _f32, _vp, _i64, _i64, _vp],
     "semipd_top_k_renorm_prob": [_vp, _vp, _vp, _i32, _i64, _i64, _vp],
     "semipd_top_p_renorm_prob": [_vp, _vp, _vp, _f32, _i64, _i64, _vp],
+    "semipd_token_logprobs": [_vp, _vp, _vp, _vp, _i64, _i64, _vp],
     "semipd_topk_softmax": [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp],
     "semipd_grouped_topk": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "semipd_moe_align_block_size": [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp],

@@ -126,6 +126,7 @@ class Engine:
         self.procs: List[mp.Process] = []
         self._rid = 0
         self._outputs: Dict[str, List[int]] = {}
+        self._logprobs: Dict[str, dict] = {}
         self._finished: Dict[str, Optional[str]] = {}
         self._first_token_time: Dict[str, float] = {}
         self._token_times: Dict[str, List[float]] = {}
@@ -252,13 +253,16 @@ class Engine:
 
     # ------------------------------------------------------------------------------------ client API
     def add_request(self, input_ids: Sequence[int], sampling_params: SamplingParams,
-                    rid: Optional[str] = None) -> str:
+                    rid: Optional[str] = None, return_logprob: bool = False, top_logprobs_num: int = 0) -> str:
         if rid is None:
             rid = f"r{self._rid}"
             self._rid += 1
         req = TokenizedGenerateReqInput(rid=rid, input_text=None, input_ids=list(input_ids),
-                                        sampling_params=sampling_params)
+                                        sampling_params=sampling_params, return_logprob=bool(return_logprob),
+                                        top_logprobs_num=int(top_logprobs_num))
         self._outputs[rid] = []
+        if return_logprob:
+            self._logprobs[rid] = {"token": [], "top": []}
         self._finished[rid] = None
         self._token_times[rid] = []
         self._send_time[rid] = time.time()
@@ -271,10 +275,14 @@ class Engine:
     def _handle_output(self, obj):
         if isinstance(obj, BatchTokenIDOut):
             now = time.time()
-            for rid, fin, toks in zip(obj.rids, obj.finished_reasons, obj.output_ids):
+            for i, (rid, fin, toks) in enumerate(zip(obj.rids, obj.finished_reasons, obj.output_ids)):
                 if rid not in self._outputs:
                     continue
                 self._outputs[rid].extend(toks)
+                if obj.output_token_logprobs is not None and rid in self._logprobs \
+                        and obj.output_token_logprobs[i] is not None:
+                    self._logprobs[rid]["token"].extend(obj.output_token_logprobs[i])
+                    self._logprobs[rid]["top"].extend(obj.output_top_logprobs[i])
                 self._token_times[rid].extend([now] * len(toks))
                 if fin is not None:
                     self._finished[rid] = fin
@@ -314,14 +322,20 @@ class Engine:
                 raise TimeoutError(f"{len(pending)} requests unfinished after {timeout}s")
 
     def generate(self, prompts: Sequence[Sequence[int]], sampling_params: SamplingParams,
-                 timeout: float = 3600.0) -> List[List[int]]:
+                 timeout: float = 3600.0, return_logprob: bool = False, top_logprobs_num: int = 0):
+        """Blocking helper: token ids per prompt; with return_logprob also (ids, logprobs) where logprobs[i] =
+        {"token": [...], "top": [[(logprob, token id), ...], ...]}."""
         import copy
         per_req = sampling_params if isinstance(sampling_params, (list, tuple)) else [sampling_params] * len(prompts)
         if len(per_req) != len(prompts):
             raise ValueError("generate: one SamplingParams per prompt (or a single one for all) expected")
-        rids = [self.add_request(p, copy.deepcopy(sp)) for p, sp in zip(prompts, per_req)]
+        rids = [self.add_request(p, copy.deepcopy(sp), return_logprob=return_logprob,
+                                 top_logprobs_num=top_logprobs_num) for p, sp in zip(prompts, per_req)]
         self.wait(rids, timeout)
-        return [self._outputs[r] for r in rids]
+        outs = [self._outputs[r] for r in rids]
+        if return_logprob:
+            return outs, [self._logprobs[r] for r in rids]
+        return outs
 
     def request_record(self, rid: str) -> dict:
         return {"send": self._send_time[rid], "token_times": self._token_times[rid],

@@ -53,6 +53,38 @@ def _openai_sampling(body: dict, default_max_tokens: Optional[int]) -> dict:
     return sp
 
 
+def _completion_logprobs(meta: dict, base_offset: int = 0) -> Optional[dict]:
+    """OpenAI completions `logprobs` object from meta_info (adapter.py to_openai_style_logprobs)."""
+    toks = meta.get("output_token_logprobs")
+    if toks is None:
+        return None
+    out = {"tokens": [], "token_logprobs": [], "top_logprobs": [], "text_offset": []}
+    off = base_offset
+    for (lp, tid, txt), top in zip(toks, meta.get("output_top_logprobs") or [None] * len(toks)):
+        piece = txt if txt is not None else str(tid)
+        out["tokens"].append(piece)
+        out["token_logprobs"].append(lp)
+        out["text_offset"].append(off)
+        off += len(piece)
+        out["top_logprobs"].append({(t if t is not None else str(i)): l for l, i, t in top} if top else None)
+    return out
+
+
+def _chat_logprobs(meta: dict) -> Optional[dict]:
+    """OpenAI chat `logprobs.content` list (adapter.py v1_chat_generate_response)."""
+    toks = meta.get("output_token_logprobs")
+    if toks is None:
+        return None
+    content = []
+    for (lp, tid, txt), top in zip(toks, meta.get("output_top_logprobs") or [None] * len(toks)):
+        piece = txt if txt is not None else str(tid)
+        content.append({"token": piece, "logprob": lp, "bytes": list(piece.encode("utf-8")),
+                        "top_logprobs": [{"token": (t if t is not None else str(i)), "logprob": l,
+                                          "bytes": list((t if t is not None else str(i)).encode("utf-8"))}
+                                         for l, i, t in (top or [])]})
+    return {"content": content}
+
+
 def build_app(tokenizer_manager, server_args) -> FastAPI:
     app = FastAPI()
     tm = tokenizer_manager
@@ -128,6 +160,8 @@ def build_app(tokenizer_manager, server_args) -> FastAPI:
         if prompt is None:
             return _error("prompt is required")
         obj: Dict[str, Any] = {"sampling_params": _openai_sampling(body, 16), "stream": bool(body.get("stream"))}
+        if body.get("logprobs") is not None and body.get("logprobs") is not False:
+            obj.update(return_logprob=True, top_logprobs_num=int(body["logprobs"]), return_text_in_logprobs=True)
         if isinstance(prompt, str) or (isinstance(prompt, list) and prompt and isinstance(prompt[0], str)):
             obj["text"] = prompt
         else:
@@ -154,8 +188,10 @@ def build_app(tokenizer_manager, server_args) -> FastAPI:
                         delta = text[start:] if start is not None else prompt_text(i) + text
                         sent[i] = len(text)
                         meta = out["meta_info"]
+                        final = meta.get("finish_reason") is not None
                         chunk = {"id": rid, "object": "text_completion", "created": created, "model": model_name,
-                                 "choices": [{"index": i, "text": delta, "logprobs": None,
+                                 "choices": [{"index": i, "text": delta,
+                                              "logprobs": _completion_logprobs(meta) if final else None,
                                               "finish_reason": _openai_finish(meta)}]}
                         if meta.get("finish_reason") is not None:
                             chunk["usage"] = {"prompt_tokens": meta["prompt_tokens"],
@@ -171,7 +207,8 @@ def build_app(tokenizer_manager, server_args) -> FastAPI:
         except ValueError as e:
             return _error(str(e))
         rets = ret if isinstance(ret, list) else [ret]
-        choices = [{"index": i, "text": prompt_text(i) + r.get("text", ""), "logprobs": None,
+        choices = [{"index": i, "text": prompt_text(i) + r.get("text", ""),
+                    "logprobs": _completion_logprobs(r["meta_info"], len(prompt_text(i))),
                     "finish_reason": _openai_finish(r["meta_info"])} for i, r in enumerate(rets)]
         pt = sum(r["meta_info"]["prompt_tokens"] for r in rets)
         ct = sum(r["meta_info"]["completion_tokens"] for r in rets)
@@ -204,6 +241,9 @@ def build_app(tokenizer_manager, server_args) -> FastAPI:
         except ValueError as e:
             return _error(str(e))
         obj = {"input_ids": ids, "sampling_params": _openai_sampling(body, None), "stream": bool(body.get("stream"))}
+        if body.get("logprobs"):
+            obj.update(return_logprob=True, top_logprobs_num=int(body.get("top_logprobs") or 0),
+                       return_text_in_logprobs=True)
         rid = "chatcmpl-" + uuid.uuid4().hex
         created = int(time.time())
         if obj["stream"]:
@@ -221,6 +261,8 @@ def build_app(tokenizer_manager, server_args) -> FastAPI:
                         delta, sent = text[sent:], len(text)
                         chunk = {"id": rid, "object": "chat.completion.chunk", "created": created, "model": model_name,
                                  "choices": [{"index": 0, "delta": {"content": delta},
+                                              "logprobs": (_chat_logprobs(meta)
+                                                           if meta.get("finish_reason") is not None else None),
                                               "finish_reason": _openai_finish(meta)}]}
                         if meta.get("finish_reason") is not None:
                             chunk["usage"] = {"prompt_tokens": meta["prompt_tokens"],
@@ -238,7 +280,7 @@ def build_app(tokenizer_manager, server_args) -> FastAPI:
         meta = r["meta_info"]
         return {"id": rid, "object": "chat.completion", "created": created, "model": model_name,
                 "choices": [{"index": 0, "message": {"role": "assistant", "content": r.get("text", "")},
-                             "logprobs": None, "finish_reason": _openai_finish(meta)}],
+                             "logprobs": _chat_logprobs(meta), "finish_reason": _openai_finish(meta)}],
                 "usage": {"prompt_tokens": meta["prompt_tokens"], "completion_tokens": meta["completion_tokens"],
                           "total_tokens": meta["prompt_tokens"] + meta["completion_tokens"]}}
 

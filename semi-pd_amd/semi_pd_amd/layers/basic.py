@@ -337,6 +337,10 @@ class LogitsProcessorOutput:
     next_token_logits: Optional[torch.Tensor]
     next_token_ids: Optional[torch.Tensor] = None
     hidden_states: Optional[torch.Tensor] = None
+    # filled by the sampler when a request asked for logprobs (logits_processor.py:40-70)
+    next_token_logprobs: Optional[torch.Tensor] = None            # fp32 [B]
+    next_token_top_logprobs_val: Optional[list] = None            # per row: k values (descending)
+    next_token_top_logprobs_idx: Optional[list] = None            # per row: k token ids
 
 
 class LogitsProcessor(nn.Module):
@@ -377,14 +381,31 @@ class Sampler(nn.Module):
 
     MAX_TOP_K_ROUND = 32  # sampler.py:92
 
-    def forward(self, logits_output: LogitsProcessorOutput, sampling_info=None) -> torch.Tensor:
+    def forward(self, logits_output: LogitsProcessorOutput, sampling_info=None, return_logprob: bool = False,
+                top_logprobs_nums: Optional[list] = None) -> torch.Tensor:
         if sampling_info is None or getattr(sampling_info, "is_all_greedy", True):
-            if logits_output.next_token_ids is not None:
-                return logits_output.next_token_ids
             logits = logits_output.next_token_logits
-            if not logits.is_contiguous():
-                logits = logits.contiguous()
-            return ops.greedy_argmax(logits)
+            if logits_output.next_token_ids is not None:
+                ids = logits_output.next_token_ids
+            else:
+                if not logits.is_contiguous():
+                    logits = logits.contiguous()
+                ids = ops.greedy_argmax(logits)
+            if return_logprob:
+                # logprobs = log_softmax(logits) (sampler.py:74-75); only the gathered values and the
+                # top-k rows are materialised
+                if logits is None:
+                    raise RuntimeError("Sampler: return_logprob needs the fp32 logits")
+                logits = logits if (logits.dtype == torch.float32 and logits.is_contiguous()) else \
+                    logits.float().contiguous()
+                token_lp, lse = ops.token_logprobs(logits, ids)
+
+                def top_logprobs(k):
+                    vals, idx = torch.topk(logits, k, dim=-1)
+                    return vals - lse[:, None], idx
+
+                self._attach_logprobs(logits_output, token_lp, top_logprobs_nums, top_logprobs)
+            return ids
         logits = logits_output.next_token_logits
         if logits is None:
             raise RuntimeError("Sampler: stochastic sampling needs the fp32 logits")
@@ -396,10 +417,27 @@ class Sampler(nn.Module):
         probs = ops.softmax_temperature_(logits, sampling_info.temperatures)  # in place, like the reference
         uniform_samples = torch.rand((self.MAX_TOP_K_ROUND, batch), device=probs.device)
         if sampling_info.need_min_p_sampling:
-            probs = ops.top_k_renorm_prob(probs, sampling_info.top_ks)
-            probs = ops.top_p_renorm_prob(probs, sampling_info.top_ps)
-            ids = ops.min_p_sampling_from_probs(probs, uniform_samples, sampling_info.min_ps)
+            filtered = ops.top_k_renorm_prob(probs, sampling_info.top_ks)
+            filtered = ops.top_p_renorm_prob(filtered, sampling_info.top_ps)
+            ids = ops.min_p_sampling_from_probs(filtered, uniform_samples, sampling_info.min_ps)
         else:
             ids, _ = ops.top_k_top_p_sampling_from_probs(probs, uniform_samples, sampling_info.top_ks,
                                                          sampling_info.top_ps, filter_apply_order="joint")
+        if return_logprob:
+            # logprobs = log(top-p-normalised probs), clamped away from -inf (sampler.py:84-89, 121-125)
+            lp = torch.log(ops.top_p_renorm_prob(probs, sampling_info.top_ps)).clamp_(
+                min=torch.finfo(torch.float32).min)
+            token_lp = lp.gather(1, ids.long().view(-1, 1)).view(-1)
+            self._attach_logprobs(logits_output, token_lp, top_logprobs_nums, lambda k: torch.topk(lp, k, dim=-1))
         return ids
+
+    @staticmethod
+    def _attach_logprobs(out: LogitsProcessorOutput, token_lp: torch.Tensor, top_nums, topk_fn):
+        """sampler.py:139-155 + get_top_logprobs (:246-262): one top-k of the largest k requested."""
+        out.next_token_logprobs = token_lp
+        kmax = max(top_nums) if top_nums else 0
+        if kmax > 0:
+            vals, idx = topk_fn(kmax)
+            vals, idx = vals.tolist(), idx.tolist()
+            out.next_token_top_logprobs_val = [v[:k] for v, k in zip(vals, top_nums)]
+            out.next_token_top_logprobs_idx = [i[:k] for i, k in zip(idx, top_nums)]

@@ -58,6 +58,7 @@ class TokenizedGenerateReqInput:
     sampling_params: SamplingParams
     stream: bool = True
     return_logprob: bool = False
+    top_logprobs_num: int = 0
     is_retracted: bool = False  # Semi-PD: re-sent to P after a decode retraction
 
 
@@ -83,6 +84,8 @@ class BatchProcessPrefillResultReq:
     when a request needs logits on the decode side (never for greedy)."""
     next_token_ids: List[int]
     next_token_logits: Optional[Any] = None
+    # per request: logprob of the sampled first token (+ top-k) when the request asked for logprobs
+    next_token_logprobs: Optional[dict] = None
 
 
 @dataclass
@@ -92,6 +95,9 @@ class BatchTokenIDOut:
     finished_reasons: List[Optional[str]]
     output_ids: List[List[int]]          # tokens emitted since the previous message
     timestamps: List[float] = field(default_factory=list)
+    # aligned with output_ids for requests with return_logprob, else None entries
+    output_token_logprobs: Optional[List[Optional[List[float]]]] = None
+    output_top_logprobs: Optional[List[Optional[List[List[tuple]]]]] = None
 
 
 @dataclass

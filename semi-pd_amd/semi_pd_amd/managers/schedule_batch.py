@@ -23,8 +23,13 @@ CLIP_MAX_NEW_TOKENS_ESTIMATION = 4096  # schedule_policy.py:36-40
 
 class Req:
     def __init__(self, rid: str, origin_input_ids: List[int], sampling_params: SamplingParams,
-                 eos_token_ids: Optional[set] = None, is_retracted: bool = False):
+                 eos_token_ids: Optional[set] = None, is_retracted: bool = False, return_logprob: bool = False,
+                 top_logprobs_num: int = 0):
         self.rid = rid
+        self.return_logprob = return_logprob
+        self.top_logprobs_num = int(top_logprobs_num)
+        self.output_token_logprobs: List[float] = []          # one per output token
+        self.output_top_logprobs: List[List[tuple]] = []      # one list of (logprob, token id) per output token
         self.origin_input_ids = list(origin_input_ids)
         self.output_ids: List[int] = []
         self.fill_ids: List[int] = []
@@ -102,6 +107,8 @@ class ModelWorkerBatch:
     extend_seq_lens: Optional[List[int]] = None
     extend_prefix_lens: Optional[List[int]] = None
     sampling_info: Optional[SamplingBatchInfo] = None
+    return_logprob: bool = False
+    top_logprobs_nums: Optional[List[int]] = None
 
 
 class ScheduleBatch:
@@ -260,7 +267,9 @@ class ScheduleBatch:
             extend_num_tokens=self.extend_num_tokens if ext else None,
             extend_seq_lens=self.extend_lens if ext else None,
             extend_prefix_lens=self.prefix_lens if ext else None,
-            sampling_info=SamplingBatchInfo.from_reqs(self.reqs, getattr(self, "vocab_size", 0), self.device))
+            sampling_info=SamplingBatchInfo.from_reqs(self.reqs, getattr(self, "vocab_size", 0), self.device),
+            return_logprob=any(r.return_logprob for r in self.reqs),
+            top_logprobs_nums=[r.top_logprobs_num if r.return_logprob else 0 for r in self.reqs])
 
 
 class AddReqResult(Enum):

@@ -114,7 +114,8 @@ class SchedulerBase:
 
     def handle_generate_request(self, recv_req: TokenizedGenerateReqInput):
         req = Req(recv_req.rid, recv_req.input_ids, recv_req.sampling_params, self.eos_token_ids,
-                  is_retracted=recv_req.is_retracted)
+                  is_retracted=recv_req.is_retracted, return_logprob=recv_req.return_logprob,
+                  top_logprobs_num=recv_req.top_logprobs_num)
         if len(req.origin_input_ids) > self.max_req_input_len:
             # validate_input_length (scheduler.py:760-775): truncate
             req.origin_input_ids = req.origin_input_ids[: self.max_req_input_len]
@@ -149,12 +150,33 @@ class SchedulerBase:
         return logits_output, next_token_ids
 
     # ---------------------------------------------------------------------------- results
-    def process_batch_result_prefill(self, batch: ScheduleBatch, next_token_ids: List[int]):
+    @staticmethod
+    def extract_logprobs(logits_output) -> Optional[dict]:
+        """Host copy of what the sampler attached for requests with return_logprob (one sync)."""
+        lp = getattr(logits_output, "next_token_logprobs", None)
+        if lp is None:
+            return None
+        return {"token": lp.tolist(), "top_val": logits_output.next_token_top_logprobs_val,
+                "top_idx": logits_output.next_token_top_logprobs_idx}
+
+    @staticmethod
+    def _record_logprob(req: Req, i: int, logprobs: Optional[dict]):
+        if not req.return_logprob or logprobs is None:
+            return
+        req.output_token_logprobs.append(float(logprobs["token"][i]))
+        if req.top_logprobs_num > 0 and logprobs.get("top_val") is not None:
+            req.output_top_logprobs.append(list(zip(logprobs["top_val"][i], logprobs["top_idx"][i])))
+        else:
+            req.output_top_logprobs.append([])
+
+    def process_batch_result_prefill(self, batch: ScheduleBatch, next_token_ids: List[int],
+                                     logprobs: Optional[dict] = None):
         """scheduler.py:1342-1420: append the first token, finish / stream, keep chunked reqs pending."""
         out_reqs = []
-        for req, tok in zip(batch.reqs, next_token_ids):
+        for i, (req, tok) in enumerate(zip(batch.reqs, next_token_ids)):
             if req.is_chunked <= 0:
                 req.output_ids.append(int(tok))
+                self._record_logprob(req, i, logprobs)
                 req.check_finished()
                 if req.finished():
                     self.tree_cache.cache_finished_req(req)
@@ -166,10 +188,12 @@ class SchedulerBase:
         self.stream_output(out_reqs)
         self.last_progress = time.monotonic()
 
-    def process_batch_result_decode(self, batch: ScheduleBatch, next_token_ids: List[int]):
+    def process_batch_result_decode(self, batch: ScheduleBatch, next_token_ids: List[int],
+                                    logprobs: Optional[dict] = None):
         self.token_to_kv_pool_allocator.free_group_begin()
-        for req, tok in zip(batch.reqs, next_token_ids):
+        for i, (req, tok) in enumerate(zip(batch.reqs, next_token_ids)):
             req.output_ids.append(int(tok))
+            self._record_logprob(req, i, logprobs)
             req.check_finished()
             if req.finished():
                 self.tree_cache.cache_finished_req(req)
@@ -187,17 +211,21 @@ class SchedulerBase:
         if self.tp_rank != 0 or self.send_to_detokenizer is None or not reqs:
             return
         now = time.time()
-        rids, fins, outs = [], [], []
+        rids, fins, outs, lps, tops = [], [], [], [], []
         for r in reqs:
             new = r.output_ids[r.send_token_offset:]
             if not new and not r.finished():
                 continue
+            lps.append(r.output_token_logprobs[r.send_token_offset:] if r.return_logprob else None)
+            tops.append(r.output_top_logprobs[r.send_token_offset:] if r.return_logprob else None)
             r.send_token_offset = len(r.output_ids)
             rids.append(r.rid)
             fins.append(r.finished_reason)
             outs.append(new)
         if rids:
-            msg = BatchTokenIDOut(rids, fins, outs, [now] * len(rids))
+            with_lp = any(x is not None for x in lps)
+            msg = BatchTokenIDOut(rids, fins, outs, [now] * len(rids), lps if with_lp else None,
+                                  tops if with_lp else None)
             if defer:
                 self._deferred_out.append(msg)
             else:
@@ -325,14 +353,15 @@ class Scheduler(SchedulerBase):
         if batch is None:
             self.last_batch = None
             return False
-        _, next_token_ids = self.run_batch(batch)
+        logits_output, next_token_ids = self.run_batch(batch)
         ids = next_token_ids.tolist()
+        logprobs = self.extract_logprobs(logits_output)
         if batch.forward_mode.is_extend():
             batch.output_ids = next_token_ids
-            self.process_batch_result_prefill(batch, ids)
+            self.process_batch_result_prefill(batch, ids, logprobs)
         else:
             batch.output_ids = next_token_ids
-            self.process_batch_result_decode(batch, ids)
+            self.process_batch_result_decode(batch, ids, logprobs)
         self.last_batch = batch
         return True
 

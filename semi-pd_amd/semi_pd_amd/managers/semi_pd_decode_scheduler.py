@@ -55,7 +55,8 @@ class SemiPDDecodeScheduler(SchedulerBase):
         for req in retracted:
             message = TokenizedGenerateReqInput(
                 rid=req.rid, input_text=None, input_ids=req.origin_input_ids + req.output_ids,
-                sampling_params=req.sampling_params, is_retracted=True)
+                sampling_params=req.sampling_params, is_retracted=True, return_logprob=req.return_logprob,
+                top_logprobs_num=req.top_logprobs_num)
             self.waiting_queue.insert(0, req)
             if self.tp_rank == 0:
                 self.send_to_p_instance.send_pyobj(message)
@@ -157,7 +158,7 @@ class SemiPDDecodeScheduler(SchedulerBase):
         if self.tp_size > 1:
             barrier_cpu()
         batch.output_ids = torch.tensor(recv_req.next_token_ids, dtype=torch.int64, device=self.device)
-        self.process_batch_result_prefill(batch, recv_req.next_token_ids)
+        self.process_batch_result_prefill(batch, recv_req.next_token_ids, recv_req.next_token_logprobs)
         batch.filter_batch(chunked_req_to_exclude=self.chunked_req)
         if not batch.is_empty():
             if self.running_batch.is_empty():
@@ -175,12 +176,12 @@ class SemiPDDecodeScheduler(SchedulerBase):
             self.flush_stream_output()
             return bool(recv)
         t1 = time.perf_counter()
-        _, next_token_ids = self.run_batch(batch)  # asynchronous: one hipGraph launch
+        logits_output, next_token_ids = self.run_batch(batch)  # asynchronous: one hipGraph launch
         batch.output_ids = next_token_ids
         self.flush_stream_output()     # tokens of the previous step: pickle + send while the GPU works
         ids = next_token_ids.tolist()  # the only device sync of a decode step
         t2 = time.perf_counter()
-        self.process_batch_result_decode(batch, ids)
+        self.process_batch_result_decode(batch, ids, self.extract_logprobs(logits_output))
         t3 = time.perf_counter()
         st = self.stats
         st["t_schedule_s"] = st.get("t_schedule_s", 0.0) + (t1 - t0)

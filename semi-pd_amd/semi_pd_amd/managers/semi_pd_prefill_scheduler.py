@@ -89,22 +89,23 @@ class SemiPDPrefillScheduler(SchedulerBase):
             self._rejected = True  # the decode instance has no room right now: back off a little
         return None
 
-    def process_batch_result_prefill(self, batch: ScheduleBatch, next_token_ids: torch.Tensor):
+    def process_batch_result_prefill(self, batch: ScheduleBatch, next_token_ids: torch.Tensor, logits_output=None):
         """semi_pd_prefill_scheduler.py:159-173.  `.tolist()` synchronises the stream, so every KV row
         this batch wrote is in HBM before the decode instance hears about it (SURVEY §3.2 hazard)."""
         ids = next_token_ids.tolist()
         self.stats["prefill_batches"] += 1
         self.stats["prefill_tokens"] += batch.extend_num_tokens
         if self.tp_rank == 0:
-            self.send_to_d_instance.send_pyobj(BatchProcessPrefillResultReq(next_token_ids=ids))
+            self.send_to_d_instance.send_pyobj(BatchProcessPrefillResultReq(
+                next_token_ids=ids, next_token_logprobs=self.extract_logprobs(logits_output)))
 
     def step(self) -> bool:
         self.process_input_requests(self.recv_requests())
         batch = self.get_next_batch_to_run()
         if batch is None:
             return False
-        _, next_token_ids = self.run_batch(batch)
-        self.process_batch_result_prefill(batch, next_token_ids)
+        logits_output, next_token_ids = self.run_batch(batch)
+        self.process_batch_result_prefill(batch, next_token_ids, logits_output)
         import time
         self.last_progress = time.monotonic()
         return True

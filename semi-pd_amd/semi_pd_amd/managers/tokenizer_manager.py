@@ -144,9 +144,20 @@ class TokenizerManager:
             return {"type": "stop", "matched": last_token}
         return {"type": "abort", "message": str(reason)}
 
-    def _out_dict(self, st: _ReqState, ids: List[int], fin: Optional[str], skip_special_tokens: bool) -> dict:
+    def _token_text(self, tok: int) -> Optional[str]:
+        return None if self.tokenizer is None else self.tokenizer.decode([tok])
+
+    def _out_dict(self, st: _ReqState, ids: List[int], fin: Optional[str], skip_special_tokens: bool,
+                  logprobs: Optional[dict] = None, text_in_logprobs: bool = False) -> dict:
         meta = {"id": st.rid, "finish_reason": self._finish_dict(fin, len(ids), ids[-1] if ids else None),
                 "prompt_tokens": st.prompt_tokens, "completion_tokens": len(ids), "cached_tokens": 0}
+        if logprobs is not None:
+            # tokenizer_manager.py convert_logprob_style: (logprob, token id, token text or None) per token
+            n = min(len(ids), len(logprobs["token"]))
+            txt = self._token_text if text_in_logprobs else (lambda t: None)
+            meta["output_token_logprobs"] = [(logprobs["token"][i], ids[i], txt(ids[i])) for i in range(n)]
+            meta["output_top_logprobs"] = [[(lp, int(t), txt(int(t))) for lp, t in logprobs["top"][i]] or None
+                                           for i in range(n)]
         if fin is not None:
             meta["e2e_latency"] = time.time() - st.created
         if self.tokenizer is None:
@@ -157,7 +168,9 @@ class TokenizerManager:
             text = text[:-1]  # an incomplete multi-byte character: wait for the next token
         return {"text": text, "output_ids": list(ids), "meta_info": meta}
 
-    async def _one(self, text, input_ids, sampling: dict, stream: bool, rid: Optional[str]) -> AsyncIterator[dict]:
+    async def _one(self, text, input_ids, sampling: dict, stream: bool, rid: Optional[str],
+                   return_logprob: bool = False, top_logprobs_num: int = 0,
+                   text_in_logprobs: bool = False) -> AsyncIterator[dict]:
         sp = sampling_params_from_dict(sampling)
         ids = self._tokenize(text, input_ids)
         self._validate(ids, sp)
@@ -168,7 +181,10 @@ class TokenizerManager:
             if rid in self.states:
                 raise ValueError(f"duplicate request id {rid}")
             self.states[rid] = st
-            self.engine.add_request(ids, sp, rid=rid)
+            if return_logprob:
+                self.engine.add_request(ids, sp, rid=rid, return_logprob=True, top_logprobs_num=int(top_logprobs_num))
+            else:
+                self.engine.add_request(ids, sp, rid=rid)
         try:
             sent = -1
             while True:
@@ -178,16 +194,18 @@ class TokenizerManager:
                     raise RuntimeError(f"scheduler failed: {self._pump_error}")
                 out_ids = list(self.engine._outputs[rid])
                 fin = self.engine._finished[rid]
+                lps = getattr(self.engine, "_logprobs", {}).get(rid) if return_logprob else None
                 if fin is not None:
-                    yield self._out_dict(st, out_ids, fin, skip_special)
+                    yield self._out_dict(st, out_ids, fin, skip_special, lps, text_in_logprobs)
                     return
                 if stream and len(out_ids) != sent:
                     sent = len(out_ids)
-                    yield self._out_dict(st, out_ids, None, skip_special)
+                    yield self._out_dict(st, out_ids, None, skip_special, lps, text_in_logprobs)
         finally:
             with self._lock:
                 self.states.pop(rid, None)
-            for d in (self.engine._outputs, self.engine._finished, self.engine._token_times, self.engine._send_time):
+            for d in (self.engine._outputs, self.engine._finished, self.engine._token_times, self.engine._send_time,
+                      getattr(self.engine, "_logprobs", {})):
                 d.pop(rid, None)
 
     async def generate_request(self, obj: Dict[str, Any]) -> AsyncIterator[Union[dict, List[dict]]]:
@@ -197,12 +215,17 @@ class TokenizerManager:
         stream = bool(obj.get("stream", False))
         sampling = obj.get("sampling_params") or {}
         rid = obj.get("rid")
-        if obj.get("return_logprob"):
-            raise ValueError("return_logprob is not supported")
+        return_logprob = bool(obj.get("return_logprob", False))
+        top_num = int(obj.get("top_logprobs_num") or 0)
+        text_in_lp = bool(obj.get("return_text_in_logprobs", False))
+        if return_logprob and obj.get("logprob_start_len", -1) not in (-1, None):
+            raise ValueError("logprobs of prompt tokens (logprob_start_len >= 0) are not supported")
+        if obj.get("token_ids_logprob"):
+            raise ValueError("token_ids_logprob is not supported")
         is_batch = isinstance(text, list) or (isinstance(input_ids, list) and input_ids
                                                and isinstance(input_ids[0], list))
         if not is_batch:
-            async for out in self._one(text, input_ids, sampling, stream, rid):
+            async for out in self._one(text, input_ids, sampling, stream, rid, return_logprob, top_num, text_in_lp):
                 yield out
             return
         n = len(text) if isinstance(text, list) else len(input_ids)
@@ -212,7 +235,8 @@ class TokenizerManager:
         rids = rid if isinstance(rid, list) else [None] * n
         if not (len(texts) == len(idss) == len(samplings) == len(rids) == n):
             raise ValueError("batch fields have different lengths")
-        gens = [self._one(texts[i], idss[i], samplings[i], stream, rids[i]) for i in range(n)]
+        gens = [self._one(texts[i], idss[i], samplings[i], stream, rids[i], return_logprob, top_num, text_in_lp)
+                for i in range(n)]
         if not stream:
             results = await asyncio.gather(*[g.__anext__() for g in gens])
             for g in gens:

@@ -48,6 +48,8 @@ class ForwardBatch:
     token_to_kv_pool: object = None
     attn_backend: object = None
     sampling_info: object = None
+    return_logprob: bool = False
+    top_logprobs_nums: Optional[List[int]] = None
 
     @classmethod
     def init_new(cls, batch, model_runner) -> "ForwardBatch":
@@ -77,4 +79,6 @@ class ForwardBatch:
         ret.token_to_kv_pool = model_runner.token_to_kv_pool
         ret.attn_backend = model_runner.attn_backend
         ret.sampling_info = getattr(batch, "sampling_info", None)
+        ret.return_logprob = bool(getattr(batch, "return_logprob", False))
+        ret.top_logprobs_nums = getattr(batch, "top_logprobs_nums", None)
         return ret

@@ -347,4 +347,6 @@ class ModelRunner:
         return self.model.forward(forward_batch.input_ids, forward_batch.positions, forward_batch)
 
     def sample(self, logits_output, forward_batch=None) -> torch.Tensor:
-        return self.sampler(logits_output, getattr(forward_batch, "sampling_info", None))
+        return self.sampler(logits_output, getattr(forward_batch, "sampling_info", None),
+                            return_logprob=bool(getattr(forward_batch, "return_logprob", False)),
+                            top_logprobs_nums=getattr(forward_batch, "top_logprobs_nums", None))

@@ -447,6 +447,20 @@ def top_p_renorm_prob(probs: torch.Tensor, top_p) -> torch.Tensor:
     return out
 
 
+def token_logprobs(logits: torch.Tensor, token_ids: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(log_softmax(logits)[b, token_ids[b]], logsumexp(logits[b])) for fp32 logits [batch, vocab]
+    (Sampler.forward with return_logprob, layers/sampler.py:74-75, 150-155)."""
+    B, V = _probs_2d(logits, "token_logprobs")
+    ids = token_ids.reshape(-1).to(torch.int32).contiguous()
+    if ids.numel() != B:
+        raise RuntimeError("token_logprobs: one token id per row required")
+    out = torch.empty(B, dtype=torch.float32, device=logits.device)
+    lse = torch.empty(B, dtype=torch.float32, device=logits.device)
+    check(_lib.load().semipd_token_logprobs(ptr(logits), ptr(ids), ptr(out), ptr(lse), B, V,
+                                            current_stream(logits.device)), "token_logprobs")
+    return out, lse
+
+
 # --------------------------------------------------------------------------- MoE
 def topk_softmax(gating_output: torch.Tensor, topk: int, renormalize: bool):
     """fused_topk (layers/moe/topk.py:44-75): fp32 softmax + top-k."""

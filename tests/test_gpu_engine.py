@@ -360,3 +360,38 @@ def test_launch_server_semi_pd_http(unified_llama, tmp_path):
         except subprocess.TimeoutExpired:
             proc.kill()
         log.close()
+
+
+def test_logprobs_unified_and_semi_pd_match_oracle(unified_llama):
+    """return_logprob through the engine: the first token's logprob is computed by the prefill instance
+    and shipped to the decode instance, the rest come from the decode hipGraph's logits.  Values against
+    the teacher-forced fp32 oracle within the reference's bar for logprobs (max abs diff 5e-2,
+    test/srt/models/test_generation_models.py:43-45)."""
+    from semi_pd_amd.entrypoints.engine import Engine
+    from semi_pd_amd.managers.io_struct import SamplingParams
+    cfg, sd, prompts, outs, eng_u = unified_llama
+    sp = SamplingParams(max_new_tokens=8, ignore_eos=True)
+    oracle = OracleLlama(cfg, sd)
+
+    def check(tokens, lps):
+        _, logits = oracle.generate(prompts, 8, forced=tokens)
+        want = torch.log_softmax(logits.float(), -1)
+        for i, toks in enumerate(tokens):
+            assert len(lps[i]["token"]) == 8 and len(lps[i]["top"]) == 8
+            for s, t in enumerate(toks):
+                assert abs(lps[i]["token"][s] - float(want[i, s, t])) <= 5e-2
+                top = lps[i]["top"][s]
+                assert len(top) == 3 and top[0][0] >= top[1][0] >= top[2][0]
+                assert abs(top[0][0] - float(want[i, s].max())) <= 5e-2
+                assert top[0][1] == t  # greedy: the sampled token leads the top-k
+
+    toks, lps = eng_u.generate(prompts, sp, return_logprob=True, top_logprobs_num=3)
+    check(toks, lps)
+    eng = Engine(server_args(cfg, enable_semi_pd=True, prefill_cu_percent=50, decode_cu_percent=50))
+    try:
+        toks2, lps2 = eng.generate(prompts, sp, timeout=300, return_logprob=True, top_logprobs_num=3)
+        plain = eng.generate(prompts[:2], sp, timeout=300)  # a request without logprobs gets none
+        assert isinstance(plain, list) and len(plain[0]) == 8
+    finally:
+        eng.shutdown()
+    check(toks2, lps2)

@@ -168,3 +168,50 @@ def test_sampler_layer_mixed_batch(ops, device):
                 assert ids[3] in top3
     info = SamplingBatchInfo.from_reqs(reqs[:1], V, device)
     assert info.is_all_greedy
+
+
+@pytest.mark.parametrize("batch,vocab", [(1, 111), (7, 32000), (33, 128256)])
+def test_token_logprobs(ops, device, batch, vocab):
+    g = torch.Generator().manual_seed(batch)
+    logits = torch.randn(batch, vocab, generator=g) * 5
+    ids = torch.randint(0, vocab, (batch,), generator=g)
+    lp, lse = ops.token_logprobs(logits.to(device), ids.to(device))
+    want = torch.log_softmax(logits, -1)
+    torch.testing.assert_close(lp.cpu(), want[torch.arange(batch), ids], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(lse.cpu(), torch.logsumexp(logits, -1), rtol=1e-5, atol=1e-5)
+
+
+def test_sampler_logprobs_greedy_and_stochastic(ops, device):
+    """Sampler.forward with return_logprob (layers/sampler.py:74-75, 84-89, 139-155): greedy rows report
+    log_softmax, stochastic batches log(top-p-normalised softmax(logits / T))."""
+    from semi_pd_amd.layers.basic import LogitsProcessorOutput, Sampler
+    from semi_pd_amd.managers.io_struct import SamplingParams
+    from semi_pd_amd.sampling_batch_info import SamplingBatchInfo
+
+    class _R:
+        def __init__(self, sp):
+            self.sampling_params = sp
+
+    torch.manual_seed(1)
+    V = 5000
+    logits = torch.randn(3, V) * 3
+    sampler = Sampler()
+    out = LogitsProcessorOutput(logits.clone().to(device))
+    ids = sampler(out, SamplingBatchInfo.from_reqs([_R(SamplingParams())] * 3, V, device), return_logprob=True,
+                  top_logprobs_nums=[0, 2, 5])
+    want = torch.log_softmax(logits, -1)
+    assert ids.tolist() == logits.argmax(-1).tolist()
+    torch.testing.assert_close(out.next_token_logprobs.cpu(), want.max(-1).values, rtol=1e-5, atol=1e-5)
+    assert [len(v) for v in out.next_token_top_logprobs_val] == [0, 2, 5]
+    tv, ti = torch.topk(want[2], 5)
+    assert out.next_token_top_logprobs_idx[2] == ti.tolist()
+    torch.testing.assert_close(torch.tensor(out.next_token_top_logprobs_val[2]), tv, rtol=1e-5, atol=1e-5)
+    # stochastic batch
+    reqs = [_R(SamplingParams(temperature=0.7, top_p=0.9)), _R(SamplingParams(temperature=1.3, top_k=50)),
+            _R(SamplingParams(temperature=1.0))]
+    info = SamplingBatchInfo.from_reqs(reqs, V, device)
+    out = LogitsProcessorOutput(logits.clone().to(device))
+    ids = sampler(out, info, return_logprob=True, top_logprobs_nums=[1, 1, 1]).cpu()
+    probs = O.softmax_temperature(logits, torch.tensor([0.7, 1.3, 1.0]))
+    want = torch.log(O.top_p_normalize_probs(probs, torch.tensor([0.9, 1.0, 1.0]))).clamp(min=torch.finfo(torch.float32).min)
+    torch.testing.assert_close(out.next_token_logprobs.cpu(), want[torch.arange(3), ids.long()], rtol=1e-3, atol=1e-3)

@@ -38,13 +38,16 @@ class ScriptedEngine:
 
     def __init__(self):
         self._outputs, self._finished, self._token_times, self._send_time = {}, {}, {}, {}
+        self._logprobs = {}
         self._live = {}
         self.requests = []
         self._lock = threading.Lock()
 
-    def add_request(self, input_ids, sampling_params, rid=None):
+    def add_request(self, input_ids, sampling_params, rid=None, return_logprob=False, top_logprobs_num=0):
         with self._lock:
             self._outputs[rid], self._finished[rid], self._token_times[rid] = [], None, []
+            if return_logprob:
+                self._logprobs[rid] = {"token": [], "top": [], "k": top_logprobs_num}
             self._send_time[rid] = time.time()
             self._live[rid] = (list(input_ids), sampling_params)
             self.requests.append((rid, list(input_ids), sampling_params))
@@ -62,6 +65,11 @@ class ScriptedEngine:
                         continue
                     tok = (ids[-1] + len(self._outputs[rid]) + 1) % len(WORDS)
                     self._outputs[rid].append(tok)
+                    if rid in self._logprobs:  # scripted values: -0.25 * (position + 1); top-k = next ids
+                        lp = self._logprobs[rid]
+                        pos = len(lp["token"]) + 1
+                        lp["token"].append(-0.25 * pos)
+                        lp["top"].append([(-0.25 * pos - 0.5 * j, (tok + j) % len(WORDS)) for j in range(lp["k"])])
                     if tok == 0 and not sp.ignore_eos:
                         self._finished[rid] = "stop"
                     elif len(self._outputs[rid]) >= sp.max_new_tokens:
@@ -199,3 +207,28 @@ def test_cli_flags_of_the_reference_parse(tmp_path):
     assert sa.enable_semi_pd and sa.disable_radix_cache and sa.tp_size == 1 and sa.context_length == 10240
     assert sa.mem_fraction_static == 0.82 and sa.served_model_name == "deepseek" and sa.load_format == "auto"
     assert sa.model_config.num_key_value_heads == 2 and sa.eos_token_ids == [7]
+
+
+def test_logprobs_native_and_openai(client):
+    r = client.post("/generate", json={"text": "alpha", "return_logprob": True, "top_logprobs_num": 2,
+                                       "return_text_in_logprobs": True, "sampling_params": {"max_new_tokens": 3}})
+    meta = r.json()["meta_info"]
+    assert [x[:2] for x in meta["output_token_logprobs"]] == [[-0.25, 2], [-0.5, 3], [-0.75, 4]]
+    assert meta["output_token_logprobs"][0][2] == "beta"
+    assert [t[1] for t in meta["output_top_logprobs"][1]] == [3, 4] and meta["output_top_logprobs"][1][1][0] == -1.0
+    # without top-k and without text
+    r = client.post("/generate", json={"input_ids": [1], "return_logprob": True, "sampling_params": {"max_new_tokens": 2}})
+    meta = r.json()["meta_info"]
+    assert meta["output_token_logprobs"] == [[-0.25, 2, None], [-0.5, 3, None]] and meta["output_top_logprobs"] == [None, None]
+    assert client.post("/generate", json={"text": "alpha", "return_logprob": True, "logprob_start_len": 0}).status_code == 400
+    # OpenAI completions: logprobs = k
+    r = client.post("/v1/completions", json={"prompt": "alpha", "max_tokens": 2, "logprobs": 1, "temperature": 0})
+    lp = r.json()["choices"][0]["logprobs"]
+    assert lp["tokens"] == ["beta", "gamma"] and lp["token_logprobs"] == [-0.25, -0.5]
+    assert lp["top_logprobs"] == [{"beta": -0.25}, {"gamma": -0.5}] and lp["text_offset"] == [0, 4]
+    # OpenAI chat
+    r = client.post("/v1/chat/completions", json={"messages": [{"role": "user", "content": "alpha"}], "max_tokens": 2,
+                                                  "logprobs": True, "top_logprobs": 2, "ignore_eos": True})
+    content = r.json()["choices"][0]["logprobs"]["content"]
+    assert len(content) == 2 and content[0]["logprob"] == -0.25 and len(content[0]["top_logprobs"]) == 2
+    assert client.post("/v1/completions", json={"prompt": "alpha", "max_tokens": 1}).json()["choices"][0]["logprobs"] is None
