@@ -269,6 +269,12 @@ def main():
                                        "schedule": round(1e3 * s.get("t_schedule_s", 0) / n, 3),
                                        "forward_and_sync": round(1e3 * s.get("t_forward_s", 0) / n, 3),
                                        "output": round(1e3 * s.get("t_output_s", 0) / n, 3)}
+        if s.get("role") == "PREFILL" and s.get("prefill_batches"):
+            n = s["prefill_batches"]
+            extra["prefill_batch_ms"] = {"batches": int(n), "avg_tokens": round(s["prefill_tokens"] / n, 1),
+                                         "avg_requests": round(s.get("prefill_reqs", 0) / n, 2),
+                                         "wait_admission": round(1e3 * s.get("t_wait_admission_s", 0) / n, 3),
+                                         "forward_and_sync": round(1e3 * s.get("t_forward_s", 0) / n, 3)}
         kt = s.get("kernel_timing") or {}
         if "decode_attention" in kt:
             k = kt["decode_attention"]

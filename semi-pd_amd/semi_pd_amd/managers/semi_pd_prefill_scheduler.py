@@ -5,6 +5,8 @@ token ids back.  Reference: managers/semi_pd_prefill_scheduler.py:40-176."""
 from __future__ import annotations
 
 import logging
+import os
+import time
 from typing import List, Optional
 
 import torch
@@ -25,6 +27,7 @@ class SemiPDPrefillScheduler(SchedulerBase):
         # send_stats_to: only StatsReq answers go there; tokens are streamed by the decode instance
         super().__init__(server_args, model_runner, tp_rank, recv_socket, send_stats_to, InstanceRole.PREFILL)
         self.enable_overlap = False
+        self._proposal_in_flight = False  # a GetNextPrefillBatchInput whose reply has not been read yet
         self.chunked_rid: Optional[str] = None
         self.send_to_d_instance = send_to_d_instance  # PUSH -> D's input socket (rank 0 only)
         self.bridge_socket = bridge_socket            # PULL <- D's replies (rank 0 only)
@@ -66,21 +69,45 @@ class SemiPDPrefillScheduler(SchedulerBase):
         batch.prepare_for_extend(pre_allocated_req_pool_indices=resp.req_pool_indices)
         return batch
 
+    def _propose(self) -> bool:
+        """Rank 0: send the decode instance the rids we would like to prefill next
+        (semi_pd_prefill_scheduler.py:120-133).  Returns False when nothing is waiting."""
+        n_prefill_tokens = 0
+        candidates: List[str] = []
+        for r in self.waiting_queue:
+            if n_prefill_tokens > self.chunked_prefill_size:
+                break
+            n_prefill_tokens += len(r.origin_input_ids)
+            candidates.append(r.rid)
+        if not candidates:
+            return False
+        self.send_to_d_instance.send_pyobj(GetNextPrefillBatchInput(rids=candidates))
+        return True
+
+    def request_next_batch_early(self):
+        """Ask for the NEXT batch while the current one is still running on the GPU: the decode instance
+        answers between two of its steps (up to one step, ~9 ms, later), which the reference pays as idle
+        time of the prefill instance before every batch.  The reply is picked up by the next
+        get_next_batch_to_run; the decode instance keeps its scheduled prefill batches in FIFO order, so
+        results and admissions stay matched."""
+        # not while a chunked request is in flight: the decode instance refuses to admit before the
+        # previous chunk's result has arrived (semi_pd_decode_scheduler.py:310-320)
+        if self.tp_rank == 0 and not self._proposal_in_flight and self.waiting_queue and self.chunked_rid is None:
+            self._proposal_in_flight = self._propose()
+
     def get_next_batch_to_run(self) -> Optional[ScheduleBatch]:
         """semi_pd_prefill_scheduler.py:120-157."""
         resp = None
-        if self.waiting_queue and self.tp_rank == 0:
-            n_prefill_tokens = 0
-            candidates: List[str] = []
-            for r in self.waiting_queue:
-                if n_prefill_tokens > self.chunked_prefill_size:
-                    break
-                n_prefill_tokens += len(r.origin_input_ids)
-                candidates.append(r.rid)
-            self.send_to_d_instance.send_pyobj(GetNextPrefillBatchInput(rids=candidates))
-            # the reference blocks forever here (semi_pd_prefill_scheduler.py:134); we bound the wait
-            resp = self.bridge_socket.recv_pyobj(timeout=self.server_args.watchdog_timeout)
-            assert isinstance(resp, GetNextPrefillBatchOutput), f"unexpected bridge message {type(resp)}"
+        if self.tp_rank == 0 and (self._proposal_in_flight or self.waiting_queue):
+            if not self._proposal_in_flight:
+                self._proposal_in_flight = self._propose()
+            if self._proposal_in_flight:
+                # the reference blocks forever here (semi_pd_prefill_scheduler.py:134); we bound the wait
+                t0 = time.perf_counter()
+                resp = self.bridge_socket.recv_pyobj(timeout=self.server_args.watchdog_timeout)
+                self.stats["t_wait_admission_s"] = self.stats.get("t_wait_admission_s", 0.0) + time.perf_counter() - t0
+                self._proposal_in_flight = False
+                assert isinstance(resp, GetNextPrefillBatchOutput), f"unexpected bridge message {type(resp)}"
         if self.tp_size > 1:
             resp = broadcast_pyobj([resp], self.tp_rank, self.tp_cpu_group, src=0)[0]
         if resp and len(resp.rids) > 0:
@@ -104,9 +131,13 @@ class SemiPDPrefillScheduler(SchedulerBase):
         batch = self.get_next_batch_to_run()
         if batch is None:
             return False
-        logits_output, next_token_ids = self.run_batch(batch)
+        t0 = time.perf_counter()
+        logits_output, next_token_ids = self.run_batch(batch)  # asynchronous launches
+        if os.environ.get("SEMIPD_EARLY_PROPOSE", "1") != "0":
+            self.request_next_batch_early()
         self.process_batch_result_prefill(batch, next_token_ids, logits_output)
-        import time
+        self.stats["t_forward_s"] = self.stats.get("t_forward_s", 0.0) + time.perf_counter() - t0
+        self.stats["prefill_reqs"] = self.stats.get("prefill_reqs", 0) + len(batch.reqs)
         self.last_progress = time.monotonic()
         return True
 
