@@ -272,6 +272,18 @@ class Engine:
             self.send_to_scheduler.send_pyobj(req)
         return rid
 
+    def abort_request(self, rid: str):
+        """Stop generating for `rid` (client disconnect, stop string): both instances are told.  A queued
+        request is dropped without a reply (scheduler.py:1565-1577), so the record is closed here; a running
+        one still sends its last tokens with finish reason "abort" when its slots are freed."""
+        from semi_pd_amd.managers.io_struct import AbortReq
+        if rid in self._finished and self._finished[rid] is None:
+            self._finished[rid] = "abort"
+        if self.scheduler is not None:
+            self._inbox.append(AbortReq(rid))
+        else:
+            self.send_to_scheduler.send_pyobj(AbortReq(rid))
+
     def _handle_output(self, obj):
         if isinstance(obj, BatchTokenIDOut):
             now = time.time()
@@ -344,6 +356,9 @@ class Engine:
     def get_stats(self, reset: bool = False, expect: int = 2, timeout: float = 60.0) -> List[dict]:
         if self.scheduler is not None:
             out = dict(self.scheduler.stats)
+            out["available_kv_slots"] = int(self.scheduler.token_to_kv_pool_allocator.available_size())
+            out["num_running_reqs"] = len(self.scheduler.running_batch.reqs)
+            out["num_waiting_reqs"] = len(self.scheduler.waiting_queue)
             kt = getattr(self.model_runner, "kernel_timing", None)
             if kt is not None:
                 out["kernel_timing"] = kt.summary()

@@ -100,7 +100,7 @@ def build_app(tokenizer_manager, server_args) -> FastAPI:
         """One-token generation round trip through both schedulers (http_server.py:151-196)."""
         obj = {"input_ids": [0], "sampling_params": {"max_new_tokens": 1, "temperature": 0.0}}
         try:
-            await asyncio.wait_for(tm.generate_request(obj).__anext__(), timeout=60)
+            await asyncio.wait_for(tm.generate_once(obj), timeout=60)
         except Exception as e:  # noqa: BLE001
             return Response(content=str(e), status_code=503)
         return Response(status_code=200)
@@ -145,7 +145,7 @@ def build_app(tokenizer_manager, server_args) -> FastAPI:
                 yield b"data: [DONE]\n\n"
             return StreamingResponse(stream_results(), media_type="text/event-stream")
         try:
-            return await tm.generate_request(obj).__anext__()
+            return await tm.generate_once(obj)
         except ValueError as e:
             return _error(str(e))
 
@@ -203,7 +203,7 @@ def build_app(tokenizer_manager, server_args) -> FastAPI:
                 yield b"data: [DONE]\n\n"
             return StreamingResponse(stream_results(), media_type="text/event-stream")
         try:
-            ret = await tm.generate_request(obj).__anext__()
+            ret = await tm.generate_once(obj)
         except ValueError as e:
             return _error(str(e))
         rets = ret if isinstance(ret, list) else [ret]
@@ -274,7 +274,7 @@ def build_app(tokenizer_manager, server_args) -> FastAPI:
                 yield b"data: [DONE]\n\n"
             return StreamingResponse(stream_results(), media_type="text/event-stream")
         try:
-            r = await tm.generate_request(obj).__anext__()
+            r = await tm.generate_once(obj)
         except ValueError as e:
             return _error(str(e))
         meta = r["meta_info"]

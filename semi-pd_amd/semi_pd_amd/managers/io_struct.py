@@ -101,6 +101,12 @@ class BatchTokenIDOut:
 
 
 @dataclass
+class AbortReq:
+    """Client went away or a stop string matched (io_struct.py AbortReq; scheduler.py:1565-1584)."""
+    rid: str
+
+
+@dataclass
 class FlushCacheReq:
     pass
 

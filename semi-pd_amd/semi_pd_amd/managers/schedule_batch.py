@@ -41,6 +41,7 @@ class Req:
         self.is_chunked = 0
         self.is_retracted = is_retracted
         self.finished_reason: Optional[str] = None
+        self.to_abort = False  # set by AbortReq; turns into finished_reason "abort" at the next check
         self.send_token_offset = 0
         self.queue_time = 0.0
 
@@ -55,6 +56,9 @@ class Req:
     def check_finished(self):
         """schedule_batch.py:470-520 (length and EOS; stop strings need a tokenizer -> next rows)."""
         if self.finished():
+            return
+        if self.to_abort:
+            self.finished_reason = "abort"
             return
         if len(self.output_ids) >= self.sampling_params.max_new_tokens:
             self.finished_reason = "length"

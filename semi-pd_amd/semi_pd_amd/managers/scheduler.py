@@ -17,7 +17,7 @@ from typing import Dict, List, Optional
 import torch
 
 from semi_pd_amd.distributed import broadcast_pyobj, get_tp_cpu_group
-from semi_pd_amd.managers.io_struct import (BatchTokenIDOut, FlushCacheReq, ShutdownReq, StatsReq,
+from semi_pd_amd.managers.io_struct import (AbortReq, BatchTokenIDOut, FlushCacheReq, ShutdownReq, StatsReq,
                                             TokenizedGenerateReqInput)
 from semi_pd_amd.managers.schedule_batch import (AddReqResult, ChunkCache, PrefillAdder, Req, ScheduleBatch)
 from semi_pd_amd.managers.transport import NOTHING
@@ -105,6 +105,8 @@ class SchedulerBase:
             self.handle_generate_request(recv_req)
         elif isinstance(recv_req, FlushCacheReq):
             pass
+        elif isinstance(recv_req, AbortReq):
+            self.abort_request(recv_req)
         elif isinstance(recv_req, ShutdownReq):
             self._shutdown = True
         elif isinstance(recv_req, StatsReq):
@@ -128,10 +130,28 @@ class SchedulerBase:
     def add_to_waiting_queue(self, req: Req):
         self.waiting_queue.append(req)
 
+    def abort_request(self, recv_req: AbortReq):
+        """scheduler.py:1565-1584: drop a queued request, or mark a running one so that it finishes (and
+        frees its KV slots) at the next step.  Requests the prefill instance is working on right now are
+        marked too and end right after they are merged."""
+        for i, req in enumerate(self.waiting_queue):
+            if req.rid == recv_req.rid:
+                self.waiting_queue.pop(i)
+                return
+        pending = [r for b in getattr(self, "scheduled_prefill_batches", []) for r in b.reqs]
+        chunked = [self.chunked_req] if self.chunked_req is not None else []
+        for req in list(self.running_batch.reqs) + pending + chunked:
+            if req.rid == recv_req.rid and not req.finished():
+                req.to_abort = True
+                return
+
     def handle_stats(self, recv_req: StatsReq):
         if self.send_to_detokenizer is not None and self.tp_rank == 0:
             out = dict(self.stats)
             out["role"] = self.role.name
+            out["available_kv_slots"] = int(self.token_to_kv_pool_allocator.available_size())
+            out["num_running_reqs"] = len(self.running_batch.reqs)
+            out["num_waiting_reqs"] = len(self.waiting_queue)
             extra = getattr(self.model_runner, "kernel_timing", None)
             if extra is not None:
                 out["kernel_timing"] = extra.summary()

@@ -28,6 +28,7 @@ class SemiPDPrefillScheduler(SchedulerBase):
         super().__init__(server_args, model_runner, tp_rank, recv_socket, send_stats_to, InstanceRole.PREFILL)
         self.enable_overlap = False
         self._proposal_in_flight = False  # a GetNextPrefillBatchInput whose reply has not been read yet
+        self._aborted: set = set()        # rids the client gave up on (see abort_request)
         self.chunked_rid: Optional[str] = None
         self.send_to_d_instance = send_to_d_instance  # PUSH -> D's input socket (rank 0 only)
         self.bridge_socket = bridge_socket            # PULL <- D's replies (rank 0 only)
@@ -38,6 +39,19 @@ class SemiPDPrefillScheduler(SchedulerBase):
             self.waiting_queue.insert(0, req)
         else:
             self.waiting_queue.append(req)
+
+    def abort_request(self, recv_req):
+        """The decode instance is the authority: it drops a queued request, or marks an admitted one.  Here
+        an aborted rid stays proposable until a reply shows which of the two happened: a reply that
+        contains it means it was admitted (run it; D finishes it after the merge), a reply without it means
+        D no longer knows it (drop it)."""
+        self._aborted.add(recv_req.rid)
+
+    def _purge_aborted(self, admitted_rids):
+        if self._aborted:
+            keep = set(admitted_rids)
+            self.waiting_queue = [r for r in self.waiting_queue if r.rid not in self._aborted or r.rid in keep]
+            self._aborted &= {r.rid for r in self.waiting_queue} | keep
 
     def to_extend_batch(self, resp: GetNextPrefillBatchOutput) -> ScheduleBatch:
         """semi_pd_prefill_scheduler.py:74-118."""
@@ -110,6 +124,8 @@ class SemiPDPrefillScheduler(SchedulerBase):
                 assert isinstance(resp, GetNextPrefillBatchOutput), f"unexpected bridge message {type(resp)}"
         if self.tp_size > 1:
             resp = broadcast_pyobj([resp], self.tp_rank, self.tp_cpu_group, src=0)[0]
+        if resp is not None:
+            self._purge_aborted(list(resp.rids) + ([resp.chunked_rid] if resp.chunked_rid else []))
         if resp and len(resp.rids) > 0:
             return self.to_extend_batch(resp)
         if resp is not None:

@@ -46,8 +46,6 @@ def sampling_params_from_dict(d: Optional[dict]) -> SamplingParams:
     for k in ("json_schema", "regex", "ebnf"):
         if d.get(k):
             raise ValueError("structured output is not supported")
-    if d.get("stop"):
-        raise ValueError("stop strings are not supported; use stop_token_ids")
     kw = {k: d[k] for k in _SAMPLING_KEYS if k in d and d[k] is not None}
     kw.setdefault("temperature", 1.0)
     kw.setdefault("max_new_tokens", 128)
@@ -172,6 +170,10 @@ class TokenizerManager:
                    return_logprob: bool = False, top_logprobs_num: int = 0,
                    text_in_logprobs: bool = False) -> AsyncIterator[dict]:
         sp = sampling_params_from_dict(sampling)
+        stop = (sampling or {}).get("stop") or []
+        stop = [stop] if isinstance(stop, str) else [s for s in stop if s]
+        if stop and self.tokenizer is None:
+            raise ValueError("stop strings need a tokenizer (server runs with --skip-tokenizer-init)")
         ids = self._tokenize(text, input_ids)
         self._validate(ids, sp)
         skip_special = bool((sampling or {}).get("skip_special_tokens", True))
@@ -185,6 +187,7 @@ class TokenizerManager:
                 self.engine.add_request(ids, sp, rid=rid, return_logprob=True, top_logprobs_num=int(top_logprobs_num))
             else:
                 self.engine.add_request(ids, sp, rid=rid)
+        completed = False
         try:
             sent = -1
             while True:
@@ -195,18 +198,41 @@ class TokenizerManager:
                 out_ids = list(self.engine._outputs[rid])
                 fin = self.engine._finished[rid]
                 lps = getattr(self.engine, "_logprobs", {}).get(rid) if return_logprob else None
+                if stop:
+                    # schedule_batch.py:470-520 checks stop strings on the scheduler side with the
+                    # tokenizer; here the front end owns the tokenizer, cuts the text and aborts the rest
+                    out = self._out_dict(st, out_ids, fin, skip_special, lps, text_in_logprobs)
+                    hit = min(((out["text"].find(s), s) for s in stop if s in out["text"]), default=None)
+                    if hit is not None:
+                        out["text"] = out["text"][: hit[0]]
+                        out["meta_info"]["finish_reason"] = {"type": "stop", "matched": hit[1]}
+                        out["meta_info"].setdefault("e2e_latency", time.time() - st.created)
+                        completed = fin is not None
+                        yield out
+                        return
                 if fin is not None:
+                    completed = True
                     yield self._out_dict(st, out_ids, fin, skip_special, lps, text_in_logprobs)
                     return
                 if stream and len(out_ids) != sent:
                     sent = len(out_ids)
                     yield self._out_dict(st, out_ids, None, skip_special, lps, text_in_logprobs)
         finally:
+            if not completed and self.engine._finished.get(rid) is None:
+                self.engine.abort_request(rid)  # client went away, or a stop string ended the request early
             with self._lock:
                 self.states.pop(rid, None)
             for d in (self.engine._outputs, self.engine._finished, self.engine._token_times, self.engine._send_time,
                       getattr(self.engine, "_logprobs", {})):
                 d.pop(rid, None)
+
+    async def generate_once(self, obj: Dict[str, Any]) -> Union[dict, List[dict]]:
+        """Non-streaming request: the single result, with the generator closed before returning."""
+        g = self.generate_request(obj)
+        try:
+            return await g.__anext__()
+        finally:
+            await g.aclose()
 
     async def generate_request(self, obj: Dict[str, Any]) -> AsyncIterator[Union[dict, List[dict]]]:
         """obj follows GenerateReqInput (managers/io_struct.py:36-120): text | input_ids (single or batch),
@@ -225,8 +251,12 @@ class TokenizerManager:
         is_batch = isinstance(text, list) or (isinstance(input_ids, list) and input_ids
                                                and isinstance(input_ids[0], list))
         if not is_batch:
-            async for out in self._one(text, input_ids, sampling, stream, rid, return_logprob, top_num, text_in_lp):
-                yield out
+            g = self._one(text, input_ids, sampling, stream, rid, return_logprob, top_num, text_in_lp)
+            try:
+                async for out in g:
+                    yield out
+            finally:
+                await g.aclose()  # run the per-request cleanup (and a pending abort) now, not at GC time
             return
         n = len(text) if isinstance(text, list) else len(input_ids)
         texts = text if isinstance(text, list) else [None] * n

@@ -395,3 +395,61 @@ def test_logprobs_unified_and_semi_pd_match_oracle(unified_llama):
     finally:
         eng.shutdown()
     check(toks2, lps2)
+
+
+
+def test_abort_frees_kv_slots_unified_and_semi_pd(unified_llama):
+    """AbortReq (scheduler.py:1565-1584): queued requests are dropped, running ones end at the next step
+    with finish reason "abort"; either way every KV slot returns to the pool and a request that was not
+    aborted is untouched.  Semi-PD: both instances hear the abort, the decode instance decides."""
+    import time
+    from semi_pd_amd.entrypoints.engine import Engine
+    from semi_pd_amd.managers.io_struct import SamplingParams
+    cfg, sd, prompts, outs, eng_u = unified_llama
+    long_sp = SamplingParams(max_new_tokens=150, ignore_eos=True)
+    short_sp = SamplingParams(max_new_tokens=12, ignore_eos=True)
+
+    def pool(eng, n):
+        return sorted(s["available_kv_slots"] for s in eng.get_stats(expect=n))
+
+    def run(eng, n_inst):
+        free0 = pool(eng, n_inst)
+        victims = [eng.add_request(p, long_sp) for p in prompts[:4]]
+        keep = eng.add_request(prompts[4], short_sp)
+        deadline = time.monotonic() + 120
+        while min(len(eng._outputs[r]) for r in victims) < 3:
+            eng.poll(timeout=0.05)
+            assert time.monotonic() < deadline
+        for r in victims[:3]:
+            eng.abort_request(r)
+        burst = [eng.add_request(p, long_sp) for p in prompts]  # aborted right behind the submit: most are still queued
+        for r in burst:
+            eng.abort_request(r)
+        eng.wait([keep], timeout=120)
+        kept = list(eng._outputs[keep])
+        assert len(kept) == 12
+        if kept != outs[4]:
+            _explain_mismatch(oracle, [prompts[4]], [kept], [outs[4]])
+        eng.abort_request(victims[3])
+        deadline = time.monotonic() + 60
+        while True:
+            eng.poll(timeout=0.05)
+            stats = eng.get_stats(expect=n_inst)
+            if sorted(s["available_kv_slots"] for s in stats) == free0 and \
+                    all(s["num_running_reqs"] == 0 and s["num_waiting_reqs"] == 0 for s in stats):
+                break
+            assert time.monotonic() < deadline, (stats, free0)
+        for r in victims + burst:
+            assert eng._finished[r] == "abort" and len(eng._outputs[r]) < 150
+        # the engine is still healthy
+        again = eng.generate(prompts[:3], short_sp, timeout=120)
+        if again != outs[:3]:
+            _explain_mismatch(oracle, prompts[:3], again, outs[:3])
+
+    oracle = OracleLlama(cfg, sd)
+    run(eng_u, 1)
+    eng = Engine(server_args(cfg, enable_semi_pd=True, prefill_cu_percent=50, decode_cu_percent=50))
+    try:
+        run(eng, 2)
+    finally:
+        eng.shutdown()

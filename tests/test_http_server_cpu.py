@@ -39,6 +39,7 @@ class ScriptedEngine:
     def __init__(self):
         self._outputs, self._finished, self._token_times, self._send_time = {}, {}, {}, {}
         self._logprobs = {}
+        self.aborted = []
         self._live = {}
         self.requests = []
         self._lock = threading.Lock()
@@ -76,9 +77,15 @@ class ScriptedEngine:
                         self._finished[rid] = "length"
                     if self._finished[rid] is not None:
                         del self._live[rid]
+                time.sleep(0.001)  # one step of a real engine is not free; lets a front-end abort land mid-request
                 return True
         time.sleep(min(timeout, 0.005))
         return False
+
+    def abort_request(self, rid):
+        with self._lock:
+            self.aborted.append(rid)
+            self._live.pop(rid, None)
 
     def check_children(self):
         pass
@@ -147,7 +154,7 @@ def test_generate_errors(client):
     assert client.post("/generate", json={"input_ids": list(range(1, 12)) * 7}).status_code == 400  # > context
     r = client.post("/generate", json={"text": "alpha", "sampling_params": {"top_p": 0.0}})
     assert r.status_code == 400 and "top_p" in r.json()["error"]["message"]
-    r = client.post("/generate", json={"text": "alpha", "sampling_params": {"stop": ["x"]}})
+    r = client.post("/generate", json={"input_ids": [1], "sampling_params": {"repetition_penalty": 1.2}})
     assert r.status_code == 400
     with pytest.raises(ValueError):
         sampling_params_from_dict({"temperatur": 1})
@@ -232,3 +239,16 @@ def test_logprobs_native_and_openai(client):
     content = r.json()["choices"][0]["logprobs"]["content"]
     assert len(content) == 2 and content[0]["logprob"] == -0.25 and len(content[0]["top_logprobs"]) == 2
     assert client.post("/v1/completions", json={"prompt": "alpha", "max_tokens": 1}).json()["choices"][0]["logprobs"] is None
+
+
+def test_stop_strings_cut_the_text_and_abort_the_request(client):
+    r = client.post("/generate", json={"text": "alpha", "sampling_params": {"max_new_tokens": 400, "ignore_eos": True, "stop": ["delta", "zeta"]}})
+    body = r.json()
+    assert body["text"] == "beta gamma " and body["meta_info"]["finish_reason"] == {"type": "stop", "matched": "delta"}
+    assert client.engine.aborted == [body["meta_info"]["id"]]          # the rest of the 400 tokens is not generated
+    r = client.post("/v1/completions", json={"prompt": "alpha", "max_tokens": 400, "ignore_eos": True, "stop": "gamma"})
+    c = r.json()["choices"][0]
+    assert c["text"] == "beta " and c["finish_reason"] == "stop" and len(client.engine.aborted) == 2
+    # a request that ends by itself is not aborted
+    client.post("/generate", json={"text": "alpha", "sampling_params": {"max_new_tokens": 2, "stop": ["zeta"]}})
+    assert len(client.engine.aborted) == 2
