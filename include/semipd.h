@@ -312,6 +312,47 @@ int semipd_ipc_num_open(void);
 int semipd_device_cu_count(int device, int* num_cus);
 
 /* ------------------------------------------------------------------ */
+/* a17  TP all-reduce over peer-mapped memory (sgl-kernel/csrc/torch_extension_rocm.cc:25-55,
+ *      csrc/allreduce/custom_all_reduce.hip, custom_all_reduce_hip.cuh)                      */
+/* ------------------------------------------------------------------ */
+/* Every rank owns one shared region: a signal block (semipd_ar_meta_size bytes, replaces meta_size
+ * custom_all_reduce.hip:117) followed by four payload slots of max_bytes each (input and reduced,
+ * double buffered).  semipd_ar_region_size(max_bytes) is the size to allocate. */
+size_t semipd_ar_meta_size(void);
+size_t semipd_ar_region_size(size_t max_bytes);
+/* Uncached, zeroed device memory for a region (replaces allocate_meta_buffer,
+ * custom_all_reduce.hip:156-172).  Export it with semipd_ipc_get_handle (replaces
+ * get_meta_buffer_ipc_handle :146-154) and map the peers' regions with semipd_ipc_open. */
+int semipd_ar_alloc_shared(size_t bytes, void** ptr);
+int semipd_ar_free_shared(void* ptr);
+/* regions[world]: every rank's region as mapped in THIS process (own allocation at [rank]).
+ * replaces init_custom_ar (custom_all_reduce.hip:13-51); world in {2, 4, 6, 8} like the reference
+ * (:18-26).  There is no register_buffer / register_graph_buffers step: the kernel stages its input
+ * into the rank's own region, so any input pointer works, also under hipGraph capture. */
+int semipd_ar_init(void* const* regions, size_t region_bytes, int rank, int world, void** comm);
+/* Bound every flag wait of the calls launched from now on (0 = wait for ever, the default and what the
+ * reference does).  A wait that gives up is counted and the call finishes with undefined payload:
+ * start-up self-tests use this to find a broken peer mapping without hanging the GPU. */
+int semipd_ar_set_timeout_ms(void* comm, uint32_t ms);
+/* Number of waits that gave up so far (synchronous device read). */
+int semipd_ar_timed_out(void* comm, uint32_t* count);
+/* Largest payload (bytes) one call can reduce. */
+int semipd_ar_max_bytes(void* comm, size_t* bytes);
+/* out = sum over ranks of in, fp32 accumulation in rank order (bit-identical on all ranks);
+ * replaces all_reduce_reg / all_reduce_unreg (custom_all_reduce.hip:59-110).  numel * element size
+ * must be a multiple of 16 (custom_all_reduce.py:451-453) and at most semipd_ar_max_bytes; in/out
+ * 16-byte aligned; out may alias in.  Every rank must issue the same sequence of calls.  Does not
+ * synchronise; capturable.  dtype: SEMIPD_F32 / BF16 / F16. */
+int semipd_ar_all_reduce(void* comm, const void* in, void* out, size_t numel, int dtype, void* stream);
+/* out[r * bytes_per_rank ...] = rank r's `in`, through the same regions and flags (the reference
+ * gathers the vocab-parallel logits with the NCCL communicator, parallel_state.py:438-489,
+ * logits_processor.py:426-427; here the decode graph then holds no RCCL node at all).
+ * bytes_per_rank: multiple of 16, at most semipd_ar_max_bytes; out holds world * bytes_per_rank. */
+int semipd_ar_all_gather(void* comm, const void* in, void* out, size_t bytes_per_rank, void* stream);
+/* replaces dispose (custom_all_reduce.hip:112-115); regions stay with their owners. */
+int semipd_ar_dispose(void* comm);
+
+/* ------------------------------------------------------------------ */
 /* a16  CU-mask compute isolation (replaces CUDA_MPS_ACTIVE_THREAD_PERCENTAGE,
  *      entrypoints/engine.py:591-593, 632-634; semi_pd/utils.py:10-11)     */
 /* ------------------------------------------------------------------ */

@@ -77,9 +77,20 @@ _SIGNATURES = {
     "semipd_stream_get_cu_mask": [_vp, _vp, _i32],
     "semipd_probe_cu_placement": [_vp, _i32, _i64, _vp],
     "semipd_launch_noop": [_i32, _vp],
+    "semipd_ar_meta_size": [],
+    "semipd_ar_region_size": [_sz],
+    "semipd_ar_alloc_shared": [_sz, _vp],
+    "semipd_ar_free_shared": [_vp],
+    "semipd_ar_init": [_vp, _sz, _i32, _i32, _vp],
+    "semipd_ar_set_timeout_ms": [_vp, C.c_uint32],
+    "semipd_ar_timed_out": [_vp, _vp],
+    "semipd_ar_max_bytes": [_vp, _vp],
+    "semipd_ar_all_reduce": [_vp, _vp, _vp, _sz, _i32, _vp],
+    "semipd_ar_all_gather": [_vp, _vp, _vp, _sz, _vp],
+    "semipd_ar_dispose": [_vp],
 }
 _RESTYPES = {"semipd_last_error": C.c_char_p, "semipd_lm_head_argmax_workspace": _sz,
-             "semipd_linear_workspace": _sz}
+             "semipd_linear_workspace": _sz, "semipd_ar_meta_size": _sz, "semipd_ar_region_size": _sz}
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

@@ -1,0 +1,189 @@
+"""Tensor-parallel all-reduce over peer-mapped memory: the host side of csrc/all_reduce.hip.
+
+Mirrors `CustomAllreduce` of the reference (distributed/device_communicators/custom_all_reduce.py:146-568:
+constructor on a non-NCCL group, `should_custom_ar`, `custom_all_reduce`, `all_reduce`, `capture`, `close`)
+with a simpler buffer protocol: one uncached region per rank, exported once through the IPC seam, and no
+per-tensor or per-graph registration (the kernel stages its input into the region itself).
+
+Ranks may live on different GPUs of one node (the regions are then read over xGMI) or share a GPU
+(world_size-2 tests on the one-GPU box: same kernels, same flags, the "link" is HBM).
+"""
+from __future__ import annotations
+
+import contextlib
+import ctypes as C
+import logging
+import os
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+from semi_pd_amd import _lib
+
+logger = logging.getLogger(__name__)
+
+
+class CustomAllreduce:
+    _SUPPORTED_WORLD_SIZES = [2, 4, 6, 8]
+    # custom_all_reduce.py:148-151: "crossover is at 16MB buffer size for ROCm"
+    _MAX_CAR_SIZE = 2 * 8192 * 1024
+
+    def __init__(self, group: dist.ProcessGroup, device: torch.device, max_size: int = _MAX_CAR_SIZE) -> None:
+        self.disabled = True
+        self._comm = None
+        self._region = None
+        self._peer_bases: List[int] = []
+        self._IS_CAPTURING = False
+        self.group = group
+        assert dist.get_backend(group) != dist.Backend.NCCL, \
+            "CustomAllreduce exchanges its handles on a CPU group (custom_all_reduce.py:181-183)"
+        self.rank = dist.get_rank(group=group)
+        self.world_size = dist.get_world_size(group=group)
+        if self.world_size == 1 or self.world_size not in self._SUPPORTED_WORLD_SIZES:
+            return
+        self.device = torch.device(device)
+        self.max_size = int(max_size)
+        lib = _lib.load()
+        with torch.cuda.device(self.device):
+            region_bytes = int(lib.semipd_ar_region_size(self.max_size))
+            region = C.c_void_p()
+            _lib.check(lib.semipd_ar_alloc_shared(region_bytes, C.addressof(region)), "ar_alloc_shared")
+            self._region = region.value
+            handle = (C.c_uint8 * 64)()
+            offset = C.c_uint64()
+            _lib.check(lib.semipd_ipc_get_handle(self._region, C.addressof(handle), C.addressof(offset)), "ipc_get_handle")
+            mine = (bytes(handle), int(offset.value), os.getpid())
+            everyone: List[Optional[tuple]] = [None] * self.world_size
+            dist.all_gather_object(everyone, mine, group=group)
+            bases = []
+            for r, (h, off, pid) in enumerate(everyone):
+                if r == self.rank:
+                    bases.append(self._region)
+                    continue
+                assert pid != os.getpid(), "one rank per process"
+                base = C.c_void_p()
+                hb = (C.c_uint8 * 64).from_buffer_copy(h)
+                _lib.check(lib.semipd_ipc_open(C.addressof(hb), self.device.index or 0, C.addressof(base)), "ipc_open")
+                self._peer_bases.append(base.value)
+                bases.append(base.value + off)
+            arr = (C.c_void_p * self.world_size)(*bases)
+            comm = C.c_void_p()
+            _lib.check(lib.semipd_ar_init(C.addressof(arr), region_bytes, self.rank, self.world_size, C.addressof(comm)), "ar_init")
+            self._comm = comm.value
+        # nobody starts reducing before every rank has mapped every region
+        dist.barrier(group=group)
+        self.disabled = False
+        if os.environ.get("SEMIPD_AR_SELF_TEST", "1") != "0" and not self._self_test():
+            logger.warning("peer-memory all-reduce failed its start-up self-test on rank %d of %d; "
+                           "falling back to the backend collectives", self.rank, self.world_size)
+            self.disabled = True
+
+    def _self_test(self) -> bool:
+        """One-stage, two-stage and all-gather calls on data every rank can predict, with bounded flag
+        waits: a peer mapping that does not work (no P2P route, stale caching) shows up here as a wrong
+        sum or a timed-out wait instead of as a hung GPU in the first forward pass.  All ranks take the
+        same decision."""
+        lib = _lib.load()
+        ok = True
+        try:
+            _lib.check(lib.semipd_ar_set_timeout_ms(self._comm, 2000), "ar_set_timeout_ms")
+            with torch.cuda.device(self.device):
+                for numel in (8, 1 << 20):  # 16 B; 2 MB of bf16 (two-stage for more than 2 ranks)
+                    if numel * 2 > self.max_size:
+                        continue
+                    i = torch.arange(numel, device=self.device, dtype=torch.int64)
+                    mine = ((i * 7 + self.rank * 13) % 31).to(torch.bfloat16)
+                    want = sum(((i * 7 + r * 13) % 31) for r in range(self.world_size)).to(torch.bfloat16)
+                    for _ in range(3):  # both slots of the double buffer
+                        ok = ok and torch.equal(self.all_reduce(mine), want)
+                    gathered = self.all_gather(mine)
+                    for r in range(self.world_size):
+                        ok = ok and torch.equal(gathered[r], ((i * 7 + r * 13) % 31).to(torch.bfloat16))
+                torch.cuda.synchronize(self.device)
+                count = C.c_uint32()
+                _lib.check(lib.semipd_ar_timed_out(self._comm, C.addressof(count)), "ar_timed_out")
+                ok = ok and count.value == 0
+        except Exception as e:  # noqa: BLE001
+            logger.warning("peer-memory all-reduce self-test raised: %s", e)
+            ok = False
+        finally:
+            lib.semipd_ar_set_timeout_ms(self._comm, 0)
+        votes: List[Optional[bool]] = [None] * self.world_size
+        dist.all_gather_object(votes, bool(ok), group=self.group)
+        return all(votes)
+
+    # ------------------------------------------------------------------ policy
+    def should_custom_ar(self, inp: torch.Tensor) -> bool:
+        """custom_all_reduce.py:447-488: multiples of 16 bytes, (weakly) contiguous, below max_size."""
+        if self.disabled or not inp.is_cuda:
+            return False
+        if inp.dtype not in (torch.float32, torch.bfloat16, torch.float16):
+            return False
+        size = inp.numel() * inp.element_size()
+        if size == 0 or size % 16 != 0 or not inp.is_contiguous() or inp.data_ptr() % 16 != 0:
+            return False
+        return size <= self.max_size
+
+    # ------------------------------------------------------------------ calls
+    def all_reduce(self, inp: torch.Tensor, *, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Out-of-place SUM (custom_all_reduce.py:503-527); `out=inp` reduces in place."""
+        if out is None:
+            out = torch.empty_like(inp)
+        lib = _lib.load()
+        stream = torch.cuda.current_stream(inp.device).cuda_stream
+        _lib.check(lib.semipd_ar_all_reduce(self._comm, _lib.ptr(inp), _lib.ptr(out), inp.numel(),
+                                            _lib.dtype_code(inp.dtype), stream), "ar_all_reduce")
+        return out
+
+    def should_custom_ag(self, inp: torch.Tensor) -> bool:
+        if self.disabled or not inp.is_cuda or not inp.is_contiguous():
+            return False
+        size = inp.numel() * inp.element_size()
+        return size > 0 and size % 16 == 0 and inp.data_ptr() % 16 == 0 and size <= self.max_size
+
+    def all_gather(self, inp: torch.Tensor) -> torch.Tensor:
+        """[world, *inp.shape]: rank r's tensor at index r (any dtype: bytes are copied)."""
+        out = torch.empty((self.world_size,) + tuple(inp.shape), dtype=inp.dtype, device=inp.device)
+        lib = _lib.load()
+        stream = torch.cuda.current_stream(inp.device).cuda_stream
+        _lib.check(lib.semipd_ar_all_gather(self._comm, _lib.ptr(inp), _lib.ptr(out), inp.numel() * inp.element_size(),
+                                            stream), "ar_all_gather")
+        return out
+
+    def custom_all_reduce(self, input: torch.Tensor) -> Optional[torch.Tensor]:
+        """custom_all_reduce.py:529-552: None when the tensor does not qualify (the caller falls back to
+        RCCL).  Nothing differs between eager and captured calls here."""
+        if not self.should_custom_ar(input):
+            return None
+        return self.all_reduce(input)
+
+    @contextlib.contextmanager
+    def capture(self):
+        """custom_all_reduce.py:369-381 registers the graph's buffers afterwards; nothing to register here."""
+        self._IS_CAPTURING = True
+        try:
+            yield
+        finally:
+            self._IS_CAPTURING = False
+
+    def close(self) -> None:
+        if self._comm is None and self._region is None:
+            return
+        lib = _lib.load()
+        if self._comm is not None:
+            lib.semipd_ar_dispose(self._comm)
+            self._comm = None
+        for b in self._peer_bases:
+            lib.semipd_ipc_close(b)
+        self._peer_bases = []
+        if self._region is not None:
+            lib.semipd_ar_free_shared(self._region)
+            self._region = None
+        self.disabled = True
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

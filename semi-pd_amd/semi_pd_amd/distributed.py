@@ -10,6 +10,7 @@ On CPU tensors the same code runs over gloo, which is how tests cover world_size
 """
 from __future__ import annotations
 
+import os
 import pickle
 from typing import Any, List, Optional
 
@@ -20,13 +21,16 @@ _TP_RANK = 0
 _TP_SIZE = 1
 _DEVICE_GROUP: Optional[dist.ProcessGroup] = None
 _CPU_GROUP: Optional[dist.ProcessGroup] = None
+_CUSTOM_AR = None  # custom_all_reduce.CustomAllreduce, GPU ranks of one node only
 
 
 def init_distributed_environment(world_size: int, rank: int, distributed_init_method: str,
                                  backend: str = "nccl", device: Optional[torch.device] = None,
-                                 timeout_s: int = 600) -> None:
-    """model_runner.py:285-344 init_torch_distributed: one device group + one gloo group."""
-    global _TP_RANK, _TP_SIZE, _DEVICE_GROUP, _CPU_GROUP
+                                 timeout_s: int = 600, use_custom_all_reduce: bool = True) -> None:
+    """model_runner.py:285-344 init_torch_distributed: one device group + one gloo group, and the
+    peer-memory all-reduce on top of the gloo group (parallel_state.py:258-266 creates CustomAllreduce
+    on the cpu_group unless --disable-custom-all-reduce)."""
+    global _TP_RANK, _TP_SIZE, _DEVICE_GROUP, _CPU_GROUP, _CUSTOM_AR
     _TP_RANK, _TP_SIZE = rank, world_size
     if world_size == 1:
         _DEVICE_GROUP = _CPU_GROUP = None
@@ -41,10 +45,19 @@ def init_distributed_environment(world_size: int, rank: int, distributed_init_me
     _DEVICE_GROUP = dist.group.WORLD
     _CPU_GROUP = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=timeout_s)) \
         if backend != "gloo" else dist.group.WORLD
+    _CUSTOM_AR = None
+    if use_custom_all_reduce and device is not None and torch.device(device).type == "cuda" \
+            and os.environ.get("SEMIPD_DISABLE_CUSTOM_ALL_REDUCE", "0") != "1":
+        from semi_pd_amd.custom_all_reduce import CustomAllreduce
+        ar = CustomAllreduce(_CPU_GROUP, torch.device(device))
+        _CUSTOM_AR = None if ar.disabled else ar
 
 
 def destroy_distributed_environment() -> None:
-    global _TP_RANK, _TP_SIZE, _DEVICE_GROUP, _CPU_GROUP
+    global _TP_RANK, _TP_SIZE, _DEVICE_GROUP, _CPU_GROUP, _CUSTOM_AR
+    if _CUSTOM_AR is not None:
+        _CUSTOM_AR.close()
+        _CUSTOM_AR = None
     if dist.is_initialized():
         dist.destroy_process_group()
     _TP_RANK, _TP_SIZE, _DEVICE_GROUP, _CPU_GROUP = 0, 1, None, None
@@ -66,8 +79,15 @@ def tensor_model_parallel_all_reduce(input_: torch.Tensor) -> torch.Tensor:
     """SUM all-reduce of [T, hidden] after o_proj / down_proj / experts (layers/linear.py:1266)."""
     if _TP_SIZE == 1:
         return input_
+    if _CUSTOM_AR is not None and _CUSTOM_AR.should_custom_ar(input_):
+        # parallel_state.py:395-410: the peer-memory kernel first, RCCL for what it does not take
+        return _CUSTOM_AR.all_reduce(input_, out=input_)
     dist.all_reduce(input_, group=_DEVICE_GROUP)
     return input_
+
+
+def get_custom_all_reduce():
+    return _CUSTOM_AR
 
 
 def tensor_model_parallel_all_gather(input_: torch.Tensor, dim: int = -1) -> torch.Tensor:
@@ -78,15 +98,23 @@ def tensor_model_parallel_all_gather(input_: torch.Tensor, dim: int = -1) -> tor
     if dim < 0:
         dim += input_.dim()
     input_ = input_.contiguous()
+    if _CUSTOM_AR is not None and _CUSTOM_AR.should_custom_ag(input_):
+        out = _CUSTOM_AR.all_gather(input_)
+    else:
+        out = _gather_with_backend(input_)
+    out = out.movedim(0, dim)
+    shape = list(input_.shape)
+    shape[dim] = shape[dim] * _TP_SIZE
+    return out.reshape(shape)
+
+
+def _gather_with_backend(input_: torch.Tensor) -> torch.Tensor:
     out = torch.empty((_TP_SIZE,) + tuple(input_.shape), dtype=input_.dtype, device=input_.device)
     if dist.get_backend(_DEVICE_GROUP) == "nccl":
         dist.all_gather_into_tensor(out, input_, group=_DEVICE_GROUP)
     else:
         dist.all_gather(list(out.unbind(0)), input_, group=_DEVICE_GROUP)
-    out = out.movedim(0, dim)
-    shape = list(input_.shape)
-    shape[dim] = shape[dim] * _TP_SIZE
-    return out.reshape(shape)
+    return out
 
 
 def broadcast_pyobj(data: List[Any], rank: int, group, src: int = 0) -> List[Any]:

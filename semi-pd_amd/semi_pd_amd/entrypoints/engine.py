@@ -23,6 +23,7 @@ from typing import Dict, Iterable, List, Optional, Sequence
 
 from semi_pd_amd.managers.io_struct import (BatchTokenIDOut, SamplingParams, ShutdownReq, StatsReq,
                                             TokenizedGenerateReqInput)
+from semi_pd_amd.distributed import get_custom_all_reduce
 from semi_pd_amd.managers.transport import PullSocket, PushSocket
 from semi_pd_amd.semi_pd.utils import AggregatedSocket, InstanceRole
 from semi_pd_amd.server_args import SemiPDPortArgs, ServerArgs
@@ -42,7 +43,8 @@ def _build_runner(server_args: ServerArgs, gpu_id: int, tp_rank: int, role: Inst
         dist_backend=server_args.dist_backend, model_path=server_args.model_path,
         load_format=server_args.load_format, kv_cache_dtype=server_args.kv_cache_dtype,
         bypass_load_weight=bypass_load_weight, seed=server_args.random_seed, cu_percent=cu_percent,
-        disable_cuda_graph=server_args.disable_cuda_graph, cuda_graph_max_bs=server_args.cuda_graph_max_bs)
+        disable_cuda_graph=server_args.disable_cuda_graph, cuda_graph_max_bs=server_args.cuda_graph_max_bs,
+        disable_custom_all_reduce=server_args.disable_custom_all_reduce)
     if server_args.collect_kernel_timing:
         from semi_pd_amd.model_executor.kernel_timing import KernelTiming
         mr.kernel_timing = KernelTiming()
@@ -95,7 +97,8 @@ def run_scheduler_process(server_args: ServerArgs, port_args: SemiPDPortArgs, gp
         torch.cuda.synchronize()
         pipe_writer.send({"status": "ready", "max_total_num_tokens": mr.max_total_num_tokens,
                           "max_req_input_len": sched.max_req_input_len, "role": role.name,
-                          "tp_rank": tp_rank, "hsa_cu_mask": os.environ.get("HSA_CU_MASK", "")})
+                          "tp_rank": tp_rank, "hsa_cu_mask": os.environ.get("HSA_CU_MASK", ""),
+                          "custom_all_reduce": get_custom_all_reduce() is not None})
         sched.event_loop_normal()
     except Exception:
         msg = traceback.format_exc()

@@ -99,7 +99,7 @@ class ModelRunner:
                  bypass_load_weight: bool = False, seed: int = 0, cu_percent: int = 100,
                  disable_cuda_graph: bool = False, cuda_graph_max_bs: int = 256,
                  load_state_dict: Optional[Dict[str, torch.Tensor]] = None, model_path: Optional[str] = None,
-                 load_format: str = "dummy", kv_cache_dtype: str = "auto"):
+                 load_format: str = "dummy", kv_cache_dtype: str = "auto", disable_custom_all_reduce: bool = False):
         self.model_config = model_config
         self.gpu_id, self.tp_rank, self.tp_size = gpu_id, tp_rank, tp_size
         self.dtype = dtype
@@ -120,7 +120,8 @@ class ModelRunner:
         self.device = torch.device("cuda", gpu_id)
         torch.cuda.set_device(self.device)
         if tp_size > 1:
-            init_distributed_environment(tp_size, tp_rank, nccl_init_method, dist_backend, self.device)
+            init_distributed_environment(tp_size, tp_rank, nccl_init_method, dist_backend, self.device,
+                                         use_custom_all_reduce=not disable_custom_all_reduce)
         else:
             init_distributed_environment(1, 0, "", dist_backend)
         self.num_cus = get_device_sm_count(gpu_id)

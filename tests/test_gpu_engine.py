@@ -272,25 +272,29 @@ def test_semi_pd_tp2_on_one_gpu_matches_oracle(unified_llama):
     """Tensor parallel 2 with both ranks on the one GPU of the test box (gloo instead of RCCL, which
     refuses two ranks per device): 2 prefill + 2 decode processes, per-rank weight shards and KV pools
     shared P<->D through per-rank IPC handles, scheduler decisions broadcast from rank 0, all-reduce after
-    o_proj / down_proj, all-gather of the vocab-parallel logits.  Tokens must agree with the fp32 oracle
-    of the unsharded model."""
+    o_proj / down_proj, all-gather of the vocab-parallel logits.  Both collectives run through the
+    peer-memory kernels (csrc/all_reduce.hip) up to 16 MB, so the decode instance replays hipGraphs that
+    contain them; larger prefill batches fall back to the backend.  Tokens must agree with the fp32
+    oracle of the unsharded model; a second engine with --disable-custom-all-reduce agrees as well."""
     from semi_pd_amd.entrypoints.engine import Engine
     from semi_pd_amd.managers.io_struct import SamplingParams
     cfg, sd, prompts, outs, _ = unified_llama
-    eng = Engine(server_args(cfg, tp_size=2, enable_semi_pd=True, prefill_cu_percent=50, decode_cu_percent=50,
-                             dist_backend="gloo", disable_cuda_graph=True),
-                 gpu_ids={0: 0, 1: 0})
-    try:
-        assert sorted((i["role"], i["tp_rank"]) for i in eng.ready_infos) == [
-            ("DECODE", 0), ("DECODE", 1), ("PREFILL", 0), ("PREFILL", 1)]
-        semi = eng.generate(prompts, SamplingParams(max_new_tokens=12, ignore_eos=True), timeout=600)
-        assert all(len(o) == 12 for o in semi)
-        oracle = OracleLlama(cfg, sd)
-        check_against_oracle(oracle, prompts, semi)
-        if semi != outs:
-            _explain_mismatch(oracle, prompts, semi, outs)
-    finally:
-        eng.shutdown()
+    oracle = OracleLlama(cfg, sd)
+    for kw in (dict(), dict(disable_custom_all_reduce=True, disable_cuda_graph=True)):
+        eng = Engine(server_args(cfg, tp_size=2, enable_semi_pd=True, prefill_cu_percent=50, decode_cu_percent=50,
+                                 dist_backend="gloo", **kw),
+                     gpu_ids={0: 0, 1: 0})
+        try:
+            assert sorted((i["role"], i["tp_rank"]) for i in eng.ready_infos) == [
+                ("DECODE", 0), ("DECODE", 1), ("PREFILL", 0), ("PREFILL", 1)]
+            assert all(i.get("custom_all_reduce") == (not kw) for i in eng.ready_infos)
+            semi = eng.generate(prompts, SamplingParams(max_new_tokens=12, ignore_eos=True), timeout=600)
+            assert all(len(o) == 12 for o in semi)
+            check_against_oracle(oracle, prompts, semi)
+            if semi != outs:
+                _explain_mismatch(oracle, prompts, semi, outs)
+        finally:
+            eng.shutdown()
 
 
 def test_launch_server_semi_pd_http(unified_llama, tmp_path):
