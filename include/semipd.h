@@ -293,6 +293,33 @@ int semipd_moe_sum(void* out, const void* in, int64_t num_tokens, int topk, int6
                    int dtype, void* stream);
 
 /* ------------------------------------------------------------------ */
+/* 8f-4  block-scaled fp8 (layers/quantization/fp8_kernel.py, fused_moe_triton/fused_moe.py:174-243) */
+/* ------------------------------------------------------------------ */
+/* fp8 here is OCP e4m3fn (max 448), the format of gfx950's matrix cores; the reference's HIP branch
+ * uses e4m3fnuz / 224 for MI300 (fp8_kernel.py:191-194).
+ *
+ * q[r, g*G .. (g+1)*G) = fp8(clamp(x * (1 / s[r, g]), +-448)), s[r, g] = max(absmax, eps) / 448;
+ * replaces per_token_group_quant_fp8 (fp8_kernel.py:75-115, 165-250; row-major scales).
+ * x [num_rows, hidden] contiguous f32/bf16/f16, hidden % group_size == 0, group_size in {64,128,256,512}. */
+int semipd_per_token_group_quant_fp8(void* q, float* s, const void* x, int64_t num_rows, int64_t hidden,
+                                     int group_size, float eps, int dtype, void* stream);
+/* c[m, n] = sum_kb (sum_{k in kb} a_q[m,k] * w_q[n,k]) * a_s[m,kb] * w_s[n / block_n, kb], fp32
+ * accumulation; replaces w8a8_block_fp8_matmul (fp8_kernel.py:409-491, 694-800).
+ * a_q [m,k] fp8, a_s [m, ceil(k/128)] f32, w_q [n,k] fp8, w_s [ceil(n/block_n), ceil(k/128)] f32, all
+ * contiguous; block_k == 128, block_n % 16 == 0, k % 16 == 0; c [m,n] of out_dtype (f32/bf16/f16). */
+int semipd_w8a8_block_fp8_matmul(void* c, const void* a_q, const float* a_s, const void* w_q, const float* w_s,
+                                 int64_t m, int64_t n, int64_t k, int block_n, int block_k, int out_dtype, void* stream);
+/* semipd_moe_grouped_gemm with use_fp8_w8a8 and block_shape = [block_n, block_k]
+ * (fused_moe.py:174-243, 516-545): a_q [num_valid / top_k_div, k] fp8 with a_s [.., ceil(k/128)],
+ * w_q [E, n, k] fp8 with w_s [E, ceil(n/block_n), ceil(k/128)]; the other arguments as in
+ * semipd_moe_grouped_gemm. */
+int semipd_moe_grouped_gemm_fp8(void* c, const void* a_q, const float* a_s, const void* w_q, const float* w_s,
+                                const float* topk_weights, const int32_t* sorted_token_ids, const int32_t* expert_ids,
+                                const int32_t* num_tokens_post_pad, int64_t num_valid, int64_t n, int64_t k,
+                                int64_t max_sorted, int top_k_div, int mul_routed_weight, int block_m, int block_n,
+                                int block_k, int out_dtype, void* stream);
+
+/* ------------------------------------------------------------------ */
 /* a14  IPC seam (semi-pd-ipc/ipc.cpp:60-97)                           */
 /* ------------------------------------------------------------------ */
 /* handle = hipIpcMemHandle of the allocation that contains dev_ptr (64 bytes),

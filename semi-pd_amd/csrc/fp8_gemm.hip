@@ -1,0 +1,411 @@
+// Block-scaled fp8 (OCP e4m3fn) linear algebra for gfx950:
+//   * per_token_group_quant_fp8: activations -> fp8 + one fp32 scale per (row, group of K)
+//     (layers/quantization/fp8_kernel.py:75-115, 165-250);
+//   * w8a8_block_fp8_matmul: C[m, n] = sum_kb (sum_{k in block kb} Aq[m, k] * Wq[n, k]) * As[m, kb] * Ws[n / bn, kb]
+//     (fp8_kernel.py:409-491, 694-800) and its grouped form inside fused_moe_kernel
+//     (fused_moe_triton/fused_moe.py:174-243).
+//
+// The matmul is the weight-streaming kernel of skinny_gemm.hip with bytes instead of bf16: a wave owns
+// NG groups of 16 weight rows and streams them from HBM straight into MFMA operand registers, one chunk
+// of K ahead; the activation rows of the block (fp8) and their scales sit in LDS.  What changes:
+//   * half the weight bytes per output, so the decode-sized blocks stage 512 bytes of K per row to keep
+//     the same bytes in flight per lane (8 x 16 B, double buffered);
+//   * v_mfma_f32_16x16x32_fp8_fp8 takes 8 bytes per lane and k-step.  A lane still loads 16 contiguous
+//     bytes (k = q4 * 16 .. + 16 of a 64-wide super-step) and feeds the two halves to two MFMAs; the
+//     activation fragment is read from LDS with the same permutation, so the dot products are intact;
+//   * every 128 k (one scale block) the partial tile is folded into the accumulator with
+//     As[m, kb] * Ws[n-block, kb] — one multiply for the product of scales, four FMAs per tile.
+// The non-scaled fp8 MFMA runs at the bf16 rate on gfx950 (MI355X_MICROARCH.md); these calls are bound by
+// the weight stream at decode sizes and by L2 re-reads of the activations at prefill sizes, like their
+// bf16 counterparts.
+#include "common.h"
+
+namespace semipd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr float kFp8Max = 448.0f;  // torch.finfo(torch.float8_e4m3fn).max; the reference's HIP branch uses
+                                   // e4m3fnuz / 224 for MI300 (fp8_kernel.py:191-194), gfx950 is OCP
+
+// ------------------------------------------------------------------------------------------------
+// per-token-group quantisation: thread = 8 consecutive elements, a group = G / 8 consecutive lanes
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+per_token_group_quant_fp8_kernel(uint8_t* __restrict__ q, float* __restrict__ s, const T* __restrict__ x,
+                                 int64_t num_vec, int lanes_per_group, float eps) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // 8-element vector index
+  const bool live = i < num_vec;
+  float v[8];
+  if (live) {
+    if constexpr (sizeof(T) == 4) {
+      const float4 a = *reinterpret_cast<const float4*>(x + i * 8);
+      const float4 b = *reinterpret_cast<const float4*>(x + i * 8 + 4);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+      const Vec16<T> a = *reinterpret_cast<const Vec16<T>*>(x + i * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = Elem<T>::to_f(a.e[j]);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+  }
+  float amax = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(v[j]));
+  // groups are aligned runs of lanes_per_group lanes (8, 16, 32 or 64) inside the wave
+  for (int off = 1; off < lanes_per_group; off <<= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+  amax = fmaxf(amax, eps);
+  const float y_s = amax / kFp8Max;
+  const float y_s_inv = 1.0f / y_s;
+  if (!live) return;
+  float w[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) w[j] = fminf(fmaxf(v[j] * y_s_inv, -kFp8Max), kFp8Max);
+  uint2 p;
+  p.x = F8Cvt<f8e4m3_t>::pack2<false>(w[0], w[1], 0u);
+  p.x = F8Cvt<f8e4m3_t>::pack2<true>(w[2], w[3], p.x);
+  p.y = F8Cvt<f8e4m3_t>::pack2<false>(w[4], w[5], 0u);
+  p.y = F8Cvt<f8e4m3_t>::pack2<true>(w[6], w[7], p.y);
+  *reinterpret_cast<uint2*>(q + i * 8) = p;
+  if ((threadIdx.x & (lanes_per_group - 1)) == 0) s[i / lanes_per_group] = y_s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// block-scaled fp8 NT GEMM (dense and grouped)
+// ------------------------------------------------------------------------------------------------
+template <typename OutT, bool GROUPED, int BM, int NG, int KC>
+__global__ void __launch_bounds__(256, 2)
+fp8_block_gemm_kernel(OutT* __restrict__ c, const uint8_t* __restrict__ a, const float* __restrict__ a_s,
+                      const uint8_t* __restrict__ w, const float* __restrict__ w_s,
+                      const float* __restrict__ topk_weights, const int32_t* __restrict__ sorted_ids,
+                      const int32_t* __restrict__ expert_ids, const int32_t* __restrict__ num_post_pad,
+                      int64_t num_valid, int64_t M, int64_t N, int64_t K, int64_t ldc, int block_n, int top_k_div,
+                      int mul_routed_weight) {
+  static_assert(NG == 1 || NG == 2 || NG == 4, "NG = groups of 16 W rows per wave");
+  // KC = bytes of K staged per barrier pair: 512 for the 64-row blocks (8 x 16 B of weights in flight per
+  // lane, double buffered), 128 for the 128-row blocks (their 64 accumulator registers leave room for less)
+  static_assert(KC == 128 || KC == 256 || KC == 512, "whole scale blocks per chunk");
+  constexpr int SB = KC / 128;     // scale blocks per chunk
+  constexpr int SS = KC / 64;      // 64-wide super-steps per chunk (one 16-byte load per lane each)
+  constexpr int BNW = 16 * NG;     // W rows per wave
+  constexpr int MT = BM / 16;      // m-tiles
+  constexpr int AS = KC + 16;      // LDS row stride in bytes
+  constexpr int CPRW = KC / 16;    // 16-byte chunks per staged row
+  constexpr int RPP = 256 / CPRW;  // rows staged per pass of the 256 threads
+  constexpr int NA = BM / RPP;     // 16-byte activation chunks per thread per K-chunk
+  static_assert(BM * SB <= 256, "one scale per thread");
+  __shared__ __attribute__((aligned(16))) uint8_t a_lds[BM * AS];
+  __shared__ float as_lds[BM * SB];
+  __shared__ int row_id[BM];
+  __shared__ int n_rows;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c16 = lane & 15, q4 = lane >> 4;
+  const int64_t m0 = (int64_t)blockIdx.y * BM;
+  const int64_t n0 = (int64_t)blockIdx.x * (4 * BNW) + wave * BNW;
+  const int64_t KB = (K + 127) / 128;  // scale blocks along K
+  int64_t expert = 0;
+  if (GROUPED) {
+    if (m0 >= *num_post_pad) return;
+    expert = expert_ids[blockIdx.y];
+    if (tid < BM) {
+      const int sid = sorted_ids[m0 + tid];
+      row_id[tid] = (sid >= 0 && sid < num_valid) ? sid : -1;
+    }
+  } else {
+    if (tid < BM) row_id[tid] = (m0 + tid < M) ? (int)(m0 + tid) : -1;
+  }
+  if (tid == 0) n_rows = 0;
+  __syncthreads();
+  if (tid < BM && row_id[tid] >= 0) atomicMax(&n_rows, tid + 1);
+  __syncthreads();
+  const int m_tiles = (n_rows + 15) >> 4;
+  if (m_tiles == 0) return;
+
+  const int ch = tid % CPRW, r0 = tid / CPRW;
+  int64_t a_off[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int rid = row_id[r0 + RPP * i];
+    const int64_t arow = GROUPED ? (int64_t)(rid / top_k_div) : (int64_t)rid;
+    a_off[i] = rid >= 0 ? arow * K + ch * 16 : -1;
+  }
+  // activation scale slot of this thread: row tid / SB, scale block tid % SB of the chunk
+  int64_t s_off = -1;
+  const int s_j = tid % SB;
+  if (tid < BM * SB) {
+    const int rid = row_id[tid / SB];
+    const int64_t arow = GROUPED ? (int64_t)(rid / top_k_div) : (int64_t)rid;
+    if (rid >= 0) s_off = arow * KB + s_j;
+  }
+  bool w_ok[NG];
+  const uint8_t* w_ptr[NG];
+  const float* ws_ptr[NG];
+  const int64_t NB = (N + block_n - 1) / block_n;
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    w_ok[g] = (n0 + g * 16 + c16) < N;
+    w_ptr[g] = w + expert * N * K + (w_ok[g] ? (n0 + g * 16 + c16) : 0) * K + q4 * 16;
+    const int64_t nb = (n0 + g * 16 < N ? n0 + g * 16 : 0) / block_n;  // one scale row per group of 16 (16 | block_n)
+    ws_ptr[g] = w_s + (expert * NB + nb) * KB;
+  }
+
+  uint4 areg[NA];
+  float sreg = 0.f;
+  uint4 wreg[2][NG][SS];
+  auto fetch_a = [&](int64_t k0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      areg[i] = make_uint4(0, 0, 0, 0);
+      if (a_off[i] >= 0 && k0 + ch * 16 < K) areg[i] = *reinterpret_cast<const uint4*>(a + a_off[i] + k0);
+    }
+    sreg = 0.f;
+    if (s_off >= 0 && k0 / 128 + s_j < KB) sreg = a_s[s_off + k0 / 128];
+  };
+  auto fetch_w = [&](uint4 (&r)[NG][SS], int64_t k0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+#pragma unroll
+      for (int ss = 0; ss < SS; ++ss) {
+        r[g][ss] = make_uint4(0, 0, 0, 0);
+        if (w_ok[g] && k0 + ss * 64 + q4 * 16 < K) r[g][ss] = *reinterpret_cast<const uint4*>(w_ptr[g] + k0 + ss * 64);
+      }
+    }
+  };
+  auto stage_a = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) *reinterpret_cast<uint4*>(&a_lds[(r0 + RPP * i) * AS + ch * 16]) = areg[i];
+    if (tid < BM * SB) as_lds[tid] = sreg;
+  };
+
+  f32x4 acc[NG][MT];
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[g][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const uint8_t* a_rd = &a_lds[c16 * AS + q4 * 16];
+
+  auto compute = [&](uint4 (&r)[NG][SS], int64_t k0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int sb = 0; sb < SB; ++sb) {
+      const int64_t kb = k0 / 128 + sb;
+      if (kb >= KB) break;
+      float wsc[NG];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) wsc[g] = ws_ptr[g][kb];
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        if (t < m_tiles) {
+          f32x4 blk[NG];
+#pragma unroll
+          for (int g = 0; g < NG; ++g) blk[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {  // the two super-steps of this scale block
+            const int ss = sb * 2 + h;
+            const uint4 b = *reinterpret_cast<const uint4*>(a_rd + t * 16 * AS + ss * 64);
+            const long b_lo = (long)(((uint64_t)b.y << 32) | b.x), b_hi = (long)(((uint64_t)b.w << 32) | b.z);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+              const long w_lo = (long)(((uint64_t)r[g][ss].y << 32) | r[g][ss].x);
+              const long w_hi = (long)(((uint64_t)r[g][ss].w << 32) | r[g][ss].z);
+              blk[g] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(w_lo, b_lo, blk[g], 0, 0, 0);
+              blk[g] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(w_hi, b_hi, blk[g], 0, 0, 0);
+            }
+          }
+          const float asc = as_lds[(t * 16 + c16) * SB + sb];
+#pragma unroll
+          for (int g = 0; g < NG; ++g) {
+            const float sc = asc * wsc[g];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[g][t][e] += blk[g][e] * sc;
+          }
+        }
+      }
+    }
+  };
+
+  fetch_a(0);
+  fetch_w(wreg[0], 0);
+  for (int64_t k0 = 0; k0 < K; k0 += 2 * KC) {
+    __syncthreads();
+    stage_a();
+    __syncthreads();
+    if (k0 + KC < K) {
+      fetch_a(k0 + KC);
+      fetch_w(wreg[1], k0 + KC);
+    }
+    compute(wreg[0], k0);
+    if (k0 + KC < K) {
+      __syncthreads();
+      stage_a();
+      __syncthreads();
+      if (k0 + 2 * KC < K) {
+        fetch_a(k0 + 2 * KC);
+        fetch_w(wreg[0], k0 + 2 * KC);
+      }
+      compute(wreg[1], k0 + KC);
+    }
+  }
+
+  // ---- epilogue: lane holds C^T[n = n0 + g*16 + q4*4 + r][m = t*16 + c16] ----
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const int64_t nb = n0 + g * 16 + q4 * 4;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      if (t >= m_tiles) continue;
+      const int rid = row_id[t * 16 + c16];
+      if (rid < 0 || nb >= N) continue;
+      float v[4];
+      const float scale = (GROUPED && mul_routed_weight) ? topk_weights[rid] : 1.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[g][t][r] * scale;
+      OutT* dst = c + (int64_t)rid * ldc + nb;
+      if (nb + 4 <= N && (ldc % 4 == 0)) {
+        if constexpr (sizeof(OutT) == 4) {
+          *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          uint2 p;
+          p.x = (uint32_t)Elem<OutT>::from_f(v[0]).v | ((uint32_t)Elem<OutT>::from_f(v[1]).v << 16);
+          p.y = (uint32_t)Elem<OutT>::from_f(v[2]).v | ((uint32_t)Elem<OutT>::from_f(v[3]).v << 16);
+          *reinterpret_cast<uint2*>(dst) = p;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (nb + r < N) {
+            if constexpr (sizeof(OutT) == 4) *reinterpret_cast<float*>(dst + r) = v[r];
+            else dst[r] = Elem<OutT>::from_f(v[r]);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <typename OutT, bool GROUPED, int BM, int NG, int KC>
+static int launch_fp8_gemm(void* c, const void* a, const float* a_s, const void* w, const float* w_s,
+                           const float* topk_weights, const int32_t* sorted_ids, const int32_t* expert_ids,
+                           const int32_t* num_post_pad, int64_t num_valid, int64_t M, int64_t N, int64_t K, int64_t ldc,
+                           int64_t m_blocks, int block_n, int top_k_div, int mul_routed_weight, hipStream_t st) {
+  constexpr int64_t kRowsPerWg = 64 * NG;
+  dim3 grid((unsigned)((N + kRowsPerWg - 1) / kRowsPerWg), (unsigned)m_blocks);
+  hipLaunchKernelGGL((fp8_block_gemm_kernel<OutT, GROUPED, BM, NG, KC>), grid, dim3(256), 0, st, (OutT*)c, (const uint8_t*)a,
+                     a_s, (const uint8_t*)w, w_s, topk_weights, sorted_ids, expert_ids, num_post_pad, num_valid, M, N, K,
+                     ldc, block_n, top_k_div, mul_routed_weight);
+  return launch_status("fp8_block_gemm");
+}
+
+template <bool GROUPED>
+static int dispatch_fp8_gemm(void* c, const void* a, const float* a_s, const void* w, const float* w_s,
+                             const float* topk_weights, const int32_t* sorted_ids, const int32_t* expert_ids,
+                             const int32_t* num_post_pad, int64_t num_valid, int64_t M, int64_t N, int64_t K, int64_t ldc,
+                             int64_t m_blocks, int block_m, int block_n, int top_k_div, int mul_routed_weight,
+                             int out_dtype, hipStream_t st) {
+#define GO(OutT)                                                                                                       \
+  do {                                                                                                                 \
+    if (block_m == 128)                                                                                                \
+      return launch_fp8_gemm<OutT, GROUPED, 128, 2, 128>(c, a, a_s, w, w_s, topk_weights, sorted_ids, expert_ids,          \
+                                                    num_post_pad, num_valid, M, N, K, ldc, m_blocks, block_n, top_k_div, \
+                                                    mul_routed_weight, st);                                            \
+    return launch_fp8_gemm<OutT, GROUPED, 64, 1, 512>(c, a, a_s, w, w_s, topk_weights, sorted_ids, expert_ids, num_post_pad, \
+                                                 num_valid, M, N, K, ldc, m_blocks, block_n, top_k_div,                \
+                                                 mul_routed_weight, st);                                               \
+  } while (0)
+  switch (out_dtype) {
+    case SEMIPD_BF16: GO(bf16_t);
+    case SEMIPD_F16: GO(f16_t);
+    case SEMIPD_F32: GO(float);
+  }
+#undef GO
+  set_error("block fp8 matmul: output dtype code %d is not f32 / bf16 / f16", out_dtype);
+  return SEMIPD_EDTYPE;
+}
+
+static int check_fp8_gemm_args(const char* what, int64_t N, int64_t K, int block_n, int block_k, const void* a,
+                               const void* w) {
+  SEMIPD_CHECK_ARG(block_k == 128, SEMIPD_ESHAPE, "%s: block_k must be 128 (got %d)", what, block_k);
+  SEMIPD_CHECK_ARG(block_n > 0 && block_n % 16 == 0, SEMIPD_ESHAPE, "%s: block_n must be a multiple of 16 (got %d)", what,
+                   block_n);
+  SEMIPD_CHECK_ARG(N > 0 && K > 0 && K % 16 == 0, SEMIPD_ESHAPE, "%s: K must be a positive multiple of 16 (N=%lld K=%lld)",
+                   what, (long long)N, (long long)K);
+  SEMIPD_CHECK_ARG(aligned16(a) && aligned16(w), SEMIPD_EALIGN, "%s: operands must be 16-byte aligned", what);
+  return 0;
+}
+
+}  // namespace semipd
+
+using namespace semipd;
+
+extern "C" {
+
+int semipd_per_token_group_quant_fp8(void* q, float* s, const void* x, int64_t num_rows, int64_t hidden,
+                                     int group_size, float eps, int dtype, void* stream) {
+  SEMIPD_CHECK_ARG(q && s && x, SEMIPD_EINVAL, "per_token_group_quant_fp8: null pointer");
+  SEMIPD_CHECK_ARG(group_size == 64 || group_size == 128 || group_size == 256 || group_size == 512, SEMIPD_ESHAPE,
+                   "per_token_group_quant_fp8: group size %d is not one of 64, 128, 256, 512", group_size);
+  // fp8_kernel.py:183-186: "the last dimension of `x` cannot be divisible by `group_size`"
+  SEMIPD_CHECK_ARG(hidden > 0 && hidden % group_size == 0, SEMIPD_ESHAPE,
+                   "per_token_group_quant_fp8: hidden size %lld is not a multiple of the group size %d", (long long)hidden,
+                   group_size);
+  SEMIPD_CHECK_ARG(aligned16(x) && (reinterpret_cast<uintptr_t>(q) & 7u) == 0, SEMIPD_EALIGN,
+                   "per_token_group_quant_fp8: x must be 16-byte and q 8-byte aligned");
+  if (num_rows == 0) return 0;
+  const int64_t num_vec = num_rows * hidden / 8;
+  dim3 grid((unsigned)((num_vec + 255) / 256));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int lpg = group_size / 8;
+  switch (dtype) {
+    case SEMIPD_F32:
+      hipLaunchKernelGGL((per_token_group_quant_fp8_kernel<float>), grid, dim3(256), 0, st, (uint8_t*)q, s, (const float*)x,
+                         num_vec, lpg, eps);
+      break;
+    case SEMIPD_BF16:
+      hipLaunchKernelGGL((per_token_group_quant_fp8_kernel<bf16_t>), grid, dim3(256), 0, st, (uint8_t*)q, s,
+                         (const bf16_t*)x, num_vec, lpg, eps);
+      break;
+    case SEMIPD_F16:
+      hipLaunchKernelGGL((per_token_group_quant_fp8_kernel<f16_t>), grid, dim3(256), 0, st, (uint8_t*)q, s, (const f16_t*)x,
+                         num_vec, lpg, eps);
+      break;
+    default:
+      set_error("per_token_group_quant_fp8: dtype code %d is not f32 / bf16 / f16", dtype);
+      return SEMIPD_EDTYPE;
+  }
+  return launch_status("per_token_group_quant_fp8");
+}
+
+int semipd_w8a8_block_fp8_matmul(void* c, const void* a_q, const float* a_s, const void* w_q, const float* w_s,
+                                 int64_t m, int64_t n, int64_t k, int block_n, int block_k, int out_dtype, void* stream) {
+  SEMIPD_CHECK_ARG(c && a_q && a_s && w_q && w_s, SEMIPD_EINVAL, "w8a8_block_fp8_matmul: null pointer");
+  if (int rc = check_fp8_gemm_args("w8a8_block_fp8_matmul", n, k, block_n, block_k, a_q, w_q)) return rc;
+  if (m == 0) return 0;
+  // up to 64 rows: one pass over the weights with 64-row blocks; more: 128-row blocks, 128 W rows per workgroup
+  const int block_m = m <= 64 ? 64 : 128;
+  const int64_t m_blocks = (m + block_m - 1) / block_m;
+  return dispatch_fp8_gemm<false>(c, a_q, a_s, w_q, w_s, nullptr, nullptr, nullptr, nullptr, 0, m, n, k, n, m_blocks, block_m,
+                                  block_n, 1, 0, out_dtype, static_cast<hipStream_t>(stream));
+}
+
+int semipd_moe_grouped_gemm_fp8(void* c, const void* a_q, const float* a_s, const void* w_q, const float* w_s,
+                                const float* topk_weights, const int32_t* sorted_token_ids, const int32_t* expert_ids,
+                                const int32_t* num_tokens_post_pad, int64_t num_valid, int64_t n, int64_t k,
+                                int64_t max_sorted, int top_k_div, int mul_routed_weight, int block_m, int block_n,
+                                int block_k, int out_dtype, void* stream) {
+  SEMIPD_CHECK_ARG(c && a_q && a_s && w_q && w_s && sorted_token_ids && expert_ids && num_tokens_post_pad, SEMIPD_EINVAL,
+                   "moe_grouped_gemm_fp8: null pointer");
+  SEMIPD_CHECK_ARG(!mul_routed_weight || topk_weights, SEMIPD_EINVAL, "moe_grouped_gemm_fp8: routed weights missing");
+  SEMIPD_CHECK_ARG(block_m == 64 || block_m == 128, SEMIPD_ESHAPE, "moe_grouped_gemm_fp8: block_m must be 64 or 128");
+  SEMIPD_CHECK_ARG(top_k_div >= 1 && max_sorted >= 0, SEMIPD_ESHAPE, "moe_grouped_gemm_fp8: top_k_div %d, max_sorted %lld",
+                   top_k_div, (long long)max_sorted);
+  if (int rc = check_fp8_gemm_args("moe_grouped_gemm_fp8", n, k, block_n, block_k, a_q, w_q)) return rc;
+  if (num_valid == 0 || max_sorted == 0) return 0;
+  return dispatch_fp8_gemm<true>(c, a_q, a_s, w_q, w_s, topk_weights, sorted_token_ids, expert_ids, num_tokens_post_pad,
+                                 num_valid, 0, n, k, n, (max_sorted + block_m - 1) / block_m, block_m, block_n, top_k_div,
+                                 mul_routed_weight,
+                                 out_dtype, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

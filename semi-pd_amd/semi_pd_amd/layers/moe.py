@@ -57,6 +57,39 @@ def fused_experts(hidden_states: torch.Tensor, w1: torch.Tensor, w2: torch.Tenso
     return ops.moe_sum(c3.view(T, topk, K))
 
 
+def fused_experts_fp8(hidden_states: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, w1_scale: torch.Tensor,
+                      w2_scale: torch.Tensor, topk_weights: torch.Tensor, topk_ids: torch.Tensor, block_shape,
+                      block_m: Optional[int] = None) -> torch.Tensor:
+    """fused_experts_impl with use_fp8_w8a8 and block_shape = [block_n, block_k] (fused_moe.py:961-1165;
+    activation quantisation inside invoke_fused_moe_kernel :526-545): the activations of both GEMMs are
+    quantised per token and group of block_k, the weights are fp8 [E, 2N, K] / [E, K, N] with one scale per
+    block_n x block_k tile.  Returns [T, K] in the dtype of hidden_states."""
+    T, K = hidden_states.shape
+    E, N2, _ = w1.shape
+    topk = topk_ids.shape[1]
+    dev, dt = hidden_states.device, hidden_states.dtype
+    numel = T * topk
+    block_k = int(block_shape[1])
+    if block_m is None:
+        block_m = MOE_BLOCK_M if numel <= 2048 else 2 * MOE_BLOCK_M
+    max_sorted = numel + E * (block_m - 1)
+    sorted_ids = torch.empty(max_sorted, dtype=torch.int32, device=dev)
+    expert_ids = torch.empty((max_sorted + block_m - 1) // block_m, dtype=torch.int32, device=dev)
+    num_post_pad = torch.empty(1, dtype=torch.int32, device=dev)
+    cumsum = torch.empty(E + 1, dtype=torch.int32, device=dev)
+    ops.moe_align_block_size(topk_ids, E, block_m, sorted_ids, expert_ids, num_post_pad, None, cumsum)
+    a_q, a_s = ops.per_token_group_quant_fp8(hidden_states, block_k)
+    c1 = torch.empty((numel, N2), dtype=dt, device=dev)
+    ops.moe_grouped_gemm_fp8(a_q, a_s, w1, w1_scale, c1, None, sorted_ids, expert_ids, num_post_pad, numel, topk,
+                             False, block_shape, block_m)
+    c2 = ops.silu_and_mul(c1)
+    c2_q, c2_s = ops.per_token_group_quant_fp8(c2, block_k)
+    c3 = torch.empty((numel, K), dtype=dt, device=dev)
+    ops.moe_grouped_gemm_fp8(c2_q, c2_s, w2, w2_scale, c3, topk_weights.reshape(-1).float(), sorted_ids, expert_ids,
+                             num_post_pad, numel, 1, True, block_shape, block_m)
+    return ops.moe_sum(c3.view(T, topk, K))
+
+
 class FusedMoE(nn.Module):
     def __init__(self, num_experts: int, top_k: int, hidden_size: int, intermediate_size: int,
                  renormalize: bool = True, use_grouped_topk: bool = False, num_expert_group: Optional[int] = None,

@@ -535,3 +535,66 @@ def moe_sum(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor
     check(lib.semipd_moe_sum(ptr(out), ptr(x.contiguous()), T, k, H, dtype_code(x.dtype),
                              current_stream(x.device)), "moe_sum")
     return out
+
+
+# --------------------------------------------------------------------------- block-scaled fp8
+FP8_DTYPE = torch.float8_e4m3fn  # OCP e4m3fn: what gfx950's matrix cores take (the reference's HIP branch: e4m3fnuz)
+
+
+def per_token_group_quant_fp8(x: torch.Tensor, group_size: int, eps: float = 1e-10,
+                              dtype: torch.dtype = FP8_DTYPE, column_major_scales: bool = False):
+    """layers/quantization/fp8_kernel.py:165-250: (x_q, x_s) with one fp32 scale per group of `group_size`
+    consecutive elements of the last dimension; row-major scales only."""
+    if dtype != FP8_DTYPE:
+        raise RuntimeError(f"per_token_group_quant_fp8: only {FP8_DTYPE} is supported on gfx950")
+    if column_major_scales:
+        raise RuntimeError("per_token_group_quant_fp8: column-major scales are a DeepGEMM layout, not used here")
+    if x.shape[-1] % group_size != 0:
+        raise RuntimeError("the last dimension of `x` cannot be divisible by `group_size`")
+    if not x.is_contiguous():
+        raise RuntimeError("`x` is not contiguous")
+    x_q = torch.empty(x.shape, dtype=dtype, device=x.device)
+    x_s = torch.empty(x.shape[:-1] + (x.shape[-1] // group_size,), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    check(lib.semipd_per_token_group_quant_fp8(ptr(x_q), ptr(x_s), ptr(x), x.numel() // x.shape[-1], x.shape[-1],
+                                               group_size, float(eps), dtype_code(x.dtype), current_stream(x.device)),
+          "per_token_group_quant_fp8")
+    return x_q, x_s
+
+
+def w8a8_block_fp8_matmul(A: torch.Tensor, B: torch.Tensor, As: torch.Tensor, Bs: torch.Tensor,
+                          block_size, output_dtype: torch.dtype = torch.float16) -> torch.Tensor:
+    """fp8_kernel.py:694-800: A [..., K] fp8 with As [..., ceil(K/bk)], B [N, K] fp8 with Bs [ceil(N/bn), ceil(K/bk)]."""
+    block_n, block_k = int(block_size[0]), int(block_size[1])
+    N, K = B.shape
+    if A.shape[-1] != K or A.shape[:-1] != As.shape[:-1] or not (A.is_contiguous() and B.is_contiguous()):
+        raise RuntimeError("w8a8_block_fp8_matmul: shape / contiguity mismatch")
+    if As.shape[-1] != -(-K // block_k) or tuple(Bs.shape) != (-(-N // block_n), -(-K // block_k)):
+        raise RuntimeError("w8a8_block_fp8_matmul: scale shapes do not match the block size")
+    if A.dtype != FP8_DTYPE or B.dtype != FP8_DTYPE:
+        raise RuntimeError(f"w8a8_block_fp8_matmul: operands must be {FP8_DTYPE}")
+    M = A.numel() // K
+    C = torch.empty(A.shape[:-1] + (N,), dtype=output_dtype, device=A.device)
+    lib = _lib.load()
+    check(lib.semipd_w8a8_block_fp8_matmul(ptr(C), ptr(A), ptr(As.contiguous().float()), ptr(B),
+                                           ptr(Bs.contiguous().float()), M, N, K, block_n, block_k,
+                                           dtype_code(output_dtype), current_stream(A.device)),
+          "w8a8_block_fp8_matmul")
+    return C
+
+
+def moe_grouped_gemm_fp8(a_q: torch.Tensor, a_s: torch.Tensor, w_q: torch.Tensor, w_s: torch.Tensor, c: torch.Tensor,
+                         topk_weights: Optional[torch.Tensor], sorted_token_ids: torch.Tensor,
+                         expert_ids: torch.Tensor, num_tokens_post_pad: torch.Tensor, num_valid: int,
+                         top_k_div: int, mul_routed_weight: bool, block_shape, block_m: int = 64) -> None:
+    """invoke_fused_moe_kernel with use_fp8_w8a8 and block_shape (fused_moe.py:501-612, kernel :174-243)."""
+    E, N, K = w_q.shape
+    if a_q.shape[-1] != K or c.shape[-1] != N or not (a_q.is_contiguous() and w_q.is_contiguous() and c.is_contiguous()
+                                                      and a_s.is_contiguous() and w_s.is_contiguous()):
+        raise RuntimeError("moe_grouped_gemm_fp8: shape / contiguity mismatch")
+    lib = _lib.load()
+    check(lib.semipd_moe_grouped_gemm_fp8(ptr(c), ptr(a_q), ptr(a_s), ptr(w_q), ptr(w_s), ptr(topk_weights),
+                                          ptr(sorted_token_ids), ptr(expert_ids), ptr(num_tokens_post_pad), num_valid,
+                                          N, K, sorted_token_ids.numel(), top_k_div, int(mul_routed_weight), block_m,
+                                          int(block_shape[0]), int(block_shape[1]), dtype_code(c.dtype),
+                                          current_stream(c.device)), "moe_grouped_gemm_fp8")

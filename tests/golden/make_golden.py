@@ -315,8 +315,86 @@ def gen_sampling():
     save("sampling", **arrs)
 
 
+def _reference_fp8_kernels():
+    """layers/quantization/__init__.py imports every quantisation method (vLLM's scalar types included), so
+    fp8_kernel.py is loaded as a stand-alone module.  Its HIP branch is written for MI300 (e4m3fnuz, 224):
+    the golden vectors are made on the other branch, OCP e4m3fn / 448, the fp8 of gfx950."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "ref_fp8_kernel", "/root/reference/python/sglang/srt/layers/quantization/fp8_kernel.py")
+    FK = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(FK)
+    FK._is_hip = False
+    FK._is_cuda = False
+    FK.get_device_name = lambda *a, **k: "cpu"
+    return FK
+
+
+def _reference_native_fp8_helpers():
+    """The torch helpers the reference's own test compares its kernels with (test/test_block_fp8.py:19-44):
+    compiled from the file at generation time, nothing of it is stored."""
+    import ast
+    path = "/root/reference/python/sglang/test/test_block_fp8.py"
+    tree = ast.parse(open(path).read())
+    want = {"native_per_token_group_quant_fp8"}
+    mod = ast.Module(body=[n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in want], type_ignores=[])
+    ns = {"torch": torch}
+    exec(compile(mod, path, "exec"), ns)
+    return ns["native_per_token_group_quant_fp8"]
+
+
+def f8bits(t: torch.Tensor) -> np.ndarray:
+    return t.contiguous().view(torch.uint8).numpy()
+
+
+def gen_fp8():
+    """per_token_group_quant_fp8 and w8a8_block_fp8_matmul: the reference's Triton kernels run by the Triton
+    interpreter (fp8_kernel.py:75-115, 409-491)."""
+    FK = _reference_fp8_kernels()
+    native_quant = _reference_native_fp8_helpers()
+    g = torch.Generator().manual_seed(21)
+    arrs = {}
+    cases = []
+    for i, (rows, hidden, group, dtype) in enumerate([(3, 256, 128, torch.float32), (7, 512, 64, torch.bfloat16),
+                                                       (5, 1024, 256, torch.float16), (2, 1024, 512, torch.bfloat16),
+                                                       (9, 384, 128, torch.bfloat16)]):
+        x = (torch.randn(rows, hidden, generator=g) * (10.0 ** torch.randint(-3, 3, (rows, 1), generator=g))).to(dtype)
+        x[0, :group] = 0  # an all-zero group: the eps path
+        if rows > 1:
+            x[1, 3] = 30000.0 if dtype != torch.float16 else 6e4  # one outlier sets the scale of its group
+        q, s = FK.per_token_group_quant_fp8(x, group, dtype=torch.float8_e4m3fn)
+        arrs[f"quant{i}_x"] = bits(x) if dtype == torch.bfloat16 else x.numpy()
+        arrs[f"quant{i}_q"] = f8bits(q)
+        arrs[f"quant{i}_s"] = s.numpy()
+        # the Triton INTERPRETER casts f32 -> fp8 with its own numpy code (ties away from zero, and a value
+        # that rounds up into the next binade comes out halved); the torch helper casts with torch (RNE)
+        qn, sn = native_quant(x, group)
+        arrs[f"quant{i}_q_native"] = f8bits(qn)
+        arrs[f"quant{i}_s_native"] = sn.numpy()
+        cases.append([rows, hidden, group, {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[dtype]])
+    arrs["quant_cases"] = np.array(cases)
+    mm = []
+    for i, (M, N, K, out_dtype) in enumerate([(1, 144, 256, torch.float32), (7, 512, 384, torch.bfloat16),
+                                               (83, 200, 1024, torch.float16), (5, 128, 128, torch.bfloat16),
+                                               (33, 272, 400, torch.float32)]):
+        A = (torch.rand(M, K, generator=g) - 0.5) * 2 * 448
+        B = (torch.rand(N, K, generator=g) - 0.5) * 2 * 448
+        Aq = A.clamp(-448, 448).to(torch.float8_e4m3fn)
+        Bq = B.clamp(-448, 448).to(torch.float8_e4m3fn)
+        kt, nt = (K + 127) // 128, (N + 127) // 128
+        As = torch.rand(M, kt, generator=g) * 1e-2
+        Bs = torch.rand(nt, kt, generator=g) * 1e-2
+        C = FK.w8a8_block_fp8_matmul(Aq, Bq, As, Bs, [128, 128], out_dtype)
+        arrs[f"mm{i}_a"], arrs[f"mm{i}_b"] = f8bits(Aq), f8bits(Bq)
+        arrs[f"mm{i}_as"], arrs[f"mm{i}_bs"] = As.numpy(), Bs.numpy()
+        arrs[f"mm{i}_c"] = bits(C) if out_dtype == torch.bfloat16 else C.numpy()
+        mm.append([M, N, K, {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[out_dtype]])
+    arrs["mm_cases"] = np.array(mm)
+    save("block_fp8", **arrs)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rmsnorm", "rope", "kv_indices", "topk", "decode", "extend", "sampling"]
+    which = sys.argv[1:] or ["rmsnorm", "rope", "kv_indices", "topk", "decode", "extend", "sampling", "fp8"]
     for w in which:
         {"rmsnorm": gen_rmsnorm, "rope": gen_rope, "kv_indices": gen_kv_indices, "topk": gen_topk,
-         "decode": gen_decode, "extend": gen_extend, "sampling": gen_sampling}[w]()
+         "decode": gen_decode, "extend": gen_extend, "sampling": gen_sampling, "fp8": gen_fp8}[w]()

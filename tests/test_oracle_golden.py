@@ -201,3 +201,68 @@ def test_sampling_renorm_formulas_agree():
     d = O.top_k_top_p_min_p_filter(probs, torch.full((5,), 20, dtype=torch.int32), torch.full((5,), 0.5),
                                    torch.zeros(5), False)
     assert ((d > 0).int() <= m).all()
+
+
+FP8_CODE = {0: torch.float32, 1: torch.bfloat16, 2: torch.float16}
+
+
+def test_block_fp8_quant_matches_reference():
+    """oracle.per_token_group_quant_fp8 against two outputs of the reference on the same inputs:
+    * its Triton kernel (fp8_kernel.py:75-115) run by the Triton interpreter on the e4m3fn / 448 branch: the
+      scales are bit-identical; the quantised bytes are identical except where the INTERPRETER's own
+      f32 -> fp8 cast is wrong (it rounds ties away from zero, and a value that rounds up into the next binade
+      comes out with half the magnitude, subnormal results are flushed) — every mismatch must be one of those;
+    * the torch helper of its test (test_block_fp8.py:19-44, torch's RNE cast, but x / s instead of
+      x * (1 / s)): scales bit-identical (but for the eps group, clamped in the input dtype there), bytes identical except a few neighbours-by-one-code where the two
+      quotients differ in the last bit."""
+    g = load_golden("block_fp8")
+
+    def f8(arr):
+        return torch.from_numpy(arr.copy()).view(torch.float8_e4m3fn).float()
+
+    for i, (rows, hidden, group, code) in enumerate(g["quant_cases"].tolist()):
+        dt = FP8_CODE[code]
+        x = from_bits(g[f"quant{i}_x"], dt)
+        q, s = O.per_token_group_quant_fp8(x, group)
+        assert torch.equal(s, torch.from_numpy(g[f"quant{i}_s"])), i
+        s_native = torch.from_numpy(g[f"quant{i}_s_native"])
+        live = s > 1e-12  # the helper clamps to eps in the input dtype: bf16(1e-10) is not 1e-10, f16(1e-10) is 0
+        assert torch.equal(s[live], s_native[live]), i
+        assert float(s[0, 0]) == pytest.approx(1e-10 / 448.0)  # the all-zero group sits on eps
+        mine = q.view(torch.uint8).numpy()
+        scaled = (x.float().reshape(-1, group) * (1.0 / s.reshape(-1, 1))).reshape(x.shape)
+        # --- Triton interpreter
+        bad = np.argwhere(mine != g[f"quant{i}_q"])
+        assert len(bad) < 0.06 * mine.size
+        for r, c in bad:
+            a, b, v = float(f8(mine[r:r + 1, c])[0]), float(f8(g[f"quant{i}_q"][r:r + 1, c])[0]), float(scaled[r, c])
+            binade_roll_over = abs(a) == 2 * abs(b) and np.log2(abs(a)) == int(np.log2(abs(a)))
+            lo, hi = sorted((a, b))
+            tie = lo < v < hi and abs((v - lo) - (hi - v)) < 1e-6 * abs(v)
+            subnormal = abs(v) < 2.0 ** -6  # below the smallest normal e4m3fn the interpreter flushes to zero
+            assert binade_roll_over or tie or subnormal, (i, r, c, v, a, b)
+        # --- torch helper
+        live_el = live.repeat_interleave(group, dim=-1).reshape(x.shape).numpy()
+        native = np.where(live_el, g[f"quant{i}_q_native"], mine)
+        diff = mine.astype(np.int16) - native.astype(np.int16)
+        assert (np.abs(diff) <= 1).all() and (diff != 0).mean() < 0.01, (i, np.abs(diff).max(), (diff != 0).mean())
+
+
+def test_block_fp8_matmul_matches_reference_kernel():
+    """oracle.w8a8_block_fp8_matmul vs the reference's Triton kernel (fp8_kernel.py:409-491).  Products of fp8
+    values are exact in fp32; only the order of the fp32 additions differs, so the comparison is far inside
+    the reference's own bar (mean |diff| / mean |ref| < 1e-3, test_block_fp8.py:276-280)."""
+    g = load_golden("block_fp8")
+    for i, (M, N, K, code) in enumerate(g["mm_cases"].tolist()):
+        dt = FP8_CODE[code]
+        a = torch.from_numpy(g[f"mm{i}_a"]).view(torch.float8_e4m3fn)
+        b = torch.from_numpy(g[f"mm{i}_b"]).view(torch.float8_e4m3fn)
+        want = from_bits(g[f"mm{i}_c"], dt).float()
+        got = O.w8a8_block_fp8_matmul(a, b, torch.from_numpy(g[f"mm{i}_as"]), torch.from_numpy(g[f"mm{i}_bs"]),
+                                      [128, 128], dt).float()
+        rel = (got - want).abs().mean() / want.abs().mean()
+        # 16-bit outputs: the interpreter truncates f32 -> bf16 / f16 where torch rounds to nearest, so those
+        # cases agree to one unit in the last place only; the f32 cases carry the arithmetic
+        assert rel < {torch.float32: 1e-6, torch.bfloat16: 4e-3, torch.float16: 5e-4}[dt], (i, float(rel))
+        if dt == torch.float32:
+            assert torch.allclose(got, want, rtol=1e-5, atol=1e-5 * float(want.abs().max()))
