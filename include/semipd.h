@@ -306,9 +306,12 @@ int semipd_per_token_group_quant_fp8(void* q, float* s, const void* x, int64_t n
 /* c[m, n] = sum_kb (sum_{k in kb} a_q[m,k] * w_q[n,k]) * a_s[m,kb] * w_s[n / block_n, kb], fp32
  * accumulation; replaces w8a8_block_fp8_matmul (fp8_kernel.py:409-491, 694-800).
  * a_q [m,k] fp8, a_s [m, ceil(k/128)] f32, w_q [n,k] fp8, w_s [ceil(n/block_n), ceil(k/128)] f32, all
- * contiguous; block_k == 128, block_n % 16 == 0, k % 16 == 0; c [m,n] of out_dtype (f32/bf16/f16). */
+ * contiguous; block_k == 128, block_n % 16 == 0, k % 16 == 0; c [m,n] of out_dtype (f32/bf16/f16).
+ * workspace (optional, 16-byte aligned device memory): room for fp32 split-K partials; calls with few
+ * output tiles split K over up to 16 workgroups per tile when it is given. */
 int semipd_w8a8_block_fp8_matmul(void* c, const void* a_q, const float* a_s, const void* w_q, const float* w_s,
-                                 int64_t m, int64_t n, int64_t k, int block_n, int block_k, int out_dtype, void* stream);
+                                 int64_t m, int64_t n, int64_t k, int block_n, int block_k, int out_dtype,
+                                 void* workspace, size_t workspace_bytes, void* stream);
 /* semipd_moe_grouped_gemm with use_fp8_w8a8 and block_shape = [block_n, block_k]
  * (fused_moe.py:174-243, 516-545): a_q [num_valid / top_k_div, k] fp8 with a_s [.., ceil(k/128)],
  * w_q [E, n, k] fp8 with w_s [E, ceil(n/block_n), ceil(k/128)]; the other arguments as in

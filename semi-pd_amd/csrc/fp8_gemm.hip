@@ -10,19 +10,23 @@
 // of K ahead; the activation rows of the block (fp8) and their scales sit in LDS.  What changes:
 //   * half the weight bytes per output, so the decode-sized blocks stage 512 bytes of K per row to keep
 //     the same bytes in flight per lane (8 x 16 B, double buffered);
-//   * v_mfma_f32_16x16x32_fp8_fp8 takes 8 bytes per lane and k-step.  A lane still loads 16 contiguous
-//     bytes (k = q4 * 16 .. + 16 of a 64-wide super-step) and feeds the two halves to two MFMAs; the
-//     activation fragment is read from LDS with the same permutation, so the dot products are intact;
-//   * every 128 k (one scale block) the partial tile is folded into the accumulator with
-//     As[m, kb] * Ws[n-block, kb] — one multiply for the product of scales, four FMAs per tile.
-// The non-scaled fp8 MFMA runs at the bf16 rate on gfx950 (MI355X_MICROARCH.md); these calls are bound by
-// the weight stream at decode sizes and by L2 re-reads of the activations at prefill sizes, like their
-// bf16 counterparts.
+//   * one scale block of 128 k is ONE v_mfma_scale_f32_16x16x128_f8f6f4 per tile (32 bytes per lane and
+//     operand; hardware scales set to 2^0).  The non-scaled 16x16x32 fp8 MFMA runs at the bf16 rate on
+//     gfx950, the K = 128 form at twice that (MI355X_MICROARCH.md).  A lane loads the 32 contiguous
+//     bytes k = q4 * 32 .. + 32 of its weight row, the activation fragment is read from LDS at the same
+//     offsets; operands A and B map lanes to k the same way, so the dot products are intact whatever the
+//     instruction's order of k inside the block is;
+//   * the block's partial tile is folded into the accumulator with As[m, kb] * Ws[n-block, kb] — one
+//     multiply for the product of scales, four FMAs per tile (the fp32 scales of this format are not
+//     powers of two, so the instruction's own E8M0 scaling cannot carry them);
+//   * split-K for calls with few output tiles (fp32 partial planes + a reduce launch, as in skinny_gemm.hip).
 #include "common.h"
 
 namespace semipd {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 constexpr float kFp8Max = 448.0f;  // torch.finfo(torch.float8_e4m3fn).max; the reference's HIP branch uses
                                    // e4m3fnuz / 224 for MI300 (fp8_kernel.py:191-194), gfx950 is OCP
@@ -82,13 +86,14 @@ fp8_block_gemm_kernel(OutT* __restrict__ c, const uint8_t* __restrict__ a, const
                       const float* __restrict__ topk_weights, const int32_t* __restrict__ sorted_ids,
                       const int32_t* __restrict__ expert_ids, const int32_t* __restrict__ num_post_pad,
                       int64_t num_valid, int64_t M, int64_t N, int64_t K, int64_t ldc, int block_n, int top_k_div,
-                      int mul_routed_weight) {
+                      int mul_routed_weight, int chunks_per_split, float* __restrict__ partial_ws) {
   static_assert(NG == 1 || NG == 2 || NG == 4, "NG = groups of 16 W rows per wave");
   // KC = bytes of K staged per barrier pair: 512 for the 64-row blocks (8 x 16 B of weights in flight per
   // lane, double buffered), 128 for the 128-row blocks (their 64 accumulator registers leave room for less)
   static_assert(KC == 128 || KC == 256 || KC == 512, "whole scale blocks per chunk");
   constexpr int SB = KC / 128;     // scale blocks per chunk
-  constexpr int SS = KC / 64;      // 64-wide super-steps per chunk (one 16-byte load per lane each)
+  constexpr int SS = KC / 64;      // 16-byte loads per lane and W row per chunk (two per scale block)
+  static_assert(SS == 2 * SB, "two 16-byte halves per scale block");
   constexpr int BNW = 16 * NG;     // W rows per wave
   constexpr int MT = BM / 16;      // m-tiles
   constexpr int AS = KC + 16;      // LDS row stride in bytes
@@ -147,30 +152,47 @@ fp8_block_gemm_kernel(OutT* __restrict__ c, const uint8_t* __restrict__ a, const
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
     w_ok[g] = (n0 + g * 16 + c16) < N;
-    w_ptr[g] = w + expert * N * K + (w_ok[g] ? (n0 + g * 16 + c16) : 0) * K + q4 * 16;
+    w_ptr[g] = w + expert * N * K + (w_ok[g] ? (n0 + g * 16 + c16) : 0) * K + q4 * 32;
     const int64_t nb = (n0 + g * 16 < N ? n0 + g * 16 : 0) / block_n;  // one scale row per group of 16 (16 | block_n)
     ws_ptr[g] = w_s + (expert * NB + nb) * KB;
   }
 
+  // split-K: blockIdx.z owns chunks [z * chunks_per_split, (z + 1) * chunks_per_split) of KC bytes
+  const int64_t k_begin = (int64_t)blockIdx.z * chunks_per_split * KC;
+  const int64_t k_end = min(K, k_begin + (int64_t)chunks_per_split * KC);
+
   uint4 areg[NA];
   float sreg = 0.f;
-  uint4 wreg[2][NG][SS];
+  i32x8 wreg[2][NG][SB];  // one MFMA operand (32 bytes) per scale block
+  float wsreg[2][NG][SB];  // and its weight scale, fetched with it (a load inside the compute phase would
+                           // have to wait for the whole prefetch: vmcnt counts in order)
   auto fetch_a = [&](int64_t k0) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       areg[i] = make_uint4(0, 0, 0, 0);
-      if (a_off[i] >= 0 && k0 + ch * 16 < K) areg[i] = *reinterpret_cast<const uint4*>(a + a_off[i] + k0);
+      if (a_off[i] >= 0 && k0 + ch * 16 < k_end) areg[i] = *reinterpret_cast<const uint4*>(a + a_off[i] + k0);
     }
     sreg = 0.f;
     if (s_off >= 0 && k0 / 128 + s_j < KB) sreg = a_s[s_off + k0 / 128];
   };
-  auto fetch_w = [&](uint4 (&r)[NG][SS], int64_t k0) __attribute__((always_inline)) {
+  auto fetch_w = [&](i32x8 (&r)[NG][SB], float (&rs)[NG][SB], int64_t k0) __attribute__((always_inline)) {
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
 #pragma unroll
-      for (int ss = 0; ss < SS; ++ss) {
-        r[g][ss] = make_uint4(0, 0, 0, 0);
-        if (w_ok[g] && k0 + ss * 64 + q4 * 16 < K) r[g][ss] = *reinterpret_cast<const uint4*>(w_ptr[g] + k0 + ss * 64);
+      for (int sb = 0; sb < SB; ++sb) {
+        rs[g][sb] = (k0 + sb * 128 < k_end) ? ws_ptr[g][k0 / 128 + sb] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+#pragma unroll
+      for (int sb = 0; sb < SB; ++sb) {
+        const int64_t kk = k0 + sb * 128;  // + q4 * 32 in w_ptr; K % 16 == 0, so the halves are guarded separately
+        i32x4 lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
+        if (w_ok[g] && kk + q4 * 32 < k_end) lo = *reinterpret_cast<const i32x4*>(w_ptr[g] + kk);
+        if (w_ok[g] && kk + q4 * 32 + 16 < k_end) hi = *reinterpret_cast<const i32x4*>(w_ptr[g] + kk + 16);
+        r[g][sb].lo = lo;
+        r[g][sb].hi = hi;
       }
     }
   };
@@ -185,67 +207,66 @@ fp8_block_gemm_kernel(OutT* __restrict__ c, const uint8_t* __restrict__ a, const
   for (int g = 0; g < NG; ++g)
 #pragma unroll
     for (int t = 0; t < MT; ++t) acc[g][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const uint8_t* a_rd = &a_lds[c16 * AS + q4 * 16];
+  const uint8_t* a_rd = &a_lds[c16 * AS + q4 * 32];
 
-  auto compute = [&](uint4 (&r)[NG][SS], int64_t k0) __attribute__((always_inline)) {
+  // One scale block: MFMA of tile t + 1 is in flight while tile t is folded into the accumulators.  TILES is
+  // a compile-time count (all of them, or half for blocks that are at most half full): no per-tile branches,
+  // rows of absent tokens are zero in LDS.
+#define SEMIPD_FP8_BLOCK_STEP(NAME, TILES)                                                                             \
+  auto NAME = [&](i32x8 (&r)[NG][SB], float (&rs)[NG][SB], int sb) __attribute__((always_inline)) {                    \
+    f32x4 blk[2][NG];                                                                                                  \
+    _Pragma("unroll") for (int t = -1; t < (TILES); ++t) {                                                             \
+      if (t + 1 < (TILES)) {                                                                                           \
+        i32x8 bv;                                                                                                      \
+        bv.lo = *reinterpret_cast<const i32x4*>(a_rd + (t + 1) * 16 * AS + sb * 128);                                  \
+        bv.hi = *reinterpret_cast<const i32x4*>(a_rd + (t + 1) * 16 * AS + sb * 128 + 16);                             \
+        _Pragma("unroll") for (int g = 0; g < NG; ++g) {                                                               \
+          /* cbsz = blgp = 0: both operands e4m3; hardware scales 0x7f = 2^0 */                                        \
+          blk[(t + 1) & 1][g] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(                                      \
+              r[g][sb], bv, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);                            \
+        }                                                                                                              \
+      }                                                                                                                \
+      if (t >= 0) {                                                                                                    \
+        const float asc = as_lds[(t * 16 + c16) * SB + sb];                                                            \
+        _Pragma("unroll") for (int g = 0; g < NG; ++g) {                                                               \
+          const float sc = asc * rs[g][sb];                                                                            \
+          _Pragma("unroll") for (int e = 0; e < 4; ++e) acc[g][t][e] += blk[t & 1][g][e] * sc;                         \
+        }                                                                                                              \
+      }                                                                                                                \
+    }                                                                                                                  \
+  }
+  SEMIPD_FP8_BLOCK_STEP(block_step_full, MT);
+  SEMIPD_FP8_BLOCK_STEP(block_step_half, MT / 2);
+#undef SEMIPD_FP8_BLOCK_STEP
+  auto compute = [&](i32x8 (&r)[NG][SB], float (&rs)[NG][SB], int64_t k0) __attribute__((always_inline)) {
 #pragma unroll
     for (int sb = 0; sb < SB; ++sb) {
-      const int64_t kb = k0 / 128 + sb;
-      if (kb >= KB) break;
-      float wsc[NG];
-#pragma unroll
-      for (int g = 0; g < NG; ++g) wsc[g] = ws_ptr[g][kb];
-#pragma unroll
-      for (int t = 0; t < MT; ++t) {
-        if (t < m_tiles) {
-          f32x4 blk[NG];
-#pragma unroll
-          for (int g = 0; g < NG; ++g) blk[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {  // the two super-steps of this scale block
-            const int ss = sb * 2 + h;
-            const uint4 b = *reinterpret_cast<const uint4*>(a_rd + t * 16 * AS + ss * 64);
-            const long b_lo = (long)(((uint64_t)b.y << 32) | b.x), b_hi = (long)(((uint64_t)b.w << 32) | b.z);
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-              const long w_lo = (long)(((uint64_t)r[g][ss].y << 32) | r[g][ss].x);
-              const long w_hi = (long)(((uint64_t)r[g][ss].w << 32) | r[g][ss].z);
-              blk[g] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(w_lo, b_lo, blk[g], 0, 0, 0);
-              blk[g] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(w_hi, b_hi, blk[g], 0, 0, 0);
-            }
-          }
-          const float asc = as_lds[(t * 16 + c16) * SB + sb];
-#pragma unroll
-          for (int g = 0; g < NG; ++g) {
-            const float sc = asc * wsc[g];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[g][t][e] += blk[g][e] * sc;
-          }
-        }
-      }
+      if (k0 + sb * 128 >= k_end) break;
+      if (m_tiles * 2 <= MT) block_step_half(r, rs, sb);
+      else block_step_full(r, rs, sb);
     }
   };
 
-  fetch_a(0);
-  fetch_w(wreg[0], 0);
-  for (int64_t k0 = 0; k0 < K; k0 += 2 * KC) {
+  fetch_a(k_begin);
+  fetch_w(wreg[0], wsreg[0], k_begin);
+  for (int64_t k0 = k_begin; k0 < k_end; k0 += 2 * KC) {
     __syncthreads();
     stage_a();
     __syncthreads();
-    if (k0 + KC < K) {
+    if (k0 + KC < k_end) {
       fetch_a(k0 + KC);
-      fetch_w(wreg[1], k0 + KC);
+      fetch_w(wreg[1], wsreg[1], k0 + KC);
     }
-    compute(wreg[0], k0);
-    if (k0 + KC < K) {
+    compute(wreg[0], wsreg[0], k0);
+    if (k0 + KC < k_end) {
       __syncthreads();
       stage_a();
       __syncthreads();
-      if (k0 + 2 * KC < K) {
+      if (k0 + 2 * KC < k_end) {
         fetch_a(k0 + 2 * KC);
-        fetch_w(wreg[0], k0 + 2 * KC);
+        fetch_w(wreg[0], wsreg[0], k0 + 2 * KC);
       }
-      compute(wreg[1], k0 + KC);
+      compute(wreg[1], wsreg[1], k0 + KC);
     }
   }
 
@@ -253,6 +274,18 @@ fp8_block_gemm_kernel(OutT* __restrict__ c, const uint8_t* __restrict__ a, const
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
     const int64_t nb = n0 + g * 16 + q4 * 4;
+    if (!GROUPED && gridDim.z > 1) {
+      // fp32 partials [z][m_block * BM + row][N], summed in z order by fp8_splitk_reduce_kernel
+      const int64_t rows_total = (int64_t)gridDim.y * BM;
+      float* ws = partial_ws + ((int64_t)blockIdx.z * rows_total + m0) * N;
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        if (t >= m_tiles || nb >= N) continue;
+        float* dst = ws + (int64_t)(t * 16 + c16) * N + nb;
+        *reinterpret_cast<float4*>(dst) = make_float4(acc[g][t][0], acc[g][t][1], acc[g][t][2], acc[g][t][3]);
+      }
+      continue;
+    }
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
       if (t >= m_tiles) continue;
@@ -285,17 +318,60 @@ fp8_block_gemm_kernel(OutT* __restrict__ c, const uint8_t* __restrict__ a, const
   }
 }
 
+template <typename OutT>
+__global__ void __launch_bounds__(256)
+fp8_splitk_reduce_kernel(OutT* __restrict__ c, const float* __restrict__ partial, int ksplit, int64_t M, int64_t N,
+                         int64_t plane_rows) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t n4 = N / 4;
+  if (i >= M * n4) return;
+  const int64_t m = i / n4, n = (i - m * n4) * 4;
+  const float* src = partial + m * N + n;
+  f32x4 acc = *reinterpret_cast<const f32x4*>(src);
+  for (int z = 1; z < ksplit; ++z) acc += *reinterpret_cast<const f32x4*>(src + (int64_t)z * plane_rows * N);
+  OutT* dst = c + m * N + n;
+  if constexpr (sizeof(OutT) == 4) {
+    *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  } else {
+    uint2 p;
+    p.x = (uint32_t)Elem<OutT>::from_f(acc[0]).v | ((uint32_t)Elem<OutT>::from_f(acc[1]).v << 16);
+    p.y = (uint32_t)Elem<OutT>::from_f(acc[2]).v | ((uint32_t)Elem<OutT>::from_f(acc[3]).v << 16);
+    *reinterpret_cast<uint2*>(dst) = p;
+  }
+}
+
+// Split-K factor: enough workgroups for two per CU (the kernel's occupancy), at least two chunks per split,
+// and only when the fp32 partial planes fit the workspace.
+static int fp8_pick_ksplit(int64_t tiles, int chunks, int64_t rows_total, int64_t N, size_t ws_bytes) {
+  int s = 1;
+  while (s < 16 && tiles * s < 512 && chunks / (s * 2) >= 2) s *= 2;
+  while (s > 1 && (size_t)s * rows_total * N * 4 > ws_bytes) s /= 2;
+  return s;
+}
+
 template <typename OutT, bool GROUPED, int BM, int NG, int KC>
 static int launch_fp8_gemm(void* c, const void* a, const float* a_s, const void* w, const float* w_s,
                            const float* topk_weights, const int32_t* sorted_ids, const int32_t* expert_ids,
                            const int32_t* num_post_pad, int64_t num_valid, int64_t M, int64_t N, int64_t K, int64_t ldc,
-                           int64_t m_blocks, int block_n, int top_k_div, int mul_routed_weight, hipStream_t st) {
+                           int64_t m_blocks, int block_n, int top_k_div, int mul_routed_weight, hipStream_t st,
+                           float* ws, size_t ws_bytes) {
   constexpr int64_t kRowsPerWg = 64 * NG;
-  dim3 grid((unsigned)((N + kRowsPerWg - 1) / kRowsPerWg), (unsigned)m_blocks);
+  const int64_t n_tiles = (N + kRowsPerWg - 1) / kRowsPerWg;
+  const int chunks = (int)((K + KC - 1) / KC);
+  int ksplit = 1;
+  if (!GROUPED && ws && N % 4 == 0) ksplit = fp8_pick_ksplit(n_tiles * m_blocks, chunks, m_blocks * BM, N, ws_bytes);
+  const int cps = (chunks + ksplit - 1) / ksplit;
+  ksplit = (chunks + cps - 1) / cps;  // no empty splits
+  dim3 grid((unsigned)n_tiles, (unsigned)m_blocks, (unsigned)ksplit);
   hipLaunchKernelGGL((fp8_block_gemm_kernel<OutT, GROUPED, BM, NG, KC>), grid, dim3(256), 0, st, (OutT*)c, (const uint8_t*)a,
                      a_s, (const uint8_t*)w, w_s, topk_weights, sorted_ids, expert_ids, num_post_pad, num_valid, M, N, K,
-                     ldc, block_n, top_k_div, mul_routed_weight);
-  return launch_status("fp8_block_gemm");
+                     ldc, block_n, top_k_div, mul_routed_weight, cps, ws);
+  int rc = launch_status("fp8_block_gemm");
+  if (rc || ksplit == 1) return rc;
+  const int64_t items = M * (N / 4);
+  hipLaunchKernelGGL((fp8_splitk_reduce_kernel<OutT>), dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, (OutT*)c,
+                     (const float*)ws, ksplit, M, N, m_blocks * BM);
+  return launch_status("fp8_splitk_reduce");
 }
 
 template <bool GROUPED>
@@ -303,16 +379,16 @@ static int dispatch_fp8_gemm(void* c, const void* a, const float* a_s, const voi
                              const float* topk_weights, const int32_t* sorted_ids, const int32_t* expert_ids,
                              const int32_t* num_post_pad, int64_t num_valid, int64_t M, int64_t N, int64_t K, int64_t ldc,
                              int64_t m_blocks, int block_m, int block_n, int top_k_div, int mul_routed_weight,
-                             int out_dtype, hipStream_t st) {
+                             int out_dtype, hipStream_t st, float* ws, size_t ws_bytes) {
 #define GO(OutT)                                                                                                       \
   do {                                                                                                                 \
     if (block_m == 128)                                                                                                \
       return launch_fp8_gemm<OutT, GROUPED, 128, 2, 128>(c, a, a_s, w, w_s, topk_weights, sorted_ids, expert_ids,          \
                                                     num_post_pad, num_valid, M, N, K, ldc, m_blocks, block_n, top_k_div, \
-                                                    mul_routed_weight, st);                                            \
+                                                    mul_routed_weight, st, ws, ws_bytes);                              \
     return launch_fp8_gemm<OutT, GROUPED, 64, 1, 512>(c, a, a_s, w, w_s, topk_weights, sorted_ids, expert_ids, num_post_pad, \
                                                  num_valid, M, N, K, ldc, m_blocks, block_n, top_k_div,                \
-                                                 mul_routed_weight, st);                                               \
+                                                 mul_routed_weight, st, ws, ws_bytes);                                 \
   } while (0)
   switch (out_dtype) {
     case SEMIPD_BF16: GO(bf16_t);
@@ -378,7 +454,8 @@ int semipd_per_token_group_quant_fp8(void* q, float* s, const void* x, int64_t n
 }
 
 int semipd_w8a8_block_fp8_matmul(void* c, const void* a_q, const float* a_s, const void* w_q, const float* w_s,
-                                 int64_t m, int64_t n, int64_t k, int block_n, int block_k, int out_dtype, void* stream) {
+                                 int64_t m, int64_t n, int64_t k, int block_n, int block_k, int out_dtype,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
   SEMIPD_CHECK_ARG(c && a_q && a_s && w_q && w_s, SEMIPD_EINVAL, "w8a8_block_fp8_matmul: null pointer");
   if (int rc = check_fp8_gemm_args("w8a8_block_fp8_matmul", n, k, block_n, block_k, a_q, w_q)) return rc;
   if (m == 0) return 0;
@@ -386,7 +463,8 @@ int semipd_w8a8_block_fp8_matmul(void* c, const void* a_q, const float* a_s, con
   const int block_m = m <= 64 ? 64 : 128;
   const int64_t m_blocks = (m + block_m - 1) / block_m;
   return dispatch_fp8_gemm<false>(c, a_q, a_s, w_q, w_s, nullptr, nullptr, nullptr, nullptr, 0, m, n, k, n, m_blocks, block_m,
-                                  block_n, 1, 0, out_dtype, static_cast<hipStream_t>(stream));
+                                  block_n, 1, 0, out_dtype, static_cast<hipStream_t>(stream), static_cast<float*>(workspace),
+                                  workspace ? workspace_bytes : 0);
 }
 
 int semipd_moe_grouped_gemm_fp8(void* c, const void* a_q, const float* a_s, const void* w_q, const float* w_s,
@@ -405,7 +483,7 @@ int semipd_moe_grouped_gemm_fp8(void* c, const void* a_q, const float* a_s, cons
   return dispatch_fp8_gemm<true>(c, a_q, a_s, w_q, w_s, topk_weights, sorted_token_ids, expert_ids, num_tokens_post_pad,
                                  num_valid, 0, n, k, n, (max_sorted + block_m - 1) / block_m, block_m, block_n, top_k_div,
                                  mul_routed_weight,
-                                 out_dtype, static_cast<hipStream_t>(stream));
+                                 out_dtype, static_cast<hipStream_t>(stream), nullptr, 0);
 }
 
 }  // extern "C"

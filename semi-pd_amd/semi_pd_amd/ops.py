@@ -576,9 +576,11 @@ def w8a8_block_fp8_matmul(A: torch.Tensor, B: torch.Tensor, As: torch.Tensor, Bs
     M = A.numel() // K
     C = torch.empty(A.shape[:-1] + (N,), dtype=output_dtype, device=A.device)
     lib = _lib.load()
+    ws = _linear_workspace(A.device)
     check(lib.semipd_w8a8_block_fp8_matmul(ptr(C), ptr(A), ptr(As.contiguous().float()), ptr(B),
                                            ptr(Bs.contiguous().float()), M, N, K, block_n, block_k,
-                                           dtype_code(output_dtype), current_stream(A.device)),
+                                           dtype_code(output_dtype), ptr(ws), ws.numel() * ws.element_size(),
+                                           current_stream(A.device)),
           "w8a8_block_fp8_matmul")
     return C
 

@@ -261,8 +261,63 @@ def bench_linear_sweep():
             del ws
 
 
+def bench_fp8():
+    """Block-scaled fp8 at DeepSeek-V3 shapes (test_block_fp8.py:229-240): quantisation, the dense
+    matmul against the bf16 library GEMM on the same shape, and the fused MoE against the bf16 fused MoE."""
+    import torch.nn.functional as F
+    from semi_pd_amd.layers.moe import fused_experts, fused_experts_fp8
+    F8 = torch.float8_e4m3fn
+    print("# per_token_group_quant_fp8 (group 128): T x H -> us, GB/s (bf16 in, fp8 + scales out)")
+    for T, H in ((32, 7168), (256, 7168), (4096, 7168), (8192 * 6, 2048)):
+        x = torch.randn(T, H, device=dev, dtype=torch.bfloat16)
+        t = timeit(lambda: ops.per_token_group_quant_fp8(x, 128), iters=20)
+        print(f"quant T={T:6d} H={H}: {t * 1e6:8.1f} us {T * H * (3 + 4 / 128) / t / 1e9:6.0f} GB/s")
+    print("# w8a8_block_fp8_matmul M x [N, K]: fp8 us, weight GB/s, TFLOP/s | bf16 F.linear us (weights twice the bytes)")
+    for M in (1, 32, 64, 128, 512, 4096):
+        for (N, K) in ((24576, 7168), (7168, 2048), (4608, 7168), (1536, 7168), (7168, 18432 // 8)):
+            copies = max(2, int(0.8e9 // (N * K)))
+            wq = [(torch.randn(N, K, device=dev) * 100).clamp(-448, 448).to(F8) for _ in range(copies)]
+            ws = torch.rand(-(-N // 128), -(-K // 128), device=dev) * 1e-2
+            wb = [torch.randn(N, K, device=dev, dtype=torch.bfloat16) * 0.02 for _ in range(min(copies, 3))]
+            x = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
+            xq, xs = ops.per_token_group_quant_fp8(x, 128)
+            it = [0]
+
+            def f8():
+                it[0] += 1
+                return ops.w8a8_block_fp8_matmul(xq, wq[it[0] % copies], xs, ws, [128, 128], torch.bfloat16)
+
+            def b16():
+                it[0] += 1
+                return F.linear(x, wb[it[0] % len(wb)])
+            t1 = timeit(f8, iters=2 * copies)
+            t2 = timeit(b16, iters=6)
+            print(f"fp8mm M={M:4d} N={N:6d} K={K:6d}: {t1 * 1e6:8.1f} us {N * K / t1 / 1e9:6.0f} GB/s "
+                  f"{2.0 * M * N * K / t1 / 1e12:7.1f} TF/s | bf16 {t2 * 1e6:8.1f} us")
+            del wq, wb
+    print("# fused MoE fp8 (quant + GEMM1 + silu*mul + quant + GEMM2 + sum) vs bf16: DeepSeek-V3 expert shapes / 8 experts-per-GPU subset")
+    E, k, K, N = 32, 8, 7168, 2048
+    w1 = (torch.randn(E, 2 * N, K, device=dev) * 100).clamp(-448, 448).to(F8)
+    w2 = (torch.randn(E, K, N, device=dev) * 100).clamp(-448, 448).to(F8)
+    w1s = torch.rand(E, 2 * N // 128, K // 128, device=dev) * 1e-2
+    w2s = torch.rand(E, K // 128, N // 128, device=dev) * 1e-2
+    w1b = torch.randn(E, 2 * N, K, device=dev, dtype=torch.bfloat16) * 0.02
+    w2b = torch.randn(E, K, N, device=dev, dtype=torch.bfloat16) * 0.02
+    for T in (1, 32, 256, 1024, 4096):
+        x = torch.randn(T, K, device=dev, dtype=torch.bfloat16)
+        tw, ti = ops.topk_softmax(torch.randn(T, E, device=dev), k, True)
+        t1 = timeit(lambda: fused_experts_fp8(x, w1, w2, w1s, w2s, tw, ti, [128, 128]), iters=5)
+        t2 = timeit(lambda: fused_experts(x, w1b, w2b, tw, ti), iters=5)
+        flops = 2.0 * T * k * 3 * N * K
+        wbytes = min(E, T * k) * 3 * N * K
+        print(f"moe_fp8 T={T:5d} E={E} k={k} K={K} N={N}: {t1 * 1e6:9.1f} us {flops / t1 / 1e12:7.1f} TF/s "
+              f"{wbytes / t1 / 1e9:6.0f} GB/s(fp8 weights) | bf16 {t2 * 1e6:9.1f} us")
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which == "fp8":
+        bench_fp8()
     if which == "linear_sweep":
         bench_linear_sweep()
     if which == "linear":
