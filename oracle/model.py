@@ -229,6 +229,11 @@ class OracleDeepseekV2:
         self.w = {k: v.detach().to("cpu") for k, v in state_dict.items()}
         self.act = act_dtype
         c = config
+        qc = getattr(c, "quantization_config", None)
+        self.block = tuple(qc["weight_block_size"]) if qc else None
+        # quantised layers see the activations in the engine's dtype: the group maxima, hence the fp8 codes,
+        # depend on it
+        self.q_act = torch.bfloat16
         self.H = c.num_attention_heads
         self.nope, self.rope, self.vd, self.lora = c.qk_nope_head_dim, c.qk_rope_head_dim, c.v_head_dim, c.kv_lora_rank
         self.scaling = (self.nope + self.rope) ** -0.5
@@ -244,7 +249,22 @@ class OracleDeepseekV2:
                                                        c.max_position_embeddings)
 
     def _lin(self, x, name):
+        scale = self.w.get(name + "_scale_inv")
+        if scale is not None:
+            # block-quantised layer (fp8_utils.py:91-134): activations per token and group of 128, block matmul
+            q, s = O.per_token_group_quant_fp8(x.to(self.q_act), self.block[1])
+            return O.w8a8_block_fp8_matmul(q, self.w[name], s, scale, self.block, self.q_act).to(self.act)
         return (x.float() @ self.w[name].float().T).to(self.act)
+
+    def _dense(self, name):
+        """A weight as a float matrix whether or not it is stored block-quantised (kv_b_proj in _layers)."""
+        scale = self.w.get(name + "_scale_inv")
+        w = self.w[name].float()
+        if scale is None:
+            return w
+        bn, bk = self.block
+        s = scale.repeat_interleave(bn, 0)[: w.shape[0]].repeat_interleave(bk, 1)[:, : w.shape[1]]
+        return w * s
 
     def _mlp(self, x, prefix):
         return self._lin(O.silu_and_mul(self._lin(x, prefix + "gate_up_proj.weight")), prefix + "down_proj.weight")
@@ -258,7 +278,12 @@ class OracleDeepseekV2:
                                            c.n_group, c.topk_group)
         else:
             tw, ti = O.grouped_topk(logits, c.num_experts_per_tok, c.norm_topk_prob, c.n_group, c.topk_group)
-        out = O.fused_moe(x, self.w[p + "experts.w13_weight"], self.w[p + "experts.w2_weight"], tw, ti)
+        if p + "experts.w13_weight_scale_inv" in self.w:
+            out = O.fused_moe_block_fp8(x.to(self.q_act), self.w[p + "experts.w13_weight"], self.w[p + "experts.w2_weight"],
+                                        self.w[p + "experts.w13_weight_scale_inv"],
+                                        self.w[p + "experts.w2_weight_scale_inv"], tw, ti, self.block).float()
+        else:
+            out = O.fused_moe(x, self.w[p + "experts.w13_weight"], self.w[p + "experts.w2_weight"], tw, ti)
         out = out * c.routed_scaling_factor
         if c.n_shared_experts is not None:
             out = out + self._mlp(x, p + "shared_experts.").float()
@@ -284,7 +309,10 @@ class OracleDeepseekV2:
             q_pe, k_pe = O.apply_rope(positions, q[..., self.nope:].reshape(T, -1), latent[:, self.lora:],
                                       self.rope, self.cache, False)
             q = torch.cat([q[..., : self.nope], q_pe.view(T, self.H, self.rope)], -1)
-            kvb = self._lin(kv_a, p + "self_attn.kv_b_proj.weight").view(T, self.H, self.nope + self.vd)
+            # (a block-quantised kv_b_proj is used dequantised: the engine's absorbed decode path multiplies with the
+            # dequantised W_kc / W_vc, deepseek_v2.py:1195-1249)
+            kvb = (kv_a.float() @ self._dense(p + "self_attn.kv_b_proj.weight").T).to(self.act)
+            kvb = kvb.view(T, self.H, self.nope + self.vd)
             k = torch.cat([kvb[..., : self.nope], k_pe.view(T, 1, self.rope).expand(T, self.H, self.rope)], -1)
             v = kvb[..., self.nope:]
             outs = []

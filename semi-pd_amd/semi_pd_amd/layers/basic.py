@@ -20,6 +20,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from semi_pd_amd import ops
+from semi_pd_amd.layers.fp8 import FP8_DTYPE, apply_w8a8_block_fp8_linear, scale_shape, shard_rows_of_scale
 from semi_pd_amd.distributed import (get_tensor_model_parallel_rank, get_tensor_model_parallel_world_size,
                                      tensor_model_parallel_all_gather, tensor_model_parallel_all_reduce)
 
@@ -181,14 +182,21 @@ def _shard(n: int, tp: int) -> int:
 class ColumnParallelLinear(nn.Module):
     """Y = X W^T with W [out/tp, in] (layers/linear.py:296-460)."""
 
-    def __init__(self, input_size: int, output_size: int, bias: bool = False, params_dtype=None):
+    def __init__(self, input_size: int, output_size: int, bias: bool = False, params_dtype=None, quant_config=None):
         super().__init__()
         tp = get_tensor_model_parallel_world_size()
         self.output_size_per_partition = _shard(output_size, tp)
-        self.weight = nn.Parameter(torch.empty(self.output_size_per_partition, input_size, dtype=params_dtype),
-                                   requires_grad=False)
+        self.quant_config = quant_config
+        self.weight = nn.Parameter(torch.empty(self.output_size_per_partition, input_size,
+                                               dtype=FP8_DTYPE if quant_config else params_dtype), requires_grad=False)
         self.bias = nn.Parameter(torch.zeros(self.output_size_per_partition, dtype=params_dtype),
                                  requires_grad=False) if bias else None
+        if quant_config:
+            # Fp8LinearMethod.create_weights (quantization/fp8.py:205-330): one fp32 scale per weight block
+            self.weight_scale_inv = nn.Parameter(torch.empty(
+                scale_shape(self.output_size_per_partition, input_size, quant_config.weight_block_size),
+                dtype=torch.float32), requires_grad=False)
+            self.weight.weight_block_size = quant_config.weight_block_size
         self._tag_shards(input_size, output_size)
 
     def _row_ranges(self, output_size: int):
@@ -202,20 +210,51 @@ class ColumnParallelLinear(nn.Module):
         ranges = self._row_ranges(output_size)
         self.weight.tp_full_shape = (output_size, input_size)
         self.weight.tp_shard = lambda full: torch.cat([full[a:b] for a, b in ranges], 0)
+        if self.quant_config:
+            block = self.quant_config.weight_block_size
+            self.weight_scale_inv.tp_full_shape = scale_shape(output_size, input_size, block)
+            if get_tensor_model_parallel_world_size() > 1:
+                s_ranges = shard_rows_of_scale(ranges, block[0])
+                self.weight_scale_inv.tp_shard = lambda full: torch.cat([full[a:b] for a, b in s_ranges], 0)
+            else:
+                self.weight_scale_inv.tp_shard = lambda full: full
         if self.bias is not None:
             self.bias.tp_full_shape = (output_size,)
             self.bias.tp_shard = lambda full: torch.cat([full[a:b] for a, b in ranges], 0)
 
     def forward(self, x):
+        if self.quant_config:
+            return apply_w8a8_block_fp8_linear(x, self.weight, self.quant_config.weight_block_size,
+                                               self.weight_scale_inv, self.bias)
         return F.linear(x, self.weight, self.bias)
+
+
+class ReplicatedLinear(ColumnParallelLinear):
+    """Every rank holds the whole weight (layers/linear.py:170-293; q_a_proj, kv_a_proj_with_mqa)."""
+
+    def _row_ranges(self, output_size: int):
+        return [(0, output_size)]
+
+    def __init__(self, input_size: int, output_size: int, bias: bool = False, params_dtype=None, quant_config=None):
+        nn.Module.__init__(self)
+        self.output_size_per_partition = output_size
+        self.quant_config = quant_config
+        self.weight = nn.Parameter(torch.empty(output_size, input_size, dtype=FP8_DTYPE if quant_config else params_dtype),
+                                   requires_grad=False)
+        self.bias = nn.Parameter(torch.zeros(output_size, dtype=params_dtype), requires_grad=False) if bias else None
+        if quant_config:
+            self.weight_scale_inv = nn.Parameter(torch.empty(
+                scale_shape(output_size, input_size, quant_config.weight_block_size), dtype=torch.float32),
+                requires_grad=False)
+            self.weight.weight_block_size = quant_config.weight_block_size
 
 
 class MergedColumnParallelLinear(ColumnParallelLinear):
     """gate_up_proj: the per-rank shard is [gate/tp ; up/tp] (linear.py:463-722)."""
 
-    def __init__(self, input_size: int, output_sizes, bias: bool = False, params_dtype=None):
+    def __init__(self, input_size: int, output_sizes, bias: bool = False, params_dtype=None, quant_config=None):
         self.output_sizes = list(output_sizes)
-        super().__init__(input_size, sum(output_sizes), bias, params_dtype)
+        super().__init__(input_size, sum(output_sizes), bias, params_dtype, quant_config)
 
     def _row_ranges(self, output_size: int):
         tp, rank = get_tensor_model_parallel_world_size(), get_tensor_model_parallel_rank()
@@ -232,7 +271,7 @@ class QKVParallelLinear(ColumnParallelLinear):
     models/llama.py:115-131)."""
 
     def __init__(self, hidden_size: int, head_size: int, total_num_heads: int, total_num_kv_heads: int,
-                 bias: bool = False, params_dtype=None):
+                 bias: bool = False, params_dtype=None, quant_config=None):
         tp = get_tensor_model_parallel_world_size()
         self.head_size = head_size
         self.num_heads = _shard(total_num_heads, tp)
@@ -244,7 +283,7 @@ class QKVParallelLinear(ColumnParallelLinear):
             self.num_kv_head_replicas = _shard(tp, total_num_kv_heads)
         self.total_num_heads, self.total_num_kv_heads = total_num_heads, total_num_kv_heads
         out = (self.num_heads + 2 * self.num_kv_heads) * tp * head_size
-        super().__init__(hidden_size, out, bias, params_dtype)
+        super().__init__(hidden_size, out, bias, params_dtype, quant_config)
 
     def _row_ranges(self, output_size: int):
         # full layout: [q heads | k heads | v heads] (linear.py:880-960 shard ids "q","k","v")
@@ -267,22 +306,40 @@ class RowParallelLinear(nn.Module):
     """Y = all_reduce(X_shard W_shard^T) with W [out, in/tp] (layers/linear.py:1103-1280, reduce :1266)."""
 
     def __init__(self, input_size: int, output_size: int, bias: bool = False, reduce_results: bool = True,
-                 params_dtype=None):
+                 params_dtype=None, quant_config=None):
         super().__init__()
         tp = get_tensor_model_parallel_world_size()
         self.input_size_per_partition = _shard(input_size, tp)
         self.reduce_results = reduce_results
-        self.weight = nn.Parameter(torch.empty(output_size, self.input_size_per_partition, dtype=params_dtype),
-                                   requires_grad=False)
+        self.quant_config = quant_config
+        self.weight = nn.Parameter(torch.empty(output_size, self.input_size_per_partition,
+                                               dtype=FP8_DTYPE if quant_config else params_dtype), requires_grad=False)
         self.bias = nn.Parameter(torch.zeros(output_size, dtype=params_dtype), requires_grad=False) if bias else None
         rank, n = get_tensor_model_parallel_rank(), self.input_size_per_partition
         self.weight.tp_full_shape = (output_size, input_size)
         self.weight.tp_shard = lambda full: full[:, rank * n:(rank + 1) * n].contiguous()
+        if quant_config:
+            block = quant_config.weight_block_size
+            self.weight.weight_block_size = block
+            self.weight_scale_inv = nn.Parameter(torch.empty(scale_shape(output_size, n, block), dtype=torch.float32),
+                                                 requires_grad=False)
+            self.weight_scale_inv.tp_full_shape = scale_shape(output_size, input_size, block)
+            if tp > 1:
+                if n % block[1]:
+                    raise ValueError(f"input partition {n} is not a multiple of the weight block width {block[1]}")
+                nb = n // block[1]
+                self.weight_scale_inv.tp_shard = lambda full: full[:, rank * nb:(rank + 1) * nb].contiguous()
+            else:
+                self.weight_scale_inv.tp_shard = lambda full: full
 
     def forward(self, x):
         # bias is added on rank 0 only so that the sum over ranks adds it once (linear.py:1258-1262)
         bias = self.bias if (self.bias is not None and get_tensor_model_parallel_rank() == 0) else None
-        out = F.linear(x, self.weight, bias)
+        if self.quant_config:
+            out = apply_w8a8_block_fp8_linear(x, self.weight, self.quant_config.weight_block_size,
+                                              self.weight_scale_inv, bias)
+        else:
+            out = F.linear(x, self.weight, bias)
         if self.reduce_results and get_tensor_model_parallel_world_size() > 1:
             out = tensor_model_parallel_all_reduce(out)
         return out

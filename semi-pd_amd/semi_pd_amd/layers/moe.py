@@ -13,6 +13,7 @@ import torch
 from torch import nn
 
 from semi_pd_amd import ops
+from semi_pd_amd.layers.fp8 import FP8_DTYPE, scale_shape
 from semi_pd_amd.distributed import (get_tensor_model_parallel_rank, get_tensor_model_parallel_world_size,
                                      tensor_model_parallel_all_reduce)
 
@@ -94,7 +95,7 @@ class FusedMoE(nn.Module):
     def __init__(self, num_experts: int, top_k: int, hidden_size: int, intermediate_size: int,
                  renormalize: bool = True, use_grouped_topk: bool = False, num_expert_group: Optional[int] = None,
                  topk_group: Optional[int] = None, correction_bias: Optional[torch.Tensor] = None,
-                 reduce_results: bool = False, params_dtype=None):
+                 reduce_results: bool = False, params_dtype=None, quant_config=None):
         super().__init__()
         tp, rank = get_tensor_model_parallel_world_size(), get_tensor_model_parallel_rank()
         assert intermediate_size % tp == 0
@@ -103,10 +104,31 @@ class FusedMoE(nn.Module):
         self.use_grouped_topk, self.num_expert_group, self.topk_group = use_grouped_topk, num_expert_group, topk_group
         self.correction_bias = correction_bias
         self.reduce_results = reduce_results
-        self.w13_weight = nn.Parameter(torch.empty(num_experts, 2 * n, hidden_size, dtype=params_dtype),
-                                       requires_grad=False)
-        self.w2_weight = nn.Parameter(torch.empty(num_experts, hidden_size, n, dtype=params_dtype),
-                                      requires_grad=False)
+        self.quant_config = quant_config
+        wdt = FP8_DTYPE if quant_config else params_dtype
+        self.w13_weight = nn.Parameter(torch.empty(num_experts, 2 * n, hidden_size, dtype=wdt), requires_grad=False)
+        self.w2_weight = nn.Parameter(torch.empty(num_experts, hidden_size, n, dtype=wdt), requires_grad=False)
+        if quant_config:
+            # Fp8MoEMethod.create_weights (quantization/fp8.py:470-620), block-wise branch
+            bn, bk = quant_config.weight_block_size
+            self.w13_weight.weight_block_size = self.w2_weight.weight_block_size = (bn, bk)
+            if tp > 1 and (n % bn or n % bk):
+                raise ValueError(f"intermediate size per rank {n} is not a multiple of the weight block {bn} x {bk}")
+            self.w13_weight_scale_inv = nn.Parameter(
+                torch.empty((num_experts,) + scale_shape(2 * n, hidden_size, (bn, bk)), dtype=torch.float32),
+                requires_grad=False)
+            self.w2_weight_scale_inv = nn.Parameter(
+                torch.empty((num_experts,) + scale_shape(hidden_size, n, (bn, bk)), dtype=torch.float32),
+                requires_grad=False)
+            full_i = intermediate_size
+            nb, kb = -(-n // bn), -(-n // bk)
+            self.w13_weight_scale_inv.tp_full_shape = (num_experts,) + scale_shape(2 * full_i, hidden_size, (bn, bk))
+            self.w13_weight_scale_inv.tp_shard = (lambda full: torch.cat(
+                [full[:, rank * nb:(rank + 1) * nb], full[:, full_i // bn + rank * nb: full_i // bn + (rank + 1) * nb]],
+                1).contiguous()) if tp > 1 else (lambda full: full)
+            self.w2_weight_scale_inv.tp_full_shape = (num_experts,) + scale_shape(hidden_size, full_i, (bn, bk))
+            self.w2_weight_scale_inv.tp_shard = (lambda full: full[:, :, rank * kb:(rank + 1) * kb].contiguous()) \
+                if tp > 1 else (lambda full: full)
         inter = intermediate_size
         self.w13_weight.tp_full_shape = (num_experts, 2 * inter, hidden_size)
         self.w13_weight.tp_shard = lambda full: torch.cat(
@@ -118,7 +140,11 @@ class FusedMoE(nn.Module):
         topk_weights, topk_ids = select_experts(hidden_states, router_logits, self.top_k, self.use_grouped_topk,
                                                 self.renormalize, self.topk_group, self.num_expert_group,
                                                 self.correction_bias)
-        out = fused_experts(hidden_states, self.w13_weight, self.w2_weight, topk_weights, topk_ids)
+        if self.quant_config:
+            out = fused_experts_fp8(hidden_states, self.w13_weight, self.w2_weight, self.w13_weight_scale_inv,
+                                    self.w2_weight_scale_inv, topk_weights, topk_ids, self.quant_config.weight_block_size)
+        else:
+            out = fused_experts(hidden_states, self.w13_weight, self.w2_weight, topk_weights, topk_ids)
         if self.reduce_results and get_tensor_model_parallel_world_size() > 1:
             out = tensor_model_parallel_all_reduce(out)
         return out

@@ -56,8 +56,24 @@ def dummy_init_weights(model: nn.Module, device: torch.device, seed: int = 0, st
     """`--load-format dummy` (model_loader/loader.py: DummyModelLoader): deterministic random weights.
     Every parameter is drawn on the device from a generator seeded by its *name*, norm weights are 1,
     so two processes (or a unified and a Semi-PD engine) build bit-identical models."""
-    for name, p in model.named_parameters():
+    params = dict(model.named_parameters())
+    for name, p in params.items():
         if p.device.type == "meta":
+            continue
+        if name.endswith("_scale_inv"):
+            continue  # written together with the fp8 weight it belongs to
+        if p.dtype == torch.float8_e4m3fn:
+            # block-quantised layer: the SAME full-size draw as the unquantised model, quantised per weight
+            # block, so an fp8 model is its bf16 twin up to quantisation error
+            from semi_pd_amd.layers.fp8 import block_quantize_weight
+            g = torch.Generator(device=device)
+            g.manual_seed(_seed_of(name, seed))
+            full_shape = getattr(p, "tp_full_shape", tuple(p.shape))
+            full = torch.randn(full_shape, generator=g, device=device, dtype=torch.float32).mul_(std)
+            sp = params[name + "_scale_inv"]
+            q, sc = block_quantize_weight(full, p.weight_block_size)
+            p.copy_(p.tp_shard(q) if hasattr(p, "tp_shard") else q)
+            sp.copy_(sp.tp_shard(sc) if hasattr(sp, "tp_shard") else sc)
             continue
         leaf = name.rsplit(".", 2)[-2] if "." in name else name
         if "norm" in leaf and name.endswith("weight"):

@@ -40,6 +40,8 @@ def config_from_hf_dict(d: dict):
     if arch == "OPTForCausalLM" and d.get("word_embed_proj_dim", d.get("hidden_size")) != d.get("hidden_size"):
         raise ValueError("OPT checkpoints with word_embed_proj_dim != hidden_size are not supported")
     names = {f.name for f in dataclasses.fields(cls)}
+    if d.get("quantization_config") and "quantization_config" not in names:
+        raise ValueError(f"{arch}: quantised checkpoints are supported for the DeepSeek family only")
     kw = {k: v for k, v in d.items() if k in names and k != "architectures"}
     return cls(architectures=(arch,), **kw)
 
@@ -86,7 +88,7 @@ class _Stacker:
 
 _QKV = {"q_proj": 0, "k_proj": 1, "v_proj": 2}
 _GATE_UP = {"gate_proj": 0, "up_proj": 1}
-_EXPERT_RE = re.compile(r"^(.*\.mlp\.experts)\.(\d+)\.(gate_proj|up_proj|down_proj)\.weight$")
+_EXPERT_RE = re.compile(r"^(.*\.mlp\.experts)\.(\d+)\.(gate_proj|up_proj|down_proj)\.(weight|weight_scale_inv)$")
 
 
 def product_items(config, weights: Iterable[Tuple[str, torch.Tensor]]) -> Iterator[Tuple[str, torch.Tensor]]:
@@ -114,16 +116,18 @@ def product_items(config, weights: Iterable[Tuple[str, torch.Tensor]]) -> Iterat
             continue
         m = _EXPERT_RE.match(name)
         if m:
-            prefix, e, which = m.group(1), int(m.group(2)), m.group(3)
-            parts = expert_parts.setdefault(prefix, {})
+            prefix, e, which, leaf = m.group(1), int(m.group(2)), m.group(3), m.group(4)
+            # block-quantised checkpoints carry experts.{e}.*.weight_scale_inv next to the fp8 weights; they stack
+            # like the weights (models/deepseek_v2.py:1150-1227 expert_params_mapping covers both)
+            parts = expert_parts.setdefault(prefix + "|" + leaf, {})
             parts[(e, which)] = t
             if len(parts) == 3 * n_exp:
-                del expert_parts[prefix]
+                del expert_parts[prefix + "|" + leaf]
                 w13 = torch.stack([torch.cat([parts[(i, "gate_proj")], parts[(i, "up_proj")]], 0)
                                    for i in range(n_exp)], 0)
                 w2 = torch.stack([parts[(i, "down_proj")] for i in range(n_exp)], 0)
-                yield prefix + ".w13_weight", w13
-                yield prefix + ".w2_weight", w2
+                yield prefix + ".w13_" + leaf, w13
+                yield prefix + ".w2_" + leaf, w2
             continue
         if name.endswith(".mlp.experts.gate_up_proj"):  # checkpoints that already store fused experts
             yield name[: -len("gate_up_proj")] + "w13_weight", t
@@ -157,6 +161,9 @@ def load_weights(model: nn.Module, config, weights: Iterable[Tuple[str, torch.Te
                 continue  # e.g. attention biases of architectures we run without them are rejected above
             raise KeyError(f"checkpoint tensor {name} has no counterpart in {type(model).__name__}")
         p = params[name]
+        if (p.dtype == torch.float8_e4m3fn) != (full.dtype == torch.float8_e4m3fn):
+            raise RuntimeError(f"{name}: checkpoint dtype {full.dtype} vs parameter {p.dtype} — block-quantised models "
+                               "need a block-quantised checkpoint (and the other way round)")
         src = full.to(p.device, p.dtype)
         if tuple(src.shape) != tuple(p.shape):
             if not hasattr(p, "tp_shard"):

@@ -23,8 +23,9 @@ from semi_pd_amd import ops
 from semi_pd_amd.distributed import (get_tensor_model_parallel_world_size, tensor_model_parallel_all_reduce)
 from semi_pd_amd.layers.attention_backend import RadixAttention
 from semi_pd_amd.layers.basic import (ColumnParallelLinear, LogitsProcessor, MergedColumnParallelLinear,
-                                      ParallelLMHead, RMSNorm, RowParallelLinear, SiluAndMul,
+                                      ParallelLMHead, ReplicatedLinear, RMSNorm, RowParallelLinear, SiluAndMul,
                                       VocabParallelEmbedding, get_rope, yarn_get_mscale)
+from semi_pd_amd.layers.fp8 import Fp8Config, block_dequantize_weight
 from semi_pd_amd.layers.moe import FusedMoE
 
 
@@ -58,6 +59,7 @@ class DeepseekV2Config:
         "type": "yarn", "factor": 40, "beta_fast": 32, "beta_slow": 1, "mscale": 0.707,
         "mscale_all_dim": 0.707, "original_max_position_embeddings": 4096})
     max_position_embeddings: int = 163840
+    quantization_config: Optional[Dict[str, Any]] = None  # {"quant_method": "fp8", "weight_block_size": [128, 128]}
     tie_word_embeddings: bool = False
     architectures: tuple = ("DeepseekV2ForCausalLM",)
 
@@ -65,12 +67,19 @@ class DeepseekV2Config:
 DEEPSEEK_V2_LITE = DeepseekV2Config()
 
 
+def quant_config_of(config) -> Optional[Fp8Config]:
+    """models/deepseek_v2.py passes `quant_config` to every linear and to FusedMoE; the gate, the norms,
+    the embedding and lm_head stay in the activation dtype."""
+    return Fp8Config.from_hf(getattr(config, "quantization_config", None))
+
+
 class DeepseekV2MLP(nn.Module):
-    def __init__(self, hidden_size: int, intermediate_size: int, dtype, reduce_results: bool = True):
+    def __init__(self, hidden_size: int, intermediate_size: int, dtype, reduce_results: bool = True, quant_config=None):
         super().__init__()
-        self.gate_up_proj = MergedColumnParallelLinear(hidden_size, [intermediate_size] * 2, params_dtype=dtype)
+        self.gate_up_proj = MergedColumnParallelLinear(hidden_size, [intermediate_size] * 2, params_dtype=dtype,
+                                                       quant_config=quant_config)
         self.down_proj = RowParallelLinear(intermediate_size, hidden_size, reduce_results=reduce_results,
-                                           params_dtype=dtype)
+                                           params_dtype=dtype, quant_config=quant_config)
         self.act_fn = SiluAndMul()
 
     def forward(self, x):
@@ -103,12 +112,12 @@ class DeepseekV2MoE(nn.Module):
                                 config.moe_intermediate_size, renormalize=config.norm_topk_prob,
                                 use_grouped_topk=True, num_expert_group=config.n_group,
                                 topk_group=config.topk_group, correction_bias=self.gate.e_score_correction_bias,
-                                params_dtype=dtype)
+                                params_dtype=dtype, quant_config=quant_config_of(config))
         self.shared_experts = None
         if config.n_shared_experts is not None:
             self.shared_experts = DeepseekV2MLP(config.hidden_size,
                                                 config.moe_intermediate_size * config.n_shared_experts, dtype,
-                                                reduce_results=False)
+                                                reduce_results=False, quant_config=quant_config_of(config))
 
     def forward(self, hidden_states: torch.Tensor) -> torch.Tensor:
         shared_output = self.shared_experts(hidden_states) if self.shared_experts is not None else None
@@ -134,18 +143,22 @@ class DeepseekV2AttentionMLA(nn.Module):
         assert config.num_attention_heads % tp == 0
         self.num_local_heads = config.num_attention_heads // tp
         H = config.num_attention_heads
+        qc = self.quant_config = quant_config_of(config)
         if self.q_lora_rank is not None:
-            self.q_a_proj = nn.Linear(config.hidden_size, self.q_lora_rank, bias=False, dtype=dtype)
+            self.q_a_proj = ReplicatedLinear(config.hidden_size, self.q_lora_rank, params_dtype=dtype, quant_config=qc)
             self.q_a_layernorm = RMSNorm(self.q_lora_rank, eps=config.rms_norm_eps)
-            self.q_b_proj = ColumnParallelLinear(self.q_lora_rank, H * self.qk_head_dim, params_dtype=dtype)
+            self.q_b_proj = ColumnParallelLinear(self.q_lora_rank, H * self.qk_head_dim, params_dtype=dtype,
+                                                 quant_config=qc)
         else:
-            self.q_proj = ColumnParallelLinear(config.hidden_size, H * self.qk_head_dim, params_dtype=dtype)
-        self.kv_a_proj_with_mqa = nn.Linear(config.hidden_size, self.kv_lora_rank + self.qk_rope_head_dim,
-                                            bias=False, dtype=dtype)
+            self.q_proj = ColumnParallelLinear(config.hidden_size, H * self.qk_head_dim, params_dtype=dtype,
+                                               quant_config=qc)
+        self.kv_a_proj_with_mqa = ReplicatedLinear(config.hidden_size, self.kv_lora_rank + self.qk_rope_head_dim,
+                                                   params_dtype=dtype, quant_config=qc)
         self.kv_a_layernorm = RMSNorm(self.kv_lora_rank, eps=config.rms_norm_eps)
         self.kv_b_proj = ColumnParallelLinear(self.kv_lora_rank, H * (self.qk_nope_head_dim + self.v_head_dim),
-                                              params_dtype=dtype)
-        self.o_proj = RowParallelLinear(H * self.v_head_dim, config.hidden_size, params_dtype=dtype)
+                                              params_dtype=dtype, quant_config=qc)
+        self.o_proj = RowParallelLinear(H * self.v_head_dim, config.hidden_size, params_dtype=dtype, quant_config=qc)
+        self.params_dtype = dtype
         rope_scaling = dict(config.rope_scaling) if config.rope_scaling else None
         self.scaling = self.qk_head_dim ** -0.5
         if rope_scaling:
@@ -166,6 +179,12 @@ class DeepseekV2AttentionMLA(nn.Module):
     def post_load_weights(self):
         """deepseek_v2.py:1228-1249: W_kc [H,128,512] and W_vc [H,512,128] out of kv_b_proj."""
         w = self.kv_b_proj.weight
+        if self.quant_config:
+            # the reference re-quantises the block-quantised kv_b_proj per tensor and, on its HIP branch, multiplies
+            # w_kc.to(bf16) * w_scale in every forward (deepseek_v2.py:1195-1209, 655-658); here the blocks are
+            # dequantised once, which skips the second rounding
+            w = block_dequantize_weight(w, self.kv_b_proj.weight_scale_inv, self.quant_config.weight_block_size,
+                                        self.params_dtype)
         w_kc, w_vc = w.unflatten(0, (-1, self.qk_nope_head_dim + self.v_head_dim)).split(
             [self.qk_nope_head_dim, self.v_head_dim], dim=1)
         self.w_kc = w_kc.contiguous()                    # [H, 128, 512]
@@ -233,8 +252,8 @@ class DeepseekV2DecoderLayer(nn.Module):
         self.self_attn = DeepseekV2AttentionMLA(config, layer_id, dtype)
         is_moe = (config.n_routed_experts is not None and layer_id >= config.first_k_dense_replace
                   and layer_id % config.moe_layer_freq == 0)
-        self.mlp = DeepseekV2MoE(config, dtype) if is_moe else DeepseekV2MLP(config.hidden_size,
-                                                                           config.intermediate_size, dtype)
+        self.mlp = DeepseekV2MoE(config, dtype) if is_moe else DeepseekV2MLP(
+            config.hidden_size, config.intermediate_size, dtype, quant_config=quant_config_of(config))
         self.input_layernorm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
         self.post_attention_layernorm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
 

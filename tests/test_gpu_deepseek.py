@@ -81,3 +81,66 @@ def test_deepseek_v3_style_routing(device):
     finally:
         eng.shutdown()
     check_against_oracle(OracleDeepseekV2(cfg, sd), prompts, outs)
+
+
+def test_deepseek_block_fp8_unified_and_semi_pd(device):
+    """DeepSeek-V3-style block-quantised model: every linear and the routed experts hold fp8
+    e4m3fn weights with one fp32 scale per 128 x 128 block, activations are quantised per token and group of
+    128 in front of each of them (quantization/fp8.py, fp8_utils.py:91-134, fused_moe.py:526-545).  The dummy
+    weights are the block-quantised twin of the bf16 model of the same seed.  Tokens against the oracle, which
+    runs the same quantised arithmetic on the CPU; the Semi-PD engine shares the fp8 tensors and their scales
+    through IPC and is held to the same oracle."""
+    from semi_pd_amd.entrypoints.engine import Engine
+    from semi_pd_amd.managers.io_struct import SamplingParams
+    qc = {"quant_method": "fp8", "weight_block_size": [128, 128], "activation_scheme": "dynamic"}
+    cfg = tiny_deepseek(quantization_config=qc)
+    prompts = make_prompts(cfg.vocab_size, [5, 37, 130, 1, 64, 17])
+    sp = SamplingParams(max_new_tokens=8, ignore_eos=True)
+    eng = Engine(server_args(cfg))
+    try:
+        sd_raw = eng.model_runner.model.state_dict()
+        fp8_names = [k for k, v in sd_raw.items() if v.dtype == torch.float8_e4m3fn]
+        assert len(fp8_names) >= 3 * 6 and all(k + "_scale_inv" in sd_raw for k in fp8_names)
+        assert any("experts.w13_weight" in k for k in fp8_names) and any("kv_a_proj_with_mqa" in k for k in fp8_names)
+        assert sd_raw["lm_head.weight"].dtype == torch.bfloat16 and sd_raw["model.layers.1.mlp.gate.weight"].dtype == torch.bfloat16
+        sd = {k: v.float().cpu() for k, v in sd_raw.items()}
+        outs = eng.generate(prompts, sp)
+        # decode through hipGraphs vs eager: the attention split count differs (a different fp32 summation
+        # order), behind every attention sits a quantiser, and a seeded random model is full of near-ties, so
+        # sequences may part ways after a flipped token; both must hold against the oracle step by step (teacher
+        # forced), and the prefill (same kernels, same order) must give the same first token
+        eager = Engine(server_args(cfg, disable_cuda_graph=True))
+        try:
+            eager_outs = eager.generate(prompts, sp)
+        finally:
+            eager.shutdown()
+    finally:
+        eng.shutdown()
+    oracle = OracleDeepseekV2(cfg, sd, act_dtype=torch.bfloat16)
+    frac = check_against_oracle(oracle, prompts, outs, margin=0.12)
+    assert frac > 0.8
+    check_against_oracle(oracle, prompts, eager_outs, margin=0.12)
+    assert [o[0] for o in eager_outs] == [o[0] for o in outs]
+    semi = Engine(server_args(cfg, enable_semi_pd=True, prefill_cu_percent=50, decode_cu_percent=50))
+    try:
+        got = semi.generate(prompts, sp, timeout=300)
+    finally:
+        semi.shutdown()
+    check_against_oracle(oracle, prompts, got, margin=0.12)
+    assert [o[0] for o in got] == [o[0] for o in outs]
+
+
+def test_block_fp8_config_and_loader_rules(device):
+    from semi_pd_amd.layers.fp8 import Fp8Config, block_dequantize_weight, block_quantize_weight
+    assert Fp8Config.from_hf(None) is None
+    assert Fp8Config.from_hf({"quant_method": "fp8", "weight_block_size": [128, 128]}).weight_block_size == (128, 128)
+    for bad in ({"quant_method": "awq"}, {"quant_method": "fp8"}, {"quant_method": "fp8", "weight_block_size": [128, 64]},
+                {"quant_method": "fp8", "weight_block_size": [128, 128], "activation_scheme": "static"}):
+        with pytest.raises(ValueError):
+            Fp8Config.from_hf(bad)
+    w = torch.randn(3, 200, 300, device=device) * 0.02
+    q, s = block_quantize_weight(w, (128, 128))
+    assert q.dtype == torch.float8_e4m3fn and s.shape == (3, 2, 3)
+    back = block_dequantize_weight(q, s, (128, 128), torch.float32)
+    assert float((back - w).abs().max()) <= float(s.max()) * 16  # half an fp8 step at the top of a block's range
+    assert float((back - w).abs().mean() / w.abs().mean()) < 0.03
