@@ -203,15 +203,27 @@ class Engine:
             self.procs.append(p)
             readers.append((role, tp_rank, reader, p))
 
-        # decode instances first: they own the weights and the KV cache
-        for r in self.local_tp_ranks:
-            spawn(InstanceRole.DECODE, r, sa.decode_cu_percent, from_top=True)
-        infos = self._wait_ready([x for x in readers if x[0] == InstanceRole.DECODE], ready_timeout)
-        self.max_total_num_tokens = min(i["max_total_num_tokens"] for i in infos)
-        n_d = len(readers)
-        for r in self.local_tp_ranks:
-            spawn(InstanceRole.PREFILL, r, sa.prefill_cu_percent, from_top=False)
-        infos += self._wait_ready(readers[n_d:], ready_timeout)
+        try:
+            # decode instances first: they own the weights and the KV cache
+            for r in self.local_tp_ranks:
+                spawn(InstanceRole.DECODE, r, sa.decode_cu_percent, from_top=True)
+            infos = self._wait_ready([x for x in readers if x[0] == InstanceRole.DECODE], ready_timeout)
+            self.max_total_num_tokens = min(i["max_total_num_tokens"] for i in infos)
+            n_d = len(readers)
+            for r in self.local_tp_ranks:
+                spawn(InstanceRole.PREFILL, r, sa.prefill_cu_percent, from_top=False)
+            infos += self._wait_ready(readers[n_d:], ready_timeout)
+        except BaseException:
+            # a child that failed after queueing its IPC info cannot exit while nobody drains the queue, and the
+            # interpreter waits for non-daemon children: stop them here so that the error surfaces at once
+            for p in self.procs:
+                if p.is_alive():
+                    p.terminate()
+            for p in self.procs:
+                p.join(timeout=10)
+                if p.is_alive():
+                    p.kill()
+            raise
         self.ready_infos = infos
         if self.is_driver:
             # every request goes to D first, then to P (tokenizer_manager.py:149-160)

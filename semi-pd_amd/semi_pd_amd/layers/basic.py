@@ -20,7 +20,8 @@ import torch.nn.functional as F
 from torch import nn
 
 from semi_pd_amd import ops
-from semi_pd_amd.layers.fp8 import FP8_DTYPE, apply_w8a8_block_fp8_linear, scale_shape, shard_rows_of_scale
+from semi_pd_amd.layers.fp8 import (FP8_DTYPE, apply_w8a8_block_fp8_linear, check_quantisable_input, scale_shape,
+                                    shard_rows_of_scale)
 from semi_pd_amd.distributed import (get_tensor_model_parallel_rank, get_tensor_model_parallel_world_size,
                                      tensor_model_parallel_all_gather, tensor_model_parallel_all_reduce)
 
@@ -193,6 +194,7 @@ class ColumnParallelLinear(nn.Module):
                                  requires_grad=False) if bias else None
         if quant_config:
             # Fp8LinearMethod.create_weights (quantization/fp8.py:205-330): one fp32 scale per weight block
+            check_quantisable_input(input_size, quant_config.weight_block_size, type(self).__name__)
             self.weight_scale_inv = nn.Parameter(torch.empty(
                 scale_shape(self.output_size_per_partition, input_size, quant_config.weight_block_size),
                 dtype=torch.float32), requires_grad=False)
@@ -243,6 +245,7 @@ class ReplicatedLinear(ColumnParallelLinear):
                                    requires_grad=False)
         self.bias = nn.Parameter(torch.zeros(output_size, dtype=params_dtype), requires_grad=False) if bias else None
         if quant_config:
+            check_quantisable_input(input_size, quant_config.weight_block_size, type(self).__name__)
             self.weight_scale_inv = nn.Parameter(torch.empty(
                 scale_shape(output_size, input_size, quant_config.weight_block_size), dtype=torch.float32),
                 requires_grad=False)
@@ -320,6 +323,7 @@ class RowParallelLinear(nn.Module):
         self.weight.tp_shard = lambda full: full[:, rank * n:(rank + 1) * n].contiguous()
         if quant_config:
             block = quant_config.weight_block_size
+            check_quantisable_input(n, block, type(self).__name__)
             self.weight.weight_block_size = block
             self.weight_scale_inv = nn.Parameter(torch.empty(scale_shape(output_size, n, block), dtype=torch.float32),
                                                  requires_grad=False)

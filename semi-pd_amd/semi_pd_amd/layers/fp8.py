@@ -45,6 +45,14 @@ def scale_shape(rows: int, cols: int, block) -> tuple:
     return (-(-rows // block[0]), -(-cols // block[1]))
 
 
+def check_quantisable_input(input_size: int, block, what: str) -> None:
+    """The activations in front of a block-quantised layer are quantised in whole groups of block_k
+    (per_token_group_quant_fp8 asserts it, fp8_kernel.py:183-186); say so when the model is built, not in the
+    middle of the first forward pass."""
+    if input_size % int(block[1]):
+        raise ValueError(f"{what}: input size {input_size} is not a multiple of the quantisation group {block[1]}")
+
+
 def apply_w8a8_block_fp8_linear(x: torch.Tensor, weight: torch.Tensor, block_size, weight_scale: torch.Tensor,
                                 bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """fp8_utils.py:91-134."""

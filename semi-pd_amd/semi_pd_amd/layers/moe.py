@@ -13,7 +13,7 @@ import torch
 from torch import nn
 
 from semi_pd_amd import ops
-from semi_pd_amd.layers.fp8 import FP8_DTYPE, scale_shape
+from semi_pd_amd.layers.fp8 import FP8_DTYPE, check_quantisable_input, scale_shape
 from semi_pd_amd.distributed import (get_tensor_model_parallel_rank, get_tensor_model_parallel_world_size,
                                      tensor_model_parallel_all_reduce)
 
@@ -111,6 +111,8 @@ class FusedMoE(nn.Module):
         if quant_config:
             # Fp8MoEMethod.create_weights (quantization/fp8.py:470-620), block-wise branch
             bn, bk = quant_config.weight_block_size
+            check_quantisable_input(hidden_size, (bn, bk), "FusedMoE w13")
+            check_quantisable_input(n, (bn, bk), "FusedMoE w2")
             self.w13_weight.weight_block_size = self.w2_weight.weight_block_size = (bn, bk)
             if tp > 1 and (n % bn or n % bk):
                 raise ValueError(f"intermediate size per rank {n} is not a multiple of the weight block {bn} x {bk}")

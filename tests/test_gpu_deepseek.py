@@ -144,3 +144,22 @@ def test_block_fp8_config_and_loader_rules(device):
     back = block_dequantize_weight(q, s, (128, 128), torch.float32)
     assert float((back - w).abs().max()) <= float(s.max()) * 16  # half an fp8 step at the top of a block's range
     assert float((back - w).abs().mean() / w.abs().mean()) < 0.03
+
+
+def test_block_fp8_rejects_ragged_inputs_at_build_time(device):
+    """A K that is not a whole number of quantisation groups is an error when the layer is created (DeepSeek-V2-Lite's
+    dense FFN, 10944 wide, is such a layer), and an engine that fails to start leaves no process behind."""
+    import time
+    from semi_pd_amd.entrypoints.engine import Engine
+    from semi_pd_amd.layers.basic import RowParallelLinear
+    from semi_pd_amd.layers.fp8 import Fp8Config
+    with pytest.raises(ValueError, match="not a multiple of the quantisation group"):
+        RowParallelLinear(10944, 2048, params_dtype=torch.bfloat16, quant_config=Fp8Config())
+    qc = {"quant_method": "fp8", "weight_block_size": [128, 128], "activation_scheme": "dynamic"}
+    cfg = tiny_deepseek(quantization_config=qc, intermediate_size=1000)
+    t0 = time.time()
+    with pytest.raises(RuntimeError, match="failed to initialise"):
+        Engine(server_args(cfg, enable_semi_pd=True, prefill_cu_percent=50, decode_cu_percent=50))
+    assert time.time() - t0 < 120
+    import multiprocessing as mp
+    assert not [p for p in mp.active_children() if p.is_alive()]
