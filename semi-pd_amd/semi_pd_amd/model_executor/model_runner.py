@@ -163,10 +163,16 @@ class ModelRunner:
                     load_weights(self.model, model_config, safetensors_weights_iterator(model_path))
                 else:
                     dummy_init_weights(self.model, self.device, seed)
+                # the initialisation temporaries (fp32 draws of full-size tensors) go back to the driver before
+                # anything else is allocated: a small tensor carved out of a cached multi-GiB block would be
+                # exported with that block's size (see _make_ipc_safe)
+                torch.cuda.empty_cache()
                 if hasattr(self.model, "post_load_weights"):
                     # e.g. MLA's W_kc / W_vc buffers (deepseek_v2.py:1228-1249); the prefill instance
                     # receives them through IPC like any other buffer
                     self.model.post_load_weights()
+                if instance_role == InstanceRole.DECODE:
+                    self._make_ipc_safe()
         finally:
             torch.set_default_dtype(torch.float32)
         # give the initialisation temporaries (fp32 draws of full-size tensors) back to the driver: later
@@ -230,6 +236,32 @@ class ModelRunner:
                                                                  self.token_to_kv_pool)
 
     # ------------------------------------------------------------------------------------ IPC export
+    @torch.no_grad()
+    def _make_ipc_safe(self):
+        """Re-home parameters and buffers whose backing allocation another process cannot import (ROCm 7.2:
+        hipIpcOpenMemHandle hangs for allocation sizes with size mod 4 GiB >= 2 GiB, csrc/ipc.hip): a tensor of
+        2 GiB or more owns its allocation, so it is copied into one that is padded to the next multiple of 4 GiB
+        (DeepSeek-V3's fused expert weights are 7 GiB per layer and rank at TP = 1)."""
+        from semi_pd_amd.mem_cache.memory_pool import ipc_safe_zeros
+        moved = 0
+        tensors = [(p, True) for _, p in self.model.named_parameters()] + \
+                  [(b, False) for _, b in self.model.named_buffers()]
+        for t, _ in tensors:
+            nbytes = t.numel() * t.element_size()
+            alloc = -(-nbytes // (2 << 20)) * (2 << 20)
+            if nbytes < (1 << 31) or (alloc & 0xFFFFFFFF) < (1 << 31) or not t.is_contiguous():
+                continue
+            new = ipc_safe_zeros(tuple(t.shape), torch.uint8 if t.dtype.itemsize == 1 else t.dtype, t.device)
+            new = new.view(t.dtype) if new.dtype != t.dtype else new
+            new.copy_(t.data)
+            t.data = new
+            moved += 1
+            # the old block must go back to the driver now: left in the allocator's cache, the next padded
+            # allocation would be carved out of it and inherit its size
+            torch.cuda.empty_cache()
+        if moved:
+            logger.info("moved %d tensors of 2 GiB+ into IPC-importable allocations", moved)
+
     def get_ipc_info(self) -> IPCInfo:
         """model_runner.py:346-479.  One (handle, offset) per parameter / buffer / KV layer /
         req_to_token; zero-size tensors are "BYPASS"."""
