@@ -134,6 +134,9 @@ def add_cli_args(parser):
                    help="share of the CUs given to the prefill instance (SEMI_PD_PREFILL_SM_PERCENTILE)")
     p.add_argument("--decode-cu-percent", type=int, default=DECODE_ENGINE_SM_PERCENTILE,
                    help="share of the CUs given to the decode instance (SEMI_PD_DECODE_SM_PERCENTILE)")
+    p.add_argument("--quantization", type=str, default=None, choices=[None, "fp8"],
+                   help="fp8 = block-scaled e4m3fn checkpoint (quantization_config with weight_block_size); with "
+                        "--load-format dummy it makes the seeded weights block-quantised")
     p.add_argument("--attention-backend", type=str, default="hip")
     p.add_argument("--sampling-backend", type=str, default="hip")
     p.add_argument("--log-level", type=str, default="info")
@@ -164,6 +167,19 @@ def from_cli_args(args) -> ServerArgs:
         enable_semi_pd=args.enable_semi_pd, prefill_cu_percent=args.prefill_cu_percent,
         decode_cu_percent=args.decode_cu_percent, attention_backend=args.attention_backend,
         sampling_backend=args.sampling_backend)
+    if args.quantization == "fp8":
+        # server_args.py --quantization: the checkpoint decides (config.json: quantization_config); the flag
+        # must agree with it.  There is no on-line weight quantisation, except for dummy weights.
+        import dataclasses
+        cfg = sa.model_config
+        if not hasattr(cfg, "quantization_config"):
+            raise ValueError(f"--quantization fp8 is supported for the DeepSeek family, not {type(cfg).__name__}")
+        if cfg.quantization_config is None:
+            if sa.load_format != "dummy":
+                raise ValueError("--quantization fp8 needs a block-quantised checkpoint (quantization_config with "
+                                 "weight_block_size in config.json); bf16 checkpoints are not quantised on load")
+            sa.model_config = dataclasses.replace(cfg, quantization_config={
+                "quant_method": "fp8", "weight_block_size": [128, 128], "activation_scheme": "dynamic"})
     ctx = args.context_length or getattr(sa.model_config, "max_position_embeddings", 4096)
     sa.context_length = int(ctx)
     eos = getattr(sa, "eos_token_ids", None)

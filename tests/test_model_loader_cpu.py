@@ -89,3 +89,52 @@ def test_per_expert_names_are_stacked():
 def test_unsupported_architecture_is_rejected():
     with pytest.raises(ValueError):
         config_from_hf_dict({"architectures": ["GPT2LMHeadModel"], "hidden_size": 8})
+
+
+def test_block_fp8_checkpoint_names_and_flags(tmp_path):
+    """Block-quantised checkpoints (DeepSeek-V3): `weight_scale_inv` tensors travel with the fp8 weights and
+    stack the same way (gate/up -> gate_up_proj, experts.{e}.* -> w13 / w2); `quantization_config` is read
+    from config.json; --quantization fp8 must agree with it."""
+    import argparse
+    import json
+    from semi_pd_amd.model_loader import product_items
+    from semi_pd_amd.models.deepseek_v2 import DeepseekV2Config
+    from semi_pd_amd.server_args import add_cli_args, from_cli_args
+    cfg = DeepseekV2Config(n_routed_experts=2, moe_intermediate_size=256, hidden_size=256)
+    g = torch.Generator().manual_seed(0)
+    ws = {}
+    for e in (1, 0):
+        for which, shape in (("gate_proj", (256, 256)), ("up_proj", (256, 256)), ("down_proj", (256, 256))):
+            ws[f"model.layers.1.mlp.experts.{e}.{which}.weight"] = torch.randn(shape, generator=g).to(torch.float8_e4m3fn)
+            ws[f"model.layers.1.mlp.experts.{e}.{which}.weight_scale_inv"] = torch.rand(2, 2, generator=g)
+    for which in ("gate_proj", "up_proj"):
+        ws[f"model.layers.0.mlp.{which}.weight"] = torch.randn(256, 256, generator=g).to(torch.float8_e4m3fn)
+        ws[f"model.layers.0.mlp.{which}.weight_scale_inv"] = torch.rand(2, 2, generator=g)
+    out = dict(product_items(cfg, ws.items()))
+    assert set(out) == {"model.layers.1.mlp.experts.w13_weight", "model.layers.1.mlp.experts.w2_weight",
+                        "model.layers.1.mlp.experts.w13_weight_scale_inv", "model.layers.1.mlp.experts.w2_weight_scale_inv",
+                        "model.layers.0.mlp.gate_up_proj.weight", "model.layers.0.mlp.gate_up_proj.weight_scale_inv"}
+    s13 = out["model.layers.1.mlp.experts.w13_weight_scale_inv"]
+    assert s13.shape == (2, 4, 2) and out["model.layers.1.mlp.experts.w13_weight"].dtype == torch.float8_e4m3fn
+    assert torch.equal(s13[1, 2:], ws["model.layers.1.mlp.experts.1.up_proj.weight_scale_inv"])
+    assert torch.equal(out["model.layers.0.mlp.gate_up_proj.weight_scale_inv"][:2],
+                       ws["model.layers.0.mlp.gate_proj.weight_scale_inv"])
+
+    base = {"architectures": ["DeepseekV3ForCausalLM"], "vocab_size": 320, "hidden_size": 256, "intermediate_size": 256,
+            "moe_intermediate_size": 128, "num_hidden_layers": 2, "num_attention_heads": 4, "n_routed_experts": 4,
+            "num_experts_per_tok": 2, "kv_lora_rank": 128, "max_position_embeddings": 256}
+    qc = {"quant_method": "fp8", "weight_block_size": [128, 128], "activation_scheme": "dynamic", "fmt": "e4m3"}
+    parse = lambda argv: from_cli_args(add_cli_args(argparse.ArgumentParser()).parse_args(argv))  # noqa: E731
+    (tmp_path / "config.json").write_text(json.dumps(dict(base, quantization_config=qc)))
+    assert parse(["--model-path", str(tmp_path)]).model_config.quantization_config["weight_block_size"] == [128, 128]
+    assert parse(["--model-path", str(tmp_path), "--quantization", "fp8"]).model_config.quantization_config == qc
+    (tmp_path / "config.json").write_text(json.dumps(base))
+    sa = parse(["--model-path", str(tmp_path), "--quantization", "fp8", "--load-format", "dummy"])
+    assert sa.model_config.quantization_config["quant_method"] == "fp8"          # dummy weights: quantised on the fly
+    with pytest.raises(ValueError, match="block-quantised checkpoint"):
+        parse(["--model-path", str(tmp_path), "--quantization", "fp8"])           # a bf16 checkpoint is not quantised on load
+    (tmp_path / "config.json").write_text(json.dumps({
+        "architectures": ["LlamaForCausalLM"], "vocab_size": 320, "hidden_size": 64, "intermediate_size": 96,
+        "num_hidden_layers": 2, "num_attention_heads": 4, "num_key_value_heads": 2, "quantization_config": qc}))
+    with pytest.raises(ValueError, match="DeepSeek family"):
+        parse(["--model-path", str(tmp_path)])
