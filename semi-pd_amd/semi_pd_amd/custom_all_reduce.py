@@ -45,39 +45,72 @@ class CustomAllreduce:
         self.device = torch.device(device)
         self.max_size = int(max_size)
         lib = _lib.load()
-        with torch.cuda.device(self.device):
-            region_bytes = int(lib.semipd_ar_region_size(self.max_size))
-            region = C.c_void_p()
-            _lib.check(lib.semipd_ar_alloc_shared(region_bytes, C.addressof(region)), "ar_alloc_shared")
-            self._region = region.value
-            handle = (C.c_uint8 * 64)()
-            offset = C.c_uint64()
-            _lib.check(lib.semipd_ipc_get_handle(self._region, C.addressof(handle), C.addressof(offset)), "ipc_get_handle")
-            mine = (bytes(handle), int(offset.value), os.getpid())
-            everyone: List[Optional[tuple]] = [None] * self.world_size
-            dist.all_gather_object(everyone, mine, group=group)
-            bases = []
-            for r, (h, off, pid) in enumerate(everyone):
-                if r == self.rank:
-                    bases.append(self._region)
-                    continue
-                assert pid != os.getpid(), "one rank per process"
-                base = C.c_void_p()
-                hb = (C.c_uint8 * 64).from_buffer_copy(h)
-                _lib.check(lib.semipd_ipc_open(C.addressof(hb), self.device.index or 0, C.addressof(base)), "ipc_open")
-                self._peer_bases.append(base.value)
-                bases.append(base.value + off)
-            arr = (C.c_void_p * self.world_size)(*bases)
-            comm = C.c_void_p()
-            _lib.check(lib.semipd_ar_init(C.addressof(arr), region_bytes, self.rank, self.world_size, C.addressof(comm)), "ar_init")
-            self._comm = comm.value
-        # nobody starts reducing before every rank has mapped every region
-        dist.barrier(group=group)
+
+        def agree(ok: bool) -> bool:
+            votes: List[Optional[bool]] = [None] * self.world_size
+            dist.all_gather_object(votes, bool(ok), group=group)
+            return all(votes)
+
+        # Every phase ends in a vote on the CPU group: a rank that cannot allocate, export or map (no P2P route,
+        # an IPC quirk of the platform) makes ALL ranks fall back to the backend collectives, instead of raising
+        # on one rank while the others wait in a barrier.
+        def fail_here(phase: str) -> None:
+            # test hook (tests/test_gpu_all_reduce.py): SEMIPD_AR_TEST_FAIL="<phase>:<rank>" breaks one rank in one phase
+            if os.environ.get("SEMIPD_AR_TEST_FAIL", "") == f"{phase}:{self.rank}":
+                raise RuntimeError(f"injected failure in phase {phase!r}")
+
+        mine = None
+        try:
+            fail_here("export")
+            with torch.cuda.device(self.device):
+                region_bytes = int(lib.semipd_ar_region_size(self.max_size))
+                region = C.c_void_p()
+                _lib.check(lib.semipd_ar_alloc_shared(region_bytes, C.addressof(region)), "ar_alloc_shared")
+                self._region = region.value
+                handle = (C.c_uint8 * 64)()
+                offset = C.c_uint64()
+                _lib.check(lib.semipd_ipc_get_handle(self._region, C.addressof(handle), C.addressof(offset)),
+                           "ipc_get_handle")
+                mine = (bytes(handle), int(offset.value), os.getpid())
+        except Exception as e:  # noqa: BLE001
+            logger.warning("peer-memory all-reduce: rank %d cannot export its region: %s", self.rank, e)
+        everyone: List[Optional[tuple]] = [None] * self.world_size
+        dist.all_gather_object(everyone, mine, group=group)
+        if any(x is None for x in everyone):
+            self.close()
+            return
+        ok = True
+        try:
+            fail_here("map")
+            with torch.cuda.device(self.device):
+                bases = []
+                for r, (h, off, pid) in enumerate(everyone):
+                    if r == self.rank:
+                        bases.append(self._region)
+                        continue
+                    assert pid != os.getpid(), "one rank per process"
+                    base = C.c_void_p()
+                    hb = (C.c_uint8 * 64).from_buffer_copy(h)
+                    _lib.check(lib.semipd_ipc_open(C.addressof(hb), self.device.index or 0, C.addressof(base)), "ipc_open")
+                    self._peer_bases.append(base.value)
+                    bases.append(base.value + off)
+                arr = (C.c_void_p * self.world_size)(*bases)
+                comm = C.c_void_p()
+                _lib.check(lib.semipd_ar_init(C.addressof(arr), region_bytes, self.rank, self.world_size,
+                                              C.addressof(comm)), "ar_init")
+                self._comm = comm.value
+        except Exception as e:  # noqa: BLE001
+            logger.warning("peer-memory all-reduce: rank %d cannot map its peers: %s", self.rank, e)
+            ok = False
+        # (the vote is also the barrier: nobody starts reducing before every rank has mapped every region)
+        if not agree(ok):
+            self.close()
+            return
         self.disabled = False
         if os.environ.get("SEMIPD_AR_SELF_TEST", "1") != "0" and not self._self_test():
             logger.warning("peer-memory all-reduce failed its start-up self-test on rank %d of %d; "
                            "falling back to the backend collectives", self.rank, self.world_size)
-            self.disabled = True
+            self.close()
 
     def _self_test(self) -> bool:
         """One-stage, two-stage and all-gather calls on data every rank can predict, with bounded flag
@@ -87,6 +120,8 @@ class CustomAllreduce:
         lib = _lib.load()
         ok = True
         try:
+            if os.environ.get("SEMIPD_AR_TEST_FAIL", "") == f"selftest:{self.rank}":
+                raise RuntimeError("injected failure in phase 'selftest'")
             _lib.check(lib.semipd_ar_set_timeout_ms(self._comm, 2000), "ar_set_timeout_ms")
             with torch.cuda.device(self.device):
                 for numel in (8, 1 << 20):  # 16 B; 2 MB of bf16 (two-stage for more than 2 ranks)

@@ -28,6 +28,12 @@ def main():
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
     ar = CustomAllreduce(dist.group.WORLD, dev, max_size=max_size)
+    if os.environ.get("SEMIPD_AR_TEST_FAIL"):
+        # one rank was broken on purpose: every rank must have fallen back, nobody may hang or raise
+        assert ar.disabled and ar.custom_all_reduce(torch.zeros(64, device=dev)) is None
+        dist.barrier()
+        print("AR_REPORT " + json.dumps({"rank": rank, "disabled": True}), flush=True)
+        return
     assert not ar.disabled
     report = {"rank": rank, "cases": 0, "bad": []}
     t_start = time.perf_counter()

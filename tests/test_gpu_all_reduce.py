@@ -64,3 +64,11 @@ def test_all_reduce_few_blocks_and_forced_two_stage(device):
     kernel switched off (two-stage even for 16 bytes: empty slices, empty sub-chunks)."""
     for r in run_world(4, {"SEMIPD_AR_MAX_BLOCKS": "3", "SEMIPD_AR_ONE_SHOT_BELOW": "0"}):
         assert not r["bad"], r["bad"][:5]
+
+
+@pytest.mark.parametrize("phase", ["export", "map", "selftest"])
+def test_a_rank_that_cannot_set_up_makes_every_rank_fall_back(device, phase):
+    """Start-up is a sequence of votes on the CPU group: a failure on one rank (injected here) disables the
+    peer-memory path on all ranks — the engine then reduces through RCCL — and nothing hangs or raises."""
+    reports = run_world(4, {"SEMIPD_AR_TEST_FAIL": f"{phase}:2"}, timeout=120)
+    assert len(reports) == 4 and all(r.get("disabled") for r in reports)
