@@ -19,6 +19,20 @@ from semi_pd_amd.distributed import (get_tensor_model_parallel_rank, get_tensor_
 
 MOE_BLOCK_M = 64  # rows per expert block = M tile of the grouped GEMM
 
+# --enable-ep-moe (server_args.py; read through global_server_args_dict in models/deepseek_v2.py:190-200): the
+# routed experts are partitioned over the TP ranks by EXPERT (E / tp whole experts per rank, layers/moe/ep_moe/
+# layer.py:106-190) instead of by intermediate column.  Set by the model runner before the model is built.
+_EXPERT_PARALLEL = False
+
+
+def set_expert_parallel(enabled: bool) -> None:
+    global _EXPERT_PARALLEL
+    _EXPERT_PARALLEL = bool(enabled)
+
+
+def expert_parallel_enabled() -> bool:
+    return _EXPERT_PARALLEL
+
 
 def select_experts(hidden_states: torch.Tensor, router_logits: torch.Tensor, top_k: int,
                    use_grouped_topk: bool, renormalize: bool, topk_group: Optional[int] = None,
@@ -30,10 +44,18 @@ def select_experts(hidden_states: torch.Tensor, router_logits: torch.Tensor, top
     return ops.topk_softmax(router_logits, top_k, renormalize)
 
 
+def _local_ids(topk_ids: torch.Tensor, expert_offset: int) -> torch.Tensor:
+    """Expert-parallel ranks hold experts [offset, offset + E_local): ids are shifted so that the local ones land
+    in [0, E_local); the others fall outside and moe_align_block_size drops them (their rows of the output stay
+    zero, the all-reduce over the ranks adds the other ranks' experts; ep_moe/layer.py:211-246, 340-360)."""
+    return topk_ids if expert_offset == 0 else (topk_ids - expert_offset).to(torch.int32)
+
+
 def fused_experts(hidden_states: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, topk_weights: torch.Tensor,
-                  topk_ids: torch.Tensor) -> torch.Tensor:
+                  topk_ids: torch.Tensor, expert_offset: int = 0, partial_experts: bool = False) -> torch.Tensor:
     """fused_experts_impl (fused_moe.py:961-1165), bf16/f16 path.  hidden [T, K]; w1 [E, 2N, K];
-    w2 [E, K, N]; returns [T, K]."""
+    w2 [E, K, N]; returns [T, K].  partial_experts: w1 / w2 hold only the experts [expert_offset, expert_offset + E)."""
+    topk_ids = _local_ids(topk_ids, expert_offset)
     T, K = hidden_states.shape
     E, N2, _ = w1.shape
     topk = topk_ids.shape[1]
@@ -52,7 +74,7 @@ def fused_experts(hidden_states: torch.Tensor, w1: torch.Tensor, w2: torch.Tenso
     ops.moe_grouped_gemm(hidden_states, w1, c1, None, sorted_ids, expert_ids, num_post_pad, numel, topk, False,
                          block_m)
     c2 = ops.silu_and_mul(c1)
-    c3 = torch.empty((numel, K), dtype=dt, device=dev)
+    c3 = (torch.zeros if partial_experts else torch.empty)((numel, K), dtype=dt, device=dev)
     ops.moe_grouped_gemm(c2, w2, c3, topk_weights.reshape(-1), sorted_ids, expert_ids, num_post_pad, numel, 1, True,
                          block_m)
     return ops.moe_sum(c3.view(T, topk, K))
@@ -60,11 +82,12 @@ def fused_experts(hidden_states: torch.Tensor, w1: torch.Tensor, w2: torch.Tenso
 
 def fused_experts_fp8(hidden_states: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, w1_scale: torch.Tensor,
                       w2_scale: torch.Tensor, topk_weights: torch.Tensor, topk_ids: torch.Tensor, block_shape,
-                      block_m: Optional[int] = None) -> torch.Tensor:
+                      block_m: Optional[int] = None, expert_offset: int = 0, partial_experts: bool = False) -> torch.Tensor:
     """fused_experts_impl with use_fp8_w8a8 and block_shape = [block_n, block_k] (fused_moe.py:961-1165;
     activation quantisation inside invoke_fused_moe_kernel :526-545): the activations of both GEMMs are
     quantised per token and group of block_k, the weights are fp8 [E, 2N, K] / [E, K, N] with one scale per
     block_n x block_k tile.  Returns [T, K] in the dtype of hidden_states."""
+    topk_ids = _local_ids(topk_ids, expert_offset)
     T, K = hidden_states.shape
     E, N2, _ = w1.shape
     topk = topk_ids.shape[1]
@@ -85,7 +108,7 @@ def fused_experts_fp8(hidden_states: torch.Tensor, w1: torch.Tensor, w2: torch.T
                              False, block_shape, block_m)
     c2 = ops.silu_and_mul(c1)
     c2_q, c2_s = ops.per_token_group_quant_fp8(c2, block_k)
-    c3 = torch.empty((numel, K), dtype=dt, device=dev)
+    c3 = (torch.zeros if partial_experts else torch.empty)((numel, K), dtype=dt, device=dev)
     ops.moe_grouped_gemm_fp8(c2_q, c2_s, w2, w2_scale, c3, topk_weights.reshape(-1).float(), sorted_ids, expert_ids,
                              num_post_pad, numel, 1, True, block_shape, block_m)
     return ops.moe_sum(c3.view(T, topk, K))
@@ -98,6 +121,18 @@ class FusedMoE(nn.Module):
                  reduce_results: bool = False, params_dtype=None, quant_config=None):
         super().__init__()
         tp, rank = get_tensor_model_parallel_world_size(), get_tensor_model_parallel_rank()
+        self.expert_parallel = expert_parallel_enabled() and tp > 1
+        if self.expert_parallel:
+            # EPMoE (ep_moe/layer.py:113-160): whole experts per rank, full intermediate size
+            assert num_experts % tp == 0, f"{num_experts} experts cannot be split over {tp} ranks"
+            self.expert_offset = rank * (num_experts // tp)
+            self._init_expert_parallel(num_experts, num_experts // tp, rank, hidden_size, intermediate_size,
+                                       params_dtype, quant_config)
+            self.top_k, self.renormalize = top_k, renormalize
+            self.use_grouped_topk, self.num_expert_group, self.topk_group = use_grouped_topk, num_expert_group, topk_group
+            self.correction_bias, self.reduce_results, self.quant_config = correction_bias, reduce_results, quant_config
+            return
+        self.expert_offset = 0
         assert intermediate_size % tp == 0
         n = intermediate_size // tp
         self.top_k, self.renormalize = top_k, renormalize
@@ -138,15 +173,38 @@ class FusedMoE(nn.Module):
         self.w2_weight.tp_full_shape = (num_experts, hidden_size, inter)
         self.w2_weight.tp_shard = lambda full: full[:, :, rank * n:(rank + 1) * n].contiguous()
 
+    def _init_expert_parallel(self, E, e_local, rank, hidden_size, n, params_dtype, quant_config):
+        wdt = FP8_DTYPE if quant_config else params_dtype
+        lo, hi = rank * e_local, (rank + 1) * e_local
+        self.w13_weight = nn.Parameter(torch.empty(e_local, 2 * n, hidden_size, dtype=wdt), requires_grad=False)
+        self.w2_weight = nn.Parameter(torch.empty(e_local, hidden_size, n, dtype=wdt), requires_grad=False)
+        self.w13_weight.tp_full_shape = (E, 2 * n, hidden_size)
+        self.w2_weight.tp_full_shape = (E, hidden_size, n)
+        self.w13_weight.tp_shard = self.w2_weight.tp_shard = lambda full: full[lo:hi].contiguous()
+        if quant_config:
+            bn, bk = quant_config.weight_block_size
+            check_quantisable_input(hidden_size, (bn, bk), "FusedMoE w13")
+            check_quantisable_input(n, (bn, bk), "FusedMoE w2")
+            self.w13_weight.weight_block_size = self.w2_weight.weight_block_size = (bn, bk)
+            self.w13_weight_scale_inv = nn.Parameter(
+                torch.empty((e_local,) + scale_shape(2 * n, hidden_size, (bn, bk)), dtype=torch.float32), requires_grad=False)
+            self.w2_weight_scale_inv = nn.Parameter(
+                torch.empty((e_local,) + scale_shape(hidden_size, n, (bn, bk)), dtype=torch.float32), requires_grad=False)
+            self.w13_weight_scale_inv.tp_full_shape = (E,) + scale_shape(2 * n, hidden_size, (bn, bk))
+            self.w2_weight_scale_inv.tp_full_shape = (E,) + scale_shape(hidden_size, n, (bn, bk))
+            self.w13_weight_scale_inv.tp_shard = self.w2_weight_scale_inv.tp_shard = lambda full: full[lo:hi].contiguous()
+
     def forward(self, hidden_states: torch.Tensor, router_logits: torch.Tensor) -> torch.Tensor:
         topk_weights, topk_ids = select_experts(hidden_states, router_logits, self.top_k, self.use_grouped_topk,
                                                 self.renormalize, self.topk_group, self.num_expert_group,
                                                 self.correction_bias)
         if self.quant_config:
             out = fused_experts_fp8(hidden_states, self.w13_weight, self.w2_weight, self.w13_weight_scale_inv,
-                                    self.w2_weight_scale_inv, topk_weights, topk_ids, self.quant_config.weight_block_size)
+                                    self.w2_weight_scale_inv, topk_weights, topk_ids, self.quant_config.weight_block_size,
+                                    expert_offset=self.expert_offset, partial_experts=self.expert_parallel)
         else:
-            out = fused_experts(hidden_states, self.w13_weight, self.w2_weight, topk_weights, topk_ids)
+            out = fused_experts(hidden_states, self.w13_weight, self.w2_weight, topk_weights, topk_ids,
+                                expert_offset=self.expert_offset, partial_experts=self.expert_parallel)
         if self.reduce_results and get_tensor_model_parallel_world_size() > 1:
             out = tensor_model_parallel_all_reduce(out)
         return out

@@ -115,7 +115,8 @@ class ModelRunner:
                  bypass_load_weight: bool = False, seed: int = 0, cu_percent: int = 100,
                  disable_cuda_graph: bool = False, cuda_graph_max_bs: int = 256,
                  load_state_dict: Optional[Dict[str, torch.Tensor]] = None, model_path: Optional[str] = None,
-                 load_format: str = "dummy", kv_cache_dtype: str = "auto", disable_custom_all_reduce: bool = False):
+                 load_format: str = "dummy", kv_cache_dtype: str = "auto", disable_custom_all_reduce: bool = False,
+                 enable_ep_moe: bool = False):
         self.model_config = model_config
         self.gpu_id, self.tp_rank, self.tp_size = gpu_id, tp_rank, tp_size
         self.dtype = dtype
@@ -144,6 +145,8 @@ class ModelRunner:
         self.num_cus_owned = max(8, self.num_cus * cu_percent // 100)
 
         # ---- model -------------------------------------------------------------------------
+        from semi_pd_amd.layers.moe import set_expert_parallel
+        set_expert_parallel(enable_ep_moe)
         torch.set_default_dtype(dtype)
         try:
             if bypass_load_weight:

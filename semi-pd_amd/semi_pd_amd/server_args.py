@@ -38,6 +38,7 @@ class ServerArgs:
     enable_semi_pd: bool = False
     disable_radix_cache: bool = True
     disable_cuda_graph: bool = False
+    enable_ep_moe: bool = False              # server_args.py --enable-ep-moe: routed experts partitioned by expert over TP
     disable_custom_all_reduce: bool = False  # server_args.py --disable-custom-all-reduce: TP all-reduce through RCCL only
     cuda_graph_max_bs: int = 256
     attention_backend: str = "hip"
@@ -126,6 +127,8 @@ def add_cli_args(parser):
     p.add_argument("--dist-init-addr", "--nccl-init-addr", dest="dist_init_addr", type=str, default="127.0.0.1")
     p.add_argument("--nccl-port", type=int, default=None)
     p.add_argument("--disable-cuda-graph", action="store_true")
+    p.add_argument("--enable-ep-moe", action="store_true",
+                   help="expert parallelism for the routed experts: E / tp whole experts per rank (ep_moe/layer.py)")
     p.add_argument("--disable-custom-all-reduce", action="store_true",
                    help="TP all-reduce through RCCL only (default: peer-memory kernel up to 16 MB)")
     p.add_argument("--cuda-graph-max-bs", type=int, default=256)
@@ -163,7 +166,7 @@ def from_cli_args(args) -> ServerArgs:
         base_gpu_id=args.base_gpu_id, random_seed=args.random_seed, watchdog_timeout=args.watchdog_timeout,
         dist_init_addr=args.dist_init_addr, nccl_port_base=args.nccl_port,
         disable_cuda_graph=args.disable_cuda_graph, disable_custom_all_reduce=args.disable_custom_all_reduce,
-        cuda_graph_max_bs=args.cuda_graph_max_bs,
+        enable_ep_moe=args.enable_ep_moe, cuda_graph_max_bs=args.cuda_graph_max_bs,
         enable_semi_pd=args.enable_semi_pd, prefill_cu_percent=args.prefill_cu_percent,
         decode_cu_percent=args.decode_cu_percent, attention_backend=args.attention_backend,
         sampling_backend=args.sampling_backend)

@@ -163,3 +163,56 @@ def test_block_fp8_rejects_ragged_inputs_at_build_time(device):
     assert time.time() - t0 < 120
     import multiprocessing as mp
     assert not [p for p in mp.active_children() if p.is_alive()]
+
+
+def test_expert_parallel_partial_outputs_sum_to_the_full_moe(device):
+    """--enable-ep-moe at the op level: each "rank" holds E / n whole experts, ids outside its range are dropped
+    by moe_align_block_size, its output holds only its experts' contributions; the sum over ranks is the MoE
+    (ep_moe/layer.py:190-360).  bf16 and block-fp8."""
+    from oracle import ops as O
+    from semi_pd_amd.layers.fp8 import block_quantize_weight
+    from semi_pd_amd.layers.moe import fused_experts, fused_experts_fp8
+    E, topk, K, N, T, ranks = 8, 3, 256, 128, 37, 4
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randn(T, K, generator=g) / 4).to(torch.bfloat16)
+    w1 = (torch.randn(E, 2 * N, K, generator=g) * 0.05).to(torch.bfloat16)
+    w2 = (torch.randn(E, K, N, generator=g) * 0.05).to(torch.bfloat16)
+    tw, ti = torch.topk(torch.softmax(torch.randn(T, E, generator=g), -1), topk)
+    want = O.fused_moe(x, w1, w2, tw, ti).float()
+    xd, twd, tid = x.to(device), tw.to(device), ti.to(torch.int32).to(device)
+    e_local = E // ranks
+    total = torch.zeros(T, K, device=device)
+    for r in range(ranks):
+        sl = slice(r * e_local, (r + 1) * e_local)
+        part = fused_experts(xd, w1[sl].to(device), w2[sl].to(device), twd, tid, expert_offset=r * e_local, partial_experts=True)
+        total += part.float()
+    assert float((total.cpu() - want).abs().max()) < 0.02 * float(want.abs().max())
+    q1, s1 = block_quantize_weight(w1.float(), (128, 128))
+    q2, s2 = block_quantize_weight(w2.float(), (128, 128))
+    want8 = O.fused_moe_block_fp8(x, q1, q2, s1, s2, tw, ti, [128, 128]).float()
+    total = torch.zeros(T, K, device=device)
+    for r in range(ranks):
+        sl = slice(r * e_local, (r + 1) * e_local)
+        part = fused_experts_fp8(xd, q1[sl].to(device), q2[sl].to(device), s1[sl].to(device), s2[sl].to(device), twd, tid,
+                                 [128, 128], expert_offset=r * e_local, partial_experts=True)
+        total += part.float()
+    assert float((total.cpu() - want8).abs().max()) < 0.02 * float(want8.abs().max())
+
+
+def test_deepseek_tp2_expert_parallel_on_one_gpu(unified_deepseek):
+    """DeepSeek with TP = 2 and --enable-ep-moe, both ranks on the one GPU (gloo + the peer-memory all-reduce):
+    attention and the shared experts are tensor parallel, the routed experts are split 8 + 8 by expert.  Same
+    tokens as the oracle of the unsharded model; the plain TP = 2 engine is held to the same."""
+    from semi_pd_amd.entrypoints.engine import Engine
+    from semi_pd_amd.managers.io_struct import SamplingParams
+    cfg, sd, prompts, outs, _ = unified_deepseek
+    oracle = OracleDeepseekV2(cfg, sd)
+    for ep in (True, False):
+        eng = Engine(server_args(cfg, tp_size=2, enable_semi_pd=True, prefill_cu_percent=50, decode_cu_percent=50,
+                                 dist_backend="gloo", enable_ep_moe=ep), gpu_ids={0: 0, 1: 0})
+        try:
+            got = eng.generate(prompts, SamplingParams(max_new_tokens=10, ignore_eos=True), timeout=600)
+        finally:
+            eng.shutdown()
+        assert all(len(o) == 10 for o in got)
+        check_against_oracle(oracle, prompts, got)
