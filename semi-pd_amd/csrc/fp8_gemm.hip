@@ -22,6 +22,8 @@
 //   * split-K for calls with few output tiles (fp32 partial planes + a reduce launch, as in skinny_gemm.hip).
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace semipd {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -86,7 +88,8 @@ fp8_block_gemm_kernel(OutT* __restrict__ c, const uint8_t* __restrict__ a, const
                       const float* __restrict__ topk_weights, const int32_t* __restrict__ sorted_ids,
                       const int32_t* __restrict__ expert_ids, const int32_t* __restrict__ num_post_pad,
                       int64_t num_valid, int64_t M, int64_t N, int64_t K, int64_t ldc, int block_n, int top_k_div,
-                      int mul_routed_weight, int chunks_per_split, float* __restrict__ partial_ws) {
+                      int mul_routed_weight, int chunks_per_split, float* __restrict__ partial_ws, int n_tiles, int m_blocks,
+                      int group_n) {
   static_assert(NG == 1 || NG == 2 || NG == 4, "NG = groups of 16 W rows per wave");
   // KC = bytes of K staged per barrier pair: 512 for the 64-row blocks (8 x 16 B of weights in flight per
   // lane, double buffered), 128 for the 128-row blocks (their 64 accumulator registers leave room for less)
@@ -108,13 +111,28 @@ fp8_block_gemm_kernel(OutT* __restrict__ c, const uint8_t* __restrict__ a, const
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c16 = lane & 15, q4 = lane >> 4;
-  const int64_t m0 = (int64_t)blockIdx.y * BM;
-  const int64_t n0 = (int64_t)blockIdx.x * (4 * BNW) + wave * BNW;
+  int tile_n = blockIdx.x, tile_m = blockIdx.y;
+  if (!GROUPED) {
+    // Dense calls come as a 1-D grid.  Workgroup b runs on XCD b % 8 (observed dispatch order; a wrong guess costs
+    // speed, not correctness), and each XCD has its own 4 MB L2: give every XCD a contiguous range of tiles
+    // (bijective remap of cdna_hip_programming.md) and walk it as "group_n weight tiles x all row blocks", so the
+    // group's weight tiles stay in that L2 while the activation tiles stream past.
+    const int nwg = n_tiles * m_blocks;
+    const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    const int per_group = group_n * m_blocks;
+    const int grp = logical / per_group, within = logical - grp * per_group;
+    const int gn = min(group_n, n_tiles - grp * group_n);  // the last group may be narrower
+    tile_n = grp * group_n + within % gn;
+    tile_m = within / gn;
+  }
+  const int64_t m0 = (int64_t)tile_m * BM;
+  const int64_t n0 = (int64_t)tile_n * (4 * BNW) + wave * BNW;
   const int64_t KB = (K + 127) / 128;  // scale blocks along K
   int64_t expert = 0;
   if (GROUPED) {
     if (m0 >= *num_post_pad) return;
-    expert = expert_ids[blockIdx.y];
+    expert = expert_ids[tile_m];
     if (tid < BM) {
       const int sid = sorted_ids[m0 + tid];
       row_id[tid] = (sid >= 0 && sid < num_valid) ? sid : -1;
@@ -276,7 +294,7 @@ fp8_block_gemm_kernel(OutT* __restrict__ c, const uint8_t* __restrict__ a, const
     const int64_t nb = n0 + g * 16 + q4 * 4;
     if (!GROUPED && gridDim.z > 1) {
       // fp32 partials [z][m_block * BM + row][N], summed in z order by fp8_splitk_reduce_kernel
-      const int64_t rows_total = (int64_t)gridDim.y * BM;
+      const int64_t rows_total = (int64_t)m_blocks * BM;
       float* ws = partial_ws + ((int64_t)blockIdx.z * rows_total + m0) * N;
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
@@ -340,6 +358,11 @@ fp8_splitk_reduce_kernel(OutT* __restrict__ c, const float* __restrict__ partial
   }
 }
 
+static long env_int(const char* name, long dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atol(v) : dflt;
+}
+
 // Split-K factor: enough workgroups for two per CU (the kernel's occupancy), at least two chunks per split,
 // and only when the fp32 partial planes fit the workspace.
 static int fp8_pick_ksplit(int64_t tiles, int chunks, int64_t rows_total, int64_t N, size_t ws_bytes) {
@@ -362,10 +385,15 @@ static int launch_fp8_gemm(void* c, const void* a, const float* a_s, const void*
   if (!GROUPED && ws && N % 4 == 0) ksplit = fp8_pick_ksplit(n_tiles * m_blocks, chunks, m_blocks * BM, N, ws_bytes);
   const int cps = (chunks + ksplit - 1) / ksplit;
   ksplit = (chunks + cps - 1) / cps;  // no empty splits
-  dim3 grid((unsigned)n_tiles, (unsigned)m_blocks, (unsigned)ksplit);
+  dim3 grid = GROUPED ? dim3((unsigned)n_tiles, (unsigned)m_blocks, 1)
+                      : dim3((unsigned)(n_tiles * m_blocks), 1, (unsigned)ksplit);
+  // weight tiles per group: measured on DeepSeek-V3 shapes at M = 4096, 8 is best (1.25 vs 1.09 PFLOP/s with 1;
+  // profiles/r01_kbench_fp8_v1.txt) — a mild effect: the 256 MB MALL already holds the whole weight matrix
+  int group_n = (int)env_int("SEMIPD_FP8_GROUP_N", 8);
+  if (group_n < 1) group_n = 1;
   hipLaunchKernelGGL((fp8_block_gemm_kernel<OutT, GROUPED, BM, NG, KC>), grid, dim3(256), 0, st, (OutT*)c, (const uint8_t*)a,
                      a_s, (const uint8_t*)w, w_s, topk_weights, sorted_ids, expert_ids, num_post_pad, num_valid, M, N, K,
-                     ldc, block_n, top_k_div, mul_routed_weight, cps, ws);
+                     ldc, block_n, top_k_div, mul_routed_weight, cps, ws, (int)n_tiles, (int)m_blocks, group_n);
   int rc = launch_status("fp8_block_gemm");
   if (rc || ksplit == 1) return rc;
   const int64_t items = M * (N / 4);
