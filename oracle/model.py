@@ -224,10 +224,14 @@ class OracleDeepseekV2:
     biased_grouped_topk + naive experts (deepseek_v2.py:119-210, layers/moe/topk.py:79-160,
     fused_moe_native.py:58-131)."""
 
-    def __init__(self, config, state_dict, act_dtype=torch.float32):
+    def __init__(self, config, state_dict, act_dtype=torch.float32, kv_cache_dtype=None):
+        """kv_cache_dtype = torch.float8_e5m2 / float8_e4m3fn: the latent rows [kv_a | k_pe] go through `.to(fp8)`
+        when they enter the cache (MLATokenToKVPool.set_kv_buffer, memory_pool.py:439-452); cached keys / values
+        are expanded from the rounded rows, the tokens of the running forward attend to each other unrounded."""
         self.cfg = config
         self.w = {k: v.detach().to("cpu") for k, v in state_dict.items()}
         self.act = act_dtype
+        self.kv_cache_dtype = kv_cache_dtype
         c = config
         qc = getattr(c, "quantization_config", None)
         self.block = tuple(qc["weight_block_size"]) if qc else None
@@ -315,11 +319,20 @@ class OracleDeepseekV2:
             kvb = kvb.view(T, self.H, self.nope + self.vd)
             k = torch.cat([kvb[..., : self.nope], k_pe.view(T, 1, self.rope).expand(T, self.H, self.rope)], -1)
             v = kvb[..., self.nope:]
+            if self.kv_cache_dtype is not None:
+                rt = lambda t: O.kv_cache_round_trip(t.to(torch.bfloat16), self.kv_cache_dtype).to(t.dtype)  # noqa: E731
+                kvb_c = (rt(kv_a).float() @ self._dense(p + "self_attn.kv_b_proj.weight").T).to(self.act)
+                kvb_c = kvb_c.view(T, self.H, self.nope + self.vd)
+                k_c = torch.cat([kvb_c[..., : self.nope], rt(k_pe).view(T, 1, self.rope).expand(T, self.H, self.rope)], -1)
+                v_c = kvb_c[..., self.nope:]
+            else:
+                k_c, v_c = k, v
             outs = []
             for b, n in enumerate(lens):
                 sl = slice(starts[b], starts[b + 1])
-                kv.append(l, b, k[sl], v[sl])
-                kk, vv = kv.k[l][b], kv.v[l][b]
+                kk = k[sl] if kv.k[l][b] is None else torch.cat([kv.k[l][b], k[sl]], 0)
+                vv = v[sl] if kv.v[l][b] is None else torch.cat([kv.v[l][b], v[sl]], 0)
+                kv.append(l, b, k_c[sl], v_c[sl])
                 s = torch.einsum("qhd,khd->hqk", q[sl].float(), kk.float()) * self.scaling
                 Tk = kk.shape[0]
                 if n > 1:

@@ -357,8 +357,8 @@ int launch_decode_mfma(T* out, const T* q, const KV* k_buf, const KV* v_buf, con
                        int splits, float sm_scale, float logit_cap, hipStream_t st);
 
 // defined in mla_decode_attention.hip
-template <typename T>
-int launch_mla_decode(T* out, const T* q, const T* kv_buf, const int32_t* kv_indptr, const int32_t* kv_indices,
+template <typename T, typename KV>
+int launch_mla_decode(T* out, const T* q, const KV* kv_buf, const int32_t* kv_indptr, const int32_t* kv_indices,
                       float* attn_logits, int64_t batch, int Hq, int64_t q_stride, int64_t o_stride,
                       int64_t kvbuf_stride, int splits, float sm_scale, float logit_cap, hipStream_t st);
 
@@ -386,9 +386,18 @@ static int run_decode(void* out, const void* q, const void* k_buf, const void* v
     // on the way from HBM to the MFMA operands; the other kernels only read rows of the activation type
     SEMIPD_CHECK_ARG(kv_dtype == SEMIPD_F8E5M2 || kv_dtype == SEMIPD_F8E4M3, SEMIPD_EDTYPE,
                      "decode_attention: unsupported kv_dtype %d", kv_dtype);
-    SEMIPD_CHECK_ARG(mfma && !mla, SEMIPD_ESHAPE,
-                     "decode_attention: fp8 KV rows need the GQA / MQA kernel (group >= 2, head dim 64 / 96 / 128)");
-    if (kv_dtype == SEMIPD_F8E5M2)
+    SEMIPD_CHECK_ARG(mfma || mla, SEMIPD_ESHAPE,
+                     "decode_attention: fp8 KV rows need the GQA / MQA kernel (group >= 2, head dim 64 / 96 / 128) or "
+                     "the MLA kernel");
+    if (mla && kv_dtype == SEMIPD_F8E5M2)
+      rc = launch_mla_decode<T, f8e5m2_t>((T*)out, (const T*)q, (const f8e5m2_t*)k_buf, kv_indptr, kv_indices, attn_logits,
+                                          batch, num_q_heads, q_stride, o_stride, kbuf_stride, num_kv_splits, sm_scale,
+                                          logit_cap, st);
+    else if (mla)
+      rc = launch_mla_decode<T, f8e4m3_t>((T*)out, (const T*)q, (const f8e4m3_t*)k_buf, kv_indptr, kv_indices, attn_logits,
+                                          batch, num_q_heads, q_stride, o_stride, kbuf_stride, num_kv_splits, sm_scale,
+                                          logit_cap, st);
+    else if (kv_dtype == SEMIPD_F8E5M2)
       rc = launch_decode_mfma<T, f8e5m2_t>((T*)out, (const T*)q, (const f8e5m2_t*)k_buf, (const f8e5m2_t*)v_buf,
                                            kv_indptr, kv_indices, attn_logits, batch, num_q_heads, num_kv_heads,
                                            head_dim_k, q_stride, o_stride, kbuf_stride, vbuf_stride, num_kv_splits,
@@ -400,7 +409,7 @@ static int run_decode(void* out, const void* q, const void* k_buf, const void* v
                                            sm_scale, logit_cap, st);
   } else if (mla) {
     // DeepSeek latent rows shared by all heads (mla_decode_attention.hip)
-    rc = launch_mla_decode<T>((T*)out, (const T*)q, (const T*)k_buf, kv_indptr, kv_indices, attn_logits, batch,
+    rc = launch_mla_decode<T, T>((T*)out, (const T*)q, (const T*)k_buf, kv_indptr, kv_indices, attn_logits, batch,
                               num_q_heads, q_stride, o_stride, kbuf_stride, num_kv_splits, sm_scale, logit_cap, st);
   } else if (mfma) {
     // GQA / MQA: matrix-core kernel (decode_attention_mfma.hip)

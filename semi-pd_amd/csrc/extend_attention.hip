@@ -375,11 +375,17 @@ extend_attn_kernel(T* __restrict__ out, const T* __restrict__ q_ext, const T* __
 
 // Generic fallback (head dims without an MFMA instantiation, e.g. MLA 576/512 with prefix):
 // one wave per (query token, q head).
-template <typename T>
+template <typename T, typename KV>
+__device__ __forceinline__ float pool_elem_to_f(const KV* p) {
+  if constexpr (KVTraits<T, KV>::kF8) return F8Cvt<KV>::template unpack2<false>((uint32_t)p->v)[0];
+  else return Elem<T>::to_f(*p);
+}
+
+template <typename T, typename KV = T>
 __global__ void __launch_bounds__(64)
 extend_attn_generic_kernel(T* __restrict__ out, const T* __restrict__ q_ext,
                            const T* __restrict__ k_ext, const T* __restrict__ v_ext,
-                           const T* __restrict__ k_buf, const T* __restrict__ v_buf,
+                           const KV* __restrict__ k_buf, const KV* __restrict__ v_buf,
                            const int32_t* __restrict__ qo_indptr,
                            const int32_t* __restrict__ kv_indptr,
                            const int32_t* __restrict__ kv_indices, int group, int Dk, int Dv,
@@ -405,11 +411,13 @@ extend_attn_generic_kernel(T* __restrict__ out, const T* __restrict__ q_ext,
   float m = -INFINITY, l = 0.f;
   const int total = pre_len + qi + 1;
   for (int t = 0; t < total; ++t) {
-    const T *kr, *vr;
-    if (t < pre_len) {
+    const bool pooled = t < pre_len;  // prefix rows live in the pool (possibly fp8), the rest in the extend tensors
+    const T *kr = nullptr, *vr = nullptr;
+    const KV *kp = nullptr, *vp = nullptr;
+    if (pooled) {
       const int64_t idx = kv_indices[kv_start + t];
-      kr = k_buf + idx * kbuf_stride + (int64_t)hk * Dk;
-      vr = v_buf + idx * vbuf_stride + (int64_t)hk * Dv;
+      kp = k_buf + idx * kbuf_stride + (int64_t)hk * Dk;
+      vp = v_buf + idx * vbuf_stride + (int64_t)hk * Dv;
     } else {
       const int64_t row = q_start + (t - pre_len);
       kr = k_ext + row * k_stride + (int64_t)hk * Dk;
@@ -419,7 +427,7 @@ extend_attn_generic_kernel(T* __restrict__ out, const T* __restrict__ q_ext,
 #pragma unroll
     for (int r = 0; r < MAXR; ++r) {
       const int dd = lane + r * 64;
-      if (dd < Dk) d = fmaf(qf[r], Elem<T>::to_f(kr[dd]), d);
+      if (dd < Dk) d = fmaf(qf[r], pooled ? pool_elem_to_f<T, KV>(kp + dd) : Elem<T>::to_f(kr[dd]), d);
     }
     d = wave_sum(d);
     if (logit_cap > 0.f) d = logit_cap * tanhf(d / logit_cap);
@@ -430,7 +438,7 @@ extend_attn_generic_kernel(T* __restrict__ out, const T* __restrict__ q_ext,
 #pragma unroll
     for (int r = 0; r < MAXR; ++r) {
       const int dd = lane + r * 64;
-      const float vv = dd < Dv ? Elem<T>::to_f(vr[dd]) : 0.f;
+      const float vv = dd < Dv ? (pooled ? pool_elem_to_f<T, KV>(vp + dd) : Elem<T>::to_f(vr[dd])) : 0.f;
       acc[r] = acc[r] * sc + p * vv;
     }
     m = mn;
@@ -486,8 +494,22 @@ static int run_extend(void* out, const void* q, const void* k, const void* v, co
     // fp8 prefix rows (mem_cache/memory_pool.py:205-209): vectorised, cap-free instantiations only
     SEMIPD_CHECK_ARG(kv_dtype == SEMIPD_F8E5M2 || kv_dtype == SEMIPD_F8E4M3, SEMIPD_EDTYPE,
                      "extend_attention: unsupported kv_dtype %d", kv_dtype);
-    SEMIPD_CHECK_ARG(vec_ok && !(logit_cap > 0.f) && Dk <= 128 && Dv <= 128, SEMIPD_ESHAPE,
-                     "extend_attention: fp8 KV rows need 8-element aligned heads up to 128 and no logit cap");
+    if (!(vec_ok && !(logit_cap > 0.f) && Dk <= 128 && Dv <= 128)) {
+      // everything else (MLA's 576 / 512 latent rows behind a chunked prefill, logit caps, ragged heads): the
+      // one-wave-per-(token, head) kernel reads pool rows element by element in either storage type
+      dim3 g2((unsigned)max_len_extend, (unsigned)Hq, (unsigned)batch);
+      if (kv_dtype == SEMIPD_F8E5M2)
+        hipLaunchKernelGGL((extend_attn_generic_kernel<T, f8e5m2_t>), g2, dim3(64), 0, st, (T*)out, (const T*)q,
+                           (const T*)k, (const T*)v, (const f8e5m2_t*)k_buf, (const f8e5m2_t*)v_buf, qo_indptr, kv_indptr,
+                           kv_indices, group, Dk, Dv, q_stride, k_stride, v_stride, o_stride, kbuf_stride, vbuf_stride,
+                           sm_scale, logit_cap);
+      else
+        hipLaunchKernelGGL((extend_attn_generic_kernel<T, f8e4m3_t>), g2, dim3(64), 0, st, (T*)out, (const T*)q,
+                           (const T*)k, (const T*)v, (const f8e4m3_t*)k_buf, (const f8e4m3_t*)v_buf, qo_indptr, kv_indptr,
+                           kv_indices, group, Dk, Dv, q_stride, k_stride, v_stride, o_stride, kbuf_stride, vbuf_stride,
+                           sm_scale, logit_cap);
+      return launch_status("extend_attention(generic, fp8 pool)");
+    }
     int miss8;
     if (kv_dtype == SEMIPD_F8E5M2)
       miss8 = launch_extend_variant<T, true, false, f8e5m2_t>(out, q, k, v, k_buf, v_buf, qo_indptr, kv_indptr,

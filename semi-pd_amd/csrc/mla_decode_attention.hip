@@ -41,9 +41,11 @@ template <> struct MfmaM<f16_t> {
   }
 };
 
-template <typename T>
+// KV = storage type of the latent rows: T, or an OCP fp8 type (--kv-cache-dtype fp8_*, memory_pool.py:439-452): 8
+// bytes per 8 elements in flight, expanded to T when the tile is written to LDS.
+template <typename T, typename KV>
 __global__ void __launch_bounds__(256, 2)
-mla_decode_kernel(T* __restrict__ out, const T* __restrict__ q, const T* __restrict__ kv_buf,
+mla_decode_kernel(T* __restrict__ out, const T* __restrict__ q, const KV* __restrict__ kv_buf,
                   const int32_t* __restrict__ kv_indptr, const int32_t* __restrict__ kv_indices,
                   float* __restrict__ attn_logits, int num_q_heads, int tiles, int64_t q_stride,
                   int64_t o_stride, int64_t kvbuf_stride, int num_kv_splits, float sm_scale,
@@ -94,8 +96,9 @@ mla_decode_kernel(T* __restrict__ out, const T* __restrict__ q, const T* __restr
 
   const int32_t* idx_base = kv_indices + kv_start;
   const int n_tiles = (s_end - s_begin + TOK - 1) / TOK;
+  using KVT = KVTraits<T, KV>;
   int32_t idx[NI];
-  FragM reg[NI];
+  typename KVT::Raw reg[NI];
   auto load_idx = [&](int ti) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
@@ -108,9 +111,8 @@ mla_decode_kernel(T* __restrict__ out, const T* __restrict__ q, const T* __restr
     for (int i = 0; i < NI; ++i) {
       const int item = tid + i * 256;
       const int r = item / CPR, ch = item - r * CPR;
-      reg[i].u = make_uint4(0, 0, 0, 0);  // rows past the end must be zero (0 * garbage could be NaN)
-      if (s_begin + ti * TOK + r < s_end)
-        reg[i].u = *reinterpret_cast<const uint4*>(kv_buf + (int64_t)idx[i] * kvbuf_stride + ch * 8);
+      reg[i] = KVT::zero();  // rows past the end must be zero (0 * garbage could be NaN)
+      if (s_begin + ti * TOK + r < s_end) reg[i] = KVT::load8(kv_buf + (int64_t)idx[i] * kvbuf_stride + ch * 8);
     }
   };
 
@@ -126,7 +128,7 @@ mla_decode_kernel(T* __restrict__ out, const T* __restrict__ q, const T* __restr
     for (int i = 0; i < NI; ++i) {
       const int item = tid + i * 256;
       const int r = item / CPR, ch = item - r * CPR;
-      *reinterpret_cast<uint4*>(tile + r * RS + ch * 16) = reg[i].u;
+      *reinterpret_cast<uint4*>(tile + r * RS + ch * 16) = KVT::expand(reg[i]);
     }
     __syncthreads();
     if (ti + 1 < n_tiles) fetch(ti + 1);
@@ -218,8 +220,8 @@ mla_decode_kernel(T* __restrict__ out, const T* __restrict__ q, const T* __restr
   }
 }
 
-template <typename T>
-int launch_mla_decode(T* out, const T* q, const T* kv_buf, const int32_t* kv_indptr, const int32_t* kv_indices,
+template <typename T, typename KV>
+int launch_mla_decode(T* out, const T* q, const KV* kv_buf, const int32_t* kv_indptr, const int32_t* kv_indices,
                       float* attn_logits, int64_t batch, int Hq, int64_t q_stride, int64_t o_stride,
                       int64_t kvbuf_stride, int splits, float sm_scale, float logit_cap, hipStream_t st) {
   const int tiles = (Hq + 15) / 16;
@@ -228,15 +230,21 @@ int launch_mla_decode(T* out, const T* q, const T* kv_buf, const int32_t* kv_ind
     set_error("mla_decode: grid too large");
     return SEMIPD_EINVAL;
   }
-  hipLaunchKernelGGL((mla_decode_kernel<T>), dim3((unsigned)total), dim3(256), 0, st, out, q, kv_buf, kv_indptr,
+  hipLaunchKernelGGL((mla_decode_kernel<T, KV>), dim3((unsigned)total), dim3(256), 0, st, out, q, kv_buf, kv_indptr,
                      kv_indices, attn_logits, Hq, tiles, q_stride, o_stride, kvbuf_stride, splits, sm_scale,
                      logit_cap);
   return launch_status("mla_decode");
 }
 
-template int launch_mla_decode<bf16_t>(bf16_t*, const bf16_t*, const bf16_t*, const int32_t*, const int32_t*, float*,
-                                       int64_t, int, int64_t, int64_t, int64_t, int, float, float, hipStream_t);
-template int launch_mla_decode<f16_t>(f16_t*, const f16_t*, const f16_t*, const int32_t*, const int32_t*, float*,
-                                      int64_t, int, int64_t, int64_t, int64_t, int, float, float, hipStream_t);
+#define MLA_INST(T, KV)                                                                                              \
+  template int launch_mla_decode<T, KV>(T*, const T*, const KV*, const int32_t*, const int32_t*, float*, int64_t, int, \
+                                        int64_t, int64_t, int64_t, int, float, float, hipStream_t);
+MLA_INST(bf16_t, bf16_t)
+MLA_INST(f16_t, f16_t)
+MLA_INST(bf16_t, f8e5m2_t)
+MLA_INST(bf16_t, f8e4m3_t)
+MLA_INST(f16_t, f8e5m2_t)
+MLA_INST(f16_t, f8e4m3_t)
+#undef MLA_INST
 
 }  // namespace semipd

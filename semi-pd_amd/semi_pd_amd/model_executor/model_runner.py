@@ -226,9 +226,7 @@ class ModelRunner:
         self.req_to_token_pool = ReqToTokenPool(self.max_running_requests + 1, self.max_context_len + 4, dev,
                                                 bypass_create_buffers=bypass)
         if geo["kind"] == "mla":
-            if self.kv_cache_dtype != self.dtype:
-                raise NotImplementedError("fp8 KV cache is implemented for MHA / GQA pools, not for MLA latent rows")
-            self.token_to_kv_pool = MLATokenToKVPool(self.max_total_num_tokens, 1, self.dtype,
+            self.token_to_kv_pool = MLATokenToKVPool(self.max_total_num_tokens, 1, self.kv_cache_dtype,
                                                      geo["kv_lora_rank"], geo["qk_rope_head_dim"],
                                                      geo["num_layers"], dev, bypass_create_buffers=bypass)
         else:

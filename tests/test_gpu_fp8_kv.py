@@ -106,6 +106,7 @@ def test_extend_attention_fp8_prefix(ops, device, kv_dtype, pre, ext, Hq, Hkv, D
 
 
 def test_unsupported_fp8_paths_fail_loudly(ops, device):
+    """MHA pools with one query head per kv head (group = 1) have no fp8 decode kernel."""
     k8 = torch.zeros(10, 4, 128, dtype=torch.float8_e5m2, device=device)
     q = torch.zeros(1, 4, 128, dtype=torch.bfloat16, device=device)     # group == 1: not the MFMA kernel
     o = torch.empty_like(q)
@@ -146,3 +147,87 @@ def test_engine_with_fp8_kv_cache_matches_quantising_oracle(kv):
     finally:
         eng.shutdown()
     check_against_oracle(oracle, prompts, semi, margin=0.15)
+
+
+# ----------------------------------------------------------------------------------------------- MLA latent rows
+def _mla_paged(B, lens, kv_dtype, seed):
+    g = torch.Generator().manual_seed(seed)
+    total = sum(lens)
+    N = total + 5
+    rows = torch.randn(N, 1, 576, generator=g).to(torch.bfloat16)
+    perm = torch.randperm(N - 1, generator=g)[:total] + 1
+    indptr = torch.zeros(B + 1, dtype=torch.int32)
+    indptr[1:] = torch.cumsum(torch.tensor(lens), 0)
+    return rows.to(kv_dtype), indptr, perm.to(torch.int32)
+
+
+@pytest.mark.parametrize("kv_dtype", F8)
+@pytest.mark.parametrize("B,lens,H,splits", [(3, [70, 1, 300], 16, 4), (2, [33, 129], 128, 1), (1, [500], 8, 8)])
+def test_mla_decode_attention_fp8_latent_rows(ops, device, kv_dtype, B, lens, H, splits):
+    """MLATokenToKVPool with an fp8 store dtype (memory_pool.py:439-452): the MLA decode kernel expands the 576-wide
+    latent rows on their way into LDS; keys are the whole row, values its first 512 columns."""
+    rows8, indptr, idx = _mla_paged(B, lens, kv_dtype, B + H)
+    q = (torch.randn(B, H, 576) * 0.3).to(torch.bfloat16)
+    o = torch.empty(B, H, 512, dtype=torch.bfloat16, device=device)
+    lg = torch.empty(B, H, splits, 513, dtype=torch.float32, device=device)
+    buf = rows8.to(device)
+    ops.decode_attention_fwd(q.to(device), buf, buf[..., :512], o, indptr.to(device), idx.to(device), lg, splits, 576 ** -0.5)
+    rows = rows8.to(torch.bfloat16)
+    want = O.decode_attention(q, rows, rows[..., :512], indptr, idx, 576 ** -0.5)
+    torch.testing.assert_close(o.cpu().float(), want.float(), rtol=1.6e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize("kv_dtype", F8)
+def test_mla_extend_with_fp8_prefix_rows(ops, device, kv_dtype):
+    """A chunked MLA prefill continues behind cached latent rows (forward_absorb + extend attention with a prefix):
+    the one-wave-per-(token, head) kernel reads the pool in either storage type."""
+    pre, ext, H = [40, 0, 97], [9, 20, 33], 8
+    B = len(pre)
+    rows8, kv_indptr, idx = _mla_paged(B, pre, kv_dtype, 11)
+    T = sum(ext)
+    g = torch.Generator().manual_seed(T)
+    q = (torch.randn(T, H, 576, generator=g) * 0.3).to(torch.bfloat16)
+    kx = torch.randn(T, 1, 576, generator=g).to(torch.bfloat16)
+    qo = torch.zeros(B + 1, dtype=torch.int32)
+    qo[1:] = torch.cumsum(torch.tensor(ext), 0)
+    o = torch.empty(T, H, 512, dtype=torch.bfloat16, device=device)
+    buf, kxd = rows8.to(device), kx.to(device)
+    ops.extend_attention_fwd(q.to(device), kxd, kxd[..., :512], o, buf, buf[..., :512], qo.to(device), kv_indptr.to(device),
+                             idx.to(device), None, None, max(ext), 576 ** -0.5)
+    rows = rows8.to(torch.bfloat16)
+    want = O.extend_attention(q, kx, kx[..., :512], rows, rows[..., :512], qo, kv_indptr, idx, 576 ** -0.5)
+    torch.testing.assert_close(o.cpu().float(), want.float(), rtol=1.6e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize("kv", ["fp8_e5m2", "fp8_e4m3"])
+def test_deepseek_engine_with_fp8_latent_cache(kv):
+    """DeepSeek (MLA) with --kv-cache-dtype fp8_*: unified, chunked prefill (prefix rows are fp8) and Semi-PD against
+    the oracle whose cache rounds the latent rows the same way."""
+    from oracle.model import OracleDeepseekV2
+    from semi_pd_amd.entrypoints.engine import Engine
+    from semi_pd_amd.managers.io_struct import SamplingParams
+    from test_gpu_deepseek import tiny_deepseek
+    from test_gpu_engine import check_against_oracle, make_prompts, server_args
+    cfg = tiny_deepseek()
+    kvd = torch.float8_e5m2 if kv == "fp8_e5m2" else torch.float8_e4m3fn
+    prompts = make_prompts(cfg.vocab_size, [5, 150, 64, 1, 90, 33], seed=5)
+    sp = SamplingParams(max_new_tokens=8, ignore_eos=True)
+    eng = Engine(server_args(cfg, kv_cache_dtype=kv))
+    try:
+        sd = {k: v.float().cpu() for k, v in eng.model_runner.model.state_dict().items()}
+        assert eng.model_runner.token_to_kv_pool.kv_buffer[0].dtype == kvd
+        outs = eng.generate(prompts, sp)
+    finally:
+        eng.shutdown()
+    oracle = OracleDeepseekV2(cfg, sd, kv_cache_dtype=kvd)
+    margin = 8e-2  # e5m2 keeps 2 mantissa bits of every cached latent value
+    assert check_against_oracle(oracle, prompts, outs, margin=margin) > 0.7
+    semi = Engine(server_args(cfg, kv_cache_dtype=kv, enable_semi_pd=True, prefill_cu_percent=50, decode_cu_percent=50,
+                              chunked_prefill_size=64))
+    try:
+        got = semi.generate(prompts, sp, timeout=300)
+    finally:
+        semi.shutdown()
+    # chunks of 64: later chunks of the long prompts read fp8 prefix rows, which the one-piece oracle prefill does
+    # not; the margin covers it
+    check_against_oracle(oracle, prompts, got, margin=0.15)

@@ -85,12 +85,13 @@ def bench_decode_small():
 
 
 def bench_mla():
-    print("# MLA decode attention (latent 576/512): B, ctx, H, splits -> us, GB/s, frac of 8 TB/s")
+    kvd = {"": torch.bfloat16, "fp8_e5m2": torch.float8_e5m2, "fp8_e4m3": torch.float8_e4m3fn}[os.environ.get("KBENCH_KV", "")]
+    print(f"# MLA decode attention (latent 576/512, rows stored as {kvd}): B, ctx, H, splits -> us, GB/s, frac of 8 TB/s")
     for H in (16, 128):
         for B in (1, 32, 128):
             for ctx in (1024, 8192):
                 N = B * ctx + 1
-                kv = torch.randn(N, 1, 576, device=dev, dtype=torch.bfloat16)
+                kv = torch.randn(N, 1, 576, device=dev, dtype=torch.bfloat16).to(kvd)
                 q = torch.randn(B, H, 576, device=dev, dtype=torch.bfloat16)
                 o = torch.empty(B, H, 512, device=dev, dtype=torch.bfloat16)
                 indptr = (torch.arange(B + 1, device=dev, dtype=torch.int32) * ctx)
@@ -104,7 +105,7 @@ def bench_mla():
                     if best is None or t < best[0]:
                         best = (t, splits)
                 t, splits = best
-                nbytes = B * ctx * 576 * 2 + B * H * (576 + 512) * 2
+                nbytes = B * ctx * 576 * kvd.itemsize + B * H * (576 + 512) * 2
                 print(f"mla B={B:4d} ctx={ctx:5d} H={H:3d} splits={splits:2d}: {t * 1e6:8.1f} us "
                       f"{nbytes / t / 1e9:7.0f} GB/s  {nbytes / t / 1e9 / HBM:.3f}")
 
