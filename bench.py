@@ -193,19 +193,26 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--fixed-load", action="store_true", help="N > 1: do not scale requests / rate with N")
+    ap.add_argument("--fixed-load", action="store_true", help="--tp with N > 1: do not scale requests / rate with N")
+    ap.add_argument("--tp", action="store_true",
+                    help="N > 1: ONE engine, tensor parallel over the N GPUs (models that need it, e.g. 70B TP=8), "
+                         "instead of N independent replicas")
     ap.add_argument("--rate-sweep", default="", help="comma-separated Poisson rates; one extra (untimed for "
                     "`value`) wave per rate after the timed steps, reported under qps_sweep (BASELINE config 2)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("SEMIPD_BENCH_ALL_ON_GPU0") == "1":
+        local_rank = 0  # functional check of the N > 1 code path on a one-GPU box (replicas share the GPU)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    # N > 1 = tensor parallel over N GPUs serving N times the offered load: the request
-    # count and the Poisson rate are per GPU ("scaling": "weak"); a fixed offered load would cap the
-    # output rate by construction.  --fixed-load keeps the N = 1 load (strong scaling of latency).
-    if world > 1 and not args.fixed_load:
+    # N > 1, default: N independent Semi-PD replicas, one per GPU, each serving the N = 1 workload with its own
+    # requests (serving requests are independent units: no data-path collective, "scaling": "weak").  --tp: one
+    # engine, tensor parallel over the N GPUs, serving N times the offered load unless --fixed-load.
+    tp_world = world if args.tp else 1
+    replica = rank if (world > 1 and not args.tp) else 0
+    if world > 1 and args.tp and not args.fixed_load:
         args.num_requests *= world
         args.request_rate *= world
         args.max_running_requests *= world
@@ -234,32 +241,36 @@ def main():
                                                             "activation_scheme": "dynamic"}, **extra)
     ctx = args.context_length or (args.input_len + args.output_len + 8)
     port_base = int(os.environ.get("MASTER_PORT", "29500")) + 100
-    sa = ServerArgs(model_config=cfg, context_length=ctx, tp_size=world, enable_semi_pd=(args.mode == "semi-pd"),
+    sa = ServerArgs(model_config=cfg, context_length=ctx, tp_size=tp_world, enable_semi_pd=(args.mode == "semi-pd"),
                     max_running_requests=args.max_running_requests, mem_fraction_static=args.mem_fraction_static,
                     max_total_tokens=args.max_total_tokens, prefill_cu_percent=args.prefill_cu,
                     decode_cu_percent=args.decode_cu, cu_mask_mode=args.cu_mask_mode,
                     disable_cuda_graph=args.disable_cuda_graph, nccl_port_base=port_base,
-                    kv_cache_dtype=args.kv_cache_dtype, cuda_graph_max_bs=min(1024, 256 * world),
+                    kv_cache_dtype=args.kv_cache_dtype, cuda_graph_max_bs=min(1024, 256 * tp_world),
                     collect_kernel_timing=not args.no_kernel_timing, random_seed=args.seed,
                     dist_init_addr=os.environ.get("MASTER_ADDR", "127.0.0.1"), watchdog_timeout=600.0)
-    if args.mode == "unified" and world > 1:
+    if args.mode == "unified" and tp_world > 1:
         raise SystemExit("unified mode is single-GPU only in this round")
-    engine = Engine(sa, local_tp_ranks=[rank], gpu_ids={rank: local_rank})
-    prompts = make_requests(args.num_requests, args.input_len, cfg.vocab_size, args.seed)
-    arrivals = arrival_times(args.num_requests, args.request_rate, args.seed)
+    if args.tp:
+        engine = Engine(sa, local_tp_ranks=[rank], gpu_ids={rank: local_rank})
+    else:
+        engine = Engine(sa, gpu_ids={0: local_rank})
+    driver = rank == 0 or not args.tp      # who sends requests: rank 0 of a TP engine, every replica otherwise
+    prompts = make_requests(args.num_requests, args.input_len, cfg.vocab_size, args.seed + 1000 * replica)
+    arrivals = arrival_times(args.num_requests, args.request_rate, args.seed + 1000 * replica)
 
     try:
         for _ in range(args.warmup):
             barrier()
-            if rank == 0:
+            if driver:
                 run_wave(engine, prompts, arrivals, args.output_len)
-        if rank == 0 and not args.no_kernel_timing:
+        if driver and not args.no_kernel_timing:
             engine.get_stats(reset=True)
         barrier()
         t0 = time.time()
         all_records, wave_summaries = [], []
         for _ in range(args.steps):
-            if rank == 0:
+            if driver:
                 recs, dur = run_wave(engine, prompts, arrivals, args.output_len)
                 all_records.extend(recs)
                 wave_summaries.append(summarize(recs, dur))
@@ -269,11 +280,17 @@ def main():
             t = torch.tensor([elapsed], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
+        if world > 1 and not args.tp:
+            # replicas: rank 0 reports over the requests of all of them (token count, latency percentiles)
+            gathered = [None] * world if rank == 0 else None
+            dist.gather_object(all_records, gathered, dst=0)
+            if rank == 0:
+                all_records = [r for part in gathered for r in part]
         stats = engine.get_stats() if (rank == 0 and not args.no_kernel_timing) else []
         sweep = []
         for rate in [float(x) for x in args.rate_sweep.split(",") if x]:
             barrier()
-            if rank == 0:
+            if driver:
                 recs, dur = run_wave(engine, prompts, arrival_times(args.num_requests, rate, args.seed), args.output_len)
                 sm = summarize(recs, dur)
                 sweep.append({"request_rate": rate, **{k: (round(v, 2) if isinstance(v, float) else v)
@@ -333,15 +350,19 @@ def main():
         "metric": "output tokens/s (Semi-PD mode; with p50 TTFT / TBT)" if args.mode == "semi-pd" else "output tokens/s (unified engine)",
         "value": round(summ["output_tok_s"], 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / max(args.steps, 1), 2),
-        "higher_is_better": True, "scaling": ("strong" if args.fixed_load else "weak"), "vs_baseline": None, "dtype": ("fp8_e4m3fn" if args.quantization else "bf16"), "data": "synthetic",
+        "higher_is_better": True, "scaling": ("strong" if (args.fixed_load and args.tp) else "weak"), "vs_baseline": None, "dtype": ("fp8_e4m3fn" if args.quantization else "bf16"), "data": "synthetic",
         "p50_ttft_ms": summ["p50_ttft_ms"], "p50_tbt_ms": summ["p50_tbt_ms"],
         "p99_ttft_ms": summ["p99_ttft_ms"], "p99_tbt_ms": summ["p99_tbt_ms"],
-        "config": {"workload": f"{args.model} {'block-fp8 (e4m3fn 128x128) linears + experts' if args.quantization else 'bf16'} TP={world} {args.mode}, CU split P{args.prefill_cu}/D{args.decode_cu} "
+        "config": {"workload": f"{args.model} {'block-fp8 (e4m3fn 128x128) linears + experts' if args.quantization else 'bf16'} TP={tp_world} {args.mode}"
+                               + (f" x {world} independent replicas (one per GPU, each with its own {args.num_requests} requests)"
+                                  if (world > 1 and not args.tp) else "") + f", CU split P{args.prefill_cu}/D{args.decode_cu} "
                                f"({args.cu_mask_mode}), {args.num_requests} synthetic requests in={args.input_len} "
                                f"out={args.output_len}, Poisson {args.request_rate} req/s, dummy weights"
                                + ("" if args.kv_cache_dtype == "auto" else f", KV cache {args.kv_cache_dtype}"),
                    "num_requests": args.num_requests, "input_len": args.input_len, "output_len": args.output_len,
-                   "request_rate": args.request_rate, "parallelism": f"tp{world}", "mode": args.mode,
+                   "request_rate": args.request_rate,
+                   "parallelism": (f"tp{world}" if (args.tp or world == 1) else f"dp{world} (replicas, tp1 each)"),
+                   "mode": args.mode,
                    "kv_cache_dtype": args.kv_cache_dtype},
         "roofline": roofline, "roofline_extra": extra, "cpu_baseline": cpu,
     }
