@@ -341,7 +341,7 @@ def main():
                                          "frac": round(k["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4),
                                          "avg_launch_us": round(k["avg_us"], 1), "launches_sampled": k["launches"]}
     cpu = None
-    if not args.no_cpu_baseline and cfg.architectures[0] == "LlamaForCausalLM":
+    if not args.no_cpu_baseline and world == 1 and cfg.architectures[0] == "LlamaForCausalLM":
         try:
             cpu = cpu_baseline(cfg, args.input_len, args.output_len)
         except Exception as e:  # the baseline must never take the measured number down with it
