@@ -1,5 +1,5 @@
 """One fixed launch shape of the dominant kernels, for rocprofv3 --pmc passes (HBM traffic check).
-Usage: python tools/pmc_target.py [decode|mla|extend]"""
+Usage: python tools/pmc_target.py [decode|mla|fp8mm]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "semi-pd_amd")]
@@ -32,4 +32,16 @@ elif which == "mla":
     for _ in range(5):
         ops.decode_attention_fwd(q, kv, kv[..., :512], o, indptr, idx, lg, splits, 0.1)
     print("algorithmic_bytes_per_launch", B * ctx * 576 * 2 + B * H * (576 + 512) * 2)
+elif which == "fp8mm":
+    # decode-sized block-fp8 linear on a DeepSeek-V3 shape: the fp8 weights (176 MB) are read once
+    M, N, K = 32, 24576, 7168
+    wq = (torch.randn(N, K, device=dev) * 100).clamp(-448, 448).to(torch.float8_e4m3fn)
+    ws = torch.rand(N // 128, K // 128, device=dev) * 1e-2
+    x = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
+    xq, xs = ops.per_token_group_quant_fp8(x, 128)
+    junk = torch.empty(1 << 28, device=dev, dtype=torch.uint8)
+    for _ in range(5):
+        junk.fill_(1)  # 256 MB: evicts the weights from the Infinity Cache between launches
+        ops.w8a8_block_fp8_matmul(xq, wq, xs, ws, [128, 128], torch.bfloat16)
+    print("algorithmic_bytes_per_launch", N * K + ws.numel() * 4 + M * K + xs.numel() * 4 + M * N * 2)
 torch.cuda.synchronize()
