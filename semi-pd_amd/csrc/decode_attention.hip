@@ -38,10 +38,10 @@ __device__ inline float safe_exp_diff(float a, float b) {
   return (a == -INFINITY) ? (b == -INFINITY ? 1.f : 0.f) : __expf(a - b);
 }
 
-template <typename T, int LPR, int G, int U>
+template <typename T, int LPR, int G, int U, typename KV = T>
 __global__ void __launch_bounds__(256)
-decode_stage1_kernel(T* __restrict__ out, const T* __restrict__ q, const T* __restrict__ k_buf,
-                     const T* __restrict__ v_buf, const int32_t* __restrict__ kv_indptr,
+decode_stage1_kernel(T* __restrict__ out, const T* __restrict__ q, const KV* __restrict__ k_buf,
+                     const KV* __restrict__ v_buf, const int32_t* __restrict__ kv_indptr,
                      const int32_t* __restrict__ kv_indices, float* __restrict__ attn_logits,
                      int num_q_heads, int num_kv_heads, int group, int tiles_per_kv, int D,
                      int64_t q_stride, int64_t o_stride, int64_t kbuf_stride, int64_t vbuf_stride,
@@ -109,14 +109,25 @@ decode_stage1_kernel(T* __restrict__ out, const T* __restrict__ q, const T* __re
       tok[u] = row0 + (it * U + u) * STEP;
       idx[u] = tok[u] < s_end ? idx_base[tok[u]] : 0;
     }
-    Vec16<T> kr[U], vr[U];
+    // pool rows in their storage type (fp8: 8 bytes per 8 elements in flight), expanded right before use
+    using KVT = KVTraits<T, KV>;
+    typename KVT::Raw kraw[U], vraw[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      if (act) kr[u] = load16(k_buf + (int64_t)idx[u] * kbuf_stride + head_off);
+      kraw[u] = KVT::zero();
+      if (act) kraw[u] = KVT::load8(k_buf + (int64_t)idx[u] * kbuf_stride + head_off);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      if (act) vr[u] = load16(v_buf + (int64_t)idx[u] * vbuf_stride + head_off);
+      vraw[u] = KVT::zero();
+      if (act) vraw[u] = KVT::load8(v_buf + (int64_t)idx[u] * vbuf_stride + head_off);
+    }
+    Vec16<T> kr[U], vr[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint4 ke = KVT::expand(kraw[u]), ve = KVT::expand(vraw[u]);
+      kr[u] = *reinterpret_cast<const Vec16<T>*>(&ke);
+      vr[u] = *reinterpret_cast<const Vec16<T>*>(&ve);
     }
     float s[U][G];
 #pragma unroll
@@ -323,8 +334,8 @@ __global__ void decode_stage2_kernel(T* __restrict__ out, const float* __restric
   }
 }
 
-template <typename T, int LPR>
-static int launch_stage1(T* out, const T* q, const T* k_buf, const T* v_buf, const int32_t* kv_indptr,
+template <typename T, int LPR, typename KV = T>
+static int launch_stage1(T* out, const T* q, const KV* k_buf, const KV* v_buf, const int32_t* kv_indptr,
                          const int32_t* kv_indices, float* attn_logits, int64_t batch, int Hq, int Hkv,
                          int D, int64_t q_stride, int64_t o_stride, int64_t kbuf_stride,
                          int64_t vbuf_stride, int splits, float sm_scale, float logit_cap,
@@ -336,7 +347,7 @@ static int launch_stage1(T* out, const T* q, const T* k_buf, const T* v_buf, con
   dim3 grid((unsigned)batch, (unsigned)(Hkv * tiles), (unsigned)splits), block(256);
   const size_t lds = (size_t)4 * G * (D + 2) * sizeof(float);
 #define S1(GG, UU)                                                                              \
-  hipLaunchKernelGGL((decode_stage1_kernel<T, LPR, GG, UU>), grid, block, lds, st, out, q, k_buf, \
+  hipLaunchKernelGGL((decode_stage1_kernel<T, LPR, GG, UU, KV>), grid, block, lds, st, out, q, k_buf, \
                      v_buf, kv_indptr, kv_indices, attn_logits, Hq, Hkv, group, tiles, D, q_stride, \
                      o_stride, kbuf_stride, vbuf_stride, splits, sm_scale, logit_cap)
   switch (G) {
@@ -382,14 +393,30 @@ static int run_decode(void* out, const void* q, const void* k_buf, const void* v
                    kbuf_stride == vbuf_stride && kbuf_stride % 8 == 0 && q_stride % 8 == 0 && aligned16(q) &&
                    aligned16(k_buf) && o_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 7u) == 0;
   if (kv_f8) {
-    // fp8 pool rows (mem_cache/memory_pool.py:205-209): the GQA / MQA matrix-core kernel expands them
-    // on the way from HBM to the MFMA operands; the other kernels only read rows of the activation type
+    // fp8 pool rows (mem_cache/memory_pool.py:205-209): every vectorised kernel keeps 8-byte fragments in flight
+    // and expands them right before use; only the scalar fallback (ragged head sizes) reads activation-type rows
     SEMIPD_CHECK_ARG(kv_dtype == SEMIPD_F8E5M2 || kv_dtype == SEMIPD_F8E4M3, SEMIPD_EDTYPE,
                      "decode_attention: unsupported kv_dtype %d", kv_dtype);
-    SEMIPD_CHECK_ARG(mfma || mla, SEMIPD_ESHAPE,
-                     "decode_attention: fp8 KV rows need the GQA / MQA kernel (group >= 2, head dim 64 / 96 / 128) or "
-                     "the MLA kernel");
-    if (mla && kv_dtype == SEMIPD_F8E5M2)
+    SEMIPD_CHECK_ARG(mfma || mla || fast, SEMIPD_ESHAPE,
+                     "decode_attention: fp8 KV rows need 8-element aligned heads of equal K / V width (or MLA rows)");
+    if (!mfma && !mla) {
+      // MHA (one query head per kv head) and head sizes without an MFMA instantiation
+      const int D = head_dim_k;
+#define S1F8(LPRV, KVT_)                                                                                           \
+  rc = launch_stage1<T, LPRV, KVT_>((T*)out, (const T*)q, (const KVT_*)k_buf, (const KVT_*)v_buf, kv_indptr,        \
+                                    kv_indices, attn_logits, batch, num_q_heads, num_kv_heads, D, q_stride, o_stride, \
+                                    kbuf_stride, vbuf_stride, num_kv_splits, sm_scale, logit_cap, st)
+      if (kv_dtype == SEMIPD_F8E5M2) {
+        if (D <= 64) S1F8(8, f8e5m2_t);
+        else if (D <= 128) S1F8(16, f8e5m2_t);
+        else S1F8(32, f8e5m2_t);
+      } else {
+        if (D <= 64) S1F8(8, f8e4m3_t);
+        else if (D <= 128) S1F8(16, f8e4m3_t);
+        else S1F8(32, f8e4m3_t);
+      }
+#undef S1F8
+    } else if (mla && kv_dtype == SEMIPD_F8E5M2)
       rc = launch_mla_decode<T, f8e5m2_t>((T*)out, (const T*)q, (const f8e5m2_t*)k_buf, kv_indptr, kv_indices, attn_logits,
                                           batch, num_q_heads, q_stride, o_stride, kbuf_stride, num_kv_splits, sm_scale,
                                           logit_cap, st);

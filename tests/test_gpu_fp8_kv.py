@@ -74,7 +74,11 @@ def _paged(B, lens, Hkv, D, kv_dtype, seed):
 
 @pytest.mark.parametrize("kv_dtype", F8)
 @pytest.mark.parametrize("B,lens,Hq,Hkv,D,splits", [(3, [70, 1, 257], 32, 8, 128, 4), (2, [33, 500], 8, 1, 64, 8),
-                                                     (1, [129], 12, 4, 96, 1)])
+                                                     (1, [129], 12, 4, 96, 1),
+                                                     # MHA (one query head per kv head: OPT, Llama-2-7B) and a head
+                                                     # size without an MFMA instantiation: the shuffle kernel
+                                                     (2, [33, 200], 4, 4, 64, 2), (1, [129], 12, 12, 128, 1),
+                                                     (2, [70, 300], 8, 2, 80, 4), (1, [65], 2, 2, 256, 1)])
 def test_decode_attention_fp8_pool(ops, device, kv_dtype, B, lens, Hq, Hkv, D, splits):
     k8, v8, indptr, idx = _paged(B, lens, Hkv, D, kv_dtype, B + D)
     q = torch.randn(B, Hq, D).to(torch.bfloat16)
@@ -106,9 +110,9 @@ def test_extend_attention_fp8_prefix(ops, device, kv_dtype, pre, ext, Hq, Hkv, D
 
 
 def test_unsupported_fp8_paths_fail_loudly(ops, device):
-    """MHA pools with one query head per kv head (group = 1) have no fp8 decode kernel."""
-    k8 = torch.zeros(10, 4, 128, dtype=torch.float8_e5m2, device=device)
-    q = torch.zeros(1, 4, 128, dtype=torch.bfloat16, device=device)     # group == 1: not the MFMA kernel
+    """Head sizes that are not a multiple of 8 only have the scalar kernel, which reads activation-type rows."""
+    k8 = torch.zeros(10, 4, 20, dtype=torch.float8_e5m2, device=device)
+    q = torch.zeros(1, 4, 20, dtype=torch.bfloat16, device=device)
     o = torch.empty_like(q)
     indptr = torch.tensor([0, 3], dtype=torch.int32, device=device)
     idx = torch.tensor([1, 2, 3], dtype=torch.int32, device=device)
