@@ -76,6 +76,11 @@ class GetNextPrefillBatchOutput:
     req_pool_indices: List[int]
     prefix_lens: List[int]
     extend_input_lens: List[int]
+    # KV slots of the tokens to prefill, per request.  The reference has P read them from the shared req_to_token
+    # table, which needs the table writes to be complete in HBM first (a GPU synchronisation on the decode side, one
+    # whole decode step long when the loop is overlapped); the decode instance knows them on the host, so they
+    # travel with the reply and the table is only needed for prefix tokens (chunked prefill, re-sent requests).
+    extend_slots: Optional[List[List[int]]] = None
 
 
 @dataclass

@@ -37,6 +37,9 @@ class Req:
         self.eos_token_ids = eos_token_ids or set()
         self.req_pool_idx: Optional[int] = None
         self.prefix_indices = torch.empty(0, dtype=torch.int64)
+        # host mirror of this request's row of req_to_token, kept by the side that allocates (the decode instance,
+        # or the unified scheduler): frees never read the device table
+        self.kv_slots: List[int] = []
         self.extend_input_len = 0
         self.is_chunked = 0
         self.is_retracted = is_retracted
@@ -71,6 +74,7 @@ class Req:
 
     def reset_for_retract(self):
         self.prefix_indices = torch.empty(0, dtype=torch.int64)
+        self.kv_slots = []
         self.extend_input_len = 0
         self.is_retracted = True
         self.req_pool_idx = None
@@ -86,10 +90,12 @@ class ChunkCache:
         self.token_to_kv_pool_allocator = token_to_kv_pool_allocator
 
     def cache_finished_req(self, req: Req):
+        # KV exists for every token but the last sampled one; a slot taken for a step that runs beyond the end of
+        # the request (overlapped decode loop) stays in req.kv_slots and is released when that step is processed
         n = len(req.origin_input_ids) + len(req.output_ids) - 1
-        kv_indices = self.req_to_token_pool.req_to_token[req.req_pool_idx, :n]
         self.req_to_token_pool.free(req.req_pool_idx)
-        self.token_to_kv_pool_allocator.free(kv_indices)
+        self.token_to_kv_pool_allocator.free(req.kv_slots[:n])
+        req.kv_slots = req.kv_slots[n:]
 
     def cache_unfinished_req(self, req: Req):
         kv_indices = self.req_to_token_pool.req_to_token[req.req_pool_idx, : len(req.fill_ids)]
@@ -115,6 +121,16 @@ class ModelWorkerBatch:
     top_logprobs_nums: Optional[List[int]] = None
 
 
+def host_list_to_device(values, dtype, device) -> torch.Tensor:
+    """A small host list as a device tensor WITHOUT synchronising the stream: a copy from pageable memory waits
+    for everything queued before it (a whole decode step in the overlapped loop); staging through pinned memory
+    (cached by torch's host allocator, which releases a block only after the copy has run) does not."""
+    t = torch.tensor(values, dtype=dtype)
+    if torch.device(device).type != "cuda":
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
+
+
 class ScheduleBatch:
     def __init__(self, reqs: List[Req], req_to_token_pool, token_to_kv_pool_allocator, tree_cache, device):
         self.reqs = reqs
@@ -127,6 +143,7 @@ class ScheduleBatch:
         self.input_ids = self.req_pool_indices = self.seq_lens = self.out_cache_loc = None
         self.output_ids: Optional[torch.Tensor] = None
         self.seq_lens_sum = 0
+        self.seq_lens_cpu: List[int] = []  # host mirror of seq_lens: bookkeeping without device round trips
         self.prefix_lens = self.extend_lens = None
         self.extend_num_tokens = 0
         self.decoding_reqs = None
@@ -156,7 +173,8 @@ class ScheduleBatch:
         return out
 
     # ---------------------------------------------------------------------------- extend
-    def prepare_for_extend(self, pre_allocated_req_pool_indices: Optional[List[int]] = None):
+    def prepare_for_extend(self, pre_allocated_req_pool_indices: Optional[List[int]] = None,
+                           pre_allocated_slots: Optional[List[List[int]]] = None):
         self.forward_mode = ForwardMode.EXTEND
         bs = len(self.reqs)
         if pre_allocated_req_pool_indices is None:
@@ -171,28 +189,38 @@ class ScheduleBatch:
         prefix_lens = [len(r.prefix_indices) for r in reqs]
         extend_lens = [r.extend_input_len for r in reqs]
         dev = self.device
-        self.req_pool_indices = torch.tensor(req_pool_indices, dtype=torch.int64, device=dev)
-        self.input_ids = torch.tensor(sum(input_ids, []), dtype=torch.int64, device=dev)
-        self.seq_lens = torch.tensor(seq_lens, dtype=torch.int64, device=dev)
+        # (pinned staging: a pageable host -> device copy would wait for everything queued on the stream)
+        self.req_pool_indices = host_list_to_device(req_pool_indices, torch.int64, dev)
+        self.input_ids = host_list_to_device(sum(input_ids, []), torch.int64, dev)
+        self.seq_lens = host_list_to_device(seq_lens, torch.int64, dev)
         table = self.req_to_token_pool.req_to_token
         for r, idx in zip(reqs, req_pool_indices):
             r.req_pool_idx = idx
         if pre_allocated_req_pool_indices is None:
             # decode instance: the only allocator.  Writes the *shared* table.
-            out_cache_loc = self.alloc_token_slots(extend_num_tokens).to(dev)
+            out_cpu = self.alloc_token_slots(extend_num_tokens)
+            out_list = out_cpu.tolist()
+            out_cache_loc = host_list_to_device(out_list, torch.int64, dev)
             pt = 0
             loc32 = out_cache_loc.to(torch.int32)
             for i, r in enumerate(reqs):
+                r.kv_slots = r.kv_slots[: prefix_lens[i]] + out_list[pt: pt + extend_lens[i]]
                 if prefix_lens[i]:
                     table[req_pool_indices[i], : prefix_lens[i]] = r.prefix_indices.to(dev, torch.int32)
                 table[req_pool_indices[i], prefix_lens[i]: seq_lens[i]] = loc32[pt: pt + extend_lens[i]]
                 pt += extend_lens[i]
         else:
-            # prefill instance: read the slots the decode instance allocated (schedule_batch.py:923-937)
-            parts = [table[idx, pre:seq] for idx, pre, seq in zip(req_pool_indices, prefix_lens, seq_lens)]
-            out_cache_loc = torch.cat(parts).to(dev, dtype=torch.int64)
+            # prefill instance: the slots the decode instance allocated — from its reply when it carries them, else
+            # from the shared table (schedule_batch.py:923-937)
+            if pre_allocated_slots is not None:
+                assert [len(x) for x in pre_allocated_slots] == extend_lens
+                out_cache_loc = host_list_to_device(sum(pre_allocated_slots, []), torch.int64, dev)
+            else:
+                parts = [table[idx, pre:seq] for idx, pre, seq in zip(req_pool_indices, prefix_lens, seq_lens)]
+                out_cache_loc = torch.cat(parts).to(dev, dtype=torch.int64)
         self.out_cache_loc = out_cache_loc
         self.seq_lens_sum = sum(seq_lens)
+        self.seq_lens_cpu = list(seq_lens)
         self.extend_num_tokens = extend_num_tokens
         self.prefix_lens = prefix_lens
         self.extend_lens = extend_lens
@@ -214,8 +242,7 @@ class ScheduleBatch:
             req = self.reqs[i]
             retracted.append(req)
             n = len(req.origin_input_ids) + len(req.output_ids) - 1
-            kv = self.req_to_token_pool.req_to_token[req.req_pool_idx, :n]
-            self.token_to_kv_pool_allocator.free(kv)
+            self.token_to_kv_pool_allocator.free(req.kv_slots[:n])
             self.req_to_token_pool.free(req.req_pool_idx)
             req.reset_for_retract()
         self.filter_batch(keep_indices=sorted(order))
@@ -229,11 +256,15 @@ class ScheduleBatch:
         bs = len(self.reqs)
         self.input_ids = self.output_ids.to(torch.int64)
         self.output_ids = None
-        self.out_cache_loc = self.alloc_token_slots(bs).to(self.device)
+        new_slots = self.alloc_token_slots(bs).tolist()
+        for r, slot in zip(self.reqs, new_slots):
+            r.kv_slots.append(slot)
+        self.out_cache_loc = host_list_to_device(new_slots, torch.int64, self.device)
         # req_to_token[req, seq_len] = new slot; then seq_len += 1 (schedule_batch.py:1190-1205)
         self.req_to_token_pool.req_to_token[self.req_pool_indices, self.seq_lens] = self.out_cache_loc.to(torch.int32)
         self.seq_lens = self.seq_lens + 1
         self.seq_lens_sum += bs
+        self.seq_lens_cpu = [x + 1 for x in self.seq_lens_cpu]
 
     # ---------------------------------------------------------------------------- bookkeeping
     def filter_batch(self, chunked_req_to_exclude: Optional[Req] = None, keep_indices: Optional[List[int]] = None):
@@ -244,13 +275,15 @@ class ScheduleBatch:
             return
         if not keep_indices:
             self.reqs = []
+            self.seq_lens_cpu = []
             return
         self.reqs = [self.reqs[i] for i in keep_indices]
-        idx = torch.tensor(keep_indices, dtype=torch.int64, device=self.device)
+        idx = host_list_to_device(keep_indices, torch.int64, self.device)
         self.req_pool_indices = self.req_pool_indices[idx]
         self.seq_lens = self.seq_lens[idx]
         self.out_cache_loc = None
-        self.seq_lens_sum = int(self.seq_lens.sum().item())
+        self.seq_lens_cpu = [self.seq_lens_cpu[i] for i in keep_indices]
+        self.seq_lens_sum = sum(self.seq_lens_cpu)  # (no .item(): the decode loop must not wait for the GPU here)
         if self.output_ids is not None:
             self.output_ids = self.output_ids[idx]
 
@@ -259,6 +292,7 @@ class ScheduleBatch:
         self.seq_lens = torch.concat([self.seq_lens, other.seq_lens])
         self.out_cache_loc = None
         self.seq_lens_sum += other.seq_lens_sum
+        self.seq_lens_cpu = self.seq_lens_cpu + other.seq_lens_cpu
         if self.output_ids is not None and other.output_ids is not None:
             self.output_ids = torch.concat([self.output_ids.to(torch.int64), other.output_ids.to(torch.int64)])
         self.reqs.extend(other.reqs)

@@ -15,7 +15,7 @@ import torch
 from semi_pd_amd.distributed import barrier_cpu
 from semi_pd_amd.managers.io_struct import (BatchProcessPrefillResultReq, GetNextPrefillBatchInput,
                                             GetNextPrefillBatchOutput, TokenizedGenerateReqInput)
-from semi_pd_amd.managers.schedule_batch import AddReqResult, Req, ScheduleBatch
+from semi_pd_amd.managers.schedule_batch import AddReqResult, Req, ScheduleBatch, host_list_to_device
 from semi_pd_amd.managers.scheduler import SchedulerBase
 from semi_pd_amd.semi_pd.utils import InstanceRole
 
@@ -31,6 +31,14 @@ class SemiPDDecodeScheduler(SchedulerBase):
         # requests handed to the prefill instance whose result has not come back yet
         self.scheduled_prefill_batches: List[ScheduleBatch] = []
         self.defer_decode_stream = True               # see step(): outputs go out behind the next launch
+        # overlap schedule (managers/tp_worker_overlap_thread.py, scheduler.py event_loop_overlap; on unless
+        # --disable-overlap-schedule): step k + 1 is launched before the tokens of step k are looked at
+        self.enable_overlap = not getattr(server_args, "disable_overlap_schedule", False) \
+            and torch.device(self.device).type == "cuda"
+        self._pending = None                          # (reqs, out_cache_loc, pinned ids, event, logits_output) of step k
+        self._pinned_ids = None
+        self._pinned_flip = 0
+
         self.bridge_socket = bridge_socket            # PUSH -> P (replies to GetNextPrefillBatchInput)
         self.send_to_p_instance = send_to_p_instance  # PUSH -> P's input socket (retracted requests)
 
@@ -123,27 +131,35 @@ class SemiPDDecodeScheduler(SchedulerBase):
 
     def get_next_prefill_batch(self, recv_req: GetNextPrefillBatchInput):
         """semi_pd_decode_scheduler.py:310-337."""
-        if self.chunked_req:
-            if self.scheduled_prefill_batches:
-                # the previous chunk is still running in P: answer "nothing yet"
-                self._reply_empty()
-                return
-            self.tree_cache.cache_unfinished_req(self.chunked_req)
-            self.req_to_token_pool.free(self.chunked_req.req_pool_idx)
-        batch = self.get_new_batch_prefill(recv_req.rids)
+        if self.chunked_req and self.scheduled_prefill_batches:
+            # the previous chunk is still running in P: answer "nothing yet"
+            self._reply_empty()
+            return
+        batch = self._admit(recv_req)
         if batch is None:
             self._reply_empty()
             return
-        # the shared table must be complete in HBM before P reads it (the reference relies on timing)
-        if torch.device(self.device).type == "cuda":
+        prefix_lens = [len(r.prefix_indices) for r in batch.reqs]
+        # P reads the shared table only for PREFIX tokens (a later chunk of a long prompt, a re-sent request): only
+        # then must the table be complete in HBM before the reply (the reference relies on timing).  The slots of
+        # the tokens to prefill go with the reply, so the common admission needs no GPU synchronisation at all —
+        # which, with a decode step always in flight (overlapped loop), would cost a whole step.
+        if any(prefix_lens) and torch.device(self.device).type == "cuda":
             torch.cuda.current_stream().synchronize()
         if self.tp_rank == 0:
             self.bridge_socket.send_pyobj(GetNextPrefillBatchOutput(
                 rids=[r.rid for r in batch.reqs],
                 chunked_rid=(self.chunked_req.rid if self.chunked_req else None),
                 req_pool_indices=[r.req_pool_idx for r in batch.reqs],
-                prefix_lens=[len(r.prefix_indices) for r in batch.reqs],
-                extend_input_lens=[r.extend_input_len for r in batch.reqs]))
+                prefix_lens=prefix_lens,
+                extend_input_lens=[r.extend_input_len for r in batch.reqs],
+                extend_slots=[r.kv_slots[p: p + r.extend_input_len] for r, p in zip(batch.reqs, prefix_lens)]))
+
+    def _admit(self, recv_req: GetNextPrefillBatchInput) -> Optional[ScheduleBatch]:
+        if self.chunked_req:
+            self.tree_cache.cache_unfinished_req(self.chunked_req)
+            self.req_to_token_pool.free(self.chunked_req.req_pool_idx)
+        return self.get_new_batch_prefill(recv_req.rids)
 
     def _reply_empty(self):
         if self.tp_rank == 0:
@@ -157,7 +173,7 @@ class SemiPDDecodeScheduler(SchedulerBase):
         assert len(batch.reqs) == len(recv_req.next_token_ids)
         if self.tp_size > 1:
             barrier_cpu()
-        batch.output_ids = torch.tensor(recv_req.next_token_ids, dtype=torch.int64, device=self.device)
+        batch.output_ids = host_list_to_device(recv_req.next_token_ids, torch.int64, self.device)
         self.process_batch_result_prefill(batch, recv_req.next_token_ids, recv_req.next_token_logprobs)
         batch.filter_batch(chunked_req_to_exclude=self.chunked_req)
         if not batch.is_empty():
@@ -168,6 +184,8 @@ class SemiPDDecodeScheduler(SchedulerBase):
 
     # ---------------------------------------------------------------------------- loop
     def step(self) -> bool:
+        if self.enable_overlap:
+            return self.step_overlap()
         t0 = time.perf_counter()
         recv = self.recv_requests()
         self.process_input_requests(recv)
@@ -188,6 +206,83 @@ class SemiPDDecodeScheduler(SchedulerBase):
         st["t_forward_s"] = st.get("t_forward_s", 0.0) + (t2 - t1)
         st["t_output_s"] = st.get("t_output_s", 0.0) + (t3 - t2)
         return True
+
+    # ---------------------------------------------------------------------------- overlap schedule
+    def step_overlap(self) -> bool:
+        """One iteration of the overlapped loop (scheduler.py event_loop_overlap, tp_worker_overlap_thread.py
+        :142-235).  The next step's input ids are the previous step's sampled ids ON THE DEVICE, so step k + 1 is
+        scheduled and launched while step k runs; the tokens of step k come to the host through a pinned buffer
+        and an event and are processed (finish checks, KV release, streaming) while step k + 1 runs.  A request
+        that ends at step k is therefore part of step k + 1 once more: that token is dropped and only the KV slot
+        taken for it is released then (scheduler.py:1437-1442 "free the one delayed token")."""
+        t0 = time.perf_counter()
+        recv = self.recv_requests()
+        self.process_input_requests(recv)
+        rb = self.running_batch
+        if self._pending is not None and not rb.is_empty() and \
+                (not rb.check_decode_mem(2) or self.forced_retractions(rb)):
+            # a retraction re-sends origin_input_ids + output_ids: every sampled token must be on the host first
+            self._drain_pending()
+        batch = self.get_next_batch_to_run()
+        if batch is None:
+            had = self._pending is not None
+            self._drain_pending()
+            self.flush_stream_output()
+            return bool(recv) or had
+        t1 = time.perf_counter()
+        logits_output, next_token_ids = self.run_batch(batch)  # asynchronous: one hipGraph launch
+        batch.output_ids = next_token_ids
+        bs = len(batch.reqs)
+        if self._pinned_ids is None or self._pinned_ids[0].numel() < bs:
+            n = max(bs, 2 * self.max_running_requests)
+            self._pinned_ids = [torch.empty(n, dtype=torch.int64, pin_memory=True) for _ in range(2)]
+        self._pinned_flip ^= 1
+        host_ids = self._pinned_ids[self._pinned_flip][:bs]
+        host_ids.copy_(next_token_ids, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        prev, self._pending = self._pending, (list(batch.reqs), batch.out_cache_loc, host_ids, ev, logits_output)
+        t2 = time.perf_counter()
+        if prev is not None:
+            self._process_pending(prev)
+        self.flush_stream_output()
+        t3 = time.perf_counter()
+        st = self.stats
+        st["t_schedule_s"] = st.get("t_schedule_s", 0.0) + (t1 - t0)
+        st["t_forward_s"] = st.get("t_forward_s", 0.0) + (t2 - t1)
+        st["t_output_s"] = st.get("t_output_s", 0.0) + (t3 - t2)
+        return True
+
+    def _drain_pending(self):
+        if self._pending is not None:
+            prev, self._pending = self._pending, None
+            self._process_pending(prev)
+
+    def _process_pending(self, pending):
+        reqs, out_cache_loc, host_ids, ev, logits_output = pending
+        ev.synchronize()                       # step k and its copy are done; step k + 1 keeps the GPU busy
+        ids = host_ids.tolist()
+        logprobs = self.extract_logprobs(logits_output)
+        alloc = self.token_to_kv_pool_allocator
+        alloc.free_group_begin()
+        live = []
+        for i, (req, tok) in enumerate(zip(reqs, ids)):
+            if req.finished():
+                # it ended one step earlier and ran once more: drop the token, release the slot of that step
+                alloc.free(req.kv_slots)
+                req.kv_slots = []
+                continue
+            req.output_ids.append(int(tok))
+            self._record_logprob(req, i, logprobs)
+            req.check_finished()
+            if req.finished():
+                self.tree_cache.cache_finished_req(req)
+            live.append(req)
+        alloc.free_group_end()
+        self.stats["decode_steps"] += 1
+        self.stats["decode_tokens"] += len(live)
+        self.stream_output(live, defer=False)
+        self.last_progress = time.monotonic()
 
     def event_loop_normal(self):
         while not self._shutdown:

@@ -80,7 +80,8 @@ class SemiPDPrefillScheduler(SchedulerBase):
             r.fill_ids = r.origin_input_ids[: pre_len + r.extend_input_len]
         batch = ScheduleBatch.init_new(can_run_list, self.req_to_token_pool, self.token_to_kv_pool_allocator,
                                        self.tree_cache, self.device)
-        batch.prepare_for_extend(pre_allocated_req_pool_indices=resp.req_pool_indices)
+        batch.prepare_for_extend(pre_allocated_req_pool_indices=resp.req_pool_indices,
+                                 pre_allocated_slots=getattr(resp, "extend_slots", None))
         return batch
 
     def _propose(self) -> bool:

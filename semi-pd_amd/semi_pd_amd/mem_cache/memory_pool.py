@@ -98,7 +98,11 @@ class TokenToKVPoolAllocator:
             return torch.empty(0, dtype=torch.int64)
         return parts[0] if len(parts) == 1 else torch.cat(parts)
 
-    def free(self, free_index: torch.Tensor):
+    def free(self, free_index):
+        """free_index: a list of ints or a tensor (a device tensor is copied to the host, which waits for the
+        stream: the schedulers pass host data)."""
+        if not torch.is_tensor(free_index):
+            free_index = torch.tensor(list(free_index), dtype=torch.int64)
         if free_index.numel() == 0:
             return
         free_index = free_index.to("cpu", torch.int64)

@@ -38,6 +38,7 @@ class ServerArgs:
     enable_semi_pd: bool = False
     disable_radix_cache: bool = True
     disable_cuda_graph: bool = False
+    disable_overlap_schedule: bool = False   # server_args.py --disable-overlap-schedule (decode instance of Semi-PD)
     enable_ep_moe: bool = False              # server_args.py --enable-ep-moe: routed experts partitioned by expert over TP
     disable_custom_all_reduce: bool = False  # server_args.py --disable-custom-all-reduce: TP all-reduce through RCCL only
     cuda_graph_max_bs: int = 256
@@ -144,7 +145,9 @@ def add_cli_args(parser):
     p.add_argument("--sampling-backend", type=str, default="hip")
     p.add_argument("--log-level", type=str, default="info")
     # accepted for command-line compatibility; no effect on this path
-    for flag in ("--trust-remote-code", "--disable-radix-cache", "--enable-metrics", "--disable-overlap-schedule",
+    p.add_argument("--disable-overlap-schedule", action="store_true",
+                   help="decode instance: look at the tokens of a step before launching the next one")
+    for flag in ("--trust-remote-code", "--disable-radix-cache", "--enable-metrics",
                  "--enable-mixed-chunk", "--show-time-cost"):
         p.add_argument(flag, action="store_true")
     p.add_argument("--dist-timeout", type=int, default=None)
@@ -166,7 +169,7 @@ def from_cli_args(args) -> ServerArgs:
         base_gpu_id=args.base_gpu_id, random_seed=args.random_seed, watchdog_timeout=args.watchdog_timeout,
         dist_init_addr=args.dist_init_addr, nccl_port_base=args.nccl_port,
         disable_cuda_graph=args.disable_cuda_graph, disable_custom_all_reduce=args.disable_custom_all_reduce,
-        enable_ep_moe=args.enable_ep_moe, cuda_graph_max_bs=args.cuda_graph_max_bs,
+        enable_ep_moe=args.enable_ep_moe, disable_overlap_schedule=args.disable_overlap_schedule, cuda_graph_max_bs=args.cuda_graph_max_bs,
         enable_semi_pd=args.enable_semi_pd, prefill_cu_percent=args.prefill_cu_percent,
         decode_cu_percent=args.decode_cu_percent, attention_backend=args.attention_backend,
         sampling_backend=args.sampling_backend)
