@@ -457,3 +457,40 @@ def test_abort_frees_kv_slots_unified_and_semi_pd(unified_llama):
         run(eng, 2)
     finally:
         eng.shutdown()
+
+
+def test_overlapped_decode_loop_equals_the_plain_loop(unified_llama):
+    """The decode instance launches step k + 1 before it looks at the tokens of step k (on by default,
+    --disable-overlap-schedule turns it off; tp_worker_overlap_thread.py:142-235).  Same tokens either way, requests of
+    different lengths end on their own step (the surplus step of a finished request is dropped), and every KV slot
+    is back in the pool afterwards."""
+    import time
+    from semi_pd_amd.entrypoints.engine import Engine
+    from semi_pd_amd.managers.io_struct import SamplingParams
+    cfg, sd, prompts, outs, _ = unified_llama
+    oracle = OracleLlama(cfg, sd)
+    lens = [3, 12, 7, 1, 9, 12, 5, 2]
+    results = {}
+    for overlap in (True, False):
+        eng = Engine(server_args(cfg, enable_semi_pd=True, prefill_cu_percent=50, decode_cu_percent=50,
+                                 disable_overlap_schedule=not overlap))
+        try:
+            free0 = sorted(s["available_kv_slots"] for s in eng.get_stats(expect=2))
+            rids = [eng.add_request(p, SamplingParams(max_new_tokens=n, ignore_eos=True)) for p, n in zip(prompts, lens)]
+            eng.wait(rids, timeout=120)
+            got = [list(eng._outputs[r]) for r in rids]
+            assert [len(g) for g in got] == lens
+            deadline = time.monotonic() + 30
+            while sorted(s["available_kv_slots"] for s in eng.get_stats(expect=2)) != free0:
+                assert time.monotonic() < deadline, "KV slots were not returned"
+                time.sleep(0.05)
+            results[overlap] = got
+        finally:
+            eng.shutdown()
+    for g, full in zip(results[True], outs):
+        if g != full[: len(g)]:
+            _explain_mismatch(oracle, prompts, [g + full[len(g):] for g in results[True]], outs)
+            break
+    if results[True] != results[False]:
+        padded = lambda rs: [g + full[len(g):] for g, full in zip(rs, outs)]  # noqa: E731
+        _explain_mismatch(oracle, prompts, padded(results[True]), padded(results[False]))
