@@ -33,8 +33,7 @@ class SemiPDDecodeScheduler(SchedulerBase):
         self.defer_decode_stream = True               # see step(): outputs go out behind the next launch
         # overlap schedule (managers/tp_worker_overlap_thread.py, scheduler.py event_loop_overlap; on unless
         # --disable-overlap-schedule): step k + 1 is launched before the tokens of step k are looked at
-        self.enable_overlap = not getattr(server_args, "disable_overlap_schedule", False) \
-            and torch.device(self.device).type == "cuda"
+        self.enable_overlap = not getattr(server_args, "disable_overlap_schedule", False)
         self._pending = None                          # (reqs, out_cache_loc, pinned ids, event, logits_output) of step k
         self._pinned_ids = None
         self._pinned_flip = 0
@@ -233,14 +232,17 @@ class SemiPDDecodeScheduler(SchedulerBase):
         logits_output, next_token_ids = self.run_batch(batch)  # asynchronous: one hipGraph launch
         batch.output_ids = next_token_ids
         bs = len(batch.reqs)
-        if self._pinned_ids is None or self._pinned_ids[0].numel() < bs:
-            n = max(bs, 2 * self.max_running_requests)
-            self._pinned_ids = [torch.empty(n, dtype=torch.int64, pin_memory=True) for _ in range(2)]
-        self._pinned_flip ^= 1
-        host_ids = self._pinned_ids[self._pinned_flip][:bs]
-        host_ids.copy_(next_token_ids, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
+        if torch.device(self.device).type == "cuda":
+            if self._pinned_ids is None or self._pinned_ids[0].numel() < bs:
+                n = max(bs, 2 * self.max_running_requests)
+                self._pinned_ids = [torch.empty(n, dtype=torch.int64, pin_memory=True) for _ in range(2)]
+            self._pinned_flip ^= 1
+            host_ids = self._pinned_ids[self._pinned_flip][:bs]
+            host_ids.copy_(next_token_ids, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        else:  # CPU runs of the protocol tests: same control flow, nothing to wait for
+            host_ids, ev = next_token_ids.to(torch.int64).clone(), None
         prev, self._pending = self._pending, (list(batch.reqs), batch.out_cache_loc, host_ids, ev, logits_output)
         t2 = time.perf_counter()
         if prev is not None:
@@ -260,7 +262,8 @@ class SemiPDDecodeScheduler(SchedulerBase):
 
     def _process_pending(self, pending):
         reqs, out_cache_loc, host_ids, ev, logits_output = pending
-        ev.synchronize()                       # step k and its copy are done; step k + 1 keeps the GPU busy
+        if ev is not None:
+            ev.synchronize()                   # step k and its copy are done; step k + 1 keeps the GPU busy
         ids = host_ids.tolist()
         logprobs = self.extract_logprobs(logits_output)
         alloc = self.token_to_kv_pool_allocator

@@ -123,6 +123,9 @@ def run_semi_pd(prompts, max_new, sa, size=4000, force_retract=0, interleave=Tru
                 got.setdefault(rid, []).extend(toks)
         if not pending and len(got) == len(reqs) and all(len(v) >= max_new for v in got.values()):
             break
+    for _ in range(3):  # the event loops keep running: the overlapped decode loop still holds its last (surplus) step
+        p.step()
+        d.step()
     # nothing leaks: every KV slot and request slot is back in the decode instance's pools
     assert d_runner.token_to_kv_pool_allocator.available_size() == size
     assert d_runner.req_to_token_pool.available_size() == d_runner.req_to_token_pool.size
@@ -197,3 +200,19 @@ def test_single_token_requests_finish_at_prefill():
     got, d, p = run_semi_pd(prompts, 1, args())
     assert got == [expected(p_, 1) for p_ in prompts]
     assert d.stats["decode_tokens"] == 0
+
+
+def test_plain_and_overlapped_decode_loops_agree():
+    """The decode instance's loop is overlapped by default (the tests above run it): step k + 1 is scheduled
+    before the tokens of step k are processed, a finished request runs one surplus step whose token is dropped and
+    whose slot is released later, a retraction drains the pending step first.  --disable-overlap-schedule gives the
+    plain loop; both produce the history-rule tokens and leak nothing (run_semi_pd asserts the pools)."""
+    prompts = prompts_of([5, 40, 17, 1, 33, 8, 21, 2, 64, 11])
+    for kw in (dict(), dict(chunked_prefill_size=16), dict(force_retract=2)):
+        force = kw.pop("force_retract", 0)
+        outs = {}
+        for plain in (False, True):
+            got, d, _ = run_semi_pd(prompts, 9, args(disable_overlap_schedule=plain, **kw), force_retract=force)
+            assert d.enable_overlap == (not plain)
+            outs[plain] = got
+        assert outs[False] == outs[True] == [expected(p, 9) for p in prompts]
