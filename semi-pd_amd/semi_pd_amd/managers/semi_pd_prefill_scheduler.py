@@ -26,7 +26,10 @@ class SemiPDPrefillScheduler(SchedulerBase):
                  send_stats_to=None):
         # send_stats_to: only StatsReq answers go there; tokens are streamed by the decode instance
         super().__init__(server_args, model_runner, tp_rank, recv_socket, send_stats_to, InstanceRole.PREFILL)
-        self.enable_overlap = False
+        # pipelined loop (on unless --disable-overlap-schedule): the next batch is launched behind the running one
+        # before the running one's ids are read, so the GPU does not idle between prefill batches
+        self.enable_overlap = not getattr(server_args, "disable_overlap_schedule", False)
+        self._inflight = None             # (batch, ids on the host side, event, logits_output, t_launch)
         self._proposal_in_flight = False  # a GetNextPrefillBatchInput whose reply has not been read yet
         self._aborted: set = set()        # rids the client gave up on (see abort_request)
         self.chunked_rid: Optional[str] = None
@@ -110,17 +113,23 @@ class SemiPDPrefillScheduler(SchedulerBase):
         if self.tp_rank == 0 and not self._proposal_in_flight and self.waiting_queue and self.chunked_rid is None:
             self._proposal_in_flight = self._propose()
 
-    def get_next_batch_to_run(self) -> Optional[ScheduleBatch]:
-        """semi_pd_prefill_scheduler.py:120-157."""
+    def get_next_batch_to_run(self, block: bool = True) -> Optional[ScheduleBatch]:
+        """semi_pd_prefill_scheduler.py:120-157.  block=False (a batch is running on the GPU): take the decode
+        instance's reply only if it is already there."""
         resp = None
         if self.tp_rank == 0 and (self._proposal_in_flight or self.waiting_queue):
-            if not self._proposal_in_flight:
+            if not self._proposal_in_flight and (block or self.chunked_rid is None):
                 self._proposal_in_flight = self._propose()
-            if self._proposal_in_flight:
+            if self._proposal_in_flight and block:
                 # the reference blocks forever here (semi_pd_prefill_scheduler.py:134); we bound the wait
                 t0 = time.perf_counter()
                 resp = self.bridge_socket.recv_pyobj(timeout=self.server_args.watchdog_timeout)
                 self.stats["t_wait_admission_s"] = self.stats.get("t_wait_admission_s", 0.0) + time.perf_counter() - t0
+            elif self._proposal_in_flight:
+                from semi_pd_amd.managers.transport import NOTHING
+                got = self.bridge_socket.recv_pyobj_nowait()
+                resp = None if got is NOTHING else got
+            if resp is not None:
                 self._proposal_in_flight = False
                 assert isinstance(resp, GetNextPrefillBatchOutput), f"unexpected bridge message {type(resp)}"
         if self.tp_size > 1:
@@ -145,18 +154,56 @@ class SemiPDPrefillScheduler(SchedulerBase):
 
     def step(self) -> bool:
         self.process_input_requests(self.recv_requests())
-        batch = self.get_next_batch_to_run()
-        if batch is None:
-            return False
+        if not self.enable_overlap:
+            batch = self.get_next_batch_to_run()
+            if batch is None:
+                return False
+            self._launch(batch)
+            self._finish()
+            return True
+        # Pipelined: while batch i runs, the reply for batch i + 1 (asked for right after the launch of i) is
+        # usually there long before i is done; batch i + 1 is then queued behind i, and only after that the ids of
+        # i are awaited and sent.  Results reach the decode instance in launch order, which is the order of its
+        # scheduled_prefill_batches.
+        if self._inflight is None:
+            batch = self.get_next_batch_to_run()
+            if batch is None:
+                return False
+            self._launch(batch)
+            return True
+        nxt = self.get_next_batch_to_run(block=False) if self.chunked_rid is None else None
+        prev = self._inflight
+        if nxt is not None:
+            self._launch(nxt)
+        else:
+            self._inflight = None
+        self._finish(prev)
+        return True
+
+    def _launch(self, batch: ScheduleBatch):
         t0 = time.perf_counter()
         logits_output, next_token_ids = self.run_batch(batch)  # asynchronous launches
+        if torch.device(self.device).type == "cuda" and self.enable_overlap:
+            host_ids = torch.empty(next_token_ids.numel(), dtype=torch.int64, pin_memory=True)
+            host_ids.copy_(next_token_ids, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        else:
+            host_ids, ev = next_token_ids, None
+        self._inflight = (batch, host_ids, ev, logits_output, t0)
         if os.environ.get("SEMIPD_EARLY_PROPOSE", "1") != "0":
             self.request_next_batch_early()
-        self.process_batch_result_prefill(batch, next_token_ids, logits_output)
+
+    def _finish(self, inflight=None):
+        if inflight is None:
+            inflight, self._inflight = self._inflight, None
+        batch, host_ids, ev, logits_output, t0 = inflight
+        if ev is not None:
+            ev.synchronize()  # the batch and the copy of its ids are done: every KV row it wrote is in HBM
+        self.process_batch_result_prefill(batch, host_ids, logits_output)
         self.stats["t_forward_s"] = self.stats.get("t_forward_s", 0.0) + time.perf_counter() - t0
         self.stats["prefill_reqs"] = self.stats.get("prefill_reqs", 0) + len(batch.reqs)
         self.last_progress = time.monotonic()
-        return True
 
     def event_loop_normal(self):
         import time

@@ -68,8 +68,10 @@ class ForwardBatch:
             # decode: position = seq_len - 1 (forward_batch_info.py:299-302, clamp_position)
             ret.positions = torch.clamp(ret.seq_lens - 1, min=0).to(torch.int64)
         elif ret.forward_mode.is_extend():
-            ret.extend_seq_lens = torch.tensor(batch.extend_seq_lens, dtype=torch.int32, device=device)
-            ret.extend_prefix_lens = torch.tensor(batch.extend_prefix_lens, dtype=torch.int32, device=device)
+            # pinned staging: a pageable copy would wait for the prefill batch that is still running (pipelined loop)
+            from semi_pd_amd.managers.schedule_batch import host_list_to_device
+            ret.extend_seq_lens = host_list_to_device(batch.extend_seq_lens, torch.int32, device)
+            ret.extend_prefix_lens = host_list_to_device(batch.extend_prefix_lens, torch.int32, device)
             ret.extend_num_tokens = batch.extend_num_tokens
             ret.positions, ret.extend_start_loc = ops.compute_position(
                 ret.extend_prefix_lens, ret.extend_seq_lens, ret.extend_num_tokens)
