@@ -186,6 +186,8 @@ def main():
     ap.add_argument("--mem-fraction-static", type=float, default=None)
     ap.add_argument("--max-total-tokens", type=int, default=None)
     ap.add_argument("--disable-cuda-graph", action="store_true")
+    ap.add_argument("--disable-overlap-schedule", action="store_true",
+                    help="plain (not overlapped / pipelined) decode and prefill loops, for A/B runs")
     ap.add_argument("--quantization", default=None, choices=[None, "fp8"],
                     help="fp8 = block-scaled e4m3fn weights (128 x 128) and per-token-group activations, DeepSeek family")
     ap.add_argument("--kv-cache-dtype", default="auto", choices=["auto", "fp8_e5m2", "fp8_e4m3"],
@@ -246,6 +248,7 @@ def main():
                     max_total_tokens=args.max_total_tokens, prefill_cu_percent=args.prefill_cu,
                     decode_cu_percent=args.decode_cu, cu_mask_mode=args.cu_mask_mode,
                     disable_cuda_graph=args.disable_cuda_graph, nccl_port_base=port_base,
+                    disable_overlap_schedule=args.disable_overlap_schedule,
                     kv_cache_dtype=args.kv_cache_dtype, cuda_graph_max_bs=min(1024, 256 * tp_world),
                     collect_kernel_timing=not args.no_kernel_timing, random_seed=args.seed,
                     dist_init_addr=os.environ.get("MASTER_ADDR", "127.0.0.1"), watchdog_timeout=600.0)
