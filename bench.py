@@ -185,6 +185,7 @@ def main():
     ap.add_argument("--max-running-requests", type=int, default=256)
     ap.add_argument("--mem-fraction-static", type=float, default=None)
     ap.add_argument("--max-total-tokens", type=int, default=None)
+    ap.add_argument("--chunked-prefill-size", type=int, default=None, help="tokens per prefill batch (default 8192)")
     ap.add_argument("--disable-cuda-graph", action="store_true")
     ap.add_argument("--disable-overlap-schedule", action="store_true",
                     help="plain (not overlapped / pipelined) decode and prefill loops, for A/B runs")
@@ -249,6 +250,7 @@ def main():
                     decode_cu_percent=args.decode_cu, cu_mask_mode=args.cu_mask_mode,
                     disable_cuda_graph=args.disable_cuda_graph, nccl_port_base=port_base,
                     disable_overlap_schedule=args.disable_overlap_schedule,
+                    **({"chunked_prefill_size": args.chunked_prefill_size} if args.chunked_prefill_size else {}),
                     kv_cache_dtype=args.kv_cache_dtype, cuda_graph_max_bs=min(1024, 256 * tp_world),
                     collect_kernel_timing=not args.no_kernel_timing, random_seed=args.seed,
                     dist_init_addr=os.environ.get("MASTER_ADDR", "127.0.0.1"), watchdog_timeout=600.0)
