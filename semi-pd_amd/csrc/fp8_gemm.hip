@@ -487,8 +487,11 @@ int semipd_w8a8_block_fp8_matmul(void* c, const void* a_q, const float* a_s, con
   SEMIPD_CHECK_ARG(c && a_q && a_s && w_q && w_s, SEMIPD_EINVAL, "w8a8_block_fp8_matmul: null pointer");
   if (int rc = check_fp8_gemm_args("w8a8_block_fp8_matmul", n, k, block_n, block_k, a_q, w_q)) return rc;
   if (m == 0) return 0;
-  // up to 64 rows: one pass over the weights with 64-row blocks; more: 128-row blocks, 128 W rows per workgroup
-  const int block_m = m <= 64 ? 64 : 128;
+  // 64-row blocks also for up to 512 rows when the weight matrix is small (<= 20 M elements: it stays in L2 / MALL
+  // and more, smaller workgroups fill the chip better: 35 vs 44 us at M = 512, 7168 x 2048); big matrices keep the
+  // 128-row blocks, which read the weights half as often (profiles/r01_kbench_fp8_v1.txt)
+  const long small_m_upto = env_int("SEMIPD_FP8_BM64_UPTO", (n * k <= 20000000) ? 512 : 64);
+  const int block_m = m <= small_m_upto ? 64 : 128;
   const int64_t m_blocks = (m + block_m - 1) / block_m;
   return dispatch_fp8_gemm<false>(c, a_q, a_s, w_q, w_s, nullptr, nullptr, nullptr, nullptr, 0, m, n, k, n, m_blocks, block_m,
                                   block_n, 1, 0, out_dtype, static_cast<hipStream_t>(stream), static_cast<float*>(workspace),

@@ -70,7 +70,10 @@ def make_mm(M, N, K, seed, block_n=128):
 def test_matmul_vs_oracle(device, M):
     # (N, K): DeepSeek-V3 shapes scaled down, ragged N (not a multiple of 16 / 64 / 128), K with a partial
     # last scale block (400 = 3 * 128 + 16) and K shorter than one chunk
-    for i, (N, K) in enumerate([(1536, 7168), (576, 1536), (4096, 512), (200, 1024), (272, 400), (130, 128), (512, 2304)]):
+    shapes = [(1536, 7168), (576, 1536), (4096, 512), (200, 1024), (272, 400), (130, 128), (512, 2304)]
+    if M >= 128:
+        shapes.append((3072, 7168))  # > 20 M elements: the 128-row blocks (smaller matrices take 64-row blocks up to M = 512)
+    for i, (N, K) in enumerate(shapes):
         A, B, As, Bs = make_mm(M, N, K, 100 * M + i)
         for out_dtype in (torch.float32, torch.bfloat16):
             got = ops.w8a8_block_fp8_matmul(A.to(device), B.to(device), As.to(device), Bs.to(device), [128, 128], out_dtype)
