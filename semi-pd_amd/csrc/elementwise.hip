@@ -33,6 +33,16 @@ rmsnorm_vec_kernel(T* __restrict__ out, T* __restrict__ in, T* __restrict__ res,
   T* res_row = FUSED ? res + row * in_stride : nullptr;
   float x[MAXV][V];
   float ss = 0.f;
+  // the weight row does not depend on the reduction: fetch it up front for rows short enough to keep it in
+  // registers (decode-sized calls are latency-bound: one dependent global load less on the critical path)
+  Vec16<T> wv[MAXV <= 2 ? MAXV : 1];
+  if constexpr (MAXV <= 2) {
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int v = threadIdx.x + i * blockDim.x;
+      if (v < nvec) wv[i] = load16(w + (int64_t)v * V);
+    }
+  }
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int v = threadIdx.x + i * blockDim.x;
@@ -61,7 +71,9 @@ rmsnorm_vec_kernel(T* __restrict__ out, T* __restrict__ in, T* __restrict__ res,
   for (int i = 0; i < MAXV; ++i) {
     const int v = threadIdx.x + i * blockDim.x;
     if (v < nvec) {
-      Vec16<T> ww = load16(w + (int64_t)v * V);
+      Vec16<T> ww;
+      if constexpr (MAXV <= 2) ww = wv[i];
+      else ww = load16(w + (int64_t)v * V);
       Vec16<T> o;
 #pragma unroll
       for (int j = 0; j < V; ++j) o.e[j] = Elem<T>::from_f(x[i][j] * rs * Elem<T>::to_f(ww.e[j]));
