@@ -383,6 +383,7 @@ static int launch_fp8_gemm(void* c, const void* a, const float* a_s, const void*
   const int chunks = (int)((K + KC - 1) / KC);
   int ksplit = 1;
   if (!GROUPED && ws && N % 4 == 0) ksplit = fp8_pick_ksplit(n_tiles * m_blocks, chunks, m_blocks * BM, N, ws_bytes);
+  if (const long forced = env_int("SEMIPD_FP8_KSPLIT", 0); forced > 0 && !GROUPED && ws && N % 4 == 0) ksplit = (int)forced;
   const int cps = (chunks + ksplit - 1) / ksplit;
   ksplit = (chunks + cps - 1) / cps;  // no empty splits
   dim3 grid = GROUPED ? dim3((unsigned)n_tiles, (unsigned)m_blocks, 1)
