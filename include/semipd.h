@@ -303,6 +303,12 @@ int semipd_moe_sum(void* out, const void* in, int64_t num_tokens, int topk, int6
  * x [num_rows, hidden] contiguous f32/bf16/f16, hidden % group_size == 0, group_size in {64,128,256,512}. */
 int semipd_per_token_group_quant_fp8(void* q, float* s, const void* x, int64_t num_rows, int64_t hidden,
                                      int group_size, float eps, int dtype, void* stream);
+/* SiluAndMul (layers/activation.py:41-44) and per_token_group_quant_fp8 of its output in one pass, as
+ * fused_experts_impl runs them back to back between its two GEMMs (fused_moe.py:1104-1125):
+ * x [num_rows, 2*d] (gate | up) bf16/f16 -> q [num_rows, d] fp8, s [num_rows, d / group_size].  Bytes and
+ * scales equal those of the two separate calls. */
+int semipd_silu_and_mul_quant_fp8(void* q, float* s, const void* x, int64_t num_rows, int64_t d, int group_size,
+                                  float eps, int dtype, void* stream);
 /* c[m, n] = sum_kb (sum_{k in kb} a_q[m,k] * w_q[n,k]) * a_s[m,kb] * w_s[n / block_n, kb], fp32
  * accumulation; replaces w8a8_block_fp8_matmul (fp8_kernel.py:409-491, 694-800).
  * a_q [m,k] fp8, a_s [m, ceil(k/128)] f32, w_q [n,k] fp8, w_s [ceil(n/block_n), ceil(k/128)] f32, all

@@ -78,6 +78,51 @@ per_token_group_quant_fp8_kernel(uint8_t* __restrict__ q, float* __restrict__ s,
   if ((threadIdx.x & (lanes_per_group - 1)) == 0) s[i / lanes_per_group] = y_s;
 }
 
+// SiLU(gate) * up and the quantisation of the product in one pass: x [rows, 2 d] -> q [rows, d], s [rows, d / G].
+// The product is rounded to T first, as SiluAndMul's output is (layers/activation.py:41-44), so the bytes equal
+// those of silu_and_mul followed by per_token_group_quant_fp8 (fused_moe.py:1104-1125 runs them back to back);
+// the T-typed intermediate never travels through HBM.
+template <typename T>
+__global__ void __launch_bounds__(256)
+silu_and_mul_quant_fp8_kernel(uint8_t* __restrict__ q, float* __restrict__ s, const T* __restrict__ x, int64_t num_vec,
+                              int vec_per_row, int lanes_per_group, float eps) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // 8-element output vector index
+  const bool live = i < num_vec;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = 0.f;
+  if (live) {
+    const int64_t row = i / vec_per_row;
+    const int c = (int)(i - row * vec_per_row);
+    const T* xr = x + row * (int64_t)vec_per_row * 16;
+    const Vec16<T> g = *reinterpret_cast<const Vec16<T>*>(xr + (int64_t)c * 8);
+    const Vec16<T> u = *reinterpret_cast<const Vec16<T>*>(xr + (int64_t)(vec_per_row + c) * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float gf = Elem<T>::to_f(g.e[j]);
+      v[j] = Elem<T>::to_f(Elem<T>::from_f(gf / (1.0f + __expf(-gf)) * Elem<T>::to_f(u.e[j])));
+    }
+  }
+  float amax = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(v[j]));
+  for (int off = 1; off < lanes_per_group; off <<= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+  amax = fmaxf(amax, eps);
+  const float y_s = amax / kFp8Max;
+  const float y_s_inv = 1.0f / y_s;
+  if (!live) return;
+  float w[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) w[j] = fminf(fmaxf(v[j] * y_s_inv, -kFp8Max), kFp8Max);
+  uint2 p;
+  p.x = F8Cvt<f8e4m3_t>::pack2<false>(w[0], w[1], 0u);
+  p.x = F8Cvt<f8e4m3_t>::pack2<true>(w[2], w[3], p.x);
+  p.y = F8Cvt<f8e4m3_t>::pack2<false>(w[4], w[5], 0u);
+  p.y = F8Cvt<f8e4m3_t>::pack2<true>(w[6], w[7], p.y);
+  *reinterpret_cast<uint2*>(q + i * 8) = p;
+  if ((threadIdx.x & (lanes_per_group - 1)) == 0) s[i / lanes_per_group] = y_s;
+}
+
 // ------------------------------------------------------------------------------------------------
 // block-scaled fp8 NT GEMM (dense and grouped)
 // ------------------------------------------------------------------------------------------------
@@ -480,6 +525,36 @@ int semipd_per_token_group_quant_fp8(void* q, float* s, const void* x, int64_t n
       return SEMIPD_EDTYPE;
   }
   return launch_status("per_token_group_quant_fp8");
+}
+
+int semipd_silu_and_mul_quant_fp8(void* q, float* s, const void* x, int64_t num_rows, int64_t d, int group_size,
+                                  float eps, int dtype, void* stream) {
+  SEMIPD_CHECK_ARG(q && s && x, SEMIPD_EINVAL, "silu_and_mul_quant_fp8: null pointer");
+  SEMIPD_CHECK_ARG(group_size == 64 || group_size == 128 || group_size == 256 || group_size == 512, SEMIPD_ESHAPE,
+                   "silu_and_mul_quant_fp8: group size %d is not one of 64, 128, 256, 512", group_size);
+  SEMIPD_CHECK_ARG(d > 0 && d % group_size == 0, SEMIPD_ESHAPE,
+                   "silu_and_mul_quant_fp8: width %lld is not a multiple of the group size %d", (long long)d, group_size);
+  SEMIPD_CHECK_ARG(aligned16(x) && (reinterpret_cast<uintptr_t>(q) & 7u) == 0, SEMIPD_EALIGN,
+                   "silu_and_mul_quant_fp8: x must be 16-byte and q 8-byte aligned");
+  if (num_rows == 0) return 0;
+  const int64_t num_vec = num_rows * d / 8;
+  dim3 grid((unsigned)((num_vec + 255) / 256));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int lpg = group_size / 8, vpr = (int)(d / 8);
+  switch (dtype) {
+    case SEMIPD_BF16:
+      hipLaunchKernelGGL((silu_and_mul_quant_fp8_kernel<bf16_t>), grid, dim3(256), 0, st, (uint8_t*)q, s, (const bf16_t*)x,
+                         num_vec, vpr, lpg, eps);
+      break;
+    case SEMIPD_F16:
+      hipLaunchKernelGGL((silu_and_mul_quant_fp8_kernel<f16_t>), grid, dim3(256), 0, st, (uint8_t*)q, s, (const f16_t*)x,
+                         num_vec, vpr, lpg, eps);
+      break;
+    default:
+      set_error("silu_and_mul_quant_fp8: dtype code %d is not bf16 / f16", dtype);
+      return SEMIPD_EDTYPE;
+  }
+  return launch_status("silu_and_mul_quant_fp8");
 }
 
 int semipd_w8a8_block_fp8_matmul(void* c, const void* a_q, const float* a_s, const void* w_q, const float* w_s,

@@ -348,6 +348,17 @@ class RowParallelLinear(nn.Module):
             out = tensor_model_parallel_all_reduce(out)
         return out
 
+    def forward_prequantized(self, x_q: torch.Tensor, x_s: torch.Tensor, out_dtype: torch.dtype):
+        """The block-fp8 layer on activations that are quantised already (by the kernel that produced them, e.g.
+        ops.silu_and_mul_quant_fp8): skips apply_w8a8_block_fp8_linear's own quantisation pass."""
+        out = ops.w8a8_block_fp8_matmul(x_q, self.weight, x_s, self.weight_scale_inv, self.quant_config.weight_block_size,
+                                        output_dtype=out_dtype)
+        if self.bias is not None and get_tensor_model_parallel_rank() == 0:
+            out = out + self.bias
+        if self.reduce_results and get_tensor_model_parallel_world_size() > 1:
+            out = tensor_model_parallel_all_reduce(out)
+        return out
+
 
 class VocabParallelEmbedding(nn.Module):
     """Embedding rows sharded over ranks; out-of-shard ids contribute zeros, then all-reduce

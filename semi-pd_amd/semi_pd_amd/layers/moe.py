@@ -106,8 +106,7 @@ def fused_experts_fp8(hidden_states: torch.Tensor, w1: torch.Tensor, w2: torch.T
     c1 = torch.empty((numel, N2), dtype=dt, device=dev)
     ops.moe_grouped_gemm_fp8(a_q, a_s, w1, w1_scale, c1, None, sorted_ids, expert_ids, num_post_pad, numel, topk,
                              False, block_shape, block_m)
-    c2 = ops.silu_and_mul(c1)
-    c2_q, c2_s = ops.per_token_group_quant_fp8(c2, block_k)
+    c2_q, c2_s = ops.silu_and_mul_quant_fp8(c1, block_k)  # SiLU * mul and the quantisation of its output in one pass
     c3 = (torch.zeros if partial_experts else torch.empty)((numel, K), dtype=dt, device=dev)
     ops.moe_grouped_gemm_fp8(c2_q, c2_s, w2, w2_scale, c3, topk_weights.reshape(-1).float(), sorted_ids, expert_ids,
                              num_post_pad, numel, 1, True, block_shape, block_m)

@@ -83,7 +83,13 @@ class DeepseekV2MLP(nn.Module):
         self.act_fn = SiluAndMul()
 
     def forward(self, x):
-        return self.down_proj(self.act_fn(self.gate_up_proj(x)))
+        gate_up = self.gate_up_proj(x)
+        qc = self.down_proj.quant_config
+        if qc is not None and gate_up.dim() == 2:
+            # block-fp8: SiLU * mul and the quantisation in front of down_proj in one kernel
+            q, s = ops.silu_and_mul_quant_fp8(gate_up, qc.weight_block_size[1])
+            return self.down_proj.forward_prequantized(q, s, x.dtype)
+        return self.down_proj(self.act_fn(gate_up))
 
 
 class MoEGate(nn.Module):

@@ -562,6 +562,23 @@ def per_token_group_quant_fp8(x: torch.Tensor, group_size: int, eps: float = 1e-
     return x_q, x_s
 
 
+def silu_and_mul_quant_fp8(x: torch.Tensor, group_size: int, eps: float = 1e-10):
+    """silu_and_mul(x) followed by per_token_group_quant_fp8(., group_size) in one kernel: (x_q [..., d], x_s
+    [..., d / group_size]) for x [..., 2 d]; the same bytes as the two calls (fused_moe.py:1104-1125)."""
+    d = x.shape[-1] // 2
+    if x.shape[-1] % 2 or d % group_size != 0:
+        raise RuntimeError("the last dimension of `x` cannot be divisible by `group_size`")
+    if not x.is_contiguous():
+        raise RuntimeError("`x` is not contiguous")
+    x_q = torch.empty(x.shape[:-1] + (d,), dtype=FP8_DTYPE, device=x.device)
+    x_s = torch.empty(x.shape[:-1] + (d // group_size,), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    check(lib.semipd_silu_and_mul_quant_fp8(ptr(x_q), ptr(x_s), ptr(x), x.numel() // x.shape[-1], d, group_size,
+                                            float(eps), dtype_code(x.dtype), current_stream(x.device)),
+          "silu_and_mul_quant_fp8")
+    return x_q, x_s
+
+
 def w8a8_block_fp8_matmul(A: torch.Tensor, B: torch.Tensor, As: torch.Tensor, Bs: torch.Tensor,
                           block_size, output_dtype: torch.dtype = torch.float16) -> torch.Tensor:
     """fp8_kernel.py:694-800: A [..., K] fp8 with As [..., ceil(K/bk)], B [N, K] fp8 with Bs [ceil(N/bn), ceil(K/bk)]."""

@@ -142,3 +142,21 @@ def test_fused_moe_block_fp8_vs_oracle(device, T, block_m):
     assert got.shape == (T, K) and got.dtype == torch.bfloat16
     assert rel_err(got, want) < 0.02  # the reference's bar (test_block_fp8.py:397-401); measured far below
     assert rel_err(got, want) < 5e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_silu_and_mul_quant_fused_equals_the_two_calls(device, dtype):
+    """ops.silu_and_mul_quant_fp8 == silu_and_mul then per_token_group_quant_fp8 (what fused_experts_impl runs between
+    its two GEMMs, fused_moe.py:1104-1125): bit-identical bytes and scales, against the oracle and against the two
+    separate kernels."""
+    g = torch.Generator().manual_seed(9)
+    for rows, d, group in [(1, 128, 128), (37, 1408, 128), (300, 2048, 64), (5, 512, 512)]:
+        x = (torch.randn(rows, 2 * d, generator=g) * 2).to(dtype)
+        q, s = ops.silu_and_mul_quant_fp8(x.to(device), group)
+        act = O.silu_and_mul(x)
+        q_ref, s_ref = O.per_token_group_quant_fp8(act, group)
+        assert torch.equal(s.cpu(), s_ref) and torch.equal(q.cpu().view(torch.uint8), q_ref.view(torch.uint8))
+        q2, s2 = ops.per_token_group_quant_fp8(ops.silu_and_mul(x.to(device)), group)
+        assert torch.equal(q.view(torch.uint8), q2.view(torch.uint8)) and torch.equal(s, s2)
+    with pytest.raises(RuntimeError, match="cannot be divisible"):
+        ops.silu_and_mul_quant_fp8(torch.randn(2, 200, device=device, dtype=dtype), 128)
