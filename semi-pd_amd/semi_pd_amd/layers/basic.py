@@ -224,10 +224,10 @@ class ColumnParallelLinear(nn.Module):
             self.bias.tp_full_shape = (output_size,)
             self.bias.tp_shard = lambda full: torch.cat([full[a:b] for a, b in ranges], 0)
 
-    def forward(self, x):
+    def forward(self, x, x_quant=None):
         if self.quant_config:
             return apply_w8a8_block_fp8_linear(x, self.weight, self.quant_config.weight_block_size,
-                                               self.weight_scale_inv, self.bias)
+                                               self.weight_scale_inv, self.bias, x_quant=x_quant)
         return F.linear(x, self.weight, self.bias)
 
 

@@ -53,13 +53,20 @@ def check_quantisable_input(input_size: int, block, what: str) -> None:
         raise ValueError(f"{what}: input size {input_size} is not a multiple of the quantisation group {block[1]}")
 
 
-def apply_w8a8_block_fp8_linear(x: torch.Tensor, weight: torch.Tensor, block_size, weight_scale: torch.Tensor,
-                                bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """fp8_utils.py:91-134."""
+def quantize_activation(x: torch.Tensor, block_size):
+    """The per-token-group quantisation in front of a block-fp8 layer, as a value: layers that read the SAME
+    activation (q_proj and kv_a_proj_with_mqa; the shared experts and the routed experts) quantise it once and pass
+    the result on (`x_quant=`), instead of once each as apply_w8a8_block_fp8_linear does (fp8_utils.py:91-134)."""
     x2 = x.reshape(-1, x.shape[-1])
     if not x2.is_contiguous():
         x2 = x2.contiguous()
-    q, s = ops.per_token_group_quant_fp8(x2, int(block_size[1]))
+    return ops.per_token_group_quant_fp8(x2, int(block_size[1]))
+
+
+def apply_w8a8_block_fp8_linear(x: torch.Tensor, weight: torch.Tensor, block_size, weight_scale: torch.Tensor,
+                                bias: Optional[torch.Tensor] = None, x_quant=None) -> torch.Tensor:
+    """fp8_utils.py:91-134.  x_quant = quantize_activation(x, block_size) computed by the caller, if it has it."""
+    q, s = x_quant if x_quant is not None else quantize_activation(x, block_size)
     out = ops.w8a8_block_fp8_matmul(q, weight, s, weight_scale, block_size, output_dtype=x.dtype)
     if bias is not None:
         out = out + bias

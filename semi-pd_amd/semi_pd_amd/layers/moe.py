@@ -82,7 +82,8 @@ def fused_experts(hidden_states: torch.Tensor, w1: torch.Tensor, w2: torch.Tenso
 
 def fused_experts_fp8(hidden_states: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, w1_scale: torch.Tensor,
                       w2_scale: torch.Tensor, topk_weights: torch.Tensor, topk_ids: torch.Tensor, block_shape,
-                      block_m: Optional[int] = None, expert_offset: int = 0, partial_experts: bool = False) -> torch.Tensor:
+                      block_m: Optional[int] = None, expert_offset: int = 0, partial_experts: bool = False,
+                      x_quant=None) -> torch.Tensor:
     """fused_experts_impl with use_fp8_w8a8 and block_shape = [block_n, block_k] (fused_moe.py:961-1165;
     activation quantisation inside invoke_fused_moe_kernel :526-545): the activations of both GEMMs are
     quantised per token and group of block_k, the weights are fp8 [E, 2N, K] / [E, K, N] with one scale per
@@ -102,7 +103,7 @@ def fused_experts_fp8(hidden_states: torch.Tensor, w1: torch.Tensor, w2: torch.T
     num_post_pad = torch.empty(1, dtype=torch.int32, device=dev)
     cumsum = torch.empty(E + 1, dtype=torch.int32, device=dev)
     ops.moe_align_block_size(topk_ids, E, block_m, sorted_ids, expert_ids, num_post_pad, None, cumsum)
-    a_q, a_s = ops.per_token_group_quant_fp8(hidden_states, block_k)
+    a_q, a_s = x_quant if x_quant is not None else ops.per_token_group_quant_fp8(hidden_states, block_k)
     c1 = torch.empty((numel, N2), dtype=dt, device=dev)
     ops.moe_grouped_gemm_fp8(a_q, a_s, w1, w1_scale, c1, None, sorted_ids, expert_ids, num_post_pad, numel, topk,
                              False, block_shape, block_m)
@@ -193,14 +194,15 @@ class FusedMoE(nn.Module):
             self.w2_weight_scale_inv.tp_full_shape = (E,) + scale_shape(hidden_size, n, (bn, bk))
             self.w13_weight_scale_inv.tp_shard = self.w2_weight_scale_inv.tp_shard = lambda full: full[lo:hi].contiguous()
 
-    def forward(self, hidden_states: torch.Tensor, router_logits: torch.Tensor) -> torch.Tensor:
+    def forward(self, hidden_states: torch.Tensor, router_logits: torch.Tensor, x_quant=None) -> torch.Tensor:
         topk_weights, topk_ids = select_experts(hidden_states, router_logits, self.top_k, self.use_grouped_topk,
                                                 self.renormalize, self.topk_group, self.num_expert_group,
                                                 self.correction_bias)
         if self.quant_config:
             out = fused_experts_fp8(hidden_states, self.w13_weight, self.w2_weight, self.w13_weight_scale_inv,
                                     self.w2_weight_scale_inv, topk_weights, topk_ids, self.quant_config.weight_block_size,
-                                    expert_offset=self.expert_offset, partial_experts=self.expert_parallel)
+                                    expert_offset=self.expert_offset, partial_experts=self.expert_parallel,
+                                    x_quant=x_quant)
         else:
             out = fused_experts(hidden_states, self.w13_weight, self.w2_weight, topk_weights, topk_ids,
                                 expert_offset=self.expert_offset, partial_experts=self.expert_parallel)

@@ -25,7 +25,7 @@ from semi_pd_amd.layers.attention_backend import RadixAttention
 from semi_pd_amd.layers.basic import (ColumnParallelLinear, LogitsProcessor, MergedColumnParallelLinear,
                                       ParallelLMHead, ReplicatedLinear, RMSNorm, RowParallelLinear, SiluAndMul,
                                       VocabParallelEmbedding, get_rope, yarn_get_mscale)
-from semi_pd_amd.layers.fp8 import Fp8Config, block_dequantize_weight
+from semi_pd_amd.layers.fp8 import Fp8Config, block_dequantize_weight, quantize_activation
 from semi_pd_amd.layers.moe import FusedMoE
 
 
@@ -82,8 +82,8 @@ class DeepseekV2MLP(nn.Module):
                                            params_dtype=dtype, quant_config=quant_config)
         self.act_fn = SiluAndMul()
 
-    def forward(self, x):
-        gate_up = self.gate_up_proj(x)
+    def forward(self, x, x_quant=None):
+        gate_up = self.gate_up_proj(x, x_quant=x_quant)
         qc = self.down_proj.quant_config
         if qc is not None and gate_up.dim() == 2:
             # block-fp8: SiLU * mul and the quantisation in front of down_proj in one kernel
@@ -126,9 +126,13 @@ class DeepseekV2MoE(nn.Module):
                                                 reduce_results=False, quant_config=quant_config_of(config))
 
     def forward(self, hidden_states: torch.Tensor) -> torch.Tensor:
-        shared_output = self.shared_experts(hidden_states) if self.shared_experts is not None else None
+        # block-fp8: the shared experts and the routed experts read the same activation: quantise it once
+        qc = self.experts.quant_config
+        x_quant = quantize_activation(hidden_states, qc.weight_block_size) \
+            if (qc is not None and self.shared_experts is not None and hidden_states.dim() == 2) else None
+        shared_output = self.shared_experts(hidden_states, x_quant=x_quant) if self.shared_experts is not None else None
         router_logits = self.gate(hidden_states)
-        out = self.experts(hidden_states, router_logits)
+        out = self.experts(hidden_states, router_logits, x_quant=x_quant)
         if self.routed_scaling_factor != 1.0:
             out = out * self.routed_scaling_factor
         if shared_output is not None:
@@ -196,17 +200,23 @@ class DeepseekV2AttentionMLA(nn.Module):
         self.w_kc = w_kc.contiguous()                    # [H, 128, 512]
         self.w_vc = w_vc.transpose(1, 2).contiguous()    # [H, 512, 128]
 
-    def _q(self, hidden_states):
+    def _x_quant(self, hidden_states):
+        """block-fp8: q_(a_)proj and kv_a_proj_with_mqa read the same activation: quantise it once."""
+        if self.quant_config is None or hidden_states.dim() != 2:
+            return None
+        return quantize_activation(hidden_states, self.quant_config.weight_block_size)
+
+    def _q(self, hidden_states, x_quant=None):
         if self.q_lora_rank is not None:
-            q = self.q_b_proj(self.q_a_layernorm(self.q_a_proj(hidden_states)))
+            q = self.q_b_proj(self.q_a_layernorm(self.q_a_proj(hidden_states, x_quant=x_quant)))
         else:
-            q = self.q_proj(hidden_states)
+            q = self.q_proj(hidden_states, x_quant=x_quant)
         return q.view(-1, self.num_local_heads, self.qk_head_dim)
 
-    def _latent(self, hidden_states, positions, q):
+    def _latent(self, hidden_states, positions, q, x_quant=None):
         """kv_a_proj -> RMSNorm on the 512 latent dims -> RoPE on the 64 rope dims (and on q_pe);
         returns the finished latent rows [T, 1, 576]."""
-        latent = self.kv_a_proj_with_mqa(hidden_states)  # [T, 576]
+        latent = self.kv_a_proj_with_mqa(hidden_states, x_quant=x_quant)  # [T, 576]
         kv_a = ops.rmsnorm(latent[:, : self.kv_lora_rank], self.kv_a_layernorm.weight.data,
                            self.kv_a_layernorm.variance_epsilon, out=latent[:, : self.kv_lora_rank])
         del kv_a
@@ -222,8 +232,9 @@ class DeepseekV2AttentionMLA(nn.Module):
         return self.forward_absorb(positions, hidden_states, forward_batch)
 
     def forward_normal(self, positions, hidden_states, forward_batch):
-        q = self._q(hidden_states)
-        latent = self._latent(hidden_states, positions, q)
+        xq = self._x_quant(hidden_states)
+        q = self._q(hidden_states, xq)
+        latent = self._latent(hidden_states, positions, q, xq)
         forward_batch.token_to_kv_pool.set_kv_buffer(self.attn_mha, forward_batch.out_cache_loc, latent, None)
         kv = self.kv_b_proj(latent[:, 0, : self.kv_lora_rank])
         kv = kv.view(-1, self.num_local_heads, self.qk_nope_head_dim + self.v_head_dim)
@@ -236,9 +247,10 @@ class DeepseekV2AttentionMLA(nn.Module):
         return self.o_proj(attn_output)
 
     def forward_absorb(self, positions, hidden_states, forward_batch):
-        q = self._q(hidden_states)
+        xq = self._x_quant(hidden_states)
+        q = self._q(hidden_states, xq)
         T = q.shape[0]
-        latent = self._latent(hidden_states, positions, q)
+        latent = self._latent(hidden_states, positions, q, xq)
         q_input = torch.empty((T, self.num_local_heads, self.kv_lora_rank + self.qk_rope_head_dim),
                               dtype=q.dtype, device=q.device)
         q_nope_out = torch.bmm(q[..., : self.qk_nope_head_dim].transpose(0, 1), self.w_kc)  # [H, T, 512]
