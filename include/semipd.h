@@ -303,6 +303,13 @@ int semipd_moe_sum(void* out, const void* in, int64_t num_tokens, int topk, int6
  * x [num_rows, hidden] contiguous f32/bf16/f16, hidden % group_size == 0, group_size in {64,128,256,512}. */
 int semipd_per_token_group_quant_fp8(void* q, float* s, const void* x, int64_t num_rows, int64_t hidden,
                                      int group_size, float eps, int dtype, void* stream);
+/* fused_add_rmsnorm (above) and per_token_group_quant_fp8 of the normalised rows in one pass: the activation
+ * in front of a block-fp8 layer is quantised by the kernel that produces it.  inout / residual as in
+ * semipd_fused_add_rmsnorm; q [num_tokens, hidden] fp8, qs [num_tokens, hidden / group_size]; hidden a multiple
+ * of group_size, at most 8192; bf16 / f16.  Bytes and scales equal those of the two separate calls. */
+int semipd_fused_add_rmsnorm_quant_fp8(void* inout, void* residual, const void* weight, void* q, float* qs,
+                                       int64_t num_tokens, int64_t hidden, float eps, int group_size, float q_eps,
+                                       int dtype, void* stream);
 /* SiluAndMul (layers/activation.py:41-44) and per_token_group_quant_fp8 of its output in one pass, as
  * fused_experts_impl runs them back to back between its two GEMMs (fused_moe.py:1104-1125):
  * x [num_rows, 2*d] (gate | up) bf16/f16 -> q [num_rows, d] fp8, s [num_rows, d / group_size].  Bytes and

@@ -20,11 +20,15 @@ void set_error(const char* fmt, ...) {
 // RMSNorm: one workgroup per row, the row lives in registers between the
 // sum-of-squares pass and the scale pass (one HBM read, one write).
 // ---------------------------------------------------------------------------
-template <typename T, int MAXV, bool FUSED>
+// QUANT: the normalised row is also quantised per group of 8 * lanes_per_group elements (per_token_group_quant_fp8
+// of the output, layers/quantization/fp8_kernel.py:99-115) in the same pass: q [rows, hidden] e4m3fn, qs [rows,
+// hidden / group].  The values quantised are the T-rounded outputs, so the bytes equal those of the separate call.
+template <typename T, int MAXV, bool FUSED, bool QUANT = false>
 __global__ void __launch_bounds__(512)
 rmsnorm_vec_kernel(T* __restrict__ out, T* __restrict__ in, T* __restrict__ res,
                    const T* __restrict__ w, int64_t in_stride, int64_t out_stride, int nvec,
-                   int hidden, float eps) {
+                   int hidden, float eps, uint8_t* __restrict__ q = nullptr, float* __restrict__ qs = nullptr,
+                   int lanes_per_group = 16, float q_eps = 1e-10f) {
   constexpr int V = Elem<T>::kVec;
   __shared__ float red[16];
   const int64_t row = blockIdx.x;
@@ -78,6 +82,28 @@ rmsnorm_vec_kernel(T* __restrict__ out, T* __restrict__ in, T* __restrict__ res,
 #pragma unroll
       for (int j = 0; j < V; ++j) o.e[j] = Elem<T>::from_f(x[i][j] * rs * Elem<T>::to_f(ww.e[j]));
       store16(out_row + (int64_t)v * V, o);
+      if constexpr (QUANT && V == 8) {
+        // groups are aligned runs of lanes (hidden % group == 0): whole groups are inside or outside this branch
+        float y[8], amax = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          y[j] = Elem<T>::to_f(o.e[j]);
+          amax = fmaxf(amax, fabsf(y[j]));
+        }
+        for (int off = 1; off < lanes_per_group; off <<= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+        amax = fmaxf(amax, q_eps);
+        const float y_s = amax / 448.0f;
+        const float y_s_inv = 1.0f / y_s;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[j] = fminf(fmaxf(y[j] * y_s_inv, -448.0f), 448.0f);
+        uint2 p;
+        p.x = F8Cvt<f8e4m3_t>::pack2<false>(y[0], y[1], 0u);
+        p.x = F8Cvt<f8e4m3_t>::pack2<true>(y[2], y[3], p.x);
+        p.y = F8Cvt<f8e4m3_t>::pack2<false>(y[4], y[5], 0u);
+        p.y = F8Cvt<f8e4m3_t>::pack2<true>(y[6], y[7], p.y);
+        *reinterpret_cast<uint2*>(q + (row * nvec + v) * 8) = p;
+        if ((v & (lanes_per_group - 1)) == 0) qs[row * (nvec / lanes_per_group) + v / lanes_per_group] = y_s;
+      }
     }
   }
 }
@@ -665,6 +691,47 @@ int semipd_fused_add_rmsnorm(void* inout, void* residual, const void* weight, in
   SEMIPD_CHECK_ARG(num_tokens < (1ll << 31), SEMIPD_EINVAL, "fused_add_rmsnorm: too many rows");
   SEMIPD_DISPATCH_DTYPE(dtype, T, return (launch_rmsnorm<T, true>((T*)inout, (T*)inout, (T*)residual, (const T*)weight, num_tokens, hidden, hidden, hidden, eps, as_stream(stream))));
   return 0;
+}
+
+int semipd_fused_add_rmsnorm_quant_fp8(void* inout, void* residual, const void* weight, void* q, float* qs,
+                                       int64_t num_tokens, int64_t hidden, float eps, int group_size, float q_eps,
+                                       int dtype, void* stream) {
+  SEMIPD_CHECK_ARG(num_tokens >= 0 && hidden > 0 && num_tokens < (1ll << 31), SEMIPD_EINVAL,
+                   "fused_add_rmsnorm_quant_fp8: bad sizes");
+  if (num_tokens == 0) return 0;
+  SEMIPD_CHECK_ARG(inout && residual && weight && q && qs, SEMIPD_EINVAL, "fused_add_rmsnorm_quant_fp8: null pointer");
+  SEMIPD_CHECK_ARG(group_size == 64 || group_size == 128 || group_size == 256 || group_size == 512, SEMIPD_ESHAPE,
+                   "fused_add_rmsnorm_quant_fp8: group size %d is not one of 64, 128, 256, 512", group_size);
+  SEMIPD_CHECK_ARG(hidden % group_size == 0 && hidden <= 8 * 512 * 2, SEMIPD_ESHAPE,
+                   "fused_add_rmsnorm_quant_fp8: hidden size %lld must be a multiple of the group size and at most 8192",
+                   (long long)hidden);
+  SEMIPD_CHECK_ARG(dtype == SEMIPD_BF16 || dtype == SEMIPD_F16, SEMIPD_EDTYPE,
+                   "fused_add_rmsnorm_quant_fp8: bf16 / f16 only");
+  SEMIPD_CHECK_ARG(aligned16(inout) && aligned16(residual) && aligned16(weight) &&
+                       (reinterpret_cast<uintptr_t>(q) & 7u) == 0,
+                   SEMIPD_EALIGN, "fused_add_rmsnorm_quant_fp8: unaligned pointer");
+  const int nvec = (int)(hidden / 8), lpg = group_size / 8;
+  // the launch shape of launch_rmsnorm, so that the reduction order — hence every output bit — is the same as in
+  // the unfused kernel
+  const int threads = nvec <= 64 ? 64 : nvec <= 128 ? 128 : nvec <= 1024 ? 256 : 512;
+  const int per = (nvec + threads - 1) / threads;
+  dim3 grid((unsigned)num_tokens), block(threads);
+  hipStream_t st = as_stream(stream);
+#define RQ(T, MV)                                                                                             \
+  hipLaunchKernelGGL((rmsnorm_vec_kernel<T, MV, true, true>), grid, block, 0, st, (T*)inout, (T*)inout,       \
+                     (T*)residual, (const T*)weight, hidden, hidden, nvec, (int)hidden, eps, (uint8_t*)q, qs, \
+                     lpg, q_eps)
+  if (dtype == SEMIPD_BF16) {
+    if (per <= 1) RQ(bf16_t, 1);
+    else if (per <= 2) RQ(bf16_t, 2);
+    else RQ(bf16_t, 4);
+  } else {
+    if (per <= 1) RQ(f16_t, 1);
+    else if (per <= 2) RQ(f16_t, 2);
+    else RQ(f16_t, 4);
+  }
+#undef RQ
+  return launch_status("fused_add_rmsnorm_quant_fp8");
 }
 
 int semipd_silu_and_mul(void* out, const void* in, int64_t num_tokens, int64_t d, int dtype,

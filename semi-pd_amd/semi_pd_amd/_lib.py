@@ -67,6 +67,7 @@ _SIGNATURES = {
                                 _i32, _i32, _vp],
     "semipd_moe_sum": [_vp, _vp, _i64, _i32, _i64, _i32, _vp],
     "semipd_per_token_group_quant_fp8": [_vp, _vp, _vp, _i64, _i64, _i32, C.c_float, _i32, _vp],
+    "semipd_fused_add_rmsnorm_quant_fp8": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, C.c_float, _i32, C.c_float, _i32, _vp],
     "semipd_silu_and_mul_quant_fp8": [_vp, _vp, _vp, _i64, _i64, _i32, C.c_float, _i32, _vp],
     "semipd_w8a8_block_fp8_matmul": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _vp, _sz, _vp],
     "semipd_moe_grouped_gemm_fp8": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32,

@@ -39,6 +39,12 @@ class RMSNorm(nn.Module):
             return x, residual
         return ops.rmsnorm(x, self.weight.data, self.variance_epsilon)
 
+    def forward_quant(self, x: torch.Tensor, residual: torch.Tensor, group_size: int):
+        """fused add + norm, and the per-token-group fp8 quantisation of the result for the block-fp8 layers that
+        read it, in one kernel: (x, residual, (x_q, x_s))."""
+        x_quant = ops.fused_add_rmsnorm_quant_fp8(x, residual, self.weight.data, self.variance_epsilon, group_size)
+        return x, residual, x_quant
+
 
 class SiluAndMul(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:

@@ -125,11 +125,11 @@ class DeepseekV2MoE(nn.Module):
                                                 config.moe_intermediate_size * config.n_shared_experts, dtype,
                                                 reduce_results=False, quant_config=quant_config_of(config))
 
-    def forward(self, hidden_states: torch.Tensor) -> torch.Tensor:
+    def forward(self, hidden_states: torch.Tensor, x_quant=None) -> torch.Tensor:
         # block-fp8: the shared experts and the routed experts read the same activation: quantise it once
         qc = self.experts.quant_config
-        x_quant = quantize_activation(hidden_states, qc.weight_block_size) \
-            if (qc is not None and self.shared_experts is not None and hidden_states.dim() == 2) else None
+        if x_quant is None and qc is not None and self.shared_experts is not None and hidden_states.dim() == 2:
+            x_quant = quantize_activation(hidden_states, qc.weight_block_size)
         shared_output = self.shared_experts(hidden_states, x_quant=x_quant) if self.shared_experts is not None else None
         router_logits = self.gate(hidden_states)
         out = self.experts(hidden_states, router_logits, x_quant=x_quant)
@@ -225,14 +225,14 @@ class DeepseekV2AttentionMLA(nn.Module):
                                        self.rotary_emb.cos_sin_cache, False)
         return latent
 
-    def forward(self, positions, hidden_states, forward_batch):
+    def forward(self, positions, hidden_states, forward_batch, x_quant=None):
         no_absorb = forward_batch.forward_mode.is_extend() and sum(forward_batch.extend_prefix_lens_cpu) == 0
         if no_absorb:
-            return self.forward_normal(positions, hidden_states, forward_batch)
-        return self.forward_absorb(positions, hidden_states, forward_batch)
+            return self.forward_normal(positions, hidden_states, forward_batch, x_quant)
+        return self.forward_absorb(positions, hidden_states, forward_batch, x_quant)
 
-    def forward_normal(self, positions, hidden_states, forward_batch):
-        xq = self._x_quant(hidden_states)
+    def forward_normal(self, positions, hidden_states, forward_batch, x_quant=None):
+        xq = x_quant if x_quant is not None else self._x_quant(hidden_states)
         q = self._q(hidden_states, xq)
         latent = self._latent(hidden_states, positions, q, xq)
         forward_batch.token_to_kv_pool.set_kv_buffer(self.attn_mha, forward_batch.out_cache_loc, latent, None)
@@ -246,8 +246,8 @@ class DeepseekV2AttentionMLA(nn.Module):
                                     forward_batch, save_kv_cache=False)
         return self.o_proj(attn_output)
 
-    def forward_absorb(self, positions, hidden_states, forward_batch):
-        xq = self._x_quant(hidden_states)
+    def forward_absorb(self, positions, hidden_states, forward_batch, x_quant=None):
+        xq = x_quant if x_quant is not None else self._x_quant(hidden_states)
         q = self._q(hidden_states, xq)
         T = q.shape[0]
         latent = self._latent(hidden_states, positions, q, xq)
@@ -274,16 +274,26 @@ class DeepseekV2DecoderLayer(nn.Module):
             config.hidden_size, config.intermediate_size, dtype, quant_config=quant_config_of(config))
         self.input_layernorm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
         self.post_attention_layernorm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+        qc = quant_config_of(config)
+        self.quant_group = int(qc.weight_block_size[1]) if (qc and config.hidden_size <= 8192) else None
 
     def forward(self, positions, hidden_states, forward_batch, residual):
+        # block-fp8: the norms quantise their output for the layers behind them in the same kernel
+        group = self.quant_group if hidden_states.dim() == 2 else None
+        attn_quant = mlp_quant = None
         if residual is None:
             residual = hidden_states
             hidden_states = self.input_layernorm(hidden_states)
+        elif group:
+            hidden_states, residual, attn_quant = self.input_layernorm.forward_quant(hidden_states, residual, group)
         else:
             hidden_states, residual = self.input_layernorm(hidden_states, residual)
-        hidden_states = self.self_attn(positions, hidden_states, forward_batch)
-        hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
-        hidden_states = self.mlp(hidden_states)
+        hidden_states = self.self_attn(positions, hidden_states, forward_batch, x_quant=attn_quant)
+        if group:
+            hidden_states, residual, mlp_quant = self.post_attention_layernorm.forward_quant(hidden_states, residual, group)
+        else:
+            hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
+        hidden_states = self.mlp(hidden_states, x_quant=mlp_quant)
         return hidden_states, residual
 
 

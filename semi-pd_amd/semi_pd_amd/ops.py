@@ -562,6 +562,24 @@ def per_token_group_quant_fp8(x: torch.Tensor, group_size: int, eps: float = 1e-
     return x_q, x_s
 
 
+def fused_add_rmsnorm_quant_fp8(input: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float,
+                                group_size: int, q_eps: float = 1e-10):
+    """fused_add_rmsnorm (in place on input / residual) plus per_token_group_quant_fp8 of the normalised rows in
+    the same kernel; returns (x_q, x_s).  Same bytes as the two calls."""
+    if input.dim() != 2 or residual.shape != input.shape or not (input.is_contiguous() and residual.is_contiguous()):
+        raise RuntimeError("fused_add_rmsnorm_quant_fp8: input / residual must be contiguous 2-D tensors of one shape")
+    if weight.shape != (input.shape[1],) or not (weight.dtype == input.dtype == residual.dtype):
+        raise RuntimeError("fused_add_rmsnorm_quant_fp8: weight shape / dtype mismatch")
+    x_q = torch.empty(input.shape, dtype=FP8_DTYPE, device=input.device)
+    x_s = torch.empty((input.shape[0], input.shape[1] // group_size), dtype=torch.float32, device=input.device)
+    lib = _lib.load()
+    check(lib.semipd_fused_add_rmsnorm_quant_fp8(ptr(input), ptr(residual), ptr(weight), ptr(x_q), ptr(x_s),
+                                                 input.shape[0], input.shape[1], float(eps), int(group_size),
+                                                 float(q_eps), dtype_code(input.dtype), current_stream(input.device)),
+          "fused_add_rmsnorm_quant_fp8")
+    return x_q, x_s
+
+
 def silu_and_mul_quant_fp8(x: torch.Tensor, group_size: int, eps: float = 1e-10):
     """silu_and_mul(x) followed by per_token_group_quant_fp8(., group_size) in one kernel: (x_q [..., d], x_s
     [..., d / group_size]) for x [..., 2 d]; the same bytes as the two calls (fused_moe.py:1104-1125)."""

@@ -160,3 +160,29 @@ def test_silu_and_mul_quant_fused_equals_the_two_calls(device, dtype):
         assert torch.equal(q.view(torch.uint8), q2.view(torch.uint8)) and torch.equal(s, s2)
     with pytest.raises(RuntimeError, match="cannot be divisible"):
         ops.silu_and_mul_quant_fp8(torch.randn(2, 200, device=device, dtype=dtype), 128)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_fused_add_rmsnorm_quant_equals_the_two_calls(device, dtype):
+    """ops.fused_add_rmsnorm_quant_fp8 == fused_add_rmsnorm then per_token_group_quant_fp8: the same normalised rows
+    and residual, bit-identical bytes and scales (against the two kernels and against the oracle)."""
+    g = torch.Generator().manual_seed(4)
+    for rows, hidden, group in [(1, 128, 128), (37, 2048, 128), (300, 7168, 128), (5, 512, 64), (3, 8192, 512)]:
+        x = torch.randn(rows, hidden, generator=g).to(dtype)
+        r = torch.randn(rows, hidden, generator=g).to(dtype)
+        w = (1 + 0.1 * torch.randn(hidden, generator=g)).to(dtype)
+        x1, r1 = x.to(device), r.to(device)
+        q, s = ops.fused_add_rmsnorm_quant_fp8(x1, r1, w.to(device), 1e-6, group)
+        x2, r2 = x.to(device), r.to(device)
+        ops.fused_add_rmsnorm(x2, r2, w.to(device), 1e-6)
+        q2, s2 = ops.per_token_group_quant_fp8(x2, group)
+        assert torch.equal(x1, x2) and torch.equal(r1, r2)
+        assert torch.equal(q.view(torch.uint8), q2.view(torch.uint8)) and torch.equal(s, s2)
+        y, _ = O.fused_add_rms_norm(x, r, w, 1e-6)
+        q_ref, s_ref = O.per_token_group_quant_fp8(x1.cpu(), group)   # quantiser on the kernel's own rows: bit-exact
+        assert torch.equal(q.cpu().view(torch.uint8), q_ref.view(torch.uint8)) and torch.equal(s.cpu(), s_ref)
+        torch.testing.assert_close(x1.cpu().float(), y.float(), rtol=1e-2, atol=1e-2)
+    with pytest.raises(RuntimeError, match="multiple of the group size"):
+        ops.fused_add_rmsnorm_quant_fp8(torch.randn(2, 200, device=device, dtype=dtype),
+                                        torch.randn(2, 200, device=device, dtype=dtype),
+                                        torch.ones(200, device=device, dtype=dtype), 1e-6, 128)
