@@ -98,6 +98,24 @@ def run_wave(engine, prompts, arrivals, output_len):
     return recs, dur
 
 
+def combine_ranks(records, elapsed, rank, world, replicas):
+    """N > 1: the timed region is as long as the slowest rank's (MAX over ranks); with independent replicas rank 0
+    also gets every replica's request records, so that `value` counts the tokens of the whole job and the latency
+    percentiles run over all requests.  (A tensor-parallel engine is driven by rank 0 alone: nothing to gather.)"""
+    if world <= 1:
+        return records, elapsed
+    import torch.distributed as dist
+    t = torch.tensor([elapsed], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    if replicas:
+        gathered = [None] * world if rank == 0 else None
+        dist.gather_object(records, gathered, dst=0)
+        if rank == 0:
+            records = [r for part in gathered for r in part]
+    return records, elapsed
+
+
 def summarize(records, duration):
     ttft, itl, out_tokens = [], [], 0
     for r in records:
@@ -281,16 +299,7 @@ def main():
                 wave_summaries.append(summarize(recs, dur))
         barrier()
         elapsed = time.time() - t0
-        if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
-        if world > 1 and not args.tp:
-            # replicas: rank 0 reports over the requests of all of them (token count, latency percentiles)
-            gathered = [None] * world if rank == 0 else None
-            dist.gather_object(all_records, gathered, dst=0)
-            if rank == 0:
-                all_records = [r for part in gathered for r in part]
+        all_records, elapsed = combine_ranks(all_records, elapsed, rank, world, replicas=not args.tp)
         stats = engine.get_stats() if (rank == 0 and not args.no_kernel_timing) else []
         sweep = []
         for rate in [float(x) for x in args.rate_sweep.split(",") if x]:
