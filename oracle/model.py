@@ -13,7 +13,6 @@ reference itself has no OPT model and its Llama cannot be imported without vLLM)
 """
 from __future__ import annotations
 
-import math
 from typing import Dict, List, Optional, Sequence
 
 import torch

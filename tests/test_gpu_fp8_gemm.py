@@ -4,7 +4,6 @@ per_token_group_quant_fp8 is elementwise IEEE arithmetic: bytes and scales must 
 oracle.  The matmuls sum exact fp8 products in fp32 in a different order than the oracle: compared with the
 reference's own criterion (mean |diff| / mean |ref| < 1e-3 for the matmul, < 2e-2 for the fused MoE,
 test/test_block_fp8.py:276-280, 397-401) and with a 20x tighter bound on f32 outputs (the inputs are uniform in +-448, so sums cancel heavily)."""
-import numpy as np
 import pytest
 import torch
 

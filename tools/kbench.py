@@ -2,7 +2,6 @@
 the achieved fraction of the HBM / MFMA roofline.  Usage: python tools/kbench.py [decode|extend|norm|moe|all]"""
 import os
 import sys
-import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "semi-pd_amd")]
