@@ -171,10 +171,12 @@ def build_app(tokenizer_manager, server_args) -> FastAPI:
         created = int(time.time())
         echo = bool(body.get("echo"))
 
+        n = int(body.get("n", 1) or 1)
+
         def prompt_text(i: int) -> str:
             if not echo:
                 return ""
-            p = prompt[i] if batch else prompt
+            p = prompt[i // n] if batch else prompt  # n > 1: choices are prompt-major
             return p if isinstance(p, str) else (tm.tokenizer.decode(p) if tm.tokenizer else "")
 
         if obj["stream"]:
@@ -210,7 +212,7 @@ def build_app(tokenizer_manager, server_args) -> FastAPI:
         choices = [{"index": i, "text": prompt_text(i) + r.get("text", ""),
                     "logprobs": _completion_logprobs(r["meta_info"], len(prompt_text(i))),
                     "finish_reason": _openai_finish(r["meta_info"])} for i, r in enumerate(rets)]
-        pt = sum(r["meta_info"]["prompt_tokens"] for r in rets)
+        pt = sum(r["meta_info"]["prompt_tokens"] for r in rets[::n])  # a prompt counts once (adapter.py:560-570)
         ct = sum(r["meta_info"]["completion_tokens"] for r in rets)
         return {"id": rid, "object": "text_completion", "created": created, "model": model_name, "choices": choices,
                 "usage": {"prompt_tokens": pt, "completion_tokens": ct, "total_tokens": pt + ct}}
@@ -248,19 +250,19 @@ def build_app(tokenizer_manager, server_args) -> FastAPI:
         created = int(time.time())
         if obj["stream"]:
             async def stream_results() -> AsyncIterator[bytes]:
-                sent = None
+                sent_by_index: Dict[int, int] = {}
                 try:
                     async for out in tm.generate_request(obj):
-                        text, meta = out.get("text", ""), out["meta_info"]
-                        if sent is None:
+                        text, meta, idx = out.get("text", ""), out["meta_info"], out.get("index", 0)
+                        if idx not in sent_by_index:
                             yield _sse({"id": rid, "object": "chat.completion.chunk", "created": created,
                                         "model": model_name,
-                                        "choices": [{"index": 0, "delta": {"role": "assistant", "content": ""},
+                                        "choices": [{"index": idx, "delta": {"role": "assistant", "content": ""},
                                                      "finish_reason": None}]})
-                            sent = 0
-                        delta, sent = text[sent:], len(text)
+                            sent_by_index[idx] = 0
+                        delta, sent_by_index[idx] = text[sent_by_index[idx]:], len(text)
                         chunk = {"id": rid, "object": "chat.completion.chunk", "created": created, "model": model_name,
-                                 "choices": [{"index": 0, "delta": {"content": delta},
+                                 "choices": [{"index": idx, "delta": {"content": delta},
                                               "logprobs": (_chat_logprobs(meta)
                                                            if meta.get("finish_reason") is not None else None),
                                               "finish_reason": _openai_finish(meta)}]}
@@ -277,12 +279,14 @@ def build_app(tokenizer_manager, server_args) -> FastAPI:
             r = await tm.generate_once(obj)
         except ValueError as e:
             return _error(str(e))
-        meta = r["meta_info"]
+        rets = r if isinstance(r, list) else [r]  # n > 1: one result per sample
+        pt = rets[0]["meta_info"]["prompt_tokens"]
+        ct = sum(x["meta_info"]["completion_tokens"] for x in rets)
         return {"id": rid, "object": "chat.completion", "created": created, "model": model_name,
-                "choices": [{"index": 0, "message": {"role": "assistant", "content": r.get("text", "")},
-                             "logprobs": _chat_logprobs(meta), "finish_reason": _openai_finish(meta)}],
-                "usage": {"prompt_tokens": meta["prompt_tokens"], "completion_tokens": meta["completion_tokens"],
-                          "total_tokens": meta["prompt_tokens"] + meta["completion_tokens"]}}
+                "choices": [{"index": i, "message": {"role": "assistant", "content": x.get("text", "")},
+                             "logprobs": _chat_logprobs(x["meta_info"]), "finish_reason": _openai_finish(x["meta_info"])}
+                            for i, x in enumerate(rets)],
+                "usage": {"prompt_tokens": pt, "completion_tokens": ct, "total_tokens": pt + ct}}
 
     @app.on_event("shutdown")
     def _shutdown():

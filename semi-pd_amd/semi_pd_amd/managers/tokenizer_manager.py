@@ -42,7 +42,7 @@ def sampling_params_from_dict(d: Optional[dict]) -> SamplingParams:
     if d.get("repetition_penalty", 1.0) != 1.0:
         raise ValueError("repetition_penalty is not supported")
     if d.get("n", 1) != 1:
-        raise ValueError("n > 1 is not supported")
+        raise ValueError("n > 1 reaches the sampler as n separate requests (generate_request expands it)")
     for k in ("json_schema", "regex", "ebnf"):
         if d.get(k):
             raise ValueError("structured output is not supported")
@@ -250,6 +250,22 @@ class TokenizerManager:
             raise ValueError("token_ids_logprob is not supported")
         is_batch = isinstance(text, list) or (isinstance(input_ids, list) and input_ids
                                                and isinstance(input_ids[0], list))
+        # parallel sampling (sampling_params.n, io_struct.py:100-160 normalize_batch_and_arguments): every prompt is
+        # sent n times, prompt-major; result i belongs to prompt i // n.  Without a radix cache the copies do not
+        # share their prefill.
+        n = int(sampling.get("n", 1) or 1) if isinstance(sampling, dict) else 1
+        if n < 1:
+            raise ValueError("n must be at least 1")
+        if n > 1:
+            sampling = dict(sampling, n=1)
+            rep = lambda xs: [x for x in xs for _ in range(n)]  # noqa: E731
+            if text is not None:
+                text = rep(text if isinstance(text, list) else [text])
+            else:
+                input_ids = rep(input_ids if is_batch else [input_ids])
+            if isinstance(rid, list):
+                raise ValueError("explicit request ids cannot be combined with n > 1")
+            rid, is_batch = None, True
         if not is_batch:
             g = self._one(text, input_ids, sampling, stream, rid, return_logprob, top_num, text_in_lp)
             try:

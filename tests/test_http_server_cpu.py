@@ -252,3 +252,22 @@ def test_stop_strings_cut_the_text_and_abort_the_request(client):
     # a request that ends by itself is not aborted
     client.post("/generate", json={"text": "alpha", "sampling_params": {"max_new_tokens": 2, "stop": ["zeta"]}})
     assert len(client.engine.aborted) == 2
+
+
+def test_parallel_sampling_n(client):
+    """n > 1 (OpenAI `n`, native sampling_params.n): every prompt is run n times, choices are prompt-major, a prompt's
+    tokens are counted once in `usage`."""
+    r = client.post("/v1/completions", json={"prompt": "alpha", "max_tokens": 3, "n": 3})
+    body = r.json()
+    assert r.status_code == 200 and [c["index"] for c in body["choices"]] == [0, 1, 2]
+    assert len({c["text"] for c in body["choices"]}) == 1            # the scripted engine is deterministic
+    assert body["usage"]["prompt_tokens"] == 1 and body["usage"]["completion_tokens"] == 9
+    r = client.post("/v1/completions", json={"prompt": ["alpha", "gamma delta"], "max_tokens": 2, "n": 2, "echo": True})
+    texts = [c["text"] for c in r.json()["choices"]]
+    assert len(texts) == 4 and texts[0] == texts[1] and texts[2] == texts[3]
+    assert texts[0].startswith("alpha") and texts[2].startswith("gamma delta")
+    assert r.json()["usage"]["prompt_tokens"] == 3
+    r = client.post("/generate", json={"text": "alpha", "sampling_params": {"max_new_tokens": 2, "n": 2}})
+    assert r.status_code == 200 and isinstance(r.json(), list) and len(r.json()) == 2
+    r = client.post("/generate", json={"text": "alpha", "sampling_params": {"n": 0}})
+    assert r.status_code == 400
