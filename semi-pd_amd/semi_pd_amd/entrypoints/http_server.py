@@ -43,7 +43,7 @@ def _openai_sampling(body: dict, default_max_tokens: Optional[int]) -> dict:
     if mt is not None:
         sp["max_new_tokens"] = int(mt)
     for k in ("top_k", "min_p", "ignore_eos", "stop_token_ids", "frequency_penalty", "presence_penalty",
-              "repetition_penalty", "skip_special_tokens"):
+              "repetition_penalty", "min_new_tokens", "skip_special_tokens"):
         if body.get(k) is not None:
             sp[k] = body[k]
     if body.get("stop"):

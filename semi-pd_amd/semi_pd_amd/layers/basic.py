@@ -461,9 +461,19 @@ class Sampler(nn.Module):
 
     def forward(self, logits_output: LogitsProcessorOutput, sampling_info=None, return_logprob: bool = False,
                 top_logprobs_nums: Optional[list] = None) -> torch.Tensor:
+        penalised = sampling_info is not None and getattr(sampling_info, "has_penalties", False)
+        if penalised:
+            # sampling_batch_info.py:188-191: penalties change the fp32 logits before anything else looks at them;
+            # ids the fused lm_head call produced from the raw logits no longer hold
+            logits = logits_output.next_token_logits
+            if logits is None:
+                raise RuntimeError("Sampler: penalties need the fp32 logits")
+            if logits.dtype != torch.float32 or not logits.is_contiguous():
+                logits = logits_output.next_token_logits = logits.float().contiguous()
+            sampling_info.apply_penalties(logits)
         if sampling_info is None or getattr(sampling_info, "is_all_greedy", True):
             logits = logits_output.next_token_logits
-            if logits_output.next_token_ids is not None:
+            if logits_output.next_token_ids is not None and not penalised:
                 ids = logits_output.next_token_ids
             else:
                 if not logits.is_contiguous():

@@ -19,6 +19,9 @@ class SamplingParams:
     min_p: float = 0.0
     ignore_eos: bool = False
     stop_token_ids: Optional[List[int]] = None
+    frequency_penalty: float = 0.0   # logits -= f * (times the token was generated)   (penaltylib/frequency_penalty.py)
+    presence_penalty: float = 0.0    # logits -= p * (the token was generated at all)  (penaltylib/presence_penalty.py)
+    min_new_tokens: int = 0          # stop / EOS tokens cannot be sampled before this many (penaltylib/min_new_tokens.py)
 
     def __post_init__(self):
         self.verify()
@@ -44,10 +47,25 @@ class SamplingParams:
             raise ValueError(f"top_k must be -1 (disable), or at least 1, got {self.top_k}.")
         if self.max_new_tokens is not None and self.max_new_tokens < 0:
             raise ValueError(f"max_new_tokens must be at least 0, got {self.max_new_tokens}.")
+        if not -2.0 <= self.frequency_penalty <= 2.0:
+            raise ValueError(f"frequency_penalty must be in [-2, 2], got {self.frequency_penalty}.")
+        if not -2.0 <= self.presence_penalty <= 2.0:
+            raise ValueError(f"presence_penalty must be in [-2, 2], got {self.presence_penalty}.")
+        if self.min_new_tokens < 0:
+            raise ValueError(f"min_new_tokens must be in (0, max_new_tokens], got {self.min_new_tokens}.")
+        if self.max_new_tokens is not None and self.min_new_tokens > self.max_new_tokens:
+            raise ValueError(f"min_new_tokens must be in (0, max_new_tokens({self.max_new_tokens})], "
+                             f"got {self.min_new_tokens}.")
 
     @property
     def is_greedy(self) -> bool:
         return self.top_k <= 1
+
+    @property
+    def needs_penalties(self) -> bool:
+        """True when the logits of this request depend on its own generated tokens (penaltylib/orchestrator.py
+        is_required): the overlapped decode loop must then have every earlier token on the host first."""
+        return self.frequency_penalty != 0.0 or self.presence_penalty != 0.0 or self.min_new_tokens > 0
 
 
 @dataclass

@@ -218,8 +218,11 @@ class SemiPDDecodeScheduler(SchedulerBase):
         recv = self.recv_requests()
         self.process_input_requests(recv)
         rb = self.running_batch
+        # penalties are a function of a request's generated tokens (sampling_batch_info.py): while any running
+        # request has them, each step waits for the previous one's ids, i.e. the loop degrades to the plain one
+        needs_history = any(r.sampling_params.needs_penalties for r in rb.reqs)
         if self._pending is not None and not rb.is_empty() and \
-                (not rb.check_decode_mem(2) or self.forced_retractions(rb)):
+                (needs_history or not rb.check_decode_mem(2) or self.forced_retractions(rb)):
             # a retraction re-sends origin_input_ids + output_ids: every sampled token must be on the host first
             self._drain_pending()
         batch = self.get_next_batch_to_run()

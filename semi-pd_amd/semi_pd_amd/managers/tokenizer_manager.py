@@ -18,7 +18,8 @@ from typing import Any, AsyncIterator, Dict, List, Optional, Union
 
 from semi_pd_amd.managers.io_struct import SamplingParams
 
-_SAMPLING_KEYS = ("max_new_tokens", "temperature", "top_p", "top_k", "min_p", "ignore_eos", "stop_token_ids")
+_SAMPLING_KEYS = ("max_new_tokens", "temperature", "top_p", "top_k", "min_p", "ignore_eos", "stop_token_ids",
+                  "frequency_penalty", "presence_penalty", "min_new_tokens")
 
 
 def get_tokenizer(path: str):
@@ -32,14 +33,11 @@ def sampling_params_from_dict(d: Optional[dict]) -> SamplingParams:
     d = dict(d or {})
     unknown = [k for k in d if k not in _SAMPLING_KEYS and k not in (
         "stop", "n", "skip_special_tokens", "spaces_between_special_tokens", "no_stop_trim",
-        "frequency_penalty", "presence_penalty", "repetition_penalty", "min_new_tokens", "json_schema", "regex",
-        "ebnf", "custom_params", "max_tokens")]
+        "repetition_penalty", "json_schema", "regex", "ebnf", "custom_params", "max_tokens")]
     if unknown:
         raise ValueError(f"unknown sampling parameters: {unknown}")
-    for k in ("frequency_penalty", "presence_penalty"):
-        if d.get(k):
-            raise ValueError(f"{k} is not supported")
     if d.get("repetition_penalty", 1.0) != 1.0:
+        # the reference accepts the field but has no penalizer for it (sampling/penaltylib/__init__.py): say so
         raise ValueError("repetition_penalty is not supported")
     if d.get("n", 1) != 1:
         raise ValueError("n > 1 reaches the sampler as n separate requests (generate_request expands it)")

@@ -93,7 +93,8 @@ def args(**kw):
     return ServerArgs(**base)
 
 
-def run_semi_pd(prompts, max_new, sa, size=4000, force_retract=0, interleave=True):
+def run_semi_pd(prompts, max_new, sa, size=4000, force_retract=0, interleave=True, sampling_kw=None,
+                worker_cls=None):
     d_runner = make_runner(size=size)
     p_runner = make_runner(shared=d_runner, size=size)
     kv = torch.zeros(size + 1, dtype=torch.int64)
@@ -103,12 +104,12 @@ def run_semi_pd(prompts, max_new, sa, size=4000, force_retract=0, interleave=Tru
     d = SemiPDDecodeScheduler(sa, d_runner, 0, d_in, out, bridge, p_in)
     p = SemiPDPrefillScheduler(sa, p_runner, 0, p_in, d_in, bridge)
     holder["d"] = d
-    d.tp_worker, p.tp_worker = FakeWorker(d_runner, kv), FakeWorker(p_runner, kv)
+    d.tp_worker, p.tp_worker = (worker_cls or FakeWorker)(d_runner, kv), FakeWorker(p_runner, kv)
     if force_retract:
         d.forced_retractions = lambda batch: force_retract if batch.batch_size() > 4 else 0
     got = {}
-    reqs = [TokenizedGenerateReqInput(f"r{i}", None, list(pr), SamplingParams(max_new_tokens=max_new, ignore_eos=True))
-            for i, pr in enumerate(prompts)]
+    reqs = [TokenizedGenerateReqInput(f"r{i}", None, list(pr), SamplingParams(
+        max_new_tokens=max_new, ignore_eos=True, **((sampling_kw or (lambda i: {}))(i)))) for i, pr in enumerate(prompts)]
     pending = collections.deque(reqs)
     for it in range(20000):
         if pending and (not interleave or it % 3 == 0):
@@ -216,3 +217,49 @@ def test_plain_and_overlapped_decode_loops_agree():
             assert d.enable_overlap == (not plain)
             outs[plain] = got
         assert outs[False] == outs[True] == [expected(p, 9) for p in prompts]
+
+
+def test_penalties_see_every_generated_token_in_the_overlapped_loop():
+    """Penalties are a function of a request's generated tokens (sampling/penaltylib).  The overlapped loop launches
+    step k + 1 before the token of step k has reached the host, so while a running request asks for penalties each
+    step waits for the previous one's ids: the penalty entries handed to the worker must then count every token
+    generated so far, for every such request, at every step.  Requests without penalties in the same batch are
+    unaffected, and the tokens stay the history-rule tokens (the fake worker does not apply the penalties)."""
+    prompts = prompts_of([5, 40, 17, 9, 33, 8])
+    plen = {}
+    seen = {"steps": 0, "rows": 0}
+
+    class CheckingWorker(FakeWorker):
+        def forward_batch_generation(self, mwb):
+            info = mwb.sampling_info
+            rows = [i for i, r in enumerate(self.batch_reqs()) if r.sampling_params.frequency_penalty]
+            if rows:
+                assert info.has_penalties
+                seen["steps"] += 1
+                for i in rows:
+                    r = self.batch_reqs()[i]
+                    counted = info.pen_vals[info.pen_rows == i].sum().item()
+                    generated = int(mwb.seq_lens[i]) - len(r.origin_input_ids)
+                    assert counted == generated == len(r.output_ids), (r.rid, counted, generated, len(r.output_ids))
+                    seen["rows"] += 1
+            return super().forward_batch_generation(mwb)
+
+    holder = {}
+    CheckingWorker.batch_reqs = lambda self: holder["d"].running_batch.reqs
+    for kw in (dict(), dict(force_retract=2)):
+        seen.update(steps=0, rows=0)
+        # run_semi_pd gives the worker no handle on the scheduler: take it from the first get_next_batch_to_run
+        orig = SemiPDDecodeScheduler.get_next_batch_to_run
+
+        def spy(self_):
+            holder["d"] = self_
+            return orig(self_)
+
+        SemiPDDecodeScheduler.get_next_batch_to_run = spy
+        try:
+            got, d, _ = run_semi_pd(prompts, 9, args(), worker_cls=CheckingWorker, force_retract=kw.get("force_retract", 0),
+                                    sampling_kw=lambda i: {"frequency_penalty": 1.0} if i % 2 == 0 else {})
+        finally:
+            SemiPDDecodeScheduler.get_next_batch_to_run = orig
+        assert d.enable_overlap and got == [expected(p, 9) for p in prompts]
+        assert seen["steps"] >= 8 and seen["rows"] >= 3 * 8
