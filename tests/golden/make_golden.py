@@ -393,8 +393,69 @@ def gen_fp8():
     save("block_fp8", **arrs)
 
 
+def gen_penalties():
+    """The reference's batched penalizers (sampling/penaltylib/*.py) driven the way ScheduleBatch drives them:
+    an orchestrator per new prefill batch, apply -> sample -> cumulate every step, merge into the running batch
+    (orchestrator.py merge, before reqs is extended), filter when a request finishes.  Stored: raw logits, the
+    penalised logits and the sampled ids of every step plus which requests formed the batch."""
+    from types import SimpleNamespace as NS
+    import sglang.srt.sampling.penaltylib as PL
+    g = torch.Generator().manual_seed(8)
+    V, EOS = 64, 7
+    # frequency, presence, min_new_tokens, stop ids (-1 padded)
+    params = [(0.7, -0.3, 0, []), (0.0, 0.0, 0, []), (0.0, 0.0, 5, [11, 12]), (0.0, 1.5, 2, []), (2.0, 0.0, 0, [3])]
+
+    def req(i):
+        f, p, m, stops = params[i]
+        return NS(sampling_params=NS(frequency_penalty=f, presence_penalty=p, min_new_tokens=m,
+                                     stop_token_ids=set(stops) or None),
+                  tokenizer=NS(additional_stop_token_ids=None, eos_token_id=EOS), idx=i)
+
+    def orch(reqs):
+        return PL.BatchedPenalizerOrchestrator(V, NS(reqs=reqs, device="cpu"), {
+            PL.BatchedFrequencyPenalizer, PL.BatchedMinNewTokensPenalizer, PL.BatchedPresencePenalizer})
+
+    arrs = {"params": np.array([[f, p, m] for f, p, m, _ in params], dtype=np.float64),
+            "stops": np.array([(s + [-1, -1])[:2] for *_, s in params], dtype=np.int64), "eos": np.array(EOS)}
+    step = [0]
+
+    def run(o):
+        rows = [r.idx for r in o.batch.reqs]
+        logits = torch.randn(len(rows), V, generator=g)
+        want = logits.clone()
+        o.apply(want)
+        ids = torch.randint(0, 16, (len(rows),), generator=g)   # a small range, so that tokens repeat
+        k = step[0]
+        arrs[f"rows_{k}"], arrs[f"logits_{k}"], arrs[f"want_{k}"], arrs[f"ids_{k}"] = (
+            np.array(rows), logits.numpy(), want.numpy(), ids.numpy())
+        step[0] += 1
+        o.cumulate_output_tokens(ids)
+
+    a = orch([req(0), req(1), req(2)])
+    for _ in range(4):                   # the prefill sample and three decode steps
+        run(a)
+    b = orch([req(3), req(4)])
+    run(b)                               # the new batch's prefill sample
+    a.merge(b)
+    a.batch.reqs.extend(b.batch.reqs)
+    for _ in range(3):
+        run(a)
+    keep = [1, 2, 3, 4]                  # request 0 finishes
+    a.batch.reqs = [a.batch.reqs[i] for i in keep]
+    a.filter(torch.tensor(keep))
+    for _ in range(3):
+        run(a)
+    keep = [0, 2]                        # the requests with min_new_tokens / frequency penalty finish
+    a.batch.reqs = [a.batch.reqs[i] for i in keep]
+    a.filter(torch.tensor(keep))
+    for _ in range(2):
+        run(a)
+    arrs["n_steps"] = np.array(step[0])
+    save("penalties", **arrs)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rmsnorm", "rope", "kv_indices", "topk", "decode", "extend", "sampling", "fp8"]
+    which = sys.argv[1:] or ["rmsnorm", "rope", "kv_indices", "topk", "decode", "extend", "sampling", "fp8", "penalties"]
     for w in which:
         {"rmsnorm": gen_rmsnorm, "rope": gen_rope, "kv_indices": gen_kv_indices, "topk": gen_topk,
-         "decode": gen_decode, "extend": gen_extend, "sampling": gen_sampling, "fp8": gen_fp8}[w]()
+         "decode": gen_decode, "extend": gen_extend, "sampling": gen_sampling, "fp8": gen_fp8, "penalties": gen_penalties}[w]()

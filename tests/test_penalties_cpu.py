@@ -111,3 +111,31 @@ def test_validation_follows_the_reference():
     assert not sampling_params_from_dict({}).needs_penalties
     with pytest.raises(ValueError):
         sampling_params_from_dict({"repetition_penalty": 1.3})
+
+
+def test_against_the_reference_penalizers_golden():
+    """tests/golden/penalties.npz was produced by the reference's own BatchedPenalizerOrchestrator (frequency,
+    presence, min_new_tokens) driven through prefill sample -> decode steps -> merge of a new batch -> two filters
+    (make_golden.py gen_penalties).  The per-step sparse rebuild must reproduce every penalised logit row: same
+    -inf pattern, values within fp32 accumulation error (the reference adds f once per occurrence)."""
+    import os
+    import numpy as np
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "penalties.npz"))
+    eos = {int(z["eos"])}
+    reqs = []
+    for (f, p, m), stops in zip(z["params"], z["stops"]):
+        sp = SamplingParams(max_new_tokens=64, frequency_penalty=float(f), presence_penalty=float(p),
+                            min_new_tokens=int(m), stop_token_ids=[int(s) for s in stops if s >= 0] or None)
+        reqs.append(Req(f"g{len(reqs)}", [1, 2], sp, eos_token_ids=eos))
+    changed = 0
+    for k in range(int(z["n_steps"])):
+        batch = [reqs[i] for i in z[f"rows_{k}"]]
+        logits = torch.from_numpy(z[f"logits_{k}"]).clone()
+        want = torch.from_numpy(z[f"want_{k}"])
+        SamplingBatchInfo.from_reqs(batch, logits.shape[1], "cpu").apply_penalties(logits)
+        assert torch.equal(torch.isinf(logits), torch.isinf(want)), k
+        assert torch.allclose(logits, want, rtol=0, atol=1e-5), k
+        changed += int((want != torch.from_numpy(z[f"logits_{k}"])).sum())
+        for r, t in zip(batch, z[f"ids_{k}"]):
+            r.output_ids.append(int(t))
+    assert changed > 50    # the golden is not trivially the identity (93 penalised entries)
