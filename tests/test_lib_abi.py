@@ -69,3 +69,21 @@ def test_cu_mask_fill_is_balanced():
         assert sum(1 for i in bits_hi if i % 8 == xcd) == 16
     n80 = lib.semipd_cu_mask_fill(256, 80, 0, C.addressof(lo), words)
     assert n80 == 208 and n80 % 8 == 0
+
+
+def test_integration_appendix_names_every_entry_point():
+    """INTEGRATION.md's appendix (tools/abi_table.py --write) is generated from the header: it must be current and
+    name every declared symbol with the reference interface its declaration cites."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("abi_table", os.path.join(root, "tools", "abi_table.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    assert mod.BEGIN in text and mod.END in text
+    block = text[text.index(mod.BEGIN) + len(mod.BEGIN):text.index(mod.END)].strip()
+    assert block == mod.table(), "run `python tools/abi_table.py --write`"
+    names = [n for n, _, _ in mod.entries()]
+    assert len(names) == len(set(names)) >= 58
+    for n in names:
+        assert f"| `{n}` |" in block
