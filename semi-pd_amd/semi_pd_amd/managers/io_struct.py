@@ -78,6 +78,9 @@ class TokenizedGenerateReqInput:
     return_logprob: bool = False
     top_logprobs_num: int = 0
     is_retracted: bool = False  # Semi-PD: re-sent to P after a decode retraction
+    # how many of the LAST input_ids of a retracted request are tokens it generated (penalties count those; the
+    # reference drops this history on the prefill instance)
+    retracted_output_len: int = 0
 
 
 @dataclass

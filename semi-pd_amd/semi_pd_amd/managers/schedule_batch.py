@@ -43,6 +43,7 @@ class Req:
         self.extend_input_len = 0
         self.is_chunked = 0
         self.is_retracted = is_retracted
+        self.retracted_output_len = 0  # prefill instance: the last k prompt tokens were generated before a retraction
         self.finished_reason: Optional[str] = None
         self.to_abort = False  # set by AbortReq; turns into finished_reason "abort" at the next check
         self.send_token_offset = 0

@@ -118,6 +118,7 @@ class SchedulerBase:
         req = Req(recv_req.rid, recv_req.input_ids, recv_req.sampling_params, self.eos_token_ids,
                   is_retracted=recv_req.is_retracted, return_logprob=recv_req.return_logprob,
                   top_logprobs_num=recv_req.top_logprobs_num)
+        req.retracted_output_len = getattr(recv_req, "retracted_output_len", 0)
         if len(req.origin_input_ids) > self.max_req_input_len:
             # validate_input_length (scheduler.py:760-775): truncate
             req.origin_input_ids = req.origin_input_ids[: self.max_req_input_len]

@@ -63,7 +63,7 @@ class SemiPDDecodeScheduler(SchedulerBase):
             message = TokenizedGenerateReqInput(
                 rid=req.rid, input_text=None, input_ids=req.origin_input_ids + req.output_ids,
                 sampling_params=req.sampling_params, is_retracted=True, return_logprob=req.return_logprob,
-                top_logprobs_num=req.top_logprobs_num)
+                top_logprobs_num=req.top_logprobs_num, retracted_output_len=len(req.output_ids))
             self.waiting_queue.insert(0, req)
             if self.tp_rank == 0:
                 self.send_to_p_instance.send_pyobj(message)

@@ -57,11 +57,15 @@ class SamplingBatchInfo:
         limit = vocab_size if vocab_size > 0 else 1 << 62   # unknown here: apply_penalties guards against the width
         for i, r in enumerate(reqs):
             sp = r.sampling_params
-            if (sp.frequency_penalty != 0.0 or sp.presence_penalty != 0.0) and r.output_ids:
-                for t, c in Counter(r.output_ids).items():
+            generated = r.output_ids
+            k = getattr(r, "retracted_output_len", 0)
+            if k:  # prefill instance, request re-sent after a retraction: its generated tokens end the prompt
+                generated = r.origin_input_ids[max(0, len(r.origin_input_ids) - k):] + r.output_ids
+            if (sp.frequency_penalty != 0.0 or sp.presence_penalty != 0.0) and generated:
+                for t, c in Counter(generated).items():
                     if 0 <= t < limit:
                         rows.append(i), toks.append(t), vals.append(sp.frequency_penalty * c + sp.presence_penalty)
-            if len(r.output_ids) < sp.min_new_tokens:
+            if len(generated) < sp.min_new_tokens:
                 for t in set(sp.stop_token_ids or ()) | set(getattr(r, "eos_token_ids", None) or ()):
                     if 0 <= t < limit:
                         rows.append(i), toks.append(t), vals.append(float("inf"))

@@ -139,3 +139,22 @@ def test_against_the_reference_penalizers_golden():
         for r, t in zip(batch, z[f"ids_{k}"]):
             r.output_ids.append(int(t))
     assert changed > 50    # the golden is not trivially the identity (93 penalised entries)
+
+
+def test_retracted_request_keeps_its_history_on_the_prefill_instance():
+    """After a retraction the decode instance re-sends prompt + generated tokens as the new prompt
+    (semi_pd_decode_scheduler.py:117-139).  The message says how many of its last ids were generated, so the prefill
+    instance's sample for the next token is penalised like the unified engine's (the reference loses that history)."""
+    sp = dict(max_new_tokens=32, frequency_penalty=1.0, min_new_tokens=4, stop_token_ids=[9])
+    whole = Req("u", [1, 2, 3], SamplingParams(**sp))
+    whole.output_ids = [5, 6, 5]                       # the unified engine / the decode instance's view
+    resent = Req("p", [1, 2, 3, 5, 6, 5], SamplingParams(**sp), is_retracted=True)
+    resent.retracted_output_len = 3                    # the prefill instance's view
+    a, b = (SamplingBatchInfo.from_reqs([r], V, "cpu") for r in (whole, resent))
+    la, lb = torch.zeros(1, V), torch.zeros(1, V)
+    a.apply_penalties(la), b.apply_penalties(lb)
+    assert torch.equal(la, lb) and la[0, 5] == -2 and la[0, 6] == -1 and la[0, 9] == float("-inf") and la[0, 1] == 0
+    resent.output_ids.append(7)                        # 4 generated tokens: stop ids are allowed again
+    lc = torch.zeros(1, V)
+    SamplingBatchInfo.from_reqs([resent], V, "cpu").apply_penalties(lc)
+    assert lc[0, 9] == 0 and lc[0, 7] == -1
