@@ -353,12 +353,18 @@ class Scheduler(SchedulerBase):
                 self.req_to_token_pool.free(self.chunked_req.req_pool_idx)
                 self.running_batch.batch_is_full = False
             else:
+                last_bs = self.last_batch.batch_size()
                 self.last_batch.filter_batch()
+                if self.last_batch.batch_size() < last_bs:
+                    # requests that ended at their first token gave their slots back (scheduler.py:1043-1047)
+                    self.running_batch.batch_is_full = False
             if not self.last_batch.is_empty():
                 if self.running_batch.is_empty():
                     self.running_batch = self.last_batch
                 else:
                     self.running_batch.merge_batch(self.last_batch)
+        if self.running_batch.is_empty():
+            self.running_batch.batch_is_full = False  # nothing runs: every slot is free again
         new_batch = self.get_new_batch_prefill()
         if new_batch is not None:
             return new_batch

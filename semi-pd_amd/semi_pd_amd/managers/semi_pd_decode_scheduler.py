@@ -174,7 +174,13 @@ class SemiPDDecodeScheduler(SchedulerBase):
             barrier_cpu()
         batch.output_ids = host_list_to_device(recv_req.next_token_ids, torch.int64, self.device)
         self.process_batch_result_prefill(batch, recv_req.next_token_ids, recv_req.next_token_logprobs)
+        n_before = len(batch.reqs)
         batch.filter_batch(chunked_req_to_exclude=self.chunked_req)
+        if len(batch.reqs) < n_before or self.running_batch.is_empty():
+            # requests that ended at their first token (max_new_tokens = 1, EOS) free their slots here; the
+            # "full" flag is otherwise only cleared by update_running_batch, which never runs on an empty
+            # running batch (the unified path resets it when the last batch shrinks, scheduler.py:1043-1047)
+            self.running_batch.batch_is_full = False
         if not batch.is_empty():
             if self.running_batch.is_empty():
                 self.running_batch = batch

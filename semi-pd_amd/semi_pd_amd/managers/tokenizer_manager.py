@@ -129,6 +129,8 @@ class TokenizerManager:
             raise ValueError("input_ids out of the vocabulary range")
         if sp.max_new_tokens is None or len(ids) + sp.max_new_tokens > ctx:
             sp.max_new_tokens = ctx - len(ids)  # tokenizer_manager.py: clipped to the context window
+            if getattr(sp, "min_new_tokens", 0) > sp.max_new_tokens:
+                sp.min_new_tokens = sp.max_new_tokens  # a clipped request must still be allowed to stop
 
     @staticmethod
     def _finish_dict(reason: Optional[str], completion_tokens: int, last_token: Optional[int]):
@@ -282,9 +284,28 @@ class TokenizerManager:
         gens = [self._one(texts[i], idss[i], samplings[i], stream, rids[i], return_logprob, top_num, text_in_lp)
                 for i in range(n)]
         if not stream:
-            results = await asyncio.gather(*[g.__anext__() for g in gens])
-            for g in gens:
-                await g.aclose()
+            # one failing sub-request (e.g. a validation error) must not leave its siblings running: stop at the first
+            # exception, cancel the rest, close every generator (per-request cleanup + abort of what is still in
+            # flight), then re-raise
+            tasks = [asyncio.ensure_future(g.__anext__()) for g in gens]
+            try:
+                done, pending = await asyncio.wait(tasks, return_when=asyncio.FIRST_EXCEPTION)
+                for t in pending:
+                    t.cancel()
+                if pending:
+                    await asyncio.gather(*pending, return_exceptions=True)
+                for t in tasks:
+                    if t in done and t.exception() is not None:
+                        raise t.exception()
+                results = [t.result() for t in tasks]
+            finally:
+                for t in tasks:
+                    t.cancel()
+                for g in gens:
+                    try:
+                        await g.aclose()
+                    except RuntimeError:
+                        pass  # generator still unwinding from the cancellation
             yield list(results)
             return
         queue: asyncio.Queue = asyncio.Queue()

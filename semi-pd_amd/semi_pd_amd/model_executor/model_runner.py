@@ -143,6 +143,10 @@ class ModelRunner:
             init_distributed_environment(1, 0, "", dist_backend)
         self.num_cus = get_device_sm_count(gpu_id)
         self.num_cus_owned = max(8, self.num_cus * cu_percent // 100)
+        # --random-seed reaches the stochastic sampler through the default device generator, the same on every
+        # TP rank and in both instances (model_runner.py: set_random_seed in every worker)
+        torch.manual_seed(seed)
+        torch.cuda.manual_seed_all(seed)
 
         # ---- model -------------------------------------------------------------------------
         from semi_pd_amd.layers.moe import set_expert_parallel

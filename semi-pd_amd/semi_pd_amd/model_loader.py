@@ -42,6 +42,16 @@ def config_from_hf_dict(d: dict):
     names = {f.name for f in dataclasses.fields(cls)}
     if d.get("quantization_config") and "quantization_config" not in names:
         raise ValueError(f"{arch}: quantised checkpoints are supported for the DeepSeek family only")
+    # config keys that change the computation and have no implementation here must not be dropped silently:
+    # the checkpoint would load (unmatched bias tensors) and produce wrong logits
+    if arch == "LlamaForCausalLM":
+        for key in ("attention_bias", "mlp_bias"):
+            if d.get(key):
+                raise ValueError(f"{arch}: {key}=true checkpoints are not supported (linears run without bias)")
+        if d.get("hidden_act", "silu") != "silu":
+            raise ValueError(f"{arch}: hidden_act={d['hidden_act']!r} is not supported (SiLU * mul only)")
+    if arch in ("DeepseekV2ForCausalLM", "DeepseekV3ForCausalLM") and d.get("attention_bias"):
+        raise ValueError(f"{arch}: attention_bias=true checkpoints are not supported")
     kw = {k: v for k, v in d.items() if k in names and k != "architectures"}
     return cls(architectures=(arch,), **kw)
 
@@ -157,8 +167,8 @@ def load_weights(model: nn.Module, config, weights: Iterable[Tuple[str, torch.Te
     loaded = []
     for name, full in product_items(config, weights):
         if name not in params:
-            if name.endswith(".bias") or "rotary" in name:
-                continue  # e.g. attention biases of architectures we run without them are rejected above
+            if "rotary_emb" in name:
+                continue  # recomputed caches (inv_freq, cos / sin); behaviour-changing extras are rejected above
             raise KeyError(f"checkpoint tensor {name} has no counterpart in {type(model).__name__}")
         p = params[name]
         if (p.dtype == torch.float8_e4m3fn) != (full.dtype == torch.float8_e4m3fn):

@@ -138,3 +138,24 @@ def test_block_fp8_checkpoint_names_and_flags(tmp_path):
         "num_hidden_layers": 2, "num_attention_heads": 4, "num_key_value_heads": 2, "quantization_config": qc}))
     with pytest.raises(ValueError, match="DeepSeek family"):
         parse(["--model-path", str(tmp_path)])
+
+
+def test_behaviour_changing_config_keys_are_rejected(tmp_path):
+    """A Llama checkpoint with attention / MLP biases (or another activation) must not load as if it had none."""
+    base = dict(architectures=["LlamaForCausalLM"], vocab_size=320, hidden_size=64, intermediate_size=96,
+                num_hidden_layers=1, num_attention_heads=4, num_key_value_heads=2)
+    config_from_hf_dict(dict(base, attention_bias=False, mlp_bias=False, hidden_act="silu"))
+    for extra in (dict(attention_bias=True), dict(mlp_bias=True), dict(hidden_act="gelu")):
+        with pytest.raises(ValueError):
+            config_from_hf_dict(dict(base, **extra))
+    # and a stray tensor that matches no parameter is an error, not a silent skip
+    torch.manual_seed(0)
+    hf = transformers.LlamaForCausalLM(transformers.LlamaConfig(
+        vocab_size=320, hidden_size=64, intermediate_size=96, num_hidden_layers=1, num_attention_heads=4,
+        num_key_value_heads=2, max_position_embeddings=64, tie_word_embeddings=False))
+    hf.save_pretrained(tmp_path, safe_serialization=True)
+    cfg = load_hf_config(str(tmp_path))
+    model = build_model(cfg, torch.float32)
+    weights = list(safetensors_weights_iterator(str(tmp_path))) + [("model.layers.0.self_attn.o_proj.bias", torch.zeros(64))]
+    with pytest.raises(KeyError):
+        load_weights(model, cfg, weights)

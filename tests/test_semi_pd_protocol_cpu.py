@@ -108,8 +108,9 @@ def run_semi_pd(prompts, max_new, sa, size=4000, force_retract=0, interleave=Tru
     if force_retract:
         d.forced_retractions = lambda batch: force_retract if batch.batch_size() > 4 else 0
     got = {}
+    new_of = max_new if isinstance(max_new, (list, tuple)) else [max_new] * len(prompts)  # per request or one for all
     reqs = [TokenizedGenerateReqInput(f"r{i}", None, list(pr), SamplingParams(
-        max_new_tokens=max_new, ignore_eos=True, **((sampling_kw or (lambda i: {}))(i)))) for i, pr in enumerate(prompts)]
+        max_new_tokens=new_of[i], ignore_eos=True, **((sampling_kw or (lambda i: {}))(i)))) for i, pr in enumerate(prompts)]
     pending = collections.deque(reqs)
     for it in range(20000):
         if pending and (not interleave or it % 3 == 0):
@@ -122,7 +123,7 @@ def run_semi_pd(prompts, max_new, sa, size=4000, force_retract=0, interleave=Tru
             o = out.q.popleft()
             for rid, toks in zip(o.rids, o.output_ids):
                 got.setdefault(rid, []).extend(toks)
-        if not pending and len(got) == len(reqs) and all(len(v) >= max_new for v in got.values()):
+        if not pending and len(got) == len(reqs) and all(len(got[f"r{i}"]) >= n for i, n in enumerate(new_of)):
             break
     for _ in range(3):  # the event loops keep running: the overlapped decode loop still holds its last (surplus) step
         p.step()
@@ -135,24 +136,25 @@ def run_semi_pd(prompts, max_new, sa, size=4000, force_retract=0, interleave=Tru
     return [got[f"r{i}"] for i in range(len(reqs))], d, p
 
 
-def run_unified(prompts, max_new, sa):
-    runner = make_runner()
-    kv = torch.zeros(4001, dtype=torch.int64)
+def run_unified(prompts, max_new, sa, size=4000):
+    runner = make_runner(size=size)
+    kv = torch.zeros(size + 1, dtype=torch.int64)
     inbox, out = Q(), Q()
     s = Scheduler(sa, runner, 0, inbox, out)
     s.tp_worker = FakeWorker(runner, kv)
+    new_of = max_new if isinstance(max_new, (list, tuple)) else [max_new] * len(prompts)
     for i, pr in enumerate(prompts):
         inbox.send_pyobj(TokenizedGenerateReqInput(f"r{i}", None, list(pr),
-                                                   SamplingParams(max_new_tokens=max_new, ignore_eos=True)))
+                                                   SamplingParams(max_new_tokens=new_of[i], ignore_eos=True)))
     got = {}
     for _ in range(20000):
-        if not s.step() and len(got) == len(prompts) and all(len(v) >= max_new for v in got.values()):
+        if not s.step() and len(got) == len(prompts) and all(len(got[f"r{i}"]) >= n for i, n in enumerate(new_of)):
             break
         while out.q:
             o = out.q.popleft()
             for rid, toks in zip(o.rids, o.output_ids):
                 got.setdefault(rid, []).extend(toks)
-    assert runner.token_to_kv_pool_allocator.available_size() == 4000
+    assert runner.token_to_kv_pool_allocator.available_size() == size
     return [got[f"r{i}"] for i in range(len(prompts))]
 
 
@@ -201,6 +203,29 @@ def test_single_token_requests_finish_at_prefill():
     got, d, p = run_semi_pd(prompts, 1, args())
     assert got == [expected(p_, 1) for p_ in prompts]
     assert d.stats["decode_tokens"] == 0
+
+
+def test_one_token_requests_do_not_leave_the_full_flag_set():
+    """A prefill batch whose requests all end at their first token (max_new_tokens = 1) merges nothing into the
+    running batch; when the admission that produced it had set batch_is_full (pool exhausted, or max_running_requests
+    reached by the in-flight prefill batches) nothing clears the flag again while the running batch stays empty, and
+    the decode instance would refuse every later admission with all KV slots free (the unified scheduler resets the
+    flag when the last batch shrinks, scheduler.py:1043-1047)."""
+    for seed in (4, 6, 20):   # seeds that stalled before the flag was reset (4, 6: max_running_requests; 20: pool)
+        g = torch.Generator().manual_seed(seed)
+        lens = torch.randint(5, 60, (40,), generator=g).tolist()
+        prompts = prompts_of(lens, seed=seed)
+        new = [1 if torch.rand(1, generator=g) < 0.7 else int(torch.randint(2, 9, (1,), generator=g))
+               for _ in range(len(prompts))]
+        want = [expected(p, n) for p, n in zip(prompts, new)]
+        for kw in (dict(max_total_tokens=200, max_running_requests=32),
+                   dict(max_total_tokens=4000, max_running_requests=4)):
+            size = kw["max_total_tokens"]
+            for plain in (False, True):
+                got, d, _ = run_semi_pd(prompts, new, args(disable_overlap_schedule=plain, **kw), size=size,
+                                        interleave=False)
+                assert [g_[:n] for g_, n in zip(got, new)] == want
+            assert run_unified(prompts, new, args(enable_semi_pd=False, **kw), size=size) == want
 
 
 def test_plain_and_overlapped_decode_loops_agree():
