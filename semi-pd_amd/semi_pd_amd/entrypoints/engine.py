@@ -187,7 +187,8 @@ class Engine:
             reader, writer = ctx.Pipe(duplex=False)
             env_add = {}
             if sa.cu_mask_mode == "env" and percent < 100:
-                env_add = cu_mask_env(gpu_id, self._num_cus(gpu_id), percent, from_top)
+                env_add = cu_mask_env(gpu_id, self._num_cus(gpu_id), percent, from_top,
+                                      library_grid=sa.library_gemm_grid)
             old = {k: os.environ.get(k) for k in env_add}
             os.environ.update(env_add)   # like engine.py:591-593: set the share, then fork
             try:

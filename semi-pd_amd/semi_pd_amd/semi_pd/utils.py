@@ -82,14 +82,16 @@ def cu_mask_words(num_cus: int, percent: int, from_top: bool) -> List[int]:
     return [int(w) for w in buf]
 
 
-def cu_mask_env(gpu_id: int, num_cus: int, percent: int, from_top: bool) -> Dict[str, str]:
+def cu_mask_env(gpu_id: int, num_cus: int, percent: int, from_top: bool, library_grid: bool = False) -> Dict[str, str]:
     """Environment that confines a *process* to `percent` of the CUs of `gpu_id`.
     ROCr reads HSA_CU_MASK ("<gpu>:<cu list>") when the process creates its queues; a 100 % share
-    needs no mask."""
+    needs no mask.  `library_grid` also tells hipBLASLt's stream-K GEMMs (one persistent workgroup per CU
+    of the DEVICE by default, i.e. two rounds under any mask) how many CUs the process really owns."""
     if percent >= 100:
         return {}
     words = cu_mask_words(num_cus, percent, from_top)
     bits = [i for i in range(num_cus) if words[i >> 5] >> (i & 31) & 1]
+    extra = {"TENSILE_STREAMK_MAX_CUS": str(len(bits))} if library_grid else {}
     # compress into ranges
     ranges, start, prev = [], bits[0], bits[0]
     for b in bits[1:]:
@@ -99,7 +101,7 @@ def cu_mask_env(gpu_id: int, num_cus: int, percent: int, from_top: bool) -> Dict
         prev = b
     ranges.append((start, prev))
     spec = ",".join(f"{a}-{b}" if a != b else f"{a}" for a, b in ranges)
-    return {"HSA_CU_MASK": f"{gpu_id}:{spec}"}
+    return {"HSA_CU_MASK": f"{gpu_id}:{spec}", **extra}
 
 
 def cu_masked_stream(device_index: int, percent: int, from_top: bool) -> torch.cuda.Stream:

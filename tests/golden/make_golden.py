@@ -23,13 +23,23 @@ MISSING = {"IPython", "zmq", "setproctitle", "orjson", "uvloop", "decord", "inte
            "modelscope", "multipart", "torchvision", "aiter"}
 
 
+class _AnyMeta(type):
+    """Fabricated classes answer any class attribute with another fabricated class (e.g. vllm's
+    scalar_types.uint4b8, read at import time by quantization/gptq.py)."""
+
+    def __getattr__(cls, name):
+        if name.startswith("__") and name.endswith("__"):
+            raise AttributeError(name)
+        return _AnyMeta(name, (), {"__init__": lambda s, *a, **k: None})
+
+
 class _Stub(types.ModuleType):
     __path__ = []
 
     def __getattr__(self, name):
         if name.startswith("__") and name.endswith("__"):
             raise AttributeError(name)
-        return type(name, (), {"__init__": lambda s, *a, **k: None})
+        return _AnyMeta(name, (), {"__init__": lambda s, *a, **k: None})
 
 
 class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
@@ -171,6 +181,178 @@ def gen_decode():
                      f"{name}_meta": np.array([splits, sm_scale, cap], dtype=np.float64)})
     arrs["names"] = np.array([c[0] for c in cases])
     save("decode_attention", **arrs)
+
+
+def gen_decode_8c():
+    """The shapes SURVEY 8(c) lists for the reference's Triton decode kernels: MLA 576 / 512 through the grouped
+    kernel (_fwd_grouped_kernel_stage1, decode_attention.py:234-390), head sizes 80 and 13 (BLOCK_DMODEL padding),
+    GQA group 16, 16 kv splits, a logit cap on the grouped path."""
+    g = torch.Generator().manual_seed(12)
+    arrs = {}
+    cases = [
+        # name, B, lens, Hq, Hkv, Dk, Dv, splits, logit_cap
+        ("mla_576_512_h16", 2, [37, 90], 16, 1, 576, 512, 4, 0.0),
+        ("mla_576_512_h128", 1, [70], 128, 1, 576, 512, 2, 0.0),
+        ("gqa4_d80", 2, [23, 51], 8, 2, 80, 80, 4, 0.0),
+        ("mha_d13", 2, [9, 30], 3, 3, 13, 13, 2, 0.0),
+        ("gqa16_d64_splits16", 2, [100, 257], 16, 1, 64, 64, 16, 0.0),
+        ("gqa8_d128_splits16_cap", 1, [300], 16, 2, 128, 128, 16, 50.0),
+        ("mha_d64_splits16", 2, [64, 129], 4, 4, 64, 64, 16, 0.0),
+    ]
+    for name, B, lens, Hq, Hkv, Dk, Dv, splits, cap in cases:
+        dt = torch.float32
+        k_buf, v_buf, kv_indptr, kv_indices = make_paged(g, B, lens, Hkv, Dk, Dv, dt)
+        if name.startswith("mla"):
+            v_buf = k_buf[..., :Dv]   # the latent row is K; V is its first 512 columns (memory_pool.py:439-452)
+        q = torch.randn(B, Hq, Dk, generator=g).to(dt)
+        o = torch.zeros(B, Hq, Dv, dtype=dt)
+        logits = torch.zeros(B, Hq, splits, Dv + 1, dtype=torch.float32)
+        sm_scale = 1.0 / (Dk ** 0.5)
+        decode_attention_fwd(q, k_buf, v_buf, o, kv_indptr, kv_indices, logits, splits, sm_scale, cap)
+        arrs.update({f"{name}_q": q.numpy(), f"{name}_k": k_buf.numpy(),
+                     f"{name}_indptr": kv_indptr.numpy(), f"{name}_indices": kv_indices.numpy(),
+                     f"{name}_o": o.numpy(),
+                     f"{name}_meta": np.array([splits, sm_scale, cap, Dv], dtype=np.float64)})
+        if not name.startswith("mla"):
+            arrs[f"{name}_v"] = v_buf.numpy()
+    arrs["names"] = np.array([c[0] for c in cases])
+    save("decode_attention_8c", **arrs)
+
+
+def gen_extend_8c():
+    """extend_attention_fwd at the MLA prefill shape (Dk 192 / Dv 128, extend_attention.py:291-410 with
+    BLOCK_DPE), head sizes 80 and 13, GQA group 16."""
+    g = torch.Generator().manual_seed(13)
+    arrs = {}
+    cases = [
+        ("mla_prefill_192_128", [0, 21], [40, 17], 4, 4, 192, 128, 0.0),
+        ("mla_absorbed_576_512", [11], [19], 4, 1, 576, 512, 0.0),
+        ("gqa2_d80", [5, 0], [33, 12], 4, 2, 80, 80, 0.0),
+        ("mha_d13", [3], [20], 2, 2, 13, 13, 0.0),
+        ("gqa16_d64", [30], [70], 16, 1, 64, 64, 0.0),
+    ]
+    for name, pre, ext, Hq, Hkv, Dk, Dv, cap in cases:
+        dt = torch.float32
+        B = len(pre)
+        k_buf, v_buf, kv_indptr, kv_indices = make_paged(g, B, pre, Hkv, Dk, Dv, dt)
+        T = sum(ext)
+        qo_indptr = torch.zeros(B + 1, dtype=torch.int32)
+        qo_indptr[1:] = torch.cumsum(torch.tensor(ext), 0)
+        q = torch.randn(T, Hq, Dk, generator=g).to(dt)
+        k = torch.randn(T, Hkv, Dk, generator=g).to(dt)
+        v = torch.randn(T, Hkv, Dv, generator=g).to(dt)
+        o = torch.zeros(T, Hq, Dv, dtype=dt)
+        sm_scale = 1.0 / (Dk ** 0.5)
+        extend_attention_fwd(q, k, v, o, k_buf, v_buf, qo_indptr, kv_indptr, kv_indices, None, None,
+                             max(ext), sm_scale, cap)
+        arrs.update({f"{name}_q": q.numpy(), f"{name}_k": k.numpy(), f"{name}_v": v.numpy(),
+                     f"{name}_kbuf": k_buf.numpy(), f"{name}_vbuf": v_buf.numpy(),
+                     f"{name}_qo_indptr": qo_indptr.numpy(), f"{name}_kv_indptr": kv_indptr.numpy(),
+                     f"{name}_kv_indices": kv_indices.numpy(), f"{name}_o": o.numpy(),
+                     f"{name}_meta": np.array([sm_scale, cap], dtype=np.float64)})
+    arrs["names"] = np.array([c[0] for c in cases])
+    save("extend_attention_8c", **arrs)
+
+
+# ---------------------------------------------------------------- SiLU * mul (layers/activation.py:41-44)
+def gen_silu():
+    from sglang.srt.layers.activation import SiluAndMul
+    g = torch.Generator().manual_seed(14)
+    arrs = {}
+    m = SiluAndMul()
+    for i, (T, d, dt) in enumerate([(3, 64, torch.bfloat16), (5, 88, torch.float16), (2, 256, torch.float32),
+                                    (7, 1408, torch.bfloat16)]):
+        x = (torch.randn(T, 2 * d, generator=g) * 3).to(dt)
+        y = m.forward_native(x)
+        arrs[f"c{i}_x"], arrs[f"c{i}_y"] = bits(x) if dt == torch.bfloat16 else x.numpy(), \
+            bits(y) if dt == torch.bfloat16 else y.numpy()
+        arrs[f"c{i}_dtype"] = np.array(str(dt))
+    arrs["n"] = np.array(4)
+    save("silu_and_mul", **arrs)
+
+
+# ---------------------------------------------------------------- moe_align_block_size (Triton reference of the test)
+def _load_by_path(name, path):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def gen_moe_align():
+    """sgl-kernel/tests/test_moe_align.py compares the CUDA op with a four-stage Triton implementation; that
+    Triton implementation is run here (interpreter) on the test's own kind of input (randperm ids per token)."""
+    TM = _load_by_path("ref_test_moe_align", "/root/reference/sgl-kernel/tests/test_moe_align.py")
+    g = torch.Generator().manual_seed(15)
+    arrs = {}
+    cases = [(32, 7, 2, 8), (64, 33, 6, 64), (16, 1, 8, 64), (128, 50, 8, 160), (64, 130, 4, 16)]
+    for i, (bs, T, k, E) in enumerate(cases):
+        topk_ids = torch.stack([torch.randperm(E, generator=g, dtype=torch.int32)[:k] for _ in range(T)])
+        max_padded = topk_ids.numel() + E * (bs - 1)
+        sorted_ids = torch.full((max_padded,), topk_ids.numel(), dtype=torch.int32)
+        expert_ids = torch.zeros((max_padded // bs,), dtype=torch.int32)
+        n_post = torch.empty((1,), dtype=torch.int32)
+        TM.moe_align_block_size_triton(topk_ids, E, bs, sorted_ids, expert_ids, n_post)
+        arrs.update({f"c{i}_topk_ids": topk_ids.numpy(), f"c{i}_sorted": sorted_ids.numpy(),
+                     f"c{i}_expert_ids": expert_ids.numpy(), f"c{i}_n_post": n_post.numpy(),
+                     f"c{i}_meta": np.array([bs, T, k, E])})
+    arrs["n"] = np.array(len(cases))
+    save("moe_align", **arrs)
+
+
+# ---------------------------------------------------------------- fused MoE (fused_moe_native.py, test_fused_moe.py)
+def _reference_torch_naive_moe():
+    """test/srt/test_fused_moe.py::TestFusedMOE.torch_naive_moe (the formula the reference's own test pins
+    fused_moe to): its module cannot be imported (vLLM's fused_moe), so exactly that method is compiled from the
+    file at generation time (nothing of it is stored)."""
+    import ast
+    from sglang.srt.layers.activation import SiluAndMul
+    path = "/root/reference/test/srt/test_fused_moe.py"
+    tree = ast.parse(open(path).read())
+    fn = next(n for c in tree.body if isinstance(c, ast.ClassDef) for n in c.body
+              if isinstance(n, ast.FunctionDef) and n.name == "torch_naive_moe")
+    mod = ast.Module(body=[fn], type_ignores=[])
+    ns = {"torch": torch, "SiluAndMul": _native_silu_and_mul()}
+    exec(compile(mod, path, "exec"), ns)
+    return lambda *a: ns["torch_naive_moe"](None, *a)
+
+
+def _native_silu_and_mul():
+    """CustomOp.__call__ dispatches to forward_cuda here (is_cuda_available is patched for the import), whose
+    sgl_kernel op is a stub: pick the reference's own forward_native instead — dispatch only, same class."""
+    from sglang.srt.layers.activation import SiluAndMul
+
+    class NativeSiluAndMul(SiluAndMul):
+        def __call__(self, x):
+            return self.forward_native(x)
+    return NativeSiluAndMul
+
+
+def gen_fused_moe():
+    from types import SimpleNamespace as NS
+    import sglang.srt.layers.moe.fused_moe_native as FN
+    from sglang.srt.layers.moe.fused_moe_native import fused_moe_forward_native, moe_forward_native
+    FN.SiluAndMul = _native_silu_and_mul()
+    naive = _reference_torch_naive_moe()
+    g = torch.Generator().manual_seed(16)
+    arrs = {}
+    cases = [(5, 32, 48, 8, 2), (33, 48, 64, 64, 6), (1, 64, 32, 8, 2)]   # m, n (intermediate), k (hidden), e, topk
+    for i, (m, n, k, e, topk) in enumerate(cases):
+        a = torch.randn(m, k, generator=g) * 0.5
+        w1 = torch.randn(e, 2 * n, k, generator=g) * 0.2
+        w2 = torch.randn(e, k, n, generator=g) * 0.2
+        score = torch.randn(m, e, generator=g)
+        layer = NS(w13_weight=w1, w2_weight=w2, num_experts=e)
+        out_naive = naive(a.clone(), w1, w2, score.clone(), topk)
+        # select_experts(torch_native=True, renormalize=False) = softmax + topk, the routing of torch_naive_moe
+        out_native = fused_moe_forward_native(layer, a.clone(), False, topk, score.clone(), False)
+        out_grouped = moe_forward_native(layer, a.clone(), False, topk, score.clone(), True)
+        arrs.update({f"c{i}_a": a.numpy(), f"c{i}_w1": w1.numpy(), f"c{i}_w2": w2.numpy(), f"c{i}_score": score.numpy(),
+                     f"c{i}_out_naive": out_naive.numpy(), f"c{i}_out_native": out_native.numpy(),
+                     f"c{i}_out_renorm": out_grouped.numpy(), f"c{i}_meta": np.array([m, n, k, e, topk])})
+    arrs["n"] = np.array(len(cases))
+    save("fused_moe", **arrs)
 
 
 # ---------------------------------------------------------------- extend attention (Triton, interpreter)
@@ -455,7 +637,10 @@ def gen_penalties():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rmsnorm", "rope", "kv_indices", "topk", "decode", "extend", "sampling", "fp8", "penalties"]
+    which = sys.argv[1:] or ["rmsnorm", "rope", "kv_indices", "topk", "decode", "extend", "sampling", "fp8", "penalties",
+                             "decode_8c", "extend_8c", "silu", "moe_align", "fused_moe"]
     for w in which:
         {"rmsnorm": gen_rmsnorm, "rope": gen_rope, "kv_indices": gen_kv_indices, "topk": gen_topk,
-         "decode": gen_decode, "extend": gen_extend, "sampling": gen_sampling, "fp8": gen_fp8, "penalties": gen_penalties}[w]()
+         "decode": gen_decode, "extend": gen_extend, "sampling": gen_sampling, "fp8": gen_fp8, "penalties": gen_penalties,
+         "decode_8c": gen_decode_8c, "extend_8c": gen_extend_8c, "silu": gen_silu, "moe_align": gen_moe_align,
+         "fused_moe": gen_fused_moe}[w]()

@@ -269,19 +269,25 @@ def test_decode_attention(ops, device, B, lens, Hq, Hkv, Dk, Dv, splits, cap, dt
     _close(o, want, dtype, rtol=2e-2, atol=4e-3 if dtype == torch.float16 else 1.5e-2)
 
 
-def test_decode_attention_golden(ops, device):
-    """fp32 golden vectors from the reference Triton kernel, evaluated here in bf16."""
-    g = load_golden("decode_attention")
+@pytest.mark.parametrize("fixture", ["decode_attention", "decode_attention_8c"])
+def test_decode_attention_golden(ops, device, fixture):
+    """fp32 golden vectors from the reference Triton kernel, evaluated here in bf16 (8c: the SURVEY 8(c) shapes,
+    MLA 576 / 512 with 16 and 128 heads, D 80 / 13, group 16, 16 splits)."""
+    g = load_golden(fixture)
     for name in g["names"]:
         name = str(name)
-        q, k, v = (torch.from_numpy(g[f"{name}_{x}"]).to(torch.bfloat16) for x in ("q", "k", "v"))
+        q, k = (torch.from_numpy(g[f"{name}_{x}"]).to(torch.bfloat16) for x in ("q", "k"))
+        v = (k[..., :int(g[name + "_meta"][3])] if name.startswith("mla_576")
+             else torch.from_numpy(g[name + "_v"]).to(torch.bfloat16))
         indptr, indices = torch.from_numpy(g[name + "_indptr"]), torch.from_numpy(g[name + "_indices"])
-        splits, sm_scale, cap = g[name + "_meta"]
+        splits, sm_scale, cap = g[name + "_meta"][:3]
         B, Hq, _ = q.shape
         Dv = v.shape[2]
         o = torch.empty(B, Hq, Dv, dtype=torch.bfloat16, device=device)
         logits = torch.empty(B, Hq, int(splits), Dv + 1, dtype=torch.float32, device=device)
-        ops.decode_attention_fwd(q.to(device), k.to(device), v.to(device), o, indptr.to(device),
+        kd = k.to(device)
+        vd = kd[..., :Dv] if name.startswith("mla_576") else v.to(device)
+        ops.decode_attention_fwd(q.to(device), kd, vd, o, indptr.to(device),
                                  indices.to(device), logits, int(splits), float(sm_scale), float(cap))
         _close(o, torch.from_numpy(g[name + "_o"]), torch.bfloat16, rtol=3e-2, atol=3e-2)
 
@@ -338,8 +344,9 @@ def test_extend_attention(ops, device, pre, ext, Hq, Hkv, Dk, Dv, cap, dtype):
     _close(o, want, dtype, rtol=2e-2, atol=4e-3 if dtype == torch.float16 else 1.5e-2)
 
 
-def test_extend_attention_golden(ops, device):
-    g = load_golden("extend_attention")
+@pytest.mark.parametrize("fixture", ["extend_attention", "extend_attention_8c"])
+def test_extend_attention_golden(ops, device, fixture):
+    g = load_golden(fixture)
     for name in g["names"]:
         name = str(name)
         q, k, v = (torch.from_numpy(g[f"{name}_{x}"]).to(torch.bfloat16) for x in ("q", "k", "v"))
@@ -487,6 +494,63 @@ def test_moe_align_block_size(ops, device, numel_tokens, topk, E, block):
         assert all(int(flat[i]) == eids[start] for i in real)
         start = end
     assert (got[n:] == numel).all()
+
+
+def test_silu_and_mul_golden(ops, device):
+    """SiluAndMul.forward_native of the reference (golden/silu_and_mul.npz): the kernel rounds once (like the
+    sgl-kernel op), forward_native twice, so outputs agree within one unit in the last place."""
+    g = load_golden("silu_and_mul")
+    for ci in range(int(g["n"])):
+        dt = DTYPES[str(g[f"c{ci}_dtype"])]
+        if dt == torch.float32:
+            continue
+        x = from_bits(g[f"c{ci}_x"], dt)
+        y = ops.silu_and_mul(x.to(device)).cpu()
+        assert torch.equal(y, O.silu_and_mul(x)) or (y.float() - O.silu_and_mul(x).float()).abs().max() < 1e-2
+        want = from_bits(g[f"c{ci}_y"], dt).float()
+        ulp = 2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10
+        assert torch.all((y.float() - want).abs() <= 1.01 * ulp * want.abs() + 1e-6), ci
+
+
+def test_moe_align_golden(ops, device):
+    """Against the Triton implementation of sgl-kernel/tests/test_moe_align.py run under the interpreter
+    (golden/moe_align.npz): expert_ids, num_tokens_post_pad and, per expert, the token set."""
+    g = load_golden("moe_align")
+    for ci in range(int(g["n"])):
+        bs, T, k, E = (int(x) for x in g[f"c{ci}_meta"])
+        ids = torch.from_numpy(g[f"c{ci}_topk_ids"])
+        numel = ids.numel()
+        max_sorted = numel + E * (bs - 1)
+        sorted_ids = torch.empty(max_sorted, dtype=torch.int32, device=device)
+        expert_ids = torch.full(((max_sorted + bs - 1) // bs,), -1, dtype=torch.int32, device=device)
+        npp = torch.empty(1, dtype=torch.int32, device=device)
+        cumsum = torch.empty(E + 1, dtype=torch.int32, device=device)
+        ops.moe_align_block_size(ids.to(device), E, bs, sorted_ids, expert_ids, npp, None, cumsum)
+        n = int(g[f"c{ci}_n_post"][0])
+        assert int(npp.item()) == n
+        nb = n // bs
+        assert np.array_equal(expert_ids.cpu().numpy()[:nb], g[f"c{ci}_expert_ids"][:nb])
+        got, ref = sorted_ids.cpu().numpy(), g[f"c{ci}_sorted"]
+        eids = g[f"c{ci}_expert_ids"][:nb]
+        for e in np.unique(eids):
+            blks = np.nonzero(eids == e)[0]
+            seg = slice(blks[0] * bs, (blks[-1] + 1) * bs)
+            assert sorted(got[seg].tolist()) == sorted(ref[seg].tolist()), (ci, e)
+
+
+def test_fused_experts_golden(ops, device):
+    """fused_moe_native.py / torch_naive_moe outputs of the reference (golden/fused_moe.npz, fp32 inputs)
+    against the fused-experts layer in bf16, at the reference test's bf16 bar (test_fused_moe.py:31-44)."""
+    from semi_pd_amd.layers.moe import fused_experts
+    g = load_golden("fused_moe")
+    for ci in range(int(g["n"])):
+        m, n, k, e, topk = (int(x) for x in g[f"c{ci}_meta"])
+        a, w1, w2, score = (torch.from_numpy(g[f"c{ci}_{x}"]) for x in ("a", "w1", "w2", "score"))
+        for renorm, key in ((False, "out_native"), (True, "out_renorm")):
+            tw, ti = ops.topk_softmax(score.to(device), topk, renorm)
+            out = fused_experts(a.to(device, torch.bfloat16), w1.to(device, torch.bfloat16),
+                                w2.to(device, torch.bfloat16), tw, ti)
+            torch.testing.assert_close(out.float().cpu(), torch.from_numpy(g[f"c{ci}_{key}"]), rtol=1e-1, atol=1e-2)
 
 
 @pytest.mark.parametrize("T,N,K,E,topk", [(1, 128, 128, 8, 2), (33, 1024, 511 + 1, 8, 2), (64, 1408, 2048, 64, 6),

@@ -266,3 +266,99 @@ def test_block_fp8_matmul_matches_reference_kernel():
         assert rel < {torch.float32: 1e-6, torch.bfloat16: 4e-3, torch.float16: 5e-4}[dt], (i, float(rel))
         if dt == torch.float32:
             assert torch.allclose(got, want, rtol=1e-5, atol=1e-5 * float(want.abs().max()))
+
+
+# ------------------------------------------------------------------- round 2: ops formerly pinned by formula only
+def test_silu_and_mul_matches_reference_module_bitwise():
+    """layers/activation.py:41-44 SiluAndMul.forward_native, run by make_golden.py."""
+    g = load_golden("silu_and_mul")
+    for ci in range(int(g["n"])):
+        dt = DTYPES[str(g[f"c{ci}_dtype"])]
+        x = from_bits(g[f"c{ci}_x"], dt)
+        want = from_bits(g[f"c{ci}_y"], dt)
+        assert torch.equal(O.silu_and_mul_native(x), want), ci
+        # the fused op's semantics (fp32, one rounding; activation.cu:22-24): what the HIP kernel is checked against.
+        # It may differ from forward_native by the rounding of the activation, i.e. one ulp of the output.
+        y = O.silu_and_mul(x).float()
+        ulp = {torch.bfloat16: 2.0 ** -7, torch.float16: 2.0 ** -10, torch.float32: 2.0 ** -22}[dt]
+        assert torch.all((y - want.float()).abs() <= ulp * want.float().abs() + 1e-30), ci
+
+
+def test_moe_align_matches_reference_triton_implementation():
+    """The four-stage Triton implementation of sgl-kernel/tests/test_moe_align.py (interpreter).  The test
+    there compares expert_ids and num_tokens_post_pad between implementations; the order of tokens INSIDE an
+    expert's segment differs between the reference's own two implementations (the Triton one walks the ids in
+    per-program strides), so sorted ids are compared per expert segment as sets, plus the sentinel padding."""
+    g = load_golden("moe_align")
+    for ci in range(int(g["n"])):
+        bs, T, k, E = (int(x) for x in g[f"c{ci}_meta"])
+        ids = torch.from_numpy(g[f"c{ci}_topk_ids"])
+        sorted_ids, expert_ids, npp = O.moe_align_block_size(ids, bs, E)
+        n = int(g[f"c{ci}_n_post"][0])
+        assert int(npp) == n
+        nb = n // bs
+        assert np.array_equal(expert_ids.numpy()[:nb], g[f"c{ci}_expert_ids"][:nb])
+        ref_sorted = g[f"c{ci}_sorted"]
+        numel = ids.numel()
+        for blk in range(nb):
+            a = sorted_ids.numpy()[blk * bs:(blk + 1) * bs]
+            b = ref_sorted[blk * bs:(blk + 1) * bs]
+            assert (a == numel).sum() == (b == numel).sum()
+        # per expert: same token set
+        eids = expert_ids.numpy()[:nb]
+        for e in np.unique(eids):
+            blks = np.nonzero(eids == e)[0]
+            seg = slice(blks[0] * bs, (blks[-1] + 1) * bs)
+            assert sorted(sorted_ids.numpy()[seg].tolist()) == sorted(ref_sorted[seg].tolist())
+        # the oracle's own order is the stable one (ascending flat index inside an expert)
+        for e in np.unique(eids):
+            blks = np.nonzero(eids == e)[0]
+            seg = sorted_ids.numpy()[blks[0] * bs:(blks[-1] + 1) * bs]
+            real = seg[seg < numel]
+            assert np.all(np.diff(real) > 0)
+
+
+def test_fused_moe_matches_reference_native_implementations():
+    """fused_moe_native.py (fused_moe_forward_native, moe_forward_native) and the reference test's
+    torch_naive_moe, run by make_golden.py on fp32 inputs; the oracle takes the routing as input."""
+    g = load_golden("fused_moe")
+    for ci in range(int(g["n"])):
+        m, n, k, e, topk = (int(x) for x in g[f"c{ci}_meta"])
+        a, w1, w2, score = (torch.from_numpy(g[f"c{ci}_{x}"]) for x in ("a", "w1", "w2", "score"))
+        w, ids = O.fused_topk_native(score, topk, False)
+        out = O.fused_moe(a, w1, w2, w, ids)
+        torch.testing.assert_close(out, torch.from_numpy(g[f"c{ci}_out_naive"]), rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(out, torch.from_numpy(g[f"c{ci}_out_native"]), rtol=1e-4, atol=1e-5)
+        w, ids = O.fused_topk_native(score, topk, True)
+        out = O.fused_moe(a, w1, w2, w, ids)
+        torch.testing.assert_close(out, torch.from_numpy(g[f"c{ci}_out_renorm"]), rtol=1e-4, atol=1e-5)
+        # the staged variant (rounding where fused_experts_impl rounds) is the same product on fp32 inputs
+        torch.testing.assert_close(O.fused_moe_staged(a, w1, w2, w, ids), out, rtol=1e-4, atol=1e-5)
+
+
+def test_attention_8c_shapes_match_reference_triton_kernels():
+    """SURVEY 8(c) shape list, run through the reference's Triton kernels by make_golden.py: MLA 576 / 512 through
+    the grouped decode kernel with 16 and 128 heads, head sizes 80 and 13, GQA group 16, 16 kv splits, a logit cap
+    on the grouped path; extend attention at 192 / 128 (MLA prefill), 576 / 512, 80, 13, group 16."""
+    g = load_golden("decode_attention_8c")
+    for name in g["names"]:
+        name = str(name)
+        q, k = torch.from_numpy(g[name + "_q"]), torch.from_numpy(g[name + "_k"])
+        splits, sm_scale, cap, dv = g[name + "_meta"]
+        v = k[..., :int(dv)] if name.startswith("mla") else torch.from_numpy(g[name + "_v"])
+        indptr, indices = torch.from_numpy(g[name + "_indptr"]), torch.from_numpy(g[name + "_indices"])
+        want = torch.from_numpy(g[name + "_o"])
+        torch.testing.assert_close(O.decode_attention(q, k, v, indptr, indices, float(sm_scale), float(cap)), want,
+                                   rtol=3e-5, atol=3e-5)
+        o2, _ = O.decode_attention_split(q, k, v, indptr, indices, int(splits), float(sm_scale), float(cap))
+        torch.testing.assert_close(o2, want, rtol=3e-5, atol=3e-5)
+    g = load_golden("extend_attention_8c")
+    for name in g["names"]:
+        name = str(name)
+        q, k, v = (torch.from_numpy(g[f"{name}_{x}"]) for x in ("q", "k", "v"))
+        kb, vb = torch.from_numpy(g[name + "_kbuf"]), torch.from_numpy(g[name + "_vbuf"])
+        sm_scale, cap = g[name + "_meta"]
+        o = O.extend_attention(q, k, v, kb, vb, torch.from_numpy(g[name + "_qo_indptr"]),
+                               torch.from_numpy(g[name + "_kv_indptr"]),
+                               torch.from_numpy(g[name + "_kv_indices"]), float(sm_scale), float(cap))
+        torch.testing.assert_close(o, torch.from_numpy(g[name + "_o"]), rtol=3e-5, atol=3e-5)

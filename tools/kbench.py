@@ -224,6 +224,21 @@ def bench_linear():
             del ws
 
 
+def bench_linear_prefill():
+    """Prefill-sized dense layers of Llama-3-8B through hipBLASLt under a CU mask (HSA_CU_MASK) with / without
+    TENSILE_STREAMK_MAX_CUS: does the library's stream-K grid follow the share?"""
+    import torch.nn.functional as F
+    print("# prefill linear M x [N, K] (hipBLASLt): us, TFLOP/s   HSA_CU_MASK=%s TENSILE_STREAMK_MAX_CUS=%s"
+          % (os.environ.get("HSA_CU_MASK", "-"), os.environ.get("TENSILE_STREAMK_MAX_CUS", "-")))
+    for M in (16, 1024, 4096, 8192):
+        for (N, K) in ((28672, 4096), (4096, 14336), (6144, 4096), (4096, 4096)):
+            w = torch.randn(N, K, device=dev, dtype=torch.bfloat16) * 0.02
+            x = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
+            t = timeit(lambda: F.linear(x, w), iters=10)
+            print(f"linear M={M:5d} N={N:6d} K={K:6d}: {t * 1e6:8.1f} us {2.0 * M * N * K / t / 1e12:7.1f} TF/s")
+            del w
+
+
 def bench_linear_sweep():
     """ops.linear with every (NG, ksplit) forced through SEMIPD_LINEAR_NG / SEMIPD_LINEAR_KSPLIT vs hipBLASLt."""
     import torch.nn.functional as F
@@ -322,6 +337,8 @@ if __name__ == "__main__":
         bench_linear_sweep()
     if which == "linear":
         bench_linear()
+    if which == "linear_prefill":
+        bench_linear_prefill()
     if which == "decode_small":
         bench_decode_small()
     if which == "mla_small":
