@@ -199,6 +199,8 @@ def main():
     ap.add_argument("--prefill-cu", type=int, default=50)
     ap.add_argument("--decode-cu", type=int, default=50)
     ap.add_argument("--cu-mask-mode", default="env")
+    ap.add_argument("--disable-stream-linear", action="store_true",
+                    help="decode-batch dense layers through hipBLASLt instead of the persistent streaming kernel (A/B)")
     ap.add_argument("--library-gemm-grid", action="store_true",
                     help="size hipBLASLt's stream-K grids to each instance's CU share (TENSILE_STREAMK_MAX_CUS)")
     ap.add_argument("--context-length", type=int, default=0)
@@ -268,7 +270,7 @@ def main():
                     max_running_requests=args.max_running_requests, mem_fraction_static=args.mem_fraction_static,
                     max_total_tokens=args.max_total_tokens, prefill_cu_percent=args.prefill_cu,
                     decode_cu_percent=args.decode_cu, cu_mask_mode=args.cu_mask_mode,
-                    library_gemm_grid=args.library_gemm_grid,
+                    library_gemm_grid=args.library_gemm_grid, disable_stream_linear=args.disable_stream_linear,
                     disable_cuda_graph=args.disable_cuda_graph, nccl_port_base=port_base,
                     disable_overlap_schedule=args.disable_overlap_schedule,
                     **({"chunked_prefill_size": args.chunked_prefill_size} if args.chunked_prefill_size else {}),

@@ -211,6 +211,20 @@ int semipd_linear(void* out, const void* x, const void* weight, void* workspace,
                   int64_t rows, int64_t n, int64_t k, int64_t ldx, int64_t ldo, int num_cus, int dtype,
                   void* stream);
 
+/* Dense layer of the DECODE instance on its CU share: out[rows, n_out] = x[rows, k] . weight[n, k]^T, rows <= 64
+ * (bf16/f16, fp32 accumulate).  Weights are streamed once through LDS-DMA rings; the launch is n / 128 row
+ * batches x KS slices of K, KS a function of the shape only (about one workgroup per CU of a half-chip share), so
+ * every process computes the same bits whatever its CU mask.  With KS > 1 the slices write fp32 planes
+ * [KS][rows][n] into `workspace` and a second small launch sums them in slice order; `workspace` NULL = no K split.  fuse_silu_mul != 0: `weight` is a merged [gate; up]
+ * matrix (rows [0, n/2) gate, [n/2, n) up) and out[rows, n/2] = SiLU(gate) * up with both GEMM outputs rounded
+ * to the activation type first, i.e. the value the unfused pair of ops produces.  k % 128 == 0.
+ * replaces UnquantizedLinearMethod.apply -> F.linear (layers/linear.py:165-172) and, fused, LlamaMLP's
+ *   gate_up_proj + SiluAndMul (models/llama.py:88-92, layers/activation.py:41-53) at decode batch sizes. */
+size_t semipd_stream_linear_workspace(int64_t max_n);
+int semipd_stream_linear(void* out, const void* x, const void* weight, void* workspace, size_t workspace_bytes,
+                         int64_t rows, int64_t n, int64_t k, int64_t ldx, int64_t ldo, int fuse_silu_mul,
+                         int dtype, void* stream);
+
 /* Stochastic branch of Sampler.forward (layers/sampler.py:77-136).  All rows fp32, contiguous
  * [batch, vocab]; per-row parameter arrays may be NULL, then the scalar *_val applies to every row.
  *

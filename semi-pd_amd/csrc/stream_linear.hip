@@ -1,0 +1,356 @@
+// Decode-instance dense layers on a CU share: out[m, n] = sum_k x[m, k] * W[n, k], m <= 64 rows.
+//
+// A decode step reads every weight once (16 GB for Llama-3-8B) and is bound by that stream, on whatever part
+// of the chip the decode instance owns.  The library GEMMs launch grids shaped for the whole device (two
+// rounds under a CU mask) and never run below ~19 us; this kernel launches about one workgroup per CU of a
+// half-chip share, needs no particular CU count to be efficient (a workgroup streams its own rows, nothing
+// is persistent) and moves the weights with LDS-DMA (see the block comment at the kernel).  Epilogues: plain store, or
+// SiLU(gate) * up for a merged gate_up weight (a wave owns 16 gate rows and the 16 up rows that belong to
+// them), which saves the activation kernel and the [m, 2 x inter] round trip.
+// C^T[n, m] tiles of v_mfma_f32_16x16x32: a lane ends with 4 consecutive n of one row m (8-byte stores).
+// replaces UnquantizedLinearMethod.apply -> F.linear (+ SiluAndMul) at decode batch sizes
+//   (layers/linear.py:165-172, models/llama.py:88-92, layers/activation.py:41-53).
+#include "common.h"
+
+namespace semipd {
+
+typedef float sl_f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 sl_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 sl_f16x8 __attribute__((ext_vector_type(8)));
+
+union SlFrag {
+  uint4 u;
+  sl_bf16x8 b;
+  sl_f16x8 f;
+};
+template <typename T> struct SlMfma;
+template <> struct SlMfma<bf16_t> {
+  __device__ static inline sl_f32x4 mma(const SlFrag& a, const SlFrag& b, sl_f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.b, b.b, c, 0, 0, 0);
+  }
+};
+template <> struct SlMfma<f16_t> {
+  __device__ static inline sl_f32x4 mma(const SlFrag& a, const SlFrag& b, sl_f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a.f, b.f, c, 0, 0, 0);
+  }
+};
+
+typedef uint32_t sl_u32x4 __attribute__((ext_vector_type(4)));
+__device__ inline uint4 sl_load_nt(const void* p) {  // streamed once: keep it out of the way of x in L2 / MALL
+  const sl_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const sl_u32x4*>(p));
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
+enum { SL_PLAIN = 0, SL_SILU_MUL = 1 };
+
+// Weights through LDS-DMA.  A fragment-shaped register load (16 rows x 64 B per wave instruction) costs the
+// CU's texture-address path ~80 cycles however it is scheduled: a first version of this file that streamed
+// weight AND activation fragments straight into registers topped out at ~17 GB/s of weights per CU
+// (profiles/r02_kbench_stream_linear_v1_register_fragments.txt).  global_load_lds moves 1 KB per wave
+// instruction as four contiguous 256-byte row segments straight into LDS, costs no VGPRs while in flight and
+// leaves the VALU / MFMA free, so the in-flight window per CU is bounded by LDS, not by registers:
+//   * every wave owns a private ring of R slots (slot = NG x 16 weight rows x 128 k = NG x 4 KB) and keeps R - 1
+//     blocks in flight; the activation block of the same 128 k (MT x 4 KB) is loaded once per WORKGROUP into a
+//     shared ring of the same depth, each wave issuing its share -- so the only synchronisation is one raw
+//     s_barrier per 128 k, and counted s_waitcnt vmcnt(N) (in order: x share and W of a block are issued
+//     together) never drains the stream;
+//   * LDS images are lane-linear (that is what the DMA writes), so the bank-conflict swizzle is applied to the
+//     SOURCE address: 16-byte chunk c of row i sits at position c ^ (i & 15) of its 256-byte LDS row, and the
+//     ds_read_b128 of an MFMA fragment reads (4 s + kq) ^ i -- 16 distinct slots per 16-lane group;
+//   * workgroup = NW waves x (NG x 16) weight rows over one K slice; the launch is n_row_batches x KS
+//     workgroups, KS chosen from the shape so that a half-chip share is filled by one round; KS > 1 writes fp32
+//     planes [KS][M][N] that splitk_planes_reduce below sums in slice order.
+template <int MT, int NG, int NW, int R>
+struct SgLayout {
+  static constexpr int kXStage = MT * 4096;                 // one activation block: MT x 16 rows x 256 B
+  static constexpr int kWSlot = NG * 4096;                  // one weight block of a wave
+  static constexpr int kXRing = R * kXStage;
+  static constexpr int kBytes = kXRing + NW * R * kWSlot;
+  static constexpr int kNX = (4 * MT + NW - 1) / NW;        // x DMA pieces per wave per block
+  static constexpr int kPerBlock = kNX + 4 * NG;            // VMEM ops a wave issues per block
+};
+
+#define SG_GLDS(gp, lp, aux) \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp), \
+                                   (__attribute__((address_space(3))) void*)(lp), 16, 0, aux)
+
+template <int N> __device__ inline void sg_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// Fragment reads are inline asm: a ds_read the compiler can see makes it wait vmcnt(0) for every LDS-DMA in flight
+// (it cannot tell the ring slots apart), which would drain the weight stream at every 128 k.  The asm reads are
+// ordered by hand: in-order lgkmcnt, a scheduling barrier between the wait and the MFMAs that consume them.
+__device__ inline uint4 sg_lds_read16(uint32_t addr) {
+  uint4 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+  return v;
+}
+template <int N> __device__ inline void sg_wait_lgkm() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ inline uint32_t sg_lds_addr(const void* p) {
+  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+
+template <typename T, int MT, int NG, int NW, int R, int EPI>
+__global__ void __launch_bounds__(64 * NW)
+stream_gemm_glds_kernel(T* __restrict__ out, float* __restrict__ planes, const T* __restrict__ x,
+                        const T* __restrict__ w, int M, int N, int K, int64_t ldx, int64_t ldo, int kb_per_slice) {
+  using L = SgLayout<MT, NG, NW, R>;
+  extern __shared__ __attribute__((aligned(16))) char sg_smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c16 = lane & 15, q4 = lane >> 4;
+  const int n_half = N >> 1;
+  const int ks = blockIdx.y;
+  const int nkb_total = K >> 7;
+  const int kb0 = ks * kb_per_slice;
+  const int nkb = min(kb_per_slice, nkb_total - kb0);       // >= 1 by construction of the grid
+  // ---- DMA source pointers (per lane): piece j = rows 4j .. 4j+3 of a 16-row block, lane -> row 4j + (lane >> 4),
+  //      chunk (lane & 15) ^ (row & 15) of the row's 256-byte k-block segment ----
+  const int prow = lane >> 4;                               // row inside a piece
+  const int rows_per_wg = (EPI == SL_SILU_MUL ? 16 : 16 * NG) * NW;
+  const int n0 = blockIdx.x * rows_per_wg + wave * (EPI == SL_SILU_MUL ? 16 : 16 * NG);
+  const T* wsrc[NG][4];
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = 4 * j + prow;
+      const int row = (EPI == SL_SILU_MUL ? g * n_half + n0 : n0 + g * 16) + i;
+      wsrc[g][j] = w + (int64_t)min(row, N - 1) * K + (int64_t)kb0 * 128 + (((lane & 15) ^ (i & 15)) << 3);
+    }
+  const T* xsrc[L::kNX];
+  int xdst[L::kNX];
+#pragma unroll
+  for (int e = 0; e < L::kNX; ++e) {
+    const int piece = (wave + e * NW) % (4 * MT);           // duplicates (same bytes, same place) when 4 MT % NW != 0
+    const int t = piece >> 2, j = piece & 3;
+    const int i = 4 * j + prow;
+    xsrc[e] = x + (int64_t)min(t * 16 + i, M - 1) * ldx + (int64_t)kb0 * 128 + (((lane & 15) ^ (i & 15)) << 3);
+    xdst[e] = t * 4096 + j * 1024;
+  }
+  char* const xring = sg_smem;
+  char* const wring = sg_smem + L::kXRing + wave * (R * L::kWSlot);
+  const uint32_t xring_addr = sg_lds_addr(xring), wring_addr = sg_lds_addr(wring);
+
+  auto issue = [&](int kb) __attribute__((always_inline)) {   // block kb of this slice -> ring position kb % R
+    const int slot = kb % R;
+    const int64_t koff = (int64_t)kb * 128;
+#pragma unroll
+    for (int e = 0; e < L::kNX; ++e) SG_GLDS(xsrc[e] + koff, xring + slot * L::kXStage + xdst[e], 0);
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) SG_GLDS(wsrc[g][j] + koff, wring + slot * L::kWSlot + g * 4096 + j * 1024, 2);
+  };
+
+  sl_f32x4 acc[NG][MT];
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[g][t] = sl_f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment read offset of this lane inside a 16-row x 256-byte image, k-step s: row c16, chunk (4 s + q4) ^ c16
+  int frag_off[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) frag_off[s] = c16 * 256 + (((4 * s + q4) ^ c16) << 4);
+
+#pragma unroll
+  for (int p = 0; p < R - 1; ++p)
+    if (p < nkb) issue(p);
+  for (int kb = 0; kb < nkb; ++kb) {
+    // block kb landed (this wave's share); the R - 2 younger blocks stay in flight.  Near the end of the slice
+    // fewer blocks are outstanding than the count assumes: drain.
+    if (kb + R - 1 <= nkb) sg_wait_vm<(R - 2) * L::kPerBlock>();
+    else sg_wait_vm<0>();
+    __builtin_amdgcn_s_barrier();       // every wave's share of x(kb) landed; everybody is done with block kb - 1
+    asm volatile("" ::: "memory");
+    if (kb + R - 1 < nkb) issue(kb + R - 1);                // into the ring position block kb - 1 just left
+    const int slot = kb % R;
+    const uint32_t xs = xring_addr + slot * L::kXStage, wsl = wring_addr + slot * L::kWSlot;
+    SlFrag a[2][NG], b[2][MT];
+    auto read_step = [&](int buf, int s) __attribute__((always_inline)) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g) a[buf][g].u = sg_lds_read16(wsl + g * 4096 + frag_off[s]);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) b[buf][t].u = sg_lds_read16(xs + t * 4096 + frag_off[s]);
+    };
+    read_step(0, 0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (s < 3) {
+        read_step((s + 1) & 1, s + 1);
+        sg_wait_lgkm<NG + MT>();          // the fragments of k-step s are in; those of s + 1 are on their way
+      } else {
+        sg_wait_lgkm<0>();
+      }
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acc[g][t] = SlMfma<T>::mma(a[s & 1][g], b[s & 1][t], acc[g][t]);
+    }
+  }
+
+  // ---- epilogue: lane holds C[m = t*16 + c16][n = nbase + q4*4 + r] ----
+  if (gridDim.y > 1) {
+    float* pl = planes + (int64_t)ks * M * N;
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        const int m = t * 16 + c16;
+        const int n = (EPI == SL_SILU_MUL ? g * n_half + n0 : n0 + g * 16) + q4 * 4;
+        if (m < M && n < N) *reinterpret_cast<sl_f32x4*>(pl + (int64_t)m * N + n) = acc[g][t];
+      }
+    return;
+  }
+  if (EPI == SL_PLAIN) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        const int m = t * 16 + c16, n = n0 + g * 16 + q4 * 4;
+        if (m < M && n < N) {
+          const sl_f32x4 v = acc[g][t];
+          uint2 p;
+          p.x = (uint32_t)Elem<T>::from_f(v[0]).v | ((uint32_t)Elem<T>::from_f(v[1]).v << 16);
+          p.y = (uint32_t)Elem<T>::from_f(v[2]).v | ((uint32_t)Elem<T>::from_f(v[3]).v << 16);
+          *reinterpret_cast<uint2*>(out + (int64_t)m * ldo + n) = p;
+        }
+      }
+  } else {
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const int m = t * 16 + c16, n = n0 + q4 * 4;
+      if (m < M && n < n_half) {
+        float r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          // the unfused path rounds the GEMM output to T before the activation reads it
+          const float gq = Elem<T>::to_f(Elem<T>::from_f(acc[0][t][j])), uq = Elem<T>::to_f(Elem<T>::from_f(acc[NG - 1][t][j]));
+          r[j] = gq / (1.f + __expf(-gq)) * uq;
+        }
+        uint2 p;
+        p.x = (uint32_t)Elem<T>::from_f(r[0]).v | ((uint32_t)Elem<T>::from_f(r[1]).v << 16);
+        p.y = (uint32_t)Elem<T>::from_f(r[2]).v | ((uint32_t)Elem<T>::from_f(r[3]).v << 16);
+        *reinterpret_cast<uint2*>(out + (int64_t)m * ldo + n) = p;
+      }
+    }
+  }
+}
+
+// out[m, n] = T(sum_z planes[z][m][n]) in slice order; SiLU * mul variant reads gate / up columns n, n + N/2
+template <typename T, int EPI>
+__global__ void __launch_bounds__(256)
+splitk_planes_reduce_kernel(T* __restrict__ out, const float* __restrict__ planes, int ksplit, int M, int N, int64_t ldo) {
+  const int n_out = EPI == SL_SILU_MUL ? N / 2 : N;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int n4 = n_out / 4;
+  if (i >= (int64_t)M * n4) return;
+  const int m = (int)(i / n4), n = (int)(i - (int64_t)m * n4) * 4;
+  const int64_t plane = (int64_t)M * N;
+  const float* src = planes + (int64_t)m * N + n;
+  sl_f32x4 a = *reinterpret_cast<const sl_f32x4*>(src);
+  for (int z = 1; z < ksplit; ++z) a += *reinterpret_cast<const sl_f32x4*>(src + z * plane);
+  float r[4] = {a[0], a[1], a[2], a[3]};
+  if (EPI == SL_SILU_MUL) {
+    sl_f32x4 u = *reinterpret_cast<const sl_f32x4*>(src + N / 2);
+    for (int z = 1; z < ksplit; ++z) u += *reinterpret_cast<const sl_f32x4*>(src + N / 2 + z * plane);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gq = Elem<T>::to_f(Elem<T>::from_f(r[j])), uq = Elem<T>::to_f(Elem<T>::from_f(u[j]));
+      r[j] = gq / (1.f + __expf(-gq)) * uq;
+    }
+  }
+  uint2 p;
+  p.x = (uint32_t)Elem<T>::from_f(r[0]).v | ((uint32_t)Elem<T>::from_f(r[1]).v << 16);
+  p.y = (uint32_t)Elem<T>::from_f(r[2]).v | ((uint32_t)Elem<T>::from_f(r[3]).v << 16);
+  *reinterpret_cast<uint2*>(out + (int64_t)m * ldo + n) = p;
+}
+
+// K slices of a launch with n_rb row batches: enough workgroups for the 128 CUs of a half-chip decode share
+// (one 8-wave workgroup per CU), at least 4 k-blocks of 128 per slice.  The split depends on the SHAPE only, so
+// the prefill and the decode instance (different CU shares) and the unified engine produce the same bits.
+static int sg_pick_ksplit(int n_rb, int nkb) {
+  int ksp = max(1, 128 / max(n_rb, 1));
+  ksp = min(ksp, max(1, nkb / 4));
+  ksp = min(ksp, 16);
+  const int per = (nkb + ksp - 1) / ksp;
+  return (nkb + per - 1) / per;                              // no empty slices
+}
+
+template <typename T, int MT, int NG, int NW, int R, int EPI>
+static int sg_launch(T* out, float* planes, size_t planes_bytes, const T* x, const T* w, int M, int N, int K,
+                     int64_t ldx, int64_t ldo, int force_ks, hipStream_t st) {
+  using L = SgLayout<MT, NG, NW, R>;
+  const int rows_per_wg = (EPI == SL_SILU_MUL ? 16 : 16 * NG) * NW;
+  const int n_rows = EPI == SL_SILU_MUL ? N / 2 : N;
+  const int n_rb = (n_rows + rows_per_wg - 1) / rows_per_wg;
+  const int nkb = K / 128;
+  int ksp = force_ks > 0 ? force_ks : sg_pick_ksplit(n_rb, nkb);
+  while (ksp > 1 && (size_t)ksp * M * N * 4 > planes_bytes) --ksp;
+  const int per = (nkb + ksp - 1) / ksp;
+  ksp = (nkb + per - 1) / per;
+  static bool attr_set = false;  // one per instantiation
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)stream_gemm_glds_kernel<T, MT, NG, NW, R, EPI>,
+                        hipFuncAttributeMaxDynamicSharedMemorySize, L::kBytes);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((stream_gemm_glds_kernel<T, MT, NG, NW, R, EPI>), dim3(n_rb, ksp), dim3(64 * NW), L::kBytes, st,
+                     out, planes, x, w, M, N, K, ldx, ldo, per);
+  int rc = launch_status("stream_gemm_glds");
+  if (rc || ksp == 1) return rc;
+  const int n_out = EPI == SL_SILU_MUL ? N / 2 : N;
+  const int64_t items = (int64_t)M * (n_out / 4);
+  hipLaunchKernelGGL((splitk_planes_reduce_kernel<T, EPI>), dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, out,
+                     (const float*)planes, ksp, M, N, ldo);
+  return launch_status("splitk_planes_reduce");
+}
+
+}  // namespace semipd
+
+using namespace semipd;
+
+extern "C" {
+
+// tuning knob for tools/kbench.py (not part of the ABI): SEMIPD_SL_KS forces the number of K slices
+static int sl_env(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+size_t semipd_stream_linear_workspace(int64_t max_n) {
+  return (size_t)16 * 64 * (size_t)max_n * 4;   // 16 K slices of [64 rows, n] fp32
+}
+
+int semipd_stream_linear(void* out, const void* x, const void* weight, void* workspace, size_t workspace_bytes,
+                         int64_t rows, int64_t n, int64_t k, int64_t ldx, int64_t ldo, int fuse_silu_mul, int dtype,
+                         void* stream) {
+  SEMIPD_CHECK_ARG(rows >= 0 && n > 0 && k > 0 && ldx >= k, SEMIPD_EINVAL, "stream_linear: bad sizes");
+  if (rows == 0) return 0;
+  SEMIPD_CHECK_ARG(out && x && weight, SEMIPD_EINVAL, "stream_linear: null pointer");
+  SEMIPD_CHECK_ARG(rows <= 64, SEMIPD_ESHAPE, "stream_linear: %lld rows; this is the weight-streaming path for decode "
+                   "batches of at most 64 rows", (long long)rows);
+  const int64_t n_out = fuse_silu_mul ? n / 2 : n;
+  SEMIPD_CHECK_ARG(ldo >= n_out && (!fuse_silu_mul || n % 2 == 0), SEMIPD_EINVAL, "stream_linear: ldo < output width");
+  SEMIPD_CHECK_ARG(k % 128 == 0 && ldx % 8 == 0 && n_out % 16 == 0 && ldo % 4 == 0 && aligned16(x) && aligned16(weight) &&
+                   (reinterpret_cast<uintptr_t>(out) & 7u) == 0 && n < (1 << 30) && k < (1 << 30) &&
+                   (!workspace || aligned16(workspace)),
+                   SEMIPD_EALIGN, "stream_linear: k %% 128, output width %% 16, 16-byte aligned rows required");
+  hipStream_t st = as_stream(stream);
+  const int M = (int)rows, N = (int)n, K = (int)k;
+  const int mt = (M + 15) / 16;
+  const int force_ks = workspace ? sl_env("SEMIPD_SL_KS", 0) : 1;
+  float* planes = (float*)workspace;
+  const size_t pb = workspace ? workspace_bytes : 0;
+  int rc = 0;
+#define SL_GO(MTV) \
+  if (fuse_silu_mul) { SEMIPD_DISPATCH_HALF(dtype, T, rc = (sg_launch<T, MTV, 2, 4, 3, SL_SILU_MUL>((T*)out, planes, pb, (const T*)x, (const T*)weight, M, N, K, ldx, ldo, force_ks, st))); } \
+  else { SEMIPD_DISPATCH_HALF(dtype, T, rc = (sg_launch<T, MTV, 1, 8, 3, SL_PLAIN>((T*)out, planes, pb, (const T*)x, (const T*)weight, M, N, K, ldx, ldo, force_ks, st))); }
+  if (mt == 1) { SL_GO(1) } else if (mt == 2) { SL_GO(2) } else if (mt == 3) { SL_GO(3) } else { SL_GO(4) }
+#undef SL_GO
+  return rc;
+}
+
+}  // extern "C"

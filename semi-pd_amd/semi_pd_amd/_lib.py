@@ -54,6 +54,8 @@ _SIGNATURES = {
     "semipd_lm_head_argmax_workspace": [_i64, _i64],
     "semipd_linear_workspace": [_i64, _i64],
     "semipd_linear": [_vp, _vp, _vp, _vp, _sz, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _vp],
+    "semipd_stream_linear_workspace": [_i64],
+    "semipd_stream_linear": [_vp, _vp, _vp, _vp, _sz, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _vp],
     "semipd_softmax_temperature": [_vp, _vp, _i64, _i64, _vp],
     "semipd_top_k_top_p_sampling_from_probs": [_vp, _vp, _vp, _i32, _vp, _f32, _vp, _vp, _i64, _i64, _i32, _vp],
     "semipd_min_p_sampling_from_probs": [_vp, _vp, _vp, _f32, _vp, _i64, _i64, _vp],
@@ -96,7 +98,7 @@ _SIGNATURES = {
     "semipd_ar_dispose": [_vp],
 }
 _RESTYPES = {"semipd_last_error": C.c_char_p, "semipd_lm_head_argmax_workspace": _sz,
-             "semipd_linear_workspace": _sz, "semipd_ar_meta_size": _sz, "semipd_ar_region_size": _sz}
+             "semipd_linear_workspace": _sz, "semipd_stream_linear_workspace": _sz, "semipd_ar_meta_size": _sz, "semipd_ar_region_size": _sz}
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

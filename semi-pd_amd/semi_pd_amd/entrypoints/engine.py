@@ -44,7 +44,8 @@ def _build_runner(server_args: ServerArgs, gpu_id: int, tp_rank: int, role: Inst
         load_format=server_args.load_format, kv_cache_dtype=server_args.kv_cache_dtype,
         bypass_load_weight=bypass_load_weight, seed=server_args.random_seed, cu_percent=cu_percent,
         disable_cuda_graph=server_args.disable_cuda_graph, cuda_graph_max_bs=server_args.cuda_graph_max_bs,
-        disable_custom_all_reduce=server_args.disable_custom_all_reduce, enable_ep_moe=server_args.enable_ep_moe)
+        disable_custom_all_reduce=server_args.disable_custom_all_reduce, enable_ep_moe=server_args.enable_ep_moe,
+        disable_stream_linear=server_args.disable_stream_linear)
     if server_args.collect_kernel_timing:
         from semi_pd_amd.model_executor.kernel_timing import KernelTiming
         mr.kernel_timing = KernelTiming()

@@ -7,7 +7,8 @@ torch.nn.Module over the HIP operators (semi_pd_amd.ops).  Class names follow th
                               layers/linear.py:296-460, 725-1100, 1103-1280; vocab_parallel_embedding.py:174-500
   LogitsProcessor             layers/logits_processor.py:220-445
   Sampler                     layers/sampler.py:29-171 (greedy branch)
-Dense GEMMs stay on hipBLASLt through F.linear (SURVEY §2.2 "TP linear").
+Dense GEMMs: hipBLASLt through F.linear (SURVEY §2.2 "TP linear") for prefill-sized calls, the persistent
+weight-streaming kernel (ops.stream_linear) for batches of at most 64 rows, i.e. every decode step.
 """
 from __future__ import annotations
 
@@ -180,6 +181,34 @@ def get_rope(head_size: int, rotary_dim: int, max_position: int, base: float, is
     return rope
 
 
+# --------------------------------------------------------------------------- dense GEMM dispatch
+# Batches of at most 64 rows (decode steps, a short last chunk of a prefill) go through the LDS-DMA
+# weight-streaming kernel (csrc/stream_linear.hip); everything else stays on hipBLASLt (F.linear).
+_STREAM_LINEAR = {"enabled": False}
+
+
+def set_stream_linear(enabled: bool):
+    """Called once per process by the model runner."""
+    _STREAM_LINEAR["enabled"] = bool(enabled)
+
+
+def dense_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """UnquantizedLinearMethod.apply (layers/linear.py:165-172)."""
+    if (_STREAM_LINEAR["enabled"] and bias is None and x.dim() == 2 and x.shape[0] <= ops.STREAM_LINEAR_MAX_ROWS
+            and ops.stream_linear_is_supported(x, weight)):
+        return ops.stream_linear(x, weight)
+    return F.linear(x, weight, bias)
+
+
+def gate_up_silu(x: torch.Tensor, gate_up_proj: "MergedColumnParallelLinear", act_fn) -> torch.Tensor:
+    """act_fn(gate_up_proj(x)) (models/llama.py:88-92); one launch for decode batches of a bf16 / f16 layer."""
+    if (_STREAM_LINEAR["enabled"] and gate_up_proj.quant_config is None and gate_up_proj.bias is None
+            and isinstance(act_fn, SiluAndMul) and x.dim() == 2 and x.shape[0] <= ops.STREAM_LINEAR_MAX_ROWS
+            and ops.stream_linear_is_supported(x, gate_up_proj.weight, fuse_silu_mul=True)):
+        return ops.stream_linear(x, gate_up_proj.weight, fuse_silu_mul=True)
+    return act_fn(gate_up_proj(x))
+
+
 # --------------------------------------------------------------------------- tensor-parallel linear
 def _shard(n: int, tp: int) -> int:
     assert n % tp == 0, f"{n} is not divisible by tp={tp}"
@@ -234,7 +263,7 @@ class ColumnParallelLinear(nn.Module):
         if self.quant_config:
             return apply_w8a8_block_fp8_linear(x, self.weight, self.quant_config.weight_block_size,
                                                self.weight_scale_inv, self.bias, x_quant=x_quant)
-        return F.linear(x, self.weight, self.bias)
+        return dense_linear(x, self.weight, self.bias)
 
 
 class ReplicatedLinear(ColumnParallelLinear):
@@ -349,7 +378,7 @@ class RowParallelLinear(nn.Module):
             out = apply_w8a8_block_fp8_linear(x, self.weight, self.quant_config.weight_block_size,
                                               self.weight_scale_inv, bias)
         else:
-            out = F.linear(x, self.weight, bias)
+            out = dense_linear(x, self.weight, bias)
         if self.reduce_results and get_tensor_model_parallel_world_size() > 1:
             out = tensor_model_parallel_all_reduce(out)
         return out

@@ -116,7 +116,7 @@ class ModelRunner:
                  disable_cuda_graph: bool = False, cuda_graph_max_bs: int = 256,
                  load_state_dict: Optional[Dict[str, torch.Tensor]] = None, model_path: Optional[str] = None,
                  load_format: str = "dummy", kv_cache_dtype: str = "auto", disable_custom_all_reduce: bool = False,
-                 enable_ep_moe: bool = False):
+                 enable_ep_moe: bool = False, disable_stream_linear: bool = False):
         self.model_config = model_config
         self.gpu_id, self.tp_rank, self.tp_size = gpu_id, tp_rank, tp_size
         self.dtype = dtype
@@ -147,6 +147,10 @@ class ModelRunner:
         # TP rank and in both instances (model_runner.py: set_random_seed in every worker)
         torch.manual_seed(seed)
         torch.cuda.manual_seed_all(seed)
+        # dense layers with at most 64 rows (decode steps) stream their weights through LDS-DMA rings
+        # (csrc/stream_linear.hip) instead of the library GEMM
+        from semi_pd_amd.layers.basic import set_stream_linear
+        set_stream_linear(not disable_stream_linear)
 
         # ---- model -------------------------------------------------------------------------
         from semi_pd_amd.layers.moe import set_expert_parallel

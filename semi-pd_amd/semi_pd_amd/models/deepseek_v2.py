@@ -24,7 +24,7 @@ from semi_pd_amd.distributed import (get_tensor_model_parallel_world_size, tenso
 from semi_pd_amd.layers.attention_backend import RadixAttention
 from semi_pd_amd.layers.basic import (ColumnParallelLinear, LogitsProcessor, MergedColumnParallelLinear,
                                       ParallelLMHead, ReplicatedLinear, RMSNorm, RowParallelLinear, SiluAndMul,
-                                      VocabParallelEmbedding, get_rope, yarn_get_mscale)
+                                      VocabParallelEmbedding, gate_up_silu, get_rope, yarn_get_mscale)
 from semi_pd_amd.layers.fp8 import Fp8Config, block_dequantize_weight, quantize_activation
 from semi_pd_amd.layers.moe import FusedMoE
 
@@ -83,8 +83,10 @@ class DeepseekV2MLP(nn.Module):
         self.act_fn = SiluAndMul()
 
     def forward(self, x, x_quant=None):
-        gate_up = self.gate_up_proj(x, x_quant=x_quant)
         qc = self.down_proj.quant_config
+        if qc is None and self.gate_up_proj.quant_config is None:
+            return self.down_proj(gate_up_silu(x, self.gate_up_proj, self.act_fn))
+        gate_up = self.gate_up_proj(x, x_quant=x_quant)
         if qc is not None and gate_up.dim() == 2:
             # block-fp8: SiLU * mul and the quantisation in front of down_proj in one kernel
             q, s = ops.silu_and_mul_quant_fp8(gate_up, qc.weight_block_size[1])

@@ -17,7 +17,7 @@ from semi_pd_amd.distributed import get_tensor_model_parallel_world_size
 from semi_pd_amd.layers.attention_backend import RadixAttention
 from semi_pd_amd.layers.basic import (LogitsProcessor, MergedColumnParallelLinear, ParallelLMHead,
                                       QKVParallelLinear, RMSNorm, RowParallelLinear, SiluAndMul,
-                                      VocabParallelEmbedding, get_rope)
+                                      VocabParallelEmbedding, gate_up_silu, get_rope)
 
 
 @dataclass
@@ -55,7 +55,7 @@ class LlamaMLP(nn.Module):
         self.act_fn = SiluAndMul()
 
     def forward(self, x):
-        return self.down_proj(self.act_fn(self.gate_up_proj(x)))
+        return self.down_proj(gate_up_silu(x, self.gate_up_proj, self.act_fn))
 
 
 class LlamaAttention(nn.Module):

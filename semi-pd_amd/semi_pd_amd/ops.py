@@ -359,6 +359,41 @@ def linear(x: torch.Tensor, weight: torch.Tensor, num_cus: int = 0, out: Optiona
     return out
 
 
+STREAM_LINEAR_MAX_ROWS = 64
+
+
+def stream_linear_is_supported(x: torch.Tensor, weight: torch.Tensor, fuse_silu_mul: bool = False) -> bool:
+    if not (x.is_cuda and x.dim() == 2 and weight.dim() == 2 and 0 < x.shape[0] <= STREAM_LINEAR_MAX_ROWS
+            and x.dtype == weight.dtype and x.dtype in (torch.bfloat16, torch.float16)
+            and x.stride(1) == 1 and weight.is_contiguous() and x.shape[1] == weight.shape[1]):
+        return False
+    N, K = weight.shape
+    n_out = N // 2 if fuse_silu_mul else N
+    return (K % 128 == 0 and n_out % 16 == 0 and (not fuse_silu_mul or N % 2 == 0)
+            and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0)
+
+
+def stream_linear(x: torch.Tensor, weight: torch.Tensor, fuse_silu_mul: bool = False,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x @ weight.T for decode batches (at most 64 rows) with the LDS-DMA weight-streaming kernel; fuse_silu_mul:
+    weight = merged [gate; up] and the result is SiluAndMul(x @ weight.T)
+    (UnquantizedLinearMethod.apply layers/linear.py:165-172; LlamaMLP models/llama.py:88-92)."""
+    if not stream_linear_is_supported(x, weight, fuse_silu_mul):
+        raise RuntimeError("stream_linear: unsupported shapes / dtypes / strides for the weight-streaming kernel")
+    M, K = x.shape
+    N = weight.shape[0]
+    n_out = N // 2 if fuse_silu_mul else N
+    if out is None:
+        out = torch.empty((M, n_out), dtype=x.dtype, device=x.device)
+    elif out.shape != (M, n_out) or out.dtype != x.dtype or out.stride(1) != 1:
+        raise RuntimeError("stream_linear: bad out tensor")
+    ws = _linear_workspace(x.device)   # fp32 K-slice planes; calls on one stream are ordered, so one buffer serves all
+    check(_lib.load().semipd_stream_linear(ptr(out), ptr(x), ptr(weight), ptr(ws), ws.numel(), M, N, K, x.stride(0),
+                                           out.stride(0), 1 if fuse_silu_mul else 0, dtype_code(x.dtype),
+                                           current_stream(x.device)), "stream_linear")
+    return out
+
+
 # --------------------------------------------------------------------------- stochastic sampling
 def _probs_2d(probs: torch.Tensor, name: str) -> Tuple[int, int]:
     if probs.dim() != 2 or probs.dtype != torch.float32 or not probs.is_contiguous():

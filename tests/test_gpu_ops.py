@@ -627,3 +627,53 @@ def test_linear_strided_rows_and_f16(ops, device):
     torch.testing.assert_close(got.cpu().float(), big[:, 512:].float() @ w.float().T, rtol=2e-3, atol=2e-2)
     with pytest.raises(RuntimeError):
         ops.linear(torch.randn(300, 512, device=device, dtype=torch.float16), w.to(device))
+
+
+# ----------------------------------------------------------------------------- decode batches: LDS-DMA streaming linear
+@pytest.mark.parametrize("M", [1, 7, 16, 17, 33, 48, 64])
+@pytest.mark.parametrize("N,K", [(4096, 4096), (6144, 4096), (28672, 4096), (4096, 14336), (1008, 512), (16, 1024)])
+def test_stream_linear(ops, device, M, N, K):
+    """F.linear semantics (layers/linear.py:165-172) from the weight-streaming kernel, bf16 bar of
+    test_fused_moe.py:31-44; deterministic (K slices are summed in slice order)."""
+    torch.manual_seed(M + N + K)
+    x = torch.randn(M, K).to(torch.bfloat16)
+    w = (torch.randn(N, K) * 0.05).to(torch.bfloat16)
+    want = x.float() @ w.float().T
+    got = ops.stream_linear(x.to(device), w.to(device))
+    torch.testing.assert_close(got.cpu().float(), want, rtol=2e-2, atol=2e-2 * float(want.abs().max()))
+    assert torch.equal(got, ops.stream_linear(x.to(device), w.to(device)))
+
+
+@pytest.mark.parametrize("M", [1, 16, 31, 64])
+@pytest.mark.parametrize("inter,K", [(14336, 4096), (1408, 2048), (48, 512)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_stream_linear_fused_silu_mul(ops, device, M, inter, K, dtype):
+    """gate_up_proj + SiluAndMul in one launch (models/llama.py:88-92): the GEMM outputs are rounded to the
+    activation type before the activation, so the result equals the oracle's two-step value up to the
+    accumulation order of the GEMM."""
+    torch.manual_seed(M + inter)
+    x = torch.randn(M, K).to(dtype)
+    w = (torch.randn(2 * inter, K) * 0.05).to(dtype)
+    gate_up = (x.float() @ w.float().T).to(dtype)
+    want = O.silu_and_mul(gate_up)
+    got = ops.stream_linear(x.to(device), w.to(device), fuse_silu_mul=True)
+    assert got.shape == (M, inter)
+    tol = dict(rtol=2e-2, atol=2e-2) if dtype == torch.bfloat16 else dict(rtol=4e-3, atol=4e-3)
+    torch.testing.assert_close(got.cpu().float(), want.float(), **tol)
+    # and the unfused product path: stream_linear, then the activation kernel (same K slicing -> same GEMM bits)
+    two_step = ops.silu_and_mul(ops.stream_linear(x.to(device), w.to(device)))
+    torch.testing.assert_close(got.float(), two_step.float(), rtol=1.6e-2 if dtype == torch.bfloat16 else 2e-3, atol=1e-3)
+
+
+def test_stream_linear_strided_rows_and_limits(ops, device):
+    torch.manual_seed(5)
+    big = torch.randn(9, 2 * 512).to(torch.float16)
+    w = (torch.randn(256, 512) * 0.05).to(torch.float16)
+    x = big.to(device)[:, 512:]  # row stride 1024, 16-byte aligned start
+    got = ops.stream_linear(x, w.to(device))
+    torch.testing.assert_close(got.cpu().float(), big[:, 512:].float() @ w.float().T, rtol=2e-3, atol=2e-2)
+    assert not ops.stream_linear_is_supported(torch.randn(65, 512, device=device, dtype=torch.float16), w.to(device))
+    assert not ops.stream_linear_is_supported(torch.randn(8, 96, device=device, dtype=torch.float16),
+                                              torch.randn(64, 96, device=device, dtype=torch.float16))  # k % 128
+    with pytest.raises(RuntimeError):
+        ops.stream_linear(torch.randn(65, 512, device=device, dtype=torch.float16), w.to(device))

@@ -224,13 +224,61 @@ def bench_linear():
             del ws
 
 
+def bench_stream_linear():
+    """Decode-sized dense layers of Llama-3-8B: hipBLASLt (F.linear [+ silu_and_mul]) vs ops.stream_linear with its
+    number of K slices swept through SEMIPD_SL_KS; KBENCH_NUM_CUS = CUs assumed."""
+    import torch.nn.functional as F
+    ncu = int(os.environ.get("KBENCH_NUM_CUS", "0"))
+    print("# stream_linear M x [N, K]: hipBLASLt us | default us GB/s | best knob us GB/s   HSA_CU_MASK=%s num_cus=%d"
+          % (os.environ.get("HSA_CU_MASK", "-"), ncu))
+    full = os.environ.get("KBENCH_SL_SWEEP", "1") == "1"
+    for M in [int(v) for v in os.environ.get("KBENCH_MS", "8,16,32,64").split(",")]:
+        for (N, K, silu) in ((28672, 4096, True), (28672, 4096, False), (4096, 14336, False), (6144, 4096, False),
+                             (4096, 4096, False)):
+            copies = max(2, int(1.2e9 // (N * K * 2)))
+            ws = [torch.randn(N, K, device=dev, dtype=torch.bfloat16) * 0.02 for _ in range(copies)]
+            x = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
+            it = [0]
+
+            def f1():
+                it[0] += 1
+                y = F.linear(x, ws[it[0] % copies])
+                return ops.silu_and_mul(y) if silu else y
+
+            def f2():
+                it[0] += 1
+                return ops.stream_linear(x, ws[it[0] % copies], fuse_silu_mul=silu)
+            t1 = timeit(f1, iters=3 * copies)
+            os.environ.pop("SEMIPD_SL_KS", None)
+            t0 = timeit(f2, iters=3 * copies)
+            res = {}
+            if full:
+                for ksp in (1, 2, 3, 4, 6, 8, 16):
+                    os.environ["SEMIPD_SL_KS"] = str(ksp)
+                    res[ksp] = timeit(f2, iters=2 * copies)
+                os.environ.pop("SEMIPD_SL_KS", None)
+            by = N * K * 2
+            line = (f"M={M:3d} N={N:6d} K={K:6d} silu={int(silu)}: blaslt {t1 * 1e6:6.1f} | default {t0 * 1e6:6.1f} us "
+                    f"{by / t0 / 1e9:5.0f} GB/s")
+            if res:
+                best = min(res, key=res.get)
+                top = sorted(res.items(), key=lambda kv: kv[1])[:4]
+                line += (f" | best KS={best} {res[best] * 1e6:6.1f} us {by / res[best] / 1e9:5.0f} GB/s | "
+                         + " ".join(f"{k}:{v * 1e6:.0f}" for k, v in sorted(res.items())))
+            print(line, flush=True)
+            del ws
+
+
 def bench_linear_prefill():
     """Prefill-sized dense layers of Llama-3-8B through hipBLASLt under a CU mask (HSA_CU_MASK) with / without
     TENSILE_STREAMK_MAX_CUS: does the library's stream-K grid follow the share?"""
     import torch.nn.functional as F
-    print("# prefill linear M x [N, K] (hipBLASLt): us, TFLOP/s   HSA_CU_MASK=%s TENSILE_STREAMK_MAX_CUS=%s"
-          % (os.environ.get("HSA_CU_MASK", "-"), os.environ.get("TENSILE_STREAMK_MAX_CUS", "-")))
-    for M in (16, 1024, 4096, 8192):
+    if os.environ.get("KBENCH_BLAS") == "rocblas":
+        torch.backends.cuda.preferred_blas_library("cublas")   # = rocBLAS on ROCm
+    print("# prefill linear M x [N, K] (%s): us, TFLOP/s   HSA_CU_MASK=%s  %s"
+          % (os.environ.get("KBENCH_BLAS", "hipBLASLt"), os.environ.get("HSA_CU_MASK", "-"),
+             " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("TENSILE_"))))
+    for M in [int(x) for x in os.environ.get("KBENCH_MS", "16,1024,4096,8192").split(",")]:
         for (N, K) in ((28672, 4096), (4096, 14336), (6144, 4096), (4096, 4096)):
             w = torch.randn(N, K, device=dev, dtype=torch.bfloat16) * 0.02
             x = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
@@ -337,6 +385,8 @@ if __name__ == "__main__":
         bench_linear_sweep()
     if which == "linear":
         bench_linear()
+    if which == "stream_linear":
+        bench_stream_linear()
     if which == "linear_prefill":
         bench_linear_prefill()
     if which == "decode_small":
