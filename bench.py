@@ -185,6 +185,36 @@ def cpu_baseline(cfg, input_len, output_len, budget_s=25.0):
                       f"measured prefill {t_prefill:.2f}s, decode step {t_decode * 1e3:.0f}ms, head {t_head * 1e3:.0f}ms"}
 
 
+def cpu_baseline_opt(cfg, num_requests, input_len, output_len, seed):
+    """BASELINE config 1 end to end on the host: the CPU oracle of the OPT model (oracle/model.py OracleOPT, HF
+    semantics, fp32) with the same seeded dummy weights and the same prompts serves ALL requests as one batch --
+    one prefill, then output_len - 1 greedy decode steps (bench_one_batch.py:229-256 drives the reference like this)."""
+    from oracle.model import OracleOPT
+    from semi_pd_amd.model_executor.model_runner import build_model, dummy_init_weights
+    cores = min(len(os.sched_getaffinity(0)), 32)
+    torch.set_num_threads(cores)
+    model = build_model(cfg, torch.float32)
+    dummy_init_weights(model, torch.device("cpu"), seed)
+    sd = {k: v.float() for k, v in model.state_dict().items()}
+    oracle = OracleOPT(cfg, sd)
+    prompts = make_requests(num_requests, input_len, cfg.vocab_size, seed)
+    t0 = time.time()
+    logits, kv, lens = oracle.prefill(prompts)
+    t_prefill = time.time() - t0
+    lens = list(lens)
+    cur = [int(torch.argmax(l)) for l in logits]
+    t0 = time.time()
+    for _ in range(output_len - 1):
+        logits = oracle.decode_step(cur, kv, lens)
+        cur = [int(torch.argmax(l)) for l in logits]
+    t_decode = time.time() - t0
+    total = t_prefill + t_decode
+    return {"value": num_requests * output_len / total, "unit": "output tokens/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/model.py OracleOPT fp32, the WHOLE workload: {num_requests} requests in={input_len} "
+                      f"out={output_len} as one batch; prefill {t_prefill:.2f}s, {output_len - 1} decode steps "
+                      f"{t_decode:.2f}s ({1e3 * t_decode / max(output_len - 1, 1):.0f} ms per step)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -218,10 +248,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--fixed-load", action="store_true", help="--tp with N > 1: do not scale requests / rate with N")
-    ap.add_argument("--tp", action="store_true",
-                    help="N > 1: ONE engine, tensor parallel over the N GPUs (models that need it, e.g. 70B TP=8), "
-                         "instead of N independent replicas")
+    ap.add_argument("--fixed-load", action="store_true", help="N > 1 (tensor parallel): do not scale requests / rate with N")
+    ap.add_argument("--tp", action="store_true", help="(default for N > 1; kept for old command lines)")
+    ap.add_argument("--replicas", action="store_true",
+                    help="N > 1: N independent Semi-PD replicas, one per GPU (no data-path collective), instead of ONE "
+                         "engine tensor-parallel over the N GPUs")
+    ap.add_argument("--no-saturation-wave", action="store_true",
+                    help="skip the extra (untimed for `value`) wave with all requests sent at once")
     ap.add_argument("--rate-sweep", default="", help="comma-separated Poisson rates; one extra (untimed for "
                     "`value`) wave per rate after the timed steps, reported under qps_sweep (BASELINE config 2)")
     args = ap.parse_args()
@@ -232,9 +265,11 @@ def main():
         local_rank = 0  # functional check of the N > 1 code path on a one-GPU box (replicas share the GPU)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    # N > 1, default: N independent Semi-PD replicas, one per GPU, each serving the N = 1 workload with its own
-    # requests (serving requests are independent units: no data-path collective, "scaling": "weak").  --tp: one
-    # engine, tensor parallel over the N GPUs, serving N times the offered load unless --fixed-load.
+    # N > 1, default: ONE engine, tensor parallel over the N GPUs (heads and MLP columns sharded, an
+    # all-reduce of [tokens, hidden] after o_proj and down_proj of every layer over RCCL / the peer-memory kernels),
+    # serving N times the offered load unless --fixed-load ("scaling": "weak").  --replicas: N independent Semi-PD
+    # engines, one per GPU, each with the N = 1 workload (no data-path collective).
+    args.tp = world > 1 and not args.replicas
     tp_world = world if args.tp else 1
     replica = rank if (world > 1 and not args.tp) else 0
     if world > 1 and args.tp and not args.fixed_load:
@@ -314,6 +349,14 @@ def main():
                 sm = summarize(recs, dur)
                 sweep.append({"request_rate": rate, **{k: (round(v, 2) if isinstance(v, float) else v)
                                                        for k, v in sm.items()}})
+        saturation = None
+        if not args.no_saturation_wave and args.request_rate > 0:
+            # capacity next to the load-bound headline: the same requests, all sent at once
+            barrier()
+            if driver:
+                recs, dur = run_wave(engine, prompts, arrival_times(args.num_requests, 0.0, args.seed), args.output_len)
+                sm = summarize(recs, dur)
+                saturation = {k: (round(v, 2) if isinstance(v, float) else v) for k, v in sm.items()}
         barrier()
     finally:
         engine.shutdown()
@@ -342,13 +385,10 @@ def main():
             kname = ("mla_decode_kernel" if "Deepseek" in cfg.architectures[0] else "decode_mfma_kernel")
             roofline = {"bound": "hbm", "kernel": kname + " + decode_stage2_kernel (one decode_attention call)", "achieved": round(k["gbps"], 1),
                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(k["gbps"] / HBM_PEAK_GBPS, 4),
-                        # PMC counters cannot be read from inside this process: `traffic` stays null here;
-                        # the separate rocprofv3 --pmc FETCH_SIZE pass of this command (x2 gfx950 correction)
-                        # is committed under profiles/ and gave traffic = 1.03 x algorithmic bytes per launch
+                        # PMC counters cannot be read from inside this process: `traffic` is null in this line.
+                        # The rocprofv3 --pmc FETCH_SIZE pass of the same command (x2 gfx950 correction) is a
+                        # separate run; its summary is committed under profiles/ (see DESIGN.md, section 6).
                         "traffic": None,
-                        "traffic_pmc": {"ratio_to_algorithmic": 1.03,
-                                        "source": "profiles/r01_pmc_decode_attention_in_situ.txt"}
-                        if kname == "decode_mfma_kernel" else None,
                         "avg_launch_us": round(k["avg_us"], 2),
                         "avg_launch_us_minus_event_overhead": round(k.get("avg_us_minus_event_overhead", k["avg_us"]), 2),
                         "event_pair_overhead_us": kt.get("_event_pair_overhead_us"),
@@ -360,9 +400,12 @@ def main():
                                          "frac": round(k["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4),
                                          "avg_launch_us": round(k["avg_us"], 1), "launches_sampled": k["launches"]}
     cpu = None
-    if not args.no_cpu_baseline and world == 1 and cfg.architectures[0] == "LlamaForCausalLM":
+    if not args.no_cpu_baseline and world == 1 and cfg.architectures[0] in ("LlamaForCausalLM", "OPTForCausalLM"):
         try:
-            cpu = cpu_baseline(cfg, args.input_len, args.output_len)
+            if cfg.architectures[0] == "OPTForCausalLM":
+                cpu = cpu_baseline_opt(cfg, args.num_requests, args.input_len, args.output_len, args.seed)
+            else:
+                cpu = cpu_baseline(cfg, args.input_len, args.output_len)
         except Exception as e:  # the baseline must never take the measured number down with it
             cpu = {"error": repr(e)}
     out = {
@@ -385,6 +428,17 @@ def main():
                    "kv_cache_dtype": args.kv_cache_dtype},
         "roofline": roofline, "roofline_extra": extra, "cpu_baseline": cpu,
     }
+    if saturation:
+        out["saturation"] = {"note": "extra wave, every request sent at t = 0: output tok/s here is the engine's capacity; "
+                                     "`value` above is measured at the Poisson rate named in config (load-bound)",
+                             **saturation}
+    if tp_world > 1:
+        L, H = cfg.num_hidden_layers, cfg.hidden_size
+        out["tensor_parallel"] = {"tp_world": tp_world, "ranks": world, "backend": "rccl (nccl backend of torch.distributed) + "
+                                  "peer-memory all-reduce kernels for payloads up to 16 MB",
+                                  "all_reduce_calls_per_forward": 2 * L + 1,
+                                  "all_reduce_bytes_per_token": (2 * L + 1) * H * 2,
+                                  "logits_all_gather_bytes_per_request": cfg.vocab_size * 4}
     if sweep:
         out["qps_sweep"] = sweep
     print(json.dumps(out), flush=True)

@@ -90,6 +90,64 @@ def get_custom_all_reduce():
     return _CUSTOM_AR
 
 
+# ---------------------------------------------------------------------------- all-reduce overlapped with the GEMMs
+# The reference reduces on the compute stream, blocking (layers/linear.py:1266).  A prefill-sized row-parallel
+# layer here is cut into token chunks: the all-reduce of chunk i runs on a communication stream while the GEMM of
+# chunk i + 1 runs on the compute stream (RowParallelLinear.forward).  The reduce is element-wise, so the chunking
+# does not change a single bit of the result.
+_COMM_STREAMS = {}
+OVERLAP_MIN_TOKENS = int(os.environ.get("SEMIPD_AR_OVERLAP_MIN_TOKENS", "1024"))   # below: one blocking call
+_OVERLAP = {"enabled": os.environ.get("SEMIPD_DISABLE_AR_OVERLAP", "0") != "1"}
+
+
+def set_all_reduce_overlap(enabled: bool) -> None:
+    _OVERLAP["enabled"] = bool(enabled)
+
+
+def all_reduce_overlap_chunks(num_tokens: int) -> int:
+    """Token chunks of a row-parallel layer whose all-reduce is overlapped with its own GEMM: chunks of at least
+    512 rows (the GEMM stays efficient), at most 4 (each chunk costs one collective launch)."""
+    if _TP_SIZE == 1 or not _OVERLAP["enabled"] or num_tokens < OVERLAP_MIN_TOKENS:
+        return 1
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        return 1
+    return max(1, min(4, num_tokens // 512))
+
+
+class _Pending:
+    """A reduce in flight; wait() orders the CURRENT stream (or the host, on CPU tensors) behind it."""
+
+    def __init__(self, work=None, event=None):
+        self.work, self.event = work, event
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+        if self.event is not None:
+            torch.cuda.current_stream().wait_event(self.event)
+
+
+def tensor_model_parallel_all_reduce_async(input_: torch.Tensor) -> _Pending:
+    """In-place SUM all-reduce of `input_` that does not block the compute stream: the peer-memory kernels run on
+    a dedicated communication stream behind the work already queued on the current one, RCCL (and gloo on CPU)
+    through async_op.  Every rank must issue the same sequence of calls; the caller waits on the returned handle
+    before it reads `input_` or issues a blocking collective."""
+    if _TP_SIZE == 1:
+        return _Pending()
+    if _CUSTOM_AR is not None and _CUSTOM_AR.should_custom_ar(input_):
+        dev = input_.device
+        comm = _COMM_STREAMS.get(dev.index)
+        if comm is None:
+            comm = _COMM_STREAMS[dev.index] = torch.cuda.Stream(device=dev)
+        comm.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(comm):
+            _CUSTOM_AR.all_reduce(input_, out=input_)
+            ev = comm.record_event()
+        input_.record_stream(comm)
+        return _Pending(event=ev)
+    return _Pending(work=dist.all_reduce(input_, group=_DEVICE_GROUP, async_op=True))
+
+
 def tensor_model_parallel_all_gather(input_: torch.Tensor, dim: int = -1) -> torch.Tensor:
     """All-gather along `dim` (logits [B, V/tp] -> [B, V], layers/logits_processor.py:426-427;
     parallel_state.py:438-489)."""

@@ -23,8 +23,9 @@ from torch import nn
 from semi_pd_amd import ops
 from semi_pd_amd.layers.fp8 import (FP8_DTYPE, apply_w8a8_block_fp8_linear, check_quantisable_input, scale_shape,
                                     shard_rows_of_scale)
-from semi_pd_amd.distributed import (get_tensor_model_parallel_rank, get_tensor_model_parallel_world_size,
-                                     tensor_model_parallel_all_gather, tensor_model_parallel_all_reduce)
+from semi_pd_amd.distributed import (all_reduce_overlap_chunks, get_tensor_model_parallel_rank,
+                                     get_tensor_model_parallel_world_size, tensor_model_parallel_all_gather,
+                                     tensor_model_parallel_all_reduce, tensor_model_parallel_all_reduce_async)
 
 
 # --------------------------------------------------------------------------- norm / activation
@@ -378,9 +379,31 @@ class RowParallelLinear(nn.Module):
             out = apply_w8a8_block_fp8_linear(x, self.weight, self.quant_config.weight_block_size,
                                               self.weight_scale_inv, bias)
         else:
+            chunks = all_reduce_overlap_chunks(x.shape[0]) if (self.reduce_results and x.dim() == 2) else 1
+            if chunks > 1:
+                return self._forward_overlapped(x, bias, chunks)
             out = dense_linear(x, self.weight, bias)
         if self.reduce_results and get_tensor_model_parallel_world_size() > 1:
             out = tensor_model_parallel_all_reduce(out)
+        return out
+
+    def _forward_overlapped(self, x: torch.Tensor, bias: Optional[torch.Tensor], chunks: int) -> torch.Tensor:
+        """Prefill-sized call under tensor parallelism: the all-reduce of token chunk i (communication stream) runs
+        while the GEMM of chunk i + 1 runs (compute stream).  Same bits as the blocking form on the same chunks:
+        the reduce is element-wise."""
+        T = x.shape[0]
+        out = torch.empty((T, self.weight.shape[0]), dtype=x.dtype, device=x.device)
+        step = -(-T // chunks)
+        step = -(-step // 16) * 16
+        pending = []
+        for a in range(0, T, step):
+            o = out[a:a + step]
+            torch.mm(x[a:a + step], self.weight.t(), out=o)
+            if bias is not None:
+                o += bias
+            pending.append(tensor_model_parallel_all_reduce_async(o))
+        for p in pending:
+            p.wait()
         return out
 
     def forward_prequantized(self, x_q: torch.Tensor, x_s: torch.Tensor, out_dtype: torch.dtype):

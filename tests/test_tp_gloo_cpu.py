@@ -97,6 +97,39 @@ def _tp_layers(rank, world):
     return True
 
 
+def _row_parallel_overlap(rank, world):
+    """RowParallelLinear on a prefill-sized batch: the all-reduce of token chunk i is issued without blocking
+    (async collective) while the GEMM of chunk i + 1 runs; the result has the bits of the blocking form on the
+    same chunks and matches the unsharded layer."""
+    import torch.distributed as dist
+    from semi_pd_amd import distributed as D
+    from semi_pd_amd.layers.basic import RowParallelLinear
+    g = torch.Generator().manual_seed(3)
+    T, I, H = 2500, 96, 64
+    full_w = torch.randn(H, I, generator=g)
+    x_full = torch.randn(T, I, generator=g)
+    layer = RowParallelLinear(I, H, params_dtype=torch.float32)
+    layer.weight.data.copy_(layer.weight.tp_shard(full_w))
+    n = I // world
+    x = x_full[:, rank * n:(rank + 1) * n].contiguous()
+    assert D.all_reduce_overlap_chunks(T) == 4 and D.all_reduce_overlap_chunks(600) == 1
+    got = layer(x)
+    # blocking form on the same chunks
+    step = -(-(-(-T // 4)) // 16) * 16
+    want = torch.empty(T, H)
+    for a in range(0, T, step):
+        torch.mm(x[a:a + step], layer.weight.t(), out=want[a:a + step])
+        dist.all_reduce(want[a:a + step])
+    assert torch.equal(got, want)
+    torch.testing.assert_close(got, x_full @ full_w.T, rtol=1e-4, atol=1e-3)
+    # and the switch: one blocking call, same values up to GEMM blocking
+    D.set_all_reduce_overlap(False)
+    assert D.all_reduce_overlap_chunks(T) == 1
+    torch.testing.assert_close(layer(x), want, rtol=1e-5, atol=1e-5)
+    D.set_all_reduce_overlap(True)
+    return True
+
+
 def _broadcast(rank, world):
     from semi_pd_amd.distributed import barrier_cpu, broadcast_pyobj, get_tp_cpu_group
     data = [{"rids": ["a", "b"], "x": list(range(1000))}] if rank == 0 else []
@@ -150,6 +183,10 @@ def _sched_proc(role, rank, port, r2t, kv, names, q, paths):
 # ------------------------------------------------------------------------------ tests
 def test_tp2_layers_match_unsharded():
     assert all(_spawn("_tp_layers").values())
+
+
+def test_tp2_row_parallel_all_reduce_overlapped_with_gemm():
+    assert all(_spawn("_row_parallel_overlap").values())
 
 
 def test_tp2_broadcast_pyobj():
