@@ -229,6 +229,8 @@ def main():
     ap.add_argument("--prefill-cu", type=int, default=50)
     ap.add_argument("--decode-cu", type=int, default=50)
     ap.add_argument("--cu-mask-mode", default="env")
+    ap.add_argument("--prefill-priority", type=int, default=0, help="HIP stream priority of the prefill instance (-1 = high)")
+    ap.add_argument("--decode-priority", type=int, default=0, help="HIP stream priority of the decode instance (-1 = high)")
     ap.add_argument("--disable-stream-linear", action="store_true",
                     help="decode-batch dense layers through hipBLASLt instead of the persistent streaming kernel (A/B)")
     ap.add_argument("--library-gemm-grid", action="store_true",
@@ -306,6 +308,7 @@ def main():
                     max_total_tokens=args.max_total_tokens, prefill_cu_percent=args.prefill_cu,
                     decode_cu_percent=args.decode_cu, cu_mask_mode=args.cu_mask_mode,
                     library_gemm_grid=args.library_gemm_grid, disable_stream_linear=args.disable_stream_linear,
+                    prefill_stream_priority=args.prefill_priority, decode_stream_priority=args.decode_priority,
                     disable_cuda_graph=args.disable_cuda_graph, nccl_port_base=port_base,
                     disable_overlap_schedule=args.disable_overlap_schedule,
                     **({"chunked_prefill_size": args.chunked_prefill_size} if args.chunked_prefill_size else {}),

@@ -225,6 +225,18 @@ int semipd_stream_linear(void* out, const void* x, const void* weight, void* wor
                          int64_t rows, int64_t n, int64_t k, int64_t ldx, int64_t ldo, int fuse_silu_mul,
                          int dtype, void* stream);
 
+/* semipd_stream_linear stopped before its reduction: fp32 planes [*ksplit][rows][n] for a consumer that sums them
+ * in slice order itself, and semipd_fused_add_rmsnorm_planes, that consumer for the o_proj / down_proj outputs:
+ * x = T(sum of planes) (the row the GEMM would have written), residual += x, out = RMSNorm(residual) * weight --
+ * the bits of semipd_stream_linear followed by semipd_fused_add_rmsnorm, two launches instead of three.
+ * replaces RowParallelLinear.forward + RMSNorm.forward(x, residual) at decode batch sizes
+ *   (layers/linear.py:1241-1270, layers/layernorm.py:47-76, models/llama.py:237-253). */
+int semipd_stream_linear_planes(float* planes, size_t planes_bytes, const void* x, const void* weight, int64_t rows,
+                                int64_t n, int64_t k, int64_t ldx, int dtype, int* ksplit, void* stream);
+int semipd_fused_add_rmsnorm_planes(void* out, void* residual, const void* weight, const float* planes, int n_planes,
+                                    int64_t plane_elems, int64_t num_tokens, int64_t hidden, float eps, int dtype,
+                                    void* stream);
+
 /* Stochastic branch of Sampler.forward (layers/sampler.py:77-136).  All rows fp32, contiguous
  * [batch, vocab]; per-row parameter arrays may be NULL, then the scalar *_val applies to every row.
  *

@@ -23,16 +23,20 @@ void set_error(const char* fmt, ...) {
 // QUANT: the normalised row is also quantised per group of 8 * lanes_per_group elements (per_token_group_quant_fp8
 // of the output, layers/quantization/fp8_kernel.py:99-115) in the same pass: q [rows, hidden] e4m3fn, qs [rows,
 // hidden / group].  The values quantised are the T-rounded outputs, so the bytes equal those of the separate call.
-template <typename T, int MAXV, bool FUSED, bool QUANT = false>
+// PLANES: the input row is not in `in` but the sum, in slice order, of `n_planes` fp32 planes [rows, hidden]
+// (the K slices of csrc/stream_linear.hip), rounded to T first -- exactly the row the GEMM's own reduction
+// launch would have written, so the fusion changes no bit and saves that launch.
+template <typename T, int MAXV, bool FUSED, bool QUANT = false, bool PLANES = false>
 __global__ void __launch_bounds__(512)
 rmsnorm_vec_kernel(T* __restrict__ out, T* __restrict__ in, T* __restrict__ res,
                    const T* __restrict__ w, int64_t in_stride, int64_t out_stride, int nvec,
                    int hidden, float eps, uint8_t* __restrict__ q = nullptr, float* __restrict__ qs = nullptr,
-                   int lanes_per_group = 16, float q_eps = 1e-10f) {
+                   int lanes_per_group = 16, float q_eps = 1e-10f, const float* __restrict__ planes = nullptr,
+                   int n_planes = 0, int64_t plane_elems = 0) {
   constexpr int V = Elem<T>::kVec;
   __shared__ float red[16];
   const int64_t row = blockIdx.x;
-  T* in_row = in + row * in_stride;
+  T* in_row = PLANES ? nullptr : in + row * in_stride;
   T* out_row = out + row * out_stride;
   T* res_row = FUSED ? res + row * in_stride : nullptr;
   float x[MAXV][V];
@@ -51,7 +55,23 @@ rmsnorm_vec_kernel(T* __restrict__ out, T* __restrict__ in, T* __restrict__ res,
   for (int i = 0; i < MAXV; ++i) {
     const int v = threadIdx.x + i * blockDim.x;
     if (v < nvec) {
-      Vec16<T> a = load16(in_row + (int64_t)v * V);
+      Vec16<T> a;
+      if constexpr (PLANES) {
+        static_assert(!PLANES || Elem<T>::kVec == 8, "plane input: 16-bit activations");
+        const float* p = planes + row * (int64_t)hidden + (int64_t)v * V;
+        float4 lo = *reinterpret_cast<const float4*>(p), hi = *reinterpret_cast<const float4*>(p + 4);
+        for (int z = 1; z < n_planes; ++z) {
+          const float4 l2 = *reinterpret_cast<const float4*>(p + z * plane_elems);
+          const float4 h2 = *reinterpret_cast<const float4*>(p + z * plane_elems + 4);
+          lo.x += l2.x; lo.y += l2.y; lo.z += l2.z; lo.w += l2.w;
+          hi.x += h2.x; hi.y += h2.y; hi.z += h2.z; hi.w += h2.w;
+        }
+        const float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+        for (int j = 0; j < V; ++j) a.e[j] = Elem<T>::from_f(f[j]);
+      } else {
+        a = load16(in_row + (int64_t)v * V);
+      }
       if (FUSED) {
         Vec16<T> r = load16(res_row + (int64_t)v * V);
         Vec16<T> s;
@@ -691,6 +711,37 @@ int semipd_fused_add_rmsnorm(void* inout, void* residual, const void* weight, in
   SEMIPD_CHECK_ARG(num_tokens < (1ll << 31), SEMIPD_EINVAL, "fused_add_rmsnorm: too many rows");
   SEMIPD_DISPATCH_DTYPE(dtype, T, return (launch_rmsnorm<T, true>((T*)inout, (T*)inout, (T*)residual, (const T*)weight, num_tokens, hidden, hidden, hidden, eps, as_stream(stream))));
   return 0;
+}
+
+int semipd_fused_add_rmsnorm_planes(void* out, void* residual, const void* weight, const float* planes, int n_planes,
+                                    int64_t plane_elems, int64_t num_tokens, int64_t hidden, float eps, int dtype,
+                                    void* stream) {
+  SEMIPD_CHECK_ARG(num_tokens >= 0 && hidden > 0 && n_planes >= 1 && n_planes <= 64, SEMIPD_EINVAL,
+                   "fused_add_rmsnorm_planes: bad sizes");
+  if (num_tokens == 0) return 0;
+  SEMIPD_CHECK_ARG(out && residual && weight && planes, SEMIPD_EINVAL, "fused_add_rmsnorm_planes: null pointer");
+  SEMIPD_CHECK_ARG(dtype == SEMIPD_BF16 || dtype == SEMIPD_F16, SEMIPD_EDTYPE, "fused_add_rmsnorm_planes: bf16 / f16 only");
+  SEMIPD_CHECK_ARG(hidden % 8 == 0 && hidden <= 8 * 512 * 16 && aligned16(out) && aligned16(residual) && aligned16(weight) &&
+                   aligned16(planes) && plane_elems % 4 == 0 && plane_elems >= num_tokens * hidden,
+                   SEMIPD_EALIGN, "fused_add_rmsnorm_planes: hidden %% 8, 16-byte aligned rows required");
+  const int nvec = (int)(hidden / 8);
+  // the launch shape of launch_rmsnorm: same reduction order, hence the same bits as the unfused pair of launches
+  const int threads = nvec <= 64 ? 64 : nvec <= 128 ? 128 : nvec <= 1024 ? 256 : 512;
+  const int per = (nvec + threads - 1) / threads;
+  dim3 grid((unsigned)num_tokens), block(threads);
+#define RMSP_LAUNCH(MV)                                                                                              \
+  hipLaunchKernelGGL((rmsnorm_vec_kernel<T, MV, true, false, true>), grid, block, 0, as_stream(stream), (T*)out,      \
+                     (T*)nullptr, (T*)residual, (const T*)weight, hidden, hidden, nvec, (int)hidden, eps,             \
+                     (uint8_t*)nullptr, (float*)nullptr, 16, 1e-10f, planes, n_planes, plane_elems)
+  SEMIPD_DISPATCH_HALF(dtype, T, {
+    if (per <= 1) RMSP_LAUNCH(1);
+    else if (per <= 2) RMSP_LAUNCH(2);
+    else if (per <= 4) RMSP_LAUNCH(4);
+    else if (per <= 8) RMSP_LAUNCH(8);
+    else RMSP_LAUNCH(16);
+  });
+#undef RMSP_LAUNCH
+  return launch_status("fused_add_rmsnorm_planes");
 }
 
 int semipd_fused_add_rmsnorm_quant_fp8(void* inout, void* residual, const void* weight, void* q, float* qs,

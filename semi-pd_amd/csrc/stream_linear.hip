@@ -94,7 +94,8 @@ __device__ inline uint32_t sg_lds_addr(const void* p) {
 template <typename T, int MT, int NG, int NW, int R, int EPI>
 __global__ void __launch_bounds__(64 * NW)
 stream_gemm_glds_kernel(T* __restrict__ out, float* __restrict__ planes, const T* __restrict__ x,
-                        const T* __restrict__ w, int M, int N, int K, int64_t ldx, int64_t ldo, int kb_per_slice) {
+                        const T* __restrict__ w, int M, int N, int K, int64_t ldx, int64_t ldo, int kb_per_slice,
+                        int planes_only) {
   using L = SgLayout<MT, NG, NW, R>;
   extern __shared__ __attribute__((aligned(16))) char sg_smem[];
   const int lane = threadIdx.x & 63;
@@ -192,7 +193,7 @@ stream_gemm_glds_kernel(T* __restrict__ out, float* __restrict__ planes, const T
   }
 
   // ---- epilogue: lane holds C[m = t*16 + c16][n = nbase + q4*4 + r] ----
-  if (gridDim.y > 1) {
+  if (gridDim.y > 1 || planes_only) {
     float* pl = planes + (int64_t)ks * M * N;
 #pragma unroll
     for (int g = 0; g < NG; ++g)
@@ -281,7 +282,7 @@ static int sg_pick_ksplit(int n_rb, int nkb) {
 
 template <typename T, int MT, int NG, int NW, int R, int EPI>
 static int sg_launch(T* out, float* planes, size_t planes_bytes, const T* x, const T* w, int M, int N, int K,
-                     int64_t ldx, int64_t ldo, int force_ks, hipStream_t st) {
+                     int64_t ldx, int64_t ldo, int force_ks, hipStream_t st, int* planes_only_ks = nullptr) {
   using L = SgLayout<MT, NG, NW, R>;
   const int rows_per_wg = (EPI == SL_SILU_MUL ? 16 : 16 * NG) * NW;
   const int n_rows = EPI == SL_SILU_MUL ? N / 2 : N;
@@ -293,13 +294,17 @@ static int sg_launch(T* out, float* planes, size_t planes_bytes, const T* x, con
   ksp = (nkb + per - 1) / per;
   static bool attr_set = false;  // one per instantiation
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)stream_gemm_glds_kernel<T, MT, NG, NW, R, EPI>,
+    (void)hipFuncSetAttribute((const void*)stream_gemm_glds_kernel<T, MT, NG, NW, R, EPI>,
                         hipFuncAttributeMaxDynamicSharedMemorySize, L::kBytes);
     attr_set = true;
   }
   hipLaunchKernelGGL((stream_gemm_glds_kernel<T, MT, NG, NW, R, EPI>), dim3(n_rb, ksp), dim3(64 * NW), L::kBytes, st,
-                     out, planes, x, w, M, N, K, ldx, ldo, per);
+                     out, planes, x, w, M, N, K, ldx, ldo, per, planes_only_ks ? 1 : 0);
   int rc = launch_status("stream_gemm_glds");
+  if (planes_only_ks) {   // the consumer sums the planes (e.g. semipd_fused_add_rmsnorm_planes)
+    *planes_only_ks = ksp;
+    return rc;
+  }
   if (rc || ksp == 1) return rc;
   const int n_out = EPI == SL_SILU_MUL ? N / 2 : N;
   const int64_t items = (int64_t)M * (n_out / 4);
@@ -348,6 +353,27 @@ int semipd_stream_linear(void* out, const void* x, const void* weight, void* wor
 #define SL_GO(MTV) \
   if (fuse_silu_mul) { SEMIPD_DISPATCH_HALF(dtype, T, rc = (sg_launch<T, MTV, 2, 4, 3, SL_SILU_MUL>((T*)out, planes, pb, (const T*)x, (const T*)weight, M, N, K, ldx, ldo, force_ks, st))); } \
   else { SEMIPD_DISPATCH_HALF(dtype, T, rc = (sg_launch<T, MTV, 1, 8, 3, SL_PLAIN>((T*)out, planes, pb, (const T*)x, (const T*)weight, M, N, K, ldx, ldo, force_ks, st))); }
+  if (mt == 1) { SL_GO(1) } else if (mt == 2) { SL_GO(2) } else if (mt == 3) { SL_GO(3) } else { SL_GO(4) }
+#undef SL_GO
+  return rc;
+}
+
+/* The same GEMM, stopped before the reduction: fp32 planes [*ksplit][rows][n] in `planes` (at least
+ * semipd_stream_linear_workspace bytes), for a consumer that sums them itself (semipd_fused_add_rmsnorm_planes). */
+int semipd_stream_linear_planes(float* planes, size_t planes_bytes, const void* x, const void* weight, int64_t rows,
+                                int64_t n, int64_t k, int64_t ldx, int dtype, int* ksplit, void* stream) {
+  SEMIPD_CHECK_ARG(rows > 0 && rows <= 64 && n > 0 && k > 0 && ldx >= k && ksplit, SEMIPD_EINVAL,
+                   "stream_linear_planes: bad sizes");
+  SEMIPD_CHECK_ARG(planes && x && weight, SEMIPD_EINVAL, "stream_linear_planes: null pointer");
+  SEMIPD_CHECK_ARG(k % 128 == 0 && ldx % 8 == 0 && n % 16 == 0 && aligned16(x) && aligned16(weight) && aligned16(planes) &&
+                   n < (1 << 30) && k < (1 << 30) && planes_bytes >= (size_t)rows * n * 4,
+                   SEMIPD_EALIGN, "stream_linear_planes: k %% 128, n %% 16, 16-byte aligned rows required");
+  hipStream_t st = as_stream(stream);
+  const int M = (int)rows, N = (int)n, K = (int)k;
+  const int mt = (M + 15) / 16;
+  int rc = 0;
+#define SL_GO(MTV) \
+  SEMIPD_DISPATCH_HALF(dtype, T, rc = (sg_launch<T, MTV, 1, 8, 3, SL_PLAIN>((T*)nullptr, planes, planes_bytes, (const T*)x, (const T*)weight, M, N, K, ldx, N, sl_env("SEMIPD_SL_KS", 0), st, ksplit)));
   if (mt == 1) { SL_GO(1) } else if (mt == 2) { SL_GO(2) } else if (mt == 3) { SL_GO(3) } else { SL_GO(4) }
 #undef SL_GO
   return rc;

@@ -55,6 +55,8 @@ _SIGNATURES = {
     "semipd_linear_workspace": [_i64, _i64],
     "semipd_linear": [_vp, _vp, _vp, _vp, _sz, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _vp],
     "semipd_stream_linear_workspace": [_i64],
+    "semipd_stream_linear_planes": [_vp, _sz, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp],
+    "semipd_fused_add_rmsnorm_planes": [_vp, _vp, _vp, _vp, _i32, _i64, _i64, _i64, _f32, _i32, _vp],
     "semipd_stream_linear": [_vp, _vp, _vp, _vp, _sz, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _vp],
     "semipd_softmax_temperature": [_vp, _vp, _i64, _i64, _vp],
     "semipd_top_k_top_p_sampling_from_probs": [_vp, _vp, _vp, _i32, _vp, _f32, _vp, _vp, _i64, _i64, _i32, _vp],

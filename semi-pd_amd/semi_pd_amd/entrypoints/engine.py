@@ -69,6 +69,12 @@ def run_scheduler_process(server_args: ServerArgs, port_args: SemiPDPortArgs, gp
         from semi_pd_amd.managers.semi_pd_decode_scheduler import SemiPDDecodeScheduler
         from semi_pd_amd.managers.semi_pd_prefill_scheduler import SemiPDPrefillScheduler
         rank0 = tp_rank == 0
+        prio = server_args.decode_stream_priority if role == InstanceRole.DECODE else server_args.prefill_stream_priority
+        if prio:
+            # the whole instance (weights, graphs, every launch) lives on one prioritised stream: the hardware
+            # scheduler serves the queue of a high-priority stream first when both instances have work ready
+            torch.cuda.set_device(gpu_id)
+            torch.cuda.set_stream(torch.cuda.Stream(device=torch.device("cuda", gpu_id), priority=int(prio)))
         if role == InstanceRole.DECODE:
             mr = _build_runner(server_args, gpu_id, tp_rank, role, port_args.d_nccl_port,
                                max_total_tokens=server_args.max_total_tokens,

@@ -35,7 +35,10 @@ class RMSNorm(nn.Module):
         self.weight = nn.Parameter(torch.ones(hidden_size), requires_grad=False)
         self.variance_epsilon = eps
 
-    def forward(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None):
+    def forward(self, x, residual: Optional[torch.Tensor] = None):
+        if isinstance(x, ops.SplitKPlanes):
+            # the row-parallel layer in front stopped before its K-slice reduction: sum, add, normalise in one launch
+            return ops.fused_add_rmsnorm_planes(x, residual, self.weight.data, self.variance_epsilon), residual
         if residual is not None:
             ops.fused_add_rmsnorm(x, residual, self.weight.data, self.variance_epsilon)
             return x, residual
@@ -372,7 +375,15 @@ class RowParallelLinear(nn.Module):
             else:
                 self.weight_scale_inv.tp_shard = lambda full: full
 
-    def forward(self, x):
+    def forward(self, x, defer_reduce: bool = False):
+        """defer_reduce: the caller hands the result straight to RMSNorm.forward(x, residual); for a decode batch
+        on one GPU the layer then returns the K-slice planes of the streaming GEMM (ops.SplitKPlanes) and the norm
+        kernel does the reduction."""
+        if (defer_reduce and _STREAM_LINEAR["enabled"] and self.quant_config is None and self.bias is None
+                and get_tensor_model_parallel_world_size() == 1 and x.dim() == 2
+                and x.shape[0] <= ops.STREAM_LINEAR_MAX_ROWS and self.weight.shape[0] % 8 == 0
+                and ops.stream_linear_is_supported(x, self.weight)):
+            return ops.stream_linear_planes(x, self.weight)
         # bias is added on rank 0 only so that the sum over ranks adds it once (linear.py:1258-1262)
         bias = self.bias if (self.bias is not None and get_tensor_model_parallel_rank() == 0) else None
         if self.quant_config:

@@ -272,7 +272,7 @@ class SemiPDDecodeScheduler(SchedulerBase):
     def _process_pending(self, pending):
         reqs, out_cache_loc, host_ids, ev, logits_output = pending
         if ev is not None:
-            ev.synchronize()                   # step k and its copy are done; step k + 1 keeps the GPU busy
+            self._wait_servicing(ev)           # step k and its copy are done; step k + 1 keeps the GPU busy
         ids = host_ids.tolist()
         logprobs = self.extract_logprobs(logits_output)
         alloc = self.token_to_kv_pool_allocator
@@ -295,6 +295,23 @@ class SemiPDDecodeScheduler(SchedulerBase):
         self.stats["decode_tokens"] += len(live)
         self.stream_output(live, defer=False)
         self.last_progress = time.monotonic()
+
+    def _wait_servicing(self, ev):
+        """Wait for a decode step on the GPU, answering the prefill instance meanwhile.  The loop comes round once
+        per decode step (6-8 ms); an admission request or a prefill result that arrives just after a launch would
+        otherwise sit in the socket for the rest of the step -- half a step on average, on the TTFT path twice
+        (admission, then first token).  Everything dispatch() does is host work plus asynchronous copies queued
+        behind the step in flight, and the step in flight owns copies of its inputs, so nothing here can touch it.
+        With tensor parallelism every rank must see the same messages at the same point: plain wait."""
+        if self.tp_size > 1 or self.recv_from_tokenizer is None:
+            ev.synchronize()
+            return
+        while not ev.query():
+            recv = self.recv_requests()
+            if recv:
+                self.process_input_requests(recv)
+            else:
+                time.sleep(30e-6)
 
     def event_loop_normal(self):
         while not self._shutdown:

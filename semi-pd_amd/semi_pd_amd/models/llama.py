@@ -55,7 +55,8 @@ class LlamaMLP(nn.Module):
         self.act_fn = SiluAndMul()
 
     def forward(self, x):
-        return self.down_proj(gate_up_silu(x, self.gate_up_proj, self.act_fn))
+        # the output goes into the next fused add + RMSNorm (next layer's input_layernorm or the final norm)
+        return self.down_proj(gate_up_silu(x, self.gate_up_proj, self.act_fn), defer_reduce=True)
 
 
 class LlamaAttention(nn.Module):
@@ -84,7 +85,7 @@ class LlamaAttention(nn.Module):
         self.rotary_emb.forward_and_store(positions, q, k, v, pool.get_key_buffer(self.attn.layer_id),
                                           pool.get_value_buffer(self.attn.layer_id), forward_batch.out_cache_loc)
         attn_output = self.attn(q, k, v, forward_batch, save_kv_cache=False)
-        return self.o_proj(attn_output)
+        return self.o_proj(attn_output, defer_reduce=True)   # consumed by post_attention_layernorm(x, residual)
 
 
 class LlamaDecoderLayer(nn.Module):

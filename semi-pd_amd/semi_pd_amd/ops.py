@@ -394,6 +394,46 @@ def stream_linear(x: torch.Tensor, weight: torch.Tensor, fuse_silu_mul: bool = F
     return out
 
 
+class SplitKPlanes:
+    """The output of a decode-batch GEMM before its K-slice reduction: fp32 planes [ksplit, rows, n] in the
+    per-device workspace (valid until the next stream_linear call on the stream), to be summed by the consumer."""
+    __slots__ = ("planes", "ksplit", "rows", "n", "dtype")
+
+    def __init__(self, planes, ksplit, rows, n, dtype):
+        self.planes, self.ksplit, self.rows, self.n, self.dtype = planes, ksplit, rows, n, dtype
+
+    @property
+    def shape(self):
+        return (self.rows, self.n)
+
+
+def stream_linear_planes(x: torch.Tensor, weight: torch.Tensor) -> SplitKPlanes:
+    """x @ weight.T for decode batches, stopped before the reduction over the K slices (semipd_stream_linear_planes)."""
+    if not stream_linear_is_supported(x, weight):
+        raise RuntimeError("stream_linear_planes: unsupported shapes / dtypes / strides")
+    M, K = x.shape
+    N = weight.shape[0]
+    ws = _linear_workspace(x.device)
+    import ctypes as _C
+    ks = _C.c_int(0)
+    check(_lib.load().semipd_stream_linear_planes(ptr(ws), ws.numel(), ptr(x), ptr(weight), M, N, K, x.stride(0),
+                                                  dtype_code(x.dtype), _C.addressof(ks), current_stream(x.device)),
+          "stream_linear_planes")
+    return SplitKPlanes(ws, int(ks.value), M, N, x.dtype)
+
+
+def fused_add_rmsnorm_planes(p: SplitKPlanes, residual: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
+    """residual += T(sum of the planes); returns RMSNorm(residual) * weight -- fused_add_rmsnorm on the GEMM output
+    that was never written (layers/layernorm.py:47-76)."""
+    if residual.shape != (p.rows, p.n) or residual.dtype != p.dtype or not residual.is_contiguous():
+        raise RuntimeError("fused_add_rmsnorm_planes: residual must be a contiguous [rows, n] tensor of the GEMM's dtype")
+    out = torch.empty_like(residual)
+    check(_lib.load().semipd_fused_add_rmsnorm_planes(ptr(out), ptr(residual), ptr(weight), ptr(p.planes), p.ksplit,
+                                                      p.rows * p.n, p.rows, p.n, float(eps), dtype_code(p.dtype),
+                                                      current_stream(residual.device)), "fused_add_rmsnorm_planes")
+    return out
+
+
 # --------------------------------------------------------------------------- stochastic sampling
 def _probs_2d(probs: torch.Tensor, name: str) -> Tuple[int, int]:
     if probs.dim() != 2 or probs.dtype != torch.float32 or not probs.is_contiguous():

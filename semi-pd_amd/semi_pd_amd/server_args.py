@@ -51,6 +51,8 @@ class ServerArgs:
     prefill_cu_percent: int = PREFILL_ENGINE_SM_PERCENTILE
     decode_cu_percent: int = DECODE_ENGINE_SM_PERCENTILE
     cu_mask_mode: str = "env"                # "env" (process-wide HSA_CU_MASK) | "none"
+    prefill_stream_priority: int = 0         # HIP stream priority of the instance's compute stream: 0 normal, -1 high
+    decode_stream_priority: int = 0
     disable_stream_linear: bool = False      # dense layers of decode batches through hipBLASLt instead of csrc/stream_linear.hip
     library_gemm_grid: bool = False          # also size hipBLASLt's stream-K grids to the share (TENSILE_STREAMK_MAX_CUS)
     dist_init_addr: str = "127.0.0.1"

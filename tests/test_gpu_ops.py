@@ -677,3 +677,28 @@ def test_stream_linear_strided_rows_and_limits(ops, device):
                                               torch.randn(64, 96, device=device, dtype=torch.float16))  # k % 128
     with pytest.raises(RuntimeError):
         ops.stream_linear(torch.randn(65, 512, device=device, dtype=torch.float16), w.to(device))
+
+
+@pytest.mark.parametrize("M", [1, 16, 40, 64])
+@pytest.mark.parametrize("N,K", [(4096, 4096), (4096, 14336), (2048, 1280), (512, 1024)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_stream_linear_planes_into_fused_add_rmsnorm(ops, device, M, N, K, dtype):
+    """o_proj / down_proj -> fused add + RMSNorm with the K-slice reduction done by the norm kernel: the bits of the
+    unfused sequence (stream_linear, then fused_add_rmsnorm), and the oracle's values."""
+    torch.manual_seed(M + N)
+    x = torch.randn(M, K).to(dtype)
+    w = (torch.randn(N, K) * 0.05).to(dtype)
+    res = torch.randn(M, N).to(dtype)
+    nw = (torch.rand(N) + 0.5).to(dtype)
+    xd, wd = x.to(device), w.to(device)
+    y = ops.stream_linear(xd, wd)
+    r1 = res.to(device).clone()
+    ops.fused_add_rmsnorm(y, r1, nw.to(device), 1e-5)          # y <- norm(y + r1), r1 <- y + r1
+    planes = ops.stream_linear_planes(xd, wd)
+    r2 = res.to(device).clone()
+    out = ops.fused_add_rmsnorm_planes(planes, r2, nw.to(device), 1e-5)
+    assert torch.equal(r1, r2) and torch.equal(y, out)
+    gemm = (x.float() @ w.float().T).to(dtype)
+    want, want_res = O.fused_add_rms_norm(gemm, res, nw, 1e-5)
+    _close(out, want, dtype, rtol=3e-2, atol=3e-2)
+    _close(r2, want_res, dtype, rtol=2e-2, atol=2e-2 * float(want_res.float().abs().max()))
