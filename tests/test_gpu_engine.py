@@ -233,7 +233,12 @@ def test_opt_125m_semi_pd_baseline_config1(device):
     dummy_init_weights(model, device, sa.random_seed)
     sd = {k: v.float().cpu() for k, v in model.state_dict().items()}
     oracle = OracleOPT(cfg, sd)
-    frac = check_against_oracle(oracle, prompts[:8], outs[:8], margin=6e-2)
+    # ALL 32 requests, every one of the 64 steps teacher-forced through the fp32 oracle: the engine's token must be
+    # the oracle's argmax, or lie within the margin of it.  (Literal equality on every step is not a property of this
+    # workload: the logits of a random-weight model are i.i.d. over 50 k tokens, so among 2048 steps the smallest
+    # top-2 gap is ~1e-4 of a logit -- below the rounding of ANY bf16 implementation, the reference's included.
+    # Where the oracle's own top-2 gap exceeds the margin, the check below IS exact equality.)
+    frac = check_against_oracle(oracle, prompts, outs, margin=6e-2)
     assert frac > 0.8
 
 
