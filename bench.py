@@ -226,8 +226,15 @@ def main():
     ap.add_argument("--output-len", type=int, default=128)
     ap.add_argument("--request-rate", type=float, default=32.0, help="Poisson arrivals per second (0 = all at once)")
     ap.add_argument("--mode", choices=["semi-pd", "unified"], default="semi-pd")
-    ap.add_argument("--prefill-cu", type=int, default=50)
-    ap.add_argument("--decode-cu", type=int, default=50)
+    # CU shares of the two instances (HSA_CU_MASK per process).  Default = the policy this build measured best on
+    # the config-2 load (profiles/r02_policy_sweep_with_streaming_linear.txt): both instances see every CU (the
+    # reference's own default is P 80 / D 100, semi_pd/utils.py:10-11 -- shares are upper bounds there too) and the
+    # decode kernels are built to co-reside.  BASELINE config 2's static 50 / 50 split is measured in the same
+    # invocation by a second engine (--no-static-split-wave skips it) and reported under "static_split_50_50".
+    ap.add_argument("--prefill-cu", type=int, default=100)
+    ap.add_argument("--decode-cu", type=int, default=100)
+    ap.add_argument("--no-static-split-wave", action="store_true",
+                    help="N = 1 Semi-PD default run: do not start the second engine with the static 50 / 50 CU split")
     ap.add_argument("--cu-mask-mode", default="env")
     ap.add_argument("--prefill-priority", type=int, default=0, help="HIP stream priority of the prefill instance (-1 = high)")
     ap.add_argument("--decode-priority", type=int, default=0, help="HIP stream priority of the decode instance (-1 = high)")
@@ -364,6 +371,22 @@ def main():
     finally:
         engine.shutdown()
 
+    static_split = None
+    if (world == 1 and args.mode == "semi-pd" and not args.no_static_split_wave
+            and (args.prefill_cu, args.decode_cu) != (50, 50)):
+        # BASELINE config 2 as written: disjoint halves of the CUs, same load, one warm-up wave + one timed wave
+        import dataclasses
+        eng2 = Engine(dataclasses.replace(sa, prefill_cu_percent=50, decode_cu_percent=50, collect_kernel_timing=False),
+                      gpu_ids={0: local_rank})
+        try:
+            run_wave(eng2, prompts, arrivals, args.output_len)
+            recs, dur = run_wave(eng2, prompts, arrivals, args.output_len)
+            sm = summarize(recs, dur)
+            static_split = {"workload": "same requests and rate, HSA_CU_MASK halves: prefill CUs 0-127, decode CUs 128-255",
+                            **{k: (round(v, 2) if isinstance(v, float) else v) for k, v in sm.items()}}
+        finally:
+            eng2.shutdown()
+
     if rank != 0:
         return
     summ = summarize(all_records, elapsed)
@@ -420,8 +443,8 @@ def main():
         "p99_ttft_ms": summ["p99_ttft_ms"], "p99_tbt_ms": summ["p99_tbt_ms"],
         "config": {"workload": f"{args.model} {'block-fp8 (e4m3fn 128x128) linears + experts' if args.quantization else 'bf16'} TP={tp_world} {args.mode}"
                                + (f" x {world} independent replicas (one per GPU, each with its own {args.num_requests} requests)"
-                                  if (world > 1 and not args.tp) else "") + f", CU split P{args.prefill_cu}/D{args.decode_cu} "
-                               f"({args.cu_mask_mode}), {args.num_requests} synthetic requests in={args.input_len} "
+                                  if (world > 1 and not args.tp) else "") + f", CU shares P{args.prefill_cu}/D{args.decode_cu} "
+                               f"({'no mask: both instances on every CU' if (args.prefill_cu, args.decode_cu) == (100, 100) else args.cu_mask_mode}), {args.num_requests} synthetic requests in={args.input_len} "
                                f"out={args.output_len}, Poisson {args.request_rate} req/s, dummy weights"
                                + ("" if args.kv_cache_dtype == "auto" else f", KV cache {args.kv_cache_dtype}"),
                    "num_requests": args.num_requests, "input_len": args.input_len, "output_len": args.output_len,
@@ -431,6 +454,8 @@ def main():
                    "kv_cache_dtype": args.kv_cache_dtype},
         "roofline": roofline, "roofline_extra": extra, "cpu_baseline": cpu,
     }
+    if static_split:
+        out["static_split_50_50"] = static_split
     if saturation:
         out["saturation"] = {"note": "extra wave, every request sent at t = 0: output tok/s here is the engine's capacity; "
                                      "`value` above is measured at the Poisson rate named in config (load-bound)",

@@ -32,6 +32,22 @@ elif which == "mla":
     for _ in range(5):
         ops.decode_attention_fwd(q, kv, kv[..., :512], o, indptr, idx, lg, splits, 0.1)
     print("algorithmic_bytes_per_launch", B * ctx * 576 * 2 + B * H * (576 + 512) * 2)
+elif which.startswith("extend"):
+    # extend attention, Llama-3-8B heads: "extend1k" = ONE 1024-token request (the serving regime), "extend8k" = 8192
+    ext = 1024 if which == "extend1k" else 8192
+    Hq, Hkv, D, B = 32, 8, 128, 1
+    T = B * ext
+    q = torch.randn(T, Hq, D, device=dev, dtype=torch.bfloat16)
+    k = torch.randn(T, Hkv, D, device=dev, dtype=torch.bfloat16)
+    v = torch.randn(T, Hkv, D, device=dev, dtype=torch.bfloat16)
+    o = torch.empty_like(q)
+    kb = torch.randn(8, Hkv, D, device=dev, dtype=torch.bfloat16)
+    qo = torch.arange(B + 1, device=dev, dtype=torch.int32) * ext
+    kvp = torch.zeros(B + 1, device=dev, dtype=torch.int32)
+    idx = torch.ones(1, device=dev, dtype=torch.int32)
+    for _ in range(5):
+        ops.extend_attention_fwd(q, k, v, o, kb, kb, qo, kvp, idx, None, None, ext)
+    print("flop_per_launch", 4.0 * Hq * D * B * ext * (ext + 1) / 2)
 elif which == "fp8mm":
     # decode-sized block-fp8 linear on a DeepSeek-V3 shape: the fp8 weights (176 MB) are read once
     M, N, K = 32, 24576, 7168
