@@ -54,6 +54,9 @@ _SIGNATURES = {
     "semipd_lm_head_argmax_workspace": [_i64, _i64],
     "semipd_linear_workspace": [_i64, _i64],
     "semipd_linear": [_vp, _vp, _vp, _vp, _sz, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _vp],
+    "semipd_input_to_float8": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _vp],
+    "semipd_bmm_fp8": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _i32,
+                       _i32, _vp],
     "semipd_stream_linear_workspace": [_i64],
     "semipd_stream_linear_planes": [_vp, _sz, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp],
     "semipd_fused_add_rmsnorm_planes": [_vp, _vp, _vp, _vp, _i32, _i64, _i64, _i64, _f32, _i32, _vp],

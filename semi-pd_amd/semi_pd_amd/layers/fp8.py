@@ -97,6 +97,21 @@ def block_dequantize_weight(q: torch.Tensor, scale: torch.Tensor, block, dtype=t
     return (q.float() * s).to(dtype)
 
 
+def block_quant_to_tensor_quant(q: torch.Tensor, scale: torch.Tensor, block):
+    """Block-wise quantised weight -> ONE scale for the whole tensor (fp8_utils.py:152-188: dequantise in fp32,
+    input_to_float8): what the reference feeds bmm_fp8 with for the absorbed MLA matrices (deepseek_v2.py
+    :1195-1209).  Load-time only: plain torch on the weight's device.  Returns (fp8 tensor, 1 / scale as fp32)."""
+    bn, bk = int(block[0]), int(block[1])
+    N, K = q.shape
+    s = scale.repeat_interleave(bn, dim=0)[:N].repeat_interleave(bk, dim=1)[:, :K]
+    x = q.to(torch.float32) * s
+    fmax = torch.finfo(q.dtype).max
+    min_val, max_val = x.aminmax()
+    amax = torch.maximum(min_val.abs(), max_val.abs()).clamp(min=1e-12)
+    sc = fmax / amax
+    return (x * sc).clamp(min=-fmax, max=fmax).to(q.dtype).contiguous(), sc.float().reciprocal()
+
+
 def shard_rows_of_scale(ranges: List[tuple], block_n: int):
     """Row ranges of a weight -> the same cut on its scale rows; every boundary must sit on a block edge
     (fp8.py:228-244 raises for partitions that are not multiples of block_n)."""

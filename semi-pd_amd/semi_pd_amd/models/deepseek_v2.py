@@ -15,6 +15,8 @@ from __future__ import annotations
 from dataclasses import dataclass, field
 from typing import Any, Dict, Optional
 
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -25,7 +27,8 @@ from semi_pd_amd.layers.attention_backend import RadixAttention
 from semi_pd_amd.layers.basic import (ColumnParallelLinear, LogitsProcessor, MergedColumnParallelLinear,
                                       ParallelLMHead, ReplicatedLinear, RMSNorm, RowParallelLinear, SiluAndMul,
                                       VocabParallelEmbedding, gate_up_silu, get_rope, yarn_get_mscale)
-from semi_pd_amd.layers.fp8 import Fp8Config, block_dequantize_weight, quantize_activation
+from semi_pd_amd.layers.fp8 import (FP8_DTYPE, Fp8Config, block_dequantize_weight, block_quant_to_tensor_quant,
+                                    quantize_activation)
 from semi_pd_amd.layers.moe import FusedMoE
 
 
@@ -185,16 +188,29 @@ class DeepseekV2AttentionMLA(nn.Module):
                                        num_kv_heads=self.num_local_heads, layer_id=layer_id,
                                        v_head_dim=self.v_head_dim)
         # Semi-PD: buffers so that they are exported / imported through IPC (deepseek_v2.py:532-536)
-        self.register_buffer("w_kc", torch.empty(0, dtype=dtype), persistent=False)
-        self.register_buffer("w_vc", torch.empty(0, dtype=dtype), persistent=False)
+        # a block-fp8 model keeps them in fp8 with ONE scale for both (bmm_fp8 path, deepseek_v2.py:659-665, 690-700);
+        # SEMIPD_MLA_ABSORB_BF16=1 restores the dequantise-at-load + torch.bmm form
+        self.absorb_fp8 = qc is not None and os.environ.get("SEMIPD_MLA_ABSORB_BF16", "0") != "1"
+        wdt = FP8_DTYPE if self.absorb_fp8 else dtype
+        self.register_buffer("w_kc", torch.empty(0, dtype=wdt), persistent=False)
+        self.register_buffer("w_vc", torch.empty(0, dtype=wdt), persistent=False)
+        if self.absorb_fp8:
+            self.register_buffer("w_scale", torch.empty(1, dtype=torch.float32), persistent=False)
 
     def post_load_weights(self):
         """deepseek_v2.py:1228-1249: W_kc [H,128,512] and W_vc [H,512,128] out of kv_b_proj."""
         w = self.kv_b_proj.weight
+        if self.absorb_fp8:
+            # deepseek_v2.py:1195-1209: the block-quantised kv_b_proj re-quantised per tensor; W_kc / W_vc stay fp8 and
+            # go through the fp8 matrix cores (ops.bmm_fp8).  Stored column-major for the product they are used in:
+            # w_kc [H, n = 512, k = 128], w_vc [H, n = 128, k = 512] (the reference's buffers, deepseek_v2.py:1234-1236)
+            wq, w_scale = block_quant_to_tensor_quant(w, self.kv_b_proj.weight_scale_inv, self.quant_config.weight_block_size)
+            w3 = wq.unflatten(0, (-1, self.qk_nope_head_dim + self.v_head_dim))
+            self.w_kc = w3[:, : self.qk_nope_head_dim, :].transpose(1, 2).contiguous()
+            self.w_vc = w3[:, self.qk_nope_head_dim:, :].contiguous()
+            self.w_scale = w_scale.reshape(1).to(torch.float32)
+            return
         if self.quant_config:
-            # the reference re-quantises the block-quantised kv_b_proj per tensor and, on its HIP branch, multiplies
-            # w_kc.to(bf16) * w_scale in every forward (deepseek_v2.py:1195-1209, 655-658); here the blocks are
-            # dequantised once, which skips the second rounding
             w = block_dequantize_weight(w, self.kv_b_proj.weight_scale_inv, self.quant_config.weight_block_size,
                                         self.params_dtype)
         w_kc, w_vc = w.unflatten(0, (-1, self.qk_nope_head_dim + self.v_head_dim)).split(
@@ -255,13 +271,24 @@ class DeepseekV2AttentionMLA(nn.Module):
         latent = self._latent(hidden_states, positions, q, xq)
         q_input = torch.empty((T, self.num_local_heads, self.kv_lora_rank + self.qk_rope_head_dim),
                               dtype=q.dtype, device=q.device)
-        q_nope_out = torch.bmm(q[..., : self.qk_nope_head_dim].transpose(0, 1), self.w_kc)  # [H, T, 512]
-        q_input[..., : self.kv_lora_rank] = q_nope_out.transpose(0, 1)
+        if self.absorb_fp8:
+            # q_nope quantised per tensor, fp8 x fp8 on the matrix cores, written straight into q_input's layout
+            q_val, q_scale = ops.input_to_float8(q[..., : self.qk_nope_head_dim].transpose(0, 1), FP8_DTYPE)
+            ops.bmm_fp8(q_val, self.w_kc.transpose(1, 2), q_scale, self.w_scale, q.dtype,
+                        out=q_input[..., : self.kv_lora_rank].transpose(0, 1))
+        else:
+            q_nope_out = torch.bmm(q[..., : self.qk_nope_head_dim].transpose(0, 1), self.w_kc)  # [H, T, 512]
+            q_input[..., : self.kv_lora_rank] = q_nope_out.transpose(0, 1)
         q_input[..., self.kv_lora_rank:] = q[..., self.qk_nope_head_dim:]
         forward_batch.token_to_kv_pool.set_kv_buffer(self.attn_mqa, forward_batch.out_cache_loc, latent, None)
         attn_output = self.attn_mqa(q_input.view(T, -1), latent.view(T, -1), latent[..., : self.kv_lora_rank],
                                     forward_batch, save_kv_cache=False)
         attn_output = attn_output.view(T, self.num_local_heads, self.kv_lora_rank)
+        if self.absorb_fp8:
+            a_val, a_scale = ops.input_to_float8(attn_output.transpose(0, 1), FP8_DTYPE)
+            out = torch.empty((T, self.num_local_heads, self.v_head_dim), dtype=q.dtype, device=q.device)
+            ops.bmm_fp8(a_val, self.w_vc.transpose(1, 2), a_scale, self.w_scale, q.dtype, out=out.transpose(0, 1))
+            return self.o_proj(out.view(T, -1))
         out = torch.bmm(attn_output.transpose(0, 1), self.w_vc)  # [H, T, 128]
         return self.o_proj(out.transpose(0, 1).reshape(T, -1))
 

@@ -637,6 +637,58 @@ def per_token_group_quant_fp8(x: torch.Tensor, group_size: int, eps: float = 1e-
     return x_q, x_s
 
 
+_F8_CODE = {torch.float8_e5m2: 3, torch.float8_e4m3fn: 4}   # SEMIPD_F8E5M2 / SEMIPD_F8E4M3
+_AMAX_WS = {}
+
+
+def input_to_float8(x: torch.Tensor, dtype: torch.dtype = FP8_DTYPE) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Tensor-wise dynamic quantisation (layers/quantization/fp8_utils.py:137-149): (x_fp8 contiguous, 1 / scale)
+    with scale = fp8_max / amax(|x|).  x: [batch, m, k] (or [m, k]) with a contiguous last dimension; a transposed
+    view like q_nope.transpose(0, 1) is read through its strides."""
+    if dtype not in _F8_CODE:
+        raise RuntimeError(f"input_to_float8: {dtype} is not an OCP fp8 type")
+    x3 = x if x.dim() == 3 else x.unsqueeze(0)
+    if x3.dim() != 3 or x3.stride(2) != 1 or not x3.is_cuda:
+        raise RuntimeError("input_to_float8: [batch, m, k] (or [m, k]) device tensor with a contiguous last dimension")
+    B, M, K = x3.shape
+    q = torch.empty((B, M, K), dtype=dtype, device=x.device)
+    scale_inv = torch.empty((), dtype=torch.float32, device=x.device)
+    key = x.device.index if x.device.index is not None else torch.cuda.current_device()
+    ws = _AMAX_WS.get(key)
+    if ws is None:
+        ws = _AMAX_WS[key] = torch.zeros(4, dtype=torch.int32, device=x.device)
+    check(_lib.load().semipd_input_to_float8(ptr(q), ptr(scale_inv), ptr(ws), ptr(x3), B, M, K, x3.stride(0), x3.stride(1),
+                                             dtype_code(x.dtype), _F8_CODE[dtype], current_stream(x.device)),
+          "input_to_float8")
+    return (q if x.dim() == 3 else q[0]), scale_inv
+
+
+def bmm_fp8(A: torch.Tensor, B: torch.Tensor, A_scale: torch.Tensor, B_scale: torch.Tensor, dtype: torch.dtype,
+            out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """sgl_kernel.bmm_fp8 (python/sgl_kernel/gemm.py:66-82): A [b, m, k] fp8 row-major, B [b, k, n] fp8 COLUMN-major
+    (a transposed view of a contiguous [b, n, k] tensor), per-tensor fp32 scales; returns (or fills) [b, m, n] in
+    `dtype`.  `out` may be any view whose last dimension is contiguous (e.g. the [h, T, 512] transpose of
+    q_input[T, h, :512])."""
+    if A.dim() != 3 or B.dim() != 3 or A.shape[0] != B.shape[0] or A.shape[2] != B.shape[1]:
+        raise RuntimeError("bmm_fp8: A [b, m, k] and B [b, k, n] expected")
+    if A.dtype not in _F8_CODE or B.dtype not in _F8_CODE:
+        raise RuntimeError("bmm_fp8: fp8 operands expected")
+    if A.stride(2) != 1 or B.stride(1) != 1:
+        raise RuntimeError("bmm_fp8: A must be row-major and B column-major (k contiguous in both)")
+    b, m, k = A.shape
+    n = B.shape[2]
+    if out is None:
+        out = torch.empty((b, m, n), dtype=dtype, device=A.device)
+    elif out.shape != (b, m, n) or out.dtype != dtype or out.stride(2) != 1:
+        raise RuntimeError("bmm_fp8: bad out tensor")
+    a_s = A_scale.reshape(-1).to(torch.float32)
+    b_s = B_scale.reshape(-1).to(torch.float32)
+    check(_lib.load().semipd_bmm_fp8(ptr(out), ptr(A), ptr(B), ptr(a_s), ptr(b_s), b, m, n, k, A.stride(0), A.stride(1),
+                                     B.stride(0), B.stride(2), out.stride(0), out.stride(1), _F8_CODE[A.dtype],
+                                     _F8_CODE[B.dtype], dtype_code(dtype), current_stream(A.device)), "bmm_fp8")
+    return out
+
+
 def fused_add_rmsnorm_quant_fp8(input: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float,
                                 group_size: int, q_eps: float = 1e-10):
     """fused_add_rmsnorm (in place on input / residual) plus per_token_group_quant_fp8 of the normalised rows in

@@ -575,6 +575,54 @@ def gen_fp8():
     save("block_fp8", **arrs)
 
 
+def _reference_fp8_utils_functions():
+    """layers/quantization/fp8_utils.py imports the CUDA / HIP kernel packages at module level; its two tensor-wise
+    helpers are plain torch: compile exactly those two function definitions from the file at generation time, on the
+    OCP branch (_is_hip = False: finfo.max = 448, what gfx950 implements; the HIP branch there is MI300's fnuz / 224)."""
+    import ast
+    from typing import List, Tuple
+    path = "/root/reference/python/sglang/srt/layers/quantization/fp8_utils.py"
+    tree = ast.parse(open(path).read())
+    want = {"input_to_float8", "block_quant_to_tensor_quant"}
+    mod = ast.Module(body=[n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in want], type_ignores=[])
+    ns = {"torch": torch, "List": List, "Tuple": Tuple, "_is_hip": False}
+    exec(compile(mod, path, "exec"), ns)
+    return ns["input_to_float8"], ns["block_quant_to_tensor_quant"]
+
+
+def gen_bmm_fp8():
+    """input_to_float8 and block_quant_to_tensor_quant of the reference (fp8_utils.py:137-188), run here; and the
+    inputs of a bmm_fp8 call shaped like the MLA absorption (models/deepseek_v2.py:659-665, 690-700) with the
+    product the reference's own test compares against (torch.bmm of the unquantised operands,
+    sgl-kernel/tests/test_bmm_fp8.py:33-44)."""
+    to_f8, block_to_tensor = _reference_fp8_utils_functions()
+    g = torch.Generator().manual_seed(31)
+    arrs = {}
+    # 1. input_to_float8 on a transposed bf16 view (q_nope.transpose(0, 1)) and on an fp32 tensor
+    q_nope = (torch.randn(7, 4, 128, generator=g) * 3).to(torch.bfloat16)
+    x = q_nope.transpose(0, 1)
+    qv, sc = to_f8(x, torch.float8_e4m3fn)
+    arrs.update(q_nope=bits(q_nope), q_nope_f8=f8bits(qv), q_nope_scale_inv=sc.numpy())
+    y = torch.randn(3, 5, 64, generator=g) * 100
+    y[1, 2, 3] = 7e4
+    yv, ys = to_f8(y, torch.float8_e5m2)
+    arrs.update(y=y.numpy(), y_f8=f8bits(yv), y_scale_inv=ys.numpy())
+    # 2. block_quant_to_tensor_quant on a block-quantised kv_b_proj-like weight
+    wq = (torch.rand(384, 256, generator=g) * 2 - 1).mul(448).to(torch.float8_e4m3fn)
+    ws = torch.rand(3, 2, generator=g) * 1e-2 + 1e-3
+    tq, ts = block_to_tensor(wq, ws, [128, 128])
+    arrs.update(w_block_q=f8bits(wq), w_block_s=ws.numpy(), w_tensor_q=f8bits(tq), w_tensor_scale_inv=ts.numpy())
+    # 3. bmm inputs: A [h, T, 128] x W_kc [h, 128, 512] (column-major), unquantised product for the cos-sim bar
+    a = torch.randn(4, 9, 128, generator=g).to(torch.bfloat16)
+    b = torch.randn(4, 512, 128, generator=g).to(torch.bfloat16)          # memory [h, n, k]
+    a8, a_s = to_f8(a, torch.float8_e4m3fn)
+    b8, b_s = to_f8(b, torch.float8_e4m3fn)
+    ref = torch.bmm(a.float(), b.float().transpose(1, 2))
+    arrs.update(bmm_a=bits(a), bmm_b=bits(b), bmm_a8=f8bits(a8), bmm_b8=f8bits(b8), bmm_a_s=a_s.numpy(), bmm_b_s=b_s.numpy(),
+                bmm_ref_unquantised=ref.numpy())
+    save("bmm_fp8", **arrs)
+
+
 def gen_penalties():
     """The reference's batched penalizers (sampling/penaltylib/*.py) driven the way ScheduleBatch drives them:
     an orchestrator per new prefill batch, apply -> sample -> cumulate every step, merge into the running batch
@@ -638,9 +686,9 @@ def gen_penalties():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["rmsnorm", "rope", "kv_indices", "topk", "decode", "extend", "sampling", "fp8", "penalties",
-                             "decode_8c", "extend_8c", "silu", "moe_align", "fused_moe"]
+                             "decode_8c", "extend_8c", "silu", "moe_align", "fused_moe", "bmm_fp8"]
     for w in which:
         {"rmsnorm": gen_rmsnorm, "rope": gen_rope, "kv_indices": gen_kv_indices, "topk": gen_topk,
          "decode": gen_decode, "extend": gen_extend, "sampling": gen_sampling, "fp8": gen_fp8, "penalties": gen_penalties,
          "decode_8c": gen_decode_8c, "extend_8c": gen_extend_8c, "silu": gen_silu, "moe_align": gen_moe_align,
-         "fused_moe": gen_fused_moe}[w]()
+         "fused_moe": gen_fused_moe, "bmm_fp8": gen_bmm_fp8}[w]()

@@ -4,6 +4,7 @@ per_token_group_quant_fp8 is elementwise IEEE arithmetic: bytes and scales must 
 oracle.  The matmuls sum exact fp8 products in fp32 in a different order than the oracle: compared with the
 reference's own criterion (mean |diff| / mean |ref| < 1e-3 for the matmul, < 2e-2 for the fused MoE,
 test/test_block_fp8.py:276-280, 397-401) and with a 20x tighter bound on f32 outputs (the inputs are uniform in +-448, so sums cancel heavily)."""
+import numpy as np
 import pytest
 import torch
 
@@ -185,3 +186,71 @@ def test_fused_add_rmsnorm_quant_equals_the_two_calls(device, dtype):
         ops.fused_add_rmsnorm_quant_fp8(torch.randn(2, 200, device=device, dtype=dtype),
                                         torch.randn(2, 200, device=device, dtype=dtype),
                                         torch.ones(200, device=device, dtype=dtype), 1e-6, 128)
+
+
+# ----------------------------------------------------------------------------- per-tensor fp8: MLA absorption (bmm_fp8)
+def test_input_to_float8_matches_reference_and_oracle(device):
+    """Bytes and scale of the reference's input_to_float8 (golden/bmm_fp8.npz) on a transposed bf16 view, and the
+    oracle on random tensors of both fp8 types."""
+    g = load_golden("bmm_fp8")
+    q_nope = from_bits(g["q_nope"], torch.bfloat16).to(device)
+    q, s = ops.input_to_float8(q_nope.transpose(0, 1), torch.float8_e4m3fn)
+    assert q.is_contiguous() and np.array_equal(q.view(torch.uint8).cpu().numpy(), g["q_nope_f8"])
+    assert float(s) == float(g["q_nope_scale_inv"])
+    torch.manual_seed(1)
+    for dt, f8 in ((torch.bfloat16, torch.float8_e5m2), (torch.float16, torch.float8_e4m3fn), (torch.bfloat16, torch.float8_e4m3fn)):
+        x = (torch.randn(5, 33, 64) * 7).to(dt)
+        x[2, 3, 4] = 300.0
+        qo, so = O.input_to_float8(x, f8)
+        qg, sg = ops.input_to_float8(x.to(device), f8)
+        assert torch.equal(qg.view(torch.uint8).cpu(), qo.view(torch.uint8)) and float(sg) == float(so)
+
+
+@pytest.mark.parametrize("a_dt,b_dt", [(torch.float8_e4m3fn, torch.float8_e4m3fn), (torch.float8_e4m3fn, torch.float8_e5m2),
+                                       (torch.float8_e5m2, torch.float8_e4m3fn)])
+@pytest.mark.parametrize("res_dtype", [torch.bfloat16, torch.float16])
+def test_bmm_fp8_reference_test_shapes(device, a_dt, b_dt, res_dtype):
+    """sgl-kernel/tests/test_bmm_fp8.py: [16, 48, 64] x [16, 64, 80] (column-major), cosine similarity > 0.99 against
+    the unquantised product; plus the oracle (same fp8 operands, fp32 accumulate) to rounding."""
+    torch.manual_seed(0)
+    a = torch.randn(16, 48, 64).to(torch.bfloat16)
+    b = torch.randn(16, 80, 64).to(torch.bfloat16)          # memory [b, n, k]; mat2 = b.transpose(-2, -1)
+    a8, a_s = O.input_to_float8(a, a_dt)
+    b8, b_s = O.input_to_float8(b, b_dt)
+    out = ops.bmm_fp8(a8.to(device), b8.to(device).transpose(1, 2), a_s.to(device), b_s.to(device), res_dtype)
+    ref = torch.bmm(a.float(), b.float().transpose(1, 2))
+    cos = torch.nn.functional.cosine_similarity(ref.reshape(-1), out.float().cpu().reshape(-1), dim=0)
+    assert cos > 0.99
+    want = O.bmm_fp8(a8, b8.transpose(1, 2), a_s, b_s, res_dtype)
+    torch.testing.assert_close(out.cpu().float(), want.float(), rtol=1e-2 if res_dtype == torch.bfloat16 else 2e-3, atol=1e-2)
+
+
+@pytest.mark.parametrize("T", [1, 9, 70])
+def test_bmm_fp8_mla_absorb_shapes_and_strided_output(device, T):
+    """The two products of forward_absorb (deepseek_v2.py:659-665, 690-700) with the outputs written through strides
+    into their consumers' layouts: q_nope [H, T, 128] x W_kc -> q_input[T, H, :512]; attn [H, T, 512] x W_vc ->
+    [T, H, 128]."""
+    H = 16
+    torch.manual_seed(T)
+    q = torch.randn(T, H, 192).to(torch.bfloat16)
+    w_kc = torch.randn(H, 512, 128).to(torch.bfloat16)       # column-major B: memory [H, n, k]
+    w_kc8, ws = O.input_to_float8(w_kc, torch.float8_e4m3fn)
+    qd = q.to(device)
+    q8, qs = ops.input_to_float8(qd[..., :128].transpose(0, 1), torch.float8_e4m3fn)
+    q8o, qso = O.input_to_float8(q[..., :128].transpose(0, 1), torch.float8_e4m3fn)
+    assert torch.equal(q8.view(torch.uint8).cpu(), q8o.view(torch.uint8)) and float(qs) == float(qso)
+    q_input = torch.full((T, H, 576), 7.0, dtype=torch.bfloat16, device=device)
+    ops.bmm_fp8(q8, w_kc8.to(device).transpose(1, 2), qs, ws.to(device), torch.bfloat16,
+                out=q_input[..., :512].transpose(0, 1))
+    want = O.bmm_fp8(q8o, w_kc8.transpose(1, 2), qso, ws, torch.bfloat16).transpose(0, 1)
+    torch.testing.assert_close(q_input[..., :512].cpu().float(), want.float(), rtol=1e-2, atol=1e-2)
+    assert torch.all(q_input[..., 512:] == 7.0)              # nothing written past the 512 columns
+    attn = torch.randn(T, H, 512).to(torch.bfloat16)
+    w_vc = torch.randn(H, 128, 512).to(torch.bfloat16)       # [H, n = 128, k = 512]
+    w_vc8, wvs = O.input_to_float8(w_vc, torch.float8_e4m3fn)
+    a8, a_s = ops.input_to_float8(attn.to(device).transpose(0, 1), torch.float8_e4m3fn)
+    out = torch.empty((T, H, 128), dtype=torch.bfloat16, device=device)
+    ops.bmm_fp8(a8, w_vc8.to(device).transpose(1, 2), a_s, wvs.to(device), torch.bfloat16, out=out.transpose(0, 1))
+    a8o, a_so = O.input_to_float8(attn.transpose(0, 1), torch.float8_e4m3fn)
+    want = O.bmm_fp8(a8o, w_vc8.transpose(1, 2), a_so, wvs, torch.bfloat16).transpose(0, 1)
+    torch.testing.assert_close(out.cpu().float(), want.float(), rtol=1e-2, atol=2e-2)

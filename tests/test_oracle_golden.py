@@ -362,3 +362,25 @@ def test_attention_8c_shapes_match_reference_triton_kernels():
                                torch.from_numpy(g[name + "_kv_indptr"]),
                                torch.from_numpy(g[name + "_kv_indices"]), float(sm_scale), float(cap))
         torch.testing.assert_close(o, torch.from_numpy(g[name + "_o"]), rtol=3e-5, atol=3e-5)
+
+
+def test_per_tensor_fp8_helpers_match_reference_bitwise():
+    """input_to_float8 / block_quant_to_tensor_quant of the reference (fp8_utils.py:137-188, OCP branch), run by
+    make_golden.py: bytes and scales bit for bit; bmm_fp8's oracle against the unquantised product at the reference
+    test's bar (cosine similarity > 0.99, sgl-kernel/tests/test_bmm_fp8.py:42-44)."""
+    g = load_golden("bmm_fp8")
+    F8 = torch.float8_e4m3fn
+    q_nope = from_bits(g["q_nope"], torch.bfloat16)
+    q, s = O.input_to_float8(q_nope.transpose(0, 1), F8)
+    assert np.array_equal(q.view(torch.uint8).numpy(), g["q_nope_f8"]) and float(s) == float(g["q_nope_scale_inv"])
+    q, s = O.input_to_float8(torch.from_numpy(g["y"]), torch.float8_e5m2)
+    assert np.array_equal(q.view(torch.uint8).numpy(), g["y_f8"]) and float(s) == float(g["y_scale_inv"])
+    wq = torch.from_numpy(g["w_block_q"]).view(F8)
+    tq, ts = O.block_quant_to_tensor_quant(wq, torch.from_numpy(g["w_block_s"]), [128, 128])
+    assert np.array_equal(tq.view(torch.uint8).numpy(), g["w_tensor_q"]) and float(ts) == float(g["w_tensor_scale_inv"])
+    a8 = torch.from_numpy(g["bmm_a8"]).view(F8)
+    b8 = torch.from_numpy(g["bmm_b8"]).view(F8)          # memory [h, n, k]
+    out = O.bmm_fp8(a8, b8.transpose(1, 2), torch.from_numpy(g["bmm_a_s"]), torch.from_numpy(g["bmm_b_s"]), torch.bfloat16)
+    ref = torch.from_numpy(g["bmm_ref_unquantised"])
+    cos = torch.nn.functional.cosine_similarity(ref.reshape(-1), out.float().reshape(-1), dim=0)
+    assert cos > 0.99
