@@ -406,19 +406,29 @@ def main():
                                          "wait_admission": round(1e3 * s.get("t_wait_admission_s", 0) / n, 3),
                                          "forward_and_sync": round(1e3 * s.get("t_forward_s", 0) / n, 3)}
         kt = s.get("kernel_timing") or {}
+        def hbm_line(k, kernel):
+            return {"bound": "hbm", "kernel": kernel, "achieved": round(k["gbps"], 1),
+                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(k["gbps"] / HBM_PEAK_GBPS, 4),
+                    # PMC counters cannot be read from inside this process: `traffic` is null in this line.
+                    # The rocprofv3 --pmc FETCH_SIZE pass of the same command (x2 gfx950 correction) is a
+                    # separate run; its summary is committed under profiles/ (see DESIGN.md, section 6).
+                    "traffic": None,
+                    "avg_launch_us": round(k["avg_us"], 2),
+                    "avg_launch_us_minus_event_overhead": round(k.get("avg_us_minus_event_overhead", k["avg_us"]), 2),
+                    "event_pair_overhead_us": kt.get("_event_pair_overhead_us"),
+                    "algorithmic_bytes_per_launch": int(k["bytes_per_launch"]), "launches_sampled": k["launches"]}
         if "decode_attention" in kt:
-            k = kt["decode_attention"]
             kname = ("mla_decode_kernel" if "Deepseek" in cfg.architectures[0] else "decode_mfma_kernel")
-            roofline = {"bound": "hbm", "kernel": kname + " + decode_stage2_kernel (one decode_attention call)", "achieved": round(k["gbps"], 1),
-                        "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(k["gbps"] / HBM_PEAK_GBPS, 4),
-                        # PMC counters cannot be read from inside this process: `traffic` is null in this line.
-                        # The rocprofv3 --pmc FETCH_SIZE pass of the same command (x2 gfx950 correction) is a
-                        # separate run; its summary is committed under profiles/ (see DESIGN.md, section 6).
-                        "traffic": None,
-                        "avg_launch_us": round(k["avg_us"], 2),
-                        "avg_launch_us_minus_event_overhead": round(k.get("avg_us_minus_event_overhead", k["avg_us"]), 2),
-                        "event_pair_overhead_us": kt.get("_event_pair_overhead_us"),
-                        "algorithmic_bytes_per_launch": int(k["bytes_per_launch"]), "launches_sampled": k["launches"]}
+            attn_line = hbm_line(kt["decode_attention"], kname + " + decode_stage2_kernel (one decode_attention call)")
+            if "stream_linear" in kt:
+                # the dominant kernel of the decode instance by GPU time is the weight-streaming GEMM
+                # (profiles/r02_bench_n1_decode_proc_kernel_stats_*.csv): qkv / o / gate_up + SiLU*mul / down of the
+                # sampled step's first layer, algorithmic bytes = weight + activations in + result out per call
+                roofline = hbm_line(kt["stream_linear"], "stream_gemm_glds_kernel (+ splitk_planes_reduce where K is "
+                                    "sliced): the four dense layers of a decoder layer, decode batch")
+                extra["decode_attention"] = attn_line
+            else:
+                roofline = attn_line
         if "extend_attention" in kt:
             k = kt["extend_attention"]
             extra["extend_attention"] = {"bound": "mfma", "achieved": round(k["tflops"], 1),

@@ -49,6 +49,8 @@ def _build_runner(server_args: ServerArgs, gpu_id: int, tp_rank: int, role: Inst
     if server_args.collect_kernel_timing:
         from semi_pd_amd.model_executor.kernel_timing import KernelTiming
         mr.kernel_timing = KernelTiming()
+        from semi_pd_amd.layers.basic import set_stream_linear_timing
+        set_stream_linear_timing(mr.kernel_timing)
     return mr
 
 

@@ -188,7 +188,7 @@ def get_rope(head_size: int, rotary_dim: int, max_position: int, base: float, is
 # --------------------------------------------------------------------------- dense GEMM dispatch
 # Batches of at most 64 rows (decode steps, a short last chunk of a prefill) go through the LDS-DMA
 # weight-streaming kernel (csrc/stream_linear.hip); everything else stays on hipBLASLt (F.linear).
-_STREAM_LINEAR = {"enabled": False}
+_STREAM_LINEAR = {"enabled": False, "timing": None}
 
 
 def set_stream_linear(enabled: bool):
@@ -196,11 +196,30 @@ def set_stream_linear(enabled: bool):
     _STREAM_LINEAR["enabled"] = bool(enabled)
 
 
+def set_stream_linear_timing(kernel_timing) -> None:
+    """bench.py's roofline: a sampled (eager) decode step brackets the streaming GEMMs of its first layer with HIP
+    events (model_executor/kernel_timing.py)."""
+    _STREAM_LINEAR["timing"] = kernel_timing
+
+
+def _timed_stream(fn, x: torch.Tensor, weight: torch.Tensor, n_out: int, n_kernels: int):
+    kt = _STREAM_LINEAR["timing"]
+    if kt is None or not kt.active or kt.linear_budget <= 0:
+        return fn()
+    kt.linear_budget -= 1
+    t0 = kt.start()
+    out = fn()
+    es = weight.element_size()
+    # SURVEY 8d "Logits + argmax"-style weight-stream formula: the weight once, activations in, result out
+    kt.stop("stream_linear", t0, weight.numel() * es + x.numel() * es + x.shape[0] * n_out * es, 0.0, n_kernels)
+    return out
+
+
 def dense_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """UnquantizedLinearMethod.apply (layers/linear.py:165-172)."""
     if (_STREAM_LINEAR["enabled"] and bias is None and x.dim() == 2 and x.shape[0] <= ops.STREAM_LINEAR_MAX_ROWS
             and ops.stream_linear_is_supported(x, weight)):
-        return ops.stream_linear(x, weight)
+        return _timed_stream(lambda: ops.stream_linear(x, weight), x, weight, weight.shape[0], 2)
     return F.linear(x, weight, bias)
 
 
@@ -209,7 +228,8 @@ def gate_up_silu(x: torch.Tensor, gate_up_proj: "MergedColumnParallelLinear", ac
     if (_STREAM_LINEAR["enabled"] and gate_up_proj.quant_config is None and gate_up_proj.bias is None
             and isinstance(act_fn, SiluAndMul) and x.dim() == 2 and x.shape[0] <= ops.STREAM_LINEAR_MAX_ROWS
             and ops.stream_linear_is_supported(x, gate_up_proj.weight, fuse_silu_mul=True)):
-        return ops.stream_linear(x, gate_up_proj.weight, fuse_silu_mul=True)
+        w = gate_up_proj.weight
+        return _timed_stream(lambda: ops.stream_linear(x, w, fuse_silu_mul=True), x, w, w.shape[0] // 2, 1)
     return act_fn(gate_up_proj(x))
 
 
@@ -383,7 +403,7 @@ class RowParallelLinear(nn.Module):
                 and get_tensor_model_parallel_world_size() == 1 and x.dim() == 2
                 and x.shape[0] <= ops.STREAM_LINEAR_MAX_ROWS and self.weight.shape[0] % 8 == 0
                 and ops.stream_linear_is_supported(x, self.weight)):
-            return ops.stream_linear_planes(x, self.weight)
+            return _timed_stream(lambda: ops.stream_linear_planes(x, self.weight), x, self.weight, self.weight.shape[0], 1)
         # bias is added on rank 0 only so that the sum over ranks adds it once (linear.py:1258-1262)
         bias = self.bias if (self.bias is not None and get_tensor_model_parallel_rank() == 0) else None
         if self.quant_config:

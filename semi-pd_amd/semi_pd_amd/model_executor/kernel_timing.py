@@ -30,6 +30,7 @@ class KernelTiming:
         self.overhead_ms: Dict[int, float] = {}
         self._step = 0
         self.active = False
+        self.linear_budget = 0   # streaming-GEMM launches still to be timed in this step (the first layer's four)
         self._pending: List[Tuple[str, torch.cuda.Event, torch.cuda.Event, float, float, int]] = []
         self._acc: Dict[str, List[float]] = defaultdict(lambda: [0.0, 0.0, 0.0, 0, 0.0])  # ms, bytes, flops, n, raw ms
 
@@ -37,6 +38,7 @@ class KernelTiming:
         """Called once per forward; returns True when this step is a sampled (eager, timed) one."""
         self._step += 1
         self.active = (self._step % self.sample_every == 0) and len(self._pending) < self.max_pending
+        self.linear_budget = 4 if self.active else 0
         return self.active
 
     def end_step(self):

@@ -5,13 +5,13 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rocprofv3 -L > $R/$OUT/counters_list.txt 2>&1
 for which in extend1k extend8k; do
-  rocprofv3 --kernel-trace --stats -d $R/$OUT/trace_$which -o t -- python $R/tools/pmc_target.py $which > $R/$OUT/trace_$which.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/trace_$which -o t -- python $R/tools/pmc_target.py $which > $R/$OUT/trace_$which.log 2>&1
   for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
              "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_VALU_MFMA_BUSY_CYCLES" \
              "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" \
              "SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL GRBM_GUI_ACTIVE" ; do
     tag=$(echo $set | cut -d' ' -f1)
-    rocprofv3 --kernel-trace --pmc $set -d $R/$OUT/pmc_${which}_$tag -o p -- python $R/tools/pmc_target.py $which > $R/$OUT/pmc_${which}_$tag.log 2>&1
+    rocprofv3 --kernel-trace --output-format csv --pmc $set -d $R/$OUT/pmc_${which}_$tag -o p -- python $R/tools/pmc_target.py $which > $R/$OUT/pmc_${which}_$tag.log 2>&1
   done
 done
 cd $R
