@@ -108,10 +108,13 @@ __global__ void __launch_bounds__(256)
 tensor_quant_fp8_kernel(uint8_t* __restrict__ q, float* __restrict__ scale_inv, const uint32_t* __restrict__ amax_bits,
                         const T* __restrict__ x, int64_t rows, int K, int M, int64_t x_bs, int64_t x_rs) {
   const float fp8_max = E5 ? 57344.0f : 448.0f;
-  // the reference computes amax, the clamp and the scale as 0-dim tensors of x's dtype (fp8_utils.py:142-147):
-  // each is rounded to T
+  // the reference computes amax, the clamp and the scale as 0-dim tensors of x's dtype (fp8_utils.py:142-147): each
+  // is rounded to T, and `fp8_max / amax` with a Python scalar on the left is Tensor.__rtruediv__, i.e.
+  // amax.reciprocal() * fp8_max -- two roundings (it differs from the correctly rounded quotient, e.g. for f16 at
+  // amax = 300: 1.4941 against 1.4932)
   const float amax = fmaxf(__uint_as_float(*amax_bits), Elem<T>::to_f(Elem<T>::from_f(1e-12f)));
-  const float scale = Elem<T>::to_f(Elem<T>::from_f(fp8_max / amax));
+  const float recip = Elem<T>::to_f(Elem<T>::from_f(1.0f / amax));
+  const float scale = Elem<T>::to_f(Elem<T>::from_f(recip * fp8_max));
   if (blockIdx.x == 0 && threadIdx.x == 0) scale_inv[0] = 1.0f / scale;   // scale.float().reciprocal()
   const int kv = K / 8;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows * kv; i += (int64_t)gridDim.x * 256) {
