@@ -18,6 +18,8 @@
 // Mirrors extend_attention_fwd (layers/attention/triton_ops/extend_attention.py:291-410).
 #include "common.h"
 
+#include <algorithm>
+
 namespace semipd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -71,7 +73,15 @@ __device__ inline Frag16 load_row8(const T* p, int valid) {
 
 // Two workgroups per CU (2 waves / SIMD, <= 256 VGPRs) wherever that fits without spilling: the second
 // wave hides the LDS / softmax latency of the first.
-template <typename T, int DKP, int DVP, bool VEC, bool CAP, typename KV = T>
+typedef int ext_i32x4 __attribute__((ext_vector_type(4)));
+
+// FAST (round 2; the PMC breakdown in profiles/r02_pmc_extend_attention.txt showed 13-16 VALU instructions per MFMA,
+// most of them staging: per-load bounds branches, zero fills, 64-bit address arithmetic in two code paths): head
+// dims equal to their padded sizes, rows in the activation type, no logit cap.  The NEW tokens' K / V rows are then
+// fetched with buffer loads -- descriptor per (sequence, kv head) whose size ends at the last row the tile may
+// see, so rows past the end read as zero in hardware; per-thread offsets are computed once, the tile offset is a
+// scalar -- and the softmax scale is folded into the exponent's fma.
+template <typename T, int DKP, int DVP, bool VEC, bool CAP, typename KV = T, bool FAST = false>
 __global__ void __launch_bounds__(256, (VEC && !CAP && DKP <= 128) ? 2 : 1)
 extend_attn_kernel(T* __restrict__ out, const T* __restrict__ q_ext, const T* __restrict__ k_ext,
                    const T* __restrict__ v_ext, const KV* __restrict__ k_buf,
@@ -140,6 +150,23 @@ extend_attn_kernel(T* __restrict__ out, const T* __restrict__ q_ext, const T* __
   const T* ke_head = k_ext + (int64_t)q_start * k_stride + (int64_t)hk * Dk;
   const T* ve_head = v_ext + (int64_t)q_start * v_stride + (int64_t)hk * Dv;
   const int32_t* idx_base = kv_indices + kv_start;
+  // FAST: the extend rows through buffer descriptors that end after row ext_end - 1 of this kv head
+  __amdgpu_buffer_rsrc_t rsrc_k, rsrc_v;
+  int kvo[NKI], vvo[NVI];
+  if constexpr (FAST) {
+    rsrc_k = __builtin_amdgcn_make_buffer_rsrc((void*)ke_head, 0, (int)(((int64_t)(ext_end - 1) * k_stride + Dk) * 2), 0x00020000);
+    rsrc_v = __builtin_amdgcn_make_buffer_rsrc((void*)ve_head, 0, (int)(((int64_t)(ext_end - 1) * v_stride + Dv) * 2), 0x00020000);
+#pragma unroll
+    for (int i = 0; i < NKI; ++i) {
+      const int item = tid + i * 256;
+      kvo[i] = (int)(((int64_t)(item / CHK) * k_stride + (item % CHK) * 8) * 2);
+    }
+#pragma unroll
+    for (int i = 0; i < NVI; ++i) {
+      const int item = tid + i * 256;
+      vvo[i] = (int)(((int64_t)(item / CHV) * v_stride + (item % CHV) * 8) * 2);
+    }
+  }
 
   // Per-thread staging slots: item = tid + i*256 -> (row r, 16-byte chunk c) of the tile.
   // The pool-slot indices of a prefix tile are loaded ONE ITERATION before its rows so that the
@@ -192,6 +219,20 @@ extend_attn_kernel(T* __restrict__ out, const T* __restrict__ q_ext, const T* __
                                         min(8, Dv - c * 8));
           }
         }
+      }
+    } else if constexpr (FAST) {  // the new tokens: one buffer load per chunk, no VALU
+      static_assert(!FAST || ((BN * CHK) % 256 == 0 && (BN * CHV) % 256 == 0), "whole passes of the 256 threads");
+      const int n0 = (it - n_pre_tiles) * BN;
+      const int ks_off = (int)((int64_t)n0 * k_stride * 2), vs_off = (int)((int64_t)n0 * v_stride * 2);
+#pragma unroll
+      for (int i = 0; i < NKI; ++i) {
+        const ext_i32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rsrc_k, kvo[i], ks_off, 0);
+        kreg[i].u = make_uint4((uint32_t)r[0], (uint32_t)r[1], (uint32_t)r[2], (uint32_t)r[3]);
+      }
+#pragma unroll
+      for (int i = 0; i < NVI; ++i) {
+        const ext_i32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, vvo[i], vs_off, 0);
+        vreg[i].u = make_uint4((uint32_t)r[0], (uint32_t)r[1], (uint32_t)r[2], (uint32_t)r[3]);
       }
     } else {  // the new tokens: contiguous rows
       const int n0 = (it - n_pre_tiles) * BN;
@@ -264,11 +305,16 @@ extend_attn_kernel(T* __restrict__ out, const T* __restrict__ q_ext, const T* __
     // ---- S^T = K Q^T : two 32-row kv tiles ----
     f32x16 s_acc[2];
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
+    for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) s_acc[kt][r] = 0.f;
+    // the two 32-row kv tiles alternate k-step by k-step: consecutive MFMAs never share an accumulator, so the
+    // 8-pass latency of one hides behind the issue of the other (PMC: 24 % -> 34 % of the wave cycles were issue
+    // stalls with the chains back to back)
 #pragma unroll
-      for (int ks = 0; ks < KSTEPS; ++ks) {
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
         Frag16 a;
         a.u = *reinterpret_cast<const uint4*>(kbase + kt * 32 * KS + ks * 16);
         s_acc[kt] = Mfma<T>::mma(as_frag<T>(a), as_frag<T>(qf[ks]), s_acc[kt]);
@@ -282,12 +328,12 @@ extend_attn_kernel(T* __restrict__ out, const T* __restrict__ q_ext, const T* __
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           s_acc[kt][r] = logit_cap * tanhf(s_acc[kt][r] * sm_scale / logit_cap) * LOG2E;
-    } else {
+    } else if constexpr (!FAST) {
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) s_acc[kt][r] *= qk_scale;
-    }
+    }  // FAST: raw scores; qk_scale > 0 is applied to the row maximum and inside the exponent's fma below
     if (need_mask) {
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
@@ -304,6 +350,7 @@ extend_attn_kernel(T* __restrict__ out, const T* __restrict__ q_ext, const T* __
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s_acc[kt][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if constexpr (FAST) mx *= qk_scale;   // -inf stays -inf
     // ---- online softmax (base 2) ----
     const float m_new = fmaxf(m_run, mx);
     if (__any(m_new > m_run)) {
@@ -322,8 +369,9 @@ extend_attn_kernel(T* __restrict__ out, const T* __restrict__ q_ext, const T* __
     for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
-        const float p0 = __builtin_amdgcn_exp2f(s_acc[kt][r] - m_use);  // exp2(-inf) = 0
-        const float p1 = __builtin_amdgcn_exp2f(s_acc[kt][r + 1] - m_use);
+        // exp2(-inf) = 0
+        const float p0 = __builtin_amdgcn_exp2f(FAST ? fmaf(s_acc[kt][r], qk_scale, -m_use) : s_acc[kt][r] - m_use);
+        const float p1 = __builtin_amdgcn_exp2f(FAST ? fmaf(s_acc[kt][r + 1], qk_scale, -m_use) : s_acc[kt][r + 1] - m_use);
         psum += p0 + p1;
         pf[kt][r >> 3].w[(r & 7) >> 1] = pack2<T>(p0, p1);
       }
@@ -331,11 +379,11 @@ extend_attn_kernel(T* __restrict__ out, const T* __restrict__ q_ext, const T* __
     l_run += psum;
     // ---- O^T += V^T P^T : V^T fragments through the transposing LDS read ----
 #pragma unroll
-    for (int t = 0; t < DVT; ++t) {
+    for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
+      for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
+        for (int t = 0; t < DVT; ++t) {   // DVT independent accumulators in a row
           Frag16 a;
           const uint16_t* vp = vbase + (kt * 32 + s2 * 16) * VS + t * 32;
           a.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp));
@@ -461,19 +509,31 @@ static int launch_extend_variant(void* out, const void* q, const void* k, const 
   // x = head (fastest), y = query tile: dispatch order is x-major, so every head of the longest
   // (last, causal) query tile starts first and the short tiles fill the tail
   dim3 grid((unsigned)Hq, (unsigned)((max_len_extend + 127) / 128), (unsigned)batch), block(256);
-#define EXT(DKP, DVP)                                                                              \
-  hipLaunchKernelGGL((extend_attn_kernel<T, DKP, DVP, VEC, CAP, KV>), grid, block, 0, st, (T*)out, \
-                     (const T*)q, (const T*)k, (const T*)v, (const KV*)k_buf, (const KV*)v_buf,     \
-                     qo_indptr, kv_indptr, kv_indices, group, Dk, Dv, q_stride, k_stride, v_stride, \
+#define EXT_(DKP, DVP, FASTV)                                                                             \
+  hipLaunchKernelGGL((extend_attn_kernel<T, DKP, DVP, VEC, CAP, KV, FASTV>), grid, block, 0, st, (T*)out, \
+                     (const T*)q, (const T*)k, (const T*)v, (const KV*)k_buf, (const KV*)v_buf,            \
+                     qo_indptr, kv_indptr, kv_indices, group, Dk, Dv, q_stride, k_stride, v_stride,        \
                      o_stride, kbuf_stride, vbuf_stride, sm_scale, logit_cap)
+#define EXT(DKP, DVP) EXT_(DKP, DVP, false)
+  // FAST: exact head dims, activation-type rows, no cap, extend rows addressable by a 32-bit buffer offset
+  constexpr bool kFastType = VEC && !CAP && !KVTraits<T, KV>::kF8;
+  const bool fast = kFastType && (int64_t)max_len_extend * std::max(k_stride, v_stride) * 2 < (1ll << 31);
   if (dkp <= 16 && dvp <= 32) EXT(16, 32);
-  else if (dkp <= 64 && dvp <= 64) EXT(64, 64);
+  else if (dkp <= 64 && dvp <= 64) {
+    if constexpr (kFastType) { if (fast && Dk == 64 && Dv == 64) EXT_(64, 64, true); else EXT(64, 64); }
+    else EXT(64, 64);
+  }
   else if (dkp <= 96 && dvp <= 96) EXT(96, 96);
-  else if (dkp <= 128 && dvp <= 128) EXT(128, 128);
+  else if (dkp <= 128 && dvp <= 128) {
+    if constexpr (kFastType) { if (fast && Dk == 128 && Dv == 128) EXT_(128, 128, true); else EXT(128, 128); }
+    else EXT(128, 128);
+  }
   else if (dkp <= 192 && dvp <= 128) {
     if constexpr (KVTraits<T, KV>::kF8) return 1;  // MLA prefill keeps its rows in the activation type
+    else if constexpr (kFastType) { if (fast && Dk == 192 && Dv == 128) EXT_(192, 128, true); else EXT(192, 128); }
     else EXT(192, 128);
   } else return 1;  // no MFMA instantiation
+#undef EXT_
 #undef EXT
   return 0;
 }
