@@ -48,6 +48,15 @@ elif which.startswith("extend"):
     for _ in range(5):
         ops.extend_attention_fwd(q, k, v, o, kb, kb, qo, kvp, idx, None, None, ext)
     print("flop_per_launch", 4.0 * Hq * D * B * ext * (ext + 1) / 2)
+elif which == "stream":
+    # the streaming GEMM of a decode batch: Llama-3-8B gate_up + SiLU*mul (235 MB of weights, read once), 6 weight
+    # copies in rotation so that the 256 MB Infinity Cache cannot serve a re-read
+    M, N, K = 32, 28672, 4096
+    ws = [torch.randn(N, K, device=dev, dtype=torch.bfloat16) * 0.02 for _ in range(6)]
+    x = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
+    for i in range(12):
+        ops.stream_linear(x, ws[i % 6], fuse_silu_mul=True)
+    print("algorithmic_bytes_per_launch", N * K * 2 + M * K * 2 + M * (N // 2) * 2)
 elif which == "fp8mm":
     # decode-sized block-fp8 linear on a DeepSeek-V3 shape: the fp8 weights (176 MB) are read once
     M, N, K = 32, 24576, 7168
