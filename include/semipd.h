@@ -386,6 +386,10 @@ int semipd_moe_grouped_gemm_fp8(void* c, const void* a_q, const float* a_s, cons
  * *offset = dev_ptr - allocation base.  replaces GetIPCMemHandle (ipc.cpp:60-64)
  * plus the _share_cuda_ offset lookup (semi_pd/utils.py:66-76). */
 int semipd_ipc_get_handle(const void* dev_ptr, uint8_t handle[64], uint64_t* offset);
+/* HIP runtime / driver version numbers (hipRuntimeGetVersion, hipDriverGetVersion): logged next to the IPC size rule
+ * of semipd_ipc_get_handle, which was measured on one runtime.  library plumbing (no reference counterpart). */
+int semipd_runtime_version(int* runtime, int* driver);
+
 /* Open (or re-use: one mapping per handle per process, ref-counted) and return the
  * mapped allocation base.  replaces ConvertIPCMemHandleToTensor's open
  * (ipc.cpp:67-85). */

@@ -62,7 +62,12 @@ int semipd_ipc_get_handle(const void* dev_ptr, uint8_t handle[64], uint64_t* off
   // allocation size modulo 4 GiB is 2 GiB or more (measured: 2.5 GiB and 6.1 GiB hang; 1.9, 5.0, 9.5, 20,
   // 40 GiB map in < 1 ms; tools/ipc_big_probe.py).  Refuse to export such an allocation instead of
   // hanging the importer; large buffers meant for sharing are sized around it (memory_pool.py).
-  SEMIPD_CHECK_ARG(((uint64_t)size & 0xffffffffull) < 0x80000000ull, SEMIPD_EINVAL,
+  // The rule was measured on ONE runtime (HIP 7.2): it is applied on every runtime (padding is harmless where the
+  // importer would not have hung), can be switched off with SEMIPD_IPC_SIZE_RULE=off once a runtime is known to be
+  // fixed, and the importer bounds every hipIpcOpenMemHandle with a watchdog (semi_pd_ipc.py) so that a size this
+  // rule does not know about fails with a message instead of hanging the prefill instance.
+  static const bool rule_off = [] { const char* e = getenv("SEMIPD_IPC_SIZE_RULE"); return e && std::string(e) == "off"; }();
+  SEMIPD_CHECK_ARG(rule_off || ((uint64_t)size & 0xffffffffull) < 0x80000000ull, SEMIPD_EINVAL,
                    "ipc_get_handle: allocation of %zu bytes cannot be imported by another process on this ROCm "
                    "(size mod 4 GiB >= 2 GiB hangs hipIpcOpenMemHandle); allocate it with ipc-safe padding",
                    size);
@@ -72,6 +77,13 @@ int semipd_ipc_get_handle(const void* dev_ptr, uint8_t handle[64], uint64_t* off
   SEMIPD_HIP(hipIpcGetMemHandle(&h, base));
   memcpy(handle, &h, 64);
   *offset = (uint64_t)((const uint8_t*)dev_ptr - (const uint8_t*)base);
+  return 0;
+}
+
+int semipd_runtime_version(int* runtime, int* driver) {
+  SEMIPD_CHECK_ARG(runtime && driver, SEMIPD_EINVAL, "runtime_version: null pointer");
+  SEMIPD_HIP(hipRuntimeGetVersion(runtime));
+  SEMIPD_HIP(hipDriverGetVersion(driver));
   return 0;
 }
 

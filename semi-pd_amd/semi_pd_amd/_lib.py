@@ -57,6 +57,7 @@ _SIGNATURES = {
     "semipd_input_to_float8": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _vp],
     "semipd_bmm_fp8": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _i32,
                        _i32, _vp],
+    "semipd_runtime_version": [_vp, _vp],
     "semipd_stream_linear_workspace": [_i64],
     "semipd_stream_linear_planes": [_vp, _sz, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp],
     "semipd_fused_add_rmsnorm_planes": [_vp, _vp, _vp, _vp, _i32, _i64, _i64, _i64, _f32, _i32, _vp],

@@ -75,13 +75,52 @@ def get_ipc_handle(tensor: torch.Tensor) -> List[int]:
     return get_ipc_handle_and_offset(tensor)[0]
 
 
+def runtime_version() -> Tuple[int, int]:
+    """(hipRuntimeGetVersion, hipDriverGetVersion)."""
+    r, d = C.c_int(0), C.c_int(0)
+    _lib.check(_lib.load().semipd_runtime_version(C.addressof(r), C.addressof(d)), "runtime_version")
+    return int(r.value), int(d.value)
+
+
+def _open_watchdog(handle: Sequence[int], seconds: float):
+    """hipIpcOpenMemHandle has been seen never to return for some allocation sizes (csrc/ipc.hip); the exporter
+    sizes its allocations around the one rule that was measured, and this bounds what the rule does not know: after
+    `seconds` the importing process says what it was doing and exits, so the engine reports a dead prefill instance
+    with a reason instead of waiting for its start-up timeout."""
+    import os
+    import sys
+    import threading
+
+    def fatal():
+        try:
+            rt = runtime_version()
+        except Exception:  # noqa: BLE001
+            rt = ("?", "?")
+        sys.stderr.write(f"semi_pd_ipc: hipIpcOpenMemHandle did not return within {seconds:.0f} s (HIP runtime {rt[0]}, "
+                         f"driver {rt[1]}; handle {bytes(int(b) & 0xFF for b in handle[:16]).hex()}...).  Known cause "
+                         "on HIP 7.2: an exported allocation whose size modulo 4 GiB is >= 2 GiB (csrc/ipc.hip); "
+                         "SEMIPD_IPC_OPEN_TIMEOUT_S changes this limit.\n")
+        sys.stderr.flush()
+        os._exit(71)
+
+    t = threading.Timer(seconds, fatal)
+    t.daemon = True
+    return t
+
+
 def _open(handle: Sequence[int], device_index: int) -> int:
     if len(handle) != 64:
         raise ValueError(f"IPC handle must have 64 bytes, got {len(handle)}")
+    import os
     lib = _lib.load()
     raw = (C.c_uint8 * 64)(*[int(b) & 0xFF for b in handle])
     base = C.c_void_p(0)
-    _lib.check(lib.semipd_ipc_open(C.addressof(raw), device_index, C.addressof(base)), "ipc_open")
+    dog = _open_watchdog(handle, float(os.environ.get("SEMIPD_IPC_OPEN_TIMEOUT_S", "120")))
+    dog.start()
+    try:
+        _lib.check(lib.semipd_ipc_open(C.addressof(raw), device_index, C.addressof(base)), "ipc_open")
+    finally:
+        dog.cancel()
     return int(base.value)
 
 

@@ -6,7 +6,7 @@ import re
 import pytest
 import torch
 
-from conftest import ROOT
+from conftest import PKG, ROOT
 from semi_pd_amd import _lib
 
 
@@ -87,3 +87,15 @@ def test_integration_appendix_names_every_entry_point():
     assert len(names) == len(set(names)) >= 58
     for n in names:
         assert f"| `{n}` |" in block
+
+
+def test_ipc_open_watchdog_ends_a_stuck_importer_with_a_reason():
+    """hipIpcOpenMemHandle can hang for allocation sizes the measured rule does not cover (csrc/ipc.hip): the importer
+    bounds every open; a process stuck past the limit prints what it was doing and exits with code 71."""
+    import subprocess
+    import sys
+    code = ("import sys, time; sys.path[:0] = %r; import semi_pd_ipc; "
+            "t = semi_pd_ipc._open_watchdog([7] * 64, 0.3); t.start(); time.sleep(5); print('not reached')"
+            % ([PKG],))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 71 and "did not return within" in r.stderr and "not reached" not in r.stdout
