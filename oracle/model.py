@@ -223,10 +223,15 @@ class OracleDeepseekV2:
     biased_grouped_topk + naive experts (deepseek_v2.py:119-210, layers/moe/topk.py:79-160,
     fused_moe_native.py:58-131)."""
 
-    def __init__(self, config, state_dict, act_dtype=torch.float32, kv_cache_dtype=None):
+    def __init__(self, config, state_dict, act_dtype=torch.float32, kv_cache_dtype=None, absorb_fp8=False):
         """kv_cache_dtype = torch.float8_e5m2 / float8_e4m3fn: the latent rows [kv_a | k_pe] go through `.to(fp8)`
         when they enter the cache (MLATokenToKVPool.set_kv_buffer, memory_pool.py:439-452); cached keys / values
-        are expanded from the rounded rows, the tokens of the running forward attend to each other unrounded."""
+        are expanded from the rounded rows, the tokens of the running forward attend to each other unrounded.
+        absorb_fp8 (block-quantised models): decode steps run forward_absorb the way the reference's CUDA path does
+        (deepseek_v2.py:633-706, 1195-1209): kv_b_proj re-quantised per tensor, q_nope and the latent attention
+        output quantised per tensor on the fly (input_to_float8 over the whole [H, T, d] tensor of the step), both
+        products through bmm_fp8.  Prefills without a prefix stay in the normal form, as in the engine."""
+        self.absorb_fp8 = bool(absorb_fp8)
         self.cfg = config
         self.w = {k: v.detach().to("cpu") for k, v in state_dict.items()}
         self.act = act_dtype
@@ -292,12 +297,52 @@ class OracleDeepseekV2:
             out = out + self._mlp(x, p + "shared_experts.").float()
         return out.to(self.act)
 
+    def _absorb_weights(self, name):
+        """(W_kc [H, 128, 512] fp8, W_vc [H, 512, 128] fp8, 1 / scale): block_quant_to_tensor_quant of kv_b_proj."""
+        if not hasattr(self, "_absorb_cache"):
+            self._absorb_cache = {}
+        if name not in self._absorb_cache:
+            wq = self.w[name]
+            if wq.dtype != torch.float8_e4m3fn:   # a state dict widened to fp32 holds the same (fp8-representable) values
+                wq = wq.to(torch.float8_e4m3fn)
+            wt, ws = O.block_quant_to_tensor_quant(wq, self.w[name + "_scale_inv"].float(), self.block)
+            w3 = wt.unflatten(0, (self.H, self.nope + self.vd))
+            self._absorb_cache[name] = (w3[:, : self.nope, :], w3[:, self.nope:, :].transpose(1, 2), ws)
+        return self._absorb_cache[name]
+
+    def _attend_absorbed(self, p, q, kv_a, k_pe, lens, starts, kv, l):
+        """forward_absorb with the per-tensor fp8 products; the cache holds latent rows [kv_a | k_pe]."""
+        T = q.shape[0]
+        w_kc, w_vc, w_s = self._absorb_weights(p + "self_attn.kv_b_proj.weight")
+        q8, q_s = O.input_to_float8(q[..., : self.nope].to(self.q_act).transpose(0, 1), torch.float8_e4m3fn)
+        q_abs = O.bmm_fp8(q8, w_kc, q_s, w_s, self.q_act).float()                      # [H, T, 512]
+        lat_new = torch.cat([kv_a.float(), k_pe.float()], -1)                             # [T, 576]
+        o_lat = torch.empty(T, self.H, self.lora)
+        for b, n in enumerate(lens):
+            sl = slice(starts[b], starts[b + 1])
+            old = kv.lat[l][b]
+            lat = lat_new[sl] if old is None else torch.cat([old, lat_new[sl]], 0)
+            kv.lat[l][b] = lat
+            s = (torch.einsum("hqc,kc->hqk", q_abs[:, sl], lat[:, : self.lora])
+                 + torch.einsum("qhr,kr->hqk", q[sl, :, self.nope:].float(), lat[:, self.lora:])) * self.scaling
+            Tk = lat.shape[0]
+            if n > 1:
+                s = s.masked_fill(~torch.ones(n, Tk, dtype=torch.bool).tril(diagonal=Tk - n), float("-inf"))
+            o_lat[sl] = torch.einsum("hqk,kc->qhc", torch.softmax(s, -1), lat[:, : self.lora])
+        a8, a_s = O.input_to_float8(o_lat.to(self.q_act).transpose(0, 1), torch.float8_e4m3fn)
+        out = O.bmm_fp8(a8, w_vc, a_s, w_s, self.q_act)                                   # [H, T, 128]
+        return out.transpose(0, 1).reshape(T, -1)
+
     def _layers(self, h, positions, lens, kv):
         c = self.cfg
         res = None
         starts = [0]
         for n in lens:
             starts.append(starts[-1] + n)
+        if self.absorb_fp8 and not hasattr(kv, "lat"):
+            kv.lat = [[None] * len(lens) for _ in range(c.num_hidden_layers)]
+        # the engine absorbs whenever cached tokens are attended to (decode, later chunks); a first prefill does not
+        absorb = self.absorb_fp8 and self.block is not None and any(x is not None for x in kv.k[0])
         for l in range(c.num_hidden_layers):
             p = f"model.layers.{l}."
             if res is None:
@@ -312,8 +357,17 @@ class OracleDeepseekV2:
             q_pe, k_pe = O.apply_rope(positions, q[..., self.nope:].reshape(T, -1), latent[:, self.lora:],
                                       self.rope, self.cache, False)
             q = torch.cat([q[..., : self.nope], q_pe.view(T, self.H, self.rope)], -1)
-            # (a block-quantised kv_b_proj is used dequantised: the engine's absorbed decode path multiplies with the
-            # dequantised W_kc / W_vc, deepseek_v2.py:1195-1249)
+            if absorb:
+                h = self._lin(self._attend_absorbed(p, q, kv_a, k_pe, lens, starts, kv, l).to(self.act),
+                              p + "self_attn.o_proj.weight")
+                for b, n in enumerate(lens):   # keep the per-head cache of the normal form in step (length bookkeeping)
+                    kv.append(l, b, torch.zeros(n, self.H, self.nope + self.rope), torch.zeros(n, self.H, self.vd))
+                x, res = O.fused_add_rms_norm(h, res, self.w[p + "post_attention_layernorm.weight"], c.rms_norm_eps)
+                is_moe = (c.n_routed_experts is not None and l >= c.first_k_dense_replace and l % c.moe_layer_freq == 0)
+                h = self._moe(x, p + "mlp.") if is_moe else self._mlp(x, p + "mlp.")
+                continue
+            # (with absorb_fp8 off, a block-quantised kv_b_proj is used dequantised, like the engine's
+            # SEMIPD_MLA_ABSORB_BF16 form and the reference's HIP branch, deepseek_v2.py:655-658, 1195-1249)
             kvb = (kv_a.float() @ self._dense(p + "self_attn.kv_b_proj.weight").T).to(self.act)
             kvb = kvb.view(T, self.H, self.nope + self.vd)
             k = torch.cat([kvb[..., : self.nope], k_pe.view(T, 1, self.rope).expand(T, self.H, self.rope)], -1)
@@ -332,6 +386,9 @@ class OracleDeepseekV2:
                 kk = k[sl] if kv.k[l][b] is None else torch.cat([kv.k[l][b], k[sl]], 0)
                 vv = v[sl] if kv.v[l][b] is None else torch.cat([kv.v[l][b], v[sl]], 0)
                 kv.append(l, b, k_c[sl], v_c[sl])
+                if self.absorb_fp8:
+                    row = torch.cat([kv_a[sl].float(), k_pe[sl].float()], -1)
+                    kv.lat[l][b] = row if kv.lat[l][b] is None else torch.cat([kv.lat[l][b], row], 0)
                 s = torch.einsum("qhd,khd->hqk", q[sl].float(), kk.float()) * self.scaling
                 Tk = kk.shape[0]
                 if n > 1:
