@@ -240,13 +240,15 @@ int semipd_fused_add_rmsnorm_planes(void* out, void* residual, const void* weigh
 /* Per-tensor fp8 for the MLA weight absorption of a block-fp8 DeepSeek model.
  * semipd_input_to_float8: q = fp8(clamp(x * scale)), scale = T(fp8_max / amax(|x|)) over the WHOLE tensor,
  *   *scale_inv = 1 / scale; x is [batch, m, k] through (batch, row) strides (a transposed view is fine), q is
- *   contiguous [batch, m, k]; amax_workspace = 4 bytes of device memory.
+ *   contiguous [batch, m, k]; amax_workspace = SEMIPD_INPUT_TO_FLOAT8_WORKSPACE_BYTES of device memory (per-block
+ *   partial maxima; contents need not be initialised and do not carry over between calls).
  *   replaces input_to_float8 (layers/quantization/fp8_utils.py:137-149, called at models/deepseek_v2.py:659-661, 690-692).
  * semipd_bmm_fp8: out[b, m, n] = sum_k A[b, m, k] * B[b, k, n] * a_scale * b_scale, A row-major [batch, m, k], B
  *   COLUMN-major (memory [batch, n, k], like the reference's w_kc / w_vc buffers), fp8 matrix cores, fp32
  *   accumulate, bf16 / f16 output through (batch, row) strides.  e4m3fn x e4m3fn, e4m3fn x e5m2, e5m2 x e4m3fn.
  *   replaces torch.ops.sgl_kernel.bmm_fp8 (sgl-kernel/csrc/torch_extension.cc:146-149, csrc/gemm/bmm_fp8.cu,
  *   python/sgl_kernel/gemm.py:66-82; models/deepseek_v2.py:662-665, 693-700). */
+#define SEMIPD_INPUT_TO_FLOAT8_WORKSPACE_BYTES 4096
 int semipd_input_to_float8(void* q, float* scale_inv, void* amax_workspace, const void* x, int64_t batch, int64_t m,
                            int64_t k, int64_t x_batch_stride, int64_t x_row_stride, int dtype, int f8_dtype,
                            void* stream);

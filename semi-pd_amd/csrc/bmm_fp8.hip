@@ -79,9 +79,11 @@ bmm_fp8_kernel(OutT* __restrict__ out, const uint8_t* __restrict__ x, const uint
 // ---- input_to_float8: amax over the tensor, then x * (fp8_max / amax) clamped and rounded (RNE) ----
 template <typename T>
 __global__ void __launch_bounds__(256)
-tensor_absmax_kernel(uint32_t* __restrict__ amax_bits, const T* __restrict__ x, int64_t rows, int K, int M,
+tensor_absmax_kernel(float* __restrict__ block_amax, const T* __restrict__ x, int64_t rows, int K, int M,
                      int64_t x_bs, int64_t x_rs) {
-  // rows = batch * M logical rows of K contiguous elements; 8 elements per thread per step
+  // rows = batch * M logical rows of K contiguous elements; 8 elements per thread per step.  One partial maximum per
+  // block, reduced again by every block of the quantiser: no atomics, nothing to zero between calls (a memset node in
+  // front of an atomicMax did not keep its place in a captured decode graph), and the same bits on every replay
   __shared__ float red[16];
   float mx = 0.f;
   const int kv = K / 8;
@@ -99,20 +101,27 @@ tensor_absmax_kernel(uint32_t* __restrict__ amax_bits, const T* __restrict__ x, 
   __syncthreads();
   if (threadIdx.x == 0) {
     const float m4 = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    atomicMax(amax_bits, __float_as_uint(m4));   // non-negative floats order like their bit patterns
+    block_amax[blockIdx.x] = m4;
   }
 }
 
 template <typename T, bool E5>
 __global__ void __launch_bounds__(256)
-tensor_quant_fp8_kernel(uint8_t* __restrict__ q, float* __restrict__ scale_inv, const uint32_t* __restrict__ amax_bits,
-                        const T* __restrict__ x, int64_t rows, int K, int M, int64_t x_bs, int64_t x_rs) {
+tensor_quant_fp8_kernel(uint8_t* __restrict__ q, float* __restrict__ scale_inv, const float* __restrict__ block_amax,
+                        int n_partials, const T* __restrict__ x, int64_t rows, int K, int M, int64_t x_bs, int64_t x_rs) {
   const float fp8_max = E5 ? 57344.0f : 448.0f;
+  __shared__ float red[4];
+  float part = 0.f;
+  for (int i = threadIdx.x; i < n_partials; i += 256) part = fmaxf(part, block_amax[i]);
+  part = wave_max(part);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+  __syncthreads();
+  const float tensor_amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   // the reference computes amax, the clamp and the scale as 0-dim tensors of x's dtype (fp8_utils.py:142-147): each
   // is rounded to T, and `fp8_max / amax` with a Python scalar on the left is Tensor.__rtruediv__, i.e.
   // amax.reciprocal() * fp8_max -- two roundings (it differs from the correctly rounded quotient, e.g. for f16 at
   // amax = 300: 1.4941 against 1.4932)
-  const float amax = fmaxf(__uint_as_float(*amax_bits), Elem<T>::to_f(Elem<T>::from_f(1e-12f)));
+  const float amax = fmaxf(tensor_amax, Elem<T>::to_f(Elem<T>::from_f(1e-12f)));
   const float recip = Elem<T>::to_f(Elem<T>::from_f(1.0f / amax));
   const float scale = Elem<T>::to_f(Elem<T>::from_f(recip * fp8_max));
   if (blockIdx.x == 0 && threadIdx.x == 0) scale_inv[0] = 1.0f / scale;   // scale.float().reciprocal()
@@ -156,17 +165,16 @@ int semipd_input_to_float8(void* q, float* scale_inv, void* amax_workspace, cons
   hipStream_t st = as_stream(stream);
   const int64_t rows = batch * m;
   const int64_t items = rows * (k / 8);
-  const unsigned grid = (unsigned)std::min<int64_t>((items + 255) / 256, 2048);
-  SEMIPD_HIP(hipMemsetAsync(amax_workspace, 0, 4, st));
+  const unsigned grid = (unsigned)std::min<int64_t>((items + 255) / 256, SEMIPD_INPUT_TO_FLOAT8_WORKSPACE_BYTES / 4);
   SEMIPD_DISPATCH_HALF(dtype, T, {
-    hipLaunchKernelGGL((tensor_absmax_kernel<T>), dim3(grid), dim3(256), 0, st, (uint32_t*)amax_workspace, (const T*)x,
+    hipLaunchKernelGGL((tensor_absmax_kernel<T>), dim3(grid), dim3(256), 0, st, (float*)amax_workspace, (const T*)x,
                        rows, (int)k, (int)m, x_batch_stride, x_row_stride);
     if (f8_dtype == SEMIPD_F8E5M2)
       hipLaunchKernelGGL((tensor_quant_fp8_kernel<T, true>), dim3(grid), dim3(256), 0, st, (uint8_t*)q, scale_inv,
-                         (const uint32_t*)amax_workspace, (const T*)x, rows, (int)k, (int)m, x_batch_stride, x_row_stride);
+                         (const float*)amax_workspace, (int)grid, (const T*)x, rows, (int)k, (int)m, x_batch_stride, x_row_stride);
     else
       hipLaunchKernelGGL((tensor_quant_fp8_kernel<T, false>), dim3(grid), dim3(256), 0, st, (uint8_t*)q, scale_inv,
-                         (const uint32_t*)amax_workspace, (const T*)x, rows, (int)k, (int)m, x_batch_stride, x_row_stride);
+                         (const float*)amax_workspace, (int)grid, (const T*)x, rows, (int)k, (int)m, x_batch_stride, x_row_stride);
   });
   return launch_status("input_to_float8");
 }

@@ -641,6 +641,9 @@ _F8_CODE = {torch.float8_e5m2: 3, torch.float8_e4m3fn: 4}   # SEMIPD_F8E5M2 / SE
 _AMAX_WS = {}
 
 
+INPUT_TO_FLOAT8_WORKSPACE_BYTES = 4096   # include/semipd.h
+
+
 def input_to_float8(x: torch.Tensor, dtype: torch.dtype = FP8_DTYPE) -> Tuple[torch.Tensor, torch.Tensor]:
     """Tensor-wise dynamic quantisation (layers/quantization/fp8_utils.py:137-149): (x_fp8 contiguous, 1 / scale)
     with scale = fp8_max / amax(|x|).  x: [batch, m, k] (or [m, k]) with a contiguous last dimension; a transposed
@@ -653,13 +656,13 @@ def input_to_float8(x: torch.Tensor, dtype: torch.dtype = FP8_DTYPE) -> Tuple[to
     B, M, K = x3.shape
     q = torch.empty((B, M, K), dtype=dtype, device=x.device)
     scale_inv = torch.empty((), dtype=torch.float32, device=x.device)
-    key = x.device.index if x.device.index is not None else torch.cuda.current_device()
+    st = current_stream(x.device)
+    key = (x.device.index if x.device.index is not None else torch.cuda.current_device(), st)   # one per stream
     ws = _AMAX_WS.get(key)
     if ws is None:
-        ws = _AMAX_WS[key] = torch.zeros(4, dtype=torch.int32, device=x.device)
+        ws = _AMAX_WS[key] = torch.zeros(INPUT_TO_FLOAT8_WORKSPACE_BYTES // 4, dtype=torch.float32, device=x.device)
     check(_lib.load().semipd_input_to_float8(ptr(q), ptr(scale_inv), ptr(ws), ptr(x3), B, M, K, x3.stride(0), x3.stride(1),
-                                             dtype_code(x.dtype), _F8_CODE[dtype], current_stream(x.device)),
-          "input_to_float8")
+                                             dtype_code(x.dtype), _F8_CODE[dtype], st), "input_to_float8")
     return (q if x.dim() == 3 else q[0]), scale_inv
 
 

@@ -206,6 +206,41 @@ def test_input_to_float8_matches_reference_and_oracle(device):
         assert torch.equal(qg.view(torch.uint8).cpu(), qo.view(torch.uint8)) and float(sg) == float(so)
 
 
+def test_input_to_float8_in_a_replayed_graph(device):
+    """Two quantisations inside one hipGraph (the absorbed MLA decode runs two per layer), a large tensor in front of a
+    small one: the second must not inherit the first one's maximum, on the capture and on every replay with new data."""
+    torch.manual_seed(2)
+    big = torch.empty(8, 8, 128, dtype=torch.bfloat16, device=device)
+    small = torch.empty(8, 8, 512, dtype=torch.bfloat16, device=device)
+    stream = torch.cuda.Stream(device=device)
+
+    def run():
+        return ops.input_to_float8(big.transpose(0, 1)), ops.input_to_float8(small.transpose(0, 1))
+
+    def fill(seed):
+        g = torch.Generator().manual_seed(seed)
+        big.copy_((torch.randn(8, 8, 128, generator=g) * 40).to(torch.bfloat16))
+        small.copy_((torch.randn(8, 8, 512, generator=g) * 0.05).to(torch.bfloat16))
+
+    fill(0)
+    stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(stream):
+        run()
+    torch.cuda.current_stream().wait_stream(stream)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=stream):
+        (qb, sb), (qs, ss) = run()
+    for seed in (1, 2, 3):
+        fill(seed)
+        graph.replay()
+        torch.cuda.synchronize()
+        for x, q, s in ((big, qb, sb), (small, qs, ss)):
+            qo, so = O.input_to_float8(x.cpu().transpose(0, 1), torch.float8_e4m3fn)
+            assert float(s) == float(so)
+            assert torch.equal(q.view(torch.uint8).cpu(), qo.contiguous().view(torch.uint8))
+
+
 @pytest.mark.parametrize("a_dt,b_dt", [(torch.float8_e4m3fn, torch.float8_e4m3fn), (torch.float8_e4m3fn, torch.float8_e5m2),
                                        (torch.float8_e5m2, torch.float8_e4m3fn)])
 @pytest.mark.parametrize("res_dtype", [torch.bfloat16, torch.float16])

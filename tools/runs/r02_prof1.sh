@@ -3,8 +3,9 @@
 # config 1 and config 3 lines
 OUT=gpurun_out/r02_prof1; mkdir -p $OUT
 R=$GRAFT_REPO_ROOT
-timeout 1800 python -m pytest tests/test_gpu_fp8_gemm.py tests/test_gpu_deepseek.py -x -q -m gpu > $OUT/pytest_fp8_deepseek.txt 2>&1; tail -4 $OUT/pytest_fp8_deepseek.txt
+timeout 1800 python -m pytest tests/test_gpu_fp8_gemm.py tests/test_gpu_deepseek.py -x -q -m gpu > $OUT/pytest_fp8_deepseek.txt 2>&1; grep -E "^FAILED|^E   |passed|failed" $OUT/pytest_fp8_deepseek.txt | head -12
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/bench_prof -- python $R/bench.py --no-cpu-baseline --no-static-split-wave --no-saturation-wave > $R/$OUT/bench_under_rocprof.json 2> $R/$OUT/bench_under_rocprof.err )
+find $OUT/bench_prof -name "*kernel_trace.csv" -delete; find $OUT -name "*.db" -delete
 tail -c 400 $OUT/bench_under_rocprof.json; echo
 for f in $(find $OUT/bench_prof -name "*kernel_stats.csv"); do python tools/stats_top.py $f | head -14; done
 ( cd /tmp && export TMPDIR=/tmp
@@ -12,6 +13,7 @@ for f in $(find $OUT/bench_prof -name "*kernel_stats.csv"); do python tools/stat
   rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $R/$OUT/stream_fetch -- python $R/tools/pmc_target.py stream > $R/$OUT/stream_fetch.log 2>&1
   rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $R/$OUT/stream_write -- python $R/tools/pmc_target.py stream > $R/$OUT/stream_write.log 2>&1
   rocprofv3 --kernel-trace --output-format csv --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $R/$OUT/stream_sq -- python $R/tools/pmc_target.py stream > $R/$OUT/stream_sq.log 2>&1 )
+find $OUT -name "*kernel_trace.csv" -size +2M -delete
 python - <<'PY'
 import csv, glob, collections
 for tag in ("fetch", "write", "sq"):
