@@ -17,45 +17,12 @@
 //
 // Mirrors extend_attention_fwd (layers/attention/triton_ops/extend_attention.py:291-410).
 #include "common.h"
+#include "mfma_frag.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace semipd {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-
-template <typename T> struct Mfma;
-template <> struct Mfma<bf16_t> {
-  typedef bf16x8_t frag;
-  __device__ static inline f32x16 mma(frag a, frag b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-  }
-};
-template <> struct Mfma<f16_t> {
-  typedef f16x8_t frag;
-  __device__ static inline f32x16 mma(frag a, frag b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-  }
-};
-
-union Frag16 {  // 16 bytes viewed as MFMA operand / raw words / elements
-  uint4 u;
-  uint32_t w[4];
-  s16x4 s[2];
-  uint16_t e[8];
-  bf16x8_t b;
-  f16x8_t f;
-};
-template <typename T> __device__ inline typename Mfma<T>::frag as_frag(const Frag16& x);
-template <> __device__ inline bf16x8_t as_frag<bf16_t>(const Frag16& x) { return x.b; }
-template <> __device__ inline f16x8_t as_frag<f16_t>(const Frag16& x) { return x.f; }
-
-template <typename T> __device__ inline uint32_t pack2(float a, float b) {
-  return (uint32_t)Elem<T>::from_f(a).v | ((uint32_t)Elem<T>::from_f(b).v << 16);
-}
 
 // 8 consecutive elements of a row.  VEC: one 16-byte load (the chunk is either whole or absent);
 // otherwise element-wise with zero fill beyond `valid`.
@@ -539,6 +506,12 @@ static int launch_extend_variant(void* out, const void* q, const void* k, const 
 }
 
 template <typename T>
+int launch_extend_shared_kv(void* out, const void* q, const void* k, const void* v, const void* k_buf, const void* v_buf,
+                            const int32_t* qo_indptr, const int32_t* kv_indptr, const int32_t* kv_indices, int64_t batch,
+                            int Hq, int Hkv, int64_t q_stride, int64_t k_stride, int64_t v_stride, int64_t o_stride,
+                            int64_t kbuf_stride, int64_t vbuf_stride, int max_len_extend, float sm_scale, hipStream_t st);
+
+template <typename T>
 static int run_extend(void* out, const void* q, const void* k, const void* v, const void* k_buf,
                       const void* v_buf, const int32_t* qo_indptr, const int32_t* kv_indptr,
                       const int32_t* kv_indices, int64_t batch, int Hq, int Hkv, int Dk, int Dv,
@@ -583,6 +556,15 @@ static int run_extend(void* out, const void* q, const void* k, const void* v, co
                                                               max_len_extend, sm_scale, logit_cap, st);
     SEMIPD_CHECK_ARG(!miss8, SEMIPD_ESHAPE, "extend_attention: no fp8 instantiation for these head sizes");
     return launch_status("extend_attention");
+  }
+  // Llama-shaped heads (128 / 128, rows in the activation type, no cap): the shared-KV kernel
+  // (extend_attention_shared_kv.hip); SEMIPD_EXTEND_SHARED_KV=0 keeps the one-head-per-workgroup kernel
+  static const bool shared_kv_on = [] { const char* e = getenv("SEMIPD_EXTEND_SHARED_KV"); return !(e && e[0] == '0'); }();
+  if (shared_kv_on && vec_ok && !(logit_cap > 0.f) && Dk == 128 && Dv == 128 &&
+      (int64_t)max_len_extend * std::max(k_stride, v_stride) * 2 < (1ll << 31)) {
+    if (launch_extend_shared_kv<T>(out, q, k, v, k_buf, v_buf, qo_indptr, kv_indptr, kv_indices, batch, Hq, Hkv, q_stride,
+                                   k_stride, v_stride, o_stride, kbuf_stride, vbuf_stride, max_len_extend, sm_scale, st) == 0)
+      return launch_status("extend_attention(shared kv)");
   }
   int miss;
 #define VARIANT(V, C)                                                                                 \

@@ -1,0 +1,398 @@
+// Prefill ("extend") attention, shared-KV form for gfx950 (round 2).
+//
+// The first kernel (extend_attention.hip) gives every (q head, 128 tokens) its own workgroup: the four q heads of a
+// GQA group each stage the same K / V rows through their own LDS tile (4x the fill and the L2 reads), every tile
+// costs two __syncthreads around a register -> LDS copy, and one 1024-token request is 256 workgroups whose longest
+// member walks 16 KV tiles alone.  This one is built the other way round:
+//
+//   workgroup = 8 waves = G q heads of ONE kv head x TB blocks of 32 tokens x 2 KV halves   (G * TB = 4)
+//     wave (half, sub): q head = sub % G, token block = sub / G; per 128-row KV tile the waves of half 0 take rows
+//     0-63 and those of half 1 rows 64-127, and the two partial (m, l, O) are merged through LDS at the end --
+//     the walk of one row block is half as long, and a 1024-token Llama-3 request is 256 workgroups x 8 waves.
+//   K / V tiles (128 rows x 256 B each) arrive by LDS-DMA (buffer_load ... lds for the new tokens, global_load ... lds
+//     through kv_indices for the paged prefix) into a two-deep ring: no staging registers, no ds_write, ONE s_barrier
+//     per tile.  The DMA image is lane-linear (row-major, 16-B chunks); bank conflicts are removed on the SOURCE
+//     side: lane (row, pos) fetches chunk pos ^ (row & 15) of a K row (ds_read_b128 fragments: 16 rows of a lane
+//     group land in 16 different chunks) and chunk pos ^ ((row & 3) << 2) of a V row (ds_read_b64_tr_b16: the four
+//     rows of a lane group land in four different 64-B groups).
+//   Rows past the end of a tile are fetched from the last valid row instead (finite data, masked to p = 0).
+//   Fragment reads are inline asm with counted lgkmcnt waits: a compiler-visible ds_read would wait vmcnt(0) for the
+//     DMA of the NEXT tile that is in flight on purpose (see stream_linear.hip).
+//
+// Arithmetic is the first kernel's FAST path instruction for instruction (S^T = K Q^T, base-2 online softmax with
+// the scale folded into the exponent's fma, O^T += V^T P^T with P in registers), so results agree with it to the
+// rounding of the half-merge.  Exact head size 128, rows in the activation type, no logit cap; everything else stays
+// on extend_attention.hip.   Mirrors extend_attention_fwd (layers/attention/triton_ops/extend_attention.py:291-410).
+#include "common.h"
+#include "mfma_frag.h"
+
+#include <type_traits>
+
+namespace semipd {
+
+namespace skv {
+
+constexpr int kD = 128;               // head size (q, k and v)
+constexpr int kRowBytes = kD * 2;     // one K or V row in LDS
+constexpr int kTileRows = 128;        // KV rows per tile (two halves of 64)
+constexpr int kStage = kTileRows * kRowBytes;   // 32 KiB: one K (or V) tile
+constexpr int kVBase = 2 * kStage;    // K stages at 0 / 32 KiB, V stages at 64 / 96 KiB
+constexpr int kLds = 4 * kStage;      // 128 KiB
+constexpr int kMergeStride = 66 * 64 * 4;   // one wave's (O 64, m, l) x 64 lanes, fp32
+
+template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+template <int OFF> __device__ __forceinline__ uint4 lds_read16(uint32_t addr) {
+  uint4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+template <int OFF> __device__ __forceinline__ s16x4 lds_read_tr8(uint32_t addr) {
+  s16x4 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+template <int N> __device__ __forceinline__ void wait_lgkm() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// The prefetched pool indices are "used" right behind the explicit wait: the compiler then places its own wait for those
+// loads here (where the counter is zero anyway) instead of in the middle of the next DMA issue, where a vmcnt(0) would
+// sit on the pieces just sent.
+__device__ __forceinline__ void wait_vm0_and(int32_t (&idx)[4]) {
+  wait_vm0();
+  asm volatile("" : "+v"(idx[0]), "+v"(idx[1]), "+v"(idx[2]), "+v"(idx[3]));
+}
+
+}  // namespace skv
+
+template <typename T, int G>
+__global__ void __launch_bounds__(512, 1)
+extend_attn_shared_kv_kernel(T* __restrict__ out, const T* __restrict__ q_ext, const T* __restrict__ k_ext,
+                             const T* __restrict__ v_ext, const T* __restrict__ k_buf, const T* __restrict__ v_buf,
+                             const int32_t* __restrict__ qo_indptr, const int32_t* __restrict__ kv_indptr,
+                             const int32_t* __restrict__ kv_indices, int group, int64_t q_stride, int64_t k_stride,
+                             int64_t v_stride, int64_t o_stride, int64_t kbuf_stride, int64_t vbuf_stride,
+                             float sm_scale) {
+  using namespace skv;
+  constexpr int TB = 4 / G;            // token blocks of 32 per workgroup
+  extern __shared__ __attribute__((aligned(16))) char skv_smem[];
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)skv_smem;
+
+  const int seq = blockIdx.z;
+  const int hpg = group / G;           // workgroups per kv head
+  const int hk = (int)blockIdx.x / hpg, hgrp = (int)blockIdx.x - hk * hpg;
+  const int qt = (int)(gridDim.y - 1 - blockIdx.y);     // longest (last) token tile first
+  // readfirstlane: opaque SGPR values -- otherwise the compiler re-loads them from memory inside the tile loop (it
+  // assumes the LDS-DMA builtins may have written anywhere), and that load's wait drains the DMA in flight
+  const int q_start = __builtin_amdgcn_readfirstlane(qo_indptr[seq]);
+  const int ext_len = __builtin_amdgcn_readfirstlane(qo_indptr[seq + 1]) - q_start;
+  if (qt * TB * 32 >= ext_len) return;
+  const int kv_start = __builtin_amdgcn_readfirstlane(kv_indptr[seq]);
+  const int pre_len = __builtin_amdgcn_readfirstlane(kv_indptr[seq + 1]) - kv_start;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = wave >> 2, sub = wave & 3;
+  const int hq = hk * group + hgrp * G + sub % G;
+  const int q0 = (qt * TB + sub / G) * 32;               // this wave's first query row
+  const int col = lane & 31, hi = lane >> 5;
+  const int q_local = q0 + col;
+  const bool q_valid = q_local < ext_len;
+  const bool wave_active = q0 < ext_len;
+
+  // ---- Q^T fragments (B operand): lane holds Q[q_local][ks*16 + hi*8 .. +8] ----
+  Frag16 qf[8];
+  {
+    const T* qrow = q_ext + (int64_t)(q_start + q_local) * q_stride + (int64_t)hq * kD;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+      qf[ks].u = q_valid ? *reinterpret_cast<const uint4*>(qrow + ks * 16 + hi * 8) : make_uint4(0, 0, 0, 0);
+  }
+
+  // the Q loads complete HERE: left pending into the loop, their wait lands in front of the first MFMA of every tile
+  // as vmcnt(0) and drains the DMA of the next tile
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks)
+    asm volatile("" : "+v"(qf[ks].w[0]), "+v"(qf[ks].w[1]), "+v"(qf[ks].w[2]), "+v"(qf[ks].w[3]));
+
+  f32x16 o_acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o_acc[t][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;   // running max in the log2 domain
+  const float qk_scale = sm_scale * 1.4426950408889634f;
+
+  // ---- the tile walk: paged prefix (no causal mask), then the new tokens up to this workgroup's last row ----
+  const int ext_end = min(ext_len, (qt + 1) * TB * 32);
+  const int n_pre = (pre_len + kTileRows - 1) / kTileRows;
+  const int n_ext = (ext_end + kTileRows - 1) / kTileRows;
+  const int n_tiles = n_pre + n_ext;
+
+  // DMA duty of this wave: rows wave*16 + j*4 + (lane >> 4), j = 0..3, of the K tile and of the V tile; pos = lane & 15
+  const int drow = wave * 16 + (lane >> 4), dpos = lane & 15;
+  const T* k_pre = k_buf + (int64_t)hk * kD;
+  const T* v_pre = v_buf + (int64_t)hk * kD;
+  const T* ke_head = k_ext + (int64_t)q_start * k_stride + (int64_t)hk * kD;
+  const T* ve_head = v_ext + (int64_t)q_start * v_stride + (int64_t)hk * kD;
+  const __amdgpu_buffer_rsrc_t rsrc_k = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)ke_head, 0, (int)(((int64_t)(ext_end - 1) * k_stride + kD) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_v = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)ve_head, 0, (int)(((int64_t)(ext_end - 1) * v_stride + kD) * 2), 0x00020000);
+  const int32_t* idx_base = kv_indices + kv_start;
+  int32_t idx[4] = {0, 0, 0, 0};
+  auto load_idx = [=, &idx](int it) __attribute__((always_inline)) {
+    if (it < n_pre) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) idx[j] = idx_base[min(it * kTileRows + drow + j * 4, pre_len - 1)];
+    }
+  };
+  auto issue_dma = [=, &idx](int it, int stage) __attribute__((always_inline)) {
+    const uint32_t kdst = lds0 + stage * kStage + wave * 16 * kRowBytes;
+    const uint32_t vdst = kdst + kVBase;
+    if (it < n_pre) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = drow + j * 4;
+        const T* kp = k_pre + (int64_t)idx[j] * kbuf_stride + ((dpos ^ (r & 15)) * 8);
+        const T* vp = v_pre + (int64_t)idx[j] * vbuf_stride + ((dpos ^ ((r & 3) << 2)) * 8);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)kp,
+                                         (__attribute__((address_space(3))) void*)(uintptr_t)(kdst + j * 4 * kRowBytes), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)vp,
+                                         (__attribute__((address_space(3))) void*)(uintptr_t)(vdst + j * 4 * kRowBytes), 16, 0, 0);
+      }
+    } else {
+      const int n0 = (it - n_pre) * kTileRows;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = drow + j * 4;
+        const int n = min(n0 + r, ext_end - 1);
+        const int ko = (int)(((int64_t)n * k_stride + (dpos ^ (r & 15)) * 8) * 2);
+        const int vo = (int)(((int64_t)n * v_stride + (dpos ^ ((r & 3) << 2)) * 8) * 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_k, (__attribute__((address_space(3))) void*)(uintptr_t)(kdst + j * 4 * kRowBytes),
+                                                 16, ko, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_v, (__attribute__((address_space(3))) void*)(uintptr_t)(vdst + j * 4 * kRowBytes),
+                                                 16, vo, 0, 0, 0);
+      }
+    }
+  };
+
+  // ---- fragment addresses (stage / kv-block / k-step offsets are immediates) ----
+  // K, A operand of S^T: lane (col, hi) reads row half*64 + kt*32 + col, chunk (ks*2 + hi) ^ (col & 15)
+  uint32_t kaddr[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks)
+    kaddr[ks] = lds0 + (half * 64 + col) * kRowBytes + (((ks * 2 + hi) ^ (col & 15)) * 16);
+  // V^T, A operand of O^T, through the transposing read: 16-lane group g = lane >> 4 supplies dv block (g & 1) * 16 of
+  // a 32-wide dv tile t; lane i of the group reads row 4*hi + (i >> 2), columns 4*(i & 3) .. +3.  The kv-slot
+  // permutation of the S^T accumulator layout is matched by the row offsets of the two reads (rows +0 and +8).
+  const int gi = lane & 15, g1 = (lane >> 4) & 1, vr = gi >> 2;
+  uint32_t vaddr[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+    vaddr[t] = lds0 + kVBase + (half * 64 + hi * 4 + vr) * kRowBytes + ((t ^ vr) * 64 + g1 * 32 + (gi & 3) * 8);
+
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  // (tile kind and bounds come in as arguments: a select between two captured scalars becomes a load through a
+  // selected closure address, which pins the closure in scratch and puts vmcnt waits into the tile loop)
+  auto compute = [=, &o_acc, &m_run, &l_run](auto stage_c, int it, bool pre, int n_end) __attribute__((always_inline)) {
+    constexpr int SO = decltype(stage_c)::value * kStage;
+    const int n0 = (pre ? it : it - n_pre) * kTileRows + half * 64;   // first kv row of this wave's half
+    // a causal half entirely above this wave's rows is all masked; a wave past the end of the sequence idles
+    if (!wave_active || (!pre && n0 > q0 + 31)) return;
+    // ---- S^T = K Q^T: two 32-row kv blocks, alternating so that consecutive MFMAs never share an accumulator ----
+    Frag16 kf[2][8];
+    static_for<0, 8>([&](auto ks) {
+      constexpr int KS = decltype(ks)::value;
+      kf[0][KS].u = lds_read16<SO>(kaddr[KS]);
+      kf[1][KS].u = lds_read16<SO + 32 * kRowBytes>(kaddr[KS]);
+    });
+    f32x16 s_acc[2];
+    static_for<0, 8>([&](auto ks) {
+      constexpr int KS = decltype(ks)::value;
+      wait_lgkm<14 - 2 * KS>();
+      s_acc[0] = Mfma<T>::mma(as_frag<T>(kf[0][KS]), as_frag<T>(qf[KS]), KS == 0 ? zero16 : s_acc[0]);
+      s_acc[1] = Mfma<T>::mma(as_frag<T>(kf[1][KS]), as_frag<T>(qf[KS]), KS == 0 ? zero16 : s_acc[1]);
+    });
+    // first V fragments (kv block 0, slot 0) in flight during the softmax
+    Frag16 vf[2][4];
+    static_for<0, 4>([&](auto t) {
+      constexpr int TT = decltype(t)::value;
+      vf[0][TT].s[0] = lds_read_tr8<SO>(vaddr[TT]);
+      vf[0][TT].s[1] = lds_read_tr8<SO + 8 * kRowBytes>(vaddr[TT]);
+    });
+    // ---- mask (boundary tiles only; wave-uniform test) ----
+    const bool need_mask = (n0 + 64 > n_end) || (!pre && n0 + 63 > q0);
+    if (need_mask) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = n0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          const bool ok = n < n_end && (pre || n <= q_local);
+          s_acc[kt][r] = ok ? s_acc[kt][r] : -INFINITY;
+        }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s_acc[kt][r]);
+    {   // the other 16 kv slots of this query row live in lane ^ 32: v_permlane32_swap, no LDS round trip
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+      mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
+    mx *= qk_scale;   // qk_scale > 0; -inf stays -inf
+    // ---- online softmax (base 2) ----
+    const float m_new = fmaxf(m_run, mx);
+    if (__any(m_new > m_run)) {
+      const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o_acc[t][r] *= alpha;
+      m_run = m_new;
+    }
+    const float m_use = (m_run == -INFINITY) ? 0.f : m_run;   // everything masked so far
+    float psum = 0.f;
+    Frag16 pf[2][2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float p0 = __builtin_amdgcn_exp2f(fmaf(s_acc[kt][r], qk_scale, -m_use));       // exp2(-inf) = 0
+        const float p1 = __builtin_amdgcn_exp2f(fmaf(s_acc[kt][r + 1], qk_scale, -m_use));
+        psum += p0 + p1;
+        pf[kt][r >> 3].w[(r & 7) >> 1] = pack2<T>(p0, p1);
+      }
+    }
+    l_run += psum;
+    // ---- O^T += V^T P^T: four (kv block, slot) groups of four dv tiles; the next group's reads fly during the MFMAs ----
+    static_for<0, 4>([&](auto g) {
+      constexpr int GG = decltype(g)::value;
+      constexpr int KT = GG >> 1, S2 = GG & 1, CUR = GG & 1, NXT = CUR ^ 1;
+      if constexpr (GG < 3) {
+        constexpr int NO = SO + (((GG + 1) >> 1) * 32 + ((GG + 1) & 1) * 16) * kRowBytes;
+        static_for<0, 4>([&](auto t) {
+          constexpr int TT = decltype(t)::value;
+          vf[NXT][TT].s[0] = lds_read_tr8<NO>(vaddr[TT]);
+          vf[NXT][TT].s[1] = lds_read_tr8<NO + 8 * kRowBytes>(vaddr[TT]);
+        });
+        wait_lgkm<8>();
+      } else {
+        wait_lgkm<0>();
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) o_acc[t] = Mfma<T>::mma(as_frag<T>(vf[CUR][t]), as_frag<T>(pf[KT][S2]), o_acc[t]);
+    });
+  };
+
+  // ---- pipeline: [own DMA of tile it landed] [barrier] [DMA of tile it+1 into the other stage] [compute tile it] ----
+  load_idx(0);
+  if (n_tiles > 0) issue_dma(0, 0);
+  load_idx(1);
+  for (int it = 0; it < n_tiles; it += 2) {
+    wait_vm0_and(idx);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (it + 1 < n_tiles) issue_dma(it + 1, 1);
+    load_idx(it + 2);
+    compute(std::integral_constant<int, 0>{}, it, it < n_pre, it < n_pre ? pre_len : ext_len);
+    if (it + 1 >= n_tiles) break;
+    wait_vm0_and(idx);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (it + 2 < n_tiles) issue_dma(it + 2, 0);
+    load_idx(it + 3);
+    compute(std::integral_constant<int, 1>{}, it + 1, it + 1 < n_pre, it + 1 < n_pre ? pre_len : ext_len);
+  }
+
+  // ---- merge the two KV halves: the waves of half 1 hand (O, m, l) to their partners through LDS ----
+  __syncthreads();   // every fragment read of the last tile is done
+  float* mbuf = reinterpret_cast<float*>(skv_smem + sub * kMergeStride);
+  if (half == 1) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mbuf[(t * 16 + r) * 64 + lane] = o_acc[t][r];
+    mbuf[64 * 64 + lane] = m_run;
+    mbuf[65 * 64 + lane] = l_run;
+  }
+  __syncthreads();
+  if (half == 1 || !wave_active) return;
+  const float m1 = mbuf[64 * 64 + lane], l1 = mbuf[65 * 64 + lane];
+  const float m_all = fmaxf(m_run, m1);
+  const float a0 = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_all);
+  const float a1 = (m1 == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m1 - m_all);
+  const float l_lane = l_run * a0 + l1 * a1;
+  const float l_tot = l_lane + __shfl_xor(l_lane, 32, 64);
+  const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+  const float s0 = a0 * inv, s1 = a1 * inv;
+  if (q_valid) {
+    T* orow = out + (int64_t)(q_start + q_local) * o_stride + (int64_t)hq * kD;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          o[j] = o_acc[t][r4 * 4 + j] * s0 + mbuf[(t * 16 + r4 * 4 + j) * 64 + lane] * s1;
+        uint2 w;
+        w.x = pack2<T>(o[0], o[1]);
+        w.y = pack2<T>(o[2], o[3]);
+        *reinterpret_cast<uint2*>(orow + t * 32 + 8 * r4 + 4 * hi) = w;
+      }
+    }
+  }
+}
+
+// Returns 0 when launched, 1 when the shape is not covered (the caller falls back to extend_attention.hip).
+template <typename T>
+int launch_extend_shared_kv(void* out, const void* q, const void* k, const void* v, const void* k_buf, const void* v_buf,
+                            const int32_t* qo_indptr, const int32_t* kv_indptr, const int32_t* kv_indices, int64_t batch,
+                            int Hq, int Hkv, int64_t q_stride, int64_t k_stride, int64_t v_stride, int64_t o_stride,
+                            int64_t kbuf_stride, int64_t vbuf_stride, int max_len_extend, float sm_scale, hipStream_t st) {
+  const int group = Hq / Hkv;
+  const int G = group % 4 == 0 ? 4 : (group % 2 == 0 ? 2 : 1);
+  const int TB = 4 / G;
+  const unsigned gx = (unsigned)(Hkv * (group / G));
+  const unsigned gy = (unsigned)((max_len_extend + TB * 32 - 1) / (TB * 32));
+  if (gy > 65535u || gx > 65535u) return 1;
+  dim3 grid(gx, gy, (unsigned)batch);
+#define SKV(GV)                                                                                                    \
+  do {                                                                                                             \
+    static bool attr_set = false;                                                                                  \
+    if (!attr_set) {                                                                                               \
+      (void)hipFuncSetAttribute((const void*)extend_attn_shared_kv_kernel<T, GV>,                                  \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, skv::kLds);                            \
+      attr_set = true;                                                                                             \
+    }                                                                                                              \
+    hipLaunchKernelGGL((extend_attn_shared_kv_kernel<T, GV>), grid, dim3(512), skv::kLds, st, (T*)out, (const T*)q, \
+                       (const T*)k, (const T*)v, (const T*)k_buf, (const T*)v_buf, qo_indptr, kv_indptr, kv_indices, \
+                       group, q_stride, k_stride, v_stride, o_stride, kbuf_stride, vbuf_stride, sm_scale);          \
+  } while (0)
+  if (G == 4) SKV(4);
+  else if (G == 2) SKV(2);
+  else SKV(1);
+#undef SKV
+  return 0;
+}
+
+template int launch_extend_shared_kv<bf16_t>(void*, const void*, const void*, const void*, const void*, const void*,
+                                             const int32_t*, const int32_t*, const int32_t*, int64_t, int, int, int64_t,
+                                             int64_t, int64_t, int64_t, int64_t, int64_t, int, float, hipStream_t);
+template int launch_extend_shared_kv<f16_t>(void*, const void*, const void*, const void*, const void*, const void*,
+                                            const int32_t*, const int32_t*, const int32_t*, int64_t, int, int, int64_t,
+                                            int64_t, int64_t, int64_t, int64_t, int64_t, int, float, hipStream_t);
+
+}  // namespace semipd

@@ -344,6 +344,51 @@ def test_extend_attention(ops, device, pre, ext, Hq, Hkv, Dk, Dv, cap, dtype):
     _close(o, want, dtype, rtol=2e-2, atol=4e-3 if dtype == torch.float16 else 1.5e-2)
 
 
+# Head size 128 / 128 without a cap runs the shared-KV kernel (extend_attention_shared_kv.hip): one workgroup = G q heads
+# of a kv head x 4 / G blocks of 32 tokens x 2 halves of every 128-row KV tile.  Cases around every seam of it: group
+# sizes that give G = 4 / 2 / 1 (and two workgroups per kv head), tile and half boundaries of the prefix and of the new
+# tokens, token blocks and whole tiles past the end of short sequences next to a long one, one-token requests.
+SHARED_KV_CASES = [
+    # prefix lens, extend lens, Hq, Hkv
+    ([0], [1], 4, 1),
+    ([0, 0, 0], [31, 32, 33], 8, 2),
+    ([0], [64], 8, 2), ([0], [65], 8, 2), ([0], [127], 4, 1), ([0], [128], 4, 1), ([0], [129], 4, 1),
+    ([63, 64, 65], [3, 2, 1], 4, 1),
+    ([127, 128, 129, 1], [40, 1, 70, 200], 8, 2),
+    ([300, 0, 17], [257, 5, 130], 16, 2),          # group 8: two workgroups per kv head
+    ([70, 0], [100, 300], 6, 3),                   # group 2: two token blocks per workgroup
+    ([70, 0, 130], [100, 300, 2], 3, 3),           # group 1 (MHA): four token blocks per workgroup
+    ([5], [97], 6, 2),                             # group 3: G = 1
+    ([513], [1000], 32, 8),                        # Llama-3-8B heads, a 1000-token prompt behind a 513-token prefix
+]
+
+
+@pytest.mark.parametrize("pre,ext,Hq,Hkv", SHARED_KV_CASES)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_extend_attention_shared_kv(ops, device, pre, ext, Hq, Hkv, dtype):
+    D = 128
+    B = len(pre)
+    k_buf, v_buf, kv_indptr, kv_indices = _paged(B, pre, Hkv, D, D, dtype, seed=Hq + sum(ext))
+    T = sum(ext)
+    qo_indptr = torch.zeros(B + 1, dtype=torch.int32)
+    qo_indptr[1:] = torch.cumsum(torch.tensor(ext), 0)
+    torch.manual_seed(T + Hq)
+    q = torch.randn(T, Hq, D).to(dtype)
+    k = torch.randn(T, Hkv, D).to(dtype)
+    v = torch.randn(T, Hkv, D).to(dtype)
+    # one key that dominates its row (a late rescale of the running maximum) and rows of V that would poison a sum if a
+    # masked or out-of-range row leaked in with a non-zero weight
+    k[T - 1] = q[T - 1, ::Hq // Hkv] * 3
+    v[T // 2] = 50.0
+    o = torch.full((T, Hq, D), float("nan"), dtype=dtype, device=device)
+    sm_scale = 1.0 / (D ** 0.5)
+    args = (q.to(device), k.to(device), v.to(device), o, k_buf.to(device), v_buf.to(device), qo_indptr.to(device),
+            kv_indptr.to(device), kv_indices.to(device), None, None, max(ext), sm_scale, 0.0)
+    ops.extend_attention_fwd(*args)
+    want = O.extend_attention(q, k, v, k_buf, v_buf, qo_indptr, kv_indptr, kv_indices, sm_scale, 0.0)
+    _close(o, want, dtype, rtol=2e-2, atol=4e-3 if dtype == torch.float16 else 1.5e-2)
+
+
 @pytest.mark.parametrize("fixture", ["extend_attention", "extend_attention_8c"])
 def test_extend_attention_golden(ops, device, fixture):
     g = load_golden(fixture)
