@@ -10,8 +10,10 @@
 //     0-63 and those of half 1 rows 64-127, and the two partial (m, l, O) are merged through LDS at the end --
 //     the walk of one row block is half as long, and a 1024-token Llama-3 request is 256 workgroups x 8 waves.
 //   K / V tiles (128 rows x 256 B each) arrive by LDS-DMA (buffer_load ... lds for the new tokens, global_load ... lds
-//     through kv_indices for the paged prefix) into a two-deep ring: no staging registers, no ds_write, ONE s_barrier
-//     per tile.  The DMA image is lane-linear (row-major, 16-B chunks); bank conflicts are removed on the SOURCE
+//     through kv_indices for the paged prefix) into two-deep rings: no staging registers, no ds_write.
+//   Each tile is two blocks per wave -- a MATRIX block (O^T += V^T P^T of the previous tile, then S^T = K Q^T of this
+//     one: 32 MFMAs) and a VECTOR block (the softmax) -- separated by s_barrier, and the waves of half 1 run one block
+//     behind those of half 0: the two waves that share a SIMD are always in opposite blocks (ping-pong).  The DMA image is lane-linear (row-major, 16-B chunks); bank conflicts are removed on the SOURCE
 //     side: lane (row, pos) fetches chunk pos ^ (row & 15) of a K row (ds_read_b128 fragments: 16 rows of a lane
 //     group land in 16 different chunks) and chunk pos ^ ((row & 3) << 2) of a V row (ds_read_b64_tr_b16: the four
 //     rows of a lane group land in four different 64-B groups).
@@ -136,7 +138,7 @@ extend_attn_shared_kv_kernel(T* __restrict__ out, const T* __restrict__ q_ext, c
   const int n_ext = (ext_end + kTileRows - 1) / kTileRows;
   const int n_tiles = n_pre + n_ext;
 
-  // DMA duty of this wave: rows wave*16 + j*4 + (lane >> 4), j = 0..3, of the K tile and of the V tile; pos = lane & 15
+  // DMA duty of this wave: rows wave*16 + j*4 + (lane >> 4), j = 0..3, of a K tile or of a V tile; pos = lane & 15
   const int drow = wave * 16 + (lane >> 4), dpos = lane & 15;
   const T* k_pre = k_buf + (int64_t)hk * kD;
   const T* v_pre = v_buf + (int64_t)hk * kD;
@@ -147,44 +149,69 @@ extend_attn_shared_kv_kernel(T* __restrict__ out, const T* __restrict__ q_ext, c
   const __amdgpu_buffer_rsrc_t rsrc_v = __builtin_amdgcn_make_buffer_rsrc(
       (void*)ve_head, 0, (int)(((int64_t)(ext_end - 1) * v_stride + kD) * 2), 0x00020000);
   const int32_t* idx_base = kv_indices + kv_start;
-  int32_t idx[4] = {0, 0, 0, 0};
-  auto load_idx = [=, &idx](int it) __attribute__((always_inline)) {
+  // pool slots of this lane's rows: idx_k for the K tile about to be fetched, idx_v (the previous idx_k) for the V tile
+  // that follows one tile behind; loaded one step ahead so that the index -> address chain is never waited for
+  int32_t idx_k[4] = {0, 0, 0, 0}, idx_v[4] = {0, 0, 0, 0};
+  auto load_idx = [=, &idx_k](int it) __attribute__((always_inline)) {
     if (it < n_pre) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) idx[j] = idx_base[min(it * kTileRows + drow + j * 4, pre_len - 1)];
+      for (int j = 0; j < 4; ++j) idx_k[j] = idx_base[min(it * kTileRows + drow + j * 4, pre_len - 1)];
     }
   };
-  auto issue_dma = [=, &idx](int it, int stage) __attribute__((always_inline)) {
-    const uint32_t kdst = lds0 + stage * kStage + wave * 16 * kRowBytes;
-    const uint32_t vdst = kdst + kVBase;
+  // whole tiles of new tokens: per-lane byte offsets computed once, the tile offset is the scalar operand of the buffer load
+  int kvo[4], vvo[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = drow + j * 4;
+    kvo[j] = r * (int)k_stride * 2 + (dpos ^ (r & 15)) * 16;          // the launcher checked ext rows * stride < 2^31 bytes
+    vvo[j] = r * (int)v_stride * 2 + (dpos ^ ((r & 3) << 2)) * 16;
+  }
+  // one tile (K: IS_V = false, swizzle row & 15; V: swizzle (row & 3) << 2) into stage (it & 1)
+  auto issue_tile = [=](auto is_v, int it, const int32_t (&idx)[4]) __attribute__((always_inline)) {
+    constexpr bool IS_V = decltype(is_v)::value;
+    const uint32_t dst = lds0 + (IS_V ? kVBase : 0) + (it & 1) * kStage + wave * 16 * kRowBytes;
+    const int n0 = (it - n_pre) * kTileRows;
+    if (it >= n_pre && n0 + kTileRows <= ext_end) {
+      // (readfirstlane: the compiler cannot prove the tile offset uniform and would wrap every load in a waterfall loop)
+      const int tile_off = __builtin_amdgcn_readfirstlane(n0 * (int)(IS_V ? v_stride : k_stride) * 2);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(IS_V ? rsrc_v : rsrc_k,
+                                                 (__attribute__((address_space(3))) void*)(uintptr_t)(dst + j * 4 * kRowBytes),
+                                                 16, IS_V ? vvo[j] : kvo[j], tile_off, 0, 0);
+      return;
+    }
+    // the paged prefix and the last, partial tile of new tokens: addresses from scratch each time (an opaque copy of the
+    // lane id keeps the compiler from hoisting a dozen 64-bit per-lane constants out of the loop and spilling them)
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int rw = wave * 16 + (ln >> 4), ps = ln & 15;
     if (it < n_pre) {
+      const T* base = IS_V ? v_pre : k_pre;
+      const int64_t stride = IS_V ? vbuf_stride : kbuf_stride;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int r = drow + j * 4;
-        const T* kp = k_pre + (int64_t)idx[j] * kbuf_stride + ((dpos ^ (r & 15)) * 8);
-        const T* vp = v_pre + (int64_t)idx[j] * vbuf_stride + ((dpos ^ ((r & 3) << 2)) * 8);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)kp,
-                                         (__attribute__((address_space(3))) void*)(uintptr_t)(kdst + j * 4 * kRowBytes), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)vp,
-                                         (__attribute__((address_space(3))) void*)(uintptr_t)(vdst + j * 4 * kRowBytes), 16, 0, 0);
+        const int r = rw + j * 4;
+        const int sw = IS_V ? ((r & 3) << 2) : (r & 15);
+        const T* p = base + ((int64_t)idx[j] * stride + ((ps ^ sw) * 8));
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                                         (__attribute__((address_space(3))) void*)(uintptr_t)(dst + j * 4 * kRowBytes), 16, 0, 0);
       }
     } else {
-      const int n0 = (it - n_pre) * kTileRows;
+      const int stride_b = (int)(IS_V ? v_stride : k_stride) * 2;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int r = drow + j * 4;
-        const int n = min(n0 + r, ext_end - 1);
-        const int ko = (int)(((int64_t)n * k_stride + (dpos ^ (r & 15)) * 8) * 2);
-        const int vo = (int)(((int64_t)n * v_stride + (dpos ^ ((r & 3) << 2)) * 8) * 2);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_k, (__attribute__((address_space(3))) void*)(uintptr_t)(kdst + j * 4 * kRowBytes),
-                                                 16, ko, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_v, (__attribute__((address_space(3))) void*)(uintptr_t)(vdst + j * 4 * kRowBytes),
-                                                 16, vo, 0, 0, 0);
+        const int r = rw + j * 4;
+        const int sw = IS_V ? ((r & 3) << 2) : (r & 15);
+        const int n = min(n0 + r, ext_end - 1);      // rows past the end: the last valid row (finite, masked)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(IS_V ? rsrc_v : rsrc_k,
+                                                 (__attribute__((address_space(3))) void*)(uintptr_t)(dst + j * 4 * kRowBytes),
+                                                 16, n * stride_b + (ps ^ sw) * 16, 0, 0, 0);
       }
     }
   };
 
-  // ---- fragment addresses (stage / kv-block / k-step offsets are immediates) ----
+  // ---- fragment addresses (stage / kv-block offsets are immediates) ----
   // K, A operand of S^T: lane (col, hi) reads row half*64 + kt*32 + col, chunk (ks*2 + hi) ^ (col & 15)
   uint32_t kaddr[8];
 #pragma unroll
@@ -201,59 +228,48 @@ extend_attn_shared_kv_kernel(T* __restrict__ out, const T* __restrict__ q_ext, c
 
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-  // (tile kind and bounds come in as arguments: a select between two captured scalars becomes a load through a
-  // selected closure address, which pins the closure in scratch and puts vmcnt waits into the tile loop)
-  auto compute = [=, &o_acc, &m_run, &l_run](auto stage_c, int it, bool pre, int n_end) __attribute__((always_inline)) {
-    constexpr int SO = decltype(stage_c)::value * kStage;
-    const int n0 = (pre ? it : it - n_pre) * kTileRows + half * 64;   // first kv row of this wave's half
-    // a causal half entirely above this wave's rows is all masked; a wave past the end of the sequence idles
-    if (!wave_active || (!pre && n0 > q0 + 31)) return;
-    // ---- S^T = K Q^T: two 32-row kv blocks, alternating so that consecutive MFMAs never share an accumulator ----
-    Frag16 kf[2][8];
-    static_for<0, 8>([&](auto ks) {
-      constexpr int KS = decltype(ks)::value;
-      kf[0][KS].u = lds_read16<SO>(kaddr[KS]);
-      kf[1][KS].u = lds_read16<SO + 32 * kRowBytes>(kaddr[KS]);
-    });
-    f32x16 s_acc[2];
-    static_for<0, 8>([&](auto ks) {
-      constexpr int KS = decltype(ks)::value;
-      wait_lgkm<14 - 2 * KS>();
-      s_acc[0] = Mfma<T>::mma(as_frag<T>(kf[0][KS]), as_frag<T>(qf[KS]), KS == 0 ? zero16 : s_acc[0]);
-      s_acc[1] = Mfma<T>::mma(as_frag<T>(kf[1][KS]), as_frag<T>(qf[KS]), KS == 0 ? zero16 : s_acc[1]);
-    });
-    // first V fragments (kv block 0, slot 0) in flight during the softmax
-    Frag16 vf[2][4];
-    static_for<0, 4>([&](auto t) {
-      constexpr int TT = decltype(t)::value;
-      vf[0][TT].s[0] = lds_read_tr8<SO>(vaddr[TT]);
-      vf[0][TT].s[1] = lds_read_tr8<SO + 8 * kRowBytes>(vaddr[TT]);
-    });
-    // ---- mask (boundary tiles only; wave-uniform test) ----
+  // ---- the tile loop, software-pipelined inside the wave ----
+  // In program order QK^T -> softmax -> PV of one tile is a dependent chain: the wave's 32 MFMAs (1024 cycles of its
+  // SIMD's matrix pipe) and its ~200 VALU instructions (~1000 issue cycles) add up, and with every wave of the
+  // workgroup in the same stage behind the tile barrier the partner wave on the SIMD does not fill the gaps either
+  // (PMC of the first version: 4900 cycles per tile and SIMD; profiles/r02_pmc_extend_shared_kv.txt).  Here the chain
+  // is cut across tiles: while the matrix pipe computes S^T of tile i + 1, the same wave turns S^T of tile i into P^T
+  // (exp2 / sum / pack, in slices between the MFMAs), and while it accumulates O^T += V^T P^T of tile i the row maxima
+  // of tile i + 1 are reduced.  K runs one tile ahead of V in the DMA rings.
+  //   A(i): mask, row maxima of S^T(i), decide whether the running maximum moves (and then rescale O, l)
+  //   B(i): P^T(i) = exp2(S^T(i) * scale - m), l += row sums; the packed words land in the first 16 registers of S^T(i)
+  f32x16 s_a[2], s_b[2];
+  float mx_part = -INFINITY;
+
+  // masking of one S^T tile (boundary tiles only; wave-uniform test): kv row of accumulator slot (kt, r) =
+  // n0 + kt*32 + (r & 3) + 8*(r >> 2) + 4*hi, visible when < n_end and, among the new tokens, <= this lane's query row
+  auto mask_tile = [=](f32x16 (&sc)[2], bool pre, int n0, int n_end) __attribute__((always_inline)) {
     const bool need_mask = (n0 + 64 > n_end) || (!pre && n0 + 63 > q0);
     if (need_mask) {
+      const int thr = (pre ? n_end - 1 : min(q_local, n_end - 1)) - 4 * hi;
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int n = n0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          const bool ok = n < n_end && (pre || n <= q_local);
-          s_acc[kt][r] = ok ? s_acc[kt][r] : -INFINITY;
-        }
+        for (int r = 0; r < 16; ++r)
+          sc[kt][r] = (n0 + kt * 32 + (r & 3) + 8 * (r >> 2)) <= thr ? sc[kt][r] : -INFINITY;
     }
-    float mx = -INFINITY;
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s_acc[kt][r]);
-    {   // the other 16 kv slots of this query row live in lane ^ 32: v_permlane32_swap, no LDS round trip
+  };
+  // the end of A: combine the two 16-slot halves of a row (lane ^ 32), move the running maximum if it has to.
+  // The maximum only moves when some row's grew by more than 2^kDeferLog2 (or was -inf): until then p = 2^(s - m) may
+  // exceed 1 by at most that factor -- p is a floating-point type, its relative precision is unchanged, l and O carry
+  // the same factor and it cancels in O / l.  Saves the 64-register rescale of O^T on almost every tile (random data:
+  // some row of 32 finds a new maximum in 40 % of the tiles even 64 tiles in).  O, l and m move together, after the
+  // previous tile's P^T V is complete and before this tile's P is formed.
+  auto finish_max = [=, &o_acc, &m_run, &l_run](float mx, bool live) __attribute__((always_inline)) {
+    constexpr float kDeferLog2 = 6.f;
+    {   // v_permlane32_swap, no LDS round trip
       const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
       mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
     }
     mx *= qk_scale;   // qk_scale > 0; -inf stays -inf
-    // ---- online softmax (base 2) ----
-    const float m_new = fmaxf(m_run, mx);
-    if (__any(m_new > m_run)) {
+    const bool grow = live && ((m_run == -INFINITY) ? (mx > -INFINITY) : (mx > m_run + kDeferLog2));
+    if (__any(grow)) {
+      const float m_new = fmaxf(m_run, mx);
       const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
       l_run *= alpha;
 #pragma unroll
@@ -262,58 +278,141 @@ extend_attn_shared_kv_kernel(T* __restrict__ out, const T* __restrict__ q_ext, c
         for (int r = 0; r < 16; ++r) o_acc[t][r] *= alpha;
       m_run = m_new;
     }
-    const float m_use = (m_run == -INFINITY) ? 0.f : m_run;   // everything masked so far
+  };
+  // one slice of B: four scores of sc -> two packed words of P^T, in place
+  auto exp_slice = [=](auto ks_c, f32x16 (&sc)[2], float m_use, float& psum) __attribute__((always_inline)) {
+    constexpr int KS = decltype(ks_c)::value, KT = KS >> 2, R0 = (KS & 3) * 4;
+    const float p0 = __builtin_amdgcn_exp2f(fmaf(sc[KT][R0], qk_scale, -m_use));       // exp2(-inf) = 0
+    const float p1 = __builtin_amdgcn_exp2f(fmaf(sc[KT][R0 + 1], qk_scale, -m_use));
+    const float p2 = __builtin_amdgcn_exp2f(fmaf(sc[KT][R0 + 2], qk_scale, -m_use));
+    const float p3 = __builtin_amdgcn_exp2f(fmaf(sc[KT][R0 + 3], qk_scale, -m_use));
+    psum += (p0 + p1) + (p2 + p3);
+    uint32_t w0 = pack2<T>(p0, p1), w1 = pack2<T>(p2, p3);
+    // pinned HERE: the optimiser otherwise sinks all 32 exponentials to their use, behind the 16 MFMAs they are to hide in
+    asm volatile("" : "+v"(w0), "+v"(w1), "+v"(psum));
+    sc[0][KT * 8 + (R0 >> 1)] = __uint_as_float(w0);
+    sc[0][KT * 8 + (R0 >> 1) + 1] = __uint_as_float(w1);
+  };
+  // S^T(next) = K Q^T from K stage KST, with B(cur) in slices between the MFMAs (WITH_B) or alone (the first tile)
+  auto qk_phase = [=, &l_run](auto kst_c, auto with_b, f32x16 (&s_nxt)[2], f32x16 (&s_cur)[2], float m_use) __attribute__((always_inline)) {
+    constexpr int KO = decltype(kst_c)::value * kStage;
+    constexpr bool WITH_B = decltype(with_b)::value;
+    Frag16 kf[2][2];   // [buffer][kv block]: the next k-step's fragments are read while this one multiplies
     float psum = 0.f;
-    Frag16 pf[2][2];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        const float p0 = __builtin_amdgcn_exp2f(fmaf(s_acc[kt][r], qk_scale, -m_use));       // exp2(-inf) = 0
-        const float p1 = __builtin_amdgcn_exp2f(fmaf(s_acc[kt][r + 1], qk_scale, -m_use));
-        psum += p0 + p1;
-        pf[kt][r >> 3].w[(r & 7) >> 1] = pack2<T>(p0, p1);
-      }
-    }
-    l_run += psum;
-    // ---- O^T += V^T P^T: four (kv block, slot) groups of four dv tiles; the next group's reads fly during the MFMAs ----
-    static_for<0, 4>([&](auto g) {
-      constexpr int GG = decltype(g)::value;
-      constexpr int KT = GG >> 1, S2 = GG & 1, CUR = GG & 1, NXT = CUR ^ 1;
-      if constexpr (GG < 3) {
-        constexpr int NO = SO + (((GG + 1) >> 1) * 32 + ((GG + 1) & 1) * 16) * kRowBytes;
-        static_for<0, 4>([&](auto t) {
-          constexpr int TT = decltype(t)::value;
-          vf[NXT][TT].s[0] = lds_read_tr8<NO>(vaddr[TT]);
-          vf[NXT][TT].s[1] = lds_read_tr8<NO + 8 * kRowBytes>(vaddr[TT]);
-        });
-        wait_lgkm<8>();
+    kf[0][0].u = lds_read16<KO>(kaddr[0]);
+    kf[0][1].u = lds_read16<KO + 32 * kRowBytes>(kaddr[0]);
+    static_for<0, 8>([&](auto ks) {
+      constexpr int KS = decltype(ks)::value, CUR = KS & 1, NXT = CUR ^ 1;
+      if constexpr (KS < 7) {
+        kf[NXT][0].u = lds_read16<KO>(kaddr[KS + 1]);
+        kf[NXT][1].u = lds_read16<KO + 32 * kRowBytes>(kaddr[KS + 1]);
+        wait_lgkm<2>();
       } else {
         wait_lgkm<0>();
       }
-#pragma unroll
-      for (int t = 0; t < 4; ++t) o_acc[t] = Mfma<T>::mma(as_frag<T>(vf[CUR][t]), as_frag<T>(pf[KT][S2]), o_acc[t]);
+      s_nxt[0] = Mfma<T>::mma(as_frag<T>(kf[CUR][0]), as_frag<T>(qf[KS]), KS == 0 ? zero16 : s_nxt[0]);
+      s_nxt[1] = Mfma<T>::mma(as_frag<T>(kf[CUR][1]), as_frag<T>(qf[KS]), KS == 0 ? zero16 : s_nxt[1]);
+      if constexpr (WITH_B) exp_slice(ks, s_cur, m_use, psum);
+      __builtin_amdgcn_sched_barrier(0);
     });
+    if constexpr (WITH_B) l_run += psum;
+  };
+  // O^T += V^T P^T from V stage VST (P^T = the first 16 registers of s_cur), the row maxima of s_nxt in slices between
+  // the MFMAs; returns this lane's partial maximum
+  auto pv_phase = [=, &o_acc](auto vst_c, const f32x16 (&s_cur)[2], const f32x16 (&s_nxt)[2]) __attribute__((always_inline)) -> float {
+    constexpr int VO = decltype(vst_c)::value * kStage;
+    Frag16 pfr[2][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int w = 0; w < 4; ++w) pfr[i >> 1][i & 1].w[w] = __float_as_uint(s_cur[0][i * 4 + w]);
+    // 8 steps = (kv block, slot) x (dv tiles 0-1 | 2-3): two MFMAs each, the fragments of the next step in flight
+    Frag16 vf[2][2];
+    float mxa = -INFINITY, mxb = -INFINITY;
+    vf[0][0].s[0] = lds_read_tr8<VO>(vaddr[0]);
+    vf[0][0].s[1] = lds_read_tr8<VO + 8 * kRowBytes>(vaddr[0]);
+    vf[0][1].s[0] = lds_read_tr8<VO>(vaddr[1]);
+    vf[0][1].s[1] = lds_read_tr8<VO + 8 * kRowBytes>(vaddr[1]);
+    static_for<0, 8>([&](auto g) {
+      constexpr int GG = decltype(g)::value;
+      constexpr int GRP = GG >> 1, T0 = (GG & 1) * 2, CUR = GG & 1, NXT = CUR ^ 1;
+      constexpr int KT = GRP >> 1, S2 = GRP & 1;
+      if constexpr (GG < 7) {
+        constexpr int NG = (GG + 1) >> 1, NT0 = ((GG + 1) & 1) * 2;
+        constexpr int NO = VO + ((NG >> 1) * 32 + (NG & 1) * 16) * kRowBytes;
+        vf[NXT][0].s[0] = lds_read_tr8<NO>(vaddr[NT0]);
+        vf[NXT][0].s[1] = lds_read_tr8<NO + 8 * kRowBytes>(vaddr[NT0]);
+        vf[NXT][1].s[0] = lds_read_tr8<NO>(vaddr[NT0 + 1]);
+        vf[NXT][1].s[1] = lds_read_tr8<NO + 8 * kRowBytes>(vaddr[NT0 + 1]);
+        wait_lgkm<4>();
+      } else {
+        wait_lgkm<0>();
+      }
+      o_acc[T0] = Mfma<T>::mma(as_frag<T>(vf[CUR][0]), as_frag<T>(pfr[KT][S2]), o_acc[T0]);
+      o_acc[T0 + 1] = Mfma<T>::mma(as_frag<T>(vf[CUR][1]), as_frag<T>(pfr[KT][S2]), o_acc[T0 + 1]);
+      constexpr int MK = GG >> 2, MR = (GG & 3) * 4;
+      mxa = fmaxf(mxa, fmaxf(s_nxt[MK][MR], s_nxt[MK][MR + 1]));
+      mxb = fmaxf(mxb, fmaxf(s_nxt[MK][MR + 2], s_nxt[MK][MR + 3]));
+      asm volatile("" : "+v"(mxa), "+v"(mxb));
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    return fmaxf(mxa, mxb);
+  };
+  // tile geometry of this wave's half (scalars)
+  auto tile_n0 = [=](int it) __attribute__((always_inline)) { return (it < n_pre ? it : it - n_pre) * kTileRows + half * 64; };
+
+  // one iteration: [K(it+1), V(it) landed] barrier [DMA of K(it+2), V(it+1)] QK(it+1) || B(it), mask, PV(it) || max(it+1), A(it+1)
+  auto iteration = [=, &o_acc, &m_run, &l_run, &idx_k, &idx_v](auto par_c, int it, f32x16 (&s_cur)[2], f32x16 (&s_nxt)[2]) __attribute__((always_inline)) {
+    constexpr int PAR = decltype(par_c)::value;   // it & 1
+    wait_vm0_and(idx_k);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (it + 2 < n_tiles) issue_tile(std::false_type{}, it + 2, idx_k);   // into K stage (it & 1): K(it) was read last iteration
+    if (it + 1 < n_tiles) issue_tile(std::true_type{}, it + 1, idx_v);    // into V stage ((it + 1) & 1): V(it - 1) likewise
+#pragma unroll
+    for (int j = 0; j < 4; ++j) idx_v[j] = idx_k[j];
+    load_idx(it + 3);
+    const float m_use = (m_run == -INFINITY) ? 0.f : m_run;   // everything masked so far
+    qk_phase(std::integral_constant<int, PAR ^ 1>{}, std::true_type{}, s_nxt, s_cur, m_use);
+    const bool live = it + 1 < n_tiles;   // past the last tile S^T(it + 1) is computed from stale LDS and dropped
+    if (live) {
+      const bool pre = it + 1 < n_pre;
+      mask_tile(s_nxt, pre, tile_n0(it + 1), pre ? pre_len : ext_len);
+    }
+    const float mx = pv_phase(std::integral_constant<int, PAR>{}, s_cur, s_nxt);
+    finish_max(mx, live);
   };
 
-  // ---- pipeline: [own DMA of tile it landed] [barrier] [DMA of tile it+1 into the other stage] [compute tile it] ----
+  // prologue: K(0); then K(1) and V(0) behind the first barrier; S^T(0) and A(0) without anything to overlap with
   load_idx(0);
-  if (n_tiles > 0) issue_dma(0, 0);
+  issue_tile(std::false_type{}, 0, idx_k);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) idx_v[j] = idx_k[j];
   load_idx(1);
+  wait_vm0_and(idx_k);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  if (1 < n_tiles) issue_tile(std::false_type{}, 1, idx_k);
+  issue_tile(std::true_type{}, 0, idx_v);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) idx_v[j] = idx_k[j];
+  load_idx(2);
+  qk_phase(std::integral_constant<int, 0>{}, std::false_type{}, s_a, s_b, 0.f);
+  {
+    const bool pre = 0 < n_pre;
+    mask_tile(s_a, pre, tile_n0(0), pre ? pre_len : ext_len);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s_a[kt][r]);
+    finish_max(mx, true);
+  }
+  (void)mx_part;
   for (int it = 0; it < n_tiles; it += 2) {
-    wait_vm0_and(idx);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    if (it + 1 < n_tiles) issue_dma(it + 1, 1);
-    load_idx(it + 2);
-    compute(std::integral_constant<int, 0>{}, it, it < n_pre, it < n_pre ? pre_len : ext_len);
+    iteration(std::integral_constant<int, 0>{}, it, s_a, s_b);
     if (it + 1 >= n_tiles) break;
-    wait_vm0_and(idx);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    if (it + 2 < n_tiles) issue_dma(it + 2, 0);
-    load_idx(it + 3);
-    compute(std::integral_constant<int, 1>{}, it + 1, it + 1 < n_pre, it + 1 < n_pre ? pre_len : ext_len);
+    iteration(std::integral_constant<int, 1>{}, it + 1, s_b, s_a);
   }
 
   // ---- merge the two KV halves: the waves of half 1 hand (O, m, l) to their partners through LDS ----
