@@ -28,6 +28,7 @@
 #include "common.h"
 #include "mfma_frag.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace semipd {
@@ -36,10 +37,10 @@ namespace skv {
 
 constexpr int kD = 128;               // head size (q, k and v)
 constexpr int kRowBytes = kD * 2;     // one K or V row in LDS
-constexpr int kTileRows = 128;        // KV rows per tile (two halves of 64)
-constexpr int kStage = kTileRows * kRowBytes;   // 32 KiB: one K (or V) tile
-constexpr int kVBase = 2 * kStage;    // K stages at 0 / 32 KiB, V stages at 64 / 96 KiB
-constexpr int kLds = 4 * kStage;      // 128 KiB
+// KV rows per tile = 64 * HALVES; one K (or V) tile = 16 KiB * HALVES; K stages at 0 / stage, V stages at 2 / 3 x stage
+constexpr int tile_rows(int halves) { return 64 * halves; }
+constexpr int stage_bytes(int halves) { return tile_rows(halves) * kRowBytes; }
+constexpr int lds_bytes(int halves) { return 4 * stage_bytes(halves); }   // 64 KiB (two workgroups per CU) / 128 KiB
 constexpr int kMergeStride = 66 * 64 * 4;   // one wave's (O 64, m, l) x 64 lanes, fp32
 
 template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
@@ -74,8 +75,8 @@ __device__ __forceinline__ void wait_vm0_and(int32_t (&idx)[4]) {
 
 }  // namespace skv
 
-template <typename T, int G>
-__global__ void __launch_bounds__(512, 1)
+template <typename T, int G, int HALVES>
+__global__ void __launch_bounds__(256 * HALVES, 3 - HALVES)
 extend_attn_shared_kv_kernel(T* __restrict__ out, const T* __restrict__ q_ext, const T* __restrict__ k_ext,
                              const T* __restrict__ v_ext, const T* __restrict__ k_buf, const T* __restrict__ v_buf,
                              const int32_t* __restrict__ qo_indptr, const int32_t* __restrict__ kv_indptr,
@@ -84,6 +85,7 @@ extend_attn_shared_kv_kernel(T* __restrict__ out, const T* __restrict__ q_ext, c
                              float sm_scale) {
   using namespace skv;
   constexpr int TB = 4 / G;            // token blocks of 32 per workgroup
+  constexpr int kTileRows = tile_rows(HALVES), kStage = stage_bytes(HALVES), kVBase = 2 * kStage;
   extern __shared__ __attribute__((aligned(16))) char skv_smem[];
   const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)skv_smem;
 
@@ -101,7 +103,7 @@ extend_attn_shared_kv_kernel(T* __restrict__ out, const T* __restrict__ q_ext, c
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int half = wave >> 2, sub = wave & 3;
+  const int half = HALVES == 2 ? (wave >> 2) : 0, sub = wave & 3;
   const int hq = hk * group + hgrp * G + sub % G;
   const int q0 = (qt * TB + sub / G) * 32;               // this wave's first query row
   const int col = lane & 31, hi = lane >> 5;
@@ -416,8 +418,10 @@ extend_attn_shared_kv_kernel(T* __restrict__ out, const T* __restrict__ q_ext, c
   }
 
   // ---- merge the two KV halves: the waves of half 1 hand (O, m, l) to their partners through LDS ----
-  __syncthreads();   // every fragment read of the last tile is done
   float* mbuf = reinterpret_cast<float*>(skv_smem + sub * kMergeStride);
+  float m1 = -INFINITY, l1 = 0.f;
+  if constexpr (HALVES == 2) {
+  __syncthreads();   // every fragment read of the last tile is done
   if (half == 1) {
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -428,7 +432,11 @@ extend_attn_shared_kv_kernel(T* __restrict__ out, const T* __restrict__ q_ext, c
   }
   __syncthreads();
   if (half == 1 || !wave_active) return;
-  const float m1 = mbuf[64 * 64 + lane], l1 = mbuf[65 * 64 + lane];
+  m1 = mbuf[64 * 64 + lane];
+  l1 = mbuf[65 * 64 + lane];
+  } else {
+    if (!wave_active) return;
+  }
   const float m_all = fmaxf(m_run, m1);
   const float a0 = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_all);
   const float a1 = (m1 == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m1 - m_all);
@@ -445,7 +453,7 @@ extend_attn_shared_kv_kernel(T* __restrict__ out, const T* __restrict__ q_ext, c
         float o[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          o[j] = o_acc[t][r4 * 4 + j] * s0 + mbuf[(t * 16 + r4 * 4 + j) * 64 + lane] * s1;
+          o[j] = HALVES == 2 ? o_acc[t][r4 * 4 + j] * s0 + mbuf[(t * 16 + r4 * 4 + j) * 64 + lane] * s1 : o_acc[t][r4 * 4 + j] * s0;
         uint2 w;
         w.x = pack2<T>(o[0], o[1]);
         w.y = pack2<T>(o[2], o[3]);
@@ -456,6 +464,9 @@ extend_attn_shared_kv_kernel(T* __restrict__ out, const T* __restrict__ q_ext, c
 }
 
 // Returns 0 when launched, 1 when the shape is not covered (the caller falls back to extend_attention.hip).
+// Two forms: HALVES = 2 (512 threads, 128-row tiles split between two wave groups, one workgroup per CU) shortens the walk
+// of a row block when there are few workgroups (one or two requests); HALVES = 1 (256 threads, 64-row tiles, two
+// workgroups per CU) when there are plenty -- the second workgroup covers the other one's prologue and epilogue.
 template <typename T>
 int launch_extend_shared_kv(void* out, const void* q, const void* k, const void* v, const void* k_buf, const void* v_buf,
                             const int32_t* qo_indptr, const int32_t* kv_indptr, const int32_t* kv_indices, int64_t batch,
@@ -468,21 +479,31 @@ int launch_extend_shared_kv(void* out, const void* q, const void* k, const void*
   const unsigned gy = (unsigned)((max_len_extend + TB * 32 - 1) / (TB * 32));
   if (gy > 65535u || gx > 65535u) return 1;
   dim3 grid(gx, gy, (unsigned)batch);
-#define SKV(GV)                                                                                                    \
+  static const int force_halves = [] { const char* e = getenv("SEMIPD_EXTEND_KV_HALVES"); return e ? atoi(e) : 0; }();
+  const int64_t wgs = (int64_t)gx * gy * batch;
+  const int halves = force_halves == 1 || force_halves == 2 ? force_halves : (wgs <= 2 * 256 ? 2 : 1);
+#define SKV(GV, HV)                                                                                                \
   do {                                                                                                             \
     static bool attr_set = false;                                                                                  \
     if (!attr_set) {                                                                                               \
-      (void)hipFuncSetAttribute((const void*)extend_attn_shared_kv_kernel<T, GV>,                                  \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, skv::kLds);                            \
+      (void)hipFuncSetAttribute((const void*)extend_attn_shared_kv_kernel<T, GV, HV>,                              \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, skv::lds_bytes(HV));                   \
       attr_set = true;                                                                                             \
     }                                                                                                              \
-    hipLaunchKernelGGL((extend_attn_shared_kv_kernel<T, GV>), grid, dim3(512), skv::kLds, st, (T*)out, (const T*)q, \
-                       (const T*)k, (const T*)v, (const T*)k_buf, (const T*)v_buf, qo_indptr, kv_indptr, kv_indices, \
-                       group, q_stride, k_stride, v_stride, o_stride, kbuf_stride, vbuf_stride, sm_scale);          \
+    hipLaunchKernelGGL((extend_attn_shared_kv_kernel<T, GV, HV>), grid, dim3(256 * HV), skv::lds_bytes(HV), st,     \
+                       (T*)out, (const T*)q, (const T*)k, (const T*)v, (const T*)k_buf, (const T*)v_buf, qo_indptr, \
+                       kv_indptr, kv_indices, group, q_stride, k_stride, v_stride, o_stride, kbuf_stride,           \
+                       vbuf_stride, sm_scale);                                                                      \
   } while (0)
-  if (G == 4) SKV(4);
-  else if (G == 2) SKV(2);
-  else SKV(1);
+  if (halves == 2) {
+    if (G == 4) SKV(4, 2);
+    else if (G == 2) SKV(2, 2);
+    else SKV(1, 2);
+  } else {
+    if (G == 4) SKV(4, 1);
+    else if (G == 2) SKV(2, 1);
+    else SKV(1, 1);
+  }
 #undef SKV
   return 0;
 }
