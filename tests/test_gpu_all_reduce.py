@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def run_world(world, extra_env=None, timeout=180):
+def run_world(world, extra_env=None, timeout=180, worker="ar_worker.py"):
     import torch
     num_cus = torch.cuda.get_device_properties(0).multi_processor_count
     share = num_cus // world // 8 * 8
@@ -26,7 +26,7 @@ def run_world(world, extra_env=None, timeout=180):
     for r in range(world):
         env = dict(os.environ, HSA_CU_MASK=f"0:{r * share}-{(r + 1) * share - 1}")
         env.update(extra_env or {})
-        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "ar_worker.py"), str(r), str(world), str(port)],
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, worker), str(r), str(world), str(port)],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     reports, logs = [], []
     try:
@@ -72,3 +72,15 @@ def test_a_rank_that_cannot_set_up_makes_every_rank_fall_back(device, phase):
     peer-memory path on all ranks — the engine then reduces through RCCL — and nothing hangs or raises."""
     reports = run_world(4, {"SEMIPD_AR_TEST_FAIL": f"{phase}:2"}, timeout=120)
     assert len(reports) == 4 and all(r.get("disabled") for r in reports)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_reference_op_set_by_name(device, world):
+    """The reference's ROCm custom all-reduce ops (sgl-kernel/csrc/torch_extension_rocm.cc:25-55; python wrappers
+    sgl_kernel/allreduce.py:5-52) exist by name in semi_pd_amd/sgl_kernel_allreduce.py and, called in the order the
+    reference's CustomAllreduce calls them, reduce to the oracle's bits -- eagerly, through all_reduce_unreg with a
+    registered buffer, and from a captured graph whose (empty) buffer list is registered afterwards."""
+    reports = run_world(world, worker="ar_opset_worker.py")
+    assert sorted(r["rank"] for r in reports) == list(range(world))
+    for r in reports:
+        assert r["cases"] == 3 * 4 * 2 + 2 and not r["bad"], r["bad"][:5]

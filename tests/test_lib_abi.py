@@ -99,3 +99,25 @@ def test_ipc_open_watchdog_ends_a_stuck_importer_with_a_reason():
             % ([PKG],))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
     assert r.returncode == 71 and "did not return within" in r.stderr and "not reached" not in r.stdout
+
+
+def test_reference_all_reduce_op_names_are_exported():
+    """The ROCm custom all-reduce op set of the reference (sgl-kernel/csrc/torch_extension_rocm.cc:25-55, wrappers in
+    sgl-kernel/python/sgl_kernel/allreduce.py:5-52): every name, with the wrapper's parameter names in order."""
+    import inspect
+    from semi_pd_amd import sgl_kernel_allreduce as ops
+    want = {
+        "init_custom_ar": ["meta", "rank_data", "handles", "offsets", "rank", "full_nvlink"],
+        "all_reduce_reg": ["fa", "inp", "out"],
+        "all_reduce_unreg": ["fa", "inp", "reg_buffer", "out"],
+        "dispose": ["fa"],
+        "meta_size": [],
+        "register_buffer": ["fa", "t", "handles", "offsets"],
+        "get_graph_buffer_ipc_meta": ["fa"],
+        "register_graph_buffers": ["fa", "handles", "offsets"],
+        "allocate_meta_buffer": ["size"],
+        "get_meta_buffer_ipc_handle": ["inp"],
+    }
+    for name, params in want.items():
+        assert list(inspect.signature(getattr(ops, name)).parameters) == params, name
+    assert ops.meta_size() > 0 and ops.meta_size() % 256 == 0
