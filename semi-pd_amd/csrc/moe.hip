@@ -2,6 +2,8 @@
 // plus the lm_head GEMM + greedy argmax that reuses the same MFMA tile (a8/a9).
 #include "common.h"
 
+#include <cstdlib>
+
 #include <stdlib.h>
 
 namespace semipd {
@@ -394,6 +396,13 @@ int skinny_pick_ksplit(int64_t rows, int64_t N, int64_t K, int64_t m_blocks, int
 
 }  // namespace semipd
 
+namespace semipd {
+template <typename T>
+int launch_moe_tiled_gemm(T* c, const T* a, const T* w, const float* topk_weights, const int32_t* sorted_ids,
+                          const int32_t* expert_ids, const int32_t* num_post_pad, int64_t num_valid, int64_t n, int64_t k,
+                          int64_t max_sorted, int top_k_div, int mul_routed_weight, hipStream_t st);
+}  // namespace semipd
+
 using namespace semipd;
 
 extern "C" {
@@ -476,6 +485,14 @@ int semipd_moe_grouped_gemm(void* c, const void* a, const void* w, const float* 
   // block of block_m rows), not by MFMA: weight-streaming kernel, 64-row blocks for decode, 128-row
   // blocks for prefill chunks
   if (skinny_gemm_ok(k, k, a, w) && n % 4 == 0) {
+    // prefill-sized calls (hundreds of rows per expert): the tiled kernel (moe_tiled_gemm.hip); SEMIPD_MOE_TILED=0 keeps
+    // the streaming kernel for every size
+    static const bool tiled_on = [] { const char* e = getenv("SEMIPD_MOE_TILED"); return !(e && e[0] == '0'); }();
+    if (tiled_on && block_m == 128 && num_valid >= 2048 && (reinterpret_cast<uintptr_t>(c) & 7u) == 0) {
+      int miss = 1;
+      SEMIPD_DISPATCH_HALF(dtype, T, miss = (launch_moe_tiled_gemm<T>((T*)c, (const T*)a, (const T*)w, topk_weights, sorted_token_ids, expert_ids, num_tokens_post_pad, num_valid, n, k, max_sorted, top_k_div, mul_routed_weight, as_stream(stream))));
+      if (!miss) return launch_status("moe_grouped_gemm(tiled)");
+    }
     if (block_m == 128) {
       SEMIPD_DISPATCH_HALF(dtype, T, return (launch_skinny_gemm<T, T, true, 128>((T*)c, (const T*)a, (const T*)w, topk_weights, sorted_token_ids, expert_ids, num_tokens_post_pad, num_valid, (int64_t)0, n, k, k, n, (max_sorted + 127) / 128, top_k_div, mul_routed_weight, as_stream(stream), 1, nullptr)));
     }

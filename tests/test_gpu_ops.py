@@ -628,6 +628,42 @@ def test_fused_moe_pipeline(ops, device, T, N, K, E, topk, dtype, block):
     _close(out, want, dtype, rtol=1e-1, atol=1e-2)
 
 
+@pytest.mark.parametrize("T,topk,E,N,K", [(512, 6, 64, 2816, 2048), (700, 4, 8, 352, 192), (400, 8, 16, 2048, 1408),
+                                          (2100, 1, 3, 96, 64)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("routed", [False, True])
+def test_moe_grouped_gemm_prefill_sized_rows(ops, device, T, topk, E, N, K, dtype, routed):
+    """The tiled grouped GEMM (moe_tiled_gemm.hip: block_m 128 and at least 2048 routed rows) row by row against an fp32
+    product with the routed expert's weights: tiles past N (352, 96), k-blocks that do not fill the DMA ring (K = 64, 192),
+    experts without rows, ragged last blocks, both epilogues (GEMM1: plain, rows through sorted id / topk; GEMM2: times the
+    routed weight, rows through the sorted id)."""
+    torch.manual_seed(T + N + K)
+    numel = T * topk
+    div = 1 if routed else topk
+    a = (torch.randn(numel // div, K) / 4).to(dtype)
+    w = (torch.randn(E, N, K) / 4).to(dtype)
+    gate = torch.randn(T, E)
+    if E > 4:
+        gate[:, 1] -= 100.0   # an expert nobody is routed to
+    tw, tid = ops.topk_softmax(gate.to(device), topk, True)
+    max_sorted = numel + E * 127
+    sorted_ids = torch.empty(max_sorted, dtype=torch.int32, device=device)
+    expert_ids = torch.empty((max_sorted + 127) // 128, dtype=torch.int32, device=device)
+    npp = torch.empty(1, dtype=torch.int32, device=device)
+    cumsum = torch.empty(E + 1, dtype=torch.int32, device=device)
+    ops.moe_align_block_size(tid, E, 128, sorted_ids, expert_ids, npp, None, cumsum)
+    c = torch.full((numel, N), float("nan"), dtype=dtype, device=device)
+    ops.moe_grouped_gemm(a.to(device), w.to(device), c, tw.flatten().contiguous() if routed else None, sorted_ids,
+                         expert_ids, npp, numel, div, routed, 128)
+    flat_e = tid.flatten().cpu().long()
+    rows = torch.arange(numel) // div
+    want = torch.einsum("rk,rnk->rn", a.float()[rows], w.float()[flat_e])
+    if routed:
+        want = want * tw.flatten().cpu().float()[:, None]
+    tol = 2e-2 if dtype == torch.bfloat16 else 4e-3
+    torch.testing.assert_close(c.float().cpu(), want, rtol=tol, atol=tol * float(want.abs().max()))
+
+
 def test_fused_experts_layer_prefill_sized(ops, device):
     """layers.moe.fused_experts above the decode threshold (T * topk > 2048 -> 128-row blocks): many rows
     per expert, several blocks per expert, ragged last blocks."""
