@@ -65,18 +65,19 @@ template <int N> __device__ __forceinline__ void wait_lgkm() {
   __builtin_amdgcn_sched_barrier(0);
 }
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-// The prefetched pool indices are "used" right behind the explicit wait: the compiler then places its own wait for those
+// (WAIT_VM0_AND) The prefetched pool indices are "used" right behind the explicit wait: the compiler then places its own wait for those
 // loads here (where the counter is zero anyway) instead of in the middle of the next DMA issue, where a vmcnt(0) would
 // sit on the pieces just sent.
-__device__ __forceinline__ void wait_vm0_and(int32_t (&idx)[4]) {
-  wait_vm0();
-  asm volatile("" : "+v"(idx[0]), "+v"(idx[1]), "+v"(idx[2]), "+v"(idx[3]));
-}
-
 }  // namespace skv
 
-template <typename T, int G, int HALVES>
-__global__ void __launch_bounds__(256 * HALVES, 3 - HALVES)
+#define SKV_WAIT_VM0_AND(IDX)                                          \
+  do {                                                                 \
+    skv::wait_vm0();                                                   \
+    _Pragma("unroll") for (int j_ = 0; j_ < kPPW; ++j_) asm volatile("" : "+v"((IDX)[j_])); \
+  } while (0)
+
+template <typename T, int G, int TB, int HALVES>
+__global__ void __launch_bounds__(64 * G * TB * HALVES, (G * TB * HALVES == 8) ? 1 : (HALVES == 2 ? 1 : 2))
 extend_attn_shared_kv_kernel(T* __restrict__ out, const T* __restrict__ q_ext, const T* __restrict__ k_ext,
                              const T* __restrict__ v_ext, const T* __restrict__ k_buf, const T* __restrict__ v_buf,
                              const int32_t* __restrict__ qo_indptr, const int32_t* __restrict__ kv_indptr,
@@ -84,7 +85,9 @@ extend_attn_shared_kv_kernel(T* __restrict__ out, const T* __restrict__ q_ext, c
                              int64_t v_stride, int64_t o_stride, int64_t kbuf_stride, int64_t vbuf_stride,
                              float sm_scale) {
   using namespace skv;
-  constexpr int TB = 4 / G;            // token blocks of 32 per workgroup
+  // G q heads x TB blocks of 32 tokens x HALVES wave groups = NW waves; every wave sends kPPW 1-KiB pieces of a K or V tile
+  constexpr int NW = G * TB * HALVES, kGT = G * TB, kPPW = 16 / kGT, kWaveRows = 4 * kPPW;
+  static_assert(kGT == 4 || kGT == 2 || kGT == 1, "4, 2 or 1 (head, token block) pairs per wave group");
   constexpr int kTileRows = tile_rows(HALVES), kStage = stage_bytes(HALVES), kVBase = 2 * kStage;
   extern __shared__ __attribute__((aligned(16))) char skv_smem[];
   const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)skv_smem;
@@ -103,7 +106,7 @@ extend_attn_shared_kv_kernel(T* __restrict__ out, const T* __restrict__ q_ext, c
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int half = HALVES == 2 ? (wave >> 2) : 0, sub = wave & 3;
+  const int half = HALVES == 2 ? (wave / kGT) : 0, sub = wave % kGT;
   const int hq = hk * group + hgrp * G + sub % G;
   const int q0 = (qt * TB + sub / G) * 32;               // this wave's first query row
   const int col = lane & 31, hi = lane >> 5;
@@ -141,7 +144,7 @@ extend_attn_shared_kv_kernel(T* __restrict__ out, const T* __restrict__ q_ext, c
   const int n_tiles = n_pre + n_ext;
 
   // DMA duty of this wave: rows wave*16 + j*4 + (lane >> 4), j = 0..3, of a K tile or of a V tile; pos = lane & 15
-  const int drow = wave * 16 + (lane >> 4), dpos = lane & 15;
+  const int drow = wave * kWaveRows + (lane >> 4), dpos = lane & 15;
   const T* k_pre = k_buf + (int64_t)hk * kD;
   const T* v_pre = v_buf + (int64_t)hk * kD;
   const T* ke_head = k_ext + (int64_t)q_start * k_stride + (int64_t)hk * kD;
@@ -153,31 +156,33 @@ extend_attn_shared_kv_kernel(T* __restrict__ out, const T* __restrict__ q_ext, c
   const int32_t* idx_base = kv_indices + kv_start;
   // pool slots of this lane's rows: idx_k for the K tile about to be fetched, idx_v (the previous idx_k) for the V tile
   // that follows one tile behind; loaded one step ahead so that the index -> address chain is never waited for
-  int32_t idx_k[4] = {0, 0, 0, 0}, idx_v[4] = {0, 0, 0, 0};
+  // (arrays of the fixed maximum size: an array whose size depends on the template arguments, captured by the lambdas
+  // below, makes the HOST pass drop the kernel's stub without a diagnostic; unused elements cost nothing)
+  int32_t idx_k[16] = {}, idx_v[16] = {};
   auto load_idx = [=, &idx_k](int it) __attribute__((always_inline)) {
     if (it < n_pre) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) idx_k[j] = idx_base[min(it * kTileRows + drow + j * 4, pre_len - 1)];
+      for (int j = 0; j < kPPW; ++j) idx_k[j] = idx_base[min(it * kTileRows + drow + j * 4, pre_len - 1)];
     }
   };
   // whole tiles of new tokens: per-lane byte offsets computed once, the tile offset is the scalar operand of the buffer load
-  int kvo[4], vvo[4];
+  int kvo[16], vvo[16];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < kPPW; ++j) {
     const int r = drow + j * 4;
     kvo[j] = r * (int)k_stride * 2 + (dpos ^ (r & 15)) * 16;          // the launcher checked ext rows * stride < 2^31 bytes
     vvo[j] = r * (int)v_stride * 2 + (dpos ^ ((r & 3) << 2)) * 16;
   }
   // one tile (K: IS_V = false, swizzle row & 15; V: swizzle (row & 3) << 2) into stage (it & 1)
-  auto issue_tile = [=](auto is_v, int it, const int32_t (&idx)[4]) __attribute__((always_inline)) {
+  auto issue_tile = [=](auto is_v, int it, const int32_t (&idx)[16]) __attribute__((always_inline)) {
     constexpr bool IS_V = decltype(is_v)::value;
-    const uint32_t dst = lds0 + (IS_V ? kVBase : 0) + (it & 1) * kStage + wave * 16 * kRowBytes;
+    const uint32_t dst = lds0 + (IS_V ? kVBase : 0) + (it & 1) * kStage + wave * kWaveRows * kRowBytes;
     const int n0 = (it - n_pre) * kTileRows;
     if (it >= n_pre && n0 + kTileRows <= ext_end) {
       // (readfirstlane: the compiler cannot prove the tile offset uniform and would wrap every load in a waterfall loop)
       const int tile_off = __builtin_amdgcn_readfirstlane(n0 * (int)(IS_V ? v_stride : k_stride) * 2);
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < kPPW; ++j)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(IS_V ? rsrc_v : rsrc_k,
                                                  (__attribute__((address_space(3))) void*)(uintptr_t)(dst + j * 4 * kRowBytes),
                                                  16, IS_V ? vvo[j] : kvo[j], tile_off, 0, 0);
@@ -187,12 +192,12 @@ extend_attn_shared_kv_kernel(T* __restrict__ out, const T* __restrict__ q_ext, c
     // lane id keeps the compiler from hoisting a dozen 64-bit per-lane constants out of the loop and spilling them)
     int ln = lane;
     asm volatile("" : "+v"(ln));
-    const int rw = wave * 16 + (ln >> 4), ps = ln & 15;
+    const int rw = wave * kWaveRows + (ln >> 4), ps = ln & 15;
     if (it < n_pre) {
       const T* base = IS_V ? v_pre : k_pre;
       const int64_t stride = IS_V ? vbuf_stride : kbuf_stride;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < kPPW; ++j) {
         const int r = rw + j * 4;
         const int sw = IS_V ? ((r & 3) << 2) : (r & 15);
         const T* p = base + ((int64_t)idx[j] * stride + ((ps ^ sw) * 8));
@@ -202,7 +207,7 @@ extend_attn_shared_kv_kernel(T* __restrict__ out, const T* __restrict__ q_ext, c
     } else {
       const int stride_b = (int)(IS_V ? v_stride : k_stride) * 2;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < kPPW; ++j) {
         const int r = rw + j * 4;
         const int sw = IS_V ? ((r & 3) << 2) : (r & 15);
         const int n = min(n0 + r, ext_end - 1);      // rows past the end: the last valid row (finite, masked)
@@ -366,13 +371,13 @@ extend_attn_shared_kv_kernel(T* __restrict__ out, const T* __restrict__ q_ext, c
   // one iteration: [K(it+1), V(it) landed] barrier [DMA of K(it+2), V(it+1)] QK(it+1) || B(it), mask, PV(it) || max(it+1), A(it+1)
   auto iteration = [=, &o_acc, &m_run, &l_run, &idx_k, &idx_v](auto par_c, int it, f32x16 (&s_cur)[2], f32x16 (&s_nxt)[2]) __attribute__((always_inline)) {
     constexpr int PAR = decltype(par_c)::value;   // it & 1
-    wait_vm0_and(idx_k);
+    SKV_WAIT_VM0_AND(idx_k);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     if (it + 2 < n_tiles) issue_tile(std::false_type{}, it + 2, idx_k);   // into K stage (it & 1): K(it) was read last iteration
     if (it + 1 < n_tiles) issue_tile(std::true_type{}, it + 1, idx_v);    // into V stage ((it + 1) & 1): V(it - 1) likewise
 #pragma unroll
-    for (int j = 0; j < 4; ++j) idx_v[j] = idx_k[j];
+    for (int j = 0; j < kPPW; ++j) idx_v[j] = idx_k[j];
     load_idx(it + 3);
     const float m_use = (m_run == -INFINITY) ? 0.f : m_run;   // everything masked so far
     qk_phase(std::integral_constant<int, PAR ^ 1>{}, std::true_type{}, s_nxt, s_cur, m_use);
@@ -389,15 +394,15 @@ extend_attn_shared_kv_kernel(T* __restrict__ out, const T* __restrict__ q_ext, c
   load_idx(0);
   issue_tile(std::false_type{}, 0, idx_k);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) idx_v[j] = idx_k[j];
+  for (int j = 0; j < kPPW; ++j) idx_v[j] = idx_k[j];
   load_idx(1);
-  wait_vm0_and(idx_k);
+  SKV_WAIT_VM0_AND(idx_k);
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
   if (1 < n_tiles) issue_tile(std::false_type{}, 1, idx_k);
   issue_tile(std::true_type{}, 0, idx_v);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) idx_v[j] = idx_k[j];
+  for (int j = 0; j < kPPW; ++j) idx_v[j] = idx_k[j];
   load_idx(2);
   qk_phase(std::integral_constant<int, 0>{}, std::false_type{}, s_a, s_b, 0.f);
   {
@@ -464,45 +469,48 @@ extend_attn_shared_kv_kernel(T* __restrict__ out, const T* __restrict__ q_ext, c
 }
 
 // Returns 0 when launched, 1 when the shape is not covered (the caller falls back to extend_attention.hip).
-// Two forms: HALVES = 2 (512 threads, 128-row tiles split between two wave groups, one workgroup per CU) shortens the walk
-// of a row block when there are few workgroups (one or two requests); HALVES = 1 (256 threads, 64-row tiles, two
-// workgroups per CU) when there are plenty -- the second workgroup covers the other one's prologue and epilogue.
+// Forms (G heads x TB token blocks x HALVES wave groups), chosen by how many workgroups the batch gives:
+//   plenty (> 512 of the 8-wave form): HALVES = 1 -- 4 waves, 64-row tiles, two workgroups per CU (the second one covers
+//     the other's prologue and epilogue);
+//   few: HALVES = 2 -- 8 waves, 128-row tiles split between two wave groups: the walk of a row block is half as long.
+// (Measured and dropped: half the heads per workgroup for a single short request -- 4 waves, ONE per SIMD, twice the
+// workgroups.  A lone wave per SIMD reaches about half the rate of two: 32.7 us against 26.9 for one 1024-token request.)
 template <typename T>
 int launch_extend_shared_kv(void* out, const void* q, const void* k, const void* v, const void* k_buf, const void* v_buf,
                             const int32_t* qo_indptr, const int32_t* kv_indptr, const int32_t* kv_indices, int64_t batch,
                             int Hq, int Hkv, int64_t q_stride, int64_t k_stride, int64_t v_stride, int64_t o_stride,
                             int64_t kbuf_stride, int64_t vbuf_stride, int max_len_extend, float sm_scale, hipStream_t st) {
   const int group = Hq / Hkv;
-  const int G = group % 4 == 0 ? 4 : (group % 2 == 0 ? 2 : 1);
-  const int TB = 4 / G;
+  const int g8 = group % 4 == 0 ? 4 : (group % 2 == 0 ? 2 : 1);   // heads per workgroup of the 8-wave form
+  const int64_t wgs8 = (int64_t)Hkv * (group / g8) * ((max_len_extend + (4 / g8) * 32 - 1) / ((4 / g8) * 32)) * batch;
+  static const int force = [] { const char* e = getenv("SEMIPD_EXTEND_KV_FORM"); return e ? atoi(e) : 0; }();   // 1 / 2
+  const int form = force == 1 || force == 2 ? force : (wgs8 > 512 ? 1 : 2);
+  const int G = g8, TB = 4 / g8;
   const unsigned gx = (unsigned)(Hkv * (group / G));
   const unsigned gy = (unsigned)((max_len_extend + TB * 32 - 1) / (TB * 32));
   if (gy > 65535u || gx > 65535u) return 1;
   dim3 grid(gx, gy, (unsigned)batch);
-  static const int force_halves = [] { const char* e = getenv("SEMIPD_EXTEND_KV_HALVES"); return e ? atoi(e) : 0; }();
-  const int64_t wgs = (int64_t)gx * gy * batch;
-  const int halves = force_halves == 1 || force_halves == 2 ? force_halves : (wgs <= 2 * 256 ? 2 : 1);
-#define SKV(GV, HV)                                                                                                \
+#define SKV(GV, TV, HV)                                                                                            \
   do {                                                                                                             \
     static bool attr_set = false;                                                                                  \
     if (!attr_set) {                                                                                               \
-      (void)hipFuncSetAttribute((const void*)extend_attn_shared_kv_kernel<T, GV, HV>,                              \
+      (void)hipFuncSetAttribute((const void*)extend_attn_shared_kv_kernel<T, GV, TV, HV>,                          \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, skv::lds_bytes(HV));                   \
       attr_set = true;                                                                                             \
     }                                                                                                              \
-    hipLaunchKernelGGL((extend_attn_shared_kv_kernel<T, GV, HV>), grid, dim3(256 * HV), skv::lds_bytes(HV), st,     \
-                       (T*)out, (const T*)q, (const T*)k, (const T*)v, (const T*)k_buf, (const T*)v_buf, qo_indptr, \
-                       kv_indptr, kv_indices, group, q_stride, k_stride, v_stride, o_stride, kbuf_stride,           \
-                       vbuf_stride, sm_scale);                                                                      \
+    hipLaunchKernelGGL((extend_attn_shared_kv_kernel<T, GV, TV, HV>), grid, dim3(64 * GV * TV * HV),                \
+                       skv::lds_bytes(HV), st, (T*)out, (const T*)q, (const T*)k, (const T*)v, (const T*)k_buf,     \
+                       (const T*)v_buf, qo_indptr, kv_indptr, kv_indices, group, q_stride, k_stride, v_stride,      \
+                       o_stride, kbuf_stride, vbuf_stride, sm_scale);                                               \
   } while (0)
-  if (halves == 2) {
-    if (G == 4) SKV(4, 2);
-    else if (G == 2) SKV(2, 2);
-    else SKV(1, 2);
+  if (form == 1) {
+    if (g8 == 4) SKV(4, 1, 1);
+    else if (g8 == 2) SKV(2, 2, 1);
+    else SKV(1, 4, 1);
   } else {
-    if (G == 4) SKV(4, 1);
-    else if (G == 2) SKV(2, 1);
-    else SKV(1, 1);
+    if (g8 == 4) SKV(4, 1, 2);
+    else if (g8 == 2) SKV(2, 2, 2);
+    else SKV(1, 4, 2);
   }
 #undef SKV
   return 0;
