@@ -62,10 +62,10 @@ def main():
             x = xs[rank].to(dev)
             out = torch.empty_like(x)
             ops.all_reduce_reg(fa, x, out)
-            check(f"reg {dtype} {nbytes}", out, all_reduce_sum(xs))
+            check(f"reg {dtype} {nbytes}", out, all_reduce_sum(xs, dtype))
             out2 = torch.empty_like(x)
             ops.all_reduce_unreg(fa, x, buffer, out2)
-            check(f"unreg {dtype} {nbytes}", out2, all_reduce_sum(xs))
+            check(f"unreg {dtype} {nbytes}", out2, all_reduce_sum(xs, dtype))
     # a captured call, registered afterwards the way custom_all_reduce.py:421-426 does, replayed on new data
     xs = inputs_of(8192, torch.bfloat16, 99)
     x = xs[rank].to(dev)
@@ -91,7 +91,7 @@ def main():
         dist.barrier()
         g.replay()
         torch.cuda.synchronize()
-        check(f"graph replay {s}", out, all_reduce_sum(xs))
+        check(f"graph replay {s}", out, all_reduce_sum(xs, torch.bfloat16))
     # error behaviour of the reference's checks
     try:
         ops.all_reduce_unreg(fa, torch.zeros(64, device=dev), torch.empty(16, dtype=torch.uint8, device=dev), torch.zeros(64, device=dev))
