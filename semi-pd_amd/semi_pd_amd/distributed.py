@@ -40,8 +40,18 @@ def init_distributed_environment(world_size: int, rank: int, distributed_init_me
         kwargs = {}
         if backend == "nccl" and device is not None:
             kwargs["device_id"] = device
-        dist.init_process_group(backend=backend, init_method=distributed_init_method, world_size=world_size,
-                                rank=rank, timeout=datetime.timedelta(seconds=timeout_s), **kwargs)
+        # Under torchrun every descendant inherits TORCHELASTIC_USE_AGENT_STORE=True, and torch then makes NO rank the
+        # server of a tcp:// rendezvous (it expects the launcher's agent store at that address): the scheduler
+        # processes of a `torch.distributed.run ... bench.py --gpus N` job all sat in connect() until the timeout.
+        # The groups here bring their own address and port, so rank 0 must serve it.
+        agent_store = os.environ.pop("TORCHELASTIC_USE_AGENT_STORE", None) \
+            if str(distributed_init_method).startswith("tcp://") else None
+        try:
+            dist.init_process_group(backend=backend, init_method=distributed_init_method, world_size=world_size,
+                                    rank=rank, timeout=datetime.timedelta(seconds=timeout_s), **kwargs)
+        finally:
+            if agent_store is not None:
+                os.environ["TORCHELASTIC_USE_AGENT_STORE"] = agent_store
     _DEVICE_GROUP = dist.group.WORLD
     _CPU_GROUP = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=timeout_s)) \
         if backend != "gloo" else dist.group.WORLD

@@ -247,3 +247,20 @@ def test_tp2_semi_pd_protocol_four_processes(tmp_path):
             if p.is_alive():
                 p.terminate()
         tok.close()
+
+
+def _just_rendezvous(rank, world):
+    import torch.distributed as dist
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    return float(t)
+
+
+def test_rendezvous_of_the_tp_groups_under_a_torchrun_environment(monkeypatch):
+    """`python -m torch.distributed.run ... bench.py --gpus N` hands TORCHELASTIC_USE_AGENT_STORE=True down to every
+    scheduler process; with it torch makes no rank the server of a tcp:// rendezvous and the TP groups of the prefill and
+    decode instances (their own ports) never form.  init_distributed_environment must serve the address itself."""
+    monkeypatch.setenv("TORCHELASTIC_USE_AGENT_STORE", "True")
+    monkeypatch.setenv("TORCHELASTIC_RESTART_COUNT", "0")
+    res = _spawn("_just_rendezvous", timeout=60)
+    assert res == {0: 3.0, 1: 3.0}
