@@ -319,9 +319,15 @@ def main():
                     disable_cuda_graph=args.disable_cuda_graph, nccl_port_base=port_base,
                     disable_overlap_schedule=args.disable_overlap_schedule,
                     **({"chunked_prefill_size": args.chunked_prefill_size} if args.chunked_prefill_size else {}),
-                    kv_cache_dtype=args.kv_cache_dtype, cuda_graph_max_bs=min(1024, 256 * tp_world),
+                    kv_cache_dtype=args.kv_cache_dtype,
+                    # (the one-GPU check of the TP path reduces over gloo, whose collectives cannot be captured beyond the
+                    # peer-memory kernels' 16 MB: small graphs there)
+                    cuda_graph_max_bs=(64 if os.environ.get("SEMIPD_BENCH_ALL_ON_GPU0") == "1" else min(1024, 256 * tp_world)),
                     collect_kernel_timing=not args.no_kernel_timing, random_seed=args.seed,
-                    dist_init_addr=os.environ.get("MASTER_ADDR", "127.0.0.1"), watchdog_timeout=600.0)
+                    dist_init_addr=os.environ.get("MASTER_ADDR", "127.0.0.1"), watchdog_timeout=600.0,
+                    # (RCCL refuses two ranks on one device: the one-GPU functional check runs the TP groups over gloo +
+                    # the peer-memory all-reduce, like tests/test_gpu_engine.py's TP = 2 case)
+                    **({"dist_backend": "gloo"} if os.environ.get("SEMIPD_BENCH_ALL_ON_GPU0") == "1" else {}))
     if args.mode == "unified" and tp_world > 1:
         raise SystemExit("unified mode is single-GPU only in this round")
     if args.tp:

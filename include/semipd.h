@@ -391,6 +391,20 @@ int semipd_ipc_get_handle(const void* dev_ptr, uint8_t handle[64], uint64_t* off
 /* HIP runtime / driver version numbers (hipRuntimeGetVersion, hipDriverGetVersion): logged next to the IPC size rule
  * of semipd_ipc_get_handle, which was measured on one runtime.  library plumbing (no reference counterpart). */
 int semipd_runtime_version(int* runtime, int* driver);
+/* A stream the caller owns (hipStreamCreateWithFlags, non-blocking) for graph capture, and the way out of a capture
+ * that failed half way.  Measured on ROCm 7.0 (tools/probe_capture_abort.py): an invalidated capture cannot be ended --
+ * hipStreamEndCapture returns hipErrorStreamCaptureInvalidated and the stream stays invalidated -- and while it exists
+ * every synchronising call of the process, on any stream, fails with that error; destroying the stream clears it.
+ * semipd_stream_abort_capture = end the capture, drop the graph, DESTROY the stream (the handle is dead afterwards),
+ * clear the sticky error.  That is why the decode graph runner captures on its own stream and not on one of torch's
+ * pooled streams.  library plumbing (the reference relies on torch.cuda.graph's exit path,
+ * model_executor/cuda_graph_runner.py:300-330). */
+int semipd_stream_create(int device, void** stream);
+int semipd_stream_abort_capture(void* stream);
+/* Reads the runtime's per-thread last error until it is hipSuccess (returns how many were pending).  After an aborted
+ * capture the host framework's own clean-up (graph and allocator bookkeeping on the dead stream) leaves
+ * hipErrorInvalidValue behind, which its next launch check would report as that launch's failure. */
+int semipd_clear_last_error(void);
 
 /* Open (or re-use: one mapping per handle per process, ref-counted) and return the
  * mapped allocation base.  replaces ConvertIPCMemHandleToTensor's open

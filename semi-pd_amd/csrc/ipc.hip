@@ -87,6 +87,39 @@ int semipd_runtime_version(int* runtime, int* driver) {
   return 0;
 }
 
+int semipd_stream_create(int device, void** stream) {
+  SEMIPD_CHECK_ARG(stream, SEMIPD_EINVAL, "stream_create: null pointer");
+  int prev = -1;
+  SEMIPD_HIP(hipGetDevice(&prev));
+  if (device >= 0 && device != prev) SEMIPD_HIP(hipSetDevice(device));
+  hipStream_t s = nullptr;
+  hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+  if (device >= 0 && device != prev) (void)hipSetDevice(prev);
+  if (e != hipSuccess) {
+    set_error("hipStreamCreateWithFlags failed: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  *stream = (void*)s;
+  return 0;
+}
+
+int semipd_stream_abort_capture(void* stream) {
+  SEMIPD_CHECK_ARG(stream, SEMIPD_EINVAL, "stream_abort_capture: null stream");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipGraph_t graph = nullptr;
+  (void)hipStreamEndCapture(st, &graph);   // returns hipErrorStreamCaptureInvalidated and leaves the stream invalidated
+  if (graph) (void)hipGraphDestroy(graph);
+  (void)hipStreamDestroy(st);              // the stream takes the invalidated capture with it
+  for (int i = 0; i < 4 && hipGetLastError() != hipSuccess; ++i) {}
+  return 0;
+}
+
+int semipd_clear_last_error(void) {
+  int n = 0;
+  while (n < 8 && hipGetLastError() != hipSuccess) ++n;
+  return n;
+}
+
 int semipd_ipc_open(const uint8_t handle[64], int device, void** base) {
   SEMIPD_CHECK_ARG(handle && base, SEMIPD_EINVAL, "ipc_open: null pointer");
   const std::string key((const char*)handle, 64);

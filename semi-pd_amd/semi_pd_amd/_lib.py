@@ -58,6 +58,9 @@ _SIGNATURES = {
     "semipd_bmm_fp8": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _i32,
                        _i32, _vp],
     "semipd_runtime_version": [_vp, _vp],
+    "semipd_stream_create": [_i32, _vp],
+    "semipd_stream_abort_capture": [_vp],
+    "semipd_clear_last_error": [],
     "semipd_stream_linear_workspace": [_i64],
     "semipd_stream_linear_planes": [_vp, _sz, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp],
     "semipd_fused_add_rmsnorm_planes": [_vp, _vp, _vp, _vp, _i32, _i64, _i64, _i64, _f32, _i32, _vp],

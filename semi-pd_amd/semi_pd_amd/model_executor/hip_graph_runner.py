@@ -20,6 +20,39 @@ def get_batch_sizes_to_capture(max_bs: int) -> List[int]:
     return [b for b in bs if b <= max_bs]
 
 
+_PARKED: list = []   # see _capture_one
+
+
+def recover_after_failed_capture(device) -> None:
+    """After HipGraphRunner raised out of a capture (its stream is destroyed, what lived on it parked): the sequence that
+    brings the process back on ROCm 7.0 (tools/probe_capture_abort.py, tests/test_gpu_ops.py::
+    test_abort_of_a_failed_stream_capture) -- one throw-away call takes the hipErrorInvalidValue the framework's
+    bookkeeping left behind, one small clean capture on a fresh stream settles its capture state."""
+    import ctypes
+    from semi_pd_amd import _lib
+    lib = _lib.load()
+    x = None
+    for _ in range(2):
+        try:
+            lib.semipd_clear_last_error()
+            x = torch.ones(8, device=device)
+            x.cpu()
+            break
+        except Exception:  # noqa: BLE001
+            continue
+    raw = ctypes.c_void_p()
+    _lib.check(lib.semipd_stream_create(torch.device(device).index or 0, ctypes.addressof(raw)), "stream_create")
+    st = torch.cuda.ExternalStream(raw.value, device=device)
+    st.wait_stream(torch.cuda.current_stream())
+    if x is None:
+        x = torch.ones(8, device=device)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=st):
+        y = x * 2
+    _PARKED.append((x, y, g, st))
+    torch.cuda.synchronize()
+
+
 class HipGraphRunner:
     def __init__(self, model_runner):
         self.mr = model_runner
@@ -38,7 +71,14 @@ class HipGraphRunner:
         self.graphs: Dict[int, torch.cuda.CUDAGraph] = {}
         self.outputs: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
         self.pool = None
-        self.stream = torch.cuda.Stream(device=dev)
+        # the capture stream is OURS (not one of torch's pooled streams): a capture that fails half way can only be got rid
+        # of by destroying its stream (include/semipd.h, semipd_stream_abort_capture)
+        import ctypes
+        from semi_pd_amd import _lib
+        raw = ctypes.c_void_p()
+        _lib.check(_lib.load().semipd_stream_create(torch.device(dev).index or 0, ctypes.addressof(raw)), "stream_create")
+        self._raw_stream = raw.value
+        self.stream = torch.cuda.ExternalStream(self._raw_stream, device=dev)
         for bs in reversed(self.capture_bs):
             self._capture_one(bs)
 
@@ -66,8 +106,19 @@ class HipGraphRunner:
         torch.cuda.current_stream().wait_stream(self.stream)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, pool=self.pool, stream=self.stream):
-            out = run_once()
+        try:
+            with torch.cuda.graph(g, pool=self.pool, stream=self.stream):
+                out = run_once()
+        except BaseException:
+            # something in the step refused capture (a collective of this TP backend, say): the invalidated capture
+            # poisons every later synchronising call of the process until its stream is destroyed
+            from semi_pd_amd import _lib
+            _lib.load().semipd_stream_abort_capture(self._raw_stream)
+            self._raw_stream = None
+            # nothing that lives on the dead stream may be freed (the allocator would touch the stream again): the graphs,
+            # their outputs and the runner itself are parked for the life of the process
+            _PARKED.append((self, g, self.graphs, self.outputs, self.pool, self.stream))
+            raise
         self.pool = self.pool or g.pool()
         self.graphs[bs] = g
         self.outputs[bs] = out

@@ -375,7 +375,9 @@ class ModelRunner:
         except Exception as e:  # pragma: no cover (needs a multi-GPU node)
             logger.warning("decode hipGraph capture failed with TP=%d (%s); running decode eagerly", self.tp_size, e)
             self.graph_runner = None
-            torch.cuda.synchronize()
+            # the runner has destroyed its capture stream and parked what lived on it (hip_graph_runner.py)
+            from semi_pd_amd.model_executor.hip_graph_runner import recover_after_failed_capture
+            recover_after_failed_capture(self.device)
 
     # ------------------------------------------------------------------------------------ forward
     @torch.no_grad()

@@ -783,3 +783,54 @@ def test_stream_linear_planes_into_fused_add_rmsnorm(ops, device, M, N, K, dtype
     want, want_res = O.fused_add_rms_norm(gemm, res, nw, 1e-5)
     _close(out, want, dtype, rtol=3e-2, atol=3e-2)
     _close(r2, want_res, dtype, rtol=2e-2, atol=2e-2 * float(want_res.float().abs().max()))
+
+
+_KEEP_ALIVE = []
+
+
+def test_abort_of_a_failed_stream_capture(device):
+    """A decode step that cannot be captured (a TP collective of a backend without capture support) must leave the process
+    able to run eagerly.  On this ROCm an invalidated capture cannot be ended, and while its stream exists every
+    synchronising call of the process fails: semipd_stream_abort_capture destroys the (caller-owned) stream."""
+    import ctypes
+    from semi_pd_amd import _lib
+    lib = _lib.load()
+    x = torch.ones(1024, device=device)
+
+    def own_stream():
+        raw = ctypes.c_void_p()
+        _lib.check(lib.semipd_stream_create(0, ctypes.addressof(raw)), "stream_create")
+        st = torch.cuda.ExternalStream(raw.value, device=device)
+        st.wait_stream(torch.cuda.current_stream())
+        return raw.value, st
+
+    raw, stream = own_stream()
+    g = torch.cuda.CUDAGraph()
+    with pytest.raises(Exception):
+        with torch.cuda.graph(g, stream=stream):
+            y = x * 2
+            y.sum().item()          # a synchronising call invalidates the capture
+    assert lib.semipd_stream_abort_capture(raw) == 0
+    # what was allocated on the dead stream goes back to the allocator now; the framework's bookkeeping on that stream
+    # fails ONE later call with hipErrorInvalidValue -- the engine's fallback path (model_runner.init_cuda_graphs) makes
+    # that call a throw-away one, like here
+    _KEEP_ALIVE.append((y, g, stream))   # freeing what lives on the dead stream makes the allocator touch it again
+    try:                                # ONE later call fails with hipErrorInvalidValue: a throw-away one
+        (x + 1).cpu()
+    except Exception:
+        pass
+    raw1, stream1 = own_stream()        # a small clean capture on a fresh stream settles the framework's capture state
+    g1 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g1, stream=stream1):
+        y1 = x * 5
+    _KEEP_ALIVE.append((y1, g1, stream1))
+    assert float((x + 1).cpu().sum()) == 2048.0
+    t = torch.arange(8).pin_memory().to(device, non_blocking=True)             # the call that failed in the engine
+    assert int(t.sum()) == 28
+    raw2, stream2 = own_stream()                                               # and a fresh capture works
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2, stream=stream2):
+        y2 = x * 3
+    g2.replay()
+    torch.cuda.synchronize()
+    assert float(y2.sum()) == 3072.0
