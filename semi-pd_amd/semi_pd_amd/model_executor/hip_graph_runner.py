@@ -5,6 +5,7 @@ hipGraphLaunch.  Padded slots use seq_len = 1 and write their KV to the dummy sl
 from __future__ import annotations
 
 import bisect
+import os
 from typing import Dict, List, Tuple
 
 import torch
@@ -109,6 +110,8 @@ class HipGraphRunner:
         try:
             with torch.cuda.graph(g, pool=self.pool, stream=self.stream):
                 out = run_once()
+                if os.environ.get("SEMIPD_TEST_FAIL_CAPTURE") == "1" and bs <= 4:
+                    out[1].sum().item()   # test hook (tests/test_gpu_engine.py): a synchronising call invalidates the capture
         except BaseException:
             # something in the step refused capture (a collective of this TP backend, say): the invalidated capture
             # poisons every later synchronising call of the process until its stream is destroyed

@@ -302,6 +302,23 @@ def test_semi_pd_tp2_on_one_gpu_matches_oracle(unified_llama):
             eng.shutdown()
 
 
+def test_tp2_falls_back_to_eager_decode_when_a_capture_fails(unified_llama, monkeypatch):
+    """A TP backend whose collectives refuse stream capture must cost the graphs, not the engine: the decode instances
+    abort the half-made capture (their own stream, destroyed), recover the process and serve eagerly -- same tokens."""
+    from semi_pd_amd.entrypoints.engine import Engine
+    from semi_pd_amd.managers.io_struct import SamplingParams
+    cfg, sd, prompts, outs, _ = unified_llama
+    oracle = OracleLlama(cfg, sd)
+    monkeypatch.setenv("SEMIPD_TEST_FAIL_CAPTURE", "1")
+    eng = Engine(server_args(cfg, tp_size=2, enable_semi_pd=True, dist_backend="gloo"), gpu_ids={0: 0, 1: 0})
+    try:
+        semi = eng.generate(prompts, SamplingParams(max_new_tokens=8, ignore_eos=True), timeout=600)
+        assert all(len(o) == 8 for o in semi)
+        check_against_oracle(oracle, prompts, semi)
+    finally:
+        eng.shutdown()
+
+
 def test_launch_server_semi_pd_http(unified_llama, tmp_path):
     """`python -m sglang.launch_server --model-path <dir> --enable-semi-pd` (the reference's launch line,
     served here by the alias module) with dummy weights: greedy /generate and /v1/completions return the
