@@ -478,8 +478,7 @@ def main():
                              **saturation}
     if tp_world > 1:
         L, H = cfg.num_hidden_layers, cfg.hidden_size
-        out["tensor_parallel"] = {"tp_world": tp_world, "ranks": world, "backend": "rccl (nccl backend of torch.distributed) + "
-                                  "peer-memory all-reduce kernels for payloads up to 16 MB",
+        out["tensor_parallel"] = {"tp_world": tp_world, "ranks": world, "backend": ("gloo (one-GPU functional check)" if sa.dist_backend == "gloo" else "rccl (nccl backend of torch.distributed)") + " + peer-memory all-reduce kernels for payloads up to 16 MB",
                                   "all_reduce_calls_per_forward": 2 * L + 1,
                                   "all_reduce_bytes_per_token": (2 * L + 1) * H * 2,
                                   "logits_all_gather_bytes_per_request": cfg.vocab_size * 4}
