@@ -105,6 +105,18 @@ int semipd_rope_kv_store(void* q, void* k, const void* v, void* k_buf, void* v_b
                          int64_t v_stride, int64_t kbuf_stride, int64_t vbuf_stride, int interleave,
                          int dtype, int kv_dtype, void* stream);
 
+/* semipd_rope_kv_store for a decode batch whose qkv row is still the K-slice planes of semipd_stream_linear_planes:
+ * planes [n_planes][num_tokens][(Hq + 2 Hk) * head] fp32 (plane stride plane_elems) are summed in slice order and
+ * rounded to dtype -- the bits the GEMM's own reduction writes -- then q is rotated into q_out [num_tokens, q_stride],
+ * k rotated into k_buf[loc[t]], v copied into v_buf[loc[t]].  neox pairing over the whole head (rot_dim == head_size).
+ * One launch instead of the reduction + semipd_rope_kv_store; same bits.
+ * replaces QKVParallelLinear.forward's output write + RotaryEmbedding.forward_cuda + set_kv_buffer for decode batches
+ *   (layers/linear.py:165-172; layers/rotary_embedding.py:143-169; mem_cache/memory_pool.py:316-346). */
+int semipd_rope_kv_store_planes(void* q_out, const float* planes, int n_planes, int64_t plane_elems, void* k_buf,
+                                void* v_buf, const int64_t* loc, const float* cos_sin_cache, const int64_t* positions,
+                                int64_t num_tokens, int num_q_heads, int num_k_heads, int head_size, int64_t q_stride,
+                                int64_t kbuf_stride, int64_t vbuf_stride, int dtype, int kv_dtype, void* stream);
+
 /* buf[loc[t], :row_elems] = src[t, :row_elems]   (byte-exact row scatter)
  * replaces MHATokenToKVPool.set_kv_buffer / MLATokenToKVPool.set_kv_buffer
  *   (mem_cache/memory_pool.py:316-346, 439-452). loc is int64 (out_cache_loc). */

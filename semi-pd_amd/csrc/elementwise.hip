@@ -319,6 +319,70 @@ __global__ void rope_vec_kernel(T* __restrict__ q, T* __restrict__ k, const T* _
   }
 }
 
+// Decode-step form for a qkv row that is still K-slice planes of the streaming GEMM (stream_linear.hip): the fp32 planes
+// [n_planes][tokens][Hq*head + 2*Hk*head] are summed in slice order and rounded to T -- the bits splitk_planes_reduce
+// would have written -- then q is rotated into q_out, k rotated into the pool, v copied into the pool.  One launch
+// instead of the reduction + rope_vec_kernel; neox pairing, rot_dim == head (Llama-shaped heads).
+template <typename T, typename KV = T>
+__global__ void rope_planes_kernel(T* __restrict__ q_out, const float* __restrict__ planes, int n_planes,
+                                   int64_t plane_elems, int64_t row_elems, KV* __restrict__ k_buf, KV* __restrict__ v_buf,
+                                   const int64_t* __restrict__ loc, const float* __restrict__ cache,
+                                   const int64_t* __restrict__ positions, int Hq, int Hk, int head, int64_t q_stride,
+                                   int64_t kbuf_stride, int64_t vbuf_stride) {
+  constexpr int V = Elem<T>::kVec;
+  static_assert(V == 8, "16-bit activations");
+  const int64_t t = blockIdx.x;
+  const float* cs = cache + positions[t] * head;
+  const int64_t dst = loc[t];
+  const int half = head >> 1, items_per_head = half / V;
+  const float* row = planes + t * row_elems;
+  auto sum8 = [&](int64_t col, float (&f)[8]) {
+    const float* p = row + col;
+    float4 lo = *reinterpret_cast<const float4*>(p), hi = *reinterpret_cast<const float4*>(p + 4);
+    for (int z = 1; z < n_planes; ++z) {
+      const float4 l2 = *reinterpret_cast<const float4*>(p + z * plane_elems);
+      const float4 h2 = *reinterpret_cast<const float4*>(p + z * plane_elems + 4);
+      lo.x += l2.x; lo.y += l2.y; lo.z += l2.z; lo.w += l2.w;
+      hi.x += h2.x; hi.y += h2.y; hi.z += h2.z; hi.w += h2.w;
+    }
+    f[0] = lo.x; f[1] = lo.y; f[2] = lo.z; f[3] = lo.w; f[4] = hi.x; f[5] = hi.y; f[6] = hi.z; f[7] = hi.w;
+  };
+  const int qk_items = (Hq + Hk) * items_per_head;
+  for (int it = threadIdx.x; it < qk_items; it += blockDim.x) {
+    const int h = it / items_per_head, i0 = (it - h * items_per_head) * V;
+    float fa[8], fb[8];
+    sum8((int64_t)h * head + i0, fa);
+    sum8((int64_t)h * head + half + i0, fb);
+    Vec16<T> oa, ob;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const float c = cs[i0 + j], sn = cs[half + i0 + j];
+      const float x1 = Elem<T>::to_f(Elem<T>::from_f(fa[j])), x2 = Elem<T>::to_f(Elem<T>::from_f(fb[j]));
+      oa.e[j] = Elem<T>::from_f(x1 * c - x2 * sn);
+      ob.e[j] = Elem<T>::from_f(x2 * c + x1 * sn);
+    }
+    if (h < Hq) {
+      T* qh = q_out + t * q_stride + (int64_t)h * head;
+      store16(qh + i0, oa);
+      store16(qh + half + i0, ob);
+    } else {
+      KV* kh = k_buf + dst * kbuf_stride + (int64_t)(h - Hq) * head;
+      KVTraits<T, KV>::store8(kh + i0, oa);
+      KVTraits<T, KV>::store8(kh + half + i0, ob);
+    }
+  }
+  const int v_vec = Hk * head / V;
+  const int64_t v_col0 = (int64_t)(Hq + Hk) * head;
+  for (int it = threadIdx.x; it < v_vec; it += blockDim.x) {
+    float f[8];
+    sum8(v_col0 + (int64_t)it * V, f);
+    Vec16<T> a;
+#pragma unroll
+    for (int j = 0; j < V; ++j) a.e[j] = Elem<T>::from_f(f[j]);
+    KVTraits<T, KV>::store8(v_buf + dst * vbuf_stride + (int64_t)it * V, a);
+  }
+}
+
 // scalar fallback: any rot_dim (even), any alignment
 template <typename T, bool STORE, typename KV = T>
 __global__ void rope_scalar_kernel(T* __restrict__ q, T* __restrict__ k, const T* __restrict__ v,
@@ -849,6 +913,40 @@ int semipd_rope_kv_store(void* q, void* k, const void* v, void* k_buf, void* v_b
                    "rope_kv_store: null pointer");
   SEMIPD_DISPATCH_DTYPE(dtype, T, return (rope_kv_store_dispatch<T>(q, k, v, k_buf, v_buf, loc, cos_sin_cache, positions, num_tokens, num_q_heads, num_k_heads, head_size, v_head_size, rot_dim, q_stride, k_stride, v_stride, kbuf_stride, vbuf_stride, interleave, dtype, kv_dtype, as_stream(stream))));
   return 0;
+}
+
+int semipd_rope_kv_store_planes(void* q_out, const float* planes, int n_planes, int64_t plane_elems, void* k_buf,
+                                void* v_buf, const int64_t* loc, const float* cos_sin_cache, const int64_t* positions,
+                                int64_t num_tokens, int num_q_heads, int num_k_heads, int head_size, int64_t q_stride,
+                                int64_t kbuf_stride, int64_t vbuf_stride, int dtype, int kv_dtype, void* stream) {
+  SEMIPD_CHECK_ARG(num_tokens >= 0 && head_size > 0 && n_planes >= 1 && num_q_heads > 0 && num_k_heads > 0, SEMIPD_EINVAL,
+                   "rope_kv_store_planes: bad sizes");
+  if (num_tokens == 0) return 0;
+  SEMIPD_CHECK_ARG(q_out && planes && k_buf && v_buf && loc && cos_sin_cache && positions, SEMIPD_EINVAL,
+                   "rope_kv_store_planes: null pointer");
+  const int64_t row_elems = (int64_t)(num_q_heads + 2 * num_k_heads) * head_size;
+  SEMIPD_CHECK_ARG(head_size % 16 == 0 && q_stride % 8 == 0 && kbuf_stride % 16 == 0 && vbuf_stride % 16 == 0 &&
+                   plane_elems % 4 == 0 && plane_elems >= num_tokens * row_elems && aligned16(q_out) && aligned16(planes) &&
+                   aligned16(k_buf) && aligned16(v_buf), SEMIPD_EALIGN,
+                   "rope_kv_store_planes: head_size %% 16, 16-byte aligned rows required");
+  SEMIPD_CHECK_ARG(dtype == SEMIPD_BF16 || dtype == SEMIPD_F16, SEMIPD_EDTYPE, "rope_kv_store_planes: bf16 / f16 activations");
+  hipStream_t st = as_stream(stream);
+  dim3 grid((unsigned)num_tokens), block(256);
+#define RPK(TT, KVT)                                                                                                  \
+  hipLaunchKernelGGL((rope_planes_kernel<TT, KVT>), grid, block, 0, st, (TT*)q_out, planes, n_planes, plane_elems,      \
+                     row_elems, (KVT*)k_buf, (KVT*)v_buf, loc, cos_sin_cache, positions, num_q_heads, num_k_heads,     \
+                     head_size, q_stride, kbuf_stride, vbuf_stride)
+  SEMIPD_DISPATCH_HALF(dtype, T, {
+    if (kv_dtype == dtype) RPK(T, T);
+    else if (kv_dtype == SEMIPD_F8E5M2) RPK(T, f8e5m2_t);
+    else if (kv_dtype == SEMIPD_F8E4M3) RPK(T, f8e4m3_t);
+    else {
+      set_error("rope_kv_store_planes: unsupported kv_dtype %d", kv_dtype);
+      return SEMIPD_EDTYPE;
+    }
+  });
+#undef RPK
+  return launch_status("rope_kv_store_planes");
 }
 
 int semipd_kv_store_cvt(void* buf, const void* src, const int64_t* loc, int64_t num_tokens, int64_t row_elems,

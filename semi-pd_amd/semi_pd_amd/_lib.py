@@ -40,6 +40,8 @@ _SIGNATURES = {
     "semipd_rope_inplace_strided": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _i32, _i32, _vp],
     "semipd_rope_kv_store": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32,
                              _i64, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _vp],
+    "semipd_rope_kv_store_planes": [_vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i64, _i64, _i64,
+                                    _i32, _i32, _vp],
     "semipd_kv_store": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp],
     "semipd_kv_store_cvt": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _vp],
     "semipd_build_kv_indices": [_vp, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _vp],

@@ -88,6 +88,15 @@ class RotaryEmbedding(nn.Module):
                               self.is_neox_style, k_buffer, v_buffer, loc)
         return query, key
 
+    def supports_planes(self) -> bool:
+        return self.is_neox_style and self.rotary_dim == self.head_size and self.head_size % 16 == 0
+
+    def forward_and_store_planes(self, positions, qkv_planes, num_q_heads, num_kv_heads, k_buffer, v_buffer, loc):
+        """Decode batches: the qkv GEMM stopped before its K-slice reduction; one kernel sums the planes, rotates q and
+        k and stores k / v (ops.rope_and_store_kv_planes).  Returns q."""
+        return ops.rope_and_store_kv_planes(positions, qkv_planes, num_q_heads, num_kv_heads, self.head_size,
+                                            self.cos_sin_cache, k_buffer, v_buffer, loc)
+
 
 class Llama3RotaryEmbedding(RotaryEmbedding):
     def __init__(self, head_size, rotary_dim, max_position_embeddings, base, is_neox_style, dtype,
@@ -288,6 +297,15 @@ class ColumnParallelLinear(nn.Module):
             return apply_w8a8_block_fp8_linear(x, self.weight, self.quant_config.weight_block_size,
                                                self.weight_scale_inv, self.bias, x_quant=x_quant)
         return dense_linear(x, self.weight, self.bias)
+
+    def forward_planes(self, x):
+        """Decode batches of an unquantised, bias-free layer: the K-slice planes of the streaming GEMM (ops.SplitKPlanes)
+        for a consumer that sums them itself, or None when this call is not eligible."""
+        if (_STREAM_LINEAR["enabled"] and self.quant_config is None and self.bias is None and x.dim() == 2
+                and x.shape[0] <= ops.STREAM_LINEAR_MAX_ROWS and self.weight.shape[0] % 8 == 0
+                and ops.stream_linear_is_supported(x, self.weight)):
+            return _timed_stream(lambda: ops.stream_linear_planes(x, self.weight), x, self.weight, self.weight.shape[0], 1)
+        return None
 
 
 class ReplicatedLinear(ColumnParallelLinear):

@@ -78,9 +78,19 @@ class LlamaAttention(nn.Module):
         del tp
 
     def forward(self, positions, hidden_states, forward_batch):
+        pool = forward_batch.token_to_kv_pool
+        if forward_batch.forward_mode.is_decode() and self.rotary_emb.supports_planes():
+            # decode: the qkv GEMM stops before its K-slice reduction and the RoPE + KV-store kernel sums the planes
+            planes = self.qkv_proj.forward_planes(hidden_states)
+            if planes is not None:
+                q = self.rotary_emb.forward_and_store_planes(positions, planes, self.num_heads, self.num_kv_heads,
+                                                             pool.get_key_buffer(self.attn.layer_id),
+                                                             pool.get_value_buffer(self.attn.layer_id),
+                                                             forward_batch.out_cache_loc)
+                attn_output = self.attn(q, None, None, forward_batch, save_kv_cache=False)
+                return self.o_proj(attn_output, defer_reduce=True)
         qkv = self.qkv_proj(hidden_states)
         q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
-        pool = forward_batch.token_to_kv_pool
         # RoPE + set_kv_buffer in one launch (rotary_embedding.py:143-169 + memory_pool.py:316-346)
         self.rotary_emb.forward_and_store(positions, q, k, v, pool.get_key_buffer(self.attn.layer_id),
                                           pool.get_value_buffer(self.attn.layer_id), forward_batch.out_cache_loc)

@@ -422,6 +422,26 @@ def stream_linear_planes(x: torch.Tensor, weight: torch.Tensor) -> SplitKPlanes:
     return SplitKPlanes(ws, int(ks.value), M, N, x.dtype)
 
 
+def rope_and_store_kv_planes(positions: torch.Tensor, qkv: SplitKPlanes, num_q_heads: int, num_kv_heads: int,
+                             head_size: int, cos_sin_cache: torch.Tensor, k_buffer: torch.Tensor, v_buffer: torch.Tensor,
+                             loc: torch.Tensor) -> torch.Tensor:
+    """rope_and_store_kv on a qkv row that is still the K-slice planes of the decode GEMM: returns the rotated q
+    [tokens, Hq * head]; rotated k and v go to the pool rows `loc` (semipd_rope_kv_store_planes)."""
+    if cos_sin_cache.dtype != torch.float32 or cos_sin_cache.shape[1] != head_size:
+        raise RuntimeError("rope_and_store_kv_planes: fp32 cos / sin cache over the whole head expected")
+    if qkv.n != (num_q_heads + 2 * num_kv_heads) * head_size:
+        raise RuntimeError("rope_and_store_kv_planes: planes do not hold a [q | k | v] row")
+    if positions.dtype != torch.int64:
+        positions = positions.long()
+    q = torch.empty((qkv.rows, num_q_heads * head_size), dtype=qkv.dtype, device=qkv.planes.device)
+    check(_lib.load().semipd_rope_kv_store_planes(ptr(q), ptr(qkv.planes), qkv.ksplit, qkv.rows * qkv.n, ptr(k_buffer),
+                                                  ptr(v_buffer), ptr(loc), ptr(cos_sin_cache), ptr(positions), qkv.rows,
+                                                  num_q_heads, num_kv_heads, head_size, q.stride(0), k_buffer.stride(0),
+                                                  v_buffer.stride(0), dtype_code(qkv.dtype), _lib.kv_dtype_code(k_buffer.dtype),
+                                                  current_stream(q.device)), "rope_and_store_kv_planes")
+    return q
+
+
 def fused_add_rmsnorm_planes(p: SplitKPlanes, residual: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
     """residual += T(sum of the planes); returns RMSNorm(residual) * weight -- fused_add_rmsnorm on the GEMM output
     that was never written (layers/layernorm.py:47-76)."""

@@ -834,3 +834,35 @@ def test_abort_of_a_failed_stream_capture(device):
     g2.replay()
     torch.cuda.synchronize()
     assert float(y2.sum()) == 3072.0
+
+
+@pytest.mark.parametrize("M", [1, 7, 33, 64])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("kv_dtype", [None, torch.float8_e4m3fn])
+def test_rope_and_store_kv_from_the_qkv_planes(ops, device, M, dtype, kv_dtype):
+    """Decode step: the qkv GEMM stopped before its K-slice reduction + ONE kernel that sums the planes, rotates q / k
+    and stores k / v has the bits of stream_linear followed by rope_and_store_kv (q, and the pool rows)."""
+    torch.manual_seed(M)
+    Hq, Hk, D, K = 32, 8, 128, 4096
+    x = torch.randn(M, K, device=device).to(dtype)
+    w = (torch.randn((Hq + 2 * Hk) * D, K, device=device) * 0.03).to(dtype)
+    pos = torch.randint(0, 4000, (M,), device=device, dtype=torch.int64)
+    inv = 1.0 / (10000 ** (torch.arange(0, D, 2, dtype=torch.float) / D))
+    fr = torch.einsum("i,j -> ij", torch.arange(4096, dtype=torch.float), inv)
+    cache = torch.cat((fr.cos(), fr.sin()), dim=-1).to(device)
+    pool_dtype = kv_dtype or dtype
+    loc = torch.randperm(200, device=device)[:M].to(torch.int64)
+
+    def pools():
+        return (torch.zeros(200, Hk, D, device=device).to(pool_dtype), torch.zeros(200, Hk, D, device=device).to(pool_dtype))
+
+    kb1, vb1 = pools()
+    qkv = ops.stream_linear(x, w)
+    q1, k1, v1 = qkv.split([Hq * D, Hk * D, Hk * D], dim=-1)
+    ops.rope_and_store_kv(pos, q1, k1, v1, D, cache, True, kb1, vb1, loc)
+    kb2, vb2 = pools()
+    planes = ops.stream_linear_planes(x, w)
+    assert planes.ksplit > 1
+    q2 = ops.rope_and_store_kv_planes(pos, planes, Hq, Hk, D, cache, kb2, vb2, loc)
+    assert torch.equal(q2.view(torch.int16), q1.contiguous().view(torch.int16))
+    assert torch.equal(kb2.view(torch.uint8), kb1.view(torch.uint8)) and torch.equal(vb2.view(torch.uint8), vb1.view(torch.uint8))
