@@ -50,7 +50,7 @@ template <int D, typename Raw> struct KRegs {
 };
 
 template <typename T, int D, typename KV>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, D <= 128 ? 2 : 1)   // D = 256 needs > 256 registers: one workgroup per SIMD set instead of 672 B of scratch
 decode_mfma_kernel(T* __restrict__ out, const T* __restrict__ q, const KV* __restrict__ k_buf,
                    const KV* __restrict__ v_buf, const int32_t* __restrict__ kv_indptr,
                    const int32_t* __restrict__ kv_indices, float* __restrict__ attn_logits,
