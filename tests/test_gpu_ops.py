@@ -389,6 +389,34 @@ def test_extend_attention_shared_kv(ops, device, pre, ext, Hq, Hkv, dtype):
     _close(o, want, dtype, rtol=2e-2, atol=4e-3 if dtype == torch.float16 else 1.5e-2)
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_extend_attention_shared_kv_random_batches(ops, device, seed):
+    """Seeded random batches through the shared-KV kernel (both forms by grid size): 1-6 requests, prefixes 0-700 (several
+    128-row tiles, odd and even counts), 1-900 new tokens, the head layouts of the models in scope."""
+    rng = np.random.RandomState(1000 + seed)
+    Hq, Hkv = [(4, 1), (8, 2), (6, 3), (3, 3), (16, 2), (32, 8)][seed % 6]
+    dtype = [torch.bfloat16, torch.float16][seed % 2]
+    B = int(rng.randint(1, 7))
+    pre = [int(rng.choice([0, 0, rng.randint(1, 130), rng.randint(130, 700)])) for _ in range(B)]
+    ext = [int(rng.choice([1, rng.randint(2, 65), rng.randint(65, 300), rng.randint(300, 900)])) for _ in range(B)]
+    D = 128
+    k_buf, v_buf, kv_indptr, kv_indices = _paged(B, pre, Hkv, D, D, dtype, seed=seed)
+    T = sum(ext)
+    qo_indptr = torch.zeros(B + 1, dtype=torch.int32)
+    qo_indptr[1:] = torch.cumsum(torch.tensor(ext), 0)
+    torch.manual_seed(seed)
+    q = torch.randn(T, Hq, D).to(dtype)
+    k = torch.randn(T, Hkv, D).to(dtype)
+    v = torch.randn(T, Hkv, D).to(dtype)
+    o = torch.full((T, Hq, D), float("nan"), dtype=dtype, device=device)
+    sm_scale = 1.0 / (D ** 0.5)
+    ops.extend_attention_fwd(q.to(device), k.to(device), v.to(device), o, k_buf.to(device), v_buf.to(device),
+                             qo_indptr.to(device), kv_indptr.to(device), kv_indices.to(device), None, None, max(ext),
+                             sm_scale, 0.0)
+    want = O.extend_attention(q, k, v, k_buf, v_buf, qo_indptr, kv_indptr, kv_indices, sm_scale, 0.0)
+    _close(o, want, dtype, rtol=2e-2, atol=4e-3 if dtype == torch.float16 else 1.5e-2)
+
+
 @pytest.mark.parametrize("fixture", ["extend_attention", "extend_attention_8c"])
 def test_extend_attention_golden(ops, device, fixture):
     g = load_golden(fixture)
