@@ -346,6 +346,17 @@ int semipd_moe_grouped_gemm(void* c, const void* a, const void* w, const float* 
                             int64_t k, int64_t max_sorted, int top_k_div, int mul_routed_weight,
                             int block_m, int dtype, void* stream);
 
+/* GEMM1 of fused_experts with the activation in its epilogue, for prefill-sized calls (the tiled kernel):
+ *   c[sorted id, :n/2] = silu(T(A W_gate^T)) * T(A W_up^T),   w = [E, n, k], gate rows first
+ * -- the bits of semipd_moe_grouped_gemm followed by semipd_silu_and_mul (whose input is the GEMM's rounded output),
+ * without the [T*k, n] intermediate.  semipd_moe_grouped_gemm_silu_supported says whether a call qualifies (block_m 128,
+ * at least 2048 routed rows, k % 64 == 0, n % 64 == 0, bf16 / f16); other calls keep the two separate entry points.
+ * replaces invoke_fused_moe_kernel + SiluAndMul inside fused_experts_impl (fused_moe.py:1085-1125). */
+int semipd_moe_grouped_gemm_silu_supported(int64_t num_valid, int64_t n, int64_t k, int top_k_div, int block_m, int dtype);
+int semipd_moe_grouped_gemm_silu(void* c, const void* a, const void* w, const int32_t* sorted_token_ids,
+                                 const int32_t* expert_ids, const int32_t* num_tokens_post_pad, int64_t num_valid, int64_t n,
+                                 int64_t k, int64_t max_sorted, int top_k_div, int block_m, int dtype, void* stream);
+
 /* out[t,:] = sum_j in[t,j,:]   (vllm moe_sum, fused_moe.py:1144-1148) */
 int semipd_moe_sum(void* out, const void* in, int64_t num_tokens, int topk, int64_t hidden,
                    int dtype, void* stream);

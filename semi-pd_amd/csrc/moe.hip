@@ -401,6 +401,11 @@ template <typename T>
 int launch_moe_tiled_gemm(T* c, const T* a, const T* w, const float* topk_weights, const int32_t* sorted_ids,
                           const int32_t* expert_ids, const int32_t* num_post_pad, int64_t num_valid, int64_t n, int64_t k,
                           int64_t max_sorted, int top_k_div, int mul_routed_weight, hipStream_t st);
+bool moe_tiled_gemm_silu_supported(int64_t num_valid, int64_t n, int64_t k, int top_k_div);
+template <typename T>
+int launch_moe_tiled_gemm_silu(T* c, const T* a, const T* w, const int32_t* sorted_ids, const int32_t* expert_ids,
+                               const int32_t* num_post_pad, int64_t num_valid, int64_t n, int64_t k, int64_t max_sorted,
+                               int top_k_div, hipStream_t st);
 }  // namespace semipd
 
 using namespace semipd;
@@ -509,6 +514,31 @@ int semipd_moe_grouped_gemm(void* c, const void* a, const void* w, const float* 
     SEMIPD_DISPATCH_HALF(dtype, T, hipLaunchKernelGGL((gemm_nt_kernel<T, T, true, 128>), grid, dim3(256), 0, as_stream(stream), (T*)c, (const T*)a, (const T*)w, topk_weights, sorted_token_ids, expert_ids, num_tokens_post_pad, num_valid, (int64_t)0, n, k, k, n, top_k_div, mul_routed_weight));
   }
   return launch_status("moe_grouped_gemm");
+}
+
+int semipd_moe_grouped_gemm_silu_supported(int64_t num_valid, int64_t n, int64_t k, int top_k_div, int block_m, int dtype) {
+  static const bool tiled_on = [] { const char* e = getenv("SEMIPD_MOE_TILED"); return !(e && e[0] == '0'); }();
+  return tiled_on && block_m == 128 && num_valid >= 2048 && (dtype == SEMIPD_BF16 || dtype == SEMIPD_F16) &&
+         moe_tiled_gemm_silu_supported(num_valid, n, k, top_k_div) ? 1 : 0;
+}
+
+int semipd_moe_grouped_gemm_silu(void* c, const void* a, const void* w, const int32_t* sorted_token_ids,
+                                 const int32_t* expert_ids, const int32_t* num_tokens_post_pad, int64_t num_valid, int64_t n,
+                                 int64_t k, int64_t max_sorted, int top_k_div, int block_m, int dtype, void* stream) {
+  SEMIPD_CHECK_ARG(n > 0 && k > 0 && num_valid >= 0 && max_sorted >= 0 && top_k_div > 0, SEMIPD_EINVAL,
+                   "moe_grouped_gemm_silu: bad sizes");
+  if (num_valid == 0 || max_sorted == 0) return 0;
+  SEMIPD_CHECK_ARG(c && a && w && sorted_token_ids && expert_ids && num_tokens_post_pad, SEMIPD_EINVAL,
+                   "moe_grouped_gemm_silu: null pointer");
+  SEMIPD_CHECK_ARG(semipd_moe_grouped_gemm_silu_supported(num_valid, n, k, top_k_div, block_m, dtype), SEMIPD_ESHAPE,
+                   "moe_grouped_gemm_silu: prefill-sized calls only (block_m 128, >= 2048 routed rows, k %% 64, n %% 64); "
+                   "use semipd_moe_grouped_gemm + semipd_silu_and_mul");
+  SEMIPD_CHECK_ARG(aligned16(a) && aligned16(w) && (reinterpret_cast<uintptr_t>(c) & 7u) == 0, SEMIPD_EALIGN,
+                   "moe_grouped_gemm_silu: unaligned pointer");
+  int miss = 1;
+  SEMIPD_DISPATCH_HALF(dtype, T, miss = (launch_moe_tiled_gemm_silu<T>((T*)c, (const T*)a, (const T*)w, sorted_token_ids, expert_ids, num_tokens_post_pad, num_valid, n, k, max_sorted, top_k_div, as_stream(stream))));
+  SEMIPD_CHECK_ARG(!miss, SEMIPD_ESHAPE, "moe_grouped_gemm_silu: shape not covered");
+  return launch_status("moe_grouped_gemm_silu");
 }
 
 size_t semipd_lm_head_argmax_workspace(int64_t batch, int64_t vocab) {

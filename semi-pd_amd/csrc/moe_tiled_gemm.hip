@@ -81,20 +81,29 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 #define MTG_NT 2
 #define MTG_BK 64
 #define MTG_RING 3
+#define MTG_SILU 0
+#include "moe_tiled_gemm_kernel.inc"
+#undef MTG_KERNEL_NAME
+#undef MTG_SILU
+#define MTG_KERNEL_NAME moe_tiled_gemm_silu_kernel_128x128
+#define MTG_SILU 1
 #include "moe_tiled_gemm_kernel.inc"
 #undef MTG_KERNEL_NAME
 #undef MTG_NT
 #undef MTG_BK
 #undef MTG_RING
+#undef MTG_SILU
 #define MTG_KERNEL_NAME moe_tiled_gemm_kernel_128x512
 #define MTG_NT 4
 #define MTG_BK 32
 #define MTG_RING 4
+#define MTG_SILU 0
 #include "moe_tiled_gemm_kernel.inc"
 #undef MTG_KERNEL_NAME
 #undef MTG_NT
 #undef MTG_BK
 #undef MTG_RING
+#undef MTG_SILU
 
 // 0 = launched, 1 = shape not covered (the caller keeps the streaming kernel)
 template <typename T>
@@ -131,6 +140,41 @@ int launch_moe_tiled_gemm(T* c, const T* a, const T* w, const float* topk_weight
 #undef MTG
   return 0;
 }
+
+// GEMM1 of the fused MoE with SiluAndMul in the epilogue: c [num_valid, n / 2] = silu(T(A W_gate^T)) * T(A W_up^T), w = [E, n, k]
+// with the gate rows first.  0 = launched, 1 = shape not covered.
+bool moe_tiled_gemm_silu_supported(int64_t num_valid, int64_t n, int64_t k, int top_k_div) {
+  const int64_t a_rows = (num_valid + top_k_div - 1) / top_k_div;
+  return k % 64 == 0 && n % 64 == 0 && a_rows * k * 2 < (1ll << 31) && (n / 2 + 128) * k * 2 < (1ll << 31) &&
+         num_valid < (1ll << 31);
+}
+
+template <typename T>
+int launch_moe_tiled_gemm_silu(T* c, const T* a, const T* w, const int32_t* sorted_ids, const int32_t* expert_ids,
+                               const int32_t* num_post_pad, int64_t num_valid, int64_t n, int64_t k, int64_t max_sorted,
+                               int top_k_div, hipStream_t st) {
+  using namespace mtg;
+  if (!moe_tiled_gemm_silu_supported(num_valid, n, k, top_k_div)) return 1;
+  using CF = Cfg<2, 64, 3>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)moe_tiled_gemm_silu_kernel_128x128<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              CF::kLds);
+    attr_set = true;
+  }
+  const int64_t a_rows = (num_valid + top_k_div - 1) / top_k_div;
+  const int64_t y_max = (max_sorted + kBM - 1) / kBM, y_per = (y_max + 7) / 8, chunks = (y_per + kChunk - 1) / kChunk;
+  const int64_t gx = (n / 2 + CF::kBN / 2 - 1) / (CF::kBN / 2);
+  dim3 grid((unsigned)(8 * chunks * kChunk * gx));
+  hipLaunchKernelGGL((moe_tiled_gemm_silu_kernel_128x128<T>), grid, dim3(512), CF::kLds, st, c, a, w, (const float*)nullptr,
+                     sorted_ids, expert_ids, num_post_pad, (int)num_valid, (int)n, (int)k, top_k_div, 0, (int)a_rows);
+  return 0;
+}
+
+template int launch_moe_tiled_gemm_silu<bf16_t>(bf16_t*, const bf16_t*, const bf16_t*, const int32_t*, const int32_t*,
+                                                const int32_t*, int64_t, int64_t, int64_t, int64_t, int, hipStream_t);
+template int launch_moe_tiled_gemm_silu<f16_t>(f16_t*, const f16_t*, const f16_t*, const int32_t*, const int32_t*,
+                                               const int32_t*, int64_t, int64_t, int64_t, int64_t, int, hipStream_t);
 
 template int launch_moe_tiled_gemm<bf16_t>(bf16_t*, const bf16_t*, const bf16_t*, const float*, const int32_t*, const int32_t*,
                                            const int32_t*, int64_t, int64_t, int64_t, int64_t, int, int, hipStream_t);

@@ -78,6 +78,8 @@ _SIGNATURES = {
     "semipd_moe_align_block_size": [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp],
     "semipd_moe_grouped_gemm": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32,
                                 _i32, _i32, _vp],
+    "semipd_moe_grouped_gemm_silu_supported": [_i64, _i64, _i64, _i32, _i32, _i32],
+    "semipd_moe_grouped_gemm_silu": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _vp],
     "semipd_moe_sum": [_vp, _vp, _i64, _i32, _i64, _i32, _vp],
     "semipd_per_token_group_quant_fp8": [_vp, _vp, _vp, _i64, _i64, _i32, C.c_float, _i32, _vp],
     "semipd_fused_add_rmsnorm_quant_fp8": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, C.c_float, _i32, C.c_float, _i32, _vp],

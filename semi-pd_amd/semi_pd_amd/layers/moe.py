@@ -70,10 +70,13 @@ def fused_experts(hidden_states: torch.Tensor, w1: torch.Tensor, w2: torch.Tenso
     num_post_pad = torch.empty(1, dtype=torch.int32, device=dev)
     cumsum = torch.empty(E + 1, dtype=torch.int32, device=dev)
     ops.moe_align_block_size(topk_ids, E, block_m, sorted_ids, expert_ids, num_post_pad, None, cumsum)
-    c1 = torch.empty((numel, N2), dtype=dt, device=dev)
-    ops.moe_grouped_gemm(hidden_states, w1, c1, None, sorted_ids, expert_ids, num_post_pad, numel, topk, False,
-                         block_m)
-    c2 = ops.silu_and_mul(c1)
+    # prefill-sized calls: SiLU * mul in GEMM1's epilogue (no [T * k, 2N] intermediate); same bits as the two calls
+    c2 = ops.moe_grouped_gemm_silu(hidden_states, w1, sorted_ids, expert_ids, num_post_pad, numel, topk, block_m)
+    if c2 is None:
+        c1 = torch.empty((numel, N2), dtype=dt, device=dev)
+        ops.moe_grouped_gemm(hidden_states, w1, c1, None, sorted_ids, expert_ids, num_post_pad, numel, topk, False,
+                             block_m)
+        c2 = ops.silu_and_mul(c1)
     c3 = (torch.zeros if partial_experts else torch.empty)((numel, K), dtype=dt, device=dev)
     ops.moe_grouped_gemm(c2, w2, c3, topk_weights.reshape(-1), sorted_ids, expert_ids, num_post_pad, numel, 1, True,
                          block_m)

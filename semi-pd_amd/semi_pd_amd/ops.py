@@ -621,6 +621,23 @@ def moe_grouped_gemm(a: torch.Tensor, w: torch.Tensor, c: torch.Tensor,
           "moe_grouped_gemm")
 
 
+def moe_grouped_gemm_silu(a: torch.Tensor, w: torch.Tensor, sorted_token_ids: torch.Tensor, expert_ids: torch.Tensor,
+                          num_tokens_post_pad: torch.Tensor, num_valid: int, top_k_div: int,
+                          block_m: int = 128) -> Optional[torch.Tensor]:
+    """GEMM1 of fused_experts with SiluAndMul in its epilogue (semipd_moe_grouped_gemm_silu): [num_valid, N / 2], or None
+    when the call does not qualify (the caller then runs moe_grouped_gemm + silu_and_mul)."""
+    E, N, K = w.shape
+    lib = _lib.load()
+    if a.shape[-1] != K or not (a.is_contiguous() and w.is_contiguous()) or not lib.semipd_moe_grouped_gemm_silu_supported(
+            num_valid, N, K, top_k_div, block_m, dtype_code(a.dtype)):
+        return None
+    c = torch.empty((num_valid, N // 2), dtype=a.dtype, device=a.device)
+    check(lib.semipd_moe_grouped_gemm_silu(ptr(c), ptr(a), ptr(w), ptr(sorted_token_ids), ptr(expert_ids),
+                                           ptr(num_tokens_post_pad), num_valid, N, K, sorted_token_ids.numel(), top_k_div,
+                                           block_m, dtype_code(a.dtype), current_stream(a.device)), "moe_grouped_gemm_silu")
+    return c
+
+
 def moe_sum(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[t] = x[t].sum(0) for x [T, topk, H] (fused_moe.py:1144-1148)."""
     T, k, H = x.shape

@@ -692,6 +692,34 @@ def test_moe_grouped_gemm_prefill_sized_rows(ops, device, T, topk, E, N, K, dtyp
     torch.testing.assert_close(c.float().cpu(), want, rtol=tol, atol=tol * float(want.abs().max()))
 
 
+@pytest.mark.parametrize("T,topk,E,Nh,K", [(512, 6, 64, 1408, 2048), (700, 4, 8, 352, 192), (2100, 1, 3, 96, 64)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_moe_gemm1_with_silu_epilogue_has_the_bits_of_the_two_calls(ops, device, T, topk, E, Nh, K, dtype):
+    """semipd_moe_grouped_gemm_silu (prefill-sized calls) against semipd_moe_grouped_gemm + semipd_silu_and_mul, bit for
+    bit: partial last column tile (352, 96), short K, an expert without rows, ragged last blocks."""
+    torch.manual_seed(T + Nh)
+    numel = T * topk
+    a = (torch.randn(T, K) / 4).to(dtype).to(device)
+    w = (torch.randn(E, 2 * Nh, K) / 4).to(dtype).to(device)
+    gate = torch.randn(T, E)
+    if E > 4:
+        gate[:, 1] -= 100.0
+    tw, tid = ops.topk_softmax(gate.to(device), topk, True)
+    max_sorted = numel + E * 127
+    sorted_ids = torch.empty(max_sorted, dtype=torch.int32, device=device)
+    expert_ids = torch.empty((max_sorted + 127) // 128, dtype=torch.int32, device=device)
+    npp = torch.empty(1, dtype=torch.int32, device=device)
+    cumsum = torch.empty(E + 1, dtype=torch.int32, device=device)
+    ops.moe_align_block_size(tid, E, 128, sorted_ids, expert_ids, npp, None, cumsum)
+    fused = ops.moe_grouped_gemm_silu(a, w, sorted_ids, expert_ids, npp, numel, topk, 128)
+    assert fused is not None and fused.shape == (numel, Nh)
+    c1 = torch.empty(numel, 2 * Nh, dtype=dtype, device=device)
+    ops.moe_grouped_gemm(a, w, c1, None, sorted_ids, expert_ids, npp, numel, topk, False, 128)
+    want = ops.silu_and_mul(c1)
+    assert torch.equal(fused.view(torch.int16), want.view(torch.int16))
+    assert ops.moe_grouped_gemm_silu(a[:100], w, sorted_ids, expert_ids, npp, 100 * topk, topk, 128) is None   # decode-sized
+
+
 def test_fused_experts_layer_prefill_sized(ops, device):
     """layers.moe.fused_experts above the decode threshold (T * topk > 2048 -> 128-row blocks): many rows
     per expert, several blocks per expert, ragged last blocks."""
