@@ -123,12 +123,6 @@ extend_attn_shared_kv_kernel(T* __restrict__ out, const T* __restrict__ q_ext, c
       qf[ks].u = q_valid ? *reinterpret_cast<const uint4*>(qrow + ks * 16 + hi * 8) : make_uint4(0, 0, 0, 0);
   }
 
-  // the Q loads complete HERE: left pending into the loop, their wait lands in front of the first MFMA of every tile
-  // as vmcnt(0) and drains the DMA of the next tile
-#pragma unroll
-  for (int ks = 0; ks < 8; ++ks)
-    asm volatile("" : "+v"(qf[ks].w[0]), "+v"(qf[ks].w[1]), "+v"(qf[ks].w[2]), "+v"(qf[ks].w[3]));
-
   f32x16 o_acc[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t)
@@ -217,6 +211,24 @@ extend_attn_shared_kv_kernel(T* __restrict__ out, const T* __restrict__ q_ext, c
       }
     }
   };
+
+  // prologue, first part: the DMA of K(0) goes out while the Q rows are still in flight (one memory latency instead of two
+  // in front of the first tile -- a single 1024-token request is 8 tile steps long, the prologue is a third of its time)
+  // K(0), V(0) and K(1) all leave now (both stages of both rings are free): the first tile step then finds its V tile
+  // landed instead of waiting one more memory latency for it
+  load_idx(0);
+  issue_tile(std::false_type{}, 0, idx_k);
+  issue_tile(std::true_type{}, 0, idx_k);
+  load_idx(1);
+  if (1 < n_tiles) issue_tile(std::false_type{}, 1, idx_k);
+#pragma unroll
+  for (int j = 0; j < kPPW; ++j) idx_v[j] = idx_k[j];
+  load_idx(2);
+  // the Q loads complete HERE (before the lambdas below capture them): left pending into the loop, their wait lands in
+  // front of the first MFMA of every tile as vmcnt(0) and drains the DMA of the next tile
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks)
+    asm volatile("" : "+v"(qf[ks].w[0]), "+v"(qf[ks].w[1]), "+v"(qf[ks].w[2]), "+v"(qf[ks].w[3]));
 
   // ---- fragment addresses (stage / kv-block offsets are immediates) ----
   // K, A operand of S^T: lane (col, hi) reads row half*64 + kt*32 + col, chunk (ks*2 + hi) ^ (col & 15)
@@ -390,20 +402,10 @@ extend_attn_shared_kv_kernel(T* __restrict__ out, const T* __restrict__ q_ext, c
     finish_max(mx, live);
   };
 
-  // prologue: K(0); then K(1) and V(0) behind the first barrier; S^T(0) and A(0) without anything to overlap with
-  load_idx(0);
-  issue_tile(std::false_type{}, 0, idx_k);
-#pragma unroll
-  for (int j = 0; j < kPPW; ++j) idx_v[j] = idx_k[j];
-  load_idx(1);
+  // prologue, second part: S^T(0) and A(0) without anything to overlap with
   SKV_WAIT_VM0_AND(idx_k);
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
-  if (1 < n_tiles) issue_tile(std::false_type{}, 1, idx_k);
-  issue_tile(std::true_type{}, 0, idx_v);
-#pragma unroll
-  for (int j = 0; j < kPPW; ++j) idx_v[j] = idx_k[j];
-  load_idx(2);
   qk_phase(std::integral_constant<int, 0>{}, std::false_type{}, s_a, s_b, 0.f);
   {
     const bool pre = 0 < n_pre;
