@@ -15,6 +15,8 @@
 // (layers/attention/triton_ops/decode_attention.py:234-390, BLOCK_DPE = 64 path).
 #include "common.h"
 
+#include <type_traits>
+
 namespace semipd {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -403,11 +405,23 @@ mla_decode_wide_kernel(T* __restrict__ out, const T* __restrict__ q, const KV* _
   }
 }
 
+// defined in mla_decode_shared.hip; -1 = shape not covered
+template <typename T>
+int launch_mla_decode_shared(T* out, const T* q, const T* kv_buf, const int32_t* kv_indptr, const int32_t* kv_indices,
+                             float* attn_logits, int64_t batch, int Hq, int64_t q_stride, int64_t o_stride,
+                             int64_t kvbuf_stride, int splits, float sm_scale, float logit_cap, hipStream_t st);
+
 template <typename T, typename KV>
 int launch_mla_decode(T* out, const T* q, const KV* kv_buf, const int32_t* kv_indptr, const int32_t* kv_indices,
                       float* attn_logits, int64_t batch, int Hq, int64_t q_stride, int64_t o_stride,
                       int64_t kvbuf_stride, int splits, float sm_scale, float logit_cap, hipStream_t st) {
   const int tiles = (Hq + 15) / 16;
+  if constexpr (std::is_same<T, KV>::value) {
+    // 64 / 128 heads per rank, rows in the activation type: the shared-tile kernel (mla_decode_shared.hip)
+    const int rc = launch_mla_decode_shared<T>(out, q, kv_buf, kv_indptr, kv_indices, attn_logits, batch, Hq, q_stride,
+                                               o_stride, kvbuf_stride, splits, sm_scale, logit_cap, st);
+    if (rc >= 0) return rc;
+  }
   if (tiles > 1) {
     // several head tiles per rank: two waves per head tile, the latent tile shared by 2 or 4 head tiles
     const int ht = tiles > 2 ? 4 : 2;

@@ -244,6 +244,8 @@ DECODE_CASES = [
     (2, [33, 70], 16, 1, 576, 512, 4, 0.0),          # MLA latent (generic path)
     (3, [300, 1, 65], 40, 1, 576, 512, 1, 0.0),      # MLA, 3 head tiles (last partial), single split
     (2, [129, 1000], 128, 1, 576, 512, 8, 20.0),     # MLA, DeepSeek-V3 head count, logit cap
+    (12, [129, 1000, 7, 64, 65, 300, 31, 32, 33, 512, 1, 96], 128, 1, 576, 512, 8, 0.0),   # MLA, 128 heads: enough
+                                                     # workgroups for the shared-tile kernel (mla_decode_shared.hip)
     (2, [12, 30], 3, 1, 13, 13, 2, 0.0),             # odd head dim (generic path)
     (1, [2048], 32, 8, 128, 128, 16, 0.0),
 ]
@@ -267,6 +269,42 @@ def test_decode_attention(ops, device, B, lens, Hq, Hkv, Dk, Dv, splits, cap, dt
     want = O.decode_attention(q, k_buf, v_buf, indptr, indices, sm_scale, cap)
     # reference bar: cos-sim > 0.99, atol 3e-2 (test_triton_attention_kernels.py:342-347); ours is tighter
     _close(o, want, dtype, rtol=2e-2, atol=4e-3 if dtype == torch.float16 else 1.5e-2)
+
+
+MLA_SHARED_CASES = [
+    # B, lens, Hq, splits  -- forced onto mla_decode_shared.hip whatever the workgroup count
+    (2, [129, 1000], 128, 8),
+    (3, [1, 31, 97], 128, 1),             # single split, rows short of one tile
+    (4, [5, 2048, 32, 33], 128, 16),      # more splits than rows (empty splits), tile boundaries
+    (2, [64, 333], 64, 3),                # 64 heads: two waves per workgroup
+    (1, [700], 256, 4),                   # two head groups
+    (2, [3000, 95], 128, 2),              # ~47 tiles per split: the ring wraps many times
+]
+
+
+@pytest.mark.parametrize("B,lens,Hq,splits", MLA_SHARED_CASES)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_mla_decode_shared_tile_kernel(ops, device, monkeypatch, B, lens, Hq, splits, dtype):
+    """MLA decode with 64 / 128 / 256 heads on one latent row: the kernel that shares a latent tile between 128 heads
+    (mla_decode_shared.hip; SEMIPD_MLA_SHARED=2 takes it whatever the size) against the oracle, and against the wide
+    kernel it replaces (SEMIPD_MLA_SHARED=0) on the same inputs."""
+    k_buf, _, indptr, indices = _paged(B, lens, 1, 576, 512, dtype, seed=Hq * 7 + splits)
+    torch.manual_seed(B * 13 + Hq)
+    q = torch.randn(B, Hq, 576).to(dtype)
+    sm_scale = 576 ** -0.5
+    kd = k_buf.to(device)
+    outs = {}
+    for mode in ("2", "0"):
+        monkeypatch.setenv("SEMIPD_MLA_SHARED", mode)
+        o = torch.full((B, Hq, 512), float("nan"), dtype=dtype, device=device)
+        logits = torch.empty(B, Hq, splits, 513, dtype=torch.float32, device=device)
+        ops.decode_attention_fwd(q.to(device), kd, kd[..., :512], o, indptr.to(device), indices.to(device), logits, splits,
+                                 sm_scale, 0.0)
+        outs[mode] = o.float().cpu()
+    want = O.decode_attention(q, k_buf, k_buf[..., :512], indptr, indices, sm_scale, 0.0)
+    _close(outs["2"].to(dtype), want, dtype, rtol=2e-2, atol=4e-3 if dtype == torch.float16 else 1.5e-2)
+    assert torch.isfinite(outs["2"]).all()
+    assert (outs["2"] - outs["0"]).abs().max() < (4e-3 if dtype == torch.float16 else 2e-2)
 
 
 @pytest.mark.parametrize("fixture", ["decode_attention", "decode_attention_8c"])

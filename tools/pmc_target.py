@@ -48,6 +48,30 @@ elif which.startswith("extend"):
     for _ in range(5):
         ops.extend_attention_fwd(q, k, v, o, kb, kb, qo, kvp, idx, None, None, ext)
     print("flop_per_launch", 4.0 * Hq * D * B * ext * (ext + 1) / 2)
+elif which == "mla128":
+    # MLA decode, 128 heads on one latent tile (mla_decode_shared.hip): B = 128, ctx = 8192, two splits
+    B, ctx, H, splits = 128, 8192, 128, 2
+    N = B * ctx + 1
+    kv = torch.randn(N, 1, 576, device=dev, dtype=torch.bfloat16)
+    q = torch.randn(B, H, 576, device=dev, dtype=torch.bfloat16)
+    o = torch.empty(B, H, 512, device=dev, dtype=torch.bfloat16)
+    indptr = torch.arange(B + 1, device=dev, dtype=torch.int32) * ctx
+    idx = (torch.randperm(N - 1, device=dev)[: B * ctx] + 1).to(torch.int32)
+    lg = torch.empty(B, H, splits, 513, device=dev, dtype=torch.float32)
+    for _ in range(4):
+        ops.decode_attention_fwd(q, kv, kv[..., :512], o, indptr, idx, lg, splits, 0.1)
+    print("rows_bytes_per_call", B * ctx * 1152, "flop", 2.0 * B * ctx * H * (576 + 512))
+elif which == "moe8k":
+    # the tiled MoE GEMM1 (with the SiLU epilogue) and GEMM2 of DeepSeek-V2-Lite experts at T = 8192
+    from semi_pd_amd.layers.moe import fused_experts
+    E, k, K, N, T = 64, 6, 2048, 1408, 8192
+    w1 = torch.randn(E, 2 * N, K, device=dev, dtype=torch.bfloat16) * 0.02
+    w2 = torch.randn(E, K, N, device=dev, dtype=torch.bfloat16) * 0.02
+    x = torch.randn(T, K, device=dev, dtype=torch.bfloat16)
+    tw, ti = ops.topk_softmax(torch.randn(T, E, device=dev), k, True)
+    for _ in range(4):
+        fused_experts(x, w1, w2, tw, ti)
+    print("flop_per_call_gemm1", 2.0 * T * k * 2 * N * K, "gemm2", 2.0 * T * k * N * K)
 elif which == "stream":
     # the streaming GEMM of a decode batch: Llama-3-8B gate_up + SiLU*mul (235 MB of weights, read once), 6 weight
     # copies in rotation so that the 256 MB Infinity Cache cannot serve a re-read

@@ -1,0 +1,6 @@
+#!/bin/bash
+OUT=gpurun_out/r02_mla; mkdir -p $OUT
+timeout 600 python -m pytest tests/test_gpu_ops.py -q -x -k "test_decode_attention" 2>&1 | tail -15 > $OUT/pytest.txt
+cat $OUT/pytest.txt
+timeout 300 python tools/kbench_mla_quick.py > $OUT/kbench_shared.txt 2>&1; cat $OUT/kbench_shared.txt
+SEMIPD_MLA_SHARED=0 timeout 300 python tools/kbench_mla_quick.py > $OUT/kbench_wide.txt 2>&1; cat $OUT/kbench_wide.txt
