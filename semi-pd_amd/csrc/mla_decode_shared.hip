@@ -455,10 +455,17 @@ mla_decode_shared_kernel(T* __restrict__ out, const T* __restrict__ q, const T* 
       }
   } else {
     float* dst = attn_logits + (((int64_t)b * num_q_heads + h) * num_kv_splits + split) * (kDV + 1);
+    // four consecutive floats per store (rows of 513 floats: dword-aligned only, which global stores accept)
+    struct __attribute__((packed, aligned(4))) F4 { float v[4]; };
 #pragma unroll
     for (int t = 0; t < 16; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) dst[t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi] = o_acc[t][r] * inv;
+      for (int r4 = 0; r4 < 4; ++r4) {
+        F4 w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w.v[j] = o_acc[t][r4 * 4 + j] * inv;
+        *reinterpret_cast<F4*>(dst + t * 32 + 8 * r4 + 4 * hi) = w;
+      }
     // the running maximum is kept in the log2 domain: natural-log lse for the stage-2 merge
     if (hi == 0) dst[kDV] = m_run * 0.6931471805599453f + __logf(l_tot);
   }
@@ -478,9 +485,11 @@ int launch_mla_decode_shared(T* out, const T* q, const T* kv_buf, const int32_t*
   const int nwv = (Hq % 128 == 0) ? 4 : 2;
   const int groups = Hq / (32 * nwv);
   const int64_t total = batch * groups * splits;
-  // a workgroup pays ~15 us before its first tile is done (Q^T: 147 KB, three dependent memory latencies): with fewer
-  // than ~100 workgroups the wide kernel's 2-4x as many, lighter ones finish first (B = 1, ctx 8 k: 48 vs 55 us)
-  if (total < 96 && !force) return -1;
+  // a workgroup loads 147 KB of Q^T and sits through three dependent memory latencies before its first tile: below
+  // ~5/8 of the CUs' worth of workgroups the wide kernel's 2-4x as many, lighter ones finish first (B = 32, ctx 1.1 k,
+  // 4 splits: 52 vs 60 us; B = 1, ctx 8 k: 48 vs 55; profiles/r02_kbench_mla_decode_short_contexts.txt).  The host
+  // side picks its split count with the same number (layers/attention_backend.py: MLA_SHARED_MIN_WORKGROUPS).
+  if (total < 160 && !force) return -1;
   if (total > 0x7fffffff) {
     set_error("mla_decode: grid too large");
     return SEMIPD_EINVAL;

@@ -60,8 +60,11 @@ class ForwardMetadata:
     num_kv_splits: int
 
 
+MLA_SHARED_MIN_WORKGROUPS = 160   # csrc/mla_decode_shared.hip: launch_mla_decode_shared takes the shape from here up
+
+
 def choose_kv_splits(batch: int, num_kv_heads: int, max_seq_len: int, num_cus: int, cap: int,
-                     mla: bool = False) -> int:
+                     mla: bool = False, mla_heads: int = 0) -> int:
     """Split-KV factor: one full round of work items on the CUs this process owns, never cutting a
     split too short.  (The reference uses a fixed --triton-attention-num-kv-splits, 16 on HIP:
     server_args.py:321-323.)"""
@@ -72,6 +75,15 @@ def choose_kv_splits(batch: int, num_kv_heads: int, max_seq_len: int, num_cus: i
     # MLA: one work item = one 4-wave workgroup of mla_decode_kernel (the waves share the latent tile in
     # LDS), 2 per CU, and a split below ~128 tokens does not amortise staging Q for 16 heads
     # (profiles/r01_kbench_mla_small_batches.txt: best B x splits = 1 .. 2 x CUs).
+    # MLA with 64 / 128 / 256 heads per rank (mla_decode_shared.hip): one work item = one workgroup for up to 128
+    # heads, ONE per CU, and it wants >= 8 tiles of 32 rows; the launcher takes that kernel from 160 workgroups up,
+    # below that the rule of the 16-head kernels applies (profiles/r02_kbench_mla_decode_short_contexts.txt: at
+    # B = 32 .. 96 and ctx 1.1 k .. 4.4 k the best split count is min(CUs / B, ctx / 256))
+    if mla and mla_heads >= 64 and mla_heads % 64 == 0:
+        groups = (mla_heads + 127) // 128
+        s = int(max(1, min(cap, num_cus // max(1, batch * groups), max_seq_len // 256)))
+        if batch * groups * s >= MLA_SHARED_MIN_WORKGROUPS:
+            return s
     target = (2 if mla else 8) * num_cus
     base = max(1, batch * num_kv_heads)
     want = max(1, target // base)
@@ -107,7 +119,7 @@ class HipAttnBackend(AttentionBackend):
             max_len = self.max_context_len if forward_batch.seq_lens_sum is None else max(
                 1, forward_batch.seq_lens_sum // max(bs, 1))
             splits = choose_kv_splits(bs, self.num_kv_head, max_len, self.num_cus, self.num_kv_splits_cap,
-                                      mla=self.is_mla)
+                                      mla=self.is_mla, mla_heads=self.num_head if self.is_mla else 0)
             attn_logits = torch.empty((bs, self.num_head, splits, self.v_head_dim + 1), dtype=torch.float32,
                                       device=dev) if splits > 1 else None
             self.forward_metadata = ForwardMetadata(attn_logits, kv_indptr, kv_indices, None, 0, splits)
@@ -150,7 +162,8 @@ class HipAttnBackend(AttentionBackend):
         the static req_pool_indices / seq_lens buffers on every replay."""
         assert forward_mode.is_decode()
         splits = num_kv_splits or choose_kv_splits(bs, self.num_kv_head, self.max_context_len, self.num_cus,
-                                                   self.num_kv_splits_cap, mla=self.is_mla)
+                                                   self.num_kv_splits_cap, mla=self.is_mla,
+                                                   mla_heads=self.num_head if self.is_mla else 0)
         kv_indptr = self.cuda_graph_kv_indptr[: bs + 1]
         ops.create_flashinfer_kv_indices(self.req_to_token, req_pool_indices, seq_lens, kv_indptr, None,
                                          self.cuda_graph_kv_indices)

@@ -244,7 +244,7 @@ DECODE_CASES = [
     (2, [33, 70], 16, 1, 576, 512, 4, 0.0),          # MLA latent (generic path)
     (3, [300, 1, 65], 40, 1, 576, 512, 1, 0.0),      # MLA, 3 head tiles (last partial), single split
     (2, [129, 1000], 128, 1, 576, 512, 8, 20.0),     # MLA, DeepSeek-V3 head count, logit cap
-    (12, [129, 1000, 7, 64, 65, 300, 31, 32, 33, 512, 1, 96], 128, 1, 576, 512, 8, 0.0),   # MLA, 128 heads: enough
+    (20, [129, 1000, 7, 64, 65, 300, 31, 32, 33, 512, 1, 96, 257, 40, 700, 2, 95, 128, 160, 511], 128, 1, 576, 512, 8, 0.0),   # MLA, 128 heads: enough
                                                      # workgroups for the shared-tile kernel (mla_decode_shared.hip)
     (2, [12, 30], 3, 1, 13, 13, 2, 0.0),             # odd head dim (generic path)
     (1, [2048], 32, 8, 128, 128, 16, 0.0),
