@@ -307,10 +307,14 @@ def test_mla_decode_shared_tile_kernel(ops, device, monkeypatch, B, lens, Hq, sp
     assert (outs["2"] - outs["0"]).abs().max() < (4e-3 if dtype == torch.float16 else 2e-2)
 
 
-@pytest.mark.parametrize("fixture", ["decode_attention", "decode_attention_8c"])
-def test_decode_attention_golden(ops, device, fixture):
+@pytest.mark.parametrize("fixture,mla_shared", [("decode_attention", ""), ("decode_attention_8c", ""),
+                                                ("decode_attention_8c", "2")])
+def test_decode_attention_golden(ops, device, monkeypatch, fixture, mla_shared):
     """fp32 golden vectors from the reference Triton kernel, evaluated here in bf16 (8c: the SURVEY 8(c) shapes,
-    MLA 576 / 512 with 16 and 128 heads, D 80 / 13, group 16, 16 splits)."""
+    MLA 576 / 512 with 16 and 128 heads, D 80 / 13, group 16, 16 splits).  mla_shared = "2": the 128-head MLA vector
+    (one request: too few workgroups for the size rule) through mla_decode_shared.hip as well."""
+    if mla_shared:
+        monkeypatch.setenv("SEMIPD_MLA_SHARED", mla_shared)
     g = load_golden(fixture)
     for name in g["names"]:
         name = str(name)
