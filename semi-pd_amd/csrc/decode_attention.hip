@@ -334,6 +334,33 @@ __global__ void decode_stage2_kernel(T* __restrict__ out, const float* __restric
   }
 }
 
+// The same merge with one WAVE per head and four heads per workgroup: 128 heads x 128 requests of MLA decode are 16 k
+// workgroups of a few KB each in the kernel above (38 us for 67 MB); this form is a quarter of the workgroups.
+template <typename T>
+__global__ void __launch_bounds__(256)
+decode_stage2_wave_kernel(T* __restrict__ out, const float* __restrict__ attn_logits, const int32_t* __restrict__ kv_indptr,
+                          int num_q_heads, int Dv, int64_t o_stride, int num_kv_splits) {
+  const int b = blockIdx.x, lane = threadIdx.x & 63;
+  const int hq = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (hq >= num_q_heads) return;
+  const int seq_len = kv_indptr[b + 1] - kv_indptr[b];
+  const int per_split = (seq_len + num_kv_splits - 1) / num_kv_splits;
+  const float* base = attn_logits + ((int64_t)b * num_q_heads + hq) * num_kv_splits * (Dv + 1);
+  const int n_valid = per_split > 0 ? min(num_kv_splits, (seq_len + per_split - 1) / per_split) : 0;
+  float e_max = -INFINITY;
+  for (int s = 0; s < n_valid; ++s) e_max = fmaxf(e_max, base[(int64_t)s * (Dv + 1) + Dv]);
+  float e_sum = 0.f;
+  for (int s = 0; s < n_valid; ++s) e_sum += __expf(base[(int64_t)s * (Dv + 1) + Dv] - e_max);
+  const float inv = e_sum > 0.f ? 1.f / e_sum : 0.f;
+  for (int d = lane; d < Dv; d += 64) {
+    float acc = 0.f;
+#pragma unroll 4
+    for (int s = 0; s < n_valid; ++s)
+      acc += __expf(base[(int64_t)s * (Dv + 1) + Dv] - e_max) * base[(int64_t)s * (Dv + 1) + d];
+    out[(int64_t)b * o_stride + (int64_t)hq * Dv + d] = Elem<T>::from_f(acc * inv);
+  }
+}
+
 template <typename T, int LPR, typename KV = T>
 static int launch_stage1(T* out, const T* q, const KV* k_buf, const KV* v_buf, const int32_t* kv_indptr,
                          const int32_t* kv_indices, float* attn_logits, int64_t batch, int Hq, int Hkv,
@@ -469,10 +496,16 @@ static int run_decode(void* out, const void* q, const void* k_buf, const void* v
     rc = launch_status("decode_stage1_generic");
   }
   if (rc == 0 && num_kv_splits > 1) {
-    dim3 grid((unsigned)batch, (unsigned)num_q_heads);
-    const int threads = head_dim_v <= 64 ? 64 : head_dim_v <= 128 ? 128 : 256;
-    hipLaunchKernelGGL((decode_stage2_kernel<T>), grid, dim3(threads), 0, st, (T*)out, attn_logits,
-                       kv_indptr, num_q_heads, head_dim_v, o_stride, num_kv_splits);
+    if (head_dim_v >= 256 && batch * num_q_heads >= 4096) {
+      dim3 grid((unsigned)batch, (unsigned)((num_q_heads + 3) / 4));
+      hipLaunchKernelGGL((decode_stage2_wave_kernel<T>), grid, dim3(256), 0, st, (T*)out, attn_logits, kv_indptr,
+                         num_q_heads, head_dim_v, o_stride, num_kv_splits);
+    } else {
+      dim3 grid((unsigned)batch, (unsigned)num_q_heads);
+      const int threads = head_dim_v <= 64 ? 64 : head_dim_v <= 128 ? 128 : 256;
+      hipLaunchKernelGGL((decode_stage2_kernel<T>), grid, dim3(threads), 0, st, (T*)out, attn_logits,
+                         kv_indptr, num_q_heads, head_dim_v, o_stride, num_kv_splits);
+    }
     rc = launch_status("decode_stage2");
   }
   return rc;

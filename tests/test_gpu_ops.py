@@ -279,6 +279,7 @@ MLA_SHARED_CASES = [
     (2, [64, 333], 64, 3),                # 64 heads: two waves per workgroup
     (1, [700], 256, 4),                   # two head groups
     (2, [3000, 95], 128, 2),              # ~47 tiles per split: the ring wraps many times
+    (33, [40 + 7 * i for i in range(33)], 128, 3),   # 4224 (request, head) pairs: the one-wave-per-head stage 2
 ]
 
 
