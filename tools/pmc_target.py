@@ -48,6 +48,20 @@ elif which.startswith("extend"):
     for _ in range(5):
         ops.extend_attention_fwd(q, k, v, o, kb, kb, qo, kvp, idx, None, None, ext)
     print("flop_per_launch", 4.0 * Hq * D * B * ext * (ext + 1) / 2)
+elif which == "mla128_b32":
+    # the same kernel at B = 32, ctx = 8192, 8 splits: 256 workgroups of 32 tiles (fixed cost per workgroup)
+    B, ctx, H = 32, 8192, 128
+    N = B * ctx + 1
+    kv = torch.randn(N, 1, 576, device=dev, dtype=torch.bfloat16)
+    q = torch.randn(B, H, 576, device=dev, dtype=torch.bfloat16)
+    o = torch.empty(B, H, 512, device=dev, dtype=torch.bfloat16)
+    indptr = torch.arange(B + 1, device=dev, dtype=torch.int32) * ctx
+    idx = (torch.randperm(N - 1, device=dev)[: B * ctx] + 1).to(torch.int32)
+    for splits in (8, 4, 16):
+        lg = torch.empty(B, H, splits, 513, device=dev, dtype=torch.float32)
+        for _ in range(4):
+            ops.decode_attention_fwd(q, kv, kv[..., :512], o, indptr, idx, lg, splits, 0.1)
+        torch.cuda.synchronize()
 elif which == "mla128":
     # MLA decode, 128 heads on one latent tile (mla_decode_shared.hip): B = 128, ctx = 8192, two splits
     B, ctx, H, splits = 128, 8192, 128, 2
