@@ -248,6 +248,8 @@ def main():
     ap.add_argument("--max-total-tokens", type=int, default=None)
     ap.add_argument("--chunked-prefill-size", type=int, default=None, help="tokens per prefill batch (default 8192)")
     ap.add_argument("--disable-cuda-graph", action="store_true")
+    ap.add_argument("--kv-splits", type=int, default=None,
+                    help="fixed split-KV count of the decode attention (--triton-attention-num-kv-splits); default: per batch")
     ap.add_argument("--disable-overlap-schedule", action="store_true",
                     help="plain (not overlapped / pipelined) decode and prefill loops, for A/B runs")
     ap.add_argument("--quantization", default=None, choices=[None, "fp8"],
@@ -318,6 +320,7 @@ def main():
                     prefill_stream_priority=args.prefill_priority, decode_stream_priority=args.decode_priority,
                     disable_cuda_graph=args.disable_cuda_graph, nccl_port_base=port_base,
                     disable_overlap_schedule=args.disable_overlap_schedule,
+                    triton_attention_num_kv_splits=args.kv_splits,
                     **({"chunked_prefill_size": args.chunked_prefill_size} if args.chunked_prefill_size else {}),
                     kv_cache_dtype=args.kv_cache_dtype,
                     # (the one-GPU check of the TP path reduces over gloo, whose collectives cannot be captured beyond the

@@ -45,7 +45,8 @@ def _build_runner(server_args: ServerArgs, gpu_id: int, tp_rank: int, role: Inst
         bypass_load_weight=bypass_load_weight, seed=server_args.random_seed, cu_percent=cu_percent,
         disable_cuda_graph=server_args.disable_cuda_graph, cuda_graph_max_bs=server_args.cuda_graph_max_bs,
         disable_custom_all_reduce=server_args.disable_custom_all_reduce, enable_ep_moe=server_args.enable_ep_moe,
-        disable_stream_linear=server_args.disable_stream_linear)
+        disable_stream_linear=server_args.disable_stream_linear,
+        num_kv_splits=server_args.triton_attention_num_kv_splits)
     if server_args.collect_kernel_timing:
         from semi_pd_amd.model_executor.kernel_timing import KernelTiming
         mr.kernel_timing = KernelTiming()

@@ -102,6 +102,11 @@ class HipAttnBackend(AttentionBackend):
         self.num_cus = model_runner.num_cus_owned
         self.is_mla = model_runner.kv_geometry["kind"] == "mla"
         self.num_kv_splits_cap = num_kv_splits_cap
+        # --triton-attention-num-kv-splits: a fixed count as in the reference (decode_attention.py's grid z)
+        fixed = getattr(model_runner, "num_kv_splits", None)
+        self.fixed_kv_splits = int(fixed) if fixed else None
+        if self.fixed_kv_splits:
+            self.num_kv_splits_cap = max(1, self.fixed_kv_splits)
         self.forward_metadata: Optional[ForwardMetadata] = None
         self.cuda_graph_attn_logits = None
         self.model_runner = model_runner
@@ -118,8 +123,9 @@ class HipAttnBackend(AttentionBackend):
                                              forward_batch.seq_lens, kv_indptr, None, kv_indices)
             max_len = self.max_context_len if forward_batch.seq_lens_sum is None else max(
                 1, forward_batch.seq_lens_sum // max(bs, 1))
-            splits = choose_kv_splits(bs, self.num_kv_head, max_len, self.num_cus, self.num_kv_splits_cap,
-                                      mla=self.is_mla, mla_heads=self.num_head if self.is_mla else 0)
+            splits = self.fixed_kv_splits or choose_kv_splits(
+                bs, self.num_kv_head, max_len, self.num_cus, self.num_kv_splits_cap, mla=self.is_mla,
+                mla_heads=self.num_head if self.is_mla else 0)
             attn_logits = torch.empty((bs, self.num_head, splits, self.v_head_dim + 1), dtype=torch.float32,
                                       device=dev) if splits > 1 else None
             self.forward_metadata = ForwardMetadata(attn_logits, kv_indptr, kv_indices, None, 0, splits)
@@ -161,7 +167,7 @@ class HipAttnBackend(AttentionBackend):
         """Called inside the capture: the kv_indices build kernel is recorded into the graph and reads
         the static req_pool_indices / seq_lens buffers on every replay."""
         assert forward_mode.is_decode()
-        splits = num_kv_splits or choose_kv_splits(bs, self.num_kv_head, self.max_context_len, self.num_cus,
+        splits = num_kv_splits or self.fixed_kv_splits or choose_kv_splits(bs, self.num_kv_head, self.max_context_len, self.num_cus,
                                                    self.num_kv_splits_cap, mla=self.is_mla,
                                                    mla_heads=self.num_head if self.is_mla else 0)
         kv_indptr = self.cuda_graph_kv_indptr[: bs + 1]

@@ -116,8 +116,10 @@ class ModelRunner:
                  disable_cuda_graph: bool = False, cuda_graph_max_bs: int = 256,
                  load_state_dict: Optional[Dict[str, torch.Tensor]] = None, model_path: Optional[str] = None,
                  load_format: str = "dummy", kv_cache_dtype: str = "auto", disable_custom_all_reduce: bool = False,
-                 enable_ep_moe: bool = False, disable_stream_linear: bool = False):
+                 enable_ep_moe: bool = False, disable_stream_linear: bool = False,
+                 num_kv_splits: Optional[int] = None):
         self.model_config = model_config
+        self.num_kv_splits = num_kv_splits        # --triton-attention-num-kv-splits; None = per batch
         self.gpu_id, self.tp_rank, self.tp_size = gpu_id, tp_rank, tp_size
         self.dtype = dtype
         # --kv-cache-dtype (server_args.py kv_cache_dtype; model_runner.py:690-710): pool rows in the

@@ -42,6 +42,9 @@ class ServerArgs:
     enable_ep_moe: bool = False              # server_args.py --enable-ep-moe: routed experts partitioned by expert over TP
     disable_custom_all_reduce: bool = False  # server_args.py --disable-custom-all-reduce: TP all-reduce through RCCL only
     cuda_graph_max_bs: int = 256
+    # server_args.py:168, 321-323 --triton-attention-num-kv-splits (8, 16 on HIP): given, the decode attention uses that
+    # split count like the reference; None (default) = chosen per batch (layers/attention_backend.py: choose_kv_splits)
+    triton_attention_num_kv_splits: Optional[int] = None
     attention_backend: str = "hip"
     sampling_backend: str = "hip"
     watchdog_timeout: float = 300.0
@@ -145,6 +148,8 @@ def add_cli_args(parser):
     p.add_argument("--quantization", type=str, default=None, choices=[None, "fp8"],
                    help="fp8 = block-scaled e4m3fn checkpoint (quantization_config with weight_block_size); with "
                         "--load-format dummy it makes the seeded weights block-quantised")
+    p.add_argument("--triton-attention-num-kv-splits", type=int, default=None,
+                   help="fixed split-KV count of the decode attention (the reference's flag); default: chosen per batch")
     p.add_argument("--attention-backend", type=str, default="hip")
     p.add_argument("--sampling-backend", type=str, default="hip")
     p.add_argument("--log-level", type=str, default="info")
@@ -176,7 +181,7 @@ def from_cli_args(args) -> ServerArgs:
         enable_ep_moe=args.enable_ep_moe, disable_overlap_schedule=args.disable_overlap_schedule, cuda_graph_max_bs=args.cuda_graph_max_bs,
         enable_semi_pd=args.enable_semi_pd, prefill_cu_percent=args.prefill_cu_percent,
         decode_cu_percent=args.decode_cu_percent, attention_backend=args.attention_backend,
-        sampling_backend=args.sampling_backend)
+        sampling_backend=args.sampling_backend, triton_attention_num_kv_splits=args.triton_attention_num_kv_splits)
     if args.quantization == "fp8":
         # server_args.py --quantization: the checkpoint decides (config.json: quantization_config); the flag
         # must agree with it.  There is no on-line weight quantisation, except for dummy weights.

@@ -214,6 +214,9 @@ def test_cli_flags_of_the_reference_parse(tmp_path):
     assert sa.enable_semi_pd and sa.disable_radix_cache and sa.tp_size == 1 and sa.context_length == 10240
     assert sa.mem_fraction_static == 0.82 and sa.served_model_name == "deepseek" and sa.load_format == "auto"
     assert sa.model_config.num_key_value_heads == 2 and sa.eos_token_ids == [7]
+    assert sa.triton_attention_num_kv_splits is None          # split count chosen per batch unless the flag is given
+    sa = from_cli_args(add_cli_args(argparse.ArgumentParser()).parse_args(argv + ["--triton-attention-num-kv-splits", "16"]))
+    assert sa.triton_attention_num_kv_splits == 16            # server_args.py:979-981
 
 
 def test_logprobs_native_and_openai(client):
