@@ -308,6 +308,36 @@ def test_mla_decode_shared_tile_kernel(ops, device, monkeypatch, B, lens, Hq, sp
     assert (outs["2"] - outs["0"]).abs().max() < (4e-3 if dtype == torch.float16 else 2e-2)
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_mla_decode_shared_tile_kernel_random_batches(ops, device, monkeypatch, seed):
+    """Random batches (1-6 requests of 1-1500 rows, 1-16 splits, 64 / 128 heads): shared-tile kernel == oracle and ~= the wide
+    kernel; empty splits, one-row requests and splits shorter than a tile come up by themselves."""
+    rng = np.random.default_rng(1000 + seed)
+    B = int(rng.integers(1, 7))
+    lens = [int(x) for x in rng.integers(1, 1500, size=B)]
+    if seed % 3 == 0:
+        lens[0] = int(rng.integers(1, 40))
+    Hq = 128 if seed % 2 == 0 else 64
+    splits = int(rng.integers(1, 17))
+    dtype = torch.bfloat16
+    k_buf, _, indptr, indices = _paged(B, lens, 1, 576, 512, dtype, seed=seed)
+    torch.manual_seed(seed)
+    q = (torch.randn(B, Hq, 576) * float(rng.uniform(0.3, 2.0))).to(dtype)
+    sm_scale = 576 ** -0.5
+    kd = k_buf.to(device)
+    outs = {}
+    for mode in ("2", "0"):
+        monkeypatch.setenv("SEMIPD_MLA_SHARED", mode)
+        o = torch.full((B, Hq, 512), float("nan"), dtype=dtype, device=device)
+        logits = torch.empty(B, Hq, splits, 513, dtype=torch.float32, device=device)
+        ops.decode_attention_fwd(q.to(device), kd, kd[..., :512], o, indptr.to(device), indices.to(device), logits, splits,
+                                 sm_scale, 0.0)
+        outs[mode] = o.float().cpu()
+    want = O.decode_attention(q, k_buf, k_buf[..., :512], indptr, indices, sm_scale, 0.0)
+    _close(outs["2"].to(dtype), want, dtype, rtol=2e-2, atol=1.5e-2)
+    assert (outs["2"] - outs["0"]).abs().max() < 2e-2
+
+
 @pytest.mark.parametrize("fixture,mla_shared", [("decode_attention", ""), ("decode_attention_8c", ""),
                                                 ("decode_attention_8c", "2")])
 def test_decode_attention_golden(ops, device, monkeypatch, fixture, mla_shared):
