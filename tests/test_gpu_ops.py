@@ -841,7 +841,9 @@ def test_linear_strided_rows_and_f16(ops, device):
 
 # ----------------------------------------------------------------------------- decode batches: LDS-DMA streaming linear
 @pytest.mark.parametrize("M", [1, 7, 16, 17, 33, 48, 64])
-@pytest.mark.parametrize("N,K", [(4096, 4096), (6144, 4096), (28672, 4096), (4096, 14336), (1008, 512), (16, 1024)])
+@pytest.mark.parametrize("N,K", [(4096, 4096), (6144, 4096), (28672, 4096), (4096, 14336), (1008, 512), (16, 1024),
+                                 # Llama-3-8B per rank at TP = 8 / TP = 4: qkv, o_proj, down_proj
+                                 (768, 4096), (4096, 512), (4096, 1792), (1536, 4096), (4096, 1024), (4096, 3584)])
 def test_stream_linear(ops, device, M, N, K):
     """F.linear semantics (layers/linear.py:165-172) from the weight-streaming kernel, bf16 bar of
     test_fused_moe.py:31-44; deterministic (K slices are summed in slice order)."""
@@ -855,7 +857,7 @@ def test_stream_linear(ops, device, M, N, K):
 
 
 @pytest.mark.parametrize("M", [1, 16, 31, 64])
-@pytest.mark.parametrize("inter,K", [(14336, 4096), (1408, 2048), (48, 512)])
+@pytest.mark.parametrize("inter,K", [(14336, 4096), (1408, 2048), (48, 512), (1792, 4096), (3584, 4096)])   # last two: TP = 8 / 4
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_stream_linear_fused_silu_mul(ops, device, M, inter, K, dtype):
     """gate_up_proj + SiluAndMul in one launch (models/llama.py:88-92): the GEMM outputs are rounded to the
