@@ -13,6 +13,7 @@ weight-streaming kernel (ops.stream_linear) for batches of at most 64 rows, i.e.
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 from typing import Any, Dict, Optional, Tuple, Union
 
@@ -522,6 +523,9 @@ class LogitsProcessorOutput:
     next_token_top_logprobs_idx: Optional[list] = None            # per row: k token ids
 
 
+LM_HEAD_FUSED_MAX_ROWS = int(os.environ.get("SEMIPD_LM_HEAD_FUSED_MAX_ROWS", "64"))
+
+
 class LogitsProcessor(nn.Module):
     """Last-token gather + lm_head + all-gather + fp32 (logits_processor.py:220-445).  With TP=1 and a
     greedy batch the argmax is produced by the same HIP call (ops.lm_head_argmax); with TP>1 the
@@ -539,7 +543,11 @@ class LogitsProcessor(nn.Module):
             pruned = ops.gather_rows(hidden_states, last_index)
         else:
             pruned = hidden_states
-        if get_tensor_model_parallel_world_size() == 1 and self.final_logit_softcapping is None:
+        # The fused lm_head + argmax kernel walks the weights once per 64 rows: at 256 rows it takes 1.18 ms where the
+        # library GEMM + argmax takes 0.36 (profiles/r02_kbench_all_final_tree.txt), at <= 64 rows it is at par or ahead
+        # and returns fp32 logits.  Above that the reference's own form: bf16 GEMM, then fp32 (logits_processor.py:394-445).
+        if get_tensor_model_parallel_world_size() == 1 and self.final_logit_softcapping is None \
+                and pruned.shape[0] <= LM_HEAD_FUSED_MAX_ROWS:
             # rows >= vocab_size are padding (vocab_parallel_embedding.py pads to a multiple of 64)
             logits, ids = ops.lm_head_argmax(pruned.contiguous(), lm_head.weight[: self.vocab_size],
                                              return_logits=True)
