@@ -1,6 +1,7 @@
 // Shared device/host helpers for libsemipd_hip.so (gfx950 only, wave64).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
@@ -31,6 +32,24 @@ void set_error(const char* fmt, ...);
       return (int)_e;                                                           \
     }                                                                           \
   } while (0)
+
+// Opt a kernel in to more than 64 KB of dynamic LDS, once per DEVICE and call site (`done` = one bit per device: the
+// attribute is per device, a second GPU in the process would otherwise fail at launch).  Returns non-zero and sets
+// the error text when the runtime refuses.
+inline int ensure_dynamic_lds(const void* kernel, size_t bytes, std::atomic<uint64_t>& done, const char* what) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_relaxed) & bit) return 0;
+  hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) {
+    set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize = %zu) failed on device %d: %s", what, bytes, dev,
+              hipGetErrorString(e));
+    return 1;
+  }
+  done.fetch_or(bit, std::memory_order_relaxed);
+  return 0;
+}
 
 inline int launch_status(const char* what) {
   hipError_t e = hipGetLastError();

@@ -494,12 +494,10 @@ int launch_extend_shared_kv(void* out, const void* q, const void* k, const void*
   dim3 grid(gx, gy, (unsigned)batch);
 #define SKV(GV, TV, HV)                                                                                            \
   do {                                                                                                             \
-    static bool attr_set = false;                                                                                  \
-    if (!attr_set) {                                                                                               \
-      (void)hipFuncSetAttribute((const void*)extend_attn_shared_kv_kernel<T, GV, TV, HV>,                          \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, skv::lds_bytes(HV));                   \
-      attr_set = true;                                                                                             \
-    }                                                                                                              \
+    static std::atomic<uint64_t> lds_ok{0};                                                                         \
+    if (ensure_dynamic_lds((const void*)extend_attn_shared_kv_kernel<T, GV, TV, HV>, skv::lds_bytes(HV), lds_ok,      \
+                           "extend_attn_shared_kv"))                                                                  \
+      return 1;                                                                                                       \
     hipLaunchKernelGGL((extend_attn_shared_kv_kernel<T, GV, TV, HV>), grid, dim3(64 * GV * TV * HV),                \
                        skv::lds_bytes(HV), st, (T*)out, (const T*)q, (const T*)k, (const T*)v, (const T*)k_buf,     \
                        (const T*)v_buf, qo_indptr, kv_indptr, kv_indices, group, q_stride, k_stride, v_stride,      \

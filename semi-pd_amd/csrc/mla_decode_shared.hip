@@ -495,21 +495,15 @@ int launch_mla_decode_shared(T* out, const T* q, const T* kv_buf, const int32_t*
     return SEMIPD_EINVAL;
   }
   if (total == 0) return 0;
-  static bool attr_done[2] = {false, false};
+  static std::atomic<uint64_t> lds_ok4{0}, lds_ok2{0};   // one bit per device
   if (nwv == 4) {
     auto kern = mla_decode_shared_kernel<T, 4>;
-    if (!attr_done[0]) {
-      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, mls::lds_bytes(4));
-      attr_done[0] = true;
-    }
+    if (ensure_dynamic_lds((const void*)kern, mls::lds_bytes(4), lds_ok4, "mla_decode_shared")) return 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), mls::lds_bytes(4), st, out, q, kv_buf, kv_indptr, kv_indices,
                        attn_logits, Hq, groups, q_stride, o_stride, kvbuf_stride, splits, sm_scale);
   } else {
     auto kern = mla_decode_shared_kernel<T, 2>;
-    if (!attr_done[1]) {
-      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, mls::lds_bytes(2));
-      attr_done[1] = true;
-    }
+    if (ensure_dynamic_lds((const void*)kern, mls::lds_bytes(2), lds_ok2, "mla_decode_shared")) return 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(128), mls::lds_bytes(2), st, out, q, kv_buf, kv_indptr, kv_indices,
                        attn_logits, Hq, groups, q_stride, o_stride, kvbuf_stride, splits, sm_scale);
   }

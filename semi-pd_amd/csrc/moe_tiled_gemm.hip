@@ -121,12 +121,8 @@ int launch_moe_tiled_gemm(T* c, const T* a, const T* w, const float* topk_weight
 #define MTG(KERNEL, NTV, BKV, RV)                                                                                      \
   do {                                                                                                                 \
     using CF = Cfg<NTV, BKV, RV>;                                                                                      \
-    static bool attr_set = false;                                                                                      \
-    if (!attr_set) {                                                                                                   \
-      (void)hipFuncSetAttribute((const void*)KERNEL<T>,                                                                                     \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, CF::kLds);                                 \
-      attr_set = true;                                                                                                 \
-    }                                                                                                                  \
+    static std::atomic<uint64_t> lds_ok{0};                                                                             \
+    if (ensure_dynamic_lds((const void*)KERNEL<T>, CF::kLds, lds_ok, "moe_tiled_gemm")) return 1;                        \
     const int64_t gx = (n + CF::kBN - 1) / CF::kBN;                                                                    \
     dim3 grid((unsigned)(8 * chunks * kChunk * gx));                                                                   \
     hipLaunchKernelGGL((KERNEL<T>), grid, dim3(512), CF::kLds, st, c, a, w, topk_weights,  \
@@ -156,12 +152,8 @@ int launch_moe_tiled_gemm_silu(T* c, const T* a, const T* w, const int32_t* sort
   using namespace mtg;
   if (!moe_tiled_gemm_silu_supported(num_valid, n, k, top_k_div)) return 1;
   using CF = Cfg<2, 64, 3>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)moe_tiled_gemm_silu_kernel_128x128<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              CF::kLds);
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> lds_ok{0};
+  if (ensure_dynamic_lds((const void*)moe_tiled_gemm_silu_kernel_128x128<T>, CF::kLds, lds_ok, "moe_tiled_gemm_silu")) return 1;
   const int64_t a_rows = (num_valid + top_k_div - 1) / top_k_div;
   const int64_t y_max = (max_sorted + kBM - 1) / kBM, y_per = (y_max + 7) / 8, chunks = (y_per + kChunk - 1) / kChunk;
   const int64_t gx = (n / 2 + CF::kBN / 2 - 1) / (CF::kBN / 2);

@@ -292,12 +292,9 @@ static int sg_launch(T* out, float* planes, size_t planes_bytes, const T* x, con
   while (ksp > 1 && (size_t)ksp * M * N * 4 > planes_bytes) --ksp;
   const int per = (nkb + ksp - 1) / ksp;
   ksp = (nkb + per - 1) / per;
-  static bool attr_set = false;  // one per instantiation
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)stream_gemm_glds_kernel<T, MT, NG, NW, R, EPI>,
-                        hipFuncAttributeMaxDynamicSharedMemorySize, L::kBytes);
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> lds_ok{0};  // one per instantiation, one bit per device
+  if (ensure_dynamic_lds((const void*)stream_gemm_glds_kernel<T, MT, NG, NW, R, EPI>, L::kBytes, lds_ok, "stream_gemm_glds"))
+    return 1;
   hipLaunchKernelGGL((stream_gemm_glds_kernel<T, MT, NG, NW, R, EPI>), dim3(n_rb, ksp), dim3(64 * NW), L::kBytes, st,
                      out, planes, x, w, M, N, K, ldx, ldo, per, planes_only_ks ? 1 : 0);
   int rc = launch_status("stream_gemm_glds");

@@ -69,6 +69,11 @@ def run_scheduler_process(server_args: ServerArgs, port_args: SemiPDPortArgs, gp
     parent = os.getppid()
     try:
         import torch
+        if os.environ.get("SEMIPD_TEST_PLUGIN"):
+            # tests reach into the scheduler processes through a plugin file executed at start-up (fault injection
+            # lives in tests/, not in the serving code)
+            import runpy
+            runpy.run_path(os.environ["SEMIPD_TEST_PLUGIN"], run_name="semipd_test_plugin")
         from semi_pd_amd.managers.semi_pd_decode_scheduler import SemiPDDecodeScheduler
         from semi_pd_amd.managers.semi_pd_prefill_scheduler import SemiPDPrefillScheduler
         rank0 = tp_rank == 0

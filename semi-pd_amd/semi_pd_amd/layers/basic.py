@@ -448,9 +448,11 @@ class RowParallelLinear(nn.Module):
         pending = []
         for a in range(0, T, step):
             o = out[a:a + step]
-            torch.mm(x[a:a + step], self.weight.t(), out=o)
             if bias is not None:
-                o += bias
+                # one rounding, like F.linear / addmm in the blocking form (mm + a separate add would round twice)
+                torch.addmm(bias, x[a:a + step], self.weight.t(), out=o)
+            else:
+                torch.mm(x[a:a + step], self.weight.t(), out=o)
             pending.append(tensor_model_parallel_all_reduce_async(o))
         for p in pending:
             p.wait()

@@ -24,7 +24,14 @@ from semi_pd_amd import ops
 
 
 class ReqToTokenPool:
-    """Maps a request slot to the KV-pool slots of its tokens: int32 [size, max_context_len]."""
+    """Request slot -> KV-pool slots of its tokens: the int32 table [size, max_context_len] both instances map
+    (interface of mem_cache/memory_pool.py:46-96: `req_to_token`, write / available_size / alloc / free / clear).
+
+    The slot allocator behind it is this build's own: a FIFO deque plus an in-use bitmap.  Only the decode instance
+    allocates (the prefill instance builds the pool with `bypass_create_buffers` and maps the table through IPC), a
+    slot is handed out at most once until it comes back, and releasing a slot twice or releasing one that was never
+    handed out raises instead of silently putting a duplicate on the free list (two requests would then share a row
+    of the table)."""
 
     def __init__(self, size: int, max_context_len: int, device: str, bypass_create_buffers: bool = False):
         self.size = size
@@ -33,29 +40,33 @@ class ReqToTokenPool:
         self.req_to_token: Optional[torch.Tensor] = None
         if not bypass_create_buffers:
             self.req_to_token = torch.zeros((size, max_context_len), dtype=torch.int32, device=device)
-        self.free_slots = list(range(size))
+        self.clear()
+
+    def clear(self):
+        self._free = collections.deque(range(self.size))
+        self._in_use = bytearray(self.size)
+
+    def available_size(self) -> int:
+        return len(self._free)
+
+    def alloc(self, need_size: int) -> Optional[List[int]]:
+        if need_size > len(self._free):
+            return None
+        slots = [self._free.popleft() for _ in range(need_size)]
+        for i in slots:
+            self._in_use[i] = 1
+        return slots
+
+    def free(self, free_index: Union[int, List[int]]):
+        for i in ((free_index,) if isinstance(free_index, int) else free_index):
+            i = int(i)
+            if not (0 <= i < self.size) or not self._in_use[i]:
+                raise ValueError(f"ReqToTokenPool.free: request slot {i} is not allocated")
+            self._in_use[i] = 0
+            self._free.append(i)
 
     def write(self, indices, values):
         self.req_to_token[indices] = values
-
-    def available_size(self):
-        return len(self.free_slots)
-
-    def alloc(self, need_size: int) -> Optional[List[int]]:
-        if need_size > len(self.free_slots):
-            return None
-        select_index = self.free_slots[:need_size]
-        self.free_slots = self.free_slots[need_size:]
-        return select_index
-
-    def free(self, free_index: Union[int, List[int]]):
-        if isinstance(free_index, int):
-            self.free_slots.append(free_index)
-        else:
-            self.free_slots.extend(free_index)
-
-    def clear(self):
-        self.free_slots = list(range(self.size))
 
 
 class TokenToKVPoolAllocator:

@@ -23,6 +23,18 @@ def get_batch_sizes_to_capture(max_bs: int) -> List[int]:
 
 _PARKED: list = []   # see _capture_one
 
+# fault injection for tests: a callable (bs, outputs) run inside the capture.  Installed only by a test plugin that the
+# scheduler process loads at start-up (entrypoints/engine.py: SEMIPD_TEST_PLUGIN); never set in production.
+capture_fault_hook = None
+
+
+def _destroy_stream(raw: int) -> None:
+    try:
+        from semi_pd_amd import _lib
+        _lib.load().semipd_stream_destroy(raw)
+    except Exception:  # noqa: BLE001  (interpreter shutdown)
+        pass
+
 
 def recover_after_failed_capture(device) -> None:
     """After HipGraphRunner raised out of a capture (its stream is destroyed, what lived on it parked): the sequence that
@@ -80,6 +92,8 @@ class HipGraphRunner:
         _lib.check(_lib.load().semipd_stream_create(torch.device(dev).index or 0, ctypes.addressof(raw)), "stream_create")
         self._raw_stream = raw.value
         self.stream = torch.cuda.ExternalStream(self._raw_stream, device=dev)
+        import weakref
+        self._stream_finalizer = weakref.finalize(self, _destroy_stream, self._raw_stream)
         for bs in reversed(self.capture_bs):
             self._capture_one(bs)
 
@@ -110,14 +124,15 @@ class HipGraphRunner:
         try:
             with torch.cuda.graph(g, pool=self.pool, stream=self.stream):
                 out = run_once()
-                if os.environ.get("SEMIPD_TEST_FAIL_CAPTURE") == "1" and bs <= 4:
-                    out[1].sum().item()   # test hook (tests/test_gpu_engine.py): a synchronising call invalidates the capture
+                if capture_fault_hook is not None:
+                    capture_fault_hook(bs, out)
         except BaseException:
             # something in the step refused capture (a collective of this TP backend, say): the invalidated capture
             # poisons every later synchronising call of the process until its stream is destroyed
             from semi_pd_amd import _lib
             _lib.load().semipd_stream_abort_capture(self._raw_stream)
             self._raw_stream = None
+            self._stream_finalizer.detach()   # the abort destroyed the stream
             # nothing that lives on the dead stream may be freed (the allocator would touch the stream again): the graphs,
             # their outputs and the runner itself are parked for the life of the process
             _PARKED.append((self, g, self.graphs, self.outputs, self.pool, self.stream))

@@ -320,17 +320,27 @@ def lm_head_argmax(hidden: torch.Tensor, weight: torch.Tensor, return_logits: bo
 
 
 # --------------------------------------------------------------------------- decode-sized dense layers
-_LINEAR_WS = {}
-_LINEAR_WS_BYTES = 64 << 20  # split-K partial planes + tile counters, shared by every layer of a process
+_LINEAR_WS = {}     # (device index, hipStream_t) -> [workspace, generation]
+_LINEAR_WS_BYTES = 64 << 20  # split-K partial planes + tile counters, shared by every layer on ONE stream of a process
+
+
+def _linear_workspace_entry(device: torch.device):
+    """Workspace of the decode-sized GEMMs, one per (device, stream): launches on one stream are ordered, so one
+    buffer serves every layer there; a second compute stream in the process (a CU-masked stream, a co-located
+    instance) gets its own and cannot overwrite planes that a consumer on the first stream has yet to read.
+    Every call bumps the entry's generation: a SplitKPlanes remembers the one it was written under."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (idx, current_stream(device))
+    ent = _LINEAR_WS.get(key)
+    if ent is None:
+        ent = [torch.zeros(_LINEAR_WS_BYTES, dtype=torch.uint8, device=device), 0]  # counters must start at zero
+        _LINEAR_WS[key] = ent
+    ent[1] += 1
+    return ent
 
 
 def _linear_workspace(device: torch.device) -> torch.Tensor:
-    key = device.index if device.index is not None else torch.cuda.current_device()
-    ws = _LINEAR_WS.get(key)
-    if ws is None:
-        ws = torch.zeros(_LINEAR_WS_BYTES, dtype=torch.uint8, device=device)  # counters must start at zero
-        _LINEAR_WS[key] = ws
-    return ws
+    return _linear_workspace_entry(device)[0]
 
 
 def linear_is_supported(x: torch.Tensor, weight: torch.Tensor, max_rows: int = 256) -> bool:
@@ -396,15 +406,28 @@ def stream_linear(x: torch.Tensor, weight: torch.Tensor, fuse_silu_mul: bool = F
 
 class SplitKPlanes:
     """The output of a decode-batch GEMM before its K-slice reduction: fp32 planes [ksplit, rows, n] in the
-    per-device workspace (valid until the next stream_linear call on the stream), to be summed by the consumer."""
-    __slots__ = ("planes", "ksplit", "rows", "n", "dtype")
+    workspace of the (device, stream) it was launched on, valid until the next GEMM that uses that workspace.  It is
+    NOT a tensor: the consumer (`fused_add_rmsnorm_planes`, `rope_and_store_kv_planes`) must be the next workspace user
+    on the same stream, and `check_live` enforces that with the generation stamp taken when the planes were written."""
+    __slots__ = ("planes", "ksplit", "rows", "n", "dtype", "_entry", "_generation", "_stream")
 
-    def __init__(self, planes, ksplit, rows, n, dtype):
+    def __init__(self, planes, ksplit, rows, n, dtype, entry=None, stream=None):
         self.planes, self.ksplit, self.rows, self.n, self.dtype = planes, ksplit, rows, n, dtype
+        self._entry, self._generation, self._stream = entry, (entry[1] if entry is not None else None), stream
 
     @property
     def shape(self):
         return (self.rows, self.n)
+
+    def check_live(self, consumer: str) -> None:
+        if self._entry is None:
+            return
+        if self._entry[1] != self._generation:
+            raise RuntimeError(f"{consumer}: the K-slice planes were overwritten by a later GEMM on their stream "
+                               f"(written at workspace generation {self._generation}, now {self._entry[1]}); the "
+                               "consumer of a deferred reduction must directly follow its producer")
+        if current_stream(self.planes.device) != self._stream:
+            raise RuntimeError(f"{consumer}: K-slice planes must be consumed on the stream that produced them")
 
 
 def stream_linear_planes(x: torch.Tensor, weight: torch.Tensor) -> SplitKPlanes:
@@ -413,13 +436,15 @@ def stream_linear_planes(x: torch.Tensor, weight: torch.Tensor) -> SplitKPlanes:
         raise RuntimeError("stream_linear_planes: unsupported shapes / dtypes / strides")
     M, K = x.shape
     N = weight.shape[0]
-    ws = _linear_workspace(x.device)
+    ent = _linear_workspace_entry(x.device)
+    ws = ent[0]
     import ctypes as _C
     ks = _C.c_int(0)
+    stream = current_stream(x.device)
     check(_lib.load().semipd_stream_linear_planes(ptr(ws), ws.numel(), ptr(x), ptr(weight), M, N, K, x.stride(0),
-                                                  dtype_code(x.dtype), _C.addressof(ks), current_stream(x.device)),
+                                                  dtype_code(x.dtype), _C.addressof(ks), stream),
           "stream_linear_planes")
-    return SplitKPlanes(ws, int(ks.value), M, N, x.dtype)
+    return SplitKPlanes(ws, int(ks.value), M, N, x.dtype, ent, stream)
 
 
 def rope_and_store_kv_planes(positions: torch.Tensor, qkv: SplitKPlanes, num_q_heads: int, num_kv_heads: int,
@@ -433,6 +458,17 @@ def rope_and_store_kv_planes(positions: torch.Tensor, qkv: SplitKPlanes, num_q_h
         raise RuntimeError("rope_and_store_kv_planes: planes do not hold a [q | k | v] row")
     if positions.dtype != torch.int64:
         positions = positions.long()
+    if loc.dtype != torch.int64:
+        raise RuntimeError("rope_and_store_kv_planes: loc must be int64 pool rows (the kernel reads 8-byte indices)")
+    if loc.numel() != qkv.rows or not loc.is_contiguous():
+        raise RuntimeError("rope_and_store_kv_planes: one contiguous pool row index per token expected")
+    for name, buf in (("k_buffer", k_buffer), ("v_buffer", v_buffer)):
+        if buf.dim() != 3 or buf.shape[1:] != (num_kv_heads, head_size) or buf.stride(2) != 1 \
+                or buf.stride(1) != head_size:
+            raise RuntimeError(f"rope_and_store_kv_planes: {name} must be [slots, kv heads, head] with dense rows")
+    if k_buffer.dtype != v_buffer.dtype:
+        raise RuntimeError("rope_and_store_kv_planes: k_buffer / v_buffer dtype mismatch")
+    qkv.check_live("rope_and_store_kv_planes")
     q = torch.empty((qkv.rows, num_q_heads * head_size), dtype=qkv.dtype, device=qkv.planes.device)
     check(_lib.load().semipd_rope_kv_store_planes(ptr(q), ptr(qkv.planes), qkv.ksplit, qkv.rows * qkv.n, ptr(k_buffer),
                                                   ptr(v_buffer), ptr(loc), ptr(cos_sin_cache), ptr(positions), qkv.rows,
@@ -445,8 +481,13 @@ def rope_and_store_kv_planes(positions: torch.Tensor, qkv: SplitKPlanes, num_q_h
 def fused_add_rmsnorm_planes(p: SplitKPlanes, residual: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
     """residual += T(sum of the planes); returns RMSNorm(residual) * weight -- fused_add_rmsnorm on the GEMM output
     that was never written (layers/layernorm.py:47-76)."""
+    if residual is None:
+        raise RuntimeError("fused_add_rmsnorm_planes: a residual is required (a layer whose output is deferred planes "
+                           "must be followed by the fused add + norm; reduce the planes with splitk_planes_reduce "
+                           "otherwise)")
     if residual.shape != (p.rows, p.n) or residual.dtype != p.dtype or not residual.is_contiguous():
         raise RuntimeError("fused_add_rmsnorm_planes: residual must be a contiguous [rows, n] tensor of the GEMM's dtype")
+    p.check_live("fused_add_rmsnorm_planes")
     out = torch.empty_like(residual)
     check(_lib.load().semipd_fused_add_rmsnorm_planes(ptr(out), ptr(residual), ptr(weight), ptr(p.planes), p.ksplit,
                                                       p.rows * p.n, p.rows, p.n, float(eps), dtype_code(p.dtype),
