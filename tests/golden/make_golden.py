@@ -1,7 +1,11 @@
 """Generate tests/golden/*.npz from the REFERENCE itself.
 
 Run only in the build container, where /root/reference exists:
-    TORCHDYNAMO_DISABLE=1 python tests/golden/make_golden.py
+    python tests/golden/make_golden.py                 # every fixture, one subprocess per generator
+    python tests/golden/make_golden.py decode extend   # just these, in this process
+    SEMIPD_GOLDEN_OUT=/tmp/g python tests/golden/make_golden.py   # write somewhere else (tests/test_golden_regen_cpu.py)
+(one process per generator because some reference modules can be loaded only once per interpreter: `gen_fp8` loads
+fp8_kernel.py stand-alone and `gen_silu` imports it again through the package, which registers the same torch op twice)
 It imports the reference's leaf modules (stubbing the packages that are not installed, SURVEY.md
 Appendix A), runs them on CPU (Triton kernels under TRITON_INTERPRET=1) on seeded inputs and
 stores inputs + outputs.  Only data is written to the repo; no reference source travels.
@@ -75,7 +79,7 @@ from sglang.srt.layers.attention.utils import create_flashinfer_kv_indices_trito
 from sglang.srt.layers.moe import topk as TK  # noqa: E402
 from sglang.srt.mem_cache.memory_pool import ReqToTokenPool, TokenToKVPoolAllocator  # noqa: E402
 
-OUT = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get("SEMIPD_GOLDEN_OUT") or os.path.dirname(os.path.abspath(__file__))
 
 
 def bits(t: torch.Tensor) -> np.ndarray:
@@ -642,8 +646,12 @@ def gen_penalties():
                   tokenizer=NS(additional_stop_token_ids=None, eos_token_id=EOS), idx=i)
 
     def orch(reqs):
-        return PL.BatchedPenalizerOrchestrator(V, NS(reqs=reqs, device="cpu"), {
-            PL.BatchedFrequencyPenalizer, PL.BatchedMinNewTokensPenalizer, PL.BatchedPresencePenalizer})
+        # the reference passes a SET of classes (schedule_batch.py), whose iteration order -- the order in which the
+        # penalties are subtracted, i.e. the last bit of the result -- changes from process to process; a tuple in a
+        # fixed order makes the fixture reproducible (presence, min_new_tokens, frequency: the order the committed fixture was made with)
+        order = [int(c) for c in os.environ.get("SEMIPD_PENALIZER_ORDER", "210")]
+        classes = (PL.BatchedFrequencyPenalizer, PL.BatchedMinNewTokensPenalizer, PL.BatchedPresencePenalizer)
+        return PL.BatchedPenalizerOrchestrator(V, NS(reqs=reqs, device="cpu"), tuple(classes[i] for i in order))
 
     arrs = {"params": np.array([[f, p, m] for f, p, m, _ in params], dtype=np.float64),
             "stops": np.array([(s + [-1, -1])[:2] for *_, s in params], dtype=np.int64), "eos": np.array(EOS)}
@@ -684,11 +692,29 @@ def gen_penalties():
     save("penalties", **arrs)
 
 
+GENERATORS = {"rmsnorm": gen_rmsnorm, "rope": gen_rope, "kv_indices": gen_kv_indices, "topk": gen_topk,
+              "decode": gen_decode, "extend": gen_extend, "sampling": gen_sampling, "fp8": gen_fp8,
+              "penalties": gen_penalties, "decode_8c": gen_decode_8c, "extend_8c": gen_extend_8c, "silu": gen_silu,
+              "moe_align": gen_moe_align, "fused_moe": gen_fused_moe, "bmm_fp8": gen_bmm_fp8}
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rmsnorm", "rope", "kv_indices", "topk", "decode", "extend", "sampling", "fp8", "penalties",
-                             "decode_8c", "extend_8c", "silu", "moe_align", "fused_moe", "bmm_fp8"]
-    for w in which:
-        {"rmsnorm": gen_rmsnorm, "rope": gen_rope, "kv_indices": gen_kv_indices, "topk": gen_topk,
-         "decode": gen_decode, "extend": gen_extend, "sampling": gen_sampling, "fp8": gen_fp8, "penalties": gen_penalties,
-         "decode_8c": gen_decode_8c, "extend_8c": gen_extend_8c, "silu": gen_silu, "moe_align": gen_moe_align,
-         "fused_moe": gen_fused_moe, "bmm_fp8": gen_bmm_fp8}[w]()
+    names = sys.argv[1:]
+    unknown = [n for n in names if n not in GENERATORS]
+    if unknown:
+        raise SystemExit(f"unknown generator(s) {unknown}; known: {sorted(GENERATORS)}")
+    if names:
+        for n in names:
+            GENERATORS[n]()
+    else:
+        # everything: a fresh interpreter per generator
+        import subprocess
+        os.makedirs(OUT, exist_ok=True)
+        failed = []
+        for n in GENERATORS:
+            rc = subprocess.call([sys.executable, os.path.abspath(__file__), n])
+            if rc != 0:
+                failed.append(n)
+        if failed:
+            raise SystemExit(f"generators failed: {failed}")
+        print("all", len(GENERATORS), "generators ran")
