@@ -232,6 +232,34 @@ int semipd_linear(void* out, const void* x, const void* weight, void* workspace,
  * to the activation type first, i.e. the value the unfused pair of ops produces.  k % 128 == 0.
  * replaces UnquantizedLinearMethod.apply -> F.linear (layers/linear.py:165-172) and, fused, LlamaMLP's
  *   gate_up_proj + SiluAndMul (models/llama.py:88-92, layers/activation.py:41-53) at decode batch sizes. */
+/* ---- prefill-sized dense layers on a CU share (csrc/dense_gemm.cpp) ------------------------------------------------
+ * out[rows, n] = x[rows, k] @ weight[n, k]^T (+ bias[n]) through hipBLASLt with the solution that MEASURED fastest on
+ * the compute units this process owns.  Replaces F.linear in UnquantizedLinearMethod.apply
+ * (python/sglang/srt/layers/linear.py:165-172) for batches above the streaming kernel's range: the reference sets the
+ * prefill / decode shares at entrypoints/engine.py:583-634 and leaves GEMM selection to the library, whose heuristic
+ * assumes the whole device.
+ *   semipd_dense_gemm_init   creates the library handle and its workspace (0 = 64 MB); start-up.
+ *   semipd_dense_gemm_tune   times the library's solutions for weight shape (n, k) at rows[0..num_rows) on this process's
+ *                            CUs; the first num_full_search row counts are searched over every solution (max_solutions
+ *                            > 0 caps that), their best pool_size each are the candidates at the other row counts.
+ *                            Allocates and frees scratch operands: start-up only.
+ *   semipd_dense_gemm        launches with the winner of the nearest tuned row count (the library's own choice when
+ *                            nothing was tuned or the winner does not support this row count).  Never allocates or
+ *                            synchronises; dtype bf16 / f16; ldx / ldo = row strides in elements.
+ *   semipd_dense_gemm_report text table of the tuning results; returns the bytes needed. */
+int semipd_dense_gemm_init(size_t workspace_bytes);
+int semipd_dense_gemm_tune(int64_t n, int64_t k, const int64_t* rows, int num_rows, int num_full_search, int dtype,
+                           int pool_size, int max_solutions, void* stream);
+int semipd_dense_gemm(void* out, const void* x, const void* weight, const void* bias, int64_t rows, int64_t n, int64_t k,
+                      int64_t ldx, int64_t ldo, int dtype, void* stream);
+size_t semipd_dense_gemm_report(char* buf, size_t len);
+
+/* Compute units of the share this process runs its decode-sized GEMMs on (its HSA_CU_MASK / stream mask); 0 = default
+ * (128, half a chip).  The K split of semipd_stream_linear / _planes fills whole rounds of that many CUs.  The split
+ * sets the order of the fp32 partial sums: processes that must produce identical bits declare the same share.
+ * Replaces nothing in the reference (its shares are MPS percentages, entrypoints/engine.py:591-593, 632-634, and its
+ * GEMMs do not know them). */
+int semipd_stream_linear_set_cus(int cus);
 size_t semipd_stream_linear_workspace(int64_t max_n);
 int semipd_stream_linear(void* out, const void* x, const void* weight, void* workspace, size_t workspace_bytes,
                          int64_t rows, int64_t n, int64_t k, int64_t ldx, int64_t ldo, int fuse_silu_mul,

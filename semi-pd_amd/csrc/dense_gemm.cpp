@@ -1,0 +1,344 @@
+// Prefill-sized dense layers on a CU share: out[rows, n] = x[rows, k] @ W[n, k]^T through hipBLASLt with the SOLUTION
+// chosen by measurement on the compute units this process owns.
+//
+// The library's heuristic picks persistent stream-K kernels whose grids are sized for the 256 CUs of the device; under
+// an HSA_CU_MASK (the Semi-PD prefill share) those run as two rounds and a 192-CU share is no faster than a 128-CU one
+// (profiles/r02_hipblaslt_under_cu_masks.txt).  Other solutions of the same library -- plain tiled kernels whose
+// workgroups the hardware spreads over whatever CUs there are -- are 15-25 % faster on such a share
+// (profiles/r03_library_gemm_under_masks_tunableop.txt, r03_blaslt_probe_under_masks.txt).  So the prefill instance
+// times the library's solutions once at start-up, ON ITS OWN SHARE, for each weight shape of the model at a few row
+// counts, and every later call takes the winner of the nearest row count.  This is the share-aware counterpart of
+// UnquantizedLinearMethod.apply -> F.linear (layers/linear.py:165-172) for batches above the streaming kernel's range;
+// the reference sets its shares at entrypoints/engine.py:583-634 and leaves the GEMMs to cuBLAS.
+//
+// Host code only (no kernels of ours run here): plumbing around a plain library GEMM.
+#include <hip/hip_runtime.h>
+#include <hipblaslt/hipblaslt-ext.hpp>
+#include <hipblaslt/hipblaslt.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+using semipd::set_error;
+
+struct Plan {   // one (rows, n, k, dtype, ldx, ldo, bias) problem, ready to launch
+  hipblasLtMatmulDesc_t desc = nullptr;
+  hipblasLtMatrixLayout_t la = nullptr, lb = nullptr, lc = nullptr;
+  hipblasLtMatmulAlgo_t algo;
+  bool have_algo = false;
+  int solution_index = -1;
+  bool tuned = false;
+};
+
+struct Tuned {  // winner of one tuning run
+  hipblasLtMatmulAlgo_t algo;
+  int solution_index;
+  float us, us_default;
+};
+
+struct State {
+  std::mutex mu;
+  hipblasLtHandle_t handle = nullptr;
+  void* workspace = nullptr;
+  size_t workspace_bytes = 0;
+  // (dtype, n, k) -> rows -> winner
+  std::map<std::tuple<int, int64_t, int64_t>, std::map<int64_t, Tuned>> tuned;
+  // (dtype, n, k) -> candidate pool (solutions that were among the fastest at some tuned row count)
+  std::map<std::tuple<int, int64_t, int64_t>, std::vector<hipblasLtMatmulAlgo_t>> pool;
+  std::map<std::tuple<int, int64_t, int64_t, int64_t, int64_t, int64_t, int>, Plan> plans;
+  int device = -1;
+};
+
+State& st() {
+  static State s;
+  return s;
+}
+
+hipDataType hip_type(int dtype) { return dtype == SEMIPD_BF16 ? HIP_R_16BF : HIP_R_16F; }
+
+int ensure_init(State& s, size_t workspace_bytes) {
+  if (s.handle) return 0;
+  if (hipblasLtCreate(&s.handle) != HIPBLAS_STATUS_SUCCESS) {
+    set_error("dense_gemm: hipblasLtCreate failed");
+    s.handle = nullptr;
+    return 1;
+  }
+  (void)hipGetDevice(&s.device);
+  s.workspace_bytes = workspace_bytes ? workspace_bytes : ((size_t)64 << 20);
+  if (hipMalloc(&s.workspace, s.workspace_bytes) != hipSuccess) {
+    set_error("dense_gemm: cannot allocate the %zu-byte library workspace", s.workspace_bytes);
+    s.workspace = nullptr;
+    return 1;
+  }
+  return 0;
+}
+
+// out^T (column-major n x rows) = W^T (W stored column-major k x n) * x (column-major k x rows)
+int make_problem(Plan& p, int dtype, int64_t rows, int64_t n, int64_t k, int64_t ldx, int64_t ldo, bool bias) {
+  const hipDataType t = hip_type(dtype);
+  if (hipblasLtMatrixLayoutCreate(&p.la, t, k, n, k) || hipblasLtMatrixLayoutCreate(&p.lb, t, k, rows, ldx) ||
+      hipblasLtMatrixLayoutCreate(&p.lc, t, n, rows, ldo) || hipblasLtMatmulDescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F)) {
+    set_error("dense_gemm: descriptor creation failed");
+    return 1;
+  }
+  hipblasOperation_t ta = HIPBLAS_OP_T, tb = HIPBLAS_OP_N;
+  hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &ta, sizeof(ta));
+  hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &tb, sizeof(tb));
+  if (bias) {
+    hipblasLtEpilogue_t epi = HIPBLASLT_EPILOGUE_BIAS;
+    hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &epi, sizeof(epi));
+    hipDataType bt = t;
+    hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &bt, sizeof(bt));
+  }
+  return 0;
+}
+
+void destroy_problem(Plan& p) {
+  if (p.la) hipblasLtMatrixLayoutDestroy(p.la);
+  if (p.lb) hipblasLtMatrixLayoutDestroy(p.lb);
+  if (p.lc) hipblasLtMatrixLayoutDestroy(p.lc);
+  if (p.desc) hipblasLtMatmulDescDestroy(p.desc);
+  p = Plan();
+}
+
+bool heuristic_algo(State& s, Plan& p, hipblasLtMatmulAlgo_t* out) {
+  hipblasLtMatmulPreference_t pref;
+  if (hipblasLtMatmulPreferenceCreate(&pref)) return false;
+  hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &s.workspace_bytes,
+                                        sizeof(s.workspace_bytes));
+  hipblasLtMatmulHeuristicResult_t r[1];
+  int got = 0;
+  const bool ok = hipblasLtMatmulAlgoGetHeuristic(s.handle, p.desc, p.la, p.lb, p.lc, p.lc, pref, 1, r, &got) ==
+                      HIPBLAS_STATUS_SUCCESS && got > 0;
+  hipblasLtMatmulPreferenceDestroy(pref);
+  if (ok) *out = r[0].algo;
+  return ok;
+}
+
+bool supported(State& s, Plan& p, hipblasLtMatmulAlgo_t& algo) {
+  float alpha = 1.f, beta = 0.f;
+  size_t need = 0;
+  return hipblaslt_ext::matmulIsAlgoSupported(s.handle, p.desc, &alpha, p.la, p.lb, &beta, p.lc, p.lc, algo, need) ==
+             HIPBLAS_STATUS_SUCCESS && need <= s.workspace_bytes;
+}
+
+float time_algo(State& s, Plan& p, hipblasLtMatmulAlgo_t& algo, const void* w, const void* x, void* o, int reps,
+                hipStream_t stream, hipEvent_t e0, hipEvent_t e1) {
+  float alpha = 1.f, beta = 0.f;
+  for (int i = 0; i < 2; ++i)
+    if (hipblasLtMatmul(s.handle, p.desc, &alpha, w, p.la, x, p.lb, &beta, o, p.lc, o, p.lc, &algo, s.workspace,
+                        s.workspace_bytes, stream) != HIPBLAS_STATUS_SUCCESS)
+      return 1e30f;
+  (void)hipEventRecord(e0, stream);
+  for (int i = 0; i < reps; ++i)
+    hipblasLtMatmul(s.handle, p.desc, &alpha, w, p.la, x, p.lb, &beta, o, p.lc, o, p.lc, &algo, s.workspace, s.workspace_bytes,
+                    stream);
+  (void)hipEventRecord(e1, stream);
+  if (hipEventSynchronize(e1) != hipSuccess) return 1e30f;
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  return ms * 1e3f / reps;
+}
+
+}  // namespace
+
+extern "C" {
+
+int semipd_dense_gemm_init(size_t workspace_bytes) {
+  State& s = st();
+  std::lock_guard<std::mutex> g(s.mu);
+  return ensure_init(s, workspace_bytes);
+}
+
+/* Time the library's solutions for out[rows, n] = x[rows, k] @ W[n, k]^T at each of `rows[0..num_rows)` on the CUs this
+ * process owns and remember the winner per row count.  The first `num_full_search` row counts are searched over EVERY
+ * solution the library has for this operand layout (`max_solutions` > 0 caps a search to the first so many supported
+ * ones); the best `pool_size` of each such search, together with the library's own choice, are the candidates at the
+ * remaining row counts.  Operands are scratch buffers allocated and freed here (start-up only); the calling thread's
+ * current device is used. */
+int semipd_dense_gemm_tune(int64_t n, int64_t k, const int64_t* rows, int num_rows, int num_full_search, int dtype,
+                           int pool_size, int max_solutions, void* stream) {
+  SEMIPD_CHECK_ARG(n > 0 && k > 0 && rows && num_rows > 0 && (dtype == SEMIPD_BF16 || dtype == SEMIPD_F16),
+                   SEMIPD_EINVAL, "dense_gemm_tune: bad arguments");
+  State& s = st();
+  std::lock_guard<std::mutex> g(s.mu);
+  if (ensure_init(s, 0)) return 1;
+  hipStream_t hs = (hipStream_t)stream;
+  int64_t max_rows = 0;
+  for (int i = 0; i < num_rows; ++i) max_rows = std::max(max_rows, rows[i]);
+  void *x = nullptr, *w = nullptr, *o = nullptr;
+  if (hipMalloc(&x, max_rows * k * 2) || hipMalloc(&w, n * k * 2) || hipMalloc(&o, max_rows * n * 2)) {
+    set_error("dense_gemm_tune: scratch allocation failed");
+    if (x) (void)hipFree(x);
+    if (w) (void)hipFree(w);
+    return 1;
+  }
+  {  // operands with realistic bit patterns: the clock a GEMM sustains depends on its data
+    std::vector<uint16_t> h((size_t)std::max(max_rows * k, n * k));
+    uint32_t r = 2463534242u;
+    const uint16_t base = dtype == SEMIPD_BF16 ? 0x3c00 : 0x2000;
+    for (auto& v : h) {
+      r ^= r << 13, r ^= r >> 17, r ^= r << 5;
+      v = (uint16_t)(base | ((r >> 16) & 0xff) | ((r >> 9) & 0x8000));
+    }
+    (void)hipMemcpy(x, h.data(), max_rows * k * 2, hipMemcpyHostToDevice);
+    (void)hipMemcpy(w, h.data(), n * k * 2, hipMemcpyHostToDevice);
+  }
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  const auto key = std::make_tuple(dtype, n, k);
+  std::vector<hipblasLtMatmulAlgo_t>& pool = s.pool[key];
+  int rc = 0;
+  for (int ri = 0; ri < num_rows && rc == 0; ++ri) {
+    const int64_t m = rows[ri];
+    Plan p;
+    if (make_problem(p, dtype, m, n, k, k, n, false)) { rc = 1; break; }
+    hipblasLtMatmulAlgo_t dflt;
+    const bool have_default = heuristic_algo(s, p, &dflt);
+    const float t_default = have_default ? time_algo(s, p, dflt, w, x, o, 8, hs, e0, e1) : 1e30f;
+    std::vector<std::pair<float, hipblasLtMatmulAlgo_t>> timed;
+    if (have_default) timed.push_back({t_default, dflt});
+    if (ri < num_full_search || pool.empty()) {
+      std::vector<hipblasLtMatmulHeuristicResult_t> all;
+      hipblasOperation_t ta = HIPBLAS_OP_T, tb = HIPBLAS_OP_N;
+      if (hipblaslt_ext::getAllAlgos(s.handle, hipblaslt_ext::GemmType::HIPBLASLT_GEMM, ta, tb, hip_type(dtype), hip_type(dtype),
+                                     hip_type(dtype), hip_type(dtype), HIPBLAS_COMPUTE_32F, all) == HIPBLAS_STATUS_SUCCESS) {
+        int tried = 0;
+        for (auto& r : all) {
+          if (!supported(s, p, r.algo)) continue;
+          if (max_solutions > 0 && tried >= max_solutions) break;
+          ++tried;
+          const float t = time_algo(s, p, r.algo, w, x, o, 3, hs, e0, e1);
+          if (t < 1e29f) timed.push_back({t, r.algo});
+        }
+      }
+      std::sort(timed.begin(), timed.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+      const size_t keep = std::min<size_t>(timed.size(), (size_t)std::max(pool_size, 1));
+      for (size_t i = 0; i < keep; ++i) {
+        const int idx = hipblaslt_ext::getIndexFromAlgo(timed[i].second);
+        bool known = false;
+        for (auto& a : pool) known = known || hipblaslt_ext::getIndexFromAlgo(a) == idx;
+        if (!known) pool.push_back(timed[i].second);
+      }
+      timed.resize(keep);
+    } else {
+      for (auto& a : pool)
+        if (supported(s, p, a)) timed.push_back({0.f, a});
+    }
+    // the leaders again, properly
+    float best = 1e30f;
+    int best_i = -1;
+    for (size_t i = 0; i < timed.size(); ++i) {
+      const float t = time_algo(s, p, timed[i].second, w, x, o, 12, hs, e0, e1);
+      if (t < best) best = t, best_i = (int)i;
+    }
+    if (best_i >= 0) {
+      Tuned t;
+      t.algo = timed[best_i].second;
+      t.solution_index = hipblaslt_ext::getIndexFromAlgo(t.algo);
+      t.us = best;
+      t.us_default = t_default;
+      s.tuned[key][m] = t;
+    }
+    destroy_problem(p);
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(x);
+  (void)hipFree(w);
+  (void)hipFree(o);
+  for (auto& kv : s.plans) destroy_problem(kv.second);   // plans made before this tuning may hold other choices
+  s.plans.clear();
+  return rc;
+}
+
+/* out[rows, n] = x[rows, k] @ weight[n, k]^T (+ bias[n]) with the solution measured fastest on this process's CUs at the
+ * nearest tuned row count (semipd_dense_gemm_tune), the library's own heuristic choice when nothing was tuned for
+ * (dtype, n, k) or the winner does not support this row count.  Replaces F.linear in UnquantizedLinearMethod.apply
+ * (layers/linear.py:165-172).  Returns SEMIPD_ESHAPE-free: any rows > 0. */
+int semipd_dense_gemm(void* out, const void* x, const void* weight, const void* bias, int64_t rows, int64_t n, int64_t k,
+                      int64_t ldx, int64_t ldo, int dtype, void* stream) {
+  SEMIPD_CHECK_ARG(rows >= 0 && n > 0 && k > 0 && ldx >= k && ldo >= n, SEMIPD_EINVAL, "dense_gemm: bad sizes");
+  if (rows == 0) return 0;
+  SEMIPD_CHECK_ARG(out && x && weight, SEMIPD_EINVAL, "dense_gemm: null pointer");
+  SEMIPD_CHECK_ARG(dtype == SEMIPD_BF16 || dtype == SEMIPD_F16, SEMIPD_EDTYPE, "dense_gemm: bf16 / f16 only");
+  State& s = st();
+  std::lock_guard<std::mutex> g(s.mu);
+  if (!s.handle) {
+    set_error("dense_gemm: call semipd_dense_gemm_init (or _tune) first: no allocation happens on the serving path");
+    return SEMIPD_EINVAL;
+  }
+  const auto pkey = std::make_tuple(dtype, rows, n, k, ldx, ldo, bias ? 1 : 0);
+  auto it = s.plans.find(pkey);
+  if (it == s.plans.end()) {
+    Plan p;
+    if (make_problem(p, dtype, rows, n, k, ldx, ldo, bias != nullptr)) return 1;
+    auto tk = s.tuned.find(std::make_tuple(dtype, n, k));
+    if (tk != s.tuned.end() && !tk->second.empty()) {
+      const Tuned* bestt = nullptr;
+      double bestd = 1e30;
+      for (auto& kv : tk->second) {
+        const double d = std::fabs(std::log2((double)kv.first) - std::log2((double)rows));
+        if (d < bestd) bestd = d, bestt = &kv.second;
+      }
+      hipblasLtMatmulAlgo_t a = bestt->algo;
+      if (supported(s, p, a)) p.algo = a, p.have_algo = true, p.tuned = true, p.solution_index = bestt->solution_index;
+    }
+    if (!p.have_algo) {
+      if (!heuristic_algo(s, p, &p.algo)) {
+        destroy_problem(p);
+        set_error("dense_gemm: the library has no solution for rows=%lld n=%lld k=%lld", (long long)rows, (long long)n,
+                  (long long)k);
+        return SEMIPD_ESHAPE;
+      }
+      p.have_algo = true;
+      p.solution_index = hipblaslt_ext::getIndexFromAlgo(p.algo);
+    }
+    it = s.plans.emplace(pkey, p).first;
+  }
+  Plan& p = it->second;
+  if (bias) hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias));
+  float alpha = 1.f, beta = 0.f;
+  const hipblasStatus_t rc = hipblasLtMatmul(s.handle, p.desc, &alpha, weight, p.la, x, p.lb, &beta, out, p.lc, out, p.lc,
+                                             &p.algo, s.workspace, s.workspace_bytes, (hipStream_t)stream);
+  if (rc != HIPBLAS_STATUS_SUCCESS) {
+    set_error("dense_gemm: hipblasLtMatmul failed with status %d (solution %d)", (int)rc, p.solution_index);
+    return 1;
+  }
+  return 0;
+}
+
+/* Text report of the tuning table: one line per (dtype, n, k, rows): solution index, its time and the time of the library's
+ * own choice on this share (microseconds).  Returns the number of bytes needed (including the terminator). */
+size_t semipd_dense_gemm_report(char* buf, size_t len) {
+  State& s = st();
+  std::lock_guard<std::mutex> g(s.mu);
+  std::string out;
+  char line[256];
+  for (auto& kv : s.tuned)
+    for (auto& rv : kv.second) {
+      snprintf(line, sizeof(line), "dtype=%d n=%lld k=%lld rows=%lld solution=%d us=%.1f library_choice_us=%.1f\n",
+               std::get<0>(kv.first), (long long)std::get<1>(kv.first), (long long)std::get<2>(kv.first), (long long)rv.first,
+               rv.second.solution_index, rv.second.us, rv.second.us_default);
+      out += line;
+    }
+  if (buf && len) {
+    const size_t c = std::min(len - 1, out.size());
+    memcpy(buf, out.data(), c);
+    buf[c] = 0;
+  }
+  return out.size() + 1;
+}
+
+}  // extern "C"

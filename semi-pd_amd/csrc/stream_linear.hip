@@ -269,15 +269,33 @@ splitk_planes_reduce_kernel(T* __restrict__ out, const float* __restrict__ plane
   *reinterpret_cast<uint2*>(out + (int64_t)m * ldo + n) = p;
 }
 
-// K slices of a launch with n_rb row batches: enough workgroups for the 128 CUs of a half-chip decode share
-// (one 8-wave workgroup per CU), at least 4 k-blocks of 128 per slice.  The split depends on the SHAPE only, so
-// the prefill and the decode instance (different CU shares) and the unified engine produce the same bits.
-static int sg_pick_ksplit(int n_rb, int nkb) {
-  int ksp = max(1, 128 / max(n_rb, 1));
-  ksp = min(ksp, max(1, nkb / 4));
-  ksp = min(ksp, 16);
-  const int per = (nkb + ksp - 1) / ksp;
-  return (nkb + per - 1) / per;                              // no empty slices
+// K slices of a launch with n_rb row batches on a share of `cus` compute units (one 8-wave workgroup per CU: the LDS
+// rings take the whole CU).  The hardware runs the n_rb x ks workgroups in ceil(n_rb * ks / cus) rounds, so the split is
+// picked to fill whole rounds of THIS share: a cost model in microseconds -- a workgroup streams one 128-k block of
+// its rows (NW x NG x 4 KB) in ~0.86 us (37 GB/s per CU, profiles/r03_kbench_stream_linear_small_shares_v0.txt), a
+// round costs ~2 us of ramp and drain, and every slice beyond the first writes and re-reads an fp32 plane.  With the
+// default share (128 CUs, a half-chip decode instance) this reproduces the round-2 table (o_proj / down 4, qkv 2,
+// gate_up 1).  The split -- and with it the summation order, i.e. the last bit of the result -- depends on the share the
+// process declares (semipd_stream_linear_set_cus); two processes that must produce the same bits declare the same.
+static std::atomic<int> g_sl_cus{128};
+
+static int sg_pick_ksplit(int n_rb, int nkb, int M, int N, bool extra_reduce_launch) {
+  const int cus = max(8, g_sl_cus.load(std::memory_order_relaxed));
+  const float t_block = 0.86f, t_round = 2.0f;
+  const float plane_us = 2.f * M * (float)N * 4.f / (cus * 37e3f);   // one plane written + read back
+  int best = 1;
+  float best_cost = 1e30f;
+  for (int ksp = 1; ksp <= 16; ++ksp) {
+    const int per = (nkb + ksp - 1) / ksp;
+    if (ksp > 1 && per < 4) break;
+    const int eff = (nkb + per - 1) / per;                         // no empty slices
+    if (eff != ksp) continue;
+    const int rounds = (n_rb * eff + cus - 1) / cus;
+    float cost = rounds * (per * t_block + t_round);
+    if (eff > 1) cost += eff * plane_us + (extra_reduce_launch ? 2.5f : 0.f);
+    if (cost < best_cost - 1e-3f) best_cost = cost, best = eff;
+  }
+  return best;
 }
 
 template <typename T, int MT, int NG, int NW, int R, int EPI>
@@ -288,7 +306,7 @@ static int sg_launch(T* out, float* planes, size_t planes_bytes, const T* x, con
   const int n_rows = EPI == SL_SILU_MUL ? N / 2 : N;
   const int n_rb = (n_rows + rows_per_wg - 1) / rows_per_wg;
   const int nkb = K / 128;
-  int ksp = force_ks > 0 ? force_ks : sg_pick_ksplit(n_rb, nkb);
+  int ksp = force_ks > 0 ? force_ks : sg_pick_ksplit(n_rb, nkb, M, N, planes_only_ks == nullptr);
   while (ksp > 1 && (size_t)ksp * M * N * 4 > planes_bytes) --ksp;
   const int per = (nkb + ksp - 1) / ksp;
   ksp = (nkb + per - 1) / per;
@@ -322,6 +340,14 @@ static int sl_env(const char* name, int dflt) {
   return e ? atoi(e) : dflt;
 }
 
+/* CUs of the share this process runs its decode-sized GEMMs on (HSA_CU_MASK / stream mask); 0 restores the default
+ * (128).  Picks the K split of semipd_stream_linear / _planes, see sg_pick_ksplit. */
+int semipd_stream_linear_set_cus(int cus) {
+  SEMIPD_CHECK_ARG(cus >= 0 && cus <= 4096, SEMIPD_EINVAL, "stream_linear_set_cus: bad CU count %d", cus);
+  g_sl_cus.store(cus == 0 ? 128 : cus, std::memory_order_relaxed);
+  return 0;
+}
+
 size_t semipd_stream_linear_workspace(int64_t max_n) {
   return (size_t)16 * 64 * (size_t)max_n * 4;   // 16 K slices of [64 rows, n] fp32
 }
@@ -347,10 +373,16 @@ int semipd_stream_linear(void* out, const void* x, const void* weight, void* wor
   float* planes = (float*)workspace;
   const size_t pb = workspace ? workspace_bytes : 0;
   int rc = 0;
-#define SL_GO(MTV) \
-  if (fuse_silu_mul) { SEMIPD_DISPATCH_HALF(dtype, T, rc = (sg_launch<T, MTV, 2, 4, 3, SL_SILU_MUL>((T*)out, planes, pb, (const T*)x, (const T*)weight, M, N, K, ldx, ldo, force_ks, st))); } \
-  else { SEMIPD_DISPATCH_HALF(dtype, T, rc = (sg_launch<T, MTV, 1, 8, 3, SL_PLAIN>((T*)out, planes, pb, (const T*)x, (const T*)weight, M, N, K, ldx, ldo, force_ks, st))); }
-  if (mt == 1) { SL_GO(1) } else if (mt == 2) { SL_GO(2) } else if (mt == 3) { SL_GO(3) } else { SL_GO(4) }
+  // ring depth: up to 32 rows the activation ring is small enough for FOUR slots in the CU's 160 KB (three blocks in
+  // flight per wave instead of two: the stream is bound by bytes in flight per CU); SEMIPD_SL_RING=3 for A/B runs
+  static const int ring_knob = sl_env("SEMIPD_SL_RING", 4);
+  const bool deep = mt <= 2 && ring_knob >= 4;
+#define SL_GO(MTV, RV) \
+  if (fuse_silu_mul) { SEMIPD_DISPATCH_HALF(dtype, T, rc = (sg_launch<T, MTV, 2, 4, RV, SL_SILU_MUL>((T*)out, planes, pb, (const T*)x, (const T*)weight, M, N, K, ldx, ldo, force_ks, st))); } \
+  else { SEMIPD_DISPATCH_HALF(dtype, T, rc = (sg_launch<T, MTV, 1, 8, RV, SL_PLAIN>((T*)out, planes, pb, (const T*)x, (const T*)weight, M, N, K, ldx, ldo, force_ks, st))); }
+  if (mt == 1) { if (deep) { SL_GO(1, 4) } else { SL_GO(1, 3) } }
+  else if (mt == 2) { if (deep) { SL_GO(2, 4) } else { SL_GO(2, 3) } }
+  else if (mt == 3) { SL_GO(3, 3) } else { SL_GO(4, 3) }
 #undef SL_GO
   return rc;
 }
@@ -369,9 +401,13 @@ int semipd_stream_linear_planes(float* planes, size_t planes_bytes, const void* 
   const int M = (int)rows, N = (int)n, K = (int)k;
   const int mt = (M + 15) / 16;
   int rc = 0;
-#define SL_GO(MTV) \
-  SEMIPD_DISPATCH_HALF(dtype, T, rc = (sg_launch<T, MTV, 1, 8, 3, SL_PLAIN>((T*)nullptr, planes, planes_bytes, (const T*)x, (const T*)weight, M, N, K, ldx, N, sl_env("SEMIPD_SL_KS", 0), st, ksplit)));
-  if (mt == 1) { SL_GO(1) } else if (mt == 2) { SL_GO(2) } else if (mt == 3) { SL_GO(3) } else { SL_GO(4) }
+  static const int ring_knob = sl_env("SEMIPD_SL_RING", 4);
+  const bool deep = mt <= 2 && ring_knob >= 4;
+#define SL_GO(MTV, RV) \
+  SEMIPD_DISPATCH_HALF(dtype, T, rc = (sg_launch<T, MTV, 1, 8, RV, SL_PLAIN>((T*)nullptr, planes, planes_bytes, (const T*)x, (const T*)weight, M, N, K, ldx, N, sl_env("SEMIPD_SL_KS", 0), st, ksplit)));
+  if (mt == 1) { if (deep) { SL_GO(1, 4) } else { SL_GO(1, 3) } }
+  else if (mt == 2) { if (deep) { SL_GO(2, 4) } else { SL_GO(2, 3) } }
+  else if (mt == 3) { SL_GO(3, 3) } else { SL_GO(4, 3) }
 #undef SL_GO
   return rc;
 }

@@ -64,6 +64,11 @@ _SIGNATURES = {
     "semipd_stream_abort_capture": [_vp],
     "semipd_clear_last_error": [],
     "semipd_stream_linear_workspace": [_i64],
+    "semipd_stream_linear_set_cus": [_i32],
+    "semipd_dense_gemm_init": [_sz],
+    "semipd_dense_gemm_tune": [_i64, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "semipd_dense_gemm": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32, _vp],
+    "semipd_dense_gemm_report": [_vp, _sz],
     "semipd_stream_linear_planes": [_vp, _sz, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp],
     "semipd_fused_add_rmsnorm_planes": [_vp, _vp, _vp, _vp, _i32, _i64, _i64, _i64, _f32, _i32, _vp],
     "semipd_stream_linear": [_vp, _vp, _vp, _vp, _sz, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _vp],
@@ -111,7 +116,7 @@ _SIGNATURES = {
     "semipd_ar_dispose": [_vp],
 }
 _RESTYPES = {"semipd_last_error": C.c_char_p, "semipd_lm_head_argmax_workspace": _sz,
-             "semipd_linear_workspace": _sz, "semipd_stream_linear_workspace": _sz, "semipd_ar_meta_size": _sz, "semipd_ar_region_size": _sz}
+             "semipd_linear_workspace": _sz, "semipd_stream_linear_workspace": _sz, "semipd_dense_gemm_report": _sz, "semipd_ar_meta_size": _sz, "semipd_ar_region_size": _sz}
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

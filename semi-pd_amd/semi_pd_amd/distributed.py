@@ -108,6 +108,9 @@ def get_custom_all_reduce():
 _COMM_STREAMS = {}
 OVERLAP_MIN_TOKENS = int(os.environ.get("SEMIPD_AR_OVERLAP_MIN_TOKENS", "1024"))   # below: one blocking call
 _OVERLAP = {"enabled": os.environ.get("SEMIPD_DISABLE_AR_OVERLAP", "0") != "1"}
+# what the overlapped path did in this process (reported with the scheduler's stats): chunk reduces issued next to a
+# GEMM, and how many of them ran as peer-memory kernels on the communication stream
+OVERLAP_STATS = {"overlapped_reduces": 0, "overlapped_reduces_peer_memory_kernel": 0}
 
 
 def set_all_reduce_overlap(enabled: bool) -> None:
@@ -144,7 +147,9 @@ def tensor_model_parallel_all_reduce_async(input_: torch.Tensor) -> _Pending:
     before it reads `input_` or issues a blocking collective."""
     if _TP_SIZE == 1:
         return _Pending()
+    OVERLAP_STATS["overlapped_reduces"] += 1
     if _CUSTOM_AR is not None and _CUSTOM_AR.should_custom_ar(input_):
+        OVERLAP_STATS["overlapped_reduces_peer_memory_kernel"] += 1
         dev = input_.device
         comm = _COMM_STREAMS.get(dev.index)
         if comm is None:

@@ -103,6 +103,11 @@ def run_scheduler_process(server_args: ServerArgs, port_args: SemiPDPortArgs, gp
                                bypass_load_weight=True, cu_percent=server_args.prefill_cu_percent)
             mr.share_params_from_ipc(ipc_info)      # semi_pd_scheduler.py:406-407
             mr.init_attention_backend()
+            tune = server_args.tune_prefill_gemm
+            if tune or (tune is None and server_args.prefill_cu_percent < 100 and server_args.cu_mask_mode == "env"):
+                t0 = time.time()
+                table = mr.tune_dense_gemms()
+                logger.warning("library GEMM solutions timed on this share in %.1f s:\n%s", time.time() - t0, table)
             sched = SemiPDPrefillScheduler(
                 server_args, mr, tp_rank,
                 recv_socket=PullSocket(port_args.p_scheduler_input_ipc_name) if rank0 else None,

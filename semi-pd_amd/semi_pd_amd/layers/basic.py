@@ -230,6 +230,10 @@ def dense_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
     if (_STREAM_LINEAR["enabled"] and bias is None and x.dim() == 2 and x.shape[0] <= ops.STREAM_LINEAR_MAX_ROWS
             and ops.stream_linear_is_supported(x, weight)):
         return _timed_stream(lambda: ops.stream_linear(x, weight), x, weight, weight.shape[0], 2)
+    if x.dim() == 2 and x.shape[0] > 0 and ops.dense_gemm_is_tuned(weight) and x.stride(1) == 1:
+        # prefill-sized batch of a layer whose library solutions were timed on this process's CU share at start-up
+        # (ModelRunner.tune_dense_gemms): the measured winner instead of the library's whole-device heuristic
+        return ops.dense_gemm(x, weight, bias)
     return F.linear(x, weight, bias)
 
 

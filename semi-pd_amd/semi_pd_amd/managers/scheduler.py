@@ -158,6 +158,8 @@ class SchedulerBase:
                 out["kernel_timing"] = extra.summary()
                 if recv_req.reset:
                     extra.reset()
+            from semi_pd_amd.distributed import OVERLAP_STATS
+            out["all_reduce_overlap"] = dict(OVERLAP_STATS)
             self.send_to_detokenizer.send_pyobj(("stats", out))
         if recv_req.reset:
             for k in self.stats:

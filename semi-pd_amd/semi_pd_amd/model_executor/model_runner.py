@@ -144,7 +144,14 @@ class ModelRunner:
         else:
             init_distributed_environment(1, 0, "", dist_backend)
         self.num_cus = get_device_sm_count(gpu_id)
-        self.num_cus_owned = max(8, self.num_cus * cu_percent // 100)
+        self.num_cus_owned = self.num_cus
+        if cu_percent < 100:
+            # what the launcher's HSA_CU_MASK really enables (whole groups of 8 logical CUs, one per XCD)
+            from semi_pd_amd.semi_pd.utils import cu_mask_words
+            self.num_cus_owned = sum(bin(w).count("1") for w in cu_mask_words(self.num_cus, cu_percent, False))
+        # the decode-sized GEMMs fill whole rounds of the CUs this process owns (csrc/stream_linear.hip: sg_pick_ksplit)
+        from semi_pd_amd import _lib as _semipd_lib
+        _semipd_lib.check(_semipd_lib.load().semipd_stream_linear_set_cus(int(self.num_cus_owned)), "stream_linear_set_cus")
         # --random-seed reaches the stochastic sampler through the default device generator, the same on every
         # TP rank and in both instances (model_runner.py: set_random_seed in every worker)
         torch.manual_seed(seed)
@@ -356,6 +363,27 @@ class ModelRunner:
         ri = ipc_info.req_to_token_info
         self.req_to_token_pool.req_to_token = self._import(
             ipc_info.req_to_token_handle, {"numel": ri["numel"], "dtype": ri["dtype"], "shape": ri["shape"]})
+
+    # ------------------------------------------------------------------------------------ library GEMM selection
+    def tune_dense_gemms(self, rows=(1024, 4096, 128, 256, 512, 2048, 8192), num_full_search: int = 2) -> str:
+        """Time hipBLASLt's solutions for every dense weight shape of the model ON THE COMPUTE UNITS THIS PROCESS OWNS and
+        route prefill-sized batches of those layers to the measured winners (csrc/dense_gemm.cpp; ops.dense_gemm).
+        Under an HSA_CU_MASK the library's own pick -- persistent stream-K grids sized for the whole device -- runs as
+        two rounds on any partial share.  Returns the tuning table as text."""
+        from semi_pd_amd import ops
+        from semi_pd_amd.layers.basic import ColumnParallelLinear, RowParallelLinear
+        shapes = []
+        for m in self.model.modules():
+            if isinstance(m, (ColumnParallelLinear, RowParallelLinear)) and getattr(m, "quant_config", None) is None:
+                w = m.weight
+                if w.dim() == 2 and w.dtype in (torch.bfloat16, torch.float16) and w.device.type == "cuda":
+                    key = (int(w.shape[0]), int(w.shape[1]), w.dtype)
+                    if key not in shapes:
+                        shapes.append(key)
+        with torch.cuda.device(self.device):
+            for n, k, dt in shapes:
+                ops.dense_gemm_tune(n, k, list(rows), dt, num_full_search=num_full_search)
+        return ops.dense_gemm_report()
 
     # ------------------------------------------------------------------------------------ backend / graphs
     def init_attention_backend(self):

@@ -369,6 +369,59 @@ def linear(x: torch.Tensor, weight: torch.Tensor, num_cus: int = 0, out: Optiona
     return out
 
 
+# --------------------------------------------------------------------------- prefill-sized dense layers on a CU share
+_DENSE_GEMM = {"ready": False, "tuned": set()}
+
+
+def dense_gemm_tune(n: int, k: int, rows, dtype: torch.dtype, num_full_search: int = 1, pool_size: int = 6,
+                    max_solutions: int = 0) -> None:
+    """Time hipBLASLt's solutions for a [n, k] weight at the row counts `rows` on the CUs THIS process owns and remember
+    the winners (semipd_dense_gemm_tune; start-up only: allocates scratch operands and synchronises)."""
+    import ctypes as _C
+    lib = _lib.load()
+    check(lib.semipd_dense_gemm_init(0), "dense_gemm_init")
+    arr = (_C.c_int64 * len(rows))(*[int(r) for r in rows])
+    check(lib.semipd_dense_gemm_tune(int(n), int(k), _C.addressof(arr), len(rows), int(num_full_search), dtype_code(dtype),
+                                     int(pool_size), int(max_solutions), current_stream(None)), "dense_gemm_tune")
+    torch.cuda.synchronize()
+    _DENSE_GEMM["ready"] = True
+    _DENSE_GEMM["tuned"].add((int(n), int(k), dtype))
+
+
+def dense_gemm_is_tuned(weight: torch.Tensor) -> bool:
+    return _DENSE_GEMM["ready"] and (weight.shape[0], weight.shape[1], weight.dtype) in _DENSE_GEMM["tuned"]
+
+
+def dense_gemm_report() -> str:
+    import ctypes as _C
+    lib = _lib.load()
+    need = lib.semipd_dense_gemm_report(None, 0)
+    buf = _C.create_string_buffer(int(need))
+    lib.semipd_dense_gemm_report(_C.addressof(buf), need)
+    return buf.value.decode()
+
+
+def dense_gemm(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
+               out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x @ weight.T (+ bias) for prefill-sized batches with the library solution measured fastest on this process's CU
+    share (UnquantizedLinearMethod.apply -> F.linear, layers/linear.py:165-172)."""
+    if x.dim() != 2 or weight.dim() != 2 or x.shape[1] != weight.shape[1] or x.dtype != weight.dtype:
+        raise RuntimeError("dense_gemm: x [rows, k] and weight [n, k] of one dtype expected")
+    if x.dtype not in (torch.bfloat16, torch.float16) or x.stride(1) != 1 or not weight.is_contiguous():
+        raise RuntimeError("dense_gemm: bf16 / f16, unit inner stride, contiguous weight required")
+    if bias is not None and (bias.dtype != x.dtype or bias.numel() != weight.shape[0] or not bias.is_contiguous()):
+        raise RuntimeError("dense_gemm: bias must be a contiguous [n] vector of the activation dtype")
+    M, K = x.shape
+    N = weight.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    elif out.shape != (M, N) or out.dtype != x.dtype or out.stride(1) != 1:
+        raise RuntimeError("dense_gemm: bad out tensor")
+    check(_lib.load().semipd_dense_gemm(ptr(out), ptr(x), ptr(weight), ptr(bias), M, N, K, x.stride(0), out.stride(0),
+                                        dtype_code(x.dtype), current_stream(x.device)), "dense_gemm")
+    return out
+
+
 STREAM_LINEAR_MAX_ROWS = 64
 
 

@@ -302,6 +302,49 @@ def test_semi_pd_tp2_on_one_gpu_matches_oracle(unified_llama):
             eng.shutdown()
 
 
+def test_tp2_overlapped_all_reduce_of_prefill_sized_layers_on_the_gpu(monkeypatch):
+    """The all-reduce that is overlapped with the GEMMs (north star; the blocking form it replaces is
+    layers/linear.py:1266): a TP = 2 Semi-PD engine (both ranks on this GPU, gloo + the peer-memory kernels) prefills
+    prompts of more than 1024 tokens, so RowParallelLinear._forward_overlapped cuts o_proj / down_proj into token
+    chunks and reduces chunk i on the communication stream while the GEMM of chunk i + 1 runs.  The prefill instance
+    must report such reduces as peer-memory kernel launches, the tokens must be those of the same engine with
+    SEMIPD_DISABLE_AR_OVERLAP=1 (one blocking reduce per layer; the reduce is element-wise, so not a bit may differ)
+    and agree with the fp32 oracle of the unsharded model."""
+    import dataclasses
+    from semi_pd_amd.entrypoints.engine import Engine
+    from semi_pd_amd.managers.io_struct import SamplingParams
+    cfg = dataclasses.replace(tiny_llama(), max_position_embeddings=4096)
+    args = dict(context_length=1700, max_total_tokens=12000, max_running_requests=8, cuda_graph_max_bs=8)
+    prompts = make_prompts(cfg.vocab_size, [1100, 1536, 40], seed=21)
+    sp = SamplingParams(max_new_tokens=6, ignore_eos=True)
+    uni = Engine(server_args(cfg, **args))
+    try:
+        sd = {k: v.float().cpu() for k, v in uni.model_runner.model.state_dict().items()}
+    finally:
+        uni.shutdown()
+    runs = {}
+    for overlap in (True, False):
+        if overlap:
+            monkeypatch.delenv("SEMIPD_DISABLE_AR_OVERLAP", raising=False)
+        else:
+            monkeypatch.setenv("SEMIPD_DISABLE_AR_OVERLAP", "1")
+        eng = Engine(server_args(cfg, tp_size=2, enable_semi_pd=True, dist_backend="gloo", **args), gpu_ids={0: 0, 1: 0})
+        try:
+            assert all(i.get("custom_all_reduce") for i in eng.ready_infos)
+            toks = eng.generate(prompts, sp, timeout=600)
+            stats = {s["role"]: s for s in eng.get_stats()}
+        finally:
+            eng.shutdown()
+        runs[overlap] = (toks, stats["PREFILL"]["all_reduce_overlap"])
+    (toks_on, st_on), (toks_off, st_off) = runs[True], runs[False]
+    # 3 layers x (o_proj + down_proj), each cut into at least two chunks
+    assert st_on["overlapped_reduces_peer_memory_kernel"] >= 12, st_on
+    assert st_on["overlapped_reduces_peer_memory_kernel"] == st_on["overlapped_reduces"], st_on
+    assert st_off["overlapped_reduces"] == 0, st_off
+    assert toks_on == toks_off
+    check_against_oracle(OracleLlama(cfg, sd), prompts, toks_on)
+
+
 def test_tp2_falls_back_to_eager_decode_when_a_capture_fails(unified_llama, monkeypatch):
     """A TP backend whose collectives refuse stream capture must cost the graphs, not the engine: the decode instances
     abort the half-made capture (their own stream, destroyed), recover the process and serve eagerly -- same tokens."""

@@ -997,3 +997,32 @@ def test_rope_and_store_kv_from_the_qkv_planes(ops, device, M, dtype, kv_dtype):
     q2 = ops.rope_and_store_kv_planes(pos, planes, Hq, Hk, D, cache, kb2, vb2, loc)
     assert torch.equal(q2.view(torch.int16), q1.contiguous().view(torch.int16))
     assert torch.equal(kb2.view(torch.uint8), kb1.view(torch.uint8)) and torch.equal(vb2.view(torch.uint8), vb1.view(torch.uint8))
+
+
+# --------------------------------------------------------------------------- prefill-sized dense layers on a CU share
+def test_dense_gemm_with_measured_library_solution_matches_fp32(device):
+    """ops.dense_gemm = F.linear (UnquantizedLinearMethod.apply, layers/linear.py:165-172) through the hipBLASLt solution
+    that was timed fastest on this process's CUs: whatever solution wins, the result is x @ W^T (+ bias) in fp32
+    accumulation, one rounding -- rows at, between and far from the tuned row counts, a strided x, f16 and bf16."""
+    import torch.nn.functional as F
+    g = torch.Generator(device="cpu").manual_seed(31)
+    for dtype, tol in ((torch.bfloat16, 2e-2), (torch.float16, 4e-3)):
+        N, K = 768, 512
+        w = (torch.randn(N, K, generator=g) * 0.05).to(dtype).to(device)
+        b = (torch.randn(N, generator=g) * 0.1).to(dtype).to(device)
+        assert not ops.dense_gemm_is_tuned(w) or dtype == torch.float16
+        ops.dense_gemm_tune(N, K, [256, 1024], dtype, num_full_search=1, pool_size=4, max_solutions=24)
+        assert ops.dense_gemm_is_tuned(w)
+        report = ops.dense_gemm_report()
+        assert f"n={N} k={K} rows=256" in report and f"n={N} k={K} rows=1024" in report
+        for rows in (1, 65, 256, 300, 1024, 3000):
+            xw = (torch.randn(rows, K + 64, generator=g)).to(dtype).to(device)
+            for x in (xw[:, :K].contiguous(), xw[:, 32:32 + K]):   # the second one: row stride K + 64
+                for bias in (None, b):
+                    got = ops.dense_gemm(x, w, bias)
+                    want = x.float() @ w.float().t() + (bias.float() if bias is not None else 0.0)
+                    torch.testing.assert_close(got.float(), want, rtol=tol, atol=tol)
+                    # and it is the library's arithmetic: same bits as F.linear up to the solution's summation order
+                    torch.testing.assert_close(got.float(), F.linear(x, w, bias).float(), rtol=tol, atol=tol)
+    with pytest.raises(RuntimeError):
+        ops.dense_gemm(torch.zeros(4, 8, device=device), torch.zeros(4, 8, device=device))   # fp32: not this path

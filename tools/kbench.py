@@ -232,6 +232,9 @@ def bench_stream_linear():
     print("# stream_linear M x [N, K]: hipBLASLt us | default us GB/s | best knob us GB/s   HSA_CU_MASK=%s num_cus=%d"
           % (os.environ.get("HSA_CU_MASK", "-"), ncu))
     full = os.environ.get("KBENCH_SL_SWEEP", "1") == "1"
+    if ncu:
+        from semi_pd_amd import _lib
+        _lib.load().semipd_stream_linear_set_cus(ncu)   # the K split fills whole rounds of this share
     for M in [int(v) for v in os.environ.get("KBENCH_MS", "8,16,32,64").split(",")]:
         for (N, K, silu) in ((28672, 4096, True), (28672, 4096, False), (4096, 14336, False), (6144, 4096, False),
                              (4096, 4096, False)):
