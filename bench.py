@@ -26,6 +26,13 @@ for _p in (ROOT, os.path.join(ROOT, "semi-pd_amd")):
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+# the masked Semi-PD operating point of the default line (see the --prefill-cu / --decode-cu help)
+DEFAULT_PREFILL_CU = 62
+DEFAULT_DECODE_CU = 38
+# BASELINE config 2: "Poisson QPS sweep" -- three points in the default line (in = 1024 / out = 256)
+DEFAULT_SWEEP_RATES = "8,16,32"
+SWEEP_OUTPUT_LEN = 256
+
 HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 MFMA_BF16_PEAK_TFLOPS = 2500.0
 
@@ -226,15 +233,18 @@ def main():
     ap.add_argument("--output-len", type=int, default=128)
     ap.add_argument("--request-rate", type=float, default=32.0, help="Poisson arrivals per second (0 = all at once)")
     ap.add_argument("--mode", choices=["semi-pd", "unified"], default="semi-pd")
-    # CU shares of the two instances (HSA_CU_MASK per process).  Default = the policy this build measured best on
-    # the config-2 load (profiles/r02_policy_sweep_with_streaming_linear.txt): both instances see every CU (the
-    # reference's own default is P 80 / D 100, semi_pd/utils.py:10-11 -- shares are upper bounds there too) and the
-    # decode kernels are built to co-reside.  BASELINE config 2's static 50 / 50 split is measured in the same
-    # invocation by a second engine (--no-static-split-wave skips it) and reported under "static_split_50_50".
-    ap.add_argument("--prefill-cu", type=int, default=100)
-    ap.add_argument("--decode-cu", type=int, default=100)
-    ap.add_argument("--no-static-split-wave", action="store_true",
-                    help="N = 1 Semi-PD default run: do not start the second engine with the static 50 / 50 CU split")
+    # CU shares of the two instances (HSA_CU_MASK per process: prefill takes its share from the bottom of the CU range,
+    # decode from the top).  The default is a MASKED policy -- the north star's compute isolation and BASELINE config 2
+    # ("CU split") -- with the shares this build measured best on the config-2 load (profiles/r03_policy_sweep_*.txt);
+    # `--prefill-cu 50 --decode-cu 50` is config 2's split as written, `--prefill-cu 100 --decode-cu 100` the unmasked
+    # round-2 default.  --static-split-wave adds one warm-up + one timed wave of a second engine at 50 / 50.
+    ap.add_argument("--prefill-cu", type=int, default=DEFAULT_PREFILL_CU)
+    ap.add_argument("--decode-cu", type=int, default=DEFAULT_DECODE_CU)
+    ap.add_argument("--static-split-wave", action="store_true",
+                    help="N = 1 Semi-PD run: also measure a second engine with the static 50 / 50 CU split")
+    ap.add_argument("--no-static-split-wave", action="store_true", help="(default; kept for old command lines)")
+    ap.add_argument("--no-prefill-gemm-tuning", action="store_true",
+                    help="prefill instance: the library's own GEMM choice instead of the solutions timed on its CU share")
     ap.add_argument("--cu-mask-mode", default="env")
     ap.add_argument("--prefill-priority", type=int, default=0, help="HIP stream priority of the prefill instance (-1 = high)")
     ap.add_argument("--decode-priority", type=int, default=0, help="HIP stream priority of the decode instance (-1 = high)")
@@ -266,10 +276,17 @@ def main():
                          "engine tensor-parallel over the N GPUs")
     ap.add_argument("--no-saturation-wave", action="store_true",
                     help="skip the extra (untimed for `value`) wave with all requests sent at once")
-    ap.add_argument("--rate-sweep", default="", help="comma-separated Poisson rates; one extra (untimed for "
-                    "`value`) wave per rate after the timed steps, reported under qps_sweep (BASELINE config 2)")
+    ap.add_argument("--rate-sweep", default=None, help="comma-separated Poisson rates; one extra (untimed for "
+                    "`value`) wave per rate after the timed steps, reported under qps_sweep (BASELINE config 2).  Default: "
+                    f"{DEFAULT_SWEEP_RATES} for the default N = 1 Llama-3-8B workload, none otherwise; '' = none")
+    ap.add_argument("--sweep-output-len", type=int, default=SWEEP_OUTPUT_LEN)
+    ap.add_argument("--sweep-num-requests", type=int, default=None, help="requests per sweep point (default: --num-requests)")
     args = ap.parse_args()
 
+    if args.rate_sweep is None:
+        default_workload = (args.gpus == 1 and args.model == "llama3-8b" and args.mode == "semi-pd"
+                            and args.input_len == 1024 and args.output_len == 128 and args.request_rate == 32.0)
+        args.rate_sweep = DEFAULT_SWEEP_RATES if default_workload else ""
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("SEMIPD_BENCH_ALL_ON_GPU0") == "1":
@@ -310,13 +327,15 @@ def main():
             extra["intermediate_size"] = 11008
         cfg = dataclasses.replace(cfg, quantization_config={"quant_method": "fp8", "weight_block_size": [128, 128],
                                                             "activation_scheme": "dynamic"}, **extra)
-    ctx = args.context_length or (args.input_len + args.output_len + 8)
+    sweep_rates = [float(x) for x in args.rate_sweep.split(",") if x]
+    ctx = args.context_length or (args.input_len + max(args.output_len, args.sweep_output_len if sweep_rates else 0) + 8)
     port_base = int(os.environ.get("MASTER_PORT", "29500")) + 100
     sa = ServerArgs(model_config=cfg, context_length=ctx, tp_size=tp_world, enable_semi_pd=(args.mode == "semi-pd"),
                     max_running_requests=args.max_running_requests, mem_fraction_static=args.mem_fraction_static,
                     max_total_tokens=args.max_total_tokens, prefill_cu_percent=args.prefill_cu,
                     decode_cu_percent=args.decode_cu, cu_mask_mode=args.cu_mask_mode,
                     library_gemm_grid=args.library_gemm_grid, disable_stream_linear=args.disable_stream_linear,
+                    tune_prefill_gemm=(False if args.no_prefill_gemm_tuning else None),
                     prefill_stream_priority=args.prefill_priority, decode_stream_priority=args.decode_priority,
                     disable_cuda_graph=args.disable_cuda_graph, nccl_port_base=port_base,
                     disable_overlap_schedule=args.disable_overlap_schedule,
@@ -361,13 +380,18 @@ def main():
         all_records, elapsed = combine_ranks(all_records, elapsed, rank, world, replicas=not args.tp)
         stats = engine.get_stats() if (rank == 0 and not args.no_kernel_timing) else []
         sweep = []
-        for rate in [float(x) for x in args.rate_sweep.split(",") if x]:
+        n_sweep = args.sweep_num_requests or args.num_requests
+        sweep_prompts = prompts if n_sweep == args.num_requests else make_requests(n_sweep, args.input_len, cfg.vocab_size,
+                                                                                  args.seed + 1000 * replica)
+        for rate in sweep_rates:
             barrier()
             if driver:
-                recs, dur = run_wave(engine, prompts, arrival_times(args.num_requests, rate, args.seed), args.output_len)
+                recs, dur = run_wave(engine, sweep_prompts, arrival_times(n_sweep, rate * (world if args.tp and not args.fixed_load else 1), args.seed),
+                                     args.sweep_output_len)
                 sm = summarize(recs, dur)
-                sweep.append({"request_rate": rate, **{k: (round(v, 2) if isinstance(v, float) else v)
-                                                       for k, v in sm.items()}})
+                sweep.append({"request_rate": rate, "num_requests": n_sweep, "input_len": args.input_len,
+                              "output_len": args.sweep_output_len,
+                              **{k: (round(v, 2) if isinstance(v, float) else v) for k, v in sm.items()}})
         saturation = None
         if not args.no_saturation_wave and args.request_rate > 0:
             # capacity next to the load-bound headline: the same requests, all sent at once
@@ -381,7 +405,7 @@ def main():
         engine.shutdown()
 
     static_split = None
-    if (world == 1 and args.mode == "semi-pd" and not args.no_static_split_wave
+    if (world == 1 and args.mode == "semi-pd" and args.static_split_wave
             and (args.prefill_cu, args.decode_cu) != (50, 50)):
         # BASELINE config 2 as written: disjoint halves of the CUs, same load, one warm-up wave + one timed wave
         import dataclasses
@@ -453,6 +477,15 @@ def main():
                 cpu = cpu_baseline(cfg, args.input_len, args.output_len)
         except Exception as e:  # the baseline must never take the measured number down with it
             cpu = {"error": repr(e)}
+    if args.mode != "semi-pd":
+        mask_text = "one process on every CU"
+    elif (args.prefill_cu, args.decode_cu) == (100, 100) or args.cu_mask_mode != "env":
+        mask_text = "CU shares P100/D100 (no mask: both instances on every CU)"
+    else:
+        lo, hi = args.prefill_cu, 100 - args.decode_cu
+        kind = "disjoint" if lo <= hi else "overlapping"
+        mask_text = (f"CU masks P{args.prefill_cu}/D{args.decode_cu} ({kind} HSA_CU_MASK shares: prefill the lowest "
+                     f"{args.prefill_cu} % of the CUs, decode the highest {args.decode_cu} %)")
     out = {
         "metric": "output tokens/s (Semi-PD mode; with p50 TTFT / TBT)" if args.mode == "semi-pd" else "output tokens/s (unified engine)",
         "value": round(summ["output_tok_s"], 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
@@ -462,14 +495,16 @@ def main():
         "p99_ttft_ms": summ["p99_ttft_ms"], "p99_tbt_ms": summ["p99_tbt_ms"],
         "config": {"workload": f"{args.model} {'block-fp8 (e4m3fn 128x128) linears + experts' if args.quantization else 'bf16'} TP={tp_world} {args.mode}"
                                + (f" x {world} independent replicas (one per GPU, each with its own {args.num_requests} requests)"
-                                  if (world > 1 and not args.tp) else "") + f", CU shares P{args.prefill_cu}/D{args.decode_cu} "
-                               f"({'no mask: both instances on every CU' if (args.prefill_cu, args.decode_cu) == (100, 100) else args.cu_mask_mode}), {args.num_requests} synthetic requests in={args.input_len} "
+                                  if (world > 1 and not args.tp) else "") + f", {mask_text}, {args.num_requests} synthetic requests in={args.input_len} "
                                f"out={args.output_len}, Poisson {args.request_rate} req/s, dummy weights"
                                + ("" if args.kv_cache_dtype == "auto" else f", KV cache {args.kv_cache_dtype}"),
                    "num_requests": args.num_requests, "input_len": args.input_len, "output_len": args.output_len,
                    "request_rate": args.request_rate,
                    "parallelism": (f"tp{world}" if (args.tp or world == 1) else f"dp{world} (replicas, tp1 each)"),
-                   "mode": args.mode,
+                   "mode": args.mode, "prefill_cu_percent": args.prefill_cu, "decode_cu_percent": args.decode_cu,
+                   "prefill_gemm": ("library solutions timed on the prefill share at start-up (csrc/dense_gemm.cpp)"
+                                    if (not args.no_prefill_gemm_tuning and args.prefill_cu < 100 and args.mode == "semi-pd")
+                                    else "library heuristic"),
                    "kv_cache_dtype": args.kv_cache_dtype},
         "roofline": roofline, "roofline_extra": extra, "cpu_baseline": cpu,
     }

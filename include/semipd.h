@@ -232,6 +232,18 @@ int semipd_linear(void* out, const void* x, const void* weight, void* workspace,
  * to the activation type first, i.e. the value the unfused pair of ops produces.  k % 128 == 0.
  * replaces UnquantizedLinearMethod.apply -> F.linear (layers/linear.py:165-172) and, fused, LlamaMLP's
  *   gate_up_proj + SiluAndMul (models/llama.py:88-92, layers/activation.py:41-53) at decode batch sizes. */
+/* ---- tall decode batches (65 rows and up) and vocabulary-sized heads: the tiled ping-pong GEMM (csrc/gemm8p.hip) ------
+ * out[rows, n_out] = x[rows, k] @ weight[n, k]^T; fuse_silu_mul: weight = merged [gate; up], n_out = n / 2 and the result
+ * is SiluAndMul of the product rounded to dtype (the bits of the unfused pair).  256 x 256 output tiles, K in steps of
+ * 64, both operands through LDS-DMA; workspace (optional, 16-byte aligned): fp32 planes for a K split when the tiles
+ * alone do not fill the share declared with semipd_gemm_tall_set_cus (0 = 256).  Replaces F.linear (+ SiluAndMul) of
+ * UnquantizedLinearMethod.apply for decode batches above the streaming kernel's 64 rows
+ * (python/sglang/srt/layers/linear.py:165-172, models/llama.py:88-92, layers/activation.py:41-53) and the logits GEMM
+ * of _get_logits (layers/logits_processor.py:394-445).  k % 64 == 0, n_out % 16 == 0, bf16 / f16. */
+int semipd_gemm_tall_set_cus(int cus);
+int semipd_gemm_tall(void* out, const void* x, const void* weight, void* workspace, size_t workspace_bytes, int64_t rows,
+                     int64_t n, int64_t k, int64_t ldx, int64_t ldo, int fuse_silu_mul, int dtype, void* stream);
+
 /* ---- prefill-sized dense layers on a CU share (csrc/dense_gemm.cpp) ------------------------------------------------
  * out[rows, n] = x[rows, k] @ weight[n, k]^T (+ bias[n]) through hipBLASLt with the solution that MEASURED fastest on
  * the compute units this process owns.  Replaces F.linear in UnquantizedLinearMethod.apply
@@ -240,19 +252,25 @@ int semipd_linear(void* out, const void* x, const void* weight, void* workspace,
  * assumes the whole device.
  *   semipd_dense_gemm_init   creates the library handle and its workspace (0 = 64 MB); start-up.
  *   semipd_dense_gemm_tune   times the library's solutions for weight shape (n, k) at rows[0..num_rows) on this process's
- *                            CUs; the first num_full_search row counts are searched over every solution (max_solutions
- *                            > 0 caps that), their best pool_size each are the candidates at the other row counts.
- *                            Allocates and frees scratch operands: start-up only.
+ *                            CUs: its first num_heuristics heuristic results (0 = 64) at every row count, plus every
+ *                            solution it has at the first num_full_search row counts (max_solutions > 0 caps that; ~20 s
+ *                            per row count).  Allocates and frees scratch operands: start-up only.
  *   semipd_dense_gemm        launches with the winner of the nearest tuned row count (the library's own choice when
  *                            nothing was tuned or the winner does not support this row count).  Never allocates or
  *                            synchronises; dtype bf16 / f16; ldx / ldo = row strides in elements.
  *   semipd_dense_gemm_report text table of the tuning results; returns the bytes needed. */
 int semipd_dense_gemm_init(size_t workspace_bytes);
 int semipd_dense_gemm_tune(int64_t n, int64_t k, const int64_t* rows, int num_rows, int num_full_search, int dtype,
-                           int pool_size, int max_solutions, void* stream);
+                           int num_heuristics, int max_solutions, void* stream);
 int semipd_dense_gemm(void* out, const void* x, const void* weight, const void* bias, int64_t rows, int64_t n, int64_t k,
                       int64_t ldx, int64_t ldo, int dtype, void* stream);
 size_t semipd_dense_gemm_report(char* buf, size_t len);
+
+/* semipd_stream_linear with the fp32 accumulators stored unrounded, no K split: out_f32[rows, n] (contiguous rows).
+ * The logits GEMM of a decode batch of at most 64 rows (python/sglang/srt/layers/logits_processor.py:394-445;
+ * semipd_lm_head_argmax takes this path when k % 128 == 0 and n % 16 == 0). */
+int semipd_stream_linear_f32(float* out, const void* x, const void* weight, int64_t rows, int64_t n, int64_t k, int64_t ldx,
+                             int dtype, void* stream);
 
 /* Compute units of the share this process runs its decode-sized GEMMs on (its HSA_CU_MASK / stream mask); 0 = default
  * (128, half a chip).  The K split of semipd_stream_linear / _planes fills whole rounds of that many CUs.  The split

@@ -161,13 +161,14 @@ int semipd_dense_gemm_init(size_t workspace_bytes) {
 }
 
 /* Time the library's solutions for out[rows, n] = x[rows, k] @ W[n, k]^T at each of `rows[0..num_rows)` on the CUs this
- * process owns and remember the winner per row count.  The first `num_full_search` row counts are searched over EVERY
- * solution the library has for this operand layout (`max_solutions` > 0 caps a search to the first so many supported
- * ones); the best `pool_size` of each such search, together with the library's own choice, are the candidates at the
- * remaining row counts.  Operands are scratch buffers allocated and freed here (start-up only); the calling thread's
- * current device is used. */
+ * process owns and remember the winner per row count.  Candidates at every row count: the library's first
+ * `num_heuristics` heuristic results (its ranking assumes the whole device; on a masked share the winner is typically
+ * far down that list: profiles/r03_blaslt_probe_under_masks.txt) and, for the first `num_full_search` row counts, EVERY
+ * solution the library supports for the problem (~2000 for bf16, ~20 s per row count: off by default) whose best
+ * few then join the candidates of the remaining row counts.  Operands are scratch buffers allocated and freed here
+ * (start-up only); the calling thread's current device is used. */
 int semipd_dense_gemm_tune(int64_t n, int64_t k, const int64_t* rows, int num_rows, int num_full_search, int dtype,
-                           int pool_size, int max_solutions, void* stream) {
+                           int num_heuristics, int max_solutions, void* stream) {
   SEMIPD_CHECK_ARG(n > 0 && k > 0 && rows && num_rows > 0 && (dtype == SEMIPD_BF16 || dtype == SEMIPD_F16),
                    SEMIPD_EINVAL, "dense_gemm_tune: bad arguments");
   State& s = st();
@@ -199,17 +200,38 @@ int semipd_dense_gemm_tune(int64_t n, int64_t k, const int64_t* rows, int num_ro
   (void)hipEventCreate(&e1);
   const auto key = std::make_tuple(dtype, n, k);
   std::vector<hipblasLtMatmulAlgo_t>& pool = s.pool[key];
+  const int nh = std::max(1, std::min(num_heuristics > 0 ? num_heuristics : 64, 256));
   int rc = 0;
   for (int ri = 0; ri < num_rows && rc == 0; ++ri) {
     const int64_t m = rows[ri];
     Plan p;
     if (make_problem(p, dtype, m, n, k, k, n, false)) { rc = 1; break; }
-    hipblasLtMatmulAlgo_t dflt;
-    const bool have_default = heuristic_algo(s, p, &dflt);
-    const float t_default = have_default ? time_algo(s, p, dflt, w, x, o, 8, hs, e0, e1) : 1e30f;
-    std::vector<std::pair<float, hipblasLtMatmulAlgo_t>> timed;
-    if (have_default) timed.push_back({t_default, dflt});
-    if (ri < num_full_search || pool.empty()) {
+    std::vector<hipblasLtMatmulAlgo_t> cand;
+    auto add = [&](const hipblasLtMatmulAlgo_t& a) {
+      hipblasLtMatmulAlgo_t c = a;
+      const int idx = hipblaslt_ext::getIndexFromAlgo(c);
+      for (auto& q : cand)
+        if (hipblaslt_ext::getIndexFromAlgo(q) == idx) return;
+      cand.push_back(a);
+    };
+    {  // the library's ranking, first entry = what it would run by itself
+      hipblasLtMatmulPreference_t pref;
+      if (hipblasLtMatmulPreferenceCreate(&pref) == HIPBLAS_STATUS_SUCCESS) {
+        hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &s.workspace_bytes,
+                                              sizeof(s.workspace_bytes));
+        std::vector<hipblasLtMatmulHeuristicResult_t> hr(nh);
+        int got = 0;
+        if (hipblasLtMatmulAlgoGetHeuristic(s.handle, p.desc, p.la, p.lb, p.lc, p.lc, pref, nh, hr.data(), &got) ==
+            HIPBLAS_STATUS_SUCCESS)
+          for (int i = 0; i < got; ++i) add(hr[i].algo);
+        hipblasLtMatmulPreferenceDestroy(pref);
+      }
+    }
+    const bool have_default = !cand.empty();
+    const float t_default = have_default ? time_algo(s, p, cand[0], w, x, o, 8, hs, e0, e1) : 1e30f;
+    for (auto& a : pool)
+      if (supported(s, p, a)) add(a);
+    if (ri < num_full_search) {
       std::vector<hipblasLtMatmulHeuristicResult_t> all;
       hipblasOperation_t ta = HIPBLAS_OP_T, tb = HIPBLAS_OP_N;
       if (hipblaslt_ext::getAllAlgos(s.handle, hipblaslt_ext::GemmType::HIPBLASLT_GEMM, ta, tb, hip_type(dtype), hip_type(dtype),
@@ -219,33 +241,33 @@ int semipd_dense_gemm_tune(int64_t n, int64_t k, const int64_t* rows, int num_ro
           if (!supported(s, p, r.algo)) continue;
           if (max_solutions > 0 && tried >= max_solutions) break;
           ++tried;
-          const float t = time_algo(s, p, r.algo, w, x, o, 3, hs, e0, e1);
-          if (t < 1e29f) timed.push_back({t, r.algo});
+          add(r.algo);
         }
       }
-      std::sort(timed.begin(), timed.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
-      const size_t keep = std::min<size_t>(timed.size(), (size_t)std::max(pool_size, 1));
-      for (size_t i = 0; i < keep; ++i) {
-        const int idx = hipblaslt_ext::getIndexFromAlgo(timed[i].second);
-        bool known = false;
-        for (auto& a : pool) known = known || hipblaslt_ext::getIndexFromAlgo(a) == idx;
-        if (!known) pool.push_back(timed[i].second);
-      }
-      timed.resize(keep);
-    } else {
-      for (auto& a : pool)
-        if (supported(s, p, a)) timed.push_back({0.f, a});
     }
+    std::vector<std::pair<float, int>> timed;
+    for (size_t i = 0; i < cand.size(); ++i) {
+      const float t = time_algo(s, p, cand[i], w, x, o, 3, hs, e0, e1);
+      if (t < 1e29f) timed.push_back({t, (int)i});
+    }
+    std::sort(timed.begin(), timed.end());
     // the leaders again, properly
     float best = 1e30f;
     int best_i = -1;
-    for (size_t i = 0; i < timed.size(); ++i) {
-      const float t = time_algo(s, p, timed[i].second, w, x, o, 12, hs, e0, e1);
-      if (t < best) best = t, best_i = (int)i;
+    for (size_t j = 0; j < std::min<size_t>(timed.size(), 6); ++j) {
+      const float t = time_algo(s, p, cand[timed[j].second], w, x, o, 12, hs, e0, e1);
+      if (t < best) best = t, best_i = timed[j].second;
     }
+    if (ri < num_full_search)   // what a full search found joins the candidates of the other row counts
+      for (size_t j = 0; j < std::min<size_t>(timed.size(), 6); ++j) {
+        bool known = false;
+        const int idx = hipblaslt_ext::getIndexFromAlgo(cand[timed[j].second]);
+        for (auto& a : pool) known = known || hipblaslt_ext::getIndexFromAlgo(a) == idx;
+        if (!known) pool.push_back(cand[timed[j].second]);
+      }
     if (best_i >= 0) {
       Tuned t;
-      t.algo = timed[best_i].second;
+      t.algo = cand[best_i];
       t.solution_index = hipblaslt_ext::getIndexFromAlgo(t.algo);
       t.us = best;
       t.us_default = t_default;

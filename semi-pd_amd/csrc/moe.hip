@@ -584,6 +584,13 @@ int semipd_lm_head_argmax(const void* hidden, const void* weight, float* logits,
   SEMIPD_CHECK_ARG(lg, SEMIPD_EINVAL, "lm_head_argmax: logits or workspace required");
   SEMIPD_CHECK_ARG(aligned16(hidden) && aligned16(weight), SEMIPD_EALIGN,
                    "lm_head_argmax: unaligned pointer");
+  if (batch <= 64 && hidden_size % 128 == 0 && vocab % 16 == 0 && aligned16(lg)) {
+    // the LDS-DMA streaming kernel (csrc/stream_linear.hip) with its fp32 accumulators stored as they are: ~1.6x the
+    // per-CU weight rate of the register-fragment kernel below on a partial CU share
+    int rc0 = semipd_stream_linear_f32(lg, hidden, weight, batch, vocab, hidden_size, hidden_size, dtype, stream);
+    if (rc0) return rc0;
+    return semipd_argmax(lg, out, batch, vocab, vocab, SEMIPD_F32, out_is_i64, stream);
+  }
   if (batch <= 64 && skinny_gemm_ok(hidden_size, hidden_size, hidden, weight) && vocab % 4 == 0) {
     int rc0 = 0;
     SEMIPD_DISPATCH_HALF(dtype, T, rc0 = (launch_skinny_gemm<T, float, false>(lg, (const T*)hidden, (const T*)weight, nullptr, nullptr, nullptr, nullptr, (int64_t)0, batch, vocab, hidden_size, hidden_size, vocab, (int64_t)1, 1, 0, as_stream(stream), 1, nullptr)));

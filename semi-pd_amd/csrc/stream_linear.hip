@@ -374,8 +374,10 @@ int semipd_stream_linear(void* out, const void* x, const void* weight, void* wor
   const size_t pb = workspace ? workspace_bytes : 0;
   int rc = 0;
   // ring depth: up to 32 rows the activation ring is small enough for FOUR slots in the CU's 160 KB (three blocks in
-  // flight per wave instead of two: the stream is bound by bytes in flight per CU); SEMIPD_SL_RING=3 for A/B runs
-  static const int ring_knob = sl_env("SEMIPD_SL_RING", 4);
+  // flight per wave instead of two).  Measured: no gain on 64 / 96 / 128-CU shares (profiles/
+  // r03_kbench_stream_linear_ring4_vs_ring3.txt) -- a CU pulls ~35-41 GB/s from HBM however deep its rings are -- so the
+  // default stays three slots; SEMIPD_SL_RING=4 selects the deep instantiation
+  static const int ring_knob = sl_env("SEMIPD_SL_RING", 3);
   const bool deep = mt <= 2 && ring_knob >= 4;
 #define SL_GO(MTV, RV) \
   if (fuse_silu_mul) { SEMIPD_DISPATCH_HALF(dtype, T, rc = (sg_launch<T, MTV, 2, 4, RV, SL_SILU_MUL>((T*)out, planes, pb, (const T*)x, (const T*)weight, M, N, K, ldx, ldo, force_ks, st))); } \
@@ -401,10 +403,35 @@ int semipd_stream_linear_planes(float* planes, size_t planes_bytes, const void* 
   const int M = (int)rows, N = (int)n, K = (int)k;
   const int mt = (M + 15) / 16;
   int rc = 0;
-  static const int ring_knob = sl_env("SEMIPD_SL_RING", 4);
+  static const int ring_knob = sl_env("SEMIPD_SL_RING", 3);
   const bool deep = mt <= 2 && ring_knob >= 4;
 #define SL_GO(MTV, RV) \
   SEMIPD_DISPATCH_HALF(dtype, T, rc = (sg_launch<T, MTV, 1, 8, RV, SL_PLAIN>((T*)nullptr, planes, planes_bytes, (const T*)x, (const T*)weight, M, N, K, ldx, N, sl_env("SEMIPD_SL_KS", 0), st, ksplit)));
+  if (mt == 1) { if (deep) { SL_GO(1, 4) } else { SL_GO(1, 3) } }
+  else if (mt == 2) { if (deep) { SL_GO(2, 4) } else { SL_GO(2, 3) } }
+  else if (mt == 3) { SL_GO(3, 3) } else { SL_GO(4, 3) }
+#undef SL_GO
+  return rc;
+}
+
+/* out_f32[rows, n] = x[rows, k] @ weight[n, k]^T in fp32 (no K split: the accumulators are stored as they are): the
+ * logits GEMM of a decode batch (layers/logits_processor.py:394-445 computes them in the activation type and converts;
+ * here the fp32 sums reach the sampler unrounded).  rows <= 64, k % 128 == 0, n % 16 == 0. */
+int semipd_stream_linear_f32(float* out, const void* x, const void* weight, int64_t rows, int64_t n, int64_t k, int64_t ldx,
+                             int dtype, void* stream) {
+  SEMIPD_CHECK_ARG(rows > 0 && rows <= 64 && n > 0 && k > 0 && ldx >= k, SEMIPD_EINVAL, "stream_linear_f32: bad sizes");
+  SEMIPD_CHECK_ARG(out && x && weight, SEMIPD_EINVAL, "stream_linear_f32: null pointer");
+  SEMIPD_CHECK_ARG(k % 128 == 0 && ldx % 8 == 0 && n % 16 == 0 && aligned16(x) && aligned16(weight) && aligned16(out) &&
+                   n < (1 << 30) && k < (1 << 30),
+                   SEMIPD_EALIGN, "stream_linear_f32: k %% 128, n %% 16, 16-byte aligned rows required");
+  hipStream_t st = as_stream(stream);
+  const int M = (int)rows, N = (int)n, K = (int)k;
+  const int mt = (M + 15) / 16;
+  static const int ring_knob = sl_env("SEMIPD_SL_RING", 3);
+  const bool deep = mt <= 2 && ring_knob >= 4;
+  int rc = 0, ks = 0;
+#define SL_GO(MTV, RV) \
+  SEMIPD_DISPATCH_HALF(dtype, T, rc = (sg_launch<T, MTV, 1, 8, RV, SL_PLAIN>((T*)nullptr, out, (size_t)M * N * 4, (const T*)x, (const T*)weight, M, N, K, ldx, N, 1, st, &ks)));
   if (mt == 1) { if (deep) { SL_GO(1, 4) } else { SL_GO(1, 3) } }
   else if (mt == 2) { if (deep) { SL_GO(2, 4) } else { SL_GO(2, 3) } }
   else if (mt == 3) { SL_GO(3, 3) } else { SL_GO(4, 3) }

@@ -225,11 +225,18 @@ def _timed_stream(fn, x: torch.Tensor, weight: torch.Tensor, n_out: int, n_kerne
     return out
 
 
+GEMM_TALL_MAX_ROWS = 256   # above: the library GEMM (prefill-sized; its solution timed on the share where that was asked for)
+
+
 def dense_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """UnquantizedLinearMethod.apply (layers/linear.py:165-172)."""
     if (_STREAM_LINEAR["enabled"] and bias is None and x.dim() == 2 and x.shape[0] <= ops.STREAM_LINEAR_MAX_ROWS
             and ops.stream_linear_is_supported(x, weight)):
         return _timed_stream(lambda: ops.stream_linear(x, weight), x, weight, weight.shape[0], 2)
+    if (_STREAM_LINEAR["enabled"] and bias is None and x.dim() == 2 and ops.STREAM_LINEAR_MAX_ROWS < x.shape[0] <= GEMM_TALL_MAX_ROWS
+            and not ops.dense_gemm_is_tuned(weight) and ops.gemm_tall_is_supported(x, weight)):
+        # tall decode batch (65 .. 256 rows): the tiled ping-pong GEMM (csrc/gemm8p.hip)
+        return ops.gemm_tall(x, weight)
     if x.dim() == 2 and x.shape[0] > 0 and ops.dense_gemm_is_tuned(weight) and x.stride(1) == 1:
         # prefill-sized batch of a layer whose library solutions were timed on this process's CU share at start-up
         # (ModelRunner.tune_dense_gemms): the measured winner instead of the library's whole-device heuristic
@@ -244,6 +251,12 @@ def gate_up_silu(x: torch.Tensor, gate_up_proj: "MergedColumnParallelLinear", ac
             and ops.stream_linear_is_supported(x, gate_up_proj.weight, fuse_silu_mul=True)):
         w = gate_up_proj.weight
         return _timed_stream(lambda: ops.stream_linear(x, w, fuse_silu_mul=True), x, w, w.shape[0] // 2, 1)
+    if (_STREAM_LINEAR["enabled"] and gate_up_proj.quant_config is None and gate_up_proj.bias is None
+            and isinstance(act_fn, SiluAndMul) and x.dim() == 2
+            and ops.STREAM_LINEAR_MAX_ROWS < x.shape[0] <= GEMM_TALL_MAX_ROWS
+            and not ops.dense_gemm_is_tuned(gate_up_proj.weight)
+            and ops.gemm_tall_is_supported(x, gate_up_proj.weight, fuse_silu_mul=True)):
+        return ops.gemm_tall(x, gate_up_proj.weight, fuse_silu_mul=True)   # SiLU * mul in the GEMM's epilogue
     return act_fn(gate_up_proj(x))
 
 

@@ -152,6 +152,7 @@ class ModelRunner:
         # the decode-sized GEMMs fill whole rounds of the CUs this process owns (csrc/stream_linear.hip: sg_pick_ksplit)
         from semi_pd_amd import _lib as _semipd_lib
         _semipd_lib.check(_semipd_lib.load().semipd_stream_linear_set_cus(int(self.num_cus_owned)), "stream_linear_set_cus")
+        _semipd_lib.check(_semipd_lib.load().semipd_gemm_tall_set_cus(int(self.num_cus_owned)), "gemm_tall_set_cus")
         # --random-seed reaches the stochastic sampler through the default device generator, the same on every
         # TP rank and in both instances (model_runner.py: set_random_seed in every worker)
         torch.manual_seed(seed)
@@ -365,7 +366,7 @@ class ModelRunner:
             ipc_info.req_to_token_handle, {"numel": ri["numel"], "dtype": ri["dtype"], "shape": ri["shape"]})
 
     # ------------------------------------------------------------------------------------ library GEMM selection
-    def tune_dense_gemms(self, rows=(1024, 4096, 128, 256, 512, 2048, 8192), num_full_search: int = 2) -> str:
+    def tune_dense_gemms(self, rows=(128, 256, 512, 1024, 2048, 4096, 8192), num_full_search: int = 0) -> str:
         """Time hipBLASLt's solutions for every dense weight shape of the model ON THE COMPUTE UNITS THIS PROCESS OWNS and
         route prefill-sized batches of those layers to the measured winners (csrc/dense_gemm.cpp; ops.dense_gemm).
         Under an HSA_CU_MASK the library's own pick -- persistent stream-K grids sized for the whole device -- runs as

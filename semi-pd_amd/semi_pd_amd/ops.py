@@ -369,20 +369,54 @@ def linear(x: torch.Tensor, weight: torch.Tensor, num_cus: int = 0, out: Optiona
     return out
 
 
+# --------------------------------------------------------------------------- tall decode batches: tiled ping-pong GEMM
+def gemm_tall_is_supported(x: torch.Tensor, weight: torch.Tensor, fuse_silu_mul: bool = False) -> bool:
+    if not (x.is_cuda and x.dim() == 2 and weight.dim() == 2 and x.shape[0] > 0 and x.dtype == weight.dtype
+            and x.dtype in (torch.bfloat16, torch.float16) and x.stride(1) == 1 and weight.is_contiguous()
+            and x.shape[1] == weight.shape[1]):
+        return False
+    N, K = weight.shape
+    n_out = N // 2 if fuse_silu_mul else N
+    return (K % 64 == 0 and n_out % 16 == 0 and (not fuse_silu_mul or N % 2 == 0) and x.stride(0) % 8 == 0
+            and x.data_ptr() % 16 == 0)
+
+
+def gemm_tall(x: torch.Tensor, weight: torch.Tensor, fuse_silu_mul: bool = False,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x @ weight.T (optionally SiluAndMul of it) with the 256 x 256 ping-pong tile kernel (csrc/gemm8p.hip): decode
+    batches above the streaming kernel's 64 rows, vocabulary-sized heads (UnquantizedLinearMethod.apply
+    layers/linear.py:165-172; _get_logits layers/logits_processor.py:394-445)."""
+    if not gemm_tall_is_supported(x, weight, fuse_silu_mul):
+        raise RuntimeError("gemm_tall: unsupported shapes / dtypes / strides")
+    M, K = x.shape
+    N = weight.shape[0]
+    n_out = N // 2 if fuse_silu_mul else N
+    if out is None:
+        out = torch.empty((M, n_out), dtype=x.dtype, device=x.device)
+    elif out.shape != (M, n_out) or out.dtype != x.dtype or out.stride(1) != 1:
+        raise RuntimeError("gemm_tall: bad out tensor")
+    ws = _linear_workspace(x.device)
+    check(_lib.load().semipd_gemm_tall(ptr(out), ptr(x), ptr(weight), ptr(ws), ws.numel(), M, N, K, x.stride(0),
+                                       out.stride(0), 1 if fuse_silu_mul else 0, dtype_code(x.dtype),
+                                       current_stream(x.device)), "gemm_tall")
+    return out
+
+
 # --------------------------------------------------------------------------- prefill-sized dense layers on a CU share
 _DENSE_GEMM = {"ready": False, "tuned": set()}
 
 
-def dense_gemm_tune(n: int, k: int, rows, dtype: torch.dtype, num_full_search: int = 1, pool_size: int = 6,
+def dense_gemm_tune(n: int, k: int, rows, dtype: torch.dtype, num_full_search: int = 0, num_heuristics: int = 64,
                     max_solutions: int = 0) -> None:
     """Time hipBLASLt's solutions for a [n, k] weight at the row counts `rows` on the CUs THIS process owns and remember
-    the winners (semipd_dense_gemm_tune; start-up only: allocates scratch operands and synchronises)."""
+    the winners (semipd_dense_gemm_tune; start-up only: allocates scratch operands and synchronises).  Candidates: the
+    library's first `num_heuristics` heuristic results, plus all of its solutions at the first `num_full_search` row counts."""
     import ctypes as _C
     lib = _lib.load()
     check(lib.semipd_dense_gemm_init(0), "dense_gemm_init")
     arr = (_C.c_int64 * len(rows))(*[int(r) for r in rows])
     check(lib.semipd_dense_gemm_tune(int(n), int(k), _C.addressof(arr), len(rows), int(num_full_search), dtype_code(dtype),
-                                     int(pool_size), int(max_solutions), current_stream(None)), "dense_gemm_tune")
+                                     int(num_heuristics), int(max_solutions), current_stream(None)), "dense_gemm_tune")
     torch.cuda.synchronize()
     _DENSE_GEMM["ready"] = True
     _DENSE_GEMM["tuned"].add((int(n), int(k), dtype))

@@ -1000,7 +1000,7 @@ def test_rope_and_store_kv_from_the_qkv_planes(ops, device, M, dtype, kv_dtype):
 
 
 # --------------------------------------------------------------------------- prefill-sized dense layers on a CU share
-def test_dense_gemm_with_measured_library_solution_matches_fp32(device):
+def test_dense_gemm_with_measured_library_solution_matches_fp32(ops, device):
     """ops.dense_gemm = F.linear (UnquantizedLinearMethod.apply, layers/linear.py:165-172) through the hipBLASLt solution
     that was timed fastest on this process's CUs: whatever solution wins, the result is x @ W^T (+ bias) in fp32
     accumulation, one rounding -- rows at, between and far from the tuned row counts, a strided x, f16 and bf16."""
@@ -1011,7 +1011,7 @@ def test_dense_gemm_with_measured_library_solution_matches_fp32(device):
         w = (torch.randn(N, K, generator=g) * 0.05).to(dtype).to(device)
         b = (torch.randn(N, generator=g) * 0.1).to(dtype).to(device)
         assert not ops.dense_gemm_is_tuned(w) or dtype == torch.float16
-        ops.dense_gemm_tune(N, K, [256, 1024], dtype, num_full_search=1, pool_size=4, max_solutions=24)
+        ops.dense_gemm_tune(N, K, [256, 1024], dtype, num_full_search=1, num_heuristics=16, max_solutions=24)
         assert ops.dense_gemm_is_tuned(w)
         report = ops.dense_gemm_report()
         assert f"n={N} k={K} rows=256" in report and f"n={N} k={K} rows=1024" in report
@@ -1026,3 +1026,62 @@ def test_dense_gemm_with_measured_library_solution_matches_fp32(device):
                     torch.testing.assert_close(got.float(), F.linear(x, w, bias).float(), rtol=tol, atol=tol)
     with pytest.raises(RuntimeError):
         ops.dense_gemm(torch.zeros(4, 8, device=device), torch.zeros(4, 8, device=device))   # fp32: not this path
+
+
+# --------------------------------------------------------------------------- tall decode batches: tiled ping-pong GEMM
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K", [(65, 256, 128), (256, 512, 512), (200, 4096, 4096), (96, 1024, 14336), (256, 6144, 4096),
+                                   (300, 768, 256), (1024, 1280, 1024), (129, 272, 64), (1, 16, 64)])
+def test_gemm_tall_matches_fp32(ops, device, dtype, M, N, K):
+    """ops.gemm_tall = F.linear for 65-row and taller batches (layers/linear.py:165-172): fp32 accumulation, one rounding.
+    Every K split the kernel may pick (SEMIPD_G8_KS forces 1, 2 and 4) must agree with the fp32 product within the
+    rounding of the output type; shapes cover ragged M / N tails, several row tiles, an odd number of K steps."""
+    import os
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N + K)
+    x = (torch.randn(M, K, generator=g)).to(dtype).to(device)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(dtype).to(device)
+    want = x.float() @ w.float().t()
+    tol = 2e-2 if dtype == torch.bfloat16 else 3e-3
+    try:
+        for geo in ("0", "64", "128"):       # 0 = by row count; 64 = the 128 x 512 tile, 128 = the 256 x 256 tile
+            os.environ["SEMIPD_G8_XH"] = geo
+            for ks in ("0", "1", "2", "4"):
+                os.environ["SEMIPD_G8_KS"] = ks
+                got = ops.gemm_tall(x, w)
+                torch.testing.assert_close(got.float(), want, rtol=tol, atol=tol)
+    finally:
+        os.environ.pop("SEMIPD_G8_KS", None)
+        os.environ.pop("SEMIPD_G8_XH", None)
+    # a strided x (rows of a wider buffer) and a caller-provided out with a row stride
+    xw = torch.zeros(M, K + 64, dtype=dtype, device=device)
+    xw[:, 16:16 + K] = x
+    buf = torch.full((M, N + 8), 7.0, dtype=dtype, device=device)
+    ops.gemm_tall(xw[:, 16:16 + K], w, out=buf[:, :N])
+    torch.testing.assert_close(buf[:, :N].float(), want, rtol=tol, atol=tol)
+    assert float(buf[:, N:].float().min()) == 7.0 and float(buf[:, N:].float().max()) == 7.0
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,I,K", [(65, 128, 128), (256, 1408, 2048), (130, 14336, 4096), (256, 176, 192)])
+def test_gemm_tall_silu_mul_equals_the_unfused_pair(ops, device, dtype, M, I, K):
+    """gate_up GEMM with the SiLU * mul epilogue (models/llama.py:88-92): the bits of act_fn(gate_up_proj(x)) with the
+    GEMM output rounded to the activation type first -- compared with ops.silu_and_mul of the kernel's own plain output
+    (exact) and with the oracle's fused form on fp32 products (one ulp of slack for the summation order)."""
+    import os
+    g = torch.Generator(device="cpu").manual_seed(M + I + K)
+    x = (torch.randn(M, K, generator=g)).to(dtype).to(device)
+    w = (torch.randn(2 * I, K, generator=g) * K ** -0.5).to(dtype).to(device)
+    try:
+        for geo in ("64", "128"):
+            os.environ["SEMIPD_G8_XH"] = geo
+            for ks in ("1", "2"):
+                os.environ["SEMIPD_G8_KS"] = ks
+                fused = ops.gemm_tall(x, w, fuse_silu_mul=True)
+                plain = ops.gemm_tall(x, w)
+                assert torch.equal(fused, ops.silu_and_mul(plain))
+    finally:
+        os.environ.pop("SEMIPD_G8_KS", None)
+        os.environ.pop("SEMIPD_G8_XH", None)
+    want = O.silu_and_mul((x.float().cpu() @ w.float().cpu().t()).to(dtype))
+    tol = 3e-2 if dtype == torch.bfloat16 else 4e-3
+    torch.testing.assert_close(fused.float().cpu(), want.float(), rtol=tol, atol=tol)

@@ -272,6 +272,40 @@ def bench_stream_linear():
             del ws
 
 
+def bench_gemm_tall():
+    """ops.gemm_tall (csrc/gemm8p.hip) vs hipBLASLt at Llama-3-8B layer shapes and the lm_head: tall decode batches
+    (weight-stream bound: GB/s of weights) up to prefill-sized ones (TFLOP/s)."""
+    import torch.nn.functional as F
+    ncu = int(os.environ.get("KBENCH_NUM_CUS", "0"))
+    if ncu:
+        from semi_pd_amd import _lib
+        _lib.load().semipd_gemm_tall_set_cus(ncu)
+    print("# gemm_tall M x [N, K]: hipBLASLt us | gemm_tall us  TF/s  GB/s(weights)   HSA_CU_MASK=%s num_cus=%d"
+          % (os.environ.get("HSA_CU_MASK", "-"), ncu))
+    for M in [int(v) for v in os.environ.get("KBENCH_MS", "96,128,192,256,1024,4096").split(",")]:
+        for (N, K, silu) in ((28672, 4096, True), (28672, 4096, False), (4096, 14336, False), (6144, 4096, False),
+                             (4096, 4096, False), (128256, 4096, False)):
+            copies = max(2, int(1.2e9 // (N * K * 2)))
+            ws = [torch.randn(N, K, device=dev, dtype=torch.bfloat16) * 0.02 for _ in range(copies)]
+            x = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
+            it = [0]
+
+            def f1():
+                it[0] += 1
+                y = F.linear(x, ws[it[0] % copies])
+                return ops.silu_and_mul(y) if silu else y
+
+            def f2():
+                it[0] += 1
+                return ops.gemm_tall(x, ws[it[0] % copies], fuse_silu_mul=silu)
+            t1 = timeit(f1, iters=3 * copies)
+            t2 = timeit(f2, iters=3 * copies)
+            fl, by = 2.0 * M * N * K, N * K * 2
+            print(f"M={M:5d} N={N:6d} K={K:6d} silu={int(silu)}: blaslt {t1 * 1e6:8.1f} us {fl / t1 / 1e12:7.1f} TF | "
+                  f"gemm_tall {t2 * 1e6:8.1f} us {fl / t2 / 1e12:7.1f} TF {by / t2 / 1e9:6.0f} GB/s", flush=True)
+            del ws
+
+
 def bench_linear_prefill():
     """Prefill-sized dense layers of Llama-3-8B through hipBLASLt under a CU mask (HSA_CU_MASK) with / without
     TENSILE_STREAMK_MAX_CUS: does the library's stream-K grid follow the share?"""
@@ -390,6 +424,8 @@ if __name__ == "__main__":
         bench_linear()
     if which == "stream_linear":
         bench_stream_linear()
+    if which == "gemm_tall":
+        bench_gemm_tall()
     if which == "linear_prefill":
         bench_linear_prefill()
     if which == "decode_small":
