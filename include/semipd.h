@@ -244,6 +244,16 @@ int semipd_gemm_tall_set_cus(int cus);
 int semipd_gemm_tall(void* out, const void* x, const void* weight, void* workspace, size_t workspace_bytes, int64_t rows,
                      int64_t n, int64_t k, int64_t ldx, int64_t ldo, int fuse_silu_mul, int dtype, void* stream);
 
+/* The grouped form of the tiled ping-pong GEMM for the fused-MoE expert GEMMs of prefill-sized calls
+ * (invoke_fused_moe_kernel, python/sglang/srt/layers/moe/fused_moe_triton/fused_moe.py:501-612; kernel :54-273):
+ * sorted_token_ids / expert_ids from semipd_moe_align_block_size with block size 256 (one expert per 256-entry tile;
+ * max_sorted = entries of sorted_token_ids, a multiple of 256).  c[id, :] = a[id / top_k_div, :] @ w[expert]^T for every
+ * routed entry id < num_valid, times topk_weights[id] when mul_routed_weight; fuse_silu_mul: w[e] = merged [gate; up]
+ * ([n, k], output width n / 2) and c = SiLU(gate) * up of the products rounded to dtype (the bits of the unfused pair). */
+int semipd_moe_gemm_tall(void* c, const void* a, const void* w, const float* topk_weights, const int32_t* sorted_token_ids,
+                         const int32_t* expert_ids, const int32_t* num_tokens_post_pad, int64_t num_valid, int64_t n, int64_t k,
+                         int64_t max_sorted, int top_k_div, int mul_routed_weight, int fuse_silu_mul, int dtype, void* stream);
+
 /* ---- prefill-sized dense layers on a CU share (csrc/dense_gemm.cpp) ------------------------------------------------
  * out[rows, n] = x[rows, k] @ weight[n, k]^T (+ bias[n]) through hipBLASLt with the solution that MEASURED fastest on
  * the compute units this process owns.  Replaces F.linear in UnquantizedLinearMethod.apply

@@ -88,10 +88,22 @@ template <int XH> struct G8Geo {
 };
 
 // NT: the weight tile is used by this workgroup only (one row of tiles): stream it non-temporally past L2 / MALL
-template <typename T, int EPI, bool NT, int XH>
+// Grouped form (GR; fused-MoE expert GEMMs, fused_moe.py:54-273): the x tile is 2 XH consecutive entries of
+// sorted_token_ids (moe_align_block_size with block size 2 XH: one expert per tile, expert_ids[tile]); entry id reads
+// activation row id / top_k_div and writes output row id (entries >= num_valid are padding), optionally scaled by
+// topk_weights[id]; W = w[expert].
+struct G8Group {
+  const int32_t* sorted_ids;
+  const int32_t* expert_ids;
+  const int32_t* num_post_pad;
+  const float* topk_weights;
+  int num_valid, top_k_div, mul_routed_weight;
+};
+
+template <typename T, int EPI, bool NT, int XH, bool GR = false>
 __global__ void __launch_bounds__(512)
 gemm8p_kernel(T* __restrict__ out, float* __restrict__ planes, const T* __restrict__ x, const T* __restrict__ w, int M, int N,
-              int K, int64_t ldx, int64_t ldo, int kt_per_slice) {
+              int K, int64_t ldx, int64_t ldo, int kt_per_slice, G8Group grp = G8Group()) {
   using G = G8Geo<XH>;
   constexpr int WH = G::WH, LX = G::LX, LW = G::LW, MT2 = G::MT2, NT2 = G::NT2;
   extern __shared__ __attribute__((aligned(16))) char g8_smem[];
@@ -108,6 +120,10 @@ gemm8p_kernel(T* __restrict__ out, float* __restrict__ planes, const T* __restri
   const int nkt_total = K >> 6;
   const int kt0 = ks * kt_per_slice;
   const int nkt = min(kt_per_slice, nkt_total - kt0);     // >= 1 by construction of the grid
+  if (GR) {
+    if (m0 >= grp.num_post_pad[0]) return;                // whole workgroup: tiles past the padded token count
+    w += (int64_t)grp.expert_ids[tile_m] * N * K;
+  }
 
   // ---- DMA sources.  A half-tile of R rows is R / 8 wave instructions (8 rows x 128 B each); a wave issues instructions
   //      wave * L + e; instruction j fills LDS rows r' = 8 j + (lane >> 3) with chunk position lane & 7, i.e. source chunk
@@ -122,8 +138,14 @@ gemm8p_kernel(T* __restrict__ out, float* __restrict__ planes, const T* __restri
     const int chunk = (lane & 7) ^ ((rp >> 1) & 7);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int xrow = m0 + XH * (rp / (XH / 2)) + (XH / 2) * h + (rp % (XH / 2));
-      srcx[h][e] = x + (int64_t)min(xrow, M - 1) * ldx + (int64_t)kt0 * 64 + chunk * 8;
+      int xrow = m0 + XH * (rp / (XH / 2)) + (XH / 2) * h + (rp % (XH / 2));
+      if (GR) {
+        const int id = grp.sorted_ids[xrow];
+        xrow = id < grp.num_valid ? id / grp.top_k_div : 0;      // padding entries read row 0 (discarded)
+      } else {
+        xrow = min(xrow, M - 1);
+      }
+      srcx[h][e] = x + (int64_t)xrow * ldx + (int64_t)kt0 * 64 + chunk * 8;
     }
   }
 #pragma unroll
@@ -268,24 +290,34 @@ gemm8p_kernel(T* __restrict__ out, float* __restrict__ planes, const T* __restri
   }
   if (EPI == G8_PLAIN) {
 #pragma unroll
-    for (int i = 0; i < 2 * MT2; ++i)
+    for (int i = 0; i < 2 * MT2; ++i) {
+      int m = mb + 16 * i;
+      float scale = 1.f;
+      if (GR) {
+        m = grp.sorted_ids[m];                                   // output row = the routed entry itself
+        if (m < grp.num_valid && grp.mul_routed_weight) scale = grp.topk_weights[m];
+      }
 #pragma unroll
       for (int j = 0; j < 2 * NT2; ++j) {
-        const int m = mb + 16 * i, n = n0 + (WH / 2) * wc + 16 * j + 4 * q4;
+        const int n = n0 + (WH / 2) * wc + 16 * j + 4 * q4;
         if (m < M && n < N) {
-          const g8_f32x4 v = acc[i][j];
+          g8_f32x4 v = acc[i][j];
+          if (GR) v *= scale;
           uint2 p;
           p.x = (uint32_t)Elem<T>::from_f(v[0]).v | ((uint32_t)Elem<T>::from_f(v[1]).v << 16);
           p.y = (uint32_t)Elem<T>::from_f(v[2]).v | ((uint32_t)Elem<T>::from_f(v[3]).v << 16);
           *reinterpret_cast<uint2*>(out + (int64_t)m * ldo + n) = p;
         }
       }
+    }
   } else {
 #pragma unroll
-    for (int i = 0; i < 2 * MT2; ++i)
+    for (int i = 0; i < 2 * MT2; ++i) {
+      int m = mb + 16 * i;
+      if (GR) m = grp.sorted_ids[m];
 #pragma unroll
       for (int j = 0; j < NT2; ++j) {
-        const int m = mb + 16 * i, n = n0 + (WH / 4) * wc + 16 * j + 4 * q4;
+        const int n = n0 + (WH / 4) * wc + 16 * j + 4 * q4;
         if (m < M && n < n_cols) {
           float r[4];
 #pragma unroll
@@ -293,6 +325,9 @@ gemm8p_kernel(T* __restrict__ out, float* __restrict__ planes, const T* __restri
             // the unfused pair rounds the GEMM output to T before the activation reads it
             const float gq = Elem<T>::to_f(Elem<T>::from_f(acc[i][j][e])), uq = Elem<T>::to_f(Elem<T>::from_f(acc[i][NT2 + j][e]));
             r[e] = gq / (1.f + __expf(-gq)) * uq;
+            // keep the product an fp32 VALUE: left alone the compiler folds multiply + conversion into one
+            // v_fma_mixlo_f16 (a single rounding), one ulp away from silu_and_mul's two in rare cases
+            asm volatile("" : "+v"(r[e]));
           }
           uint2 p;
           p.x = (uint32_t)Elem<T>::from_f(r[0]).v | ((uint32_t)Elem<T>::from_f(r[1]).v << 16);
@@ -300,6 +335,7 @@ gemm8p_kernel(T* __restrict__ out, float* __restrict__ planes, const T* __restri
           *reinterpret_cast<uint2*>(out + (int64_t)m * ldo + n) = p;
         }
       }
+    }
   }
 }
 
@@ -324,6 +360,7 @@ gemm8p_reduce_kernel(T* __restrict__ out, const float* __restrict__ planes, int 
     for (int j = 0; j < 4; ++j) {
       const float gq = Elem<T>::to_f(Elem<T>::from_f(r[j])), uq = Elem<T>::to_f(Elem<T>::from_f(u[j]));
       r[j] = gq / (1.f + __expf(-gq)) * uq;
+      asm volatile("" : "+v"(r[j]));   // see the kernel's epilogue
     }
   }
   uint2 p;
@@ -395,6 +432,21 @@ static int g8_launch(T* out, float* planes, size_t planes_bytes, const T* x, con
   return g8_launch_geo<T, EPI, 128>(out, planes, planes_bytes, x, w, M, N, K, ldx, ldo, force_ks, st);
 }
 
+template <typename T, int EPI>
+static int g8_launch_grouped(T* c, const T* a, const T* w, const G8Group& grp, int64_t max_sorted, int N, int K, int64_t lda,
+                             int64_t ldc, hipStream_t st) {
+  using G = G8Geo<128>;
+  const int n_cols = EPI == G8_SILU_MUL ? N / 2 : N;
+  const int cols_per_tile = EPI == G8_SILU_MUL ? G::WH : G::BN;
+  const int tiles_n = (n_cols + cols_per_tile - 1) / cols_per_tile, tiles_m = (int)(max_sorted / G::BM);
+  if (tiles_m == 0) return 0;
+  static std::atomic<uint64_t> lds_ok{0};
+  if (ensure_dynamic_lds((const void*)gemm8p_kernel<T, EPI, false, 128, true>, G::kLds, lds_ok, "gemm8p_grouped")) return 1;
+  hipLaunchKernelGGL((gemm8p_kernel<T, EPI, false, 128, true>), dim3(tiles_m * tiles_n, 1), dim3(512), G::kLds, st, c,
+                     (float*)nullptr, a, w, grp.num_valid, N, K, lda, ldc, K / 64, grp);
+  return launch_status("gemm8p_grouped");
+}
+
 }  // namespace semipd
 
 using namespace semipd;
@@ -432,6 +484,36 @@ int semipd_gemm_tall(void* out, const void* x, const void* weight, void* workspa
     SEMIPD_DISPATCH_HALF(dtype, T, rc = (g8_launch<T, G8_PLAIN>((T*)out, (float*)workspace, workspace_bytes, (const T*)x,
                                                                 (const T*)weight, (int)rows, (int)n, (int)k, ldx, ldo, force_ks,
                                                                 force_geo, st)));
+  }
+  return rc;
+}
+
+/* invoke_fused_moe_kernel (fused_moe.py:501-612) for prefill-sized calls with the tiled ping-pong GEMM: sorted_token_ids /
+ * expert_ids from moe_align_block_size with block size 256 (one expert per 256-entry tile; sorted_token_ids must hold
+ * max_sorted entries, a multiple of 256).  c[id, :] = a[id / top_k_div, :] @ w[expert]^T for every routed entry id <
+ * num_valid, times topk_weights[id] when mul_routed_weight; fuse_silu_mul: w[e] = merged [gate; up] ([n, k], n = 2 x
+ * output width) and c = SiLU(gate) * up of the products rounded to dtype. */
+int semipd_moe_gemm_tall(void* c, const void* a, const void* w, const float* topk_weights, const int32_t* sorted_token_ids,
+                         const int32_t* expert_ids, const int32_t* num_tokens_post_pad, int64_t num_valid, int64_t n, int64_t k,
+                         int64_t max_sorted, int top_k_div, int mul_routed_weight, int fuse_silu_mul, int dtype, void* stream) {
+  SEMIPD_CHECK_ARG(num_valid >= 0 && n > 0 && k > 0 && max_sorted >= 0 && top_k_div > 0, SEMIPD_EINVAL, "moe_gemm_tall: bad sizes");
+  if (num_valid == 0 || max_sorted == 0) return 0;
+  SEMIPD_CHECK_ARG(c && a && w && sorted_token_ids && expert_ids && num_tokens_post_pad, SEMIPD_EINVAL,
+                   "moe_gemm_tall: null pointer");
+  SEMIPD_CHECK_ARG(!mul_routed_weight || topk_weights, SEMIPD_EINVAL, "moe_gemm_tall: topk_weights required");
+  const int64_t n_out = fuse_silu_mul ? n / 2 : n;
+  SEMIPD_CHECK_ARG(max_sorted % 256 == 0 && k % 64 == 0 && n_out % 16 == 0 && (!fuse_silu_mul || n % 2 == 0) && aligned16(a) &&
+                       aligned16(w) && (reinterpret_cast<uintptr_t>(c) & 7u) == 0 && num_valid < (1 << 30) && n < (1 << 30) &&
+                       k < (1 << 30),
+                   SEMIPD_ESHAPE, "moe_gemm_tall: block size 256, k %% 64, output width %% 16 required");
+  G8Group grp{sorted_token_ids, expert_ids, num_tokens_post_pad, topk_weights, (int)num_valid, top_k_div, mul_routed_weight};
+  int rc = 0;
+  if (fuse_silu_mul) {
+    SEMIPD_DISPATCH_HALF(dtype, T, rc = (g8_launch_grouped<T, G8_SILU_MUL>((T*)c, (const T*)a, (const T*)w, grp, max_sorted, (int)n,
+                                                                           (int)k, k, n_out, as_stream(stream))));
+  } else {
+    SEMIPD_DISPATCH_HALF(dtype, T, rc = (g8_launch_grouped<T, G8_PLAIN>((T*)c, (const T*)a, (const T*)w, grp, max_sorted, (int)n,
+                                                                        (int)k, k, n_out, as_stream(stream))));
   }
   return rc;
 }

@@ -230,6 +230,9 @@ stream_gemm_glds_kernel(T* __restrict__ out, float* __restrict__ planes, const T
           // the unfused path rounds the GEMM output to T before the activation reads it
           const float gq = Elem<T>::to_f(Elem<T>::from_f(acc[0][t][j])), uq = Elem<T>::to_f(Elem<T>::from_f(acc[NG - 1][t][j]));
           r[j] = gq / (1.f + __expf(-gq)) * uq;
+          // keep the product an fp32 VALUE: left alone the compiler folds multiply + conversion into one
+          // v_fma_mixlo_f16 (a single rounding), one ulp away from silu_and_mul's two in rare cases
+          asm volatile("" : "+v"(r[j]));
         }
         uint2 p;
         p.x = (uint32_t)Elem<T>::from_f(r[0]).v | ((uint32_t)Elem<T>::from_f(r[1]).v << 16);
@@ -261,6 +264,7 @@ splitk_planes_reduce_kernel(T* __restrict__ out, const float* __restrict__ plane
     for (int j = 0; j < 4; ++j) {
       const float gq = Elem<T>::to_f(Elem<T>::from_f(r[j])), uq = Elem<T>::to_f(Elem<T>::from_f(u[j]));
       r[j] = gq / (1.f + __expf(-gq)) * uq;
+      asm volatile("" : "+v"(r[j]));   // see the kernel's epilogue
     }
   }
   uint2 p;

@@ -7,6 +7,8 @@ weights w13 [E, 2N, K] and w2 [E, K, N], TP all-reduce :637-638).
 """
 from __future__ import annotations
 
+import os
+
 from typing import Optional
 
 import torch
@@ -44,6 +46,12 @@ def select_experts(hidden_states: torch.Tensor, router_logits: torch.Tensor, top
     return ops.topk_softmax(router_logits, top_k, renormalize)
 
 
+# rows (tokens x top-k) from which the expert GEMMs take the 256-row-block tiled kernel, and the least average rows per
+# expert (below that the padding to 256 per expert costs more than the faster tile buys)
+MOE_TALL_MIN_ROWS = int(os.environ.get("SEMIPD_MOE_TALL_MIN_ROWS", "16384"))
+MOE_TALL_MIN_ROWS_PER_EXPERT = int(os.environ.get("SEMIPD_MOE_TALL_MIN_ROWS_PER_EXPERT", "384"))
+
+
 def _local_ids(topk_ids: torch.Tensor, expert_offset: int) -> torch.Tensor:
     """Expert-parallel ranks hold experts [offset, offset + E_local): ids are shifted so that the local ones land
     in [0, E_local); the others fall outside and moe_align_block_size drops them (their rows of the output stay
@@ -63,13 +71,24 @@ def fused_experts(hidden_states: torch.Tensor, w1: torch.Tensor, w2: torch.Tenso
     numel = T * topk
     # rows per block: every block streams its expert's weights once, so prefill chunks use the taller
     # block (fused_moe.py:614-700 get_default_config picks BLOCK_SIZE_M by M the same way)
-    block_m = MOE_BLOCK_M if numel <= 2048 else 2 * MOE_BLOCK_M
-    max_sorted = numel + E * (block_m - 1)
+    # prefill-sized calls with enough rows per expert: 256-row blocks and the tiled ping-pong GEMM (csrc/gemm8p.hip, grouped
+    # form), SiLU * mul in GEMM1's epilogue; every expert's rows are padded to a multiple of 256, which is why it only
+    # pays from a few hundred rows per expert up
+    tall = (numel >= MOE_TALL_MIN_ROWS and numel >= MOE_TALL_MIN_ROWS_PER_EXPERT * E
+            and ops.moe_gemm_tall_is_supported(hidden_states, w1, True) and w2.shape[2] % 64 == 0 and K % 16 == 0)
+    block_m = ops.MOE_TALL_BLOCK_M if tall else (MOE_BLOCK_M if numel <= 2048 else 2 * MOE_BLOCK_M)
+    max_sorted = -(-(numel + E * (block_m - 1)) // block_m) * block_m
     sorted_ids = torch.empty(max_sorted, dtype=torch.int32, device=dev)
     expert_ids = torch.empty((max_sorted + block_m - 1) // block_m, dtype=torch.int32, device=dev)
     num_post_pad = torch.empty(1, dtype=torch.int32, device=dev)
     cumsum = torch.empty(E + 1, dtype=torch.int32, device=dev)
     ops.moe_align_block_size(topk_ids, E, block_m, sorted_ids, expert_ids, num_post_pad, None, cumsum)
+    if tall:
+        c2 = torch.empty((numel, N2 // 2), dtype=dt, device=dev)
+        ops.moe_gemm_tall(hidden_states, w1, c2, None, sorted_ids, expert_ids, num_post_pad, numel, topk, False, True)
+        c3 = (torch.zeros if partial_experts else torch.empty)((numel, K), dtype=dt, device=dev)
+        ops.moe_gemm_tall(c2, w2, c3, topk_weights.reshape(-1), sorted_ids, expert_ids, num_post_pad, numel, 1, True, False)
+        return ops.moe_sum(c3.view(T, topk, K))
     # prefill-sized calls: SiLU * mul in GEMM1's epilogue (no [T * k, 2N] intermediate); same bits as the two calls
     c2 = ops.moe_grouped_gemm_silu(hidden_states, w1, sorted_ids, expert_ids, num_post_pad, numel, topk, block_m)
     if c2 is None:

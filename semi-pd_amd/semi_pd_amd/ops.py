@@ -766,6 +766,37 @@ def moe_grouped_gemm_silu(a: torch.Tensor, w: torch.Tensor, sorted_token_ids: to
     return c
 
 
+MOE_TALL_BLOCK_M = 256
+
+
+def moe_gemm_tall_is_supported(a: torch.Tensor, w: torch.Tensor, fuse_silu_mul: bool) -> bool:
+    E, N, K = w.shape
+    n_out = N // 2 if fuse_silu_mul else N
+    return (a.dtype == w.dtype and a.dtype in (torch.bfloat16, torch.float16) and a.shape[-1] == K and a.is_contiguous()
+            and w.is_contiguous() and K % 64 == 0 and n_out % 16 == 0 and (not fuse_silu_mul or N % 2 == 0))
+
+
+def moe_gemm_tall(a: torch.Tensor, w: torch.Tensor, c: torch.Tensor, topk_weights: Optional[torch.Tensor],
+                  sorted_token_ids: torch.Tensor, expert_ids: torch.Tensor, num_tokens_post_pad: torch.Tensor,
+                  num_valid: int, top_k_div: int, mul_routed_weight: bool, fuse_silu_mul: bool = False) -> None:
+    """invoke_fused_moe_kernel (fused_moe.py:501-612) for prefill-sized calls with the 256 x 256 ping-pong tile kernel
+    (csrc/gemm8p.hip, grouped form): sorted_token_ids / expert_ids must come from moe_align_block_size with block size
+    MOE_TALL_BLOCK_M.  c[id] = a[id // top_k_div] @ w[expert].T (SiLU(gate) * up of it with fuse_silu_mul)."""
+    E, N, K = w.shape
+    n_out = N // 2 if fuse_silu_mul else N
+    if not moe_gemm_tall_is_supported(a, w, fuse_silu_mul) or c.shape[-1] != n_out or not c.is_contiguous() \
+            or sorted_token_ids.numel() % MOE_TALL_BLOCK_M:
+        raise RuntimeError("moe_gemm_tall: shape / contiguity / block-size mismatch")
+    if sorted_token_ids.dtype != torch.int32 or expert_ids.dtype != torch.int32 or num_tokens_post_pad.dtype != torch.int32:
+        raise RuntimeError("moe_gemm_tall: int32 routing tensors expected")
+    if mul_routed_weight and (topk_weights is None or topk_weights.dtype != torch.float32):
+        raise RuntimeError("moe_gemm_tall: fp32 topk_weights required")
+    check(_lib.load().semipd_moe_gemm_tall(ptr(c), ptr(a), ptr(w), ptr(topk_weights), ptr(sorted_token_ids), ptr(expert_ids),
+                                           ptr(num_tokens_post_pad), num_valid, N, K, sorted_token_ids.numel(), top_k_div,
+                                           int(mul_routed_weight), int(fuse_silu_mul), dtype_code(a.dtype),
+                                           current_stream(a.device)), "moe_gemm_tall")
+
+
 def moe_sum(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[t] = x[t].sum(0) for x [T, topk, H] (fused_moe.py:1144-1148)."""
     T, k, H = x.shape

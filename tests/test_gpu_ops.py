@@ -1085,3 +1085,60 @@ def test_gemm_tall_silu_mul_equals_the_unfused_pair(ops, device, dtype, M, I, K)
     want = O.silu_and_mul((x.float().cpu() @ w.float().cpu().t()).to(dtype))
     tol = 3e-2 if dtype == torch.bfloat16 else 4e-3
     torch.testing.assert_close(fused.float().cpu(), want.float(), rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("T,E,topk,K,N", [(700, 8, 2, 256, 192), (1500, 16, 6, 2048, 1408), (300, 4, 1, 128, 64)])
+def test_moe_gemm_tall_matches_fp32_per_expert(ops, device, dtype, T, E, topk, K, N):
+    """The grouped form of the tiled kernel on 256-row blocks (invoke_fused_moe_kernel, fused_moe.py:501-612): every routed
+    entry id gets a[id // top_k] @ w[expert(id)]^T -- checked row by row against fp32 products; GEMM1 with the SiLU * mul
+    epilogue equals silu_and_mul of its own plain output bit for bit; GEMM2 multiplies by the routed weight before the
+    rounding; padding entries (>= num_valid) write nothing (c is pre-filled with a sentinel)."""
+    g = torch.Generator(device="cpu").manual_seed(T + E + K)
+    a = torch.randn(T, K, generator=g).to(dtype).to(device)
+    w1 = (torch.randn(E, 2 * N, K, generator=g) * K ** -0.5).to(dtype).to(device)
+    w2 = (torch.randn(E, K, N, generator=g) * N ** -0.5).to(dtype).to(device)
+    logits = torch.randn(T, E, generator=g).to(device)
+    tw, ti = ops.topk_softmax(logits, topk, True)
+    numel, bm = T * topk, ops.MOE_TALL_BLOCK_M
+    max_sorted = -(-(numel + E * (bm - 1)) // bm) * bm
+    sorted_ids = torch.empty(max_sorted, dtype=torch.int32, device=device)
+    expert_ids = torch.empty(max_sorted // bm, dtype=torch.int32, device=device)
+    npp = torch.empty(1, dtype=torch.int32, device=device)
+    ops.moe_align_block_size(ti, E, bm, sorted_ids, expert_ids, npp, None, torch.empty(E + 1, dtype=torch.int32, device=device))
+    tol = 2e-2 if dtype == torch.bfloat16 else 3e-3
+    flat_e = ti.reshape(-1).long()
+    rows = torch.arange(numel, device=device) // topk
+    # GEMM1 plain and fused
+    c1 = torch.full((numel, 2 * N), 77.0, dtype=dtype, device=device)
+    ops.moe_gemm_tall(a, w1, c1, None, sorted_ids, expert_ids, npp, numel, topk, False, False)
+    want1 = torch.einsum("rk,rnk->rn", a[rows].float(), w1[flat_e].float())
+    torch.testing.assert_close(c1.float(), want1, rtol=tol, atol=tol)
+    c2 = torch.full((numel, N), 77.0, dtype=dtype, device=device)
+    ops.moe_gemm_tall(a, w1, c2, None, sorted_ids, expert_ids, npp, numel, topk, False, True)
+    assert torch.equal(c2, ops.silu_and_mul(c1))
+    # GEMM2 with the routed weight
+    c3 = torch.full((numel, K), 77.0, dtype=dtype, device=device)
+    ops.moe_gemm_tall(c2, w2, c3, tw.reshape(-1), sorted_ids, expert_ids, npp, numel, 1, True, False)
+    want3 = torch.einsum("rn,rkn->rk", c2.float(), w2[flat_e].float()) * tw.reshape(-1, 1).float()
+    torch.testing.assert_close(c3.float(), want3, rtol=tol, atol=tol)
+
+
+def test_fused_experts_takes_the_tall_kernel_for_prefill_sized_calls(ops, device, monkeypatch):
+    """layers.moe.fused_experts above the row thresholds (256-row blocks, grouped ping-pong GEMM) against the same call
+    below them (128-row blocks, the round-2 kernels) and the oracle's fused MoE."""
+    from semi_pd_amd.layers import moe as M
+    g = torch.Generator(device="cpu").manual_seed(77)
+    T, E, k, K, N = 1024, 8, 2, 512, 384
+    x = torch.randn(T, K, generator=g).to(torch.bfloat16).to(device)
+    w1 = (torch.randn(E, 2 * N, K, generator=g) * K ** -0.5).to(torch.bfloat16).to(device)
+    w2 = (torch.randn(E, K, N, generator=g) * N ** -0.5).to(torch.bfloat16).to(device)
+    tw, ti = ops.topk_softmax(torch.randn(T, E, generator=g).to(device), k, True)
+    monkeypatch.setattr(M, "MOE_TALL_MIN_ROWS", 1 << 30)
+    base = M.fused_experts(x, w1, w2, tw, ti)
+    monkeypatch.setattr(M, "MOE_TALL_MIN_ROWS", 1024)
+    monkeypatch.setattr(M, "MOE_TALL_MIN_ROWS_PER_EXPERT", 128)
+    tall = M.fused_experts(x, w1, w2, tw, ti)
+    want = O.fused_moe(x.float().cpu(), w1.float().cpu(), w2.float().cpu(), tw.cpu(), ti.cpu().long())
+    torch.testing.assert_close(tall.float().cpu(), want.float(), rtol=3e-2, atol=3e-2)
+    torch.testing.assert_close(tall.float(), base.float(), rtol=3e-2, atol=3e-2)
