@@ -47,9 +47,11 @@ def select_experts(hidden_states: torch.Tensor, router_logits: torch.Tensor, top
 
 
 # rows (tokens x top-k) from which the expert GEMMs take the 256-row-block tiled kernel, and the least average rows per
-# expert (below that the padding to 256 per expert costs more than the faster tile buys)
-MOE_TALL_MIN_ROWS = int(os.environ.get("SEMIPD_MOE_TALL_MIN_ROWS", "16384"))
-MOE_TALL_MIN_ROWS_PER_EXPERT = int(os.environ.get("SEMIPD_MOE_TALL_MIN_ROWS_PER_EXPERT", "384"))
+# expert (below that the padding to 256 per expert costs more than the faster tile buys).  DeepSeek-V2-Lite experts,
+# whole fused MoE: T = 2048 410 -> 362 us, 4096 702 -> 611, 8192 1158 -> 1032 (0.73 -> 0.82 PFLOP/s); T = 1024 276 -> 330
+# (profiles/r03_kbench_moe_tall_blocks.txt)
+MOE_TALL_MIN_ROWS = int(os.environ.get("SEMIPD_MOE_TALL_MIN_ROWS", "12288"))
+MOE_TALL_MIN_ROWS_PER_EXPERT = int(os.environ.get("SEMIPD_MOE_TALL_MIN_ROWS_PER_EXPERT", "192"))
 
 
 def _local_ids(topk_ids: torch.Tensor, expert_offset: int) -> torch.Tensor:

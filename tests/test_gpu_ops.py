@@ -1112,16 +1112,22 @@ def test_moe_gemm_tall_matches_fp32_per_expert(ops, device, dtype, T, E, topk, K
     # GEMM1 plain and fused
     c1 = torch.full((numel, 2 * N), 77.0, dtype=dtype, device=device)
     ops.moe_gemm_tall(a, w1, c1, None, sorted_ids, expert_ids, npp, numel, topk, False, False)
-    want1 = torch.einsum("rk,rnk->rn", a[rows].float(), w1[flat_e].float())
-    torch.testing.assert_close(c1.float(), want1, rtol=tol, atol=tol)
+    def per_expert(x_rows, w, scale=None):       # fp32 reference, one expert at a time (a gather of w would not fit)
+        want = torch.empty(numel, w.shape[1], dtype=torch.float32, device=device)
+        for e in range(E):
+            sel = (flat_e == e).nonzero().squeeze(1)
+            if sel.numel():
+                want[sel] = x_rows[sel].float() @ w[e].float().t()
+        return want if scale is None else want * scale
+
+    torch.testing.assert_close(c1.float(), per_expert(a[rows], w1), rtol=tol, atol=tol)
     c2 = torch.full((numel, N), 77.0, dtype=dtype, device=device)
     ops.moe_gemm_tall(a, w1, c2, None, sorted_ids, expert_ids, npp, numel, topk, False, True)
     assert torch.equal(c2, ops.silu_and_mul(c1))
     # GEMM2 with the routed weight
     c3 = torch.full((numel, K), 77.0, dtype=dtype, device=device)
     ops.moe_gemm_tall(c2, w2, c3, tw.reshape(-1), sorted_ids, expert_ids, npp, numel, 1, True, False)
-    want3 = torch.einsum("rn,rkn->rk", c2.float(), w2[flat_e].float()) * tw.reshape(-1, 1).float()
-    torch.testing.assert_close(c3.float(), want3, rtol=tol, atol=tol)
+    torch.testing.assert_close(c3.float(), per_expert(c2, w2, tw.reshape(-1, 1).float()), rtol=tol, atol=tol)
 
 
 def test_fused_experts_takes_the_tall_kernel_for_prefill_sized_calls(ops, device, monkeypatch):
