@@ -237,12 +237,12 @@ def main():
     # decode from the top).  The default is a MASKED policy -- the north star's compute isolation and BASELINE config 2
     # ("CU split") -- with the shares this build measured best on the config-2 load (profiles/r03_policy_sweep_*.txt);
     # `--prefill-cu 50 --decode-cu 50` is config 2's split as written, `--prefill-cu 100 --decode-cu 100` the unmasked
-    # round-2 default.  --static-split-wave adds one warm-up + one timed wave of a second engine at 50 / 50.
+    # round-2 default.  The literal 50 / 50 split is measured in the same invocation by a second engine (one warm-up +
+    # one timed wave, "static_split_50_50"; --no-static-split-wave skips it).
     ap.add_argument("--prefill-cu", type=int, default=DEFAULT_PREFILL_CU)
     ap.add_argument("--decode-cu", type=int, default=DEFAULT_DECODE_CU)
-    ap.add_argument("--static-split-wave", action="store_true",
-                    help="N = 1 Semi-PD run: also measure a second engine with the static 50 / 50 CU split")
-    ap.add_argument("--no-static-split-wave", action="store_true", help="(default; kept for old command lines)")
+    ap.add_argument("--no-static-split-wave", action="store_true",
+                    help="N = 1 Semi-PD default run: do not start the second engine with BASELINE config 2's literal 50 / 50 split")
     ap.add_argument("--no-prefill-gemm-tuning", action="store_true",
                     help="prefill instance: the library's own GEMM choice instead of the solutions timed on its CU share")
     ap.add_argument("--cu-mask-mode", default="env")
@@ -405,7 +405,7 @@ def main():
         engine.shutdown()
 
     static_split = None
-    if (world == 1 and args.mode == "semi-pd" and args.static_split_wave
+    if (world == 1 and args.mode == "semi-pd" and not args.no_static_split_wave
             and (args.prefill_cu, args.decode_cu) != (50, 50)):
         # BASELINE config 2 as written: disjoint halves of the CUs, same load, one warm-up wave + one timed wave
         import dataclasses

@@ -49,12 +49,7 @@ template <int D, typename Raw> struct KRegs {
   Raw k[2][D / 32];
 };
 
-// KL (K through LDS): the K rows of a tile are loaded like the V rows -- a wave instruction covers 4 whole 2 D-byte rows,
-// 8 cache lines, where a fragment-shaped load (16 rows x 64 B) touches 16 -- written to a per-wave row-major LDS tile
-// (row stride 2 D + 16 bytes: conflict-free for the 16-row ds_read_b128 of an MFMA fragment) and read from there in
-// operand layout.  The CU's address path, not HBM, bounds this kernel on a partial CU share (a CU sustains ~25 GB/s of
-// fragment-shaped loads, ~40 GB/s of row-shaped ones: profiles/r03_kbench_decode_k_through_lds.txt).
-template <typename T, int D, typename KV, bool KL>
+template <typename T, int D, typename KV>
 __global__ void __launch_bounds__(256, D <= 128 ? 2 : 1)   // D = 256 needs > 256 registers: one workgroup per SIMD set instead of 672 B of scratch
 decode_mfma_kernel(T* __restrict__ out, const T* __restrict__ q, const KV* __restrict__ k_buf,
                    const KV* __restrict__ v_buf, const int32_t* __restrict__ kv_indptr,
@@ -68,8 +63,6 @@ decode_mfma_kernel(T* __restrict__ out, const T* __restrict__ q, const KV* __res
   constexpr int PAD = ((D / 2) % 32 == 16) ? 0 : 64;  // row stride == 16 or 48 dwords (mod 64):
   constexpr int RS = D * 2 + PAD;                     // conflict-free ds_read_b64_tr_b16
   __shared__ __attribute__((aligned(16))) uint8_t v_lds_all[4][32 * RS];
-  constexpr int KRS = D * 2 + 16;
-  __shared__ __attribute__((aligned(16))) uint8_t k_lds_all[KL ? 4 : 1][KL ? 32 * KRS : 16];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c16 = lane & 15, q4 = lane >> 4;
@@ -85,7 +78,6 @@ decode_mfma_kernel(T* __restrict__ out, const T* __restrict__ q, const KV* __res
   const int heads = min(16, group - h0);
   const int hq0 = hk * group + h0;
   uint8_t* v_lds = v_lds_all[wave];
-  uint8_t* k_lds = k_lds_all[KL ? wave : 0];
 
   const int kv_start = kv_indptr[b];
   const int seq_len = kv_indptr[b + 1] - kv_start;
@@ -134,17 +126,6 @@ decode_mfma_kernel(T* __restrict__ out, const T* __restrict__ q, const KV* __res
         r.k[t][ks] = KVT::load8(k_buf + row + ks * 32);
     }
   };
-  Raw kreg[KL ? NV : 1];  // KL: K rows of the NEXT tile, in flight like the V rows
-  auto issue_k_rows = [&](int32_t idx_reg) {
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const int it = j * 64 + lane;
-      const int tok = it / CPR, ch = it - tok * CPR;
-      // rows past the end read pool row 0 (the dummy slot): their scores are masked to -inf below
-      const int64_t row = (int64_t)__shfl(idx_reg, tok, 64) * kbuf_stride + (int64_t)hk * D;
-      kreg[KL ? j : 0] = KVT::load8(k_buf + row + ch * 8);
-    }
-  };
   Raw vreg[NV];  // V rows of the NEXT tile, in flight while the current tile is computed
   auto issue_v = [&](int32_t idx_reg, int ti) {
     const int base_tok = s_begin + ti * 32;
@@ -169,15 +150,6 @@ decode_mfma_kernel(T* __restrict__ out, const T* __restrict__ q, const KV* __res
       const int tok = it / CPR, ch = it - tok * CPR;
       *reinterpret_cast<uint4*>(v_lds + tok * RS + ch * 16) = KVT::expand(vreg[j]);
     }
-    if (KL) {
-#pragma unroll
-      for (int j = 0; j < NV; ++j) {
-        const int it = j * 64 + lane;
-        const int tok = it / CPR, ch = it - tok * CPR;
-        *reinterpret_cast<uint4*>(k_lds + tok * KRS + ch * 16) = KVT::expand(kreg[KL ? j : 0]);
-      }
-      if (ti + 1 < n_tiles) issue_k_rows(idx_v);
-    }
     if (ti + 1 < n_tiles) issue_v(idx_v, ti + 1);
     // ---- S^T = K Q^T ----
     f32x4 s_acc[2];
@@ -187,8 +159,7 @@ decode_mfma_kernel(T* __restrict__ out, const T* __restrict__ q, const KV* __res
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         FragD kf;
-        if (KL) kf.u = *reinterpret_cast<const uint4*>(k_lds + (t * 16 + c16) * KRS + ks * 64 + q4 * 16);
-        else kf.u = KVT::expand(r.k[t][ks]);
+        kf.u = KVT::expand(r.k[t][ks]);
         s_acc[t] = Mfma16<T>::mma(kf, qf[ks], s_acc[t]);
       }
     }
@@ -246,28 +217,19 @@ decode_mfma_kernel(T* __restrict__ out, const T* __restrict__ q, const KV* __res
 
   KRegs<D, Raw> ra, rb;
   int32_t idx_cur = load_idx(0);
-  if (KL) issue_k_rows(idx_cur);
-  else issue_k(ra, idx_cur);
+  issue_k(ra, idx_cur);
   issue_v(idx_cur, 0);
   int32_t idx_next = load_idx(1);
-  if (KL) {
-    for (int ti = 0; ti < n_tiles; ++ti) {
-      idx_cur = idx_next;            // indices of tile ti + 1 (its K and V rows are issued inside compute)
-      idx_next = load_idx(ti + 2);
-      compute(ra, ti, idx_cur);
-    }
-  } else {
-    for (int ti = 0; ti < n_tiles; ti += 2) {
-      if (ti + 1 < n_tiles) issue_k(rb, idx_next);
-      idx_cur = idx_next;            // indices of tile ti+1 (its V rows are issued inside compute)
-      idx_next = load_idx(ti + 2);
-      compute(ra, ti, idx_cur);
-      if (ti + 1 < n_tiles) {
-        if (ti + 2 < n_tiles) issue_k(ra, idx_next);
-        idx_cur = idx_next;
-        idx_next = load_idx(ti + 3);
-        compute(rb, ti + 1, idx_cur);
-      }
+  for (int ti = 0; ti < n_tiles; ti += 2) {
+    if (ti + 1 < n_tiles) issue_k(rb, idx_next);
+    idx_cur = idx_next;            // indices of tile ti+1 (its V rows are issued inside compute)
+    idx_next = load_idx(ti + 2);
+    compute(ra, ti, idx_cur);
+    if (ti + 1 < n_tiles) {
+      if (ti + 2 < n_tiles) issue_k(ra, idx_next);
+      idx_cur = idx_next;
+      idx_next = load_idx(ti + 3);
+      compute(rb, ti + 1, idx_cur);
     }
   }
 
@@ -306,18 +268,10 @@ int launch_decode_mfma(T* out, const T* q, const KV* k_buf, const KV* v_buf, con
   const int tiles = (group + 15) / 16;
   const int64_t total = batch * Hkv * tiles * splits;
   dim3 grid((unsigned)((total + 3) / 4)), block(256);
-  static const bool k_lds = []() { const char* e = getenv("SEMIPD_DECODE_K_LDS"); return e ? atoi(e) != 0 : true; }();
 #define DM(DD)                                                                                      \
-  do {                                                                                              \
-    if (k_lds && DD <= 128)                                                                         \
-      hipLaunchKernelGGL((decode_mfma_kernel<T, DD, KV, true>), grid, block, 0, st, out, q, k_buf, v_buf, kv_indptr, \
-                         kv_indices, attn_logits, Hq, Hkv, group, tiles, q_stride, o_stride, kbuf_stride,  \
-                         vbuf_stride, splits, total, sm_scale, logit_cap);                            \
-    else                                                                                            \
-      hipLaunchKernelGGL((decode_mfma_kernel<T, DD, KV, false>), grid, block, 0, st, out, q, k_buf, v_buf, kv_indptr, \
-                         kv_indices, attn_logits, Hq, Hkv, group, tiles, q_stride, o_stride, kbuf_stride,  \
-                         vbuf_stride, splits, total, sm_scale, logit_cap);                            \
-  } while (0)
+  hipLaunchKernelGGL((decode_mfma_kernel<T, DD, KV>), grid, block, 0, st, out, q, k_buf, v_buf, kv_indptr, \
+                     kv_indices, attn_logits, Hq, Hkv, group, tiles, q_stride, o_stride, kbuf_stride,  \
+                     vbuf_stride, splits, total, sm_scale, logit_cap)
   switch (D) {
     case 64: DM(64); break;
     case 96: DM(96); break;
