@@ -244,6 +244,18 @@ int semipd_gemm_tall_set_cus(int cus);
 int semipd_gemm_tall(void* out, const void* x, const void* weight, void* workspace, size_t workspace_bytes, int64_t rows,
                      int64_t n, int64_t k, int64_t ldx, int64_t ldo, int fuse_silu_mul, int dtype, void* stream);
 
+/* The grouped form of the LDS-DMA streaming kernel for the expert GEMMs of DECODE-sized fused-MoE calls
+ * (invoke_fused_moe_kernel, python/sglang/srt/layers/moe/fused_moe_triton/fused_moe.py:501-612): every touched expert's
+ * weights are streamed once by row-shaped LDS-DMA.  sorted_token_ids / expert_ids from semipd_moe_align_block_size with
+ * block size block_m in {16, 32, 48, 64} (T tokens route at most T rows to one expert: block_m = 16 ceil(T / 16));
+ * max_sorted = entries of sorted_token_ids, a multiple of block_m.  c[id, :] = a[id / top_k_div, :] @ w[expert]^T for
+ * id < num_valid, times topk_weights[id] when mul_routed_weight; fuse_silu_mul: w[e] = merged [gate; up], output width
+ * n / 2, c = SiLU(gate) * up of the products rounded to dtype.  k % 128 == 0, output width % 16 == 0. */
+int semipd_moe_stream_gemm(void* c, const void* a, const void* w, const float* topk_weights, const int32_t* sorted_token_ids,
+                           const int32_t* expert_ids, const int32_t* num_tokens_post_pad, int64_t num_valid, int64_t n,
+                           int64_t k, int64_t max_sorted, int top_k_div, int mul_routed_weight, int fuse_silu_mul, int block_m,
+                           int dtype, void* stream);
+
 /* The grouped form of the tiled ping-pong GEMM for the fused-MoE expert GEMMs of prefill-sized calls
  * (invoke_fused_moe_kernel, python/sglang/srt/layers/moe/fused_moe_triton/fused_moe.py:501-612; kernel :54-273):
  * sorted_token_ids / expert_ids from semipd_moe_align_block_size with block size 256 (one expert per 256-entry tile;

@@ -91,21 +91,38 @@ __device__ inline uint32_t sg_lds_addr(const void* p) {
   return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
 }
 
-template <typename T, int MT, int NG, int NW, int R, int EPI>
+// Grouped form (GR; the expert GEMMs of a decode-sized fused MoE, fused_moe.py:54-273): blockIdx.y = a block of 16 MT
+// entries of sorted_token_ids (moe_align_block_size with block size 16 MT: one expert per block, expert_ids[block]); entry
+// id reads activation row id / top_k_div and writes output row id (entries >= num_valid are padding), optionally
+// scaled by topk_weights[id]; W = w[expert]; no K split.
+struct SgGroup {
+  const int32_t* sorted_ids;
+  const int32_t* expert_ids;
+  const int32_t* num_post_pad;
+  const float* topk_weights;
+  int num_valid, top_k_div, mul_routed_weight;
+};
+
+template <typename T, int MT, int NG, int NW, int R, int EPI, bool GR = false>
 __global__ void __launch_bounds__(64 * NW)
 stream_gemm_glds_kernel(T* __restrict__ out, float* __restrict__ planes, const T* __restrict__ x,
                         const T* __restrict__ w, int M, int N, int K, int64_t ldx, int64_t ldo, int kb_per_slice,
-                        int planes_only) {
+                        int planes_only, SgGroup grp = SgGroup()) {
   using L = SgLayout<MT, NG, NW, R>;
   extern __shared__ __attribute__((aligned(16))) char sg_smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c16 = lane & 15, q4 = lane >> 4;
   const int n_half = N >> 1;
-  const int ks = blockIdx.y;
+  const int ks = GR ? 0 : blockIdx.y;
   const int nkb_total = K >> 7;
   const int kb0 = ks * kb_per_slice;
   const int nkb = min(kb_per_slice, nkb_total - kb0);       // >= 1 by construction of the grid
+  const int m_blk = GR ? (int)blockIdx.y * (16 * MT) : 0;   // first entry of this block in sorted_token_ids
+  if (GR) {
+    if (m_blk >= grp.num_post_pad[0]) return;               // whole workgroup: blocks past the padded token count
+    w += (int64_t)grp.expert_ids[blockIdx.y] * N * K;
+  }
   // ---- DMA source pointers (per lane): piece j = rows 4j .. 4j+3 of a 16-row block, lane -> row 4j + (lane >> 4),
   //      chunk (lane & 15) ^ (row & 15) of the row's 256-byte k-block segment ----
   const int prow = lane >> 4;                               // row inside a piece
@@ -127,7 +144,14 @@ stream_gemm_glds_kernel(T* __restrict__ out, float* __restrict__ planes, const T
     const int piece = (wave + e * NW) % (4 * MT);           // duplicates (same bytes, same place) when 4 MT % NW != 0
     const int t = piece >> 2, j = piece & 3;
     const int i = 4 * j + prow;
-    xsrc[e] = x + (int64_t)min(t * 16 + i, M - 1) * ldx + (int64_t)kb0 * 128 + (((lane & 15) ^ (i & 15)) << 3);
+    int xrow = t * 16 + i;
+    if (GR) {
+      const int id = grp.sorted_ids[m_blk + xrow];
+      xrow = id < grp.num_valid ? id / grp.top_k_div : 0;   // padding entries read row 0 (discarded)
+    } else {
+      xrow = min(xrow, M - 1);
+    }
+    xsrc[e] = x + (int64_t)xrow * ldx + (int64_t)kb0 * 128 + (((lane & 15) ^ (i & 15)) << 3);
     xdst[e] = t * 4096 + j * 1024;
   }
   char* const xring = sg_smem;
@@ -193,7 +217,7 @@ stream_gemm_glds_kernel(T* __restrict__ out, float* __restrict__ planes, const T
   }
 
   // ---- epilogue: lane holds C[m = t*16 + c16][n = nbase + q4*4 + r] ----
-  if (gridDim.y > 1 || planes_only) {
+  if (!GR && (gridDim.y > 1 || planes_only)) {
     float* pl = planes + (int64_t)ks * M * N;
 #pragma unroll
     for (int g = 0; g < NG; ++g)
@@ -210,9 +234,16 @@ stream_gemm_glds_kernel(T* __restrict__ out, float* __restrict__ planes, const T
     for (int g = 0; g < NG; ++g)
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
-        const int m = t * 16 + c16, n = n0 + g * 16 + q4 * 4;
+        int m = t * 16 + c16;
+        const int n = n0 + g * 16 + q4 * 4;
+        float scale = 1.f;
+        if (GR) {
+          m = grp.sorted_ids[m_blk + m];                    // output row = the routed entry itself
+          if (m < grp.num_valid && grp.mul_routed_weight) scale = grp.topk_weights[m];
+        }
         if (m < M && n < N) {
-          const sl_f32x4 v = acc[g][t];
+          sl_f32x4 v = acc[g][t];
+          if (GR) v *= scale;
           uint2 p;
           p.x = (uint32_t)Elem<T>::from_f(v[0]).v | ((uint32_t)Elem<T>::from_f(v[1]).v << 16);
           p.y = (uint32_t)Elem<T>::from_f(v[2]).v | ((uint32_t)Elem<T>::from_f(v[3]).v << 16);
@@ -222,7 +253,9 @@ stream_gemm_glds_kernel(T* __restrict__ out, float* __restrict__ planes, const T
   } else {
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
-      const int m = t * 16 + c16, n = n0 + q4 * 4;
+      int m = t * 16 + c16;
+      const int n = n0 + q4 * 4;
+      if (GR) m = grp.sorted_ids[m_blk + m];
       if (m < M && n < n_half) {
         float r[4];
 #pragma unroll
@@ -330,6 +363,25 @@ static int sg_launch(T* out, float* planes, size_t planes_bytes, const T* x, con
   hipLaunchKernelGGL((splitk_planes_reduce_kernel<T, EPI>), dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, out,
                      (const float*)planes, ksp, M, N, ldo);
   return launch_status("splitk_planes_reduce");
+}
+
+template <typename T, int MT, int EPI>
+static int sg_launch_grouped(T* c, const T* a, const T* w, const SgGroup& grp, int64_t max_sorted, int N, int K, int64_t lda,
+                             int64_t ldc, hipStream_t st) {
+  constexpr int NG = EPI == SL_SILU_MUL ? 2 : 1, NW = EPI == SL_SILU_MUL ? 4 : 8, R = 3;
+  using L = SgLayout<MT, NG, NW, R>;
+  const int rows_per_wg = (EPI == SL_SILU_MUL ? 16 : 16 * NG) * NW;
+  const int n_rows = EPI == SL_SILU_MUL ? N / 2 : N;
+  const int n_rb = (n_rows + rows_per_wg - 1) / rows_per_wg;
+  const int blocks = (int)(max_sorted / (16 * MT));
+  if (blocks == 0) return 0;
+  static std::atomic<uint64_t> lds_ok{0};
+  if (ensure_dynamic_lds((const void*)stream_gemm_glds_kernel<T, MT, NG, NW, R, EPI, true>, L::kBytes, lds_ok,
+                         "stream_gemm_glds_grouped"))
+    return 1;
+  hipLaunchKernelGGL((stream_gemm_glds_kernel<T, MT, NG, NW, R, EPI, true>), dim3(n_rb, blocks), dim3(64 * NW), L::kBytes, st,
+                     c, (float*)nullptr, a, w, grp.num_valid, N, K, lda, ldc, K / 128, 0, grp);
+  return launch_status("stream_gemm_glds_grouped");
 }
 
 }  // namespace semipd
@@ -440,6 +492,39 @@ int semipd_stream_linear_f32(float* out, const void* x, const void* weight, int6
   else if (mt == 2) { if (deep) { SL_GO(2, 4) } else { SL_GO(2, 3) } }
   else if (mt == 3) { SL_GO(3, 3) } else { SL_GO(4, 3) }
 #undef SL_GO
+  return rc;
+}
+
+/* invoke_fused_moe_kernel (fused_moe.py:501-612) for DECODE-sized calls with the LDS-DMA streaming kernel: every expert's
+ * weights are read once, by row-shaped LDS-DMA (a CU sustains ~36-41 GB/s of those against ~23 GB/s of the register-
+ * fragment loads of semipd_moe_grouped_gemm's streaming kernel: what counts on a partial CU share).  sorted_token_ids /
+ * expert_ids from moe_align_block_size with block size block_m in {16, 32, 48, 64} (a decode batch of T tokens routes
+ * at most T rows to one expert, so block_m = 16 ceil(T / 16) never splits an expert); max_sorted = entries of
+ * sorted_token_ids, a multiple of block_m.  c[id, :] = a[id / top_k_div, :] @ w[expert]^T for id < num_valid, times
+ * topk_weights[id] when mul_routed_weight; fuse_silu_mul: w[e] = merged [gate; up] and c = SiLU(gate) * up. */
+int semipd_moe_stream_gemm(void* c, const void* a, const void* w, const float* topk_weights, const int32_t* sorted_token_ids,
+                           const int32_t* expert_ids, const int32_t* num_tokens_post_pad, int64_t num_valid, int64_t n,
+                           int64_t k, int64_t max_sorted, int top_k_div, int mul_routed_weight, int fuse_silu_mul, int block_m,
+                           int dtype, void* stream) {
+  SEMIPD_CHECK_ARG(num_valid >= 0 && n > 0 && k > 0 && max_sorted >= 0 && top_k_div > 0, SEMIPD_EINVAL,
+                   "moe_stream_gemm: bad sizes");
+  if (num_valid == 0 || max_sorted == 0) return 0;
+  SEMIPD_CHECK_ARG(c && a && w && sorted_token_ids && expert_ids && num_tokens_post_pad, SEMIPD_EINVAL,
+                   "moe_stream_gemm: null pointer");
+  SEMIPD_CHECK_ARG(!mul_routed_weight || topk_weights, SEMIPD_EINVAL, "moe_stream_gemm: topk_weights required");
+  const int64_t n_out = fuse_silu_mul ? n / 2 : n;
+  SEMIPD_CHECK_ARG((block_m == 16 || block_m == 32 || block_m == 48 || block_m == 64) && max_sorted % block_m == 0 &&
+                       k % 128 == 0 && n_out % 16 == 0 && (!fuse_silu_mul || n % 2 == 0) && aligned16(a) && aligned16(w) &&
+                       (reinterpret_cast<uintptr_t>(c) & 7u) == 0 && num_valid < (1 << 30) && n < (1 << 30) && k < (1 << 30),
+                   SEMIPD_ESHAPE, "moe_stream_gemm: block_m in {16, 32, 48, 64}, k %% 128, output width %% 16 required");
+  SgGroup grp{sorted_token_ids, expert_ids, num_tokens_post_pad, topk_weights, (int)num_valid, top_k_div, mul_routed_weight};
+  hipStream_t st = as_stream(stream);
+  int rc = 0;
+#define SGG(MTV) \
+  if (fuse_silu_mul) { SEMIPD_DISPATCH_HALF(dtype, T, rc = (sg_launch_grouped<T, MTV, SL_SILU_MUL>((T*)c, (const T*)a, (const T*)w, grp, max_sorted, (int)n, (int)k, k, n_out, st))); } \
+  else { SEMIPD_DISPATCH_HALF(dtype, T, rc = (sg_launch_grouped<T, MTV, SL_PLAIN>((T*)c, (const T*)a, (const T*)w, grp, max_sorted, (int)n, (int)k, k, n_out, st))); }
+  if (block_m == 16) { SGG(1) } else if (block_m == 32) { SGG(2) } else if (block_m == 48) { SGG(3) } else { SGG(4) }
+#undef SGG
   return rc;
 }
 

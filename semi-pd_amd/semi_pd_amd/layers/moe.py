@@ -54,6 +54,9 @@ MOE_TALL_MIN_ROWS = int(os.environ.get("SEMIPD_MOE_TALL_MIN_ROWS", "12288"))
 MOE_TALL_MIN_ROWS_PER_EXPERT = int(os.environ.get("SEMIPD_MOE_TALL_MIN_ROWS_PER_EXPERT", "192"))
 
 
+MOE_STREAM_DECODE = os.environ.get("SEMIPD_MOE_STREAM_DECODE", "1") != "0"   # A/B knob: 0 = the register-fragment kernel
+
+
 def _local_ids(topk_ids: torch.Tensor, expert_offset: int) -> torch.Tensor:
     """Expert-parallel ranks hold experts [offset, offset + E_local): ids are shifted so that the local ones land
     in [0, E_local); the others fall outside and moe_align_block_size drops them (their rows of the output stay
@@ -78,13 +81,24 @@ def fused_experts(hidden_states: torch.Tensor, w1: torch.Tensor, w2: torch.Tenso
     # pays from a few hundred rows per expert up
     tall = (numel >= MOE_TALL_MIN_ROWS and numel >= MOE_TALL_MIN_ROWS_PER_EXPERT * E
             and ops.moe_gemm_tall_is_supported(hidden_states, w1, True) and w2.shape[2] % 64 == 0 and K % 16 == 0)
-    block_m = ops.MOE_TALL_BLOCK_M if tall else (MOE_BLOCK_M if numel <= 2048 else 2 * MOE_BLOCK_M)
+    # decode batches (at most 64 tokens): blocks of 16 ceil(T / 16) rows -- a token routes to an expert at most once, so no
+    # expert needs more -- and the grouped LDS-DMA streaming kernel (csrc/stream_linear.hip), SiLU * mul in GEMM1's epilogue
+    small = (MOE_STREAM_DECODE and T <= 64 and ops.moe_stream_gemm_is_supported(hidden_states, w1, True)
+             and w2.shape[2] % 128 == 0 and K % 16 == 0)
+    block_m = ops.MOE_TALL_BLOCK_M if tall else (16 * -(-T // 16) if small else
+                                                 (MOE_BLOCK_M if numel <= 2048 else 2 * MOE_BLOCK_M))
     max_sorted = -(-(numel + E * (block_m - 1)) // block_m) * block_m
     sorted_ids = torch.empty(max_sorted, dtype=torch.int32, device=dev)
     expert_ids = torch.empty((max_sorted + block_m - 1) // block_m, dtype=torch.int32, device=dev)
     num_post_pad = torch.empty(1, dtype=torch.int32, device=dev)
     cumsum = torch.empty(E + 1, dtype=torch.int32, device=dev)
     ops.moe_align_block_size(topk_ids, E, block_m, sorted_ids, expert_ids, num_post_pad, None, cumsum)
+    if small:
+        c2 = torch.empty((numel, N2 // 2), dtype=dt, device=dev)
+        ops.moe_stream_gemm(hidden_states, w1, c2, None, sorted_ids, expert_ids, num_post_pad, numel, topk, False, block_m, True)
+        c3 = (torch.zeros if partial_experts else torch.empty)((numel, K), dtype=dt, device=dev)
+        ops.moe_stream_gemm(c2, w2, c3, topk_weights.reshape(-1), sorted_ids, expert_ids, num_post_pad, numel, 1, True, block_m)
+        return ops.moe_sum(c3.view(T, topk, K))
     if tall:
         c2 = torch.empty((numel, N2 // 2), dtype=dt, device=dev)
         ops.moe_gemm_tall(hidden_states, w1, c2, None, sorted_ids, expert_ids, num_post_pad, numel, topk, False, True)

@@ -766,6 +766,36 @@ def moe_grouped_gemm_silu(a: torch.Tensor, w: torch.Tensor, sorted_token_ids: to
     return c
 
 
+def moe_stream_gemm_is_supported(a: torch.Tensor, w: torch.Tensor, fuse_silu_mul: bool) -> bool:
+    E, N, K = w.shape
+    n_out = N // 2 if fuse_silu_mul else N
+    return (a.dtype == w.dtype and a.dtype in (torch.bfloat16, torch.float16) and a.shape[-1] == K and a.is_contiguous()
+            and w.is_contiguous() and K % 128 == 0 and n_out % 16 == 0 and (not fuse_silu_mul or N % 2 == 0))
+
+
+def moe_stream_gemm(a: torch.Tensor, w: torch.Tensor, c: torch.Tensor, topk_weights: Optional[torch.Tensor],
+                    sorted_token_ids: torch.Tensor, expert_ids: torch.Tensor, num_tokens_post_pad: torch.Tensor,
+                    num_valid: int, top_k_div: int, mul_routed_weight: bool, block_m: int,
+                    fuse_silu_mul: bool = False) -> None:
+    """invoke_fused_moe_kernel (fused_moe.py:501-612) for decode-sized calls with the LDS-DMA streaming kernel (grouped
+    form of csrc/stream_linear.hip): sorted_token_ids / expert_ids from moe_align_block_size with block size block_m
+    (16, 32, 48 or 64).  c[id] = a[id // top_k_div] @ w[expert].T (SiLU(gate) * up of it with fuse_silu_mul)."""
+    E, N, K = w.shape
+    n_out = N // 2 if fuse_silu_mul else N
+    if not moe_stream_gemm_is_supported(a, w, fuse_silu_mul) or c.shape[-1] != n_out or not c.is_contiguous() \
+            or block_m not in (16, 32, 48, 64) or sorted_token_ids.numel() % block_m:
+        raise RuntimeError("moe_stream_gemm: shape / contiguity / block-size mismatch")
+    if sorted_token_ids.dtype != torch.int32 or expert_ids.dtype != torch.int32 or num_tokens_post_pad.dtype != torch.int32:
+        raise RuntimeError("moe_stream_gemm: int32 routing tensors expected")
+    if mul_routed_weight and (topk_weights is None or topk_weights.dtype != torch.float32):
+        raise RuntimeError("moe_stream_gemm: fp32 topk_weights required")
+    check(_lib.load().semipd_moe_stream_gemm(ptr(c), ptr(a), ptr(w), ptr(topk_weights), ptr(sorted_token_ids),
+                                             ptr(expert_ids), ptr(num_tokens_post_pad), num_valid, N, K,
+                                             sorted_token_ids.numel(), top_k_div, int(mul_routed_weight),
+                                             int(fuse_silu_mul), int(block_m), dtype_code(a.dtype),
+                                             current_stream(a.device)), "moe_stream_gemm")
+
+
 MOE_TALL_BLOCK_M = 256
 
 

@@ -1148,3 +1148,55 @@ def test_fused_experts_takes_the_tall_kernel_for_prefill_sized_calls(ops, device
     want = O.fused_moe(x.float().cpu(), w1.float().cpu(), w2.float().cpu(), tw.cpu(), ti.cpu().long())
     torch.testing.assert_close(tall.float().cpu(), want.float(), rtol=3e-2, atol=3e-2)
     torch.testing.assert_close(tall.float(), base.float(), rtol=3e-2, atol=3e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("T,E,topk,K,N", [(1, 8, 2, 256, 128), (17, 16, 6, 2048, 1408), (33, 64, 6, 2048, 1408), (64, 8, 2, 384, 128),
+                                          (48, 4, 1, 128, 64)])
+def test_moe_stream_gemm_matches_fp32_per_expert(ops, device, dtype, T, E, topk, K, N):
+    """The grouped form of the LDS-DMA streaming kernel (decode-sized invoke_fused_moe_kernel, fused_moe.py:501-612) on
+    blocks of 16 ceil(T / 16) rows: every routed entry against fp32 products of its expert; GEMM1 with the SiLU * mul
+    epilogue equals silu_and_mul of the plain output bit for bit; GEMM2 times the routed weight; padding entries write
+    nothing; and layers.moe.fused_experts (which takes this path up to 64 tokens) agrees with the path it replaces."""
+    g = torch.Generator(device="cpu").manual_seed(T * 3 + E + K)
+    a = torch.randn(T, K, generator=g).to(dtype).to(device)
+    w1 = (torch.randn(E, 2 * N, K, generator=g) * K ** -0.5).to(dtype).to(device)
+    w2 = (torch.randn(E, K, N, generator=g) * N ** -0.5).to(dtype).to(device)
+    tw, ti = ops.topk_softmax(torch.randn(T, E, generator=g).to(device), topk, True)
+    numel, bm = T * topk, 16 * -(-T // 16)
+    max_sorted = -(-(numel + E * (bm - 1)) // bm) * bm
+    sorted_ids = torch.empty(max_sorted, dtype=torch.int32, device=device)
+    expert_ids = torch.empty(max_sorted // bm, dtype=torch.int32, device=device)
+    npp = torch.empty(1, dtype=torch.int32, device=device)
+    ops.moe_align_block_size(ti, E, bm, sorted_ids, expert_ids, npp, None, torch.empty(E + 1, dtype=torch.int32, device=device))
+    tol = 2e-2 if dtype == torch.bfloat16 else 3e-3
+    flat_e = ti.reshape(-1).long()
+    rows = torch.arange(numel, device=device) // topk
+
+    def per_expert(x_rows, w, scale=None):
+        want = torch.empty(numel, w.shape[1], dtype=torch.float32, device=device)
+        for e in range(E):
+            sel = (flat_e == e).nonzero().squeeze(1)
+            if sel.numel():
+                want[sel] = x_rows[sel].float() @ w[e].float().t()
+        return want if scale is None else want * scale
+
+    if N * 2 % 16 == 0 and K % 128 == 0:
+        c1 = torch.full((numel, 2 * N), 77.0, dtype=dtype, device=device)
+        ops.moe_stream_gemm(a, w1, c1, None, sorted_ids, expert_ids, npp, numel, topk, False, bm, False)
+        torch.testing.assert_close(c1.float(), per_expert(a[rows], w1), rtol=tol, atol=tol)
+        c2 = torch.full((numel, N), 77.0, dtype=dtype, device=device)
+        ops.moe_stream_gemm(a, w1, c2, None, sorted_ids, expert_ids, npp, numel, topk, False, bm, True)
+        assert torch.equal(c2, ops.silu_and_mul(c1))
+        if N % 128 == 0:
+            c3 = torch.full((numel, K), 77.0, dtype=dtype, device=device)
+            ops.moe_stream_gemm(c2, w2, c3, tw.reshape(-1), sorted_ids, expert_ids, npp, numel, 1, True, bm, False)
+            torch.testing.assert_close(c3.float(), per_expert(c2, w2, tw.reshape(-1, 1).float()), rtol=tol, atol=tol)
+    from semi_pd_amd.layers import moe as M
+    new = M.fused_experts(a, w1, w2, tw, ti)
+    old_flag, M.MOE_STREAM_DECODE = M.MOE_STREAM_DECODE, False
+    try:
+        old = M.fused_experts(a, w1, w2, tw, ti)
+    finally:
+        M.MOE_STREAM_DECODE = old_flag
+    torch.testing.assert_close(new.float(), old.float(), rtol=3e-2, atol=3e-2)
