@@ -17,7 +17,10 @@ from oracle.model import OracleLlama, OracleOPT
 
 pytestmark = pytest.mark.gpu
 
-MARGIN = 4e-2  # logit tie margin (bf16 engine vs fp32 oracle)
+# logit tie margin (bf16 engine vs fp32 oracle): the reference's own bar for generated-token logprobs
+# (test/srt/models/test_generation_models.py:43-45, 5e-2).  Two engines may take different kernels for the same layer
+# (streaming / tiled / library GEMM by batch size, K split by CU share), so a flip needs the full bar, not a tighter one.
+MARGIN = 5e-2
 
 
 def tiny_llama():

@@ -95,6 +95,16 @@ elif which == "stream":
     for i in range(12):
         ops.stream_linear(x, ws[i % 6], fuse_silu_mul=True)
     print("algorithmic_bytes_per_launch", N * K * 2 + M * K * 2 + M * (N // 2) * 2)
+elif which in ("gemm_tall256", "gemm_tall4k"):
+    # the tiled ping-pong GEMM (csrc/gemm8p.hip): gate_up + SiLU*mul of Llama-3-8B at 256 rows (weight stream, 6 weight
+    # copies in rotation) or at 4096 rows (matrix bound)
+    M = 256 if which == "gemm_tall256" else 4096
+    N, K = 28672, 4096
+    ws = [torch.randn(N, K, device=dev, dtype=torch.bfloat16) * 0.02 for _ in range(6)]
+    x = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
+    for i in range(12):
+        ops.gemm_tall(x, ws[i % 6], fuse_silu_mul=True)
+    print("algorithmic_bytes_per_launch", N * K * 2 + M * K * 2 + M * (N // 2) * 2, "flop_per_launch", 2.0 * M * N * K)
 elif which == "fp8mm":
     # decode-sized block-fp8 linear on a DeepSeek-V3 shape: the fp8 weights (176 MB) are read once
     M, N, K = 32, 24576, 7168
