@@ -63,6 +63,13 @@ def model_config(name: str):
             rope_scaling={"type": "yarn", "factor": 40, "beta_fast": 32, "beta_slow": 1, "mscale": 1.0,
                           "mscale_all_dim": 1.0, "original_max_position_embeddings": 4096},
             architectures=("DeepseekV3ForCausalLM",))
+    if name == "llama3-70b-tp8-rank":
+        # what ONE rank of BASELINE config 4 (Llama-3-70B, TP = 8) computes, without the collectives: 80 layers of hidden
+        # 8192 with 1/8 of the heads (8 q, 1 kv, head size 128), 1/8 of the MLP columns (3584) and 1/8 of the vocabulary:
+        # 17.4 GB of weights per decode step = 2.2 ms at 8 TB/s.  A one-GPU measurement of the per-rank kernel shapes and
+        # launch count (9 per layer x 80), not a claim about config 4
+        return LlamaConfig(vocab_size=16032, hidden_size=8192, intermediate_size=3584, num_hidden_layers=80,
+                           num_attention_heads=8, num_key_value_heads=1, head_dim=128, max_position_embeddings=8192)
     if name == "llama-tiny":
         return LlamaConfig(vocab_size=32000, hidden_size=1024, intermediate_size=2816, num_hidden_layers=4,
                            num_attention_heads=8, num_key_value_heads=2, max_position_embeddings=8192)
@@ -239,8 +246,8 @@ def main():
     # `--prefill-cu 50 --decode-cu 50` is config 2's split as written, `--prefill-cu 100 --decode-cu 100` the unmasked
     # round-2 default.  The literal 50 / 50 split is measured in the same invocation by a second engine (one warm-up +
     # one timed wave, "static_split_50_50"; --no-static-split-wave skips it).
-    ap.add_argument("--prefill-cu", type=int, default=DEFAULT_PREFILL_CU)
-    ap.add_argument("--decode-cu", type=int, default=DEFAULT_DECODE_CU)
+    ap.add_argument("--prefill-cu", type=int, default=None, help=f"default {DEFAULT_PREFILL_CU} (MoE models: 50)")
+    ap.add_argument("--decode-cu", type=int, default=None, help=f"default {DEFAULT_DECODE_CU} (MoE models: 50)")
     ap.add_argument("--no-static-split-wave", action="store_true",
                     help="N = 1 Semi-PD default run: do not start the second engine with BASELINE config 2's literal 50 / 50 split")
     ap.add_argument("--no-prefill-gemm-tuning", action="store_true",
@@ -283,6 +290,12 @@ def main():
     ap.add_argument("--sweep-num-requests", type=int, default=None, help="requests per sweep point (default: --num-requests)")
     args = ap.parse_args()
 
+    if args.prefill_cu is None or args.decode_cu is None:
+        # a decode step of the MoE models reads ~29 GB (every expert is touched at batch >= 20): their decode instance
+        # needs the bigger share (DeepSeek-V2-Lite: TBT p50 17.0 ms at 38 %, 13.6 ms at 50 %)
+        moe = args.model.startswith("deepseek")
+        args.prefill_cu = args.prefill_cu if args.prefill_cu is not None else (50 if moe else DEFAULT_PREFILL_CU)
+        args.decode_cu = args.decode_cu if args.decode_cu is not None else (50 if moe else DEFAULT_DECODE_CU)
     if args.rate_sweep is None:
         default_workload = (args.gpus == 1 and args.model == "llama3-8b" and args.mode == "semi-pd"
                             and args.input_len == 1024 and args.output_len == 128 and args.request_rate == 32.0)

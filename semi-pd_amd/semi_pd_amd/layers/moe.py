@@ -55,6 +55,7 @@ MOE_TALL_MIN_ROWS_PER_EXPERT = int(os.environ.get("SEMIPD_MOE_TALL_MIN_ROWS_PER_
 
 
 MOE_STREAM_DECODE = os.environ.get("SEMIPD_MOE_STREAM_DECODE", "1") != "0"   # A/B knob: 0 = the register-fragment kernel
+MOE_STREAM_MAX_TOKENS = int(os.environ.get("SEMIPD_MOE_STREAM_MAX_TOKENS", "320"))
 
 
 def _local_ids(topk_ids: torch.Tensor, expert_offset: int) -> torch.Tensor:
@@ -81,11 +82,12 @@ def fused_experts(hidden_states: torch.Tensor, w1: torch.Tensor, w2: torch.Tenso
     # pays from a few hundred rows per expert up
     tall = (numel >= MOE_TALL_MIN_ROWS and numel >= MOE_TALL_MIN_ROWS_PER_EXPERT * E
             and ops.moe_gemm_tall_is_supported(hidden_states, w1, True) and w2.shape[2] % 64 == 0 and K % 16 == 0)
-    # decode batches (at most 64 tokens): blocks of 16 ceil(T / 16) rows -- a token routes to an expert at most once, so no
-    # expert needs more -- and the grouped LDS-DMA streaming kernel (csrc/stream_linear.hip), SiLU * mul in GEMM1's epilogue
-    small = (MOE_STREAM_DECODE and T <= 64 and ops.moe_stream_gemm_is_supported(hidden_states, w1, True)
+    # decode batches: blocks of 16 ceil(T / 16) rows up to 64 tokens -- a token routes to an expert at most once, so no
+    # expert needs more -- blocks of 64 above (an expert with more rows takes several), and the grouped LDS-DMA streaming
+    # kernel (csrc/stream_linear.hip), SiLU * mul in GEMM1's epilogue
+    small = (MOE_STREAM_DECODE and T <= MOE_STREAM_MAX_TOKENS and ops.moe_stream_gemm_is_supported(hidden_states, w1, True)
              and w2.shape[2] % 128 == 0 and K % 16 == 0)
-    block_m = ops.MOE_TALL_BLOCK_M if tall else (16 * -(-T // 16) if small else
+    block_m = ops.MOE_TALL_BLOCK_M if tall else (min(64, 16 * -(-T // 16)) if small else
                                                  (MOE_BLOCK_M if numel <= 2048 else 2 * MOE_BLOCK_M))
     max_sorted = -(-(numel + E * (block_m - 1)) // block_m) * block_m
     sorted_ids = torch.empty(max_sorted, dtype=torch.int32, device=dev)

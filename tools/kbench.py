@@ -172,7 +172,7 @@ def bench_moe():
     E, k, K, N = 64, 6, 2048, 1408
     w1 = torch.randn(E, 2 * N, K, device=dev, dtype=torch.bfloat16) * 0.02
     w2 = torch.randn(E, K, N, device=dev, dtype=torch.bfloat16) * 0.02
-    for T in (1, 32, 256, 512, 1024, 2048, 4096, 8192):
+    for T in [int(v) for v in os.environ.get("KBENCH_MOE_TS", "1,32,256,512,1024,2048,4096,8192").split(",")]:
         x = torch.randn(T, K, device=dev, dtype=torch.bfloat16)
         tw, ti = ops.topk_softmax(torch.randn(T, E, device=dev), k, True)
         t = timeit(lambda: fused_experts(x, w1, w2, tw, ti), iters=10)
