@@ -258,13 +258,14 @@ int semipd_moe_stream_gemm(void* c, const void* a, const void* w, const float* t
 
 /* The grouped form of the tiled ping-pong GEMM for the fused-MoE expert GEMMs of prefill-sized calls
  * (invoke_fused_moe_kernel, python/sglang/srt/layers/moe/fused_moe_triton/fused_moe.py:501-612; kernel :54-273):
- * sorted_token_ids / expert_ids from semipd_moe_align_block_size with block size 256 (one expert per 256-entry tile;
- * max_sorted = entries of sorted_token_ids, a multiple of 256).  c[id, :] = a[id / top_k_div, :] @ w[expert]^T for every
+ * sorted_token_ids / expert_ids from semipd_moe_align_block_size with block size block_m = 256 (256 x 256 tiles) or 128
+ * (128 x 512 tiles): one expert per tile; max_sorted = entries of sorted_token_ids, a multiple of block_m.  c[id, :] = a[id / top_k_div, :] @ w[expert]^T for every
  * routed entry id < num_valid, times topk_weights[id] when mul_routed_weight; fuse_silu_mul: w[e] = merged [gate; up]
  * ([n, k], output width n / 2) and c = SiLU(gate) * up of the products rounded to dtype (the bits of the unfused pair). */
 int semipd_moe_gemm_tall(void* c, const void* a, const void* w, const float* topk_weights, const int32_t* sorted_token_ids,
                          const int32_t* expert_ids, const int32_t* num_tokens_post_pad, int64_t num_valid, int64_t n, int64_t k,
-                         int64_t max_sorted, int top_k_div, int mul_routed_weight, int fuse_silu_mul, int dtype, void* stream);
+                         int64_t max_sorted, int top_k_div, int mul_routed_weight, int fuse_silu_mul, int block_m, int dtype,
+                         void* stream);
 
 /* ---- prefill-sized dense layers on a CU share (csrc/dense_gemm.cpp) ------------------------------------------------
  * out[rows, n] = x[rows, k] @ weight[n, k]^T (+ bias[n]) through hipBLASLt with the solution that MEASURED fastest on

@@ -432,17 +432,17 @@ static int g8_launch(T* out, float* planes, size_t planes_bytes, const T* x, con
   return g8_launch_geo<T, EPI, 128>(out, planes, planes_bytes, x, w, M, N, K, ldx, ldo, force_ks, st);
 }
 
-template <typename T, int EPI>
+template <typename T, int EPI, int XH>
 static int g8_launch_grouped(T* c, const T* a, const T* w, const G8Group& grp, int64_t max_sorted, int N, int K, int64_t lda,
                              int64_t ldc, hipStream_t st) {
-  using G = G8Geo<128>;
+  using G = G8Geo<XH>;
   const int n_cols = EPI == G8_SILU_MUL ? N / 2 : N;
   const int cols_per_tile = EPI == G8_SILU_MUL ? G::WH : G::BN;
   const int tiles_n = (n_cols + cols_per_tile - 1) / cols_per_tile, tiles_m = (int)(max_sorted / G::BM);
   if (tiles_m == 0) return 0;
   static std::atomic<uint64_t> lds_ok{0};
-  if (ensure_dynamic_lds((const void*)gemm8p_kernel<T, EPI, false, 128, true>, G::kLds, lds_ok, "gemm8p_grouped")) return 1;
-  hipLaunchKernelGGL((gemm8p_kernel<T, EPI, false, 128, true>), dim3(tiles_m * tiles_n, 1), dim3(512), G::kLds, st, c,
+  if (ensure_dynamic_lds((const void*)gemm8p_kernel<T, EPI, false, XH, true>, G::kLds, lds_ok, "gemm8p_grouped")) return 1;
+  hipLaunchKernelGGL((gemm8p_kernel<T, EPI, false, XH, true>), dim3(tiles_m * tiles_n, 1), dim3(512), G::kLds, st, c,
                      (float*)nullptr, a, w, grp.num_valid, N, K, lda, ldc, K / 64, grp);
   return launch_status("gemm8p_grouped");
 }
@@ -489,32 +489,34 @@ int semipd_gemm_tall(void* out, const void* x, const void* weight, void* workspa
 }
 
 /* invoke_fused_moe_kernel (fused_moe.py:501-612) for prefill-sized calls with the tiled ping-pong GEMM: sorted_token_ids /
- * expert_ids from moe_align_block_size with block size 256 (one expert per 256-entry tile; sorted_token_ids must hold
- * max_sorted entries, a multiple of 256).  c[id, :] = a[id / top_k_div, :] @ w[expert]^T for every routed entry id <
+ * expert_ids from moe_align_block_size with block size block_m = 256 (256 x 256 tiles) or 128 (128 x 512 tiles): one
+ * expert per tile; sorted_token_ids must hold max_sorted entries, a multiple of block_m.  c[id, :] = a[id / top_k_div, :] @ w[expert]^T for every routed entry id <
  * num_valid, times topk_weights[id] when mul_routed_weight; fuse_silu_mul: w[e] = merged [gate; up] ([n, k], n = 2 x
  * output width) and c = SiLU(gate) * up of the products rounded to dtype. */
 int semipd_moe_gemm_tall(void* c, const void* a, const void* w, const float* topk_weights, const int32_t* sorted_token_ids,
                          const int32_t* expert_ids, const int32_t* num_tokens_post_pad, int64_t num_valid, int64_t n, int64_t k,
-                         int64_t max_sorted, int top_k_div, int mul_routed_weight, int fuse_silu_mul, int dtype, void* stream) {
+                         int64_t max_sorted, int top_k_div, int mul_routed_weight, int fuse_silu_mul, int block_m, int dtype,
+                         void* stream) {
   SEMIPD_CHECK_ARG(num_valid >= 0 && n > 0 && k > 0 && max_sorted >= 0 && top_k_div > 0, SEMIPD_EINVAL, "moe_gemm_tall: bad sizes");
   if (num_valid == 0 || max_sorted == 0) return 0;
   SEMIPD_CHECK_ARG(c && a && w && sorted_token_ids && expert_ids && num_tokens_post_pad, SEMIPD_EINVAL,
                    "moe_gemm_tall: null pointer");
   SEMIPD_CHECK_ARG(!mul_routed_weight || topk_weights, SEMIPD_EINVAL, "moe_gemm_tall: topk_weights required");
   const int64_t n_out = fuse_silu_mul ? n / 2 : n;
-  SEMIPD_CHECK_ARG(max_sorted % 256 == 0 && k % 64 == 0 && n_out % 16 == 0 && (!fuse_silu_mul || n % 2 == 0) && aligned16(a) &&
+  SEMIPD_CHECK_ARG((block_m == 256 || block_m == 128) && max_sorted % block_m == 0 && k % 64 == 0 && n_out % 16 == 0 && (!fuse_silu_mul || n % 2 == 0) && aligned16(a) &&
                        aligned16(w) && (reinterpret_cast<uintptr_t>(c) & 7u) == 0 && num_valid < (1 << 30) && n < (1 << 30) &&
                        k < (1 << 30),
-                   SEMIPD_ESHAPE, "moe_gemm_tall: block size 256, k %% 64, output width %% 16 required");
+                   SEMIPD_ESHAPE, "moe_gemm_tall: block size 256 or 128, k %% 64, output width %% 16 required");
   G8Group grp{sorted_token_ids, expert_ids, num_tokens_post_pad, topk_weights, (int)num_valid, top_k_div, mul_routed_weight};
   int rc = 0;
-  if (fuse_silu_mul) {
-    SEMIPD_DISPATCH_HALF(dtype, T, rc = (g8_launch_grouped<T, G8_SILU_MUL>((T*)c, (const T*)a, (const T*)w, grp, max_sorted, (int)n,
-                                                                           (int)k, k, n_out, as_stream(stream))));
+#define G8G(EPIV, XHV) \
+  SEMIPD_DISPATCH_HALF(dtype, T, rc = (g8_launch_grouped<T, EPIV, XHV>((T*)c, (const T*)a, (const T*)w, grp, max_sorted, (int)n, (int)k, k, n_out, as_stream(stream))))
+  if (block_m == 256) {
+    if (fuse_silu_mul) { G8G(G8_SILU_MUL, 128); } else { G8G(G8_PLAIN, 128); }
   } else {
-    SEMIPD_DISPATCH_HALF(dtype, T, rc = (g8_launch_grouped<T, G8_PLAIN>((T*)c, (const T*)a, (const T*)w, grp, max_sorted, (int)n,
-                                                                        (int)k, k, n_out, as_stream(stream))));
+    if (fuse_silu_mul) { G8G(G8_SILU_MUL, 64); } else { G8G(G8_PLAIN, 64); }
   }
+#undef G8G
   return rc;
 }
 

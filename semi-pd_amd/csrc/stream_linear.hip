@@ -329,7 +329,7 @@ static int sg_pick_ksplit(int n_rb, int nkb, int M, int N, bool extra_reduce_lau
     if (eff != ksp) continue;
     const int rounds = (n_rb * eff + cus - 1) / cus;
     float cost = rounds * (per * t_block + t_round);
-    if (eff > 1) cost += eff * plane_us + (extra_reduce_launch ? 2.5f : 0.f);
+    if (eff > 1) cost += eff * plane_us + (extra_reduce_launch ? 8.f : 0.f);   // a reduction launch: ~5 us + its ramp
     if (cost < best_cost - 1e-3f) best_cost = cost, best = eff;
   }
   return best;

@@ -796,7 +796,9 @@ def moe_stream_gemm(a: torch.Tensor, w: torch.Tensor, c: torch.Tensor, topk_weig
                                              current_stream(a.device)), "moe_stream_gemm")
 
 
-MOE_TALL_BLOCK_M = 256
+import os as _os
+
+MOE_TALL_BLOCK_M = int(_os.environ.get("SEMIPD_MOE_TALL_BLOCK_M", "256"))   # 256: 256 x 256 tiles; 128: 128 x 512 tiles
 
 
 def moe_gemm_tall_is_supported(a: torch.Tensor, w: torch.Tensor, fuse_silu_mul: bool) -> bool:
@@ -815,7 +817,7 @@ def moe_gemm_tall(a: torch.Tensor, w: torch.Tensor, c: torch.Tensor, topk_weight
     E, N, K = w.shape
     n_out = N // 2 if fuse_silu_mul else N
     if not moe_gemm_tall_is_supported(a, w, fuse_silu_mul) or c.shape[-1] != n_out or not c.is_contiguous() \
-            or sorted_token_ids.numel() % MOE_TALL_BLOCK_M:
+            or MOE_TALL_BLOCK_M not in (128, 256) or sorted_token_ids.numel() % MOE_TALL_BLOCK_M:
         raise RuntimeError("moe_gemm_tall: shape / contiguity / block-size mismatch")
     if sorted_token_ids.dtype != torch.int32 or expert_ids.dtype != torch.int32 or num_tokens_post_pad.dtype != torch.int32:
         raise RuntimeError("moe_gemm_tall: int32 routing tensors expected")
@@ -823,8 +825,8 @@ def moe_gemm_tall(a: torch.Tensor, w: torch.Tensor, c: torch.Tensor, topk_weight
         raise RuntimeError("moe_gemm_tall: fp32 topk_weights required")
     check(_lib.load().semipd_moe_gemm_tall(ptr(c), ptr(a), ptr(w), ptr(topk_weights), ptr(sorted_token_ids), ptr(expert_ids),
                                            ptr(num_tokens_post_pad), num_valid, N, K, sorted_token_ids.numel(), top_k_div,
-                                           int(mul_routed_weight), int(fuse_silu_mul), dtype_code(a.dtype),
-                                           current_stream(a.device)), "moe_gemm_tall")
+                                           int(mul_routed_weight), int(fuse_silu_mul), int(MOE_TALL_BLOCK_M),
+                                           dtype_code(a.dtype), current_stream(a.device)), "moe_gemm_tall")
 
 
 def moe_sum(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
