@@ -366,7 +366,7 @@ class ModelRunner:
             ipc_info.req_to_token_handle, {"numel": ri["numel"], "dtype": ri["dtype"], "shape": ri["shape"]})
 
     # ------------------------------------------------------------------------------------ library GEMM selection
-    def tune_dense_gemms(self, rows=(1024, 2048, 128, 256, 512, 4096, 8192), num_full_search: int = 2) -> str:
+    def tune_dense_gemms(self, rows=(1024, 2048, 128, 256, 512, 1536, 3072, 4096, 6144, 8192), num_full_search: int = 2) -> str:
         """Time hipBLASLt's solutions for every dense weight shape of the model ON THE COMPUTE UNITS THIS PROCESS OWNS and
         route prefill-sized batches of those layers to the measured winners (csrc/dense_gemm.cpp; ops.dense_gemm).
         Under an HSA_CU_MASK the library's own pick -- persistent stream-K grids sized for the whole device -- runs as
