@@ -267,7 +267,7 @@ int semipd_moe_gemm_tall(void* c, const void* a, const void* w, const float* top
                          int64_t max_sorted, int top_k_div, int mul_routed_weight, int fuse_silu_mul, int block_m, int dtype,
                          void* stream);
 
-/* ---- prefill-sized dense layers on a CU share (csrc/dense_gemm.cpp) ------------------------------------------------
+/* ---- prefill-sized dense layers on a CU share (csrc/dense_gemm.hip) ------------------------------------------------
  * out[rows, n] = x[rows, k] @ weight[n, k]^T (+ bias[n]) through hipBLASLt with the solution that MEASURED fastest on
  * the compute units this process owns.  Replaces F.linear in UnquantizedLinearMethod.apply
  * (python/sglang/srt/layers/linear.py:165-172) for batches above the streaming kernel's range: the reference sets the

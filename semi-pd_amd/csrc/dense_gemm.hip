@@ -11,7 +11,9 @@
 // UnquantizedLinearMethod.apply -> F.linear (layers/linear.py:165-172) for batches above the streaming kernel's range;
 // the reference sets its shares at entrypoints/engine.py:583-634 and leaves the GEMMs to cuBLAS.
 //
-// Host code only (no kernels of ours run here): plumbing around a plain library GEMM.
+// Host code around a plain library GEMM; the one kernel here compares a candidate's output with the library's own
+// choice (a solution that is fast and WRONG for a shape must never win: every finalist is checked before it is timed
+// for the table).
 #include <hip/hip_runtime.h>
 #include <hipblaslt/hipblaslt-ext.hpp>
 #include <hipblaslt/hipblaslt.h>
@@ -31,6 +33,28 @@ namespace {
 
 using semipd::set_error;
 
+// max |a - b| and max |b| over n 16-bit elements (bf16 or f16), as float bit patterns through atomicMax (values >= 0)
+template <bool BF16>
+__global__ void dg_maxdiff_kernel(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b, int64_t n,
+                                  unsigned int* __restrict__ out) {
+  float md = 0.f, mr = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float x, y;
+    if (BF16) {
+      x = __uint_as_float((uint32_t)a[i] << 16);
+      y = __uint_as_float((uint32_t)b[i] << 16);
+    } else {
+      x = __half2float(__ushort_as_half(a[i]));
+      y = __half2float(__ushort_as_half(b[i]));
+    }
+    const float d = fabsf(x - y);
+    md = (d == d) ? fmaxf(md, d) : INFINITY;   // NaN anywhere = infinitely wrong
+    mr = fmaxf(mr, fabsf(y));
+  }
+  atomicMax(out, __float_as_uint(md));
+  atomicMax(out + 1, __float_as_uint(mr));
+}
+
 struct Plan {   // one (rows, n, k, dtype, ldx, ldo, bias) problem, ready to launch
   hipblasLtMatmulDesc_t desc = nullptr;
   hipblasLtMatrixLayout_t la = nullptr, lb = nullptr, lc = nullptr;
@@ -44,6 +68,7 @@ struct Tuned {  // winner of one tuning run
   hipblasLtMatmulAlgo_t algo;
   int solution_index;
   float us, us_default;
+  int candidates, rejected;   // solutions timed; fast ones dropped because their result disagreed with the library's choice
 };
 
 struct State {
@@ -177,11 +202,15 @@ int semipd_dense_gemm_tune(int64_t n, int64_t k, const int64_t* rows, int num_ro
   hipStream_t hs = (hipStream_t)stream;
   int64_t max_rows = 0;
   for (int i = 0; i < num_rows; ++i) max_rows = std::max(max_rows, rows[i]);
-  void *x = nullptr, *w = nullptr, *o = nullptr;
-  if (hipMalloc(&x, max_rows * k * 2) || hipMalloc(&w, n * k * 2) || hipMalloc(&o, max_rows * n * 2)) {
+  void *x = nullptr, *w = nullptr, *o = nullptr, *o_ref = nullptr;
+  unsigned int* d_cmp = nullptr;
+  if (hipMalloc(&x, max_rows * k * 2) || hipMalloc(&w, n * k * 2) || hipMalloc(&o, max_rows * n * 2) ||
+      hipMalloc(&o_ref, max_rows * n * 2) || hipMalloc((void**)&d_cmp, 8)) {
     set_error("dense_gemm_tune: scratch allocation failed");
     if (x) (void)hipFree(x);
     if (w) (void)hipFree(w);
+    if (o) (void)hipFree(o);
+    if (o_ref) (void)hipFree(o_ref);
     return 1;
   }
   {  // operands with realistic bit patterns: the clock a GEMM sustains depends on its data
@@ -228,7 +257,31 @@ int semipd_dense_gemm_tune(int64_t n, int64_t k, const int64_t* rows, int num_ro
       }
     }
     const bool have_default = !cand.empty();
-    const float t_default = have_default ? time_algo(s, p, cand[0], w, x, o, 8, hs, e0, e1) : 1e30f;
+    const float t_default = have_default ? time_algo(s, p, cand[0], w, x, o_ref, 8, hs, e0, e1) : 1e30f;   // o_ref = its output
+    // a finalist must reproduce the library's own result on these operands up to the rounding of a different summation
+    // order: max |difference| <= 2 % of max |reference| (garbage, a half-written tile or a NaN is far outside)
+    auto agrees = [&](hipblasLtMatmulAlgo_t& a) -> bool {
+      if (!have_default) return true;
+      float alpha = 1.f, beta = 0.f;
+      (void)hipMemsetAsync(o, 0xff, (size_t)m * n * 2, hs);          // NaN pattern: unwritten elements show up
+      if (hipblasLtMatmul(s.handle, p.desc, &alpha, w, p.la, x, p.lb, &beta, o, p.lc, o, p.lc, &a, s.workspace,
+                          s.workspace_bytes, hs) != HIPBLAS_STATUS_SUCCESS)
+        return false;
+      (void)hipMemsetAsync(d_cmp, 0, 8, hs);
+      if (dtype == SEMIPD_BF16)
+        hipLaunchKernelGGL(dg_maxdiff_kernel<true>, dim3(1024), dim3(256), 0, hs, (const uint16_t*)o, (const uint16_t*)o_ref,
+                           (int64_t)m * n, d_cmp);
+      else
+        hipLaunchKernelGGL(dg_maxdiff_kernel<false>, dim3(1024), dim3(256), 0, hs, (const uint16_t*)o, (const uint16_t*)o_ref,
+                           (int64_t)m * n, d_cmp);
+      unsigned int h[2] = {0, 0};
+      if (hipMemcpyAsync(h, d_cmp, 8, hipMemcpyDeviceToHost, hs) != hipSuccess || hipStreamSynchronize(hs) != hipSuccess)
+        return false;
+      float md, mr;
+      memcpy(&md, &h[0], 4);
+      memcpy(&mr, &h[1], 4);
+      return md <= 0.02f * mr;
+    };
     for (auto& a : pool)
       if (supported(s, p, a)) add(a);
     if (ri < num_full_search) {
@@ -251,19 +304,25 @@ int semipd_dense_gemm_tune(int64_t n, int64_t k, const int64_t* rows, int num_ro
       if (t < 1e29f) timed.push_back({t, (int)i});
     }
     std::sort(timed.begin(), timed.end());
-    // the leaders again, properly
+    // the leaders again, properly -- and only those whose result agrees with the library's own choice
     float best = 1e30f;
     int best_i = -1;
-    for (size_t j = 0; j < std::min<size_t>(timed.size(), 6); ++j) {
-      const float t = time_algo(s, p, cand[timed[j].second], w, x, o, 12, hs, e0, e1);
-      if (t < best) best = t, best_i = timed[j].second;
+    std::vector<int> finalists;
+    int rejected = 0;
+    for (size_t j = 0; j < timed.size() && finalists.size() < 6; ++j) {
+      if (agrees(cand[timed[j].second])) finalists.push_back(timed[j].second);
+      else ++rejected;
+    }
+    for (int ci : finalists) {
+      const float t = time_algo(s, p, cand[ci], w, x, o, 12, hs, e0, e1);
+      if (t < best) best = t, best_i = ci;
     }
     if (ri < num_full_search)   // what a full search found joins the candidates of the other row counts
-      for (size_t j = 0; j < std::min<size_t>(timed.size(), 6); ++j) {
+      for (int ci : finalists) {
         bool known = false;
-        const int idx = hipblaslt_ext::getIndexFromAlgo(cand[timed[j].second]);
+        const int idx = hipblaslt_ext::getIndexFromAlgo(cand[ci]);
         for (auto& a : pool) known = known || hipblaslt_ext::getIndexFromAlgo(a) == idx;
-        if (!known) pool.push_back(cand[timed[j].second]);
+        if (!known) pool.push_back(cand[ci]);
       }
     if (best_i >= 0) {
       Tuned t;
@@ -271,6 +330,8 @@ int semipd_dense_gemm_tune(int64_t n, int64_t k, const int64_t* rows, int num_ro
       t.solution_index = hipblaslt_ext::getIndexFromAlgo(t.algo);
       t.us = best;
       t.us_default = t_default;
+      t.candidates = (int)timed.size();
+      t.rejected = rejected;
       s.tuned[key][m] = t;
     }
     destroy_problem(p);
@@ -280,6 +341,8 @@ int semipd_dense_gemm_tune(int64_t n, int64_t k, const int64_t* rows, int num_ro
   (void)hipFree(x);
   (void)hipFree(w);
   (void)hipFree(o);
+  (void)hipFree(o_ref);
+  (void)hipFree(d_cmp);
   for (auto& kv : s.plans) destroy_problem(kv.second);   // plans made before this tuning may hold other choices
   s.plans.clear();
   return rc;
@@ -350,9 +413,10 @@ size_t semipd_dense_gemm_report(char* buf, size_t len) {
   char line[256];
   for (auto& kv : s.tuned)
     for (auto& rv : kv.second) {
-      snprintf(line, sizeof(line), "dtype=%d n=%lld k=%lld rows=%lld solution=%d us=%.1f library_choice_us=%.1f\n",
+      snprintf(line, sizeof(line),
+               "dtype=%d n=%lld k=%lld rows=%lld solution=%d us=%.1f library_choice_us=%.1f candidates=%d wrong_results_rejected=%d\n",
                std::get<0>(kv.first), (long long)std::get<1>(kv.first), (long long)std::get<2>(kv.first), (long long)rv.first,
-               rv.second.solution_index, rv.second.us, rv.second.us_default);
+               rv.second.solution_index, rv.second.us, rv.second.us_default, rv.second.candidates, rv.second.rejected);
       out += line;
     }
   if (buf && len) {

@@ -343,7 +343,9 @@ static int sg_launch(T* out, float* planes, size_t planes_bytes, const T* x, con
   const int n_rows = EPI == SL_SILU_MUL ? N / 2 : N;
   const int n_rb = (n_rows + rows_per_wg - 1) / rows_per_wg;
   const int nkb = K / 128;
-  int ksp = force_ks > 0 ? force_ks : sg_pick_ksplit(n_rb, nkb, M, N, planes_only_ks == nullptr);
+  // (the separate-reduction charge applies to the SiLU epilogue only: a plain layer's planes are usually summed by its
+  //  consumer, and its reducing and plane-returning forms must pick the SAME split to produce the same bits)
+  int ksp = force_ks > 0 ? force_ks : sg_pick_ksplit(n_rb, nkb, M, N, EPI == SL_SILU_MUL);
   while (ksp > 1 && (size_t)ksp * M * N * 4 > planes_bytes) --ksp;
   const int per = (nkb + ksp - 1) / ksp;
   ksp = (nkb + per - 1) / per;

@@ -368,7 +368,7 @@ class ModelRunner:
     # ------------------------------------------------------------------------------------ library GEMM selection
     def tune_dense_gemms(self, rows=(1024, 2048, 128, 256, 512, 1536, 3072, 4096, 6144, 8192), num_full_search: int = 2) -> str:
         """Time hipBLASLt's solutions for every dense weight shape of the model ON THE COMPUTE UNITS THIS PROCESS OWNS and
-        route prefill-sized batches of those layers to the measured winners (csrc/dense_gemm.cpp; ops.dense_gemm).
+        route prefill-sized batches of those layers to the measured winners (csrc/dense_gemm.hip; ops.dense_gemm).
         Under an HSA_CU_MASK the library's own pick -- persistent stream-K grids sized for the whole device -- runs as
         two rounds on any partial share.  Returns the tuning table as text."""
         from semi_pd_amd import ops

@@ -57,7 +57,7 @@ class ServerArgs:
     prefill_stream_priority: int = 0         # HIP stream priority of the instance's compute stream: 0 normal, -1 high
     decode_stream_priority: int = 0
     # prefill-sized dense layers: time the library's GEMM solutions on the instance's own CU share at start-up and use
-    # the winners (csrc/dense_gemm.cpp).  None = when the instance that prefills runs under a CU mask
+    # the winners (csrc/dense_gemm.hip).  None = when the instance that prefills runs under a CU mask
     tune_prefill_gemm: Optional[bool] = None
     disable_stream_linear: bool = False      # dense layers of decode batches through hipBLASLt instead of csrc/stream_linear.hip
     library_gemm_grid: bool = False          # also size hipBLASLt's stream-K grids to the share (TENSILE_STREAMK_MAX_CUS)

@@ -1200,3 +1200,25 @@ def test_moe_stream_gemm_matches_fp32_per_expert(ops, device, dtype, T, E, topk,
     finally:
         M.MOE_STREAM_DECODE = old_flag
     torch.testing.assert_close(new.float(), old.float(), rtol=3e-2, atol=3e-2)
+
+
+def test_logits_processor_above_64_rows_reads_the_head_once(ops, device):
+    """_get_logits (layers/logits_processor.py:394-445) for a decode batch above the fused kernel's 64 rows: the tiled
+    ping-pong GEMM on the (padded) vocabulary-sized weight, logits in the activation type then fp32 -- equal to the
+    reference form torch.matmul(hidden, weight.T) within its rounding, same argmax wherever the top-2 gap is clear."""
+    from types import SimpleNamespace as NS
+    from semi_pd_amd.layers.basic import LogitsProcessor
+    from semi_pd_amd.model_executor.forward_batch_info import ForwardMode
+    g = torch.Generator(device="cpu").manual_seed(5)
+    V, Vpad, H, B = 5000, 5056, 512, 100
+    weight = (torch.randn(Vpad, H, generator=g) * 0.05).to(torch.bfloat16).to(device)
+    hidden = torch.randn(B, H, generator=g).to(torch.bfloat16).to(device)
+    lp = LogitsProcessor(V)
+    fb = NS(forward_mode=ForwardMode.DECODE)
+    out = lp(None, hidden, NS(weight=weight), fb)
+    want = (hidden.float() @ weight[:V].float().t())
+    assert out.next_token_logits.shape == (B, V) and out.next_token_logits.dtype == torch.float32
+    torch.testing.assert_close(out.next_token_logits, want, rtol=2e-2, atol=2e-2)
+    top2 = torch.topk(want, 2, dim=-1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 4e-2
+    assert torch.equal(out.next_token_logits.argmax(-1)[clear], want.argmax(-1)[clear])
