@@ -35,6 +35,8 @@ class SemiPDDecodeScheduler(SchedulerBase):
         # --disable-overlap-schedule): step k + 1 is launched before the tokens of step k are looked at
         self.enable_overlap = not getattr(server_args, "disable_overlap_schedule", False)
         self._pending = None                          # (reqs, out_cache_loc, pinned ids, event, logits_output) of step k
+        self._in_wait = False                         # inside _wait_servicing (it must not nest)
+        self._deferred_input: list = []               # messages a wait set aside for the loop top
         self._pinned_ids = None
         self._pinned_flip = 0
 
@@ -296,22 +298,46 @@ class SemiPDDecodeScheduler(SchedulerBase):
         self.stream_output(live, defer=False)
         self.last_progress = time.monotonic()
 
+    # what may be handled while a step is in flight and the previous one is not accounted yet: enqueueing a request
+    # (host list only), an admission (KV / request slots come from the host allocator; the reply is built from host
+    # state) and a prefill result (merged into the running batch that the NEXT schedule reads).  Everything else -- aborts,
+    # statistics resets, cache flushes, shutdown -- touches the running batch or the loop's own state and waits for the
+    # loop top, in arrival order.
+    _SERVICED_IN_WAIT = (TokenizedGenerateReqInput, GetNextPrefillBatchInput, BatchProcessPrefillResultReq)
+
     def _wait_servicing(self, ev):
         """Wait for a decode step on the GPU, answering the prefill instance meanwhile.  The loop comes round once
         per decode step (6-8 ms); an admission request or a prefill result that arrives just after a launch would
         otherwise sit in the socket for the rest of the step -- half a step on average, on the TTFT path twice
-        (admission, then first token).  Everything dispatch() does is host work plus asynchronous copies queued
-        behind the step in flight, and the step in flight owns copies of its inputs, so nothing here can touch it.
+        (admission, then first token).  Only the three message kinds of _SERVICED_IN_WAIT are handled here (host work
+        plus asynchronous copies queued behind the step in flight, which owns copies of its inputs); the rest is kept
+        for the loop top.  The wait never nests: nothing it dispatches may wait for a step itself.
         With tensor parallelism every rank must see the same messages at the same point: plain wait."""
         if self.tp_size > 1 or self.recv_from_tokenizer is None:
             ev.synchronize()
             return
-        while not ev.query():
-            recv = self.recv_requests()
-            if recv:
-                self.process_input_requests(recv)
-            else:
-                time.sleep(30e-6)
+        assert not self._in_wait, "_wait_servicing re-entered: a message handled inside the wait waited for a step"
+        self._in_wait = True
+        try:
+            while not ev.query():
+                recv = self.recv_requests()
+                if recv:
+                    now = [r for r in recv if isinstance(r, self._SERVICED_IN_WAIT)]
+                    self._deferred_input.extend(r for r in recv if not isinstance(r, self._SERVICED_IN_WAIT))
+                    if now:
+                        self.process_input_requests(now)
+                else:
+                    time.sleep(30e-6)
+        finally:
+            self._in_wait = False
+
+    def recv_requests(self) -> list:
+        """The loop top also gets what a wait set aside (in arrival order, before anything newer)."""
+        recv = super().recv_requests()
+        if self._deferred_input and not self._in_wait:
+            recv = self._deferred_input + recv
+            self._deferred_input = []
+        return recv
 
     def event_loop_normal(self):
         while not self._shutdown:

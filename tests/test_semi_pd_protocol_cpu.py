@@ -288,3 +288,45 @@ def test_penalties_see_every_generated_token_in_the_overlapped_loop():
             SemiPDDecodeScheduler.get_next_batch_to_run = orig
         assert d.enable_overlap and got == [expected(p, 9) for p in prompts]
         assert seen["steps"] >= 8 and seen["rows"] >= 3 * 8
+
+
+def test_wait_for_a_step_services_only_the_pd_messages_and_defers_the_rest():
+    """While the decode instance waits for a step it answers the prefill instance (admissions, prefill results) and
+    enqueues new requests; anything that touches the running batch or the loop's own state -- an abort, a statistics
+    reset -- is kept, in arrival order, for the top of the loop.  The wait does not nest."""
+    from semi_pd_amd.managers.io_struct import AbortReq, GetNextPrefillBatchInput, StatsReq
+    sa = args()
+    d_runner = make_runner()
+    d_in, out, bridge, p_in = Q(), Q(), Q(), Q()
+    d = SemiPDDecodeScheduler(sa, d_runner, 0, d_in, out, bridge, p_in)
+
+    class Ev:   # an event that completes after a few polls; messages arrive in between
+        def __init__(self):
+            self.polls = 0
+
+        def query(self):
+            self.polls += 1
+            if self.polls == 2:
+                d_in.send_pyobj(TokenizedGenerateReqInput("w0", None, [1, 2, 3], SamplingParams(max_new_tokens=4, ignore_eos=True)))
+                d_in.send_pyobj(AbortReq("nobody"))
+                d_in.send_pyobj(StatsReq(reset=True))
+                d_in.send_pyobj(GetNextPrefillBatchInput(["w0"]))
+            return self.polls > 4
+
+        def synchronize(self):
+            raise AssertionError("the servicing wait polls, it does not block")
+
+    d.stats["decode_steps"] = 7
+    d._wait_servicing(Ev())
+    # the request was enqueued and admitted inside the wait (the reply to P is on the bridge), the other two were kept
+    assert not d.waiting_queue and len(d.scheduled_prefill_batches) == 1
+    assert bridge.q, "no admission reply was sent during the wait"
+    assert [type(m).__name__ for m in d._deferred_input] == ["AbortReq", "StatsReq"]
+    assert d.stats["decode_steps"] == 7, "a statistics reset ran inside the wait"
+    # the loop top hands them on, before anything newer, and the wait cannot be entered from inside itself
+    d_in.send_pyobj(StatsReq(reset=False))
+    got = d.recv_requests()
+    assert [type(m).__name__ for m in got] == ["AbortReq", "StatsReq", "StatsReq"] and not d._deferred_input
+    d._in_wait = True
+    with pytest.raises(AssertionError):
+        d._wait_servicing(Ev())
