@@ -100,7 +100,7 @@ struct G8Group {
   int num_valid, top_k_div, mul_routed_weight;
 };
 
-template <typename T, int EPI, bool NT, int XH, bool GR = false>
+template <typename T, int EPI, bool NT, int XH, bool GR = false, int ORDER = 0>
 __global__ void __launch_bounds__(512)
 gemm8p_kernel(T* __restrict__ out, float* __restrict__ planes, const T* __restrict__ x, const T* __restrict__ w, int M, int N,
               int K, int64_t ldx, int64_t ldo, int kt_per_slice, G8Group grp = G8Group()) {
@@ -114,7 +114,18 @@ gemm8p_kernel(T* __restrict__ out, float* __restrict__ planes, const T* __restri
   const int n_cols = EPI == G8_SILU_MUL ? N / 2 : N;       // output columns
   constexpr int cols_per_tile = EPI == G8_SILU_MUL ? WH : G::BN;
   const int tiles_n = (n_cols + cols_per_tile - 1) / cols_per_tile;
-  const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;   // neighbours share the x tile
+  int tile_m, tile_n;
+  if (GR || ORDER == 0) {
+    tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;   // neighbours share the x tile
+  } else {
+    // several row tiles (prefill-sized calls): workgroup id runs on XCD id % 8; give every XCD a contiguous range of
+    // logical tiles and walk the row tiles fastest, so that the row tiles of one W tile sit on ONE XCD next to each
+    // other in time: the W tile is fetched once into that L2 instead of once per row tile from the fabric
+    const int nwg = gridDim.x, id = blockIdx.x, xcd = id & 7, q = nwg >> 3, r = nwg & 7;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+    const int tiles_m = nwg / tiles_n;
+    tile_n = logical / tiles_m, tile_m = logical - tile_n * tiles_m;
+  }
   const int m0 = tile_m * G::BM, n0 = tile_n * cols_per_tile;
   const int ks = blockIdx.y;
   const int nkt_total = K >> 6;
@@ -411,9 +422,21 @@ static int g8_launch_geo(T* out, float* planes, size_t planes_bytes, const T* x,
     hipLaunchKernelGGL((gemm8p_kernel<T, EPI, true, XH>), dim3(tiles, ksp), dim3(512), G::kLds, st, out,
                        ksp > 1 ? planes : (float*)nullptr, x, w, M, N, K, ldx, ldo, per);
   } else {
-    if (ensure_dynamic_lds((const void*)gemm8p_kernel<T, EPI, false, XH>, G::kLds, lds_ok, "gemm8p")) return 1;
-    hipLaunchKernelGGL((gemm8p_kernel<T, EPI, false, XH>), dim3(tiles, ksp), dim3(512), G::kLds, st, out,
-                       ksp > 1 ? planes : (float*)nullptr, x, w, M, N, K, ldx, ldo, per);
+    // XCD-contiguous order pays where the weight does not fit the caches between row tiles (vocabulary-sized heads:
+    // 128 256 x 4096 at 1024 rows 1073 -> 834 us) and is neutral to slightly negative for layer-sized weights
+    // (profiles/r03_kbench_gemm_tall_tile_order.txt); SEMIPD_G8_XCD_ORDER=0 / 1 forces it
+    static const int xcd_knob = []() { const char* e = getenv("SEMIPD_G8_XCD_ORDER"); return e ? atoi(e) : -1; }();
+    const bool xcd_order = xcd_knob >= 0 ? xcd_knob != 0 : n_cols >= 32768;
+    static std::atomic<uint64_t> lds_ok_x{0};
+    if (xcd_order) {
+      if (ensure_dynamic_lds((const void*)gemm8p_kernel<T, EPI, false, XH, false, 1>, G::kLds, lds_ok_x, "gemm8p")) return 1;
+      hipLaunchKernelGGL((gemm8p_kernel<T, EPI, false, XH, false, 1>), dim3(tiles, ksp), dim3(512), G::kLds, st, out,
+                         ksp > 1 ? planes : (float*)nullptr, x, w, M, N, K, ldx, ldo, per);
+    } else {
+      if (ensure_dynamic_lds((const void*)gemm8p_kernel<T, EPI, false, XH>, G::kLds, lds_ok, "gemm8p")) return 1;
+      hipLaunchKernelGGL((gemm8p_kernel<T, EPI, false, XH>), dim3(tiles, ksp), dim3(512), G::kLds, st, out,
+                         ksp > 1 ? planes : (float*)nullptr, x, w, M, N, K, ldx, ldo, per);
+    }
   }
   int rc = launch_status("gemm8p");
   if (rc || ksp == 1) return rc;

@@ -329,7 +329,9 @@ static int sg_pick_ksplit(int n_rb, int nkb, int M, int N, bool extra_reduce_lau
     if (eff != ksp) continue;
     const int rounds = (n_rb * eff + cus - 1) / cus;
     float cost = rounds * (per * t_block + t_round);
-    if (eff > 1) cost += eff * plane_us + (extra_reduce_launch ? 8.f : 0.f);   // a reduction launch: ~5 us + its ramp
+    // every slice beyond the first: its plane's round trip + ~1 us in the consumer (whole chip, o_proj: 8 slices 15.3 us,
+    // 4 slices 13.1 us, profiles/r03_kbench_stream_linear_whole_chip.txt); a separate reduction launch: ~5 us + its ramp
+    if (eff > 1) cost += eff * (plane_us + 1.0f) + (extra_reduce_launch ? 8.f : 0.f);
     if (cost < best_cost - 1e-3f) best_cost = cost, best = eff;
   }
   return best;
