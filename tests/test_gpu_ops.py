@@ -1222,3 +1222,58 @@ def test_logits_processor_above_64_rows_reads_the_head_once(ops, device):
     top2 = torch.topk(want, 2, dim=-1).values
     clear = (top2[:, 0] - top2[:, 1]) > 4e-2
     assert torch.equal(out.next_token_logits.argmax(-1)[clear], want.argmax(-1)[clear])
+
+
+@pytest.mark.parametrize("M,N,K,silu", [(256, 4096, 4096, False), (128, 2048, 4096, True), (1024, 2048, 2048, False), (700, 1024, 512, True)])
+def test_gemm_tall_race_screen_repeated_launches_under_memory_load(ops, device, M, N, K, silu):
+    """The ping-pong GEMM orders its LDS-DMA by counted waits and barriers; a hole in that ordering shows as a rare wrong
+    tile that comes and goes with timing.  The kernel is deterministic (fixed summation order), so: 150 launches on the
+    same operands, next to a second stream that saturates HBM with copies, must all give the bits of the first launch
+    -- and that launch the fp32 product."""
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(device)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(torch.bfloat16).to(device)
+    want = x.float() @ w.float().t()
+    if silu:
+        want = O.silu_and_mul(want.to(torch.bfloat16).cpu()).float().to(device)
+    first = ops.gemm_tall(x, w, fuse_silu_mul=silu).clone()
+    torch.testing.assert_close(first.float(), want, rtol=3e-2, atol=3e-2)
+    junk_a = torch.empty(64 << 20, dtype=torch.uint8, device=device)
+    junk_b = torch.empty_like(junk_a)
+    side = torch.cuda.Stream(device=device)
+    outs = []
+    for i in range(150):
+        if i % 3 == 0:
+            with torch.cuda.stream(side):
+                junk_b.copy_(junk_a)
+                junk_a.copy_(junk_b)
+        outs.append(ops.gemm_tall(x, w, fuse_silu_mul=silu))
+    torch.cuda.synchronize()
+    bad = [i for i, o in enumerate(outs) if not torch.equal(o, first)]
+    assert not bad, f"launches {bad[:8]} of 150 differ from the first one"
+
+
+def test_grouped_kernels_race_screen_repeated_launches(ops, device):
+    """The same screen for the grouped forms (fused-MoE expert GEMMs): decode-sized through the LDS-DMA streaming kernel,
+    prefill-sized through the ping-pong tile kernel, 100 launches each next to a stream of HBM copies."""
+    from semi_pd_amd.layers import moe as M
+    g = torch.Generator(device="cpu").manual_seed(9)
+    E, k, K, N = 16, 4, 1024, 512
+    w1 = (torch.randn(E, 2 * N, K, generator=g) * K ** -0.5).to(torch.bfloat16).to(device)
+    w2 = (torch.randn(E, K, N, generator=g) * N ** -0.5).to(torch.bfloat16).to(device)
+    junk_a = torch.empty(64 << 20, dtype=torch.uint8, device=device)
+    junk_b = torch.empty_like(junk_a)
+    side = torch.cuda.Stream(device=device)
+    for T in (24, 4096):
+        x = torch.randn(T, K, generator=g).to(torch.bfloat16).to(device)
+        tw, ti = ops.topk_softmax(torch.randn(T, E, generator=g).to(device), k, True)
+        first = M.fused_experts(x, w1, w2, tw, ti).clone()
+        outs = []
+        for i in range(100):
+            if i % 3 == 0:
+                with torch.cuda.stream(side):
+                    junk_b.copy_(junk_a)
+            outs.append(M.fused_experts(x, w1, w2, tw, ti))
+        torch.cuda.synchronize()
+        bad = [i for i, o in enumerate(outs) if not torch.equal(o, first)]
+        assert not bad, f"T = {T}: launches {bad[:8]} of 100 differ from the first one"
