@@ -86,22 +86,9 @@ def choose_kv_splits(batch: int, num_kv_heads: int, max_seq_len: int, num_cus: i
             return s
     target = (2 if mla else 8) * num_cus
     base = max(1, batch * num_kv_heads)
+    want = max(1, target // base)
     by_len = max(1, max_seq_len // (128 if mla else 64))
-    if mla:
-        want = max(1, target // base)
-        return int(max(1, min(cap, want, by_len)))
-    # GQA / MQA: the work items run in ceil(base * s / target) rounds of waves; a wave walks len / s tokens plus ~96
-    # tokens' worth of prologue, and stage 2 grows with s.  On a share the rounds decide: at 64 requests on 96 CUs one
-    # split is 0.67 rounds of 1100 tokens, three are exactly two rounds of 367 (104.9 vs 88.3 us); with whole-number
-    # ratios this picks what "one full round" picked (profiles/r03_kbench_decode_k_through_lds_negative.txt lists every
-    # split count on 96 / 128 / 256 CUs)
-    best, best_cost = 1, None
-    for s in range(1, int(min(cap, by_len)) + 1):
-        rounds = -(-base * s // target)
-        cost = rounds * (max_seq_len / s + 96.0) + 8.0 * s
-        if best_cost is None or cost < best_cost - 1e-9:
-            best, best_cost = s, cost
-    return int(best)
+    return int(max(1, min(cap, want, by_len)))
 
 
 class HipAttnBackend(AttentionBackend):
