@@ -63,6 +63,22 @@ def model_config(name: str):
             rope_scaling={"type": "yarn", "factor": 40, "beta_fast": 32, "beta_slow": 1, "mscale": 1.0,
                           "mscale_all_dim": 1.0, "original_max_position_embeddings": 4096},
             architectures=("DeepseekV3ForCausalLM",))
+    if name == "deepseek-v3-tp8-rank":
+        # what ONE rank of BASELINE config 5 (DeepSeek-V3, block-fp8, TP = 8) holds and computes, without the collectives:
+        # all 61 layers at hidden 7168 with 128 / 8 = 16 MLA heads, every MLP / expert intermediate width / 8 (dense 2304,
+        # experts 256: the reference's column split, fused_moe_triton/layer.py), 256 routed experts top-8 in 8 groups, 1 / 8
+        # of the vocabulary: ~85 GB of fp8 weights on one GPU.  Use with --quantization fp8.  A one-GPU measurement of the
+        # per-rank kernel shapes, not a claim about config 5
+        from semi_pd_amd.models.deepseek_v2 import DeepseekV2Config
+        return DeepseekV2Config(
+            vocab_size=16160, hidden_size=7168, intermediate_size=2304, moe_intermediate_size=256,
+            num_hidden_layers=61, num_attention_heads=16, n_shared_experts=1, n_routed_experts=256,
+            num_experts_per_tok=8, routed_scaling_factor=2.5, topk_method="noaux_tc", n_group=8, topk_group=4,
+            norm_topk_prob=True, first_k_dense_replace=3, kv_lora_rank=512, q_lora_rank=1536, qk_rope_head_dim=64,
+            qk_nope_head_dim=128, v_head_dim=128, rope_theta=10000.0,
+            rope_scaling={"type": "yarn", "factor": 40, "beta_fast": 32, "beta_slow": 1, "mscale": 1.0,
+                          "mscale_all_dim": 1.0, "original_max_position_embeddings": 4096},
+            architectures=("DeepseekV3ForCausalLM",))
     if name == "llama3-70b-tp8-rank":
         # what ONE rank of BASELINE config 4 (Llama-3-70B, TP = 8) computes, without the collectives: 80 layers of hidden
         # 8192 with 1/8 of the heads (8 q, 1 kv, head size 128), 1/8 of the MLP columns (3584) and 1/8 of the vocabulary:
