@@ -21,8 +21,12 @@ import torch
 import semi_pd_ipc
 from semi_pd_amd import _lib
 
-PREFILL_ENGINE_SM_PERCENTILE = int(os.getenv("SEMI_PD_PREFILL_SM_PERCENTILE", 80))
-DECODE_ENGINE_SM_PERCENTILE = int(os.getenv("SEMI_PD_DECODE_SM_PERCENTILE", 100))
+# The reference's defaults are 80 / 100 (semi_pd/utils.py:10-11): MPS percentages are upper bounds that may overlap.
+# CU masks are hard partitions, and overlapping ones measured badly on this chip (decode workgroups wait behind prefill
+# workgroups on every shared CU: 80 / 100 gives TTFT p50 70 ms where disjoint 62 / 38 gives 42 ms at the same TBT tail;
+# DESIGN.md 4.2), so the built-in defaults are the disjoint pair; the reference's environment variables still override.
+PREFILL_ENGINE_SM_PERCENTILE = int(os.getenv("SEMI_PD_PREFILL_SM_PERCENTILE", 62))
+DECODE_ENGINE_SM_PERCENTILE = int(os.getenv("SEMI_PD_DECODE_SM_PERCENTILE", 38))
 
 
 @dataclass
