@@ -390,6 +390,10 @@ int semipd_dense_gemm(void* out, const void* x, const void* weight, const void* 
       p.have_algo = true;
       p.solution_index = hipblaslt_ext::getIndexFromAlgo(p.algo);
     }
+    if (s.plans.size() >= 4096) {   // every distinct batch row count makes a plan: bound the cache of a long-running server
+      for (auto& kv : s.plans) destroy_problem(kv.second);
+      s.plans.clear();
+    }
     it = s.plans.emplace(pkey, p).first;
   }
   Plan& p = it->second;
