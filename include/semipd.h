@@ -426,6 +426,12 @@ int semipd_moe_grouped_gemm_silu(void* c, const void* a, const void* w, const in
                                  const int32_t* expert_ids, const int32_t* num_tokens_post_pad, int64_t num_valid, int64_t n,
                                  int64_t k, int64_t max_sorted, int top_k_div, int block_m, int dtype, void* stream);
 
+/* moe_sum continued in registers by the element-wise tail of DeepseekV2MoE.forward (python/sglang/srt/models/
+ * deepseek_v2.py:139-160): out = T(T(T(sum_j in[t,j,:]) * scale) + addend[t,:]); scale only when apply_scale, addend may be
+ * NULL.  Every intermediate is rounded to the activation type like the separate kernels round it. */
+int semipd_moe_sum_scale_add(void* out, const void* in, const void* addend, int64_t num_tokens, int topk, int64_t hidden,
+                             float scale, int apply_scale, int dtype, void* stream);
+
 /* out[t,:] = sum_j in[t,j,:]   (vllm moe_sum, fused_moe.py:1144-1148) */
 int semipd_moe_sum(void* out, const void* in, int64_t num_tokens, int topk, int64_t hidden,
                    int dtype, void* stream);

@@ -656,10 +656,13 @@ argmax_kernel(const T* __restrict__ logits, void* __restrict__ out, int64_t voca
   }
 }
 
-// moe_sum: out[t,:] = sum_j in[t,j,:]
+// moe_sum: out[t,:] = sum_j in[t,j,:]; the fused form continues in registers with the two element-wise ops that follow
+// it in DeepseekV2MoE.forward (models/deepseek_v2.py:139-160): * routed_scaling_factor, + shared_output -- each rounded to T
+// like the separate kernels round it, so the bits are those of the three-launch sequence
 template <typename T>
 __global__ void moe_sum_kernel(T* __restrict__ out, const T* __restrict__ in, int64_t num_tokens,
-                               int topk, int hvec) {
+                               int topk, int hvec, float scale = 1.f, const T* __restrict__ addend = nullptr,
+                               int apply_scale = 0) {
   constexpr int V = Elem<T>::kVec;
   const int64_t total = num_tokens * hvec;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -677,6 +680,15 @@ __global__ void moe_sum_kernel(T* __restrict__ out, const T* __restrict__ in, in
     Vec16<T> o;
 #pragma unroll
     for (int j = 0; j < V; ++j) o.e[j] = Elem<T>::from_f(acc[j]);
+    if (apply_scale) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) o.e[j] = Elem<T>::from_f(Elem<T>::to_f(o.e[j]) * scale);
+    }
+    if (addend != nullptr) {
+      const Vec16<T> b = load16(addend + (t * hvec + c) * V);
+#pragma unroll
+      for (int j = 0; j < V; ++j) o.e[j] = Elem<T>::from_f(Elem<T>::to_f(o.e[j]) + Elem<T>::to_f(b.e[j]));
+    }
     store16(out + (t * hvec + c) * V, o);
   }
 }
@@ -1037,6 +1049,26 @@ int semipd_moe_sum(void* out, const void* in, int64_t num_tokens, int topk, int6
                        (const T*)in, num_tokens, topk, (int)(hidden / V));
   });
   return launch_status("moe_sum");
+}
+
+/* moe_sum followed, in registers, by the element-wise tail of DeepseekV2MoE.forward: out = T(T(T(sum_j in[t,j,:]) * scale)
+ * + addend[t,:]) (scale applied only when apply_scale, addend optional) -- the roundings of the three separate launches. */
+int semipd_moe_sum_scale_add(void* out, const void* in, const void* addend, int64_t num_tokens, int topk, int64_t hidden,
+                             float scale, int apply_scale, int dtype, void* stream) {
+  SEMIPD_CHECK_ARG(num_tokens >= 0 && topk > 0 && hidden > 0, SEMIPD_EINVAL, "moe_sum_scale_add: bad sizes");
+  if (num_tokens == 0) return 0;
+  SEMIPD_CHECK_ARG(out && in, SEMIPD_EINVAL, "moe_sum_scale_add: null pointer");
+  SEMIPD_DISPATCH_DTYPE(dtype, T, {
+    constexpr int V = Elem<T>::kVec;
+    SEMIPD_CHECK_ARG(hidden % V == 0 && aligned16(out) && aligned16(in) && (!addend || aligned16(addend)), SEMIPD_EALIGN,
+                     "moe_sum_scale_add: hidden must be a multiple of %d and pointers 16-byte aligned", V);
+    const int64_t nv = num_tokens * (hidden / V);
+    int blocks = (int)((nv + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL((moe_sum_kernel<T>), dim3(blocks), dim3(256), 0, as_stream(stream), (T*)out, (const T*)in,
+                       num_tokens, topk, (int)(hidden / V), scale, (const T*)addend, apply_scale);
+  });
+  return launch_status("moe_sum_scale_add");
 }
 
 }  // extern "C"

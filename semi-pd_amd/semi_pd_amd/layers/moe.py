@@ -65,8 +65,17 @@ def _local_ids(topk_ids: torch.Tensor, expert_offset: int) -> torch.Tensor:
     return topk_ids if expert_offset == 0 else (topk_ids - expert_offset).to(torch.int32)
 
 
+def _finish(c3: torch.Tensor, out_scale: float, out_addend: Optional[torch.Tensor]) -> torch.Tensor:
+    """The sum over the top-k rows; with a scale and / or an addend (DeepseekV2MoE's `* routed_scaling_factor` and
+    `+ shared_output`) continued in the same launch with the roundings of the separate ones."""
+    if out_scale == 1.0 and out_addend is None:
+        return ops.moe_sum(c3)
+    return ops.moe_sum_scale_add(c3, out_scale, out_addend)
+
+
 def fused_experts(hidden_states: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, topk_weights: torch.Tensor,
-                  topk_ids: torch.Tensor, expert_offset: int = 0, partial_experts: bool = False) -> torch.Tensor:
+                  topk_ids: torch.Tensor, expert_offset: int = 0, partial_experts: bool = False,
+                  out_scale: float = 1.0, out_addend: Optional[torch.Tensor] = None) -> torch.Tensor:
     """fused_experts_impl (fused_moe.py:961-1165), bf16/f16 path.  hidden [T, K]; w1 [E, 2N, K];
     w2 [E, K, N]; returns [T, K].  partial_experts: w1 / w2 hold only the experts [expert_offset, expert_offset + E)."""
     topk_ids = _local_ids(topk_ids, expert_offset)
@@ -100,13 +109,13 @@ def fused_experts(hidden_states: torch.Tensor, w1: torch.Tensor, w2: torch.Tenso
         ops.moe_stream_gemm(hidden_states, w1, c2, None, sorted_ids, expert_ids, num_post_pad, numel, topk, False, block_m, True)
         c3 = (torch.zeros if partial_experts else torch.empty)((numel, K), dtype=dt, device=dev)
         ops.moe_stream_gemm(c2, w2, c3, topk_weights.reshape(-1), sorted_ids, expert_ids, num_post_pad, numel, 1, True, block_m)
-        return ops.moe_sum(c3.view(T, topk, K))
+        return _finish(c3.view(T, topk, K), out_scale, out_addend)
     if tall:
         c2 = torch.empty((numel, N2 // 2), dtype=dt, device=dev)
         ops.moe_gemm_tall(hidden_states, w1, c2, None, sorted_ids, expert_ids, num_post_pad, numel, topk, False, True)
         c3 = (torch.zeros if partial_experts else torch.empty)((numel, K), dtype=dt, device=dev)
         ops.moe_gemm_tall(c2, w2, c3, topk_weights.reshape(-1), sorted_ids, expert_ids, num_post_pad, numel, 1, True, False)
-        return ops.moe_sum(c3.view(T, topk, K))
+        return _finish(c3.view(T, topk, K), out_scale, out_addend)
     # prefill-sized calls: SiLU * mul in GEMM1's epilogue (no [T * k, 2N] intermediate); same bits as the two calls
     c2 = ops.moe_grouped_gemm_silu(hidden_states, w1, sorted_ids, expert_ids, num_post_pad, numel, topk, block_m)
     if c2 is None:
@@ -117,13 +126,13 @@ def fused_experts(hidden_states: torch.Tensor, w1: torch.Tensor, w2: torch.Tenso
     c3 = (torch.zeros if partial_experts else torch.empty)((numel, K), dtype=dt, device=dev)
     ops.moe_grouped_gemm(c2, w2, c3, topk_weights.reshape(-1), sorted_ids, expert_ids, num_post_pad, numel, 1, True,
                          block_m)
-    return ops.moe_sum(c3.view(T, topk, K))
+    return _finish(c3.view(T, topk, K), out_scale, out_addend)
 
 
 def fused_experts_fp8(hidden_states: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, w1_scale: torch.Tensor,
                       w2_scale: torch.Tensor, topk_weights: torch.Tensor, topk_ids: torch.Tensor, block_shape,
                       block_m: Optional[int] = None, expert_offset: int = 0, partial_experts: bool = False,
-                      x_quant=None) -> torch.Tensor:
+                      x_quant=None, out_scale: float = 1.0, out_addend: Optional[torch.Tensor] = None) -> torch.Tensor:
     """fused_experts_impl with use_fp8_w8a8 and block_shape = [block_n, block_k] (fused_moe.py:961-1165;
     activation quantisation inside invoke_fused_moe_kernel :526-545): the activations of both GEMMs are
     quantised per token and group of block_k, the weights are fp8 [E, 2N, K] / [E, K, N] with one scale per
@@ -151,7 +160,7 @@ def fused_experts_fp8(hidden_states: torch.Tensor, w1: torch.Tensor, w2: torch.T
     c3 = (torch.zeros if partial_experts else torch.empty)((numel, K), dtype=dt, device=dev)
     ops.moe_grouped_gemm_fp8(c2_q, c2_s, w2, w2_scale, c3, topk_weights.reshape(-1).float(), sorted_ids, expert_ids,
                              num_post_pad, numel, 1, True, block_shape, block_m)
-    return ops.moe_sum(c3.view(T, topk, K))
+    return _finish(c3.view(T, topk, K), out_scale, out_addend)
 
 
 class FusedMoE(nn.Module):
@@ -234,7 +243,12 @@ class FusedMoE(nn.Module):
             self.w2_weight_scale_inv.tp_full_shape = (E,) + scale_shape(hidden_size, n, (bn, bk))
             self.w13_weight_scale_inv.tp_shard = self.w2_weight_scale_inv.tp_shard = lambda full: full[lo:hi].contiguous()
 
-    def forward(self, hidden_states: torch.Tensor, router_logits: torch.Tensor, x_quant=None) -> torch.Tensor:
+    def forward(self, hidden_states: torch.Tensor, router_logits: torch.Tensor, x_quant=None, out_scale: float = 1.0,
+                out_addend: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """out_scale / out_addend: `experts(x) * out_scale + out_addend` with the roundings of the separate element-wise
+        ops, in the launch that sums the top-k rows (not combined with reduce_results: the caller reduces afterwards)."""
+        if (out_scale != 1.0 or out_addend is not None) and self.reduce_results and get_tensor_model_parallel_world_size() > 1:
+            raise RuntimeError("FusedMoE: out_scale / out_addend cannot be combined with reduce_results")
         topk_weights, topk_ids = select_experts(hidden_states, router_logits, self.top_k, self.use_grouped_topk,
                                                 self.renormalize, self.topk_group, self.num_expert_group,
                                                 self.correction_bias)
@@ -242,10 +256,11 @@ class FusedMoE(nn.Module):
             out = fused_experts_fp8(hidden_states, self.w13_weight, self.w2_weight, self.w13_weight_scale_inv,
                                     self.w2_weight_scale_inv, topk_weights, topk_ids, self.quant_config.weight_block_size,
                                     expert_offset=self.expert_offset, partial_experts=self.expert_parallel,
-                                    x_quant=x_quant)
+                                    x_quant=x_quant, out_scale=out_scale, out_addend=out_addend)
         else:
             out = fused_experts(hidden_states, self.w13_weight, self.w2_weight, topk_weights, topk_ids,
-                                expert_offset=self.expert_offset, partial_experts=self.expert_parallel)
+                                expert_offset=self.expert_offset, partial_experts=self.expert_parallel,
+                                out_scale=out_scale, out_addend=out_addend)
         if self.reduce_results and get_tensor_model_parallel_world_size() > 1:
             out = tensor_model_parallel_all_reduce(out)
         return out

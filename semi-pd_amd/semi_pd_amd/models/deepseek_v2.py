@@ -137,11 +137,16 @@ class DeepseekV2MoE(nn.Module):
             x_quant = quantize_activation(hidden_states, qc.weight_block_size)
         shared_output = self.shared_experts(hidden_states, x_quant=x_quant) if self.shared_experts is not None else None
         router_logits = self.gate(hidden_states)
-        out = self.experts(hidden_states, router_logits, x_quant=x_quant)
-        if self.routed_scaling_factor != 1.0:
-            out = out * self.routed_scaling_factor
-        if shared_output is not None:
-            out = out + shared_output
+        if hidden_states.dim() == 2 and (shared_output is None or shared_output.is_contiguous()):
+            # `* routed_scaling_factor` and `+ shared_output` ride in the launch that sums the top-k rows (same roundings)
+            out = self.experts(hidden_states, router_logits, x_quant=x_quant, out_scale=float(self.routed_scaling_factor),
+                               out_addend=shared_output)
+        else:
+            out = self.experts(hidden_states, router_logits, x_quant=x_quant)
+            if self.routed_scaling_factor != 1.0:
+                out = out * self.routed_scaling_factor
+            if shared_output is not None:
+                out = out + shared_output
         if self.tp_size > 1:
             out = tensor_model_parallel_all_reduce(out)
         return out
@@ -277,8 +282,9 @@ class DeepseekV2AttentionMLA(nn.Module):
             ops.bmm_fp8(q_val, self.w_kc.transpose(1, 2), q_scale, self.w_scale, q.dtype,
                         out=q_input[..., : self.kv_lora_rank].transpose(0, 1))
         else:
-            q_nope_out = torch.bmm(q[..., : self.qk_nope_head_dim].transpose(0, 1), self.w_kc)  # [H, T, 512]
-            q_input[..., : self.kv_lora_rank] = q_nope_out.transpose(0, 1)
+            # [H, T, 512], written through the strides of q_input's layout (no copy behind the batched GEMM)
+            torch.bmm(q[..., : self.qk_nope_head_dim].transpose(0, 1), self.w_kc,
+                      out=q_input[..., : self.kv_lora_rank].transpose(0, 1))
         q_input[..., self.kv_lora_rank:] = q[..., self.qk_nope_head_dim:]
         forward_batch.token_to_kv_pool.set_kv_buffer(self.attn_mqa, forward_batch.out_cache_loc, latent, None)
         attn_output = self.attn_mqa(q_input.view(T, -1), latent.view(T, -1), latent[..., : self.kv_lora_rank],
@@ -289,8 +295,10 @@ class DeepseekV2AttentionMLA(nn.Module):
             out = torch.empty((T, self.num_local_heads, self.v_head_dim), dtype=q.dtype, device=q.device)
             ops.bmm_fp8(a_val, self.w_vc.transpose(1, 2), a_scale, self.w_scale, q.dtype, out=out.transpose(0, 1))
             return self.o_proj(out.view(T, -1))
-        out = torch.bmm(attn_output.transpose(0, 1), self.w_vc)  # [H, T, 128]
-        return self.o_proj(out.transpose(0, 1).reshape(T, -1))
+        out = torch.empty((T, self.num_local_heads, self.v_head_dim), dtype=q.dtype, device=q.device)
+        torch.bmm(attn_output.transpose(0, 1), self.w_vc, out=out.transpose(0, 1))  # [H, T, 128] in [T, H, 128]'s memory
+        # (its K-slice planes are summed by post_attention_layernorm: one launch less for decode batches)
+        return self.o_proj(out.view(T, -1), defer_reduce=True)
 
 
 class DeepseekV2DecoderLayer(nn.Module):

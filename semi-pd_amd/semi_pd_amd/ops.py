@@ -766,6 +766,19 @@ def moe_grouped_gemm_silu(a: torch.Tensor, w: torch.Tensor, sorted_token_ids: to
     return c
 
 
+def moe_sum_scale_add(x: torch.Tensor, scale: float = 1.0, addend: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """moe_sum(x) * scale + addend in one launch with the roundings of the three (DeepseekV2MoE.forward,
+    models/deepseek_v2.py:139-160): x [T, topk, H]; the multiply is skipped for scale == 1 like the model skips it."""
+    T, k, H = x.shape
+    out = torch.empty((T, H), dtype=x.dtype, device=x.device)
+    if addend is not None and (addend.shape != (T, H) or addend.dtype != x.dtype or not addend.is_contiguous()):
+        raise RuntimeError("moe_sum_scale_add: addend must be a contiguous [T, H] tensor of the same dtype")
+    check(_lib.load().semipd_moe_sum_scale_add(ptr(out), ptr(x.contiguous()), ptr(addend), T, k, H, float(scale),
+                                               int(scale != 1.0), dtype_code(x.dtype), current_stream(x.device)),
+          "moe_sum_scale_add")
+    return out
+
+
 def moe_stream_gemm_is_supported(a: torch.Tensor, w: torch.Tensor, fuse_silu_mul: bool) -> bool:
     E, N, K = w.shape
     n_out = N // 2 if fuse_silu_mul else N

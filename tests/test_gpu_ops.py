@@ -729,6 +729,27 @@ def test_fused_moe_pipeline(ops, device, T, N, K, E, topk, dtype, block):
     _close(out, want, dtype, rtol=1e-1, atol=1e-2)
 
 
+@pytest.mark.parametrize("T,topk,H", [(1, 6, 2048), (37, 6, 2048), (64, 2, 136), (300, 8, 7168)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("scale,with_addend", [(1.0, True), (16.0, True), (2.5, False), (0.3, True)])
+def test_moe_sum_scale_add_has_the_bits_of_the_three_launches(ops, device, T, topk, H, dtype, scale, with_addend):
+    """DeepseekV2MoE.forward (models/deepseek_v2.py:139-160): moe_sum, `* routed_scaling_factor`, `+ shared_output`;
+    the one-launch form rounds to the storage type after each of the three like the separate kernels do."""
+    torch.manual_seed(T * topk + H)
+    x = torch.randn(T, topk, H, device=device).to(dtype)
+    addend = torch.randn(T, H, device=device).to(dtype) if with_addend else None
+    want = ops.moe_sum(x)
+    if scale != 1.0:
+        want = want * scale
+    if addend is not None:
+        want = want + addend
+    got = ops.moe_sum_scale_add(x, scale, addend)
+    assert torch.equal(got, want)
+    if addend is not None:
+        with pytest.raises(RuntimeError):
+            ops.moe_sum_scale_add(x, scale, addend[:, : H // 2])
+
+
 @pytest.mark.parametrize("T,topk,E,N,K", [(512, 6, 64, 2816, 2048), (700, 4, 8, 352, 192), (400, 8, 16, 2048, 1408),
                                           (2100, 1, 3, 96, 64)])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
