@@ -25,6 +25,7 @@ from semi_pd_amd.managers.io_struct import (BatchTokenIDOut, SamplingParams, Shu
                                             TokenizedGenerateReqInput)
 from semi_pd_amd.distributed import get_custom_all_reduce
 from semi_pd_amd.managers.transport import PullSocket, PushSocket
+from semi_pd_amd.semi_pd import ttft_trace
 from semi_pd_amd.semi_pd.utils import AggregatedSocket, InstanceRole
 from semi_pd_amd.server_args import SemiPDPortArgs, ServerArgs
 
@@ -302,6 +303,7 @@ class Engine:
         self._finished[rid] = None
         self._token_times[rid] = []
         self._send_time[rid] = time.time()
+        ttft_trace.mark("client_send", [rid])
         if self.scheduler is not None:
             self._inbox.append(req)
         else:
@@ -331,6 +333,8 @@ class Engine:
                         and obj.output_token_logprobs[i] is not None:
                     self._logprobs[rid]["token"].extend(obj.output_token_logprobs[i])
                     self._logprobs[rid]["top"].extend(obj.output_top_logprobs[i])
+                if not self._token_times[rid]:
+                    ttft_trace.mark("client_first_token", [rid])
                 self._token_times[rid].extend([now] * len(toks))
                 if fin is not None:
                     self._finished[rid] = fin

@@ -17,6 +17,7 @@ from semi_pd_amd.managers.io_struct import (BatchProcessPrefillResultReq, GetNex
                                             GetNextPrefillBatchOutput, TokenizedGenerateReqInput)
 from semi_pd_amd.managers.schedule_batch import AddReqResult, Req, ScheduleBatch, host_list_to_device
 from semi_pd_amd.managers.scheduler import SchedulerBase
+from semi_pd_amd.semi_pd import ttft_trace
 from semi_pd_amd.semi_pd.utils import InstanceRole
 
 logger = logging.getLogger(__name__)
@@ -136,6 +137,7 @@ class SemiPDDecodeScheduler(SchedulerBase):
             # the previous chunk is still running in P: answer "nothing yet"
             self._reply_empty()
             return
+        ttft_trace.mark("d_got_proposal", recv_req.rids)
         batch = self._admit(recv_req)
         if batch is None:
             self._reply_empty()
@@ -172,10 +174,12 @@ class SemiPDDecodeScheduler(SchedulerBase):
         """semi_pd_decode_scheduler.py:339-377."""
         batch = self.scheduled_prefill_batches.pop(0)
         assert len(batch.reqs) == len(recv_req.next_token_ids)
+        ttft_trace.mark("d_got_result", [r.rid for r in batch.reqs])
         if self.tp_size > 1:
             barrier_cpu()
         batch.output_ids = host_list_to_device(recv_req.next_token_ids, torch.int64, self.device)
         self.process_batch_result_prefill(batch, recv_req.next_token_ids, recv_req.next_token_logprobs)
+        ttft_trace.mark("d_streamed", [r.rid for r in batch.reqs])
         n_before = len(batch.reqs)
         batch.filter_batch(chunked_req_to_exclude=self.chunked_req)
         if len(batch.reqs) < n_before or self.running_batch.is_empty():

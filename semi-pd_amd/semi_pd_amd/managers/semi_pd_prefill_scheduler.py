@@ -12,10 +12,11 @@ from typing import List, Optional
 import torch
 
 from semi_pd_amd.distributed import broadcast_pyobj
-from semi_pd_amd.managers.io_struct import (BatchProcessPrefillResultReq, GetNextPrefillBatchInput,
-                                            GetNextPrefillBatchOutput)
+from semi_pd_amd.managers.io_struct import (AbortReq, BatchProcessPrefillResultReq, GetNextPrefillBatchInput,
+                                            GetNextPrefillBatchOutput, TokenizedGenerateReqInput)
 from semi_pd_amd.managers.schedule_batch import ScheduleBatch
 from semi_pd_amd.managers.scheduler import SchedulerBase
+from semi_pd_amd.semi_pd import ttft_trace
 from semi_pd_amd.semi_pd.utils import InstanceRole
 
 logger = logging.getLogger(__name__)
@@ -30,6 +31,20 @@ class SemiPDPrefillScheduler(SchedulerBase):
         # before the running one's ids are read, so the GPU does not idle between prefill batches
         self.enable_overlap = not getattr(server_args, "disable_overlap_schedule", False)
         self._inflight = None             # (batch, ids on the host side, event, logits_output, t_launch)
+        # late binding (on by default, one GPU per instance; SEMIPD_PREFILL_LATE_BIND=0: the early proposal of round 2):
+        # the batch that follows a running one is put together as late as its launch still lands behind the running
+        # one without a gap -- requests that arrive while a batch runs make the NEXT batch instead of the one after it
+        self.late_bind = (self.enable_overlap and server_args.tp_size == 1 and recv_socket is not None
+                          and torch.device(model_runner.device).type == "cuda"
+                          and os.environ.get("SEMIPD_PREFILL_LATE_BIND", "1") != "0")
+        self.lead_s = float(os.environ.get("SEMIPD_PREFILL_LEAD_MS", "4.0")) * 1e-3
+        self._s_per_token = None          # running estimate: GPU seconds per prefilled token
+        self._gpu_free_at = 0.0           # when the last finished batch left the GPU (perf_counter)
+        self._watch = None                # the running batch whose end the layer hooks of the next launch look for
+        self._in_wait = False
+        self._deferred_input: list = []   # messages a wait set aside for the loop top
+        if self.late_bind:
+            self._install_layer_hooks(model_runner)
         self._proposal_in_flight = False  # a GetNextPrefillBatchInput whose reply has not been read yet
         self._aborted: set = set()        # rids the client gave up on (see abort_request)
         self.chunked_rid: Optional[str] = None
@@ -37,6 +52,7 @@ class SemiPDPrefillScheduler(SchedulerBase):
         self.bridge_socket = bridge_socket            # PULL <- D's replies (rank 0 only)
 
     def add_to_waiting_queue(self, req):
+        ttft_trace.mark("p_recv", [req.rid])
         if req.is_retracted:
             # retracted requests jump the queue, like the decode side does (semi_pd_decode_scheduler.py:137)
             self.waiting_queue.insert(0, req)
@@ -99,6 +115,7 @@ class SemiPDPrefillScheduler(SchedulerBase):
             candidates.append(r.rid)
         if not candidates:
             return False
+        ttft_trace.mark("p_propose", candidates)
         self.send_to_d_instance.send_pyobj(GetNextPrefillBatchInput(rids=candidates))
         return True
 
@@ -137,6 +154,7 @@ class SemiPDPrefillScheduler(SchedulerBase):
         if resp is not None:
             self._purge_aborted(list(resp.rids) + ([resp.chunked_rid] if resp.chunked_rid else []))
         if resp and len(resp.rids) > 0:
+            ttft_trace.mark("p_admitted", resp.rids)
             return self.to_extend_batch(resp)
         if resp is not None:
             self._rejected = True  # the decode instance has no room right now: back off a little
@@ -151,6 +169,82 @@ class SemiPDPrefillScheduler(SchedulerBase):
         if self.tp_rank == 0:
             self.send_to_d_instance.send_pyobj(BatchProcessPrefillResultReq(
                 next_token_ids=ids, next_token_logprobs=self.extract_logprobs(logits_output)))
+
+    # ---------------------------------------------------------------------------- late binding
+    # what may be handled while a batch is on the GPU: enqueueing a request (host list) and noting an abort (a set);
+    # everything else (statistics, flush, shutdown) waits for the loop top, in arrival order
+    _SERVICED_IN_WAIT = (TokenizedGenerateReqInput, AbortReq)
+
+    def _install_layer_hooks(self, model_runner):
+        """Launching a prefill batch keeps the host busy for ~5 ms (eager launches, layer by layer).  When that batch
+        is queued BEHIND a running one, the running one usually ends inside those 5 ms: the hook (called before every
+        decoder layer) then sends its first tokens at once instead of after the last launch."""
+        import torch.nn as nn
+        model = getattr(model_runner, "model", None)
+        if model is None:
+            return
+        for m in model.modules():
+            if isinstance(m, nn.ModuleList):
+                for layer in m:
+                    layer.register_forward_pre_hook(self._between_layers)
+
+    def _between_layers(self, module, args):
+        w = self._watch
+        # (not with logprobs to fetch: that copy would queue behind the layers already launched)
+        if w is not None and getattr(w[3], "next_token_logprobs", None) is None and w[2].query():
+            self._watch = None
+            self._finish(w)
+
+    def _predicted_end(self, inflight) -> float:
+        batch, _, _, _, t0 = inflight
+        per_token = self._s_per_token if self._s_per_token is not None else 20e-6
+        return max(t0, self._gpu_free_at) + per_token * batch.extend_num_tokens
+
+    def _wait_launching_next(self, prev):
+        """Wait for `prev` on the GPU; take new requests meanwhile; `lead_s` before its predicted end ask the decode
+        instance for the next batch (everything that has arrived until then) and launch it behind `prev`.  `prev` is
+        finished -- its ids sent -- by the first layer hook of that launch that finds it done, or here."""
+        ev = prev[2]
+        launch_at = self._predicted_end(prev) - self.lead_s
+        launched = False
+        self._in_wait = True
+        try:
+            while not ev.query():
+                recv = self.recv_requests()
+                if recv:
+                    now = [r for r in recv if isinstance(r, self._SERVICED_IN_WAIT)]
+                    self._deferred_input.extend(r for r in recv if not isinstance(r, self._SERVICED_IN_WAIT))
+                    self.process_input_requests(now)
+                if (not launched and self.chunked_rid is None and (self._proposal_in_flight or self.waiting_queue)
+                        and time.perf_counter() >= launch_at):
+                    self._rejected = False
+                    nxt = self.get_next_batch_to_run(block=False)
+                    if nxt is not None:
+                        launched = True
+                        self._watch = prev
+                        try:
+                            self._launch(nxt)      # self._inflight = nxt; a layer hook may finish prev on the way
+                        finally:
+                            watched, self._watch = self._watch, None
+                        if watched is None:
+                            return                 # a hook has finished prev
+                    elif self._rejected:           # the decode instance has no room: ask again a little later
+                        launch_at = time.perf_counter() + 1e-3
+                    continue                       # (proposal in flight: poll for the reply without the sleep)
+                time.sleep(50e-6)
+        finally:
+            self._in_wait = False
+        if not launched:
+            self._inflight = None
+        self._finish(prev)
+
+    def recv_requests(self) -> list:
+        """The loop top also gets what a wait set aside (in arrival order, before anything newer)."""
+        recv = super().recv_requests()
+        if self._deferred_input and not self._in_wait:
+            recv = self._deferred_input + recv
+            self._deferred_input = []
+        return recv
 
     def step(self) -> bool:
         self.process_input_requests(self.recv_requests())
@@ -170,6 +264,9 @@ class SemiPDPrefillScheduler(SchedulerBase):
             if batch is None:
                 return False
             self._launch(batch)
+            return True
+        if self.late_bind and self._inflight[2] is not None:
+            self._wait_launching_next(self._inflight)
             return True
         nxt = self.get_next_batch_to_run(block=False) if self.chunked_rid is None else None
         prev = self._inflight
@@ -191,7 +288,8 @@ class SemiPDPrefillScheduler(SchedulerBase):
         else:
             host_ids, ev = next_token_ids, None
         self._inflight = (batch, host_ids, ev, logits_output, t0)
-        if os.environ.get("SEMIPD_EARLY_PROPOSE", "1") != "0":
+        ttft_trace.mark("p_launched", [r.rid for r in batch.reqs])
+        if not self.late_bind and os.environ.get("SEMIPD_EARLY_PROPOSE", "1") != "0":
             self.request_next_batch_early()
 
     def _finish(self, inflight=None):
@@ -200,6 +298,13 @@ class SemiPDPrefillScheduler(SchedulerBase):
         batch, host_ids, ev, logits_output, t0 = inflight
         if ev is not None:
             ev.synchronize()  # the batch and the copy of its ids are done: every KV row it wrote is in HBM
+        t_done = time.perf_counter()
+        ttft_trace.mark("p_done", [r.rid for r in batch.reqs])
+        if ev is not None and batch.extend_num_tokens >= 128:
+            # GPU seconds per token of this batch: it started when it was launched or when the one before it ended
+            per_token = (t_done - max(t0, self._gpu_free_at)) / batch.extend_num_tokens
+            self._s_per_token = per_token if self._s_per_token is None else 0.7 * self._s_per_token + 0.3 * per_token
+        self._gpu_free_at = t_done
         self.process_batch_result_prefill(batch, host_ids, logits_output)
         self.stats["t_forward_s"] = self.stats.get("t_forward_s", 0.0) + time.perf_counter() - t0
         self.stats["prefill_reqs"] = self.stats.get("prefill_reqs", 0) + len(batch.reqs)

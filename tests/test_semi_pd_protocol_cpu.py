@@ -330,3 +330,97 @@ def test_wait_for_a_step_services_only_the_pd_messages_and_defers_the_rest():
     d._in_wait = True
     with pytest.raises(AssertionError):
         d._wait_servicing(Ev())
+
+
+def _late_binding_rig(finish_in_hook):
+    """P and D in one process; P's batches carry a fake event (the CPU path has none) so that the late-binding wait of
+    the GPU path runs: the event of the first batch completes only after `done["first"]` is set."""
+    import time
+    sa = args()
+    d_runner = make_runner()
+    p_runner = make_runner(shared=d_runner)
+    kv = torch.zeros(4001, dtype=torch.int64)
+    d_in, p_in, out, bridge = Q(), Q(), Q(), Q()
+    d = SemiPDDecodeScheduler(sa, d_runner, 0, d_in, out, bridge, p_in)
+    p = SemiPDPrefillScheduler(sa, p_runner, 0, p_in, d_in, bridge)
+    bridge.pump = d.step
+    state = {"polls": 0, "first_done": False, "order": []}
+
+    class HookedWorker(FakeWorker):   # a model whose layers call the scheduler's hook, like the real one's
+        def forward_batch_generation(self, mwb):
+            if finish_in_hook and len(state["order"]) == 1:
+                state["first_done"] = True        # the running batch ends while the next one is being launched
+            p._between_layers(None, ())
+            return super().forward_batch_generation(mwb)
+
+    d.tp_worker, p.tp_worker = FakeWorker(d_runner, kv), HookedWorker(p_runner, kv)
+    p.late_bind, p.lead_s = True, 0.0
+
+    def send(rid, prompt):
+        r = TokenizedGenerateReqInput(rid, None, list(prompt), SamplingParams(max_new_tokens=3, ignore_eos=True))
+        d_in.send_pyobj(r)
+        p_in.send_pyobj(r)
+
+    class Ev:
+        def __init__(self, first):
+            self.first = first
+
+        def query(self):
+            d.step()                              # the decode instance is another process: it runs meanwhile
+            if not self.first:
+                return True
+            state["polls"] += 1
+            if state["polls"] == 2:
+                send("b", prompts[1])
+            if state["polls"] == 5:
+                send("c", prompts[2])
+                from semi_pd_amd.managers.io_struct import StatsReq
+                p_in.send_pyobj(StatsReq(reset=True))
+            if not finish_in_hook and state["polls"] > 40:
+                state["first_done"] = True
+            return state["first_done"]
+
+        def synchronize(self):
+            assert self.query(), "a batch was waited for with a blocking call before it was done"
+
+    launch = p._launch
+
+    def launch_with_event(batch):
+        launch(batch)
+        b, ids, _, lo, t0 = p._inflight
+        p._inflight = (b, ids, Ev(first=not state["order"]), lo, t0)
+        state["order"].append([r.rid for r in b.reqs])
+
+    p._launch = launch_with_event
+    handle_stats = p.handle_stats
+    state["stats_handled_in_wait"] = []
+    p.handle_stats = lambda req: (state["stats_handled_in_wait"].append(p._in_wait), handle_stats(req))
+    # the next batch is asked for 30 ms after the wait begins: "b" and "c" have both arrived by then
+    p._predicted_end = lambda prev: time.perf_counter() + 0.03
+    prompts = prompts_of([40, 33, 21], seed=5)
+    send("a", prompts[0])
+    got = {}
+    for _ in range(400):
+        p.step()
+        d.step()
+        while out.q:
+            o = out.q.popleft()
+            for rid, toks in zip(o.rids, o.output_ids):
+                got.setdefault(rid, []).extend(toks)
+        if len(got) == 3 and all(len(v) >= 3 for v in got.values()):
+            break
+    return p, d, state, got, prompts
+
+
+@pytest.mark.parametrize("finish_in_hook", [False, True])
+def test_late_binding_puts_arrivals_during_a_batch_into_the_next_one(finish_in_hook):
+    """While a prefill batch runs, new requests are taken from the socket; shortly before the batch's predicted end
+    ONE next batch is admitted with everything that has arrived and launched behind it; the running batch's ids go
+    out as soon as it is done -- from the layer hook of the launch in progress, or from the wait -- and before the
+    next batch's (the decode instance matches results to admissions in order).  Other messages wait for the loop top."""
+    p, d, state, got, prompts = _late_binding_rig(finish_in_hook)
+    assert state["order"] == [["a"], ["b", "c"]], state["order"]
+    assert state["stats_handled_in_wait"] == [False] and not p._deferred_input
+    for rid, pr in zip("abc", prompts):
+        assert got[rid][:3] == expected(pr, 3), rid
+    assert not d.scheduled_prefill_batches and not p.waiting_queue and p._inflight is None
