@@ -48,12 +48,15 @@ def select_experts(hidden_states: torch.Tensor, router_logits: torch.Tensor, top
 
 # rows (tokens x top-k) from which the expert GEMMs take the 256-row-block tiled kernel, and the least average rows per
 # expert (below that the padding to 256 per expert costs more than the faster tile buys).  DeepSeek-V2-Lite experts,
-# whole fused MoE: T = 2048 410 -> 362 us, 4096 702 -> 611, 8192 1158 -> 1032 (0.73 -> 0.82 PFLOP/s); T = 1024 276 -> 330
+# whole fused MoE: T = 2048 410 -> 362 us, 4096 702 -> 611, 8192 1158 -> 1032 (0.73 -> 0.82 PFLOP/s)
 # (profiles/r03_kbench_moe_tall_blocks.txt)
-MOE_TALL_MIN_ROWS = int(os.environ.get("SEMIPD_MOE_TALL_MIN_ROWS", "12288"))
-MOE_TALL_MIN_ROWS_PER_EXPERT = int(os.environ.get("SEMIPD_MOE_TALL_MIN_ROWS_PER_EXPERT", "192"))
-
-
+MOE_TALL_MIN_ROWS = int(os.environ.get("SEMIPD_MOE_TALL_MIN_ROWS", "4096"))
+MOE_TALL_MIN_ROWS_PER_EXPERT = int(os.environ.get("SEMIPD_MOE_TALL_MIN_ROWS_PER_EXPERT", "128"))
+# below those bounds, from this many rows per expert up: the 128-row x 512-column geometry of the same kernel (most experts
+# are one block; the 256-row geometry takes over where most would be two).  One prefill request of DeepSeek-V2-Lite on
+# the 128-CU share: T = 512 338 -> 306 us, 1024 381 -> 331, 1280 ~470 -> 417; from 1408 tokens the 256-row geometry
+# (632 -> 463 at 1536) (profiles/r03_kbench_moe_mid_geometry.txt)
+MOE_MID_MIN_ROWS_PER_EXPERT = int(os.environ.get("SEMIPD_MOE_MID_MIN_ROWS_PER_EXPERT", "40"))
 MOE_STREAM_DECODE = os.environ.get("SEMIPD_MOE_STREAM_DECODE", "1") != "0"   # A/B knob: 0 = the register-fragment kernel
 MOE_STREAM_MAX_TOKENS = int(os.environ.get("SEMIPD_MOE_STREAM_MAX_TOKENS", "320"))
 
@@ -96,8 +99,15 @@ def fused_experts(hidden_states: torch.Tensor, w1: torch.Tensor, w2: torch.Tenso
     # kernel (csrc/stream_linear.hip), SiLU * mul in GEMM1's epilogue
     small = (MOE_STREAM_DECODE and T <= MOE_STREAM_MAX_TOKENS and ops.moe_stream_gemm_is_supported(hidden_states, w1, True)
              and w2.shape[2] % 128 == 0 and K % 16 == 0)
-    block_m = ops.MOE_TALL_BLOCK_M if tall else (min(64, 16 * -(-T // 16)) if small else
-                                                 (MOE_BLOCK_M if numel <= 2048 else 2 * MOE_BLOCK_M))
+    # in between (one prefill request of a many-expert model: ~100 rows per expert): the same kernel in its 128-row x
+    # 512-column geometry -- half the padding, and every expert's weights are read by one row of tiles
+    if not tall and not small and (numel >= MOE_MID_MIN_ROWS_PER_EXPERT * E and ops.moe_gemm_tall_is_supported(hidden_states, w1, True)
+                                   and w2.shape[2] % 64 == 0 and K % 16 == 0):
+        tall, tall_block = True, 128
+    else:
+        tall_block = ops.MOE_TALL_BLOCK_M
+    block_m = tall_block if tall else (min(64, 16 * -(-T // 16)) if small else
+                                       (MOE_BLOCK_M if numel <= 2048 else 2 * MOE_BLOCK_M))
     max_sorted = -(-(numel + E * (block_m - 1)) // block_m) * block_m
     sorted_ids = torch.empty(max_sorted, dtype=torch.int32, device=dev)
     expert_ids = torch.empty((max_sorted + block_m - 1) // block_m, dtype=torch.int32, device=dev)
@@ -112,9 +122,11 @@ def fused_experts(hidden_states: torch.Tensor, w1: torch.Tensor, w2: torch.Tenso
         return _finish(c3.view(T, topk, K), out_scale, out_addend)
     if tall:
         c2 = torch.empty((numel, N2 // 2), dtype=dt, device=dev)
-        ops.moe_gemm_tall(hidden_states, w1, c2, None, sorted_ids, expert_ids, num_post_pad, numel, topk, False, True)
+        ops.moe_gemm_tall(hidden_states, w1, c2, None, sorted_ids, expert_ids, num_post_pad, numel, topk, False, True,
+                          block_m=block_m)
         c3 = (torch.zeros if partial_experts else torch.empty)((numel, K), dtype=dt, device=dev)
-        ops.moe_gemm_tall(c2, w2, c3, topk_weights.reshape(-1), sorted_ids, expert_ids, num_post_pad, numel, 1, True, False)
+        ops.moe_gemm_tall(c2, w2, c3, topk_weights.reshape(-1), sorted_ids, expert_ids, num_post_pad, numel, 1, True, False,
+                          block_m=block_m)
         return _finish(c3.view(T, topk, K), out_scale, out_addend)
     # prefill-sized calls: SiLU * mul in GEMM1's epilogue (no [T * k, 2N] intermediate); same bits as the two calls
     c2 = ops.moe_grouped_gemm_silu(hidden_states, w1, sorted_ids, expert_ids, num_post_pad, numel, topk, block_m)

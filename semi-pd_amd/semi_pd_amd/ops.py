@@ -823,14 +823,17 @@ def moe_gemm_tall_is_supported(a: torch.Tensor, w: torch.Tensor, fuse_silu_mul: 
 
 def moe_gemm_tall(a: torch.Tensor, w: torch.Tensor, c: torch.Tensor, topk_weights: Optional[torch.Tensor],
                   sorted_token_ids: torch.Tensor, expert_ids: torch.Tensor, num_tokens_post_pad: torch.Tensor,
-                  num_valid: int, top_k_div: int, mul_routed_weight: bool, fuse_silu_mul: bool = False) -> None:
-    """invoke_fused_moe_kernel (fused_moe.py:501-612) for prefill-sized calls with the 256 x 256 ping-pong tile kernel
-    (csrc/gemm8p.hip, grouped form): sorted_token_ids / expert_ids must come from moe_align_block_size with block size
-    MOE_TALL_BLOCK_M.  c[id] = a[id // top_k_div] @ w[expert].T (SiLU(gate) * up of it with fuse_silu_mul)."""
+                  num_valid: int, top_k_div: int, mul_routed_weight: bool, fuse_silu_mul: bool = False,
+                  block_m: Optional[int] = None) -> None:
+    """invoke_fused_moe_kernel (fused_moe.py:501-612) for prefill-sized calls with the ping-pong tile kernel
+    (csrc/gemm8p.hip, grouped form; 256 x 256 tiles for block_m = 256, 128 rows x 512 columns for block_m = 128):
+    sorted_token_ids / expert_ids must come from moe_align_block_size with block size block_m (default
+    MOE_TALL_BLOCK_M).  c[id] = a[id // top_k_div] @ w[expert].T (SiLU(gate) * up of it with fuse_silu_mul)."""
     E, N, K = w.shape
     n_out = N // 2 if fuse_silu_mul else N
+    block_m = MOE_TALL_BLOCK_M if block_m is None else int(block_m)
     if not moe_gemm_tall_is_supported(a, w, fuse_silu_mul) or c.shape[-1] != n_out or not c.is_contiguous() \
-            or MOE_TALL_BLOCK_M not in (128, 256) or sorted_token_ids.numel() % MOE_TALL_BLOCK_M:
+            or block_m not in (128, 256) or sorted_token_ids.numel() % block_m:
         raise RuntimeError("moe_gemm_tall: shape / contiguity / block-size mismatch")
     if sorted_token_ids.dtype != torch.int32 or expert_ids.dtype != torch.int32 or num_tokens_post_pad.dtype != torch.int32:
         raise RuntimeError("moe_gemm_tall: int32 routing tensors expected")
@@ -838,7 +841,7 @@ def moe_gemm_tall(a: torch.Tensor, w: torch.Tensor, c: torch.Tensor, topk_weight
         raise RuntimeError("moe_gemm_tall: fp32 topk_weights required")
     check(_lib.load().semipd_moe_gemm_tall(ptr(c), ptr(a), ptr(w), ptr(topk_weights), ptr(sorted_token_ids), ptr(expert_ids),
                                            ptr(num_tokens_post_pad), num_valid, N, K, sorted_token_ids.numel(), top_k_div,
-                                           int(mul_routed_weight), int(fuse_silu_mul), int(MOE_TALL_BLOCK_M),
+                                           int(mul_routed_weight), int(fuse_silu_mul), block_m,
                                            dtype_code(a.dtype), current_stream(a.device)), "moe_gemm_tall")
 
 

@@ -1110,8 +1110,10 @@ def test_gemm_tall_silu_mul_equals_the_unfused_pair(ops, device, dtype, M, I, K)
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("T,E,topk,K,N", [(700, 8, 2, 256, 192), (1500, 16, 6, 2048, 1408), (300, 4, 1, 128, 64)])
-def test_moe_gemm_tall_matches_fp32_per_expert(ops, device, dtype, T, E, topk, K, N):
-    """The grouped form of the tiled kernel on 256-row blocks (invoke_fused_moe_kernel, fused_moe.py:501-612): every routed
+@pytest.mark.parametrize("bm", [256, 128])
+def test_moe_gemm_tall_matches_fp32_per_expert(ops, device, dtype, T, E, topk, K, N, bm):
+    """The grouped form of the tiled kernel on 256-row blocks (256 x 256 tiles) and on 128-row blocks (128 rows x 512
+    columns) (invoke_fused_moe_kernel, fused_moe.py:501-612): every routed
     entry id gets a[id // top_k] @ w[expert(id)]^T -- checked row by row against fp32 products; GEMM1 with the SiLU * mul
     epilogue equals silu_and_mul of its own plain output bit for bit; GEMM2 multiplies by the routed weight before the
     rounding; padding entries (>= num_valid) write nothing (c is pre-filled with a sentinel)."""
@@ -1121,7 +1123,7 @@ def test_moe_gemm_tall_matches_fp32_per_expert(ops, device, dtype, T, E, topk, K
     w2 = (torch.randn(E, K, N, generator=g) * N ** -0.5).to(dtype).to(device)
     logits = torch.randn(T, E, generator=g).to(device)
     tw, ti = ops.topk_softmax(logits, topk, True)
-    numel, bm = T * topk, ops.MOE_TALL_BLOCK_M
+    numel = T * topk
     max_sorted = -(-(numel + E * (bm - 1)) // bm) * bm
     sorted_ids = torch.empty(max_sorted, dtype=torch.int32, device=device)
     expert_ids = torch.empty(max_sorted // bm, dtype=torch.int32, device=device)
@@ -1132,7 +1134,7 @@ def test_moe_gemm_tall_matches_fp32_per_expert(ops, device, dtype, T, E, topk, K
     rows = torch.arange(numel, device=device) // topk
     # GEMM1 plain and fused
     c1 = torch.full((numel, 2 * N), 77.0, dtype=dtype, device=device)
-    ops.moe_gemm_tall(a, w1, c1, None, sorted_ids, expert_ids, npp, numel, topk, False, False)
+    ops.moe_gemm_tall(a, w1, c1, None, sorted_ids, expert_ids, npp, numel, topk, False, False, block_m=bm)
     def per_expert(x_rows, w, scale=None):       # fp32 reference, one expert at a time (a gather of w would not fit)
         want = torch.empty(numel, w.shape[1], dtype=torch.float32, device=device)
         for e in range(E):
@@ -1143,11 +1145,11 @@ def test_moe_gemm_tall_matches_fp32_per_expert(ops, device, dtype, T, E, topk, K
 
     torch.testing.assert_close(c1.float(), per_expert(a[rows], w1), rtol=tol, atol=tol)
     c2 = torch.full((numel, N), 77.0, dtype=dtype, device=device)
-    ops.moe_gemm_tall(a, w1, c2, None, sorted_ids, expert_ids, npp, numel, topk, False, True)
+    ops.moe_gemm_tall(a, w1, c2, None, sorted_ids, expert_ids, npp, numel, topk, False, True, block_m=bm)
     assert torch.equal(c2, ops.silu_and_mul(c1))
     # GEMM2 with the routed weight
     c3 = torch.full((numel, K), 77.0, dtype=dtype, device=device)
-    ops.moe_gemm_tall(c2, w2, c3, tw.reshape(-1), sorted_ids, expert_ids, npp, numel, 1, True, False)
+    ops.moe_gemm_tall(c2, w2, c3, tw.reshape(-1), sorted_ids, expert_ids, npp, numel, 1, True, False, block_m=bm)
     torch.testing.assert_close(c3.float(), per_expert(c2, w2, tw.reshape(-1, 1).float()), rtol=tol, atol=tol)
 
 
@@ -1161,14 +1163,24 @@ def test_fused_experts_takes_the_tall_kernel_for_prefill_sized_calls(ops, device
     w1 = (torch.randn(E, 2 * N, K, generator=g) * K ** -0.5).to(torch.bfloat16).to(device)
     w2 = (torch.randn(E, K, N, generator=g) * N ** -0.5).to(torch.bfloat16).to(device)
     tw, ti = ops.topk_softmax(torch.randn(T, E, generator=g).to(device), k, True)
+    calls = []
+    real = ops.moe_gemm_tall
+    monkeypatch.setattr(ops, "moe_gemm_tall", lambda *a, **kw: (calls.append(kw.get("block_m")), real(*a, **kw))[1])
     monkeypatch.setattr(M, "MOE_TALL_MIN_ROWS", 1 << 30)
+    monkeypatch.setattr(M, "MOE_MID_MIN_ROWS_PER_EXPERT", 1 << 30)
     base = M.fused_experts(x, w1, w2, tw, ti)
-    monkeypatch.setattr(M, "MOE_TALL_MIN_ROWS", 1024)
-    monkeypatch.setattr(M, "MOE_TALL_MIN_ROWS_PER_EXPERT", 128)
-    tall = M.fused_experts(x, w1, w2, tw, ti)
+    assert not calls
     want = O.fused_moe(x.float().cpu(), w1.float().cpu(), w2.float().cpu(), tw.cpu(), ti.cpu().long())
-    torch.testing.assert_close(tall.float().cpu(), want.float(), rtol=3e-2, atol=3e-2)
-    torch.testing.assert_close(tall.float(), base.float(), rtol=3e-2, atol=3e-2)
+    # 256 rows per expert here: the 256-row geometry above its bounds, the 128-row one between its bound and those
+    for tall_min, mid_min, block in ((1024, 1 << 30, 256), (1 << 30, 40, 128)):
+        monkeypatch.setattr(M, "MOE_TALL_MIN_ROWS", tall_min)
+        monkeypatch.setattr(M, "MOE_TALL_MIN_ROWS_PER_EXPERT", 128)
+        monkeypatch.setattr(M, "MOE_MID_MIN_ROWS_PER_EXPERT", mid_min)
+        del calls[:]
+        tall = M.fused_experts(x, w1, w2, tw, ti)
+        assert calls == [block, block]
+        torch.testing.assert_close(tall.float().cpu(), want.float(), rtol=3e-2, atol=3e-2)
+        torch.testing.assert_close(tall.float(), base.float(), rtol=3e-2, atol=3e-2)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
