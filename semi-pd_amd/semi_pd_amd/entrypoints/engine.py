@@ -21,7 +21,7 @@ import time
 import traceback
 from typing import Dict, Iterable, List, Optional, Sequence
 
-from semi_pd_amd.managers.io_struct import (BatchTokenIDOut, SamplingParams, ShutdownReq, StatsReq,
+from semi_pd_amd.managers.io_struct import (BatchTokenIDOut, SamplingParams, ShutdownReq, StatsReq, SyntheticLoadReq,
                                             TokenizedGenerateReqInput)
 from semi_pd_amd.distributed import get_custom_all_reduce
 from semi_pd_amd.managers.transport import PullSocket, PushSocket
@@ -104,15 +104,32 @@ def run_scheduler_process(server_args: ServerArgs, port_args: SemiPDPortArgs, gp
                                bypass_load_weight=True, cu_percent=server_args.prefill_cu_percent)
             mr.share_params_from_ipc(ipc_info)      # semi_pd_scheduler.py:406-407
             mr.init_attention_backend()
+            to_d = PushSocket(port_args.d_scheduler_input_ipc_name) if rank0 else None
             tune = server_args.tune_prefill_gemm
             if tune or (tune is None and server_args.prefill_cu_percent < 100 and server_args.cu_mask_mode == "env"):
+                # the candidates are timed next to what they will run next to: the decode instance (ready and idle at
+                # this point) replays a captured decode step in a loop meanwhile
+                under_load = (rank0 and server_args.tp_size == 1
+                              and os.environ.get("SEMIPD_TUNE_UNDER_DECODE_LOAD", "1") != "0")
                 t0 = time.time()
-                table = mr.tune_dense_gemms()
-                logger.warning("library GEMM solutions timed on this share in %.1f s:\n%s", time.time() - t0, table)
+                if under_load:
+                    to_d.send_pyobj(SyntheticLoadReq(on=True))
+                    time.sleep(0.1)
+                    # watch every candidate for longer than the load's period (a decode step, ~6 ms)
+                    os.environ.setdefault("SEMIPD_DG_FIRST_US", "1500")
+                    os.environ.setdefault("SEMIPD_DG_FINAL_US", "20000")
+                    os.environ.setdefault("SEMIPD_DG_FINALISTS", "10")
+                try:
+                    table = mr.tune_dense_gemms()
+                finally:
+                    if under_load:
+                        to_d.send_pyobj(SyntheticLoadReq(on=False))
+                logger.warning("library GEMM solutions timed on this share%s in %.1f s:\n%s",
+                               " next to a running decode step" if under_load else "", time.time() - t0, table)
             sched = SemiPDPrefillScheduler(
                 server_args, mr, tp_rank,
                 recv_socket=PullSocket(port_args.p_scheduler_input_ipc_name) if rank0 else None,
-                send_to_d_instance=PushSocket(port_args.d_scheduler_input_ipc_name) if rank0 else None,
+                send_to_d_instance=to_d,
                 bridge_socket=PullSocket(port_args.bridge_ipc_name) if rank0 else None,
                 send_stats_to=PushSocket(port_args.tokenizer_ipc_name) if rank0 else None)
         torch.cuda.synchronize()

@@ -143,6 +143,14 @@ class ShutdownReq:
 
 
 @dataclass
+class SyntheticLoadReq:
+    """Prefill instance -> decode instance at start-up: replay a captured decode step in a loop while idle (on) /
+    stop (off).  The prefill instance times its GEMM candidates next to that stream of weight reads, i.e. under the
+    HBM contention they will serve in (entrypoints/engine.py)."""
+    on: bool = True
+
+
+@dataclass
 class StatsReq:
     """Ask a scheduler for its counters (kernel timing samples, steps, tokens)."""
     reset: bool = False

@@ -14,7 +14,7 @@ import torch
 
 from semi_pd_amd.distributed import barrier_cpu
 from semi_pd_amd.managers.io_struct import (BatchProcessPrefillResultReq, GetNextPrefillBatchInput,
-                                            GetNextPrefillBatchOutput, TokenizedGenerateReqInput)
+                                            GetNextPrefillBatchOutput, SyntheticLoadReq, TokenizedGenerateReqInput)
 from semi_pd_amd.managers.schedule_batch import AddReqResult, Req, ScheduleBatch, host_list_to_device
 from semi_pd_amd.managers.scheduler import SchedulerBase
 from semi_pd_amd.semi_pd import ttft_trace
@@ -40,6 +40,7 @@ class SemiPDDecodeScheduler(SchedulerBase):
         self._deferred_input: list = []               # messages a wait set aside for the loop top
         self._pinned_ids = None
         self._pinned_flip = 0
+        self._synthetic_load_until = 0.0              # see SyntheticLoadReq
 
         self.bridge_socket = bridge_socket            # PUSH -> P (replies to GetNextPrefillBatchInput)
         self.send_to_p_instance = send_to_p_instance  # PUSH -> P's input socket (retracted requests)
@@ -50,6 +51,9 @@ class SemiPDDecodeScheduler(SchedulerBase):
             self.get_next_prefill_batch(recv_req)
         elif isinstance(recv_req, BatchProcessPrefillResultReq):
             self.process_prefill_result(recv_req)
+        elif isinstance(recv_req, SyntheticLoadReq):
+            # bounded: a prefill instance that dies while tuning must not leave this one spinning
+            self._synthetic_load_until = time.monotonic() + 300.0 if recv_req.on else 0.0
         else:
             super().dispatch(recv_req)
 
@@ -343,8 +347,23 @@ class SemiPDDecodeScheduler(SchedulerBase):
             self._deferred_input = []
         return recv
 
+    def _synthetic_step(self) -> bool:
+        """One captured decode step (the graph closest to 32 requests, inputs as the capture left them: dummy slot 0)
+        for nobody: the weight stream of a busy decode instance, for the prefill instance to tune next to."""
+        gr = getattr(self.model_runner, "graph_runner", None)
+        if gr is None or self.tp_size > 1 or not gr.graphs or time.monotonic() > self._synthetic_load_until:
+            self._synthetic_load_until = 0.0
+            return False
+        bs = min(gr.graphs, key=lambda b: abs(b - 32))
+        gr.graphs[bs].replay()
+        torch.cuda.current_stream().synchronize()
+        self.last_progress = time.monotonic()
+        return True
+
     def event_loop_normal(self):
         while not self._shutdown:
             if not self.step():
+                if self._synthetic_load_until and self.running_batch.is_empty() and self._synthetic_step():
+                    continue
                 self.check_watchdog()
                 self.idle_sleep()

@@ -424,3 +424,35 @@ def test_late_binding_puts_arrivals_during_a_batch_into_the_next_one(finish_in_h
     for rid, pr in zip("abc", prompts):
         assert got[rid][:3] == expected(pr, 3), rid
     assert not d.scheduled_prefill_batches and not p.waiting_queue and p._inflight is None
+
+
+def test_synthetic_load_request_is_bounded_and_needs_a_captured_graph():
+    """SyntheticLoadReq (prefill instance -> decode instance while the prefill GEMMs are timed): on arms a deadline, off
+    clears it; without captured graphs (this CPU rig), with tensor parallelism or past the deadline nothing is replayed
+    and the flag drops, so an idle decode loop never spins for a prefill instance that went away."""
+    import time
+    from semi_pd_amd.managers.io_struct import SyntheticLoadReq
+    d_in, out, bridge, p_in = Q(), Q(), Q(), Q()
+    d = SemiPDDecodeScheduler(args(), make_runner(), 0, d_in, out, bridge, p_in)
+    d_in.send_pyobj(SyntheticLoadReq(on=True))
+    d.step()
+    assert d._synthetic_load_until > time.monotonic() + 60
+    assert d._synthetic_step() is False and d._synthetic_load_until == 0.0     # no graph runner here
+    replays = []
+    d.model_runner.graph_runner = SimpleNamespace(graphs={8: SimpleNamespace(replay=lambda: replays.append(8)),
+                                                          32: SimpleNamespace(replay=lambda: replays.append(32)),
+                                                          64: SimpleNamespace(replay=lambda: replays.append(64))})
+    d_in.send_pyobj(SyntheticLoadReq(on=True))
+    d.step()
+    sync = torch.cuda.current_stream
+    try:
+        torch.cuda.current_stream = lambda *a, **k: SimpleNamespace(synchronize=lambda: None)
+        assert d._synthetic_step() is True and replays == [32]
+        d._synthetic_load_until = time.monotonic() - 1.0                         # the deadline has passed
+        assert d._synthetic_step() is False and replays == [32]
+        d_in.send_pyobj(SyntheticLoadReq(on=True))
+        d_in.send_pyobj(SyntheticLoadReq(on=False))
+        d.step()
+        assert d._synthetic_load_until == 0.0
+    finally:
+        torch.cuda.current_stream = sync

@@ -1,0 +1,13 @@
+#!/bin/bash
+# round 3: A/B/A/B on one box: prefill GEMM solutions timed alone vs next to a replaying decode step
+OUT=gpurun_out/r03_tune_under_load; mkdir -p $OUT
+run() { name=$1; shift
+  env "$@" timeout 900 python bench.py --no-cpu-baseline --no-static-split-wave --no-saturation-wave --rate-sweep "" --steps 3 --warmup 1 > $OUT/bench_$name.json 2> $OUT/bench_$name.err
+  python -c "
+import json; d=json.loads(open('$OUT/bench_$name.json').read().strip().splitlines()[-1]); print('$name', d['value'], d['p50_ttft_ms'], d['p99_ttft_ms'], d['p50_tbt_ms'], d['p99_tbt_ms'])"
+}
+run alone_a SEMIPD_TUNE_UNDER_DECODE_LOAD=0
+run load_a SEMIPD_TUNE_UNDER_DECODE_LOAD=1
+run alone_b SEMIPD_TUNE_UNDER_DECODE_LOAD=0
+run load_b SEMIPD_TUNE_UNDER_DECODE_LOAD=1
+grep -A45 "library GEMM solutions timed" $OUT/bench_load_b.err | grep -E "timed on|rows=" > $OUT/tuning_table_under_load.txt
