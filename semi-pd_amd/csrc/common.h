@@ -36,6 +36,13 @@ void set_error(const char* fmt, ...);
 // Opt a kernel in to more than 64 KB of dynamic LDS, once per DEVICE and call site (`done` = one bit per device: the
 // attribute is per device, a second GPU in the process would otherwise fail at launch).  Returns non-zero and sets
 // the error text when the runtime refuses.
+// Compute units this process may use (its HSA_CU_MASK share), as told through semipd_stream_linear_set_cus /
+// semipd_gemm_tall_set_cus by the model runner; 0 = never told (whole device assumed by the kernels that ask).
+inline std::atomic<int>& owned_cus() {
+  static std::atomic<int> v{0};
+  return v;
+}
+
 inline int ensure_dynamic_lds(const void* kernel, size_t bytes, std::atomic<uint64_t>& done, const char* what) {
   int dev = 0;
   (void)hipGetDevice(&dev);

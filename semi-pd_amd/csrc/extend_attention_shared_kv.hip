@@ -486,7 +486,14 @@ int launch_extend_shared_kv(void* out, const void* q, const void* k, const void*
   const int g8 = group % 4 == 0 ? 4 : (group % 2 == 0 ? 2 : 1);   // heads per workgroup of the 8-wave form
   const int64_t wgs8 = (int64_t)Hkv * (group / g8) * ((max_len_extend + (4 / g8) * 32 - 1) / ((4 / g8) * 32)) * batch;
   static const int force = [] { const char* e = getenv("SEMIPD_EXTEND_KV_FORM"); return e ? atoi(e) : 0; }();   // 1 / 2
-  const int form = force == 1 || force == 2 ? force : (wgs8 > 512 ? 1 : 2);
+  // the 8-wave form keeps ONE workgroup per CU: it pays while its workgroups are whole rounds (one or two) of the CUs this
+  // process owns -- one 1024-token Llama-3 request on the whole chip (256), two (512); on a 160-CU share the same 256
+  // workgroups are 1.6 rounds and the 4-wave form (two per CU, all resident) is faster at every size
+  // (profiles/r03_kbench_extend_forms_160cu.txt: 1 x 1024 33.0 -> 31.4 us, 2 x 1024 behind prefixes 116 -> 100)
+  const int own = owned_cus().load(std::memory_order_relaxed);
+  const int64_t cus = own > 0 ? own : 256;
+  const bool whole_rounds = wgs8 <= cus || (wgs8 <= 2 * cus && wgs8 % cus == 0);
+  const int form = force == 1 || force == 2 ? force : (whole_rounds ? 2 : 1);
   const int G = g8, TB = 4 / g8;
   const unsigned gx = (unsigned)(Hkv * (group / G));
   const unsigned gy = (unsigned)((max_len_extend + TB * 32 - 1) / (TB * 32));

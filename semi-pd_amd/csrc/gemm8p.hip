@@ -479,6 +479,7 @@ extern "C" {
 int semipd_gemm_tall_set_cus(int cus) {
   SEMIPD_CHECK_ARG(cus >= 0 && cus <= 4096, SEMIPD_EINVAL, "gemm_tall_set_cus: bad CU count %d", cus);
   g_g8_cus.store(cus == 0 ? 256 : cus, std::memory_order_relaxed);
+  owned_cus().store(cus, std::memory_order_relaxed);
   return 0;
 }
 

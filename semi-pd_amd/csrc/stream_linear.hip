@@ -405,6 +405,7 @@ static int sl_env(const char* name, int dflt) {
 int semipd_stream_linear_set_cus(int cus) {
   SEMIPD_CHECK_ARG(cus >= 0 && cus <= 4096, SEMIPD_EINVAL, "stream_linear_set_cus: bad CU count %d", cus);
   g_sl_cus.store(cus == 0 ? 128 : cus, std::memory_order_relaxed);
+  owned_cus().store(cus, std::memory_order_relaxed);
   return 0;
 }
 
