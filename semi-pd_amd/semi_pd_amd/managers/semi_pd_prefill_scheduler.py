@@ -229,7 +229,7 @@ class SemiPDPrefillScheduler(SchedulerBase):
                         if watched is None:
                             return                 # a hook has finished prev
                     elif self._rejected:           # the decode instance has no room: ask again a little later
-                        launch_at = time.perf_counter() + 1e-3
+                        launch_at = time.perf_counter() + 2e-3
                     continue                       # (proposal in flight: poll for the reply without the sleep)
                 time.sleep(50e-6)
         finally:
