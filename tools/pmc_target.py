@@ -86,6 +86,19 @@ elif which == "moe8k":
     for _ in range(4):
         fused_experts(x, w1, w2, tw, ti)
     print("flop_per_call_gemm1", 2.0 * T * k * 2 * N * K, "gemm2", 2.0 * T * k * N * K)
+elif which == "moe1k":
+    # ONE prefill request of DeepSeek-V2-Lite through the fused MoE (~96 rows per expert: the 128-row x 512-column geometry
+    # of the grouped ping-pong GEMM); the expert weights (738 + 369 MB) exceed the Infinity Cache by themselves
+    from semi_pd_amd.layers.moe import fused_experts
+    E, k, K, N, T = 64, 6, 2048, 1408, 1024
+    w1 = torch.randn(E, 2 * N, K, device=dev, dtype=torch.bfloat16) * 0.02
+    w2 = torch.randn(E, K, N, device=dev, dtype=torch.bfloat16) * 0.02
+    x = torch.randn(T, K, device=dev, dtype=torch.bfloat16)
+    tw, ti = ops.topk_softmax(torch.randn(T, E, device=dev), k, True)
+    for _ in range(6):
+        fused_experts(x, w1, w2, tw, ti)
+    print("algorithmic_bytes gemm1", E * 2 * N * K * 2 + T * k * K * 2 + T * k * N * 2, "gemm2",
+          E * K * N * 2 + T * k * N * 2 + T * k * K * 2, "flop gemm1", 2.0 * T * k * 2 * N * K, "gemm2", 2.0 * T * k * N * K)
 elif which == "stream":
     # the streaming GEMM of a decode batch: Llama-3-8B gate_up + SiLU*mul (235 MB of weights, read once), 6 weight
     # copies in rotation so that the 256 MB Infinity Cache cannot serve a re-read
