@@ -466,7 +466,11 @@ def main():
             extra["prefill_batch_ms"] = {"batches": int(n), "avg_tokens": round(s["prefill_tokens"] / n, 1),
                                          "avg_requests": round(s.get("prefill_reqs", 0) / n, 2),
                                          "wait_admission": round(1e3 * s.get("t_wait_admission_s", 0) / n, 3),
-                                         "forward_and_sync": round(1e3 * s.get("t_forward_s", 0) / n, 3)}
+                                         "forward_and_sync": round(1e3 * s.get("t_forward_s", 0) / n, 3),
+                                         # batches queued behind a running one by the late-binding loop, and how many
+                                         # running batches had their first tokens sent from a layer hook of that launch
+                                         "launched_behind_a_running_batch": int(s.get("late_bound_launches", 0)),
+                                         "results_sent_from_layer_hook": int(s.get("results_sent_from_layer_hook", 0))}
         kt = s.get("kernel_timing") or {}
         def hbm_line(k, kernel):
             return {"bound": "hbm", "kernel": kernel, "achieved": round(k["gbps"], 1),

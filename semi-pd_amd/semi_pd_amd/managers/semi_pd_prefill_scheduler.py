@@ -22,6 +22,34 @@ from semi_pd_amd.semi_pd.utils import InstanceRole
 logger = logging.getLogger(__name__)
 
 
+class BatchTimeModel:
+    """GPU seconds of a prefill batch of n tokens, d = a + b n, fitted to the recent batches with exponential forgetting
+    (weighted least squares over running sums).  While the sizes seen so far do not spread (every batch one 1024-token
+    request), the ratio d / n of the weighted means stands in; before any batch, a guess of 20 us per token."""
+
+    def __init__(self, decay: float = 0.85):
+        self.decay = decay
+        self.s1 = self.sn = self.sd = self.snn = self.snd = 0.0
+
+    def update(self, n: int, d: float) -> None:
+        if n <= 0 or d <= 0:
+            return
+        k = self.decay
+        self.s1, self.sn, self.sd = k * self.s1 + 1.0, k * self.sn + n, k * self.sd + d
+        self.snn, self.snd = k * self.snn + float(n) * n, k * self.snd + n * d
+
+    def predict(self, n: int) -> float:
+        if self.s1 <= 0:
+            return 20e-6 * n
+        det = self.s1 * self.snn - self.sn * self.sn
+        if det > 1e-3 * self.s1 * self.snn:                    # the sizes spread enough for a slope
+            b = (self.s1 * self.snd - self.sn * self.sd) / det
+            a = (self.sd - b * self.sn) / self.s1
+            if b > 0 and a >= 0:
+                return a + b * n
+        return self.sd / self.sn * n
+
+
 class SemiPDPrefillScheduler(SchedulerBase):
     def __init__(self, server_args, model_runner, tp_rank, recv_socket, send_to_d_instance, bridge_socket,
                  send_stats_to=None):
@@ -38,7 +66,7 @@ class SemiPDPrefillScheduler(SchedulerBase):
                           and torch.device(model_runner.device).type == "cuda"
                           and os.environ.get("SEMIPD_PREFILL_LATE_BIND", "1") != "0")
         self.lead_s = float(os.environ.get("SEMIPD_PREFILL_LEAD_MS", "4.0")) * 1e-3
-        self._s_per_token = None          # running estimate: GPU seconds per prefilled token
+        self._batch_time = BatchTimeModel()   # GPU seconds of a batch as a function of its tokens
         self._gpu_free_at = 0.0           # when the last finished batch left the GPU (perf_counter)
         self._watch = None                # the running batch whose end the layer hooks of the next launch look for
         self._in_wait = False
@@ -193,12 +221,12 @@ class SemiPDPrefillScheduler(SchedulerBase):
         # (not with logprobs to fetch: that copy would queue behind the layers already launched)
         if w is not None and getattr(w[3], "next_token_logprobs", None) is None and w[2].query():
             self._watch = None
+            self.stats["results_sent_from_layer_hook"] = self.stats.get("results_sent_from_layer_hook", 0) + 1
             self._finish(w)
 
     def _predicted_end(self, inflight) -> float:
         batch, _, _, _, t0 = inflight
-        per_token = self._s_per_token if self._s_per_token is not None else 20e-6
-        return max(t0, self._gpu_free_at) + per_token * batch.extend_num_tokens
+        return max(t0, self._gpu_free_at) + self._batch_time.predict(batch.extend_num_tokens)
 
     def _wait_launching_next(self, prev):
         """Wait for `prev` on the GPU; take new requests meanwhile; `lead_s` before its predicted end ask the decode
@@ -221,6 +249,7 @@ class SemiPDPrefillScheduler(SchedulerBase):
                     nxt = self.get_next_batch_to_run(block=False)
                     if nxt is not None:
                         launched = True
+                        self.stats["late_bound_launches"] = self.stats.get("late_bound_launches", 0) + 1
                         self._watch = prev
                         try:
                             self._launch(nxt)      # self._inflight = nxt; a layer hook may finish prev on the way
@@ -300,10 +329,9 @@ class SemiPDPrefillScheduler(SchedulerBase):
             ev.synchronize()  # the batch and the copy of its ids are done: every KV row it wrote is in HBM
         t_done = time.perf_counter()
         ttft_trace.mark("p_done", [r.rid for r in batch.reqs])
-        if ev is not None and batch.extend_num_tokens >= 128:
-            # GPU seconds per token of this batch: it started when it was launched or when the one before it ended
-            per_token = (t_done - max(t0, self._gpu_free_at)) / batch.extend_num_tokens
-            self._s_per_token = per_token if self._s_per_token is None else 0.7 * self._s_per_token + 0.3 * per_token
+        if ev is not None:
+            # this batch had the GPU from its launch, or from the end of the batch it was queued behind
+            self._batch_time.update(batch.extend_num_tokens, t_done - max(t0, self._gpu_free_at))
         self._gpu_free_at = t_done
         self.process_batch_result_prefill(batch, host_ids, logits_output)
         self.stats["t_forward_s"] = self.stats.get("t_forward_s", 0.0) + time.perf_counter() - t0

@@ -562,3 +562,4 @@ def test_overlapped_decode_loop_equals_the_plain_loop(unified_llama):
         _explain_mismatch(oracle, prompts, padded(results[True]), outs)
     if results[True] != results[False]:
         _explain_mismatch(oracle, prompts, padded(results[True]), padded(results[False]))
+

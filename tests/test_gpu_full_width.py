@@ -69,3 +69,4 @@ def test_deepseek_v2_lite_width_two_layers_unified_and_semi_pd_match_the_oracle(
     cfg = dataclasses.replace(DEEPSEEK_V2_LITE, num_hidden_layers=2)   # layer 0 dense, layer 1 MoE
     frac_u, frac_s = _run_both(cfg, OracleDeepseekV2)
     assert frac_u >= 0.8 and frac_s >= 0.8, (frac_u, frac_s)
+

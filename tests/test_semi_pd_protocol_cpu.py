@@ -456,3 +456,28 @@ def test_synthetic_load_request_is_bounded_and_needs_a_captured_graph():
         assert d._synthetic_load_until == 0.0
     finally:
         torch.cuda.current_stream = sync
+
+
+def test_batch_time_model_recovers_an_affine_law_and_degrades_gracefully():
+    """The prefill scheduler's predictor of a batch's GPU time (late binding asks for the next batch a lead before the
+    predicted end): a guess before any sample, the ratio of the means while all batches have one size, the weighted
+    least-squares line once sizes spread, recent batches weighing more, nonsense fits (negative slope) refused."""
+    from semi_pd_amd.managers.semi_pd_prefill_scheduler import BatchTimeModel
+    m = BatchTimeModel()
+    assert m.predict(1000) == pytest.approx(0.02)
+    for _ in range(5):
+        m.update(1024, 22.3e-3)
+    assert m.predict(1024) == pytest.approx(22.3e-3, rel=1e-6) and m.predict(2048) == pytest.approx(44.6e-3, rel=1e-6)
+    for n in (2048, 1024, 3072, 1024, 2048, 1024):
+        m.update(n, 4e-3 + 17.87e-6 * n)           # T(n) = 4 ms + 18.3 ms per 1024 tokens
+    assert m.predict(2048) == pytest.approx(4e-3 + 17.87e-6 * 2048, rel=0.03)
+    assert m.predict(4096) == pytest.approx(4e-3 + 17.87e-6 * 4096, rel=0.05)
+    for _ in range(40):                            # the law changes (another share): the old samples fade
+        for n in (1024, 2048):
+            m.update(n, 2e-3 + 10e-6 * n)
+    assert m.predict(3072) == pytest.approx(2e-3 + 10e-6 * 3072, rel=0.02)
+    bad = BatchTimeModel()
+    bad.update(1000, 10e-3)
+    bad.update(2000, 5e-3)                         # a shorter time for more tokens: no line through that
+    assert bad.predict(3000) == pytest.approx((10e-3 * 0.85 + 5e-3) / (1000 * 0.85 + 2000) * 3000)
+    bad.update(0, 1.0), bad.update(10, -1.0)       # ignored
