@@ -30,10 +30,19 @@ class BatchTimeModel:
     def __init__(self, decay: float = 0.85):
         self.decay = decay
         self.s1 = self.sn = self.sd = self.snn = self.snd = 0.0
+        self._seen = 0        # samples offered
+        self._outliers = 0    # consecutive samples set aside as outliers
 
     def update(self, n: int, d: float) -> None:
         if n <= 0 or d <= 0:
             return
+        self._seen += 1
+        if self._seen == 1:
+            return            # a process's first batch pays for lazily loaded code objects and first-touch allocations
+        if self.s1 > 0 and d > 3.0 * self.predict(n) and self._outliers < 2:
+            self._outliers += 1   # a stall (another first-time shape): not the law; three in a row ARE the law
+            return
+        self._outliers = 0
         k = self.decay
         self.s1, self.sn, self.sd = k * self.s1 + 1.0, k * self.sn + n, k * self.sd + d
         self.snn, self.snd = k * self.snn + float(n) * n, k * self.snd + n * d

@@ -465,8 +465,13 @@ def test_batch_time_model_recovers_an_affine_law_and_degrades_gracefully():
     from semi_pd_amd.managers.semi_pd_prefill_scheduler import BatchTimeModel
     m = BatchTimeModel()
     assert m.predict(1000) == pytest.approx(0.02)
+    m.update(1024, 95e-3)                          # a process's first batch (lazy code-object loads): not a sample
+    assert m.predict(1000) == pytest.approx(0.02)
     for _ in range(5):
         m.update(1024, 22.3e-3)
+    m.update(1024, 90e-3)                          # one stall: set aside ...
+    assert m.predict(1024) == pytest.approx(22.3e-3, rel=1e-6)
+    m.update(1024, 22.3e-3)
     assert m.predict(1024) == pytest.approx(22.3e-3, rel=1e-6) and m.predict(2048) == pytest.approx(44.6e-3, rel=1e-6)
     for n in (2048, 1024, 3072, 1024, 2048, 1024):
         m.update(n, 4e-3 + 17.87e-6 * n)           # T(n) = 4 ms + 18.3 ms per 1024 tokens
@@ -476,7 +481,14 @@ def test_batch_time_model_recovers_an_affine_law_and_degrades_gracefully():
         for n in (1024, 2048):
             m.update(n, 2e-3 + 10e-6 * n)
     assert m.predict(3072) == pytest.approx(2e-3 + 10e-6 * 3072, rel=0.02)
+    slow = BatchTimeModel()
+    slow.update(1024, 1.0)
+    slow.update(1024, 10e-3)
+    for _ in range(3):                             # ... three in a row are the new law
+        slow.update(1024, 50e-3)
+    assert slow.predict(1024) > 20e-3
     bad = BatchTimeModel()
+    bad.update(500, 1.0)                           # (first sample of a process: skipped)
     bad.update(1000, 10e-3)
     bad.update(2000, 5e-3)                         # a shorter time for more tokens: no line through that
     assert bad.predict(3000) == pytest.approx((10e-3 * 0.85 + 5e-3) / (1000 * 0.85 + 2000) * 3000)
