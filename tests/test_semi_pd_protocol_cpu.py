@@ -493,3 +493,92 @@ def test_batch_time_model_recovers_an_affine_law_and_degrades_gracefully():
     bad.update(2000, 5e-3)                         # a shorter time for more tokens: no line through that
     assert bad.predict(3000) == pytest.approx((10e-3 * 0.85 + 5e-3) / (1000 * 0.85 + 2000) * 3000)
     bad.update(0, 1.0), bad.update(10, -1.0)       # ignored
+
+
+def test_late_binding_survives_a_cold_first_batch(monkeypatch):
+    """The whole pipelined loop against a simulated GPU and clock: batches take 1 ms + 5 us per token, the process's FIRST
+    batch 60x that (lazy code-object loads).  With the real predictor (BatchTimeModel) the slow first batch must not keep
+    the following bursts from being launched behind running batches (it did, when it was a sample: the estimate stayed
+    several times too long and every batch ended before its successor was asked for)."""
+    from semi_pd_amd.managers import semi_pd_prefill_scheduler as mod
+
+    class Clock:                                   # stands in for the `time` module inside the scheduler
+        def __init__(self):
+            self.t = 100.0
+
+        def perf_counter(self):
+            self.t += 2e-6
+            return self.t
+
+        monotonic = time = perf_counter
+
+        def sleep(self, dt):
+            self.t += dt
+
+    clock = Clock()
+    monkeypatch.setattr(mod, "time", clock)
+    sa = args()
+    d_runner = make_runner()
+    p_runner = make_runner(shared=d_runner)
+    kv = torch.zeros(4001, dtype=torch.int64)
+    d_in, p_in, out, bridge = Q(), Q(), Q(), Q()
+    d = SemiPDDecodeScheduler(sa, d_runner, 0, d_in, out, bridge, p_in)
+    p = SemiPDPrefillScheduler(sa, p_runner, 0, p_in, d_in, bridge)
+    bridge.pump = d.step
+    d.tp_worker, p.tp_worker = FakeWorker(d_runner, kv), FakeWorker(p_runner, kv)
+    p.late_bind, p.lead_s = True, 0.4e-3
+    gpu = {"free_at": 0.0, "batches": 0}
+
+    class Ev:
+        def __init__(self, end):
+            self.end = end
+
+        def query(self):
+            d.step()
+            return clock.t >= self.end
+
+        def synchronize(self):
+            clock.t = max(clock.t, self.end)
+
+    launch = p._launch
+
+    def launch_on_simulated_gpu(batch):
+        launch(batch)
+        clock.t += 0.3e-3                          # the host's launches
+        b, ids, _, lo, t0 = p._inflight
+        dur = 1e-3 + 5e-6 * b.extend_num_tokens
+        if gpu["batches"] == 0:
+            dur *= 60
+        gpu["batches"] += 1
+        gpu["free_at"] = max(gpu["free_at"], t0) + dur
+        p._inflight = (b, ids, Ev(gpu["free_at"]), lo, t0)
+
+    p._launch = launch_on_simulated_gpu
+    prompts = prompts_of([200, 180, 190, 170, 160, 200], seed=9)
+    got, n_sent = {}, 0
+    for burst in range(4):
+        pending = collections.deque((f"b{burst}r{i}", pr) for i, pr in enumerate(prompts))
+        next_send = clock.t
+        for _ in range(20000):
+            if pending and clock.t >= next_send:
+                rid, pr = pending.popleft()
+                r = TokenizedGenerateReqInput(rid, None, list(pr), SamplingParams(max_new_tokens=2, ignore_eos=True))
+                d_in.send_pyobj(r), p_in.send_pyobj(r)
+                n_sent += 1
+                next_send = clock.t + 0.25e-3      # arrivals 0.25 ms apart: they fall into running batches
+            if not p.step():
+                clock.sleep(50e-6)
+            d.step()
+            while out.q:
+                o = out.q.popleft()
+                for rid, toks in zip(o.rids, o.output_ids):
+                    got.setdefault(rid, []).extend(toks)
+            if not pending and len(got) == n_sent and all(len(v) >= 2 for v in got.values()) and p._inflight is None:
+                break
+    for burst in range(4):
+        for i, pr in enumerate(prompts):
+            assert got[f"b{burst}r{i}"][:2] == expected(pr, 2)
+    print("late-bound launches:", p.stats.get("late_bound_launches", 0), "of", p.stats["prefill_batches"], "batches")
+    assert p.stats.get("late_bound_launches", 0) >= 8, p.stats
+    # the cold batch was not a sample: a 200-token batch is predicted at about its true 2 ms, not at tens of ms
+    assert p._batch_time.predict(200) < 4e-3
