@@ -582,3 +582,122 @@ def test_late_binding_survives_a_cold_first_batch(monkeypatch):
     assert p.stats.get("late_bound_launches", 0) >= 8, p.stats
     # the cold batch was not a sample: a 200-token batch is predicted at about its true 2 ms, not at tens of ms
     assert p._batch_time.predict(200) < 4e-3
+
+
+def _simulated_serving(seed, monkeypatch, n_reqs=24, size=1500, max_reqs=6, chunk=8192, abort_some=False):
+    """P and D against a simulated GPU and clock (see the test above), with randomised arrival gaps, prompt lengths, batch
+    durations (+-30 % noise, occasional 5x stalls) and a decode instance small enough to refuse admissions.  Returns
+    (expected tokens per request, received tokens per request, schedulers)."""
+    import random
+    from semi_pd_amd.managers import semi_pd_prefill_scheduler as mod
+    from semi_pd_amd.managers.io_struct import AbortReq
+    rnd = random.Random(seed)
+
+    class Clock:
+        def __init__(self):
+            self.t = 50.0
+
+        def perf_counter(self):
+            self.t += 2e-6
+            return self.t
+
+        monotonic = time = perf_counter
+
+        def sleep(self, dt):
+            self.t += dt
+
+    clock = Clock()
+    monkeypatch.setattr(mod, "time", clock)
+    sa = args(max_running_requests=max_reqs, chunked_prefill_size=chunk, max_total_tokens=size)
+    d_runner = make_runner(size=size, max_reqs=max_reqs)
+    p_runner = make_runner(shared=d_runner, size=size, max_reqs=max_reqs)
+    kv = torch.zeros(size + 1, dtype=torch.int64)
+    d_in, p_in, out, bridge = Q(), Q(), Q(), Q()
+    d = SemiPDDecodeScheduler(sa, d_runner, 0, d_in, out, bridge, p_in)
+    p = SemiPDPrefillScheduler(sa, p_runner, 0, p_in, d_in, bridge)
+    bridge.pump = d.step
+
+    class LayeredWorker(FakeWorker):              # a model of four layers: host time passes between them, the hook runs
+        def forward_batch_generation(self, mwb):
+            for _ in range(4):
+                clock.t += rnd.uniform(0.02e-3, 0.15e-3)
+                p._between_layers(None, ())
+            return super().forward_batch_generation(mwb)
+
+    d.tp_worker, p.tp_worker = FakeWorker(d_runner, kv), LayeredWorker(p_runner, kv)
+    p.late_bind, p.lead_s = True, rnd.choice([0.1e-3, 0.4e-3, 1.5e-3])
+    gpu = {"free_at": 0.0}
+
+    class Ev:
+        def __init__(self, end):
+            self.end = end
+
+        def query(self):
+            d.step()
+            return clock.t >= self.end
+
+        def synchronize(self):
+            clock.t = max(clock.t, self.end)
+
+    launch = p._launch
+
+    def launch_on_simulated_gpu(batch):
+        launch(batch)
+        b, ids, _, lo, t0 = p._inflight
+        dur = (0.5e-3 + 5e-6 * b.extend_num_tokens) * rnd.uniform(0.7, 1.3) * (5.0 if rnd.random() < 0.08 else 1.0)
+        gpu["free_at"] = max(gpu["free_at"], t0) + dur
+        p._inflight = (b, ids, Ev(gpu["free_at"]), lo, t0)
+
+    p._launch = launch_on_simulated_gpu
+    lens = [rnd.randint(3, 120) for _ in range(n_reqs)]
+    prompts = prompts_of(lens, seed=seed)
+    new_of = [rnd.randint(1, 6) for _ in range(n_reqs)]
+    aborted = set()
+    pending = collections.deque(range(n_reqs))
+    next_send, got, sent = clock.t, {}, []
+    for _ in range(200000):
+        if pending and clock.t >= next_send:
+            i = pending.popleft()
+            r = TokenizedGenerateReqInput(f"r{i}", None, list(prompts[i]), SamplingParams(max_new_tokens=new_of[i], ignore_eos=True))
+            d_in.send_pyobj(r), p_in.send_pyobj(r)
+            sent.append(i)
+            if abort_some and rnd.random() < 0.15:
+                aborted.add(i)
+                d_in.send_pyobj(AbortReq(f"r{i}")), p_in.send_pyobj(AbortReq(f"r{i}"))
+            next_send = clock.t + rnd.choice([0.0, 0.05e-3, 0.3e-3, 2e-3])
+        if not p.step():
+            clock.sleep(50e-6)
+        d.step()
+        while out.q:
+            o = out.q.popleft()
+            for rid, toks in zip(o.rids, o.output_ids):
+                got.setdefault(rid, []).extend(toks)
+        live = [i for i in sent if i not in aborted]
+        if (not pending and all(len(got.get(f"r{i}", [])) >= new_of[i] for i in live) and p._inflight is None
+                and not p.waiting_queue and not d.scheduled_prefill_batches and d.running_batch.is_empty()):
+            break
+    else:
+        raise AssertionError(f"seed {seed}: the simulated serving run did not finish: waiting {len(p.waiting_queue)}, "
+                             f"scheduled {len(d.scheduled_prefill_batches)}, running {len(d.running_batch.reqs)}")
+    for _ in range(3):
+        p.step(), d.step()
+    return prompts, new_of, aborted, got, p, d, d_runner, size
+
+
+@pytest.mark.parametrize("seed", range(25))
+@pytest.mark.parametrize("mode", ["plain", "tight", "chunked", "aborts"])
+def test_late_binding_randomised_serving_keeps_every_invariant(seed, mode, monkeypatch):
+    """Random arrivals, lengths and batch durations through the late-binding loop (simulated GPU and clock): every request
+    gets exactly its tokens (= the history rule, so slots, the shared table and result order are right), refused
+    admissions and chunked prompts do not wedge the pipeline, aborted requests end, every KV and request slot returns."""
+    kw = {"plain": {}, "tight": dict(size=700, max_reqs=3), "chunked": dict(chunk=64),
+          "aborts": dict(abort_some=True)}[mode]
+    prompts, new_of, aborted, got, p, d, d_runner, size = _simulated_serving(seed * 7 + 1, monkeypatch, **kw)
+    for i, (pr, n) in enumerate(zip(prompts, new_of)):
+        if i in aborted:
+            assert got.get(f"r{i}", []) == expected(pr, n)[: len(got.get(f"r{i}", []))]
+            continue
+        assert got[f"r{i}"] == expected(pr, n), (mode, seed, i)
+    assert d_runner.token_to_kv_pool_allocator.available_size() == size
+    assert d_runner.req_to_token_pool.available_size() == d_runner.req_to_token_pool.size
+    assert not p._deferred_input and not p._aborted or mode == "aborts"
