@@ -186,9 +186,16 @@ int semipd_cu_mask_fill(int num_cus, int percent, int from_top, uint32_t* mask, 
   // The KFD spreads consecutive mask bits round-robin over the XCDs (and shader engines inside
   // an XCD), so a contiguous range of logical CU bits is automatically XCD-balanced: bit i lands
   // on XCD i % 8.  We enable round(num_cus*percent/100) bits, rounded to a multiple of 8 so every
-  // XCD gets the same number of CUs, from the bottom or from the top of the range.
-  int n = (num_cus * percent + 50) / 100;
-  n = (n + 4) / 8 * 8;
+  // XCD gets the same number of CUs, from the bottom or from the top of the range.  A share taken from the TOP is what
+  // the complementary share from the bottom leaves (num_cus - bottom(100 - percent)): the two roundings of a pair like
+  // 62 / 38 can then never claim the same group (on 304 CUs they did: 192 + 120), and on 256 CUs nothing changes for
+  // the pairs in use (160 / 96, 128 / 128, 192 / 64).
+  auto bottom = [num_cus](int pct) {
+    int m = (num_cus * pct + 50) / 100;
+    m = (m + 4) / 8 * 8;
+    return m > num_cus ? num_cus : m;
+  };
+  int n = from_top ? num_cus - bottom(100 - percent) : bottom(percent);
   if (n < 8) n = 8;
   if (n > num_cus) n = num_cus;
   for (int w = 0; w < words; ++w) mask[w] = 0;
