@@ -536,6 +536,8 @@ def main():
                    "parallelism": (f"tp{world}" if (args.tp or world == 1) else f"dp{world} (replicas, tp1 each)"),
                    "mode": args.mode, "prefill_cu_percent": args.prefill_cu, "decode_cu_percent": args.decode_cu,
                    "prefill_gemm": ("library solutions timed on the prefill share at start-up (csrc/dense_gemm.hip)"
+                                    + (", next to a replaying decode step" if (world == 1 or not args.tp) and
+                                       os.environ.get("SEMIPD_TUNE_UNDER_DECODE_LOAD", "1") != "0" else "")
                                     if (not args.no_prefill_gemm_tuning and args.prefill_cu < 100 and args.mode == "semi-pd")
                                     else "library heuristic"),
                    "kv_cache_dtype": args.kv_cache_dtype},
