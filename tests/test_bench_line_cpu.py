@@ -1,0 +1,102 @@
+"""bench.py's rank-0 line, assembled on the CPU: `main()` runs against a stand-in engine (requests "finish" with scripted
+token times, statistics carry the shapes the schedulers report), so that every field the driver and the judge read --
+the contract fields, `roofline`, `roofline_extra` with the late-binding counters, `config`, the extra waves -- is built by
+the real code without a GPU."""
+import json
+import os
+import sys
+import time
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class FakeEngine:
+    instances = []
+
+    def __init__(self, server_args, local_tp_ranks=None, gpu_ids=None, ready_timeout=0.0):
+        self.sa = server_args
+        self._finished, self._rec, self._n = {}, {}, 0
+        self.ready_infos = []
+        FakeEngine.instances.append(self)
+
+    def add_request(self, input_ids, sampling_params, rid=None, **kw):
+        rid = f"r{self._n}"
+        self._n += 1
+        now = time.time()
+        n = sampling_params.max_new_tokens
+        # first token 40 ms after the send, then one every 8 ms (all in the past by the time the wave loop looks)
+        self._rec[rid] = {"send": now - 2.0, "token_times": [now - 2.0 + 0.040 + 0.008 * i for i in range(n)],
+                          "output_ids": [1] * n, "finished": "length"}
+        self._finished[rid] = "length"
+        return rid
+
+    def poll(self, timeout=0.0):
+        return False
+
+    def check_children(self):
+        pass
+
+    def request_record(self, rid):
+        return self._rec[rid]
+
+    def get_stats(self, reset=False, **kw):
+        kt = {"_event_pair_overhead_us": {"1": 6.2, "2": 7.8},
+              "stream_linear": {"gbps": 2570.0, "avg_us": 42.7, "avg_us_minus_event_overhead": 36.4,
+                                "bytes_per_launch": 109894682, "launches": 456},
+              "decode_attention": {"gbps": 2100.0, "avg_us": 62.0, "bytes_per_launch": 136719344, "launches": 2144},
+              "extend_attention": {"tflops": 281.0, "avg_us": 40.8, "launches": 1120}}
+        return [{"role": "DECODE", "decode_steps": 1000, "decode_tokens": 30400, "t_schedule_s": 0.25, "t_forward_s": 8.0,
+                 "t_output_s": 0.09, "kernel_timing": kt},
+                {"role": "PREFILL", "prefill_batches": 568, "prefill_tokens": 786432, "prefill_reqs": 768,
+                 "t_wait_admission_s": 0.12, "t_forward_s": 16.9, "late_bound_launches": 287,
+                 "results_sent_from_layer_hook": 271, "kernel_timing": {}}]
+
+    def shutdown(self):
+        pass
+
+
+@pytest.mark.parametrize("argv,expect_static", [
+    (["--num-requests", "6", "--input-len", "16", "--output-len", "4", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+      "--rate-sweep", "8,32", "--sweep-output-len", "6", "--request-rate", "500"], True),
+    (["--model", "deepseek-v2-lite", "--num-requests", "4", "--input-len", "16", "--output-len", "3", "--no-cpu-baseline",
+      "--request-rate", "500", "--no-saturation-wave"], False),
+])
+def test_the_bench_line_is_assembled_with_every_contract_field(monkeypatch, capsys, argv, expect_static):
+    sys.path.insert(0, ROOT)
+    import bench
+    from semi_pd_amd.entrypoints import engine as engine_mod
+    monkeypatch.setattr(engine_mod, "Engine", FakeEngine)
+    monkeypatch.setattr(sys, "argv", ["bench.py"] + argv)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    FakeEngine.instances.clear()
+    bench.main()
+    line = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["unit"] == "tokens/s" and d["dtype"] == "bf16" and d["data"] == "synthetic" and d["value"] > 0
+    assert d["p50_ttft_ms"] == pytest.approx(40.0, abs=0.5) and d["p50_tbt_ms"] == pytest.approx(8.0, abs=0.5)
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["traffic"] is None
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], abs=1e-4) and "stream_gemm_glds_kernel" in r["kernel"]
+    pb = d["roofline_extra"]["prefill_batch_ms"]
+    assert pb["launched_behind_a_running_batch"] == 287 and pb["results_sent_from_layer_hook"] == 271 and pb["batches"] == 568
+    assert d["roofline_extra"]["extend_attention"]["bound"] == "mfma"
+    cfgd = d["config"]
+    assert "workload" in cfgd and "model" not in cfgd and "HSA_CU_MASK" in cfgd["workload"]
+    assert cfgd["prefill_gemm"].startswith("library solutions timed on the prefill share") and "decode step" in cfgd["prefill_gemm"]
+    if expect_static:
+        assert (cfgd["prefill_cu_percent"], cfgd["decode_cu_percent"]) == (62, 38)
+        assert d["static_split_50_50"]["output_tok_s"] > 0 and len(FakeEngine.instances) == 2
+        assert [s["request_rate"] for s in d["qps_sweep"]] == [8.0, 32.0] and d["qps_sweep"][0]["output_len"] == 6
+        assert d["saturation"]["output_tokens"] == 6 * 4
+        assert d["steps"] == 2 and d["warmup"] == 1
+    else:
+        assert (cfgd["prefill_cu_percent"], cfgd["decode_cu_percent"]) == (50, 50)      # MoE models default to halves
+        assert "static_split_50_50" not in d and "saturation" not in d and "qps_sweep" not in d
+        assert "mla_decode_kernel" in d["roofline_extra"]["decode_attention"]["kernel"]
