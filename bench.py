@@ -268,7 +268,11 @@ def main():
                     help="N = 1 Semi-PD default run: do not start the second engine with BASELINE config 2's literal 50 / 50 split")
     ap.add_argument("--no-prefill-gemm-tuning", action="store_true",
                     help="prefill instance: the library's own GEMM choice instead of the solutions timed on its CU share")
-    ap.add_argument("--cu-mask-mode", default="env")
+    ap.add_argument("--cu-mask-mode", default="env", choices=["env", "none", "dynamic"],
+                    help="env: static HSA_CU_MASK per instance; dynamic: unmasked processes with a CU-masked stream over their "
+                         "share and a stream over every CU, chosen per decode step / prefill batch (work-conserving shares)")
+    ap.add_argument("--prefill-backlog-full-tokens", type=int, default=0,
+                    help="dynamic mode: waiting prompt tokens from which a prefill batch takes every CU (0 = never)")
     ap.add_argument("--prefill-priority", type=int, default=0, help="HIP stream priority of the prefill instance (-1 = high)")
     ap.add_argument("--decode-priority", type=int, default=0, help="HIP stream priority of the decode instance (-1 = high)")
     ap.add_argument("--disable-stream-linear", action="store_true",
@@ -363,6 +367,7 @@ def main():
                     max_running_requests=args.max_running_requests, mem_fraction_static=args.mem_fraction_static,
                     max_total_tokens=args.max_total_tokens, prefill_cu_percent=args.prefill_cu,
                     decode_cu_percent=args.decode_cu, cu_mask_mode=args.cu_mask_mode,
+                    prefill_backlog_full_tokens=args.prefill_backlog_full_tokens,
                     library_gemm_grid=args.library_gemm_grid, disable_stream_linear=args.disable_stream_linear,
                     tune_prefill_gemm=(False if args.no_prefill_gemm_tuning else None),
                     prefill_stream_priority=args.prefill_priority, decode_stream_priority=args.decode_priority,
@@ -460,7 +465,8 @@ def main():
             extra["decode_step_ms"] = {"steps": int(n), "avg_batch": round(s["decode_tokens"] / n, 1),
                                        "schedule": round(1e3 * s.get("t_schedule_s", 0) / n, 3),
                                        "forward_and_sync": round(1e3 * s.get("t_forward_s", 0) / n, 3),
-                                       "output": round(1e3 * s.get("t_output_s", 0) / n, 3)}
+                                       "output": round(1e3 * s.get("t_output_s", 0) / n, 3),
+                                       **{k: int(v) for k, v in s.items() if k.startswith("steps_on_")}}
         if s.get("role") == "PREFILL" and s.get("prefill_batches"):
             n = s["prefill_batches"]
             extra["prefill_batch_ms"] = {"batches": int(n), "avg_tokens": round(s["prefill_tokens"] / n, 1),
@@ -470,7 +476,8 @@ def main():
                                          # batches queued behind a running one by the late-binding loop, and how many
                                          # running batches had their first tokens sent from a layer hook of that launch
                                          "launched_behind_a_running_batch": int(s.get("late_bound_launches", 0)),
-                                         "results_sent_from_layer_hook": int(s.get("results_sent_from_layer_hook", 0))}
+                                         "results_sent_from_layer_hook": int(s.get("results_sent_from_layer_hook", 0)),
+                                         **{k: int(v) for k, v in s.items() if k.startswith("batches_on_")}}
         kt = s.get("kernel_timing") or {}
         def hbm_line(k, kernel):
             return {"bound": "hbm", "kernel": kernel, "achieved": round(k["gbps"], 1),
@@ -512,6 +519,11 @@ def main():
             cpu = {"error": repr(e)}
     if args.mode != "semi-pd":
         mask_text = "one process on every CU"
+    elif args.cu_mask_mode == "dynamic":
+        mask_text = (f"dynamic CU shares P{args.prefill_cu}/D{args.decode_cu} (CU-masked streams: prefill the lowest "
+                     f"{args.prefill_cu} % of the CUs, decode the highest {args.decode_cu} %, each instance on every CU while "
+                     f"the other has nothing in flight"
+                     + (f" or, prefill, from {args.prefill_backlog_full_tokens} waiting prompt tokens" if args.prefill_backlog_full_tokens else "") + ")")
     elif (args.prefill_cu, args.decode_cu) == (100, 100) or args.cu_mask_mode != "env":
         mask_text = "CU shares P100/D100 (no mask: both instances on every CU)"
     else:

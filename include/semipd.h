@@ -281,8 +281,12 @@ int semipd_moe_gemm_tall(void* c, const void* a, const void* w, const float* top
  *   semipd_dense_gemm        launches with the winner of the nearest tuned row count (the library's own choice when
  *                            nothing was tuned or the winner does not support this row count).  Never allocates or
  *                            synchronises; dtype bf16 / f16; ldx / ldo = row strides in elements.
- *   semipd_dense_gemm_report text table of the tuning results; returns the bytes needed. */
+ *   semipd_dense_gemm_report text table of the tuning results; returns the bytes needed.
+ *   semipd_dense_gemm_set_cus the CU count of the stream the following _tune / _dense_gemm calls run on: results are
+ *                            filed under it and looked up by it (an instance that moves between its masked share and
+ *                            the whole chip keeps one table per count; an untuned count gets the library's choice). */
 int semipd_dense_gemm_init(size_t workspace_bytes);
+int semipd_dense_gemm_set_cus(int cus);
 int semipd_dense_gemm_tune(int64_t n, int64_t k, const int64_t* rows, int num_rows, int num_full_search, int dtype,
                            int num_heuristics, int max_solutions, void* stream);
 int semipd_dense_gemm(void* out, const void* x, const void* weight, const void* bias, int64_t rows, int64_t n, int64_t k,
@@ -570,6 +574,20 @@ int semipd_stream_create_cu_mask(int device, const uint32_t* mask, int words, vo
 int semipd_stream_destroy(void* stream);
 /* Read back the mask of a stream (hipExtStreamGetCUMask). */
 int semipd_stream_get_cu_mask(void* stream, uint32_t* mask, int words);
+
+/* Share board: one 4 KB page of HOST memory that the prefill and the decode instance of a GPU both map (a file in the
+ * engine's socket directory), 64 slots of one int64 each, every slot written by one instance and read by the other with
+ * release / acquire ordering.  It carries what the reference's MPS percentages cannot express: whether the other
+ * instance has work in flight RIGHT NOW, so that an instance may run a step on every CU while the other one idles
+ * (the reference's shares overlap -- P 80 %, D 100 %, semi_pd/utils.py:10-11 -- and MPS time-shares what overlaps; CU masks
+ * are hard partitions, so the work-conserving part has to be decided per step by the instances themselves).
+ * create != 0: make and zero the file if it is missing.  No reference counterpart. */
+int semipd_share_board_open(const char* path, int create, void** board);
+int semipd_share_board_close(void* board);
+int semipd_share_board_store(void* board, int slot, int64_t value);
+/* atomic slot += delta; *result (may be NULL) receives the new value. */
+int semipd_share_board_add(void* board, int slot, int64_t delta, int64_t* result);
+int semipd_share_board_load(void* board, int slot, int64_t* value);
 
 /* Test/diagnostic kernel: every workgroup records the XCC id and CU id it ran on
  * (out[2*wg], out[2*wg+1]) and spins for `spin_cycles`. */

@@ -76,11 +76,14 @@ struct State {
   hipblasLtHandle_t handle = nullptr;
   void* workspace = nullptr;
   size_t workspace_bytes = 0;
-  // (dtype, n, k) -> rows -> winner
-  std::map<std::tuple<int, int64_t, int64_t>, std::map<int64_t, Tuned>> tuned;
+  // (share, dtype, n, k) -> rows -> winner.  share = the CU count the calling process declared for the stream it is on
+  // (semipd_dense_gemm_set_cus): an instance that moves between a masked stream and the whole chip keeps one table per
+  // CU count, and a count nothing was tuned for gets the library's own choice
+  std::map<std::tuple<int, int, int64_t, int64_t>, std::map<int64_t, Tuned>> tuned;
+  int share = 0;
   // (dtype, n, k) -> candidate pool (solutions that were among the fastest at some tuned row count)
   std::map<std::tuple<int, int64_t, int64_t>, std::vector<hipblasLtMatmulAlgo_t>> pool;
-  std::map<std::tuple<int, int64_t, int64_t, int64_t, int64_t, int64_t, int>, Plan> plans;
+  std::map<std::tuple<int, int, int64_t, int64_t, int64_t, int64_t, int64_t, int>, Plan> plans;
   int device = -1;
 };
 
@@ -195,6 +198,16 @@ float env_us(const char* name) {
 }  // namespace
 
 extern "C" {
+
+/* The CU count of the stream the following semipd_dense_gemm / _tune calls of this process run on (0 = unspecified).  Tuning
+ * results are filed under it and looked up by it. */
+int semipd_dense_gemm_set_cus(int cus) {
+  SEMIPD_CHECK_ARG(cus >= 0 && cus <= 4096, SEMIPD_EINVAL, "dense_gemm_set_cus: bad CU count %d", cus);
+  State& s = st();
+  std::lock_guard<std::mutex> g(s.mu);
+  s.share = cus;
+  return 0;
+}
 
 int semipd_dense_gemm_init(size_t workspace_bytes) {
   State& s = st();
@@ -357,7 +370,7 @@ int semipd_dense_gemm_tune(int64_t n, int64_t k, const int64_t* rows, int num_ro
       t.us_default = t_default;
       t.candidates = (int)timed.size();
       t.rejected = rejected;
-      s.tuned[key][m] = t;
+      s.tuned[std::make_tuple(s.share, dtype, n, k)][m] = t;
     }
     destroy_problem(p);
   }
@@ -389,12 +402,12 @@ int semipd_dense_gemm(void* out, const void* x, const void* weight, const void* 
     set_error("dense_gemm: call semipd_dense_gemm_init (or _tune) first: no allocation happens on the serving path");
     return SEMIPD_EINVAL;
   }
-  const auto pkey = std::make_tuple(dtype, rows, n, k, ldx, ldo, bias ? 1 : 0);
+  const auto pkey = std::make_tuple(s.share, dtype, rows, n, k, ldx, ldo, bias ? 1 : 0);
   auto it = s.plans.find(pkey);
   if (it == s.plans.end()) {
     Plan p;
     if (make_problem(p, dtype, rows, n, k, ldx, ldo, bias != nullptr)) return 1;
-    auto tk = s.tuned.find(std::make_tuple(dtype, n, k));
+    auto tk = s.tuned.find(std::make_tuple(s.share, dtype, n, k));
     if (tk != s.tuned.end() && !tk->second.empty()) {
       const Tuned* bestt = nullptr;
       double bestd = 1e30;
@@ -443,8 +456,8 @@ size_t semipd_dense_gemm_report(char* buf, size_t len) {
   for (auto& kv : s.tuned)
     for (auto& rv : kv.second) {
       snprintf(line, sizeof(line),
-               "dtype=%d n=%lld k=%lld rows=%lld solution=%d us=%.1f library_choice_us=%.1f candidates=%d wrong_results_rejected=%d\n",
-               std::get<0>(kv.first), (long long)std::get<1>(kv.first), (long long)std::get<2>(kv.first), (long long)rv.first,
+               "cus=%d dtype=%d n=%lld k=%lld rows=%lld solution=%d us=%.1f library_choice_us=%.1f candidates=%d wrong_results_rejected=%d\n",
+               std::get<0>(kv.first), std::get<1>(kv.first), (long long)std::get<2>(kv.first), (long long)std::get<3>(kv.first), (long long)rv.first,
                rv.second.solution_index, rv.second.us, rv.second.us_default, rv.second.candidates, rv.second.rejected);
       out += line;
     }

@@ -11,8 +11,14 @@
 //  * errors are returned, never exit(1) (ipc.cpp:74-79).
 #include "common.h"
 
+#include <errno.h>
+#include <fcntl.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
@@ -237,6 +243,62 @@ int semipd_probe_cu_placement(int32_t* out, int num_workgroups, int64_t spin_cyc
   hipLaunchKernelGGL(probe_cu_placement_kernel, dim3(num_workgroups), dim3(64), 0, as_stream(stream),
                      out, (long long)spin_cycles);
   return launch_status("probe_cu_placement");
+}
+
+// ---- share board: one page of host memory both instances of a GPU map (a file in the engine's socket directory) ----
+// 64 slots of one 64-bit word, each on its own cache line is not needed: a slot has ONE writer and is read a few hundred
+// times per second.  The words are std::atomic on a MAP_SHARED page: lock-free 8-byte atomics work across processes.
+enum { kBoardSlots = 64, kBoardBytes = 4096 };
+static_assert(sizeof(std::atomic<int64_t>) == 8 && std::atomic<int64_t>::is_always_lock_free, "8-byte lock-free atomics");
+
+int semipd_share_board_open(const char* path, int create, void** board) {
+  SEMIPD_CHECK_ARG(path && board, SEMIPD_EINVAL, "share_board_open: null pointer");
+  const int fd = open(path, create ? (O_RDWR | O_CREAT) : O_RDWR, 0600);
+  if (fd < 0) {
+    set_error("share_board_open: cannot open %s: %s", path, strerror(errno));
+    return SEMIPD_ENOTFOUND;
+  }
+  struct stat sb;
+  if (fstat(fd, &sb) != 0 || (sb.st_size < kBoardBytes && (!create || ftruncate(fd, kBoardBytes) != 0))) {
+    // (a fresh file is zero-filled by ftruncate: every slot starts at 0 = "idle")
+    set_error("share_board_open: %s is not a board (size %lld) and cannot be sized: %s", path, (long long)sb.st_size,
+              strerror(errno));
+    close(fd);
+    return SEMIPD_EINVAL;
+  }
+  void* p = mmap(nullptr, kBoardBytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (p == MAP_FAILED) {
+    set_error("share_board_open: mmap of %s failed: %s", path, strerror(errno));
+    return SEMIPD_EINVAL;
+  }
+  *board = p;
+  return 0;
+}
+
+int semipd_share_board_close(void* board) {
+  SEMIPD_CHECK_ARG(board, SEMIPD_EINVAL, "share_board_close: null board");
+  munmap(board, kBoardBytes);
+  return 0;
+}
+
+int semipd_share_board_store(void* board, int slot, int64_t value) {
+  SEMIPD_CHECK_ARG(board && slot >= 0 && slot < kBoardSlots, SEMIPD_EINVAL, "share_board_store: bad slot %d", slot);
+  reinterpret_cast<std::atomic<int64_t>*>(board)[slot].store(value, std::memory_order_release);
+  return 0;
+}
+
+int semipd_share_board_add(void* board, int slot, int64_t delta, int64_t* result) {
+  SEMIPD_CHECK_ARG(board && slot >= 0 && slot < kBoardSlots, SEMIPD_EINVAL, "share_board_add: bad slot %d", slot);
+  const int64_t v = reinterpret_cast<std::atomic<int64_t>*>(board)[slot].fetch_add(delta, std::memory_order_acq_rel) + delta;
+  if (result) *result = v;
+  return 0;
+}
+
+int semipd_share_board_load(void* board, int slot, int64_t* value) {
+  SEMIPD_CHECK_ARG(board && value && slot >= 0 && slot < kBoardSlots, SEMIPD_EINVAL, "share_board_load: bad slot %d", slot);
+  *value = reinterpret_cast<std::atomic<int64_t>*>(board)[slot].load(std::memory_order_acquire);
+  return 0;
 }
 
 int semipd_launch_noop(int count, void* stream) {

@@ -72,6 +72,7 @@ _SIGNATURES = {
     "semipd_moe_sum_scale_add": [_vp, _vp, _vp, _i64, _i32, _i64, _f32, _i32, _i32, _vp],
     "semipd_moe_gemm_tall": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp],
     "semipd_dense_gemm_init": [_sz],
+    "semipd_dense_gemm_set_cus": [_i32],
     "semipd_dense_gemm_tune": [_i64, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "semipd_dense_gemm": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32, _vp],
     "semipd_dense_gemm_report": [_vp, _sz],
@@ -107,6 +108,11 @@ _SIGNATURES = {
     "semipd_stream_create_cu_mask": [_i32, _vp, _i32, _vp],
     "semipd_stream_destroy": [_vp],
     "semipd_stream_get_cu_mask": [_vp, _vp, _i32],
+    "semipd_share_board_open": [C.c_char_p, _i32, _vp],
+    "semipd_share_board_close": [_vp],
+    "semipd_share_board_store": [_vp, _i32, _i64],
+    "semipd_share_board_add": [_vp, _i32, _i64, _vp],
+    "semipd_share_board_load": [_vp, _i32, _vp],
     "semipd_probe_cu_placement": [_vp, _i32, _i64, _vp],
     "semipd_launch_noop": [_i32, _vp],
     "semipd_ar_meta_size": [],

@@ -47,13 +47,26 @@ def _build_runner(server_args: ServerArgs, gpu_id: int, tp_rank: int, role: Inst
         disable_cuda_graph=server_args.disable_cuda_graph, cuda_graph_max_bs=server_args.cuda_graph_max_bs,
         disable_custom_all_reduce=server_args.disable_custom_all_reduce, enable_ep_moe=server_args.enable_ep_moe,
         disable_stream_linear=server_args.disable_stream_linear,
-        num_kv_splits=server_args.triton_attention_num_kv_splits)
+        num_kv_splits=server_args.triton_attention_num_kv_splits,
+        dummy_lm_head_scale=server_args.dummy_lm_head_scale)
     if server_args.collect_kernel_timing:
         from semi_pd_amd.model_executor.kernel_timing import KernelTiming
         mr.kernel_timing = KernelTiming()
         from semi_pd_amd.layers.basic import set_stream_linear_timing
         set_stream_linear_timing(mr.kernel_timing)
     return mr
+
+
+def _init_dynamic_share(server_args: ServerArgs, port_args: SemiPDPortArgs, mr, role: InstanceRole):
+    """--cu-mask-mode dynamic: the process is unmasked; it gets a masked stream over its share next to a stream over every
+    CU (model_executor/cu_share.py) and meets the other instance on the share board (semi_pd/share_board.py), a file next
+    to the engine's sockets."""
+    if server_args.cu_mask_mode != "dynamic":
+        return
+    from semi_pd_amd.semi_pd.share_board import ShareBoard
+    board = ShareBoard(os.path.join(os.path.dirname(port_args.tokenizer_ipc_name), "share_board"), create=True)
+    percent = server_args.decode_cu_percent if role == InstanceRole.DECODE else server_args.prefill_cu_percent
+    mr.init_cu_share(role, percent, board)
 
 
 def run_scheduler_process(server_args: ServerArgs, port_args: SemiPDPortArgs, gpu_id: int, tp_rank: int,
@@ -89,6 +102,7 @@ def run_scheduler_process(server_args: ServerArgs, port_args: SemiPDPortArgs, gp
                                max_total_tokens=server_args.max_total_tokens,
                                cu_percent=server_args.decode_cu_percent)
             ipc_queue.put(mr.get_ipc_info())       # semi_pd_scheduler.py:388-389
+            _init_dynamic_share(server_args, port_args, mr, role)
             mr.init_attention_backend()
             mr.init_cuda_graphs()                   # decode only (semi_pd_scheduler.py:409-411)
             sched = SemiPDDecodeScheduler(
@@ -103,10 +117,12 @@ def run_scheduler_process(server_args: ServerArgs, port_args: SemiPDPortArgs, gp
                                max_total_tokens=ipc_info.kvcache_info["max_total_num_tokens"],
                                bypass_load_weight=True, cu_percent=server_args.prefill_cu_percent)
             mr.share_params_from_ipc(ipc_info)      # semi_pd_scheduler.py:406-407
+            _init_dynamic_share(server_args, port_args, mr, role)
             mr.init_attention_backend()
             to_d = PushSocket(port_args.d_scheduler_input_ipc_name) if rank0 else None
             tune = server_args.tune_prefill_gemm
-            if tune or (tune is None and server_args.prefill_cu_percent < 100 and server_args.cu_mask_mode == "env"):
+            if tune or (tune is None and server_args.prefill_cu_percent < 100
+                        and server_args.cu_mask_mode in ("env", "dynamic")):
                 # the candidates are timed next to what they will run next to: the decode instance (ready and idle at
                 # this point) replays a captured decode step in a loop meanwhile
                 under_load = (rank0 and server_args.tp_size == 1

@@ -99,7 +99,6 @@ class HipAttnBackend(AttentionBackend):
         self.v_head_dim = model_runner.v_head_dim
         self.req_to_token = model_runner.req_to_token_pool.req_to_token
         self.max_context_len = model_runner.max_context_len
-        self.num_cus = model_runner.num_cus_owned
         self.is_mla = model_runner.kv_geometry["kind"] == "mla"
         self.num_kv_splits_cap = num_kv_splits_cap
         # --triton-attention-num-kv-splits: a fixed count as in the reference (decode_attention.py's grid z)
@@ -111,6 +110,11 @@ class HipAttnBackend(AttentionBackend):
         self.cuda_graph_attn_logits = None
         self.model_runner = model_runner
         self._algo = (0.0, 0.0)  # algorithmic (bytes, flops) per layer call of the current batch
+
+    @property
+    def num_cus(self) -> int:
+        # the CUs of the stream the instance is on right now (ModelRunner.set_owned_cus)
+        return self.model_runner.num_cus_owned
 
     # ---- eager path ---------------------------------------------------------------------
     def init_forward_metadata(self, forward_batch: ForwardBatch):

@@ -41,6 +41,7 @@ class SemiPDDecodeScheduler(SchedulerBase):
         self._pinned_ids = None
         self._pinned_flip = 0
         self._synthetic_load_until = 0.0              # see SyntheticLoadReq
+        self._published_busy = -1                     # what the share board last heard from this instance
 
         self.bridge_socket = bridge_socket            # PUSH -> P (replies to GetNextPrefillBatchInput)
         self.send_to_p_instance = send_to_p_instance  # PUSH -> P's input socket (retracted requests)
@@ -197,6 +198,21 @@ class SemiPDDecodeScheduler(SchedulerBase):
             else:
                 self.running_batch.merge_batch(batch)
 
+    # ---------------------------------------------------------------------------- CU share
+    def _share_step(self, running: int):
+        """--cu-mask-mode dynamic (model_executor/cu_share.py): tell the prefill instance how many requests this step
+        decodes (0: nothing in flight -- it may take every CU) and put the step on the whole chip while the prefill
+        instance has no batch in flight, on the decode share otherwise."""
+        share = getattr(self.model_runner, "cu_share", None)
+        if share is None:
+            return
+        if running or running != self._published_busy:   # (a busy instance refreshes its heartbeat with every step)
+            share.publish(running)
+            self._published_busy = running
+        if running:
+            name = share.step()
+            self.stats["steps_on_" + name] = self.stats.get("steps_on_" + name, 0) + 1
+
     # ---------------------------------------------------------------------------- loop
     def step(self) -> bool:
         if self.enable_overlap:
@@ -207,8 +223,10 @@ class SemiPDDecodeScheduler(SchedulerBase):
         batch = self.get_next_batch_to_run()
         if batch is None:
             self.flush_stream_output()
+            self._share_step(0)
             return bool(recv)
         t1 = time.perf_counter()
+        self._share_step(len(batch.reqs))
         logits_output, next_token_ids = self.run_batch(batch)  # asynchronous: one hipGraph launch
         batch.output_ids = next_token_ids
         self.flush_stream_output()     # tokens of the previous step: pickle + send while the GPU works
@@ -246,8 +264,10 @@ class SemiPDDecodeScheduler(SchedulerBase):
             had = self._pending is not None
             self._drain_pending()
             self.flush_stream_output()
+            self._share_step(0)
             return bool(recv) or had
         t1 = time.perf_counter()
+        self._share_step(len(batch.reqs))
         logits_output, next_token_ids = self.run_batch(batch)  # asynchronous: one hipGraph launch
         batch.output_ids = next_token_ids
         bs = len(batch.reqs)
@@ -354,8 +374,8 @@ class SemiPDDecodeScheduler(SchedulerBase):
         if gr is None or self.tp_size > 1 or not gr.graphs or time.monotonic() > self._synthetic_load_until:
             self._synthetic_load_until = 0.0
             return False
-        bs = min(gr.graphs, key=lambda b: abs(b - 32))
-        gr.graphs[bs].replay()
+        key = min(gr.graphs, key=lambda cb: (cb[0] != self.model_runner.num_cus_owned, abs(cb[1] - 32)))
+        gr.graphs[key].replay()
         torch.cuda.current_stream().synchronize()
         self.last_progress = time.monotonic()
         return True

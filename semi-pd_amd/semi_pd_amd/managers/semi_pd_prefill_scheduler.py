@@ -82,6 +82,9 @@ class SemiPDPrefillScheduler(SchedulerBase):
         self._deferred_input: list = []   # messages a wait set aside for the loop top
         if self.late_bind:
             self._install_layer_hooks(model_runner)
+        self._share_inflight = 0          # batches launched and not finished (published on the share board)
+        # prompt tokens waiting from which a batch takes every CU whatever the decode instance does (0 = never)
+        self.backlog_full_tokens = int(getattr(server_args, "prefill_backlog_full_tokens", 0) or 0)
         self._proposal_in_flight = False  # a GetNextPrefillBatchInput whose reply has not been read yet
         self._aborted: set = set()        # rids the client gave up on (see abort_request)
         self.chunked_rid: Optional[str] = None
@@ -315,8 +318,31 @@ class SemiPDPrefillScheduler(SchedulerBase):
         self._finish(prev)
         return True
 
+    def _share_launch(self, batch: ScheduleBatch):
+        """--cu-mask-mode dynamic (model_executor/cu_share.py): a batch runs on every CU while the decode instance has
+        nothing in flight, or while this instance's backlog says the GPU is overloaded anyway (more than
+        `backlog_full_tokens` prompt tokens waiting: throughput first, the decode instance's steps then share their CUs
+        with it as in the reference's overlapping MPS shares); on the prefill share otherwise."""
+        share = getattr(self.model_runner, "cu_share", None)
+        if share is None:
+            return
+        self._share_inflight += 1
+        share.publish(self._share_inflight)
+        backlog = sum(len(r.origin_input_ids) for r in self.waiting_queue)
+        from semi_pd_amd.model_executor.cu_share import FULL
+        name = FULL if (self.backlog_full_tokens and backlog >= self.backlog_full_tokens) else share.choose()
+        share.activate(name)
+        self.stats["batches_on_" + name] = self.stats.get("batches_on_" + name, 0) + 1
+
+    def _share_done(self):
+        share = getattr(self.model_runner, "cu_share", None)
+        if share is not None:
+            self._share_inflight = max(0, self._share_inflight - 1)
+            share.publish(self._share_inflight)
+
     def _launch(self, batch: ScheduleBatch):
         t0 = time.perf_counter()
+        self._share_launch(batch)
         logits_output, next_token_ids = self.run_batch(batch)  # asynchronous launches
         if torch.device(self.device).type == "cuda" and self.enable_overlap:
             host_ids = torch.empty(next_token_ids.numel(), dtype=torch.int64, pin_memory=True)
@@ -337,6 +363,7 @@ class SemiPDPrefillScheduler(SchedulerBase):
         if ev is not None:
             ev.synchronize()  # the batch and the copy of its ids are done: every KV row it wrote is in HBM
         t_done = time.perf_counter()
+        self._share_done()
         ttft_trace.mark("p_done", [r.rid for r in batch.reqs])
         if ev is not None:
             # this batch had the GPU from its launch, or from the end of the batch it was queued behind

@@ -1,0 +1,84 @@
+"""Work-conserving CU shares: the compute streams of ONE instance and the rule that picks between them.
+
+Reference behaviour this stands in for: the MPS percentages of the two instances overlap (prefill 80 %, decode 100 %:
+semi_pd/utils.py:10-11, set per process at entrypoints/engine.py:588-593, 632-634), so whichever instance is alone on the
+GPU gets all of it.  HSA_CU_MASK is a hard, process-wide partition; `--cu-mask-mode dynamic` therefore leaves the process
+unmasked and gives it TWO streams instead:
+
+    "share"   hipExtStreamCreateWithCUMask over the instance's own CUs (prefill: the lowest P %, decode: the highest D %),
+    "full"    an ordinary stream: every CU of the device,
+
+and the instance runs each unit of work (a decode step = one hipGraph launch, a prefill batch = one forward) on "full" while
+the other instance has nothing in flight (semi_pd/share_board.py) and on "share" otherwise.  Kernels launched on a stream --
+and the nodes of a hipGraph launched on it -- inherit the stream's CU mask (tools/cu_mask_check.py --streams verifies this
+on the box).  Grids, K splits and split-KV counts are sized for the CUs of the stream they run on, so the decode instance
+keeps one set of graphs per stream.
+
+Ordering: the instance has ONE logical queue of work.  Whenever it moves from one stream to the other, the new stream first
+waits for everything queued on the old one, so buffers allocated under one stream and read under the other are safe, and
+the caching allocator (which reuses a block only on the stream it was allocated on) stays consistent.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import logging
+from typing import Dict, Optional
+
+import torch
+
+from semi_pd_amd import _lib
+from semi_pd_amd.semi_pd.utils import InstanceRole, cu_mask_words, cu_masked_stream
+
+logger = logging.getLogger(__name__)
+
+SHARE, FULL = "share", "full"
+
+
+class CuShare:
+    def __init__(self, model_runner, role: InstanceRole, percent: int, board=None):
+        self.mr = model_runner
+        self.role = role
+        self.board = board
+        dev = model_runner.device
+        idx = dev.index or 0
+        from_top = role == InstanceRole.DECODE
+        n = model_runner.num_cus
+        self.cus: Dict[str, int] = {
+            SHARE: sum(bin(w).count("1") for w in cu_mask_words(n, percent, from_top)) if percent < 100 else n,
+            FULL: n}
+        raw = C.c_void_p()
+        _lib.check(_lib.load().semipd_stream_create(idx, C.addressof(raw)), "stream_create")
+        self.streams: Dict[str, torch.cuda.Stream] = {
+            SHARE: cu_masked_stream(idx, percent, from_top) if percent < 100
+            else torch.cuda.ExternalStream(raw.value, device=dev),
+            FULL: torch.cuda.ExternalStream(raw.value, device=dev)}
+        self.active: Optional[str] = None
+        self.taken = {SHARE: 0, FULL: 0}   # units of work run on each stream (statistics)
+        self.activate(SHARE)
+
+    # ---- which stream the next unit of work runs on ------------------------------------------------------------
+    def choose(self) -> str:
+        """The whole chip while the other instance is idle, the own share otherwise."""
+        if self.board is None or self.cus[SHARE] == self.cus[FULL]:
+            return SHARE
+        return FULL if self.board.peer_busy(self.role) == 0 else SHARE
+
+    def activate(self, name: str) -> str:
+        """Make `name` the stream every following launch of this thread goes to (torch's current stream; the C-ABI calls
+        take it from there) and tell the kernels how many CUs it has."""
+        new = self.streams[name]
+        if name != self.active:
+            if self.active is not None:
+                new.wait_stream(self.streams[self.active])
+            torch.cuda.set_stream(new)
+            self.active = name
+            self.mr.set_owned_cus(self.cus[name])
+        self.taken[name] += 1
+        return name
+
+    def step(self) -> str:
+        return self.activate(self.choose())
+
+    def publish(self, busy: int) -> None:
+        if self.board is not None:
+            self.board.publish(self.role, busy)

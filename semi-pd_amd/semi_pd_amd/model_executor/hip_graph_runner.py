@@ -81,8 +81,8 @@ class HipGraphRunner:
             self.out_cache_loc = torch.zeros(self.max_bs, dtype=torch.int64)
             self.positions = torch.zeros(self.max_bs, dtype=torch.int64)
         model_runner.attn_backend.init_cuda_graph_state(self.max_bs)
-        self.graphs: Dict[int, torch.cuda.CUDAGraph] = {}
-        self.outputs: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
+        self.graphs: Dict[Tuple[int, int], torch.cuda.CUDAGraph] = {}      # (CUs of the stream, batch size) -> graph
+        self.outputs: Dict[Tuple[int, int], Tuple[torch.Tensor, torch.Tensor]] = {}
         self.pool = None
         # the capture stream is OURS (not one of torch's pooled streams): a capture that fails half way can only be got rid
         # of by destroying its stream (include/semipd.h, semipd_stream_abort_capture)
@@ -94,8 +94,22 @@ class HipGraphRunner:
         self.stream = torch.cuda.ExternalStream(self._raw_stream, device=dev)
         import weakref
         self._stream_finalizer = weakref.finalize(self, _destroy_stream, self._raw_stream)
-        for bs in reversed(self.capture_bs):
-            self._capture_one(bs)
+        # one set of graphs per CU count the instance may run a step on (--cu-mask-mode dynamic with a decode share below
+        # 100 %: its masked stream and the whole chip; model_executor/cu_share.py): grids, K splits and split-KV counts
+        # are baked into a graph at capture
+        share = getattr(model_runner, "cu_share", None)
+        self.variants = sorted(set(share.cus.values())) if share is not None else [model_runner.num_cus_owned]
+        entered = model_runner.num_cus_owned
+        try:
+            for cus in self.variants:
+                if len(self.variants) > 1:
+                    model_runner.set_owned_cus(cus)
+                self._cus = cus
+                for bs in reversed(self.capture_bs):
+                    self._capture_one(bs)
+        finally:
+            if len(self.variants) > 1:
+                model_runner.set_owned_cus(entered)
 
     def _capture_one(self, bs: int):
         mr = self.mr
@@ -138,8 +152,8 @@ class HipGraphRunner:
             _PARKED.append((self, g, self.graphs, self.outputs, self.pool, self.stream))
             raise
         self.pool = self.pool or g.pool()
-        self.graphs[bs] = g
-        self.outputs[bs] = out
+        self.graphs[(self._cus, bs)] = g
+        self.outputs[(self._cus, bs)] = out
 
     def can_run(self, forward_batch: ForwardBatch) -> bool:
         return forward_batch.forward_mode.is_decode() and forward_batch.batch_size <= self.max_bs
@@ -156,6 +170,7 @@ class HipGraphRunner:
         self.req_pool_indices[:raw_bs].copy_(forward_batch.req_pool_indices)
         self.seq_lens[:raw_bs].copy_(forward_batch.seq_lens)
         self.out_cache_loc[:raw_bs].copy_(forward_batch.out_cache_loc)
-        self.graphs[bs].replay()
-        logits, ids = self.outputs[bs]
+        key = (self.mr.num_cus_owned if len(self.variants) > 1 else self.variants[0], bs)
+        self.graphs[key].replay()
+        logits, ids = self.outputs[key]
         return LogitsProcessorOutput(logits[:raw_bs] if logits is not None else None, next_token_ids=ids[:raw_bs])

@@ -52,12 +52,17 @@ def _seed_of(name: str, seed: int) -> int:
 
 
 @torch.no_grad()
-def dummy_init_weights(model: nn.Module, device: torch.device, seed: int = 0, std: float = 0.02):
+def dummy_init_weights(model: nn.Module, device: torch.device, seed: int = 0, std: float = 0.02,
+                       lm_head_scale: float = 1.0):
     """`--load-format dummy` (model_loader/loader.py: DummyModelLoader): deterministic random weights.
     Every parameter is drawn on the device from a generator seeded by its *name*, norm weights are 1,
-    so two processes (or a unified and a Semi-PD engine) build bit-identical models."""
+    so two processes (or a unified and a Semi-PD engine) build bit-identical models.  lm_head_scale multiplies the
+    vocabulary projection: i.i.d. logits over a 128 k vocabulary are nearly flat (top-2 gap mostly below the 5e-2 tie
+    margin of the parity tests); a scaled head spreads them so that most steps of a test discriminate."""
     params = dict(model.named_parameters())
+    base_std = std
     for name, p in params.items():
+        std = base_std * (lm_head_scale if name == "lm_head.weight" else 1.0)
         if p.device.type == "meta":
             continue
         if name.endswith("_scale_inv"):
@@ -117,7 +122,7 @@ class ModelRunner:
                  load_state_dict: Optional[Dict[str, torch.Tensor]] = None, model_path: Optional[str] = None,
                  load_format: str = "dummy", kv_cache_dtype: str = "auto", disable_custom_all_reduce: bool = False,
                  enable_ep_moe: bool = False, disable_stream_linear: bool = False,
-                 num_kv_splits: Optional[int] = None):
+                 num_kv_splits: Optional[int] = None, dummy_lm_head_scale: float = 1.0):
         self.model_config = model_config
         self.num_kv_splits = num_kv_splits        # --triton-attention-num-kv-splits; None = per batch
         self.gpu_id, self.tp_rank, self.tp_size = gpu_id, tp_rank, tp_size
@@ -145,14 +150,16 @@ class ModelRunner:
             init_distributed_environment(1, 0, "", dist_backend)
         self.num_cus = get_device_sm_count(gpu_id)
         self.num_cus_owned = self.num_cus
+        self.cu_share = None                     # --cu-mask-mode dynamic: model_executor/cu_share.py (init_cu_share)
         if cu_percent < 100:
-            # what the launcher's HSA_CU_MASK really enables (whole groups of 8 logical CUs, one per XCD)
+            # what the launcher's HSA_CU_MASK really enables (whole groups of 8 logical CUs, one per XCD); the decode
+            # instance's share is taken from the top of the range, which rounds differently on devices whose CU count is
+            # not a multiple of 16
             from semi_pd_amd.semi_pd.utils import cu_mask_words
-            self.num_cus_owned = sum(bin(w).count("1") for w in cu_mask_words(self.num_cus, cu_percent, False))
+            from_top = instance_role == InstanceRole.DECODE
+            self.num_cus_owned = sum(bin(w).count("1") for w in cu_mask_words(self.num_cus, cu_percent, from_top))
         # the decode-sized GEMMs fill whole rounds of the CUs this process owns (csrc/stream_linear.hip: sg_pick_ksplit)
-        from semi_pd_amd import _lib as _semipd_lib
-        _semipd_lib.check(_semipd_lib.load().semipd_stream_linear_set_cus(int(self.num_cus_owned)), "stream_linear_set_cus")
-        _semipd_lib.check(_semipd_lib.load().semipd_gemm_tall_set_cus(int(self.num_cus_owned)), "gemm_tall_set_cus")
+        self.set_owned_cus(self.num_cus_owned)
         # --random-seed reaches the stochastic sampler through the default device generator, the same on every
         # TP rank and in both instances (model_runner.py: set_random_seed in every worker)
         torch.manual_seed(seed)
@@ -183,7 +190,7 @@ class ModelRunner:
                         raise ValueError("load_format=%r needs a model_path" % load_format)
                     load_weights(self.model, model_config, safetensors_weights_iterator(model_path))
                 else:
-                    dummy_init_weights(self.model, self.device, seed)
+                    dummy_init_weights(self.model, self.device, seed, lm_head_scale=dummy_lm_head_scale)
                 # the initialisation temporaries (fp32 draws of full-size tensors) go back to the driver before
                 # anything else is allocated: a small tensor carved out of a cached multi-GiB block would be
                 # exported with that block's size (see _make_ipc_safe)
@@ -212,6 +219,25 @@ class ModelRunner:
         self.init_memory_pool(max_total_tokens)
         self.attn_backend = None
         self.graph_runner = None
+
+    # ------------------------------------------------------------------------------------ CU share
+    def set_owned_cus(self, cus: int) -> None:
+        """The CUs of the stream the following launches go to: grids, K splits and split-KV counts are sized for them
+        (csrc/stream_linear.hip: sg_pick_ksplit, csrc/gemm8p.hip, csrc/dense_gemm.hip's table, choose_kv_splits)."""
+        from semi_pd_amd import _lib
+        lib = _lib.load()
+        self.num_cus_owned = int(cus)
+        _lib.check(lib.semipd_stream_linear_set_cus(int(cus)), "stream_linear_set_cus")
+        _lib.check(lib.semipd_gemm_tall_set_cus(int(cus)), "gemm_tall_set_cus")
+        _lib.check(lib.semipd_dense_gemm_set_cus(int(cus)), "dense_gemm_set_cus")
+
+    def init_cu_share(self, role: InstanceRole, percent: int, board=None):
+        """--cu-mask-mode dynamic: this (unmasked) process gets a CU-masked stream over its own share next to a stream over
+        every CU and picks between them per unit of work (model_executor/cu_share.py)."""
+        from semi_pd_amd.model_executor.cu_share import CuShare
+        torch.cuda.synchronize(self.device)
+        self.cu_share = CuShare(self, role, percent, board)
+        return self.cu_share
 
     # ------------------------------------------------------------------------------------ memory
     def profile_max_num_token(self) -> int:
@@ -396,6 +422,9 @@ class ModelRunner:
         if self.disable_cuda_graph:
             return
         from semi_pd_amd.model_executor.hip_graph_runner import HipGraphRunner
+        if self.cu_share is not None:
+            # the process's own capture stream is unmasked; replays go to whichever stream is current (cu_share.py)
+            torch.cuda.synchronize(self.device)
         if self.tp_size == 1:
             self.graph_runner = HipGraphRunner(self)
             return

@@ -1,0 +1,72 @@
+"""Share board of one GPU's prefill / decode pair (include/semipd.h: semipd_share_board_*).
+
+The reference gives its instances OVERLAPPING shares -- prefill 80 % of the SMs, decode 100 % (semi_pd/utils.py:10-11,
+entrypoints/engine.py:588-593, 632-634) -- and lets MPS time-share what overlaps, so its decode instance is never confined to a
+slice.  CU masks are hard partitions: a masked decode instance keeps to its slice even while the prefill instance has
+nothing to do.  Here each instance publishes how much work it has in flight on one page of shared host memory, and picks --
+per decode step / per prefill batch -- between its own share and the whole chip (model_executor/cu_share.py).
+
+Slots (int64 each, one writer per slot):
+    BUSY_PREFILL   prefill batches launched and not yet finished
+    BUSY_DECODE    requests in the decode instance's running batch (0 = no step in flight)
+    BEAT_*         time.monotonic_ns() of the writer's last update (a reader treats a silent peer as idle after `stale_s`)
+    TAKEN_*        counters for the statistics: steps / batches the instance ran on the whole chip
+"""
+from __future__ import annotations
+
+import ctypes as C
+import time
+
+from semi_pd_amd import _lib
+from semi_pd_amd.semi_pd.utils import InstanceRole
+
+BUSY_PREFILL, BUSY_DECODE, BEAT_PREFILL, BEAT_DECODE, TAKEN_PREFILL, TAKEN_DECODE = range(6)
+
+
+class ShareBoard:
+    def __init__(self, path: str, create: bool = False, stale_s: float = 2.0):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self._lib.semipd_share_board_open(path.encode(), 1 if create else 0, C.addressof(h)), "share_board_open")
+        self._h = h.value
+        self.path = path
+        self.stale_ns = int(stale_s * 1e9)
+
+    def close(self):
+        if self._h:
+            self._lib.semipd_share_board_close(self._h)
+            self._h = None
+
+    def store(self, slot: int, value: int) -> None:
+        _lib.check(self._lib.semipd_share_board_store(self._h, slot, int(value)), "share_board_store")
+
+    def add(self, slot: int, delta: int) -> int:
+        out = C.c_int64()
+        _lib.check(self._lib.semipd_share_board_add(self._h, slot, int(delta), C.addressof(out)), "share_board_add")
+        return int(out.value)
+
+    def load(self, slot: int) -> int:
+        out = C.c_int64()
+        _lib.check(self._lib.semipd_share_board_load(self._h, slot, C.addressof(out)), "share_board_load")
+        return int(out.value)
+
+    # ---- the two instances' view -------------------------------------------------------------------------------
+    @staticmethod
+    def _slots(role: InstanceRole):
+        return (BUSY_PREFILL, BEAT_PREFILL) if role == InstanceRole.PREFILL else (BUSY_DECODE, BEAT_DECODE)
+
+    def publish(self, role: InstanceRole, busy: int) -> None:
+        """`role` has `busy` units of work in flight right now (0 = idle)."""
+        b, t = self._slots(role)
+        self.store(t, time.monotonic_ns())
+        self.store(b, busy)
+
+    def peer_busy(self, role: InstanceRole) -> int:
+        """Work the OTHER instance has in flight (0 = idle, or silent for longer than stale_s: a peer that died while busy
+        must not confine this instance for ever)."""
+        peer = InstanceRole.DECODE if role == InstanceRole.PREFILL else InstanceRole.PREFILL
+        b, t = self._slots(peer)
+        busy = self.load(b)
+        if busy and time.monotonic_ns() - self.load(t) > self.stale_ns:
+            return 0
+        return busy

@@ -24,6 +24,7 @@ class ServerArgs:
     host: str = "127.0.0.1"
     port: int = 30000
     load_format: str = "dummy"               # "dummy" (seeded random weights) | "auto" (HF safetensors)
+    dummy_lm_head_scale: float = 1.0         # dummy weights: lm_head drawn this much wider (sharper logits for parity tests)
     dtype: str = "bfloat16"
     kv_cache_dtype: str = "auto"             # "auto" | "fp8_e5m2" | "fp8_e4m3" (MHA / GQA pools)
     context_length: int = 4096
@@ -53,7 +54,13 @@ class ServerArgs:
     # Semi-PD compute split (semi_pd/utils.py:10-11 env knobs; BASELINE config 2 asks 50/50)
     prefill_cu_percent: int = PREFILL_ENGINE_SM_PERCENTILE
     decode_cu_percent: int = DECODE_ENGINE_SM_PERCENTILE
-    cu_mask_mode: str = "env"                # "env" (process-wide HSA_CU_MASK) | "none"
+    # "env": process-wide HSA_CU_MASK per instance (static shares) | "none" | "dynamic": unmasked processes, each with a
+    # CU-masked stream over its share and a stream over every CU, chosen per decode step / prefill batch from what the
+    # other instance has in flight (semi_pd/share_board.py, model_executor/cu_share.py)
+    cu_mask_mode: str = "env"
+    # dynamic mode: from this many waiting prompt tokens on a prefill batch takes every CU even while the decode
+    # instance is busy (an overloaded GPU: throughput first).  0 = never
+    prefill_backlog_full_tokens: int = 0
     prefill_stream_priority: int = 0         # HIP stream priority of the instance's compute stream: 0 normal, -1 high
     decode_stream_priority: int = 0
     # prefill-sized dense layers: time the library's GEMM solutions on the instance's own CU share at start-up and use

@@ -439,9 +439,12 @@ def test_synthetic_load_request_is_bounded_and_needs_a_captured_graph():
     assert d._synthetic_load_until > time.monotonic() + 60
     assert d._synthetic_step() is False and d._synthetic_load_until == 0.0     # no graph runner here
     replays = []
-    d.model_runner.graph_runner = SimpleNamespace(graphs={8: SimpleNamespace(replay=lambda: replays.append(8)),
-                                                          32: SimpleNamespace(replay=lambda: replays.append(32)),
-                                                          64: SimpleNamespace(replay=lambda: replays.append(64))})
+    # graphs are keyed (CUs of the stream they were captured for, batch size): the set of the current stream is taken
+    d.model_runner.num_cus_owned = 96
+    d.model_runner.graph_runner = SimpleNamespace(graphs={(96, 8): SimpleNamespace(replay=lambda: replays.append(8)),
+                                                          (96, 32): SimpleNamespace(replay=lambda: replays.append(32)),
+                                                          (256, 32): SimpleNamespace(replay=lambda: replays.append(-32)),
+                                                          (96, 64): SimpleNamespace(replay=lambda: replays.append(64))})
     d_in.send_pyobj(SyntheticLoadReq(on=True))
     d.step()
     sync = torch.cuda.current_stream
