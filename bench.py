@@ -162,6 +162,20 @@ def summarize(records, duration):
             "p99_tbt_ms": float(np.percentile(itl, 99) * 1e3) if itl else None}
 
 
+def pmc_traffic(kernel: str, algorithmic_bytes: float) -> dict:
+    """`traffic` of the roofline object: HBM bytes per launch from the committed PMC pass of the kernel (its measured
+    traffic / algorithmic ratio times this launch's algorithmic bytes), with the file it comes from; null without one."""
+    try:
+        table = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        for name, rec in table.items():
+            if name in kernel:
+                return {"traffic": int(rec["traffic_over_algorithmic"] * algorithmic_bytes),
+                        "traffic_over_algorithmic": rec["traffic_over_algorithmic"], "traffic_source": rec["source"]}
+    except (OSError, ValueError, KeyError):
+        pass
+    return {"traffic": None}
+
+
 def cpu_baseline(cfg, input_len, output_len, budget_s=25.0):
     """The CPU oracle (oracle/model.py, a port of the reference's torch_native path) timed on this
     host, on a bounded sample of the same workload: ONE transformer layer of the model's real shape
@@ -268,6 +282,8 @@ def main():
                     help="N = 1 Semi-PD default run: do not start the second engine with BASELINE config 2's literal 50 / 50 split")
     ap.add_argument("--no-prefill-gemm-tuning", action="store_true",
                     help="prefill instance: the library's own GEMM choice instead of the solutions timed on its CU share")
+    ap.add_argument("--tune-prefill-gemm", action="store_true",
+                    help="time the library's GEMM solutions at start-up even when the prefill instance owns every CU")
     ap.add_argument("--cu-mask-mode", default="env", choices=["env", "none", "dynamic"],
                     help="env: static HSA_CU_MASK per instance; dynamic: unmasked processes with a CU-masked stream over their "
                          "share and a stream over every CU, chosen per decode step / prefill batch (work-conserving shares)")
@@ -301,6 +317,9 @@ def main():
     ap.add_argument("--replicas", action="store_true",
                     help="N > 1: N independent Semi-PD replicas, one per GPU (no data-path collective), instead of ONE "
                          "engine tensor-parallel over the N GPUs")
+    ap.add_argument("--no-side-configs", action="store_true",
+                    help="default Llama-3-8B line: skip the one-wave runs of BASELINE configs 1 (OPT-125m, with its CPU "
+                         "baseline) and 3 (DeepSeek-V2-Lite)")
     ap.add_argument("--no-saturation-wave", action="store_true",
                     help="skip the extra (untimed for `value`) wave with all requests sent at once")
     ap.add_argument("--rate-sweep", default=None, help="comma-separated Poisson rates; one extra (untimed for "
@@ -369,7 +388,7 @@ def main():
                     decode_cu_percent=args.decode_cu, cu_mask_mode=args.cu_mask_mode,
                     prefill_backlog_full_tokens=args.prefill_backlog_full_tokens,
                     library_gemm_grid=args.library_gemm_grid, disable_stream_linear=args.disable_stream_linear,
-                    tune_prefill_gemm=(False if args.no_prefill_gemm_tuning else None),
+                    tune_prefill_gemm=(False if args.no_prefill_gemm_tuning else (True if args.tune_prefill_gemm else None)),
                     prefill_stream_priority=args.prefill_priority, decode_stream_priority=args.decode_priority,
                     disable_cuda_graph=args.disable_cuda_graph, nccl_port_base=port_base,
                     disable_overlap_schedule=args.disable_overlap_schedule,
@@ -454,6 +473,38 @@ def main():
         finally:
             eng2.shutdown()
 
+    # BASELINE configs 1 and 3, one wave each, in the same invocation (they are parity-test cases, not the bench line:
+    # extra keys only).  Config 1 runs the reference's own CPU-runnable case whole, with the CPU oracle timed on the same
+    # workload beside it; config 3 is the MLA + MoE model at the config-2 load.
+    side = {}
+    default_line = (world == 1 and args.mode == "semi-pd" and args.model == "llama3-8b" and not args.no_side_configs)
+    if default_line:
+        import dataclasses
+        for key, model, nreq, ilen, olen, rate, pcu, dcu in (
+                ("config1_opt_125m", "opt-125m", 32, 128, 64, 0.0, args.prefill_cu, args.decode_cu),
+                ("config3_deepseek_v2_lite", "deepseek-v2-lite", 256, 1024, 128, 32.0, args.prefill_cu, args.decode_cu)):
+            try:
+                scfg = model_config(model)
+                ssa = dataclasses.replace(sa, model_config=scfg, context_length=ilen + olen + 8, prefill_cu_percent=pcu,
+                                          decode_cu_percent=dcu, collect_kernel_timing=False, served_model_name=None)
+                eng3 = Engine(ssa, gpu_ids={0: local_rank})
+                try:
+                    sp = make_requests(nreq, ilen, scfg.vocab_size, args.seed)
+                    sarr = arrival_times(nreq, rate, args.seed)
+                    run_wave(eng3, sp, sarr, olen)
+                    recs, dur = run_wave(eng3, sp, sarr, olen)
+                finally:
+                    eng3.shutdown()
+                sm = summarize(recs, dur)
+                side[key] = {"workload": f"{model} bf16 TP=1 semi-pd, same CU policy as the headline, {nreq} synthetic requests "
+                                         f"in={ilen} out={olen}, " + (f"Poisson {rate} req/s" if rate else "all sent at t = 0")
+                                         + ", one warm-up wave + one timed wave",
+                             **{k: (round(v, 2) if isinstance(v, float) else v) for k, v in sm.items()}}
+                if model == "opt-125m" and not args.no_cpu_baseline:
+                    side[key]["cpu_baseline"] = cpu_baseline_opt(scfg, nreq, ilen, olen, args.seed)
+            except Exception as e:  # a side wave must never take the measured line down with it
+                side[key] = {"error": repr(e)}
+
     if rank != 0:
         return
     summ = summarize(all_records, elapsed)
@@ -482,10 +533,10 @@ def main():
         def hbm_line(k, kernel):
             return {"bound": "hbm", "kernel": kernel, "achieved": round(k["gbps"], 1),
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(k["gbps"] / HBM_PEAK_GBPS, 4),
-                    # PMC counters cannot be read from inside this process: `traffic` is null in this line.
-                    # The rocprofv3 --pmc FETCH_SIZE pass of the same command (x2 gfx950 correction) is a
-                    # separate run; its summary is committed under profiles/ (see DESIGN.md, section 6).
-                    "traffic": None,
+                    # PMC counters cannot be read from inside this process: the HBM bytes per launch come from the
+                    # committed rocprofv3 --pmc pass of this kernel (profiles/pmc_traffic.json: FETCH_SIZE x 2 on gfx950
+                    # + WRITE_SIZE over the algorithmic bytes of the profiled launch), scaled to this launch's bytes
+                    **pmc_traffic(kernel, k["bytes_per_launch"]),
                     "avg_launch_us": round(k["avg_us"], 2),
                     "avg_launch_us_minus_event_overhead": round(k.get("avg_us_minus_event_overhead", k["avg_us"]), 2),
                     "event_pair_overhead_us": kt.get("_event_pair_overhead_us"),
@@ -557,6 +608,7 @@ def main():
     }
     if static_split:
         out["static_split_50_50"] = static_split
+    out.update(side)
     if saturation:
         out["saturation"] = {"note": "extra wave, every request sent at t = 0: output tok/s here is the engine's capacity; "
                                      "`value` above is measured at the Poisson rate named in config (load-bound)",

@@ -69,6 +69,7 @@ struct Tuned {  // winner of one tuning run
   int solution_index;
   float us, us_default;
   int candidates, rejected;   // solutions timed; fast ones dropped because their result disagreed with the library's choice
+  std::string name;           // the library's name of the winning solution (tile sizes, stream-K or not, ...)
 };
 
 struct State {
@@ -266,9 +267,16 @@ int semipd_dense_gemm_tune(int64_t n, int64_t k, const int64_t* rows, int num_ro
     Plan p;
     if (make_problem(p, dtype, m, n, k, k, n, false)) { rc = 1; break; }
     std::vector<hipblasLtMatmulAlgo_t> cand;
+    // SEMIPD_DG_EXCLUDE=<substring>: solutions whose library name contains it are not candidates (e.g. the persistent
+    // stream-K kernels, which hold every CU they run on for the whole GEMM: next to another instance's short kernels a
+    // tiled solution of equal speed is the better neighbour).  The library's own first choice is always kept.
+    const char* exclude = getenv("SEMIPD_DG_EXCLUDE");
     auto add = [&](const hipblasLtMatmulAlgo_t& a) {
       hipblasLtMatmulAlgo_t c = a;
       const int idx = hipblaslt_ext::getIndexFromAlgo(c);
+      if (exclude && *exclude && !cand.empty() &&
+          hipblaslt_ext::getSolutionNameFromAlgo(s.handle, c).find(exclude) != std::string::npos)
+        return;
       for (auto& q : cand)
         if (hipblaslt_ext::getIndexFromAlgo(q) == idx) return;
       cand.push_back(a);
@@ -370,6 +378,7 @@ int semipd_dense_gemm_tune(int64_t n, int64_t k, const int64_t* rows, int num_ro
       t.us_default = t_default;
       t.candidates = (int)timed.size();
       t.rejected = rejected;
+      t.name = hipblaslt_ext::getSolutionNameFromAlgo(s.handle, t.algo);
       s.tuned[std::make_tuple(s.share, dtype, n, k)][m] = t;
     }
     destroy_problem(p);
@@ -452,13 +461,14 @@ size_t semipd_dense_gemm_report(char* buf, size_t len) {
   State& s = st();
   std::lock_guard<std::mutex> g(s.mu);
   std::string out;
-  char line[256];
+  char line[1024];
   for (auto& kv : s.tuned)
     for (auto& rv : kv.second) {
       snprintf(line, sizeof(line),
-               "cus=%d dtype=%d n=%lld k=%lld rows=%lld solution=%d us=%.1f library_choice_us=%.1f candidates=%d wrong_results_rejected=%d\n",
+               "cus=%d dtype=%d n=%lld k=%lld rows=%lld solution=%d us=%.1f library_choice_us=%.1f candidates=%d wrong_results_rejected=%d kernel=%s\n",
                std::get<0>(kv.first), std::get<1>(kv.first), (long long)std::get<2>(kv.first), (long long)std::get<3>(kv.first), (long long)rv.first,
-               rv.second.solution_index, rv.second.us, rv.second.us_default, rv.second.candidates, rv.second.rejected);
+               rv.second.solution_index, rv.second.us, rv.second.us_default, rv.second.candidates, rv.second.rejected,
+               rv.second.name.c_str());
       out += line;
     }
   if (buf && len) {
@@ -467,6 +477,54 @@ size_t semipd_dense_gemm_report(char* buf, size_t len) {
     buf[c] = 0;
   }
   return out.size() + 1;
+}
+
+/* Load a tuning table written by semipd_dense_gemm_report (same text, one line per entry) instead of timing again: every
+ * line's solution index is turned back into an algorithm of THIS library build and checked for support on the line's own
+ * problem; lines that do not survive are skipped.  *loaded (may be NULL) receives the number of entries taken.  The caller
+ * keys the file on (architecture, CU count, library version): an index means nothing to another build. */
+int semipd_dense_gemm_import(const char* text, int* loaded) {
+  SEMIPD_CHECK_ARG(text, SEMIPD_EINVAL, "dense_gemm_import: null text");
+  State& s = st();
+  std::lock_guard<std::mutex> g(s.mu);
+  if (ensure_init(s, 0)) return 1;
+  int taken = 0;
+  const char* p = text;
+  while (*p) {
+    const char* e = strchr(p, '\n');
+    std::string line(p, e ? (size_t)(e - p) : strlen(p));
+    p = e ? e + 1 : p + line.size();
+    int cus = 0, dtype = 0, sol = -1, cand = 0, rej = 0;
+    long long n = 0, k = 0, rows = 0;
+    float us = 0.f, us_def = 0.f;
+    if (sscanf(line.c_str(), "cus=%d dtype=%d n=%lld k=%lld rows=%lld solution=%d us=%f library_choice_us=%f candidates=%d "
+               "wrong_results_rejected=%d", &cus, &dtype, &n, &k, &rows, &sol, &us, &us_def, &cand, &rej) != 10)
+      continue;
+    if ((dtype != SEMIPD_BF16 && dtype != SEMIPD_F16) || n <= 0 || k <= 0 || rows <= 0 || sol < 0) continue;
+    std::vector<int> idx{sol};
+    std::vector<hipblasLtMatmulHeuristicResult_t> res;
+    if (hipblaslt_ext::getAlgosFromIndex(s.handle, idx, res) != HIPBLAS_STATUS_SUCCESS || res.empty()) continue;
+    Plan pl;
+    if (make_problem(pl, dtype, rows, n, k, k, n, false)) continue;
+    hipblasLtMatmulAlgo_t a = res[0].algo;
+    const bool ok = supported(s, pl, a);
+    destroy_problem(pl);
+    if (!ok) continue;
+    Tuned t;
+    t.algo = a;
+    t.solution_index = sol;
+    t.us = us;
+    t.us_default = us_def;
+    t.candidates = cand;
+    t.rejected = rej;
+    t.name = hipblaslt_ext::getSolutionNameFromAlgo(s.handle, a);
+    s.tuned[std::make_tuple(cus, dtype, (int64_t)n, (int64_t)k)][(int64_t)rows] = t;
+    ++taken;
+  }
+  for (auto& kv : s.plans) destroy_problem(kv.second);
+  s.plans.clear();
+  if (loaded) *loaded = taken;
+  return 0;
 }
 
 }  // extern "C"

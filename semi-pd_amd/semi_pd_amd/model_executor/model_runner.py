@@ -124,6 +124,7 @@ class ModelRunner:
                  enable_ep_moe: bool = False, disable_stream_linear: bool = False,
                  num_kv_splits: Optional[int] = None, dummy_lm_head_scale: float = 1.0):
         self.model_config = model_config
+        self.model_path = model_path
         self.num_kv_splits = num_kv_splits        # --triton-attention-num-kv-splits; None = per batch
         self.gpu_id, self.tp_rank, self.tp_size = gpu_id, tp_rank, tp_size
         self.dtype = dtype
@@ -225,7 +226,13 @@ class ModelRunner:
         """The CUs of the stream the following launches go to: grids, K splits and split-KV counts are sized for them
         (csrc/stream_linear.hip: sg_pick_ksplit, csrc/gemm8p.hip, csrc/dense_gemm.hip's table, choose_kv_splits)."""
         from semi_pd_amd import _lib
+        import os
         lib = _lib.load()
+        # experiments: SEMIPD_DECLARED_CUS_DECODE / _PREFILL size an instance's grids for another CU count than it owns (an
+        # unmasked decode instance next to a masked prefill instance finds only part of the chip free at any moment)
+        over = os.environ.get("SEMIPD_DECLARED_CUS_" + self.instance_role.name)
+        if over:
+            cus = int(over)
         self.num_cus_owned = int(cus)
         _lib.check(lib.semipd_stream_linear_set_cus(int(cus)), "stream_linear_set_cus")
         _lib.check(lib.semipd_gemm_tall_set_cus(int(cus)), "gemm_tall_set_cus")
@@ -407,9 +414,42 @@ class ModelRunner:
                     key = (int(w.shape[0]), int(w.shape[1]), w.dtype)
                     if key not in shapes:
                         shapes.append(key)
+        # start-up cache: the table is a property of (architecture, CUs of the share, library build, shapes, row counts);
+        # it is kept under $SEMIPD_CACHE_DIR (default ~/.cache/semipd) and next to the model when there is a model path
+        import hashlib, os
+        lib_ver = torch.version.hip or "?"
+        arch = torch.cuda.get_device_properties(self.device).gcnArchName.split(":")[0]
+        key = hashlib.sha256(repr((arch, self.num_cus, self.num_cus_owned, lib_ver, sorted((n, k, str(dt)) for n, k, dt in shapes),
+                                   tuple(rows), int(num_full_search), os.environ.get("SEMIPD_DG_FINAL_US", ""))).encode()).hexdigest()[:16]
+        dirs = [os.environ.get("SEMIPD_CACHE_DIR") or os.path.join(os.path.expanduser("~"), ".cache", "semipd")]
+        if getattr(self, "model_path", None) and os.path.isdir(self.model_path):
+            dirs.insert(0, self.model_path)
+        name = f"dense_gemm_{arch}_{self.num_cus_owned}cus_{key}.txt"
+        if os.environ.get("SEMIPD_DG_CACHE", "1") != "0":
+            for d in dirs:
+                try:
+                    text = open(os.path.join(d, name)).read()
+                except OSError:
+                    continue
+                if ops.dense_gemm_import(text, shapes) > 0:
+                    logger.warning("library GEMM table for %d CUs taken from %s", self.num_cus_owned, os.path.join(d, name))
+                    return ops.dense_gemm_report()
         with torch.cuda.device(self.device):
             for n, k, dt in shapes:
                 ops.dense_gemm_tune(n, k, list(rows), dt, num_full_search=num_full_search)
+        report = ops.dense_gemm_report()
+        if os.environ.get("SEMIPD_DG_CACHE", "1") != "0":
+            mine = "".join(ln + "\n" for ln in report.splitlines() if ln.startswith(f"cus={self.num_cus_owned} "))
+            for d in dirs:
+                try:
+                    os.makedirs(d, exist_ok=True)
+                    tmp = os.path.join(d, name + f".{os.getpid()}.tmp")
+                    with open(tmp, "w") as f:
+                        f.write(mine)
+                    os.replace(tmp, os.path.join(d, name))
+                    break
+                except OSError:
+                    continue
         return ops.dense_gemm_report()
 
     # ------------------------------------------------------------------------------------ backend / graphs

@@ -422,6 +422,22 @@ def dense_gemm_tune(n: int, k: int, rows, dtype: torch.dtype, num_full_search: i
     _DENSE_GEMM["tuned"].add((int(n), int(k), dtype))
 
 
+def dense_gemm_import(text: str, shapes) -> int:
+    """Take a tuning table written by dense_gemm_report (a start-up cache) instead of timing; `shapes` = the (n, k, dtype)
+    the table was made for (they are marked tuned when at least one of their lines was taken).  Returns entries taken."""
+    import ctypes as _C
+    lib = _lib.load()
+    check(lib.semipd_dense_gemm_init(0), "dense_gemm_init")
+    got = _C.c_int(0)
+    check(lib.semipd_dense_gemm_import(text.encode(), _C.addressof(got)), "dense_gemm_import")
+    if got.value:
+        _DENSE_GEMM["ready"] = True
+        for n, k, dt in shapes:
+            if f" n={int(n)} k={int(k)} " in text:
+                _DENSE_GEMM["tuned"].add((int(n), int(k), dt))
+    return int(got.value)
+
+
 def dense_gemm_is_tuned(weight: torch.Tensor) -> bool:
     return _DENSE_GEMM["ready"] and (weight.shape[0], weight.shape[1], weight.dtype) in _DENSE_GEMM["tuned"]
 

@@ -1,0 +1,91 @@
+"""Work-conserving CU shares on the GPU (--cu-mask-mode dynamic; model_executor/cu_share.py, semi_pd/share_board.py).
+
+ * a hipGraph captured on an ordinary stream and replayed on a CU-masked stream runs on the masked CUs only (the decode
+   instance's step is one graph launch: the mask of the stream it is launched on must reach every node), and the same
+   graph replayed on the unmasked stream uses the whole chip again;
+ * the Semi-PD engine in dynamic mode -- unmasked processes, each with a masked stream over its share and a stream over
+   every CU, chosen per decode step / prefill batch from the share board -- produces the oracle's tokens, and both
+   instances report which streams their work ran on.
+Stands in for the reference's overlapping MPS percentages (semi_pd/utils.py:10-11, entrypoints/engine.py:588-593,
+632-634), which time-share what overlaps; no reference test exists for them."""
+import ctypes as C
+
+import pytest
+import torch
+
+from oracle.model import OracleLlama
+from test_gpu_engine import check_against_oracle, make_prompts, server_args, tiny_llama
+
+pytestmark = pytest.mark.gpu
+
+
+def _slots(out):
+    return {(int(x), int(c)) for x, c in out.cpu().tolist()}
+
+
+def test_a_graph_replayed_on_a_masked_stream_keeps_to_the_mask(device):
+    from semi_pd_amd import _lib
+    from semi_pd_amd.semi_pd.utils import cu_masked_stream, get_device_sm_count
+    lib = _lib.load()
+    ncu = get_device_sm_count(0)
+    nwg = 4096
+    out = torch.full((nwg, 2), -1, dtype=torch.int32, device=device)
+    cap = torch.cuda.Stream()
+    cap.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=cap):
+        _lib.check(lib.semipd_probe_cu_placement(out.data_ptr(), nwg, 20000, _lib.current_stream(out.device)), "probe")
+    torch.cuda.synchronize()
+    g.replay()
+    torch.cuda.synchronize()
+    full = _slots(out)
+    assert len(full) >= 0.9 * ncu
+    seen = {}
+    for from_top, pct in ((True, 38), (False, 62)):
+        st = cu_masked_stream(0, pct, from_top)
+        out.fill_(-1)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(st):
+            g.replay()
+        torch.cuda.synchronize()
+        seen[from_top] = _slots(out)
+        want = ncu * pct // 100
+        assert len(seen[from_top]) <= want + 10, (len(seen[from_top]), want)
+        assert len({x for x, _ in seen[from_top]}) == len({x for x, _ in full}), "share is not spread over all XCDs"
+    assert not (seen[True] & seen[False]), "a decode-share replay and a prefill-share replay met on a CU"
+    out.fill_(-1)
+    g.replay()   # back on the ordinary stream: the whole chip
+    torch.cuda.synchronize()
+    assert len(_slots(out)) >= 0.9 * ncu
+
+
+def test_semi_pd_with_dynamic_shares_matches_the_oracle_and_reports_its_streams(device):
+    from semi_pd_amd.entrypoints.engine import Engine
+    from semi_pd_amd.managers.io_struct import SamplingParams
+    cfg = tiny_llama()
+    prompts = make_prompts(cfg.vocab_size, [5, 37, 128, 1, 64, 90, 17, 33])
+    sp = SamplingParams(max_new_tokens=12, ignore_eos=True)
+    uni = Engine(server_args(cfg))
+    try:
+        sd = {k: v.float().cpu() for k, v in uni.model_runner.model.state_dict().items()}
+    finally:
+        uni.shutdown()
+    oracle = OracleLlama(cfg, sd)
+    for p_cu, d_cu in ((62, 38), (75, 100)):
+        eng = Engine(server_args(cfg, enable_semi_pd=True, cu_mask_mode="dynamic", prefill_cu_percent=p_cu,
+                                 decode_cu_percent=d_cu, tune_prefill_gemm=False))
+        try:
+            assert all(not i["hsa_cu_mask"] for i in eng.ready_infos), "dynamic mode must not mask the processes"
+            got = eng.generate(prompts, sp, timeout=300)
+            again = eng.generate(prompts, sp, timeout=300)
+            stats = {s["role"]: s for s in eng.get_stats()}
+        finally:
+            eng.shutdown()
+        check_against_oracle(oracle, prompts, got)
+        check_against_oracle(oracle, prompts, again)
+        d, p = stats["DECODE"], stats["PREFILL"]
+        assert d.get("steps_on_full", 0) + d.get("steps_on_share", 0) == d["decode_steps"] + d.get("steps_dropped", 0) \
+            or d.get("steps_on_full", 0) + d.get("steps_on_share", 0) >= d["decode_steps"]
+        assert p.get("batches_on_full", 0) + p.get("batches_on_share", 0) == p["prefill_batches"]
+        # the first prefill batch of an idle engine finds the decode instance idle: it takes every CU
+        assert p.get("batches_on_full", 0) >= 1

@@ -56,19 +56,23 @@ def check_against_oracle(oracle, prompts, outputs, margin=MARGIN, min_discrimina
     _, logits = oracle.generate(prompts, n, forced=outputs)
     exact = disc = 0
     deficit = 0.0     # how far below the oracle's maximum the engine's token ever was (headroom against `margin`)
+    bad = []
     for b, toks in enumerate(outputs):
         for s, t in enumerate(toks):
             row = logits[b, s]
             top2 = torch.topk(row.float(), 2).values
             best, gap = float(top2[0]), float(top2[0] - top2[1])
-            assert float(row[t]) >= best - margin, (
-                f"request {b} step {s}: engine token {t} has oracle logit {float(row[t]):.4f}, "
-                f"argmax {int(row.argmax())} has {best:.4f}")
-            deficit = max(deficit, best - float(row[t]))
+            d = best - float(row[t])
+            deficit = max(deficit, d)
+            if d > margin:
+                bad.append(f"request {b} step {s}: engine token {t} has oracle logit {float(row[t]):.4f}, "
+                           f"argmax {int(row.argmax())} has {best:.4f} (deficit {d:.4f}, oracle top-2 gap {gap:.4f})")
             if gap > margin:
                 disc += 1
-                assert int(row.argmax()) == t, f"request {b} step {s}: discriminating step (gap {gap:.3f}) lost"
+                if int(row.argmax()) != t and d <= margin:
+                    bad.append(f"request {b} step {s}: discriminating step (gap {gap:.3f}) lost")
             exact += int(int(row.argmax()) == t)
+    assert not bad, f"{len(bad)} of {len(outputs) * n} steps outside the margin {margin} (largest deficit {deficit:.4f}):\n" + "\n".join(bad[:8])
     total = len(outputs) * n
     check_against_oracle.last = {"steps": total, "discriminating": disc, "exact": exact, "margin": margin,
                                  "max_deficit": deficit}

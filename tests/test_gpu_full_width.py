@@ -20,13 +20,18 @@ from test_gpu_engine import check_against_oracle, make_prompts, server_args
 pytestmark = pytest.mark.gpu
 
 MARGIN = 6e-2
+# On a DISCRIMINATING step (oracle top-2 gap > MARGIN) check_against_oracle demands the engine's token to EQUAL the
+# oracle's argmax; it counts and prints those steps.  i.i.d. logits over a 128 k vocabulary have a typical top-2 gap of
+# 0.2 of their std, so about a fifth of the steps of a random-weight model are near-ties inside any margin that bf16
+# arithmetic needs; scaling the head (ServerArgs.dummy_lm_head_scale) scales gap and rounding noise alike.
+HEAD_SCALE = 1.0
 LENS = [1024, 300, 7]
 STEPS = 8
 
 
 def _args(cfg, **kw):
     base = dict(context_length=1100, max_running_requests=8, max_total_tokens=6000, cuda_graph_max_bs=8,
-                watchdog_timeout=300.0)
+                watchdog_timeout=300.0, dummy_lm_head_scale=HEAD_SCALE)
     base.update(kw)
     return server_args(cfg, **base)
 
@@ -45,14 +50,14 @@ def _run_both(cfg, oracle_cls):
     torch.cuda.empty_cache()
     oracle = oracle_cls(cfg, sd)
     assert all(len(o) == STEPS for o in uni)
-    frac_u = check_against_oracle(oracle, prompts, uni, margin=MARGIN)
+    frac_u = check_against_oracle(oracle, prompts, uni, margin=MARGIN, min_discriminating=0.6)
     eng = Engine(_args(cfg, enable_semi_pd=True, prefill_cu_percent=50, decode_cu_percent=50))
     try:
         semi = eng.generate(prompts, sp, timeout=600)
     finally:
         eng.shutdown()
     assert all(len(o) == STEPS for o in semi)
-    frac_s = check_against_oracle(oracle, prompts, semi, margin=MARGIN)
+    frac_s = check_against_oracle(oracle, prompts, semi, margin=MARGIN, min_discriminating=0.6)
     return frac_u, frac_s
 
 
@@ -60,7 +65,7 @@ def test_llama3_8b_width_two_layers_unified_and_semi_pd_match_the_oracle(device)
     from semi_pd_amd.models.llama import LLAMA3_8B
     cfg = dataclasses.replace(LLAMA3_8B, num_hidden_layers=2, max_position_embeddings=2048)
     frac_u, frac_s = _run_both(cfg, OracleLlama)
-    # 24 tokens over a 128 k vocabulary of i.i.d. logits: a flipped near-tie (inside MARGIN) is rare but possible
+    # the discriminating steps are equal to the oracle's argmax (asserted inside); of the near-ties some may flip
     assert frac_u >= 0.8 and frac_s >= 0.8, (frac_u, frac_s)
 
 

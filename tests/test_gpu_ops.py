@@ -1047,6 +1047,25 @@ def test_dense_gemm_with_measured_library_solution_matches_fp32(ops, device):
                     torch.testing.assert_close(got.float(), F.linear(x, w, bias).float(), rtol=tol, atol=tol)
     with pytest.raises(RuntimeError):
         ops.dense_gemm(torch.zeros(4, 8, device=device), torch.zeros(4, 8, device=device))   # fp32: not this path
+    # the table as a start-up cache: what the report prints is what the import reads; filed under another CU count
+    # (semipd_dense_gemm_set_cus: an instance on another stream) it is found there and nowhere else, and the product of a
+    # re-imported solution is still the product
+    from semi_pd_amd import _lib
+    lib = _lib.load()
+    report = ops.dense_gemm_report()
+    mine = "".join(ln + "\n" for ln in report.splitlines() if " n=768 k=512 " in ln)
+    assert mine.count("\n") == 4                                  # two row counts x two dtypes
+    moved = mine.replace("cus=0 ", "cus=77 ")
+    assert ops.dense_gemm_import(moved + "garbage line\ncus=77 dtype=2 n=768 k=512 rows=64 solution=-3 us=1 library_choice_us=1 "
+                                 "candidates=1 wrong_results_rejected=0\n", [(768, 512, torch.bfloat16)]) == 4
+    assert "cus=77 " in ops.dense_gemm_report()
+    try:
+        _lib.check(lib.semipd_dense_gemm_set_cus(77), "set_cus")
+        x = torch.randn(256, 512, generator=g).to(torch.bfloat16).to(device)
+        w = (torch.randn(768, 512, generator=g) * 0.05).to(torch.bfloat16).to(device)
+        torch.testing.assert_close(ops.dense_gemm(x, w).float(), x.float() @ w.float().t(), rtol=2e-2, atol=2e-2)
+    finally:
+        _lib.check(lib.semipd_dense_gemm_set_cus(0), "set_cus")
 
 
 # --------------------------------------------------------------------------- tall decode batches: tiled ping-pong GEMM

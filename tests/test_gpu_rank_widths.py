@@ -1,0 +1,108 @@
+"""Engine-level parity at the per-rank widths of BASELINE configs 4 and 5 (bench.py: llama3-70b-tp8-rank,
+deepseek-v3-tp8-rank) and of the 70B layer under TP = 2.
+
+ * Llama-3-70B TP = 8, one rank: hidden 8192, 8 q heads / 1 kv head of 128 (MQA inside the rank), MLP columns 3584,
+   1 / 8 of the vocabulary -- two layers, unified and Semi-PD, against OracleLlama;
+ * DeepSeek-V3 block-fp8 TP = 8, one rank: hidden 7168, 16 MLA heads, q_lora 1536, kv_lora 512 + 64, 256 routed experts
+   of width 256 (top-8 in 8 groups, sigmoid routing with bias), dense width 2304, fp8 e4m3fn weights with 128 x 128 block
+   scales -- one dense + one MoE layer, unified and Semi-PD, against OracleDeepseekV2 running the same quantised arithmetic;
+ * Llama-3-70B layers (hidden 8192, 64 / 8 heads, intermediate 28672) sharded TP = 2 on the one GPU (gloo + the
+   peer-memory all-reduce): the sharded loaders, the all-reduce behind o_proj / down_proj (the reference's
+   layers/linear.py:1266) and the logits all-gather at the real width, against the oracle of the unsharded model.
+
+Tolerance.  Every engine token must be the oracle's argmax or within the tie margin of it, and on every DISCRIMINATING step
+(oracle top-2 gap above the margin) it must EQUAL the argmax (check_against_oracle counts and prints them).  The margin is
+what bf16 arithmetic needs at this width, measured on the CPU: the oracle with activations rounded to bf16 where the
+engine materialises them differs from the fp32 oracle by a logit error of std 0.030 at hidden 8192 (1.7 % of the logits'
+std 1.81; tools: OracleLlama(act_dtype=bfloat16) on the rank-width model), so the difference of two logits carries
+0.042 and 0.15 is 3.5 sigma of it (the reference's own bar is 5e-2 on logprobs of trained models,
+test/srt/models/test_generation_models.py:43-45; i.i.d. logits over 16 k tokens have a typical top-2 gap of 0.23 std, so
+a fifth to a quarter of the steps of ANY random-weight model sit inside such a margin -- scaling the head scales gap and
+noise alike, ServerArgs.dummy_lm_head_scale changes nothing about that ratio).  The fp8 model keeps the margin of
+test_gpu_deepseek.py's fp8 case."""
+import dataclasses
+
+import pytest
+import torch
+
+from oracle.model import OracleDeepseekV2, OracleLlama
+from test_gpu_engine import check_against_oracle, make_prompts, server_args
+
+pytestmark = pytest.mark.gpu
+
+MARGIN = 0.15        # hidden 8192: see the docstring
+HEAD_SCALE = 1.0
+LENS = [1024, 300, 7]
+STEPS = 8
+
+
+def _args(cfg, **kw):
+    base = dict(context_length=1100, max_running_requests=8, max_total_tokens=6000, cuda_graph_max_bs=8,
+                watchdog_timeout=300.0, dummy_lm_head_scale=HEAD_SCALE)
+    base.update(kw)
+    return server_args(cfg, **base)
+
+
+def _generate(args, prompts, want_sd=False, **engine_kw):
+    from semi_pd_amd.entrypoints.engine import Engine
+    from semi_pd_amd.managers.io_struct import SamplingParams
+    eng = Engine(args, **engine_kw)
+    try:
+        sd = None
+        if want_sd:
+            sd = {k: v.float().cpu() for k, v in eng.model_runner.model.state_dict().items()}
+        outs = eng.generate(prompts, SamplingParams(max_new_tokens=STEPS, ignore_eos=True), timeout=600)
+    finally:
+        eng.shutdown()
+    torch.cuda.empty_cache()
+    assert all(len(o) == STEPS for o in outs)
+    return outs, sd
+
+
+def test_llama3_70b_tp8_rank_width_unified_and_semi_pd_match_the_oracle(device):
+    from semi_pd_amd.models.llama import LlamaConfig
+    cfg = LlamaConfig(vocab_size=16032, hidden_size=8192, intermediate_size=3584, num_hidden_layers=2,
+                      num_attention_heads=8, num_key_value_heads=1, head_dim=128, max_position_embeddings=8192)
+    prompts = make_prompts(cfg.vocab_size, LENS, seed=13)
+    uni, sd = _generate(_args(cfg), prompts, want_sd=True)
+    oracle = OracleLlama(cfg, sd)
+    check_against_oracle(oracle, prompts, uni, margin=MARGIN, min_discriminating=0.6)
+    semi, _ = _generate(_args(cfg, enable_semi_pd=True, prefill_cu_percent=50, decode_cu_percent=50), prompts)
+    check_against_oracle(oracle, prompts, semi, margin=MARGIN, min_discriminating=0.6)
+
+
+def test_deepseek_v3_tp8_rank_width_block_fp8_unified_and_semi_pd_match_the_oracle(device):
+    from semi_pd_amd.models.deepseek_v2 import DeepseekV2Config
+    qc = {"quant_method": "fp8", "weight_block_size": [128, 128], "activation_scheme": "dynamic"}
+    cfg = DeepseekV2Config(
+        vocab_size=16160, hidden_size=7168, intermediate_size=2304, moe_intermediate_size=256,
+        num_hidden_layers=2, num_attention_heads=16, n_shared_experts=1, n_routed_experts=256,
+        num_experts_per_tok=8, routed_scaling_factor=2.5, topk_method="noaux_tc", n_group=8, topk_group=4,
+        norm_topk_prob=True, first_k_dense_replace=1, kv_lora_rank=512, q_lora_rank=1536, qk_rope_head_dim=64,
+        qk_nope_head_dim=128, v_head_dim=128, rope_theta=10000.0,
+        rope_scaling={"type": "yarn", "factor": 40, "beta_fast": 32, "beta_slow": 1, "mscale": 1.0,
+                      "mscale_all_dim": 1.0, "original_max_position_embeddings": 4096},
+        architectures=("DeepseekV3ForCausalLM",), quantization_config=qc)
+    lens = [512, 100, 7]      # (the CPU oracle runs 256 experts per MoE layer)
+    prompts = make_prompts(cfg.vocab_size, lens, seed=17)
+    uni, sd = _generate(_args(cfg), prompts, want_sd=True)
+    oracle = OracleDeepseekV2(cfg, sd, act_dtype=torch.bfloat16, absorb_fp8=True)
+    # per-tensor activation scales of the bmm_fp8 absorption depend on which tokens share a step (as in the
+    # reference): the margin of test_gpu_deepseek.py's fp8 case (0.2 at head scale 1)
+    margin = 0.2
+    check_against_oracle(oracle, prompts, uni, margin=margin)
+    semi, _ = _generate(_args(cfg, enable_semi_pd=True, prefill_cu_percent=50, decode_cu_percent=50), prompts)
+    check_against_oracle(oracle, prompts, semi, margin=margin)
+
+
+def test_llama3_70b_width_tp2_on_one_gpu_matches_the_unsharded_oracle(device):
+    from semi_pd_amd.models.llama import LLAMA3_70B
+    cfg = dataclasses.replace(LLAMA3_70B, num_hidden_layers=2, vocab_size=32064, max_position_embeddings=2048)
+    prompts = make_prompts(cfg.vocab_size, LENS, seed=19)
+    # the unsharded weights come from a TP = 1 engine of the same seed (shards are slices of ONE full-size draw)
+    uni, sd = _generate(_args(cfg), prompts, want_sd=True)
+    oracle = OracleLlama(cfg, sd)
+    check_against_oracle(oracle, prompts, uni, margin=MARGIN, min_discriminating=0.6)
+    tp2, _ = _generate(_args(cfg, tp_size=2, enable_semi_pd=True, prefill_cu_percent=50, decode_cu_percent=50,
+                             dist_backend="gloo"), prompts, gpu_ids={0: 0, 1: 0})
+    check_against_oracle(oracle, prompts, tp2, margin=MARGIN, min_discriminating=0.6)

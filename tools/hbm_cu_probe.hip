@@ -76,6 +76,78 @@ __global__ void __launch_bounds__(64 * WAVES) read_lds(const char* __restrict__ 
   if (sink == (uint32_t*)1) sink[threadIdx.x] = smem[lane];
 }
 
+// The weight-streaming GEMM's loop taken apart (csrc/stream_linear.hip): the same per-wave LDS-DMA rings as read_lds<8, 4, 3>,
+// plus, per 4 KB block: BAR = one s_barrier of the 8 waves (the shared activation ring's synchronisation), RD = that many
+// ds_read_b128 sweeps of 4 KB by every wave (the GEMM reads its own 4 KB of weights once and MT x 4 KB of activations),
+// MF = that many v_mfma_f32_16x16x32_bf16 on what was read.  Which of them takes the stream from ~50 to ~35 GB/s per CU?
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+template <int WAVES, int BLK, int R, int BAR, int RD, int MF, int XKB>
+__global__ void __launch_bounds__(64 * WAVES) read_anat(const char* __restrict__ base, size_t span, size_t bytes_per_wg,
+                                                        size_t rot, uint32_t* __restrict__ sink) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const size_t per_wave = bytes_per_wg / WAVES;
+  size_t off = ((size_t)blockIdx.x * bytes_per_wg + rot) % span + (size_t)wave * per_wave;
+  const char* p = base + off + lane * 16;
+  // XKB > 0: a shared "activation" ring of R slots of XKB KB, every wave DMAs its share (from a 64 KB region that stays in L2)
+  char* xring = smem;
+  char* ring = smem + R * XKB * 1024 + wave * (R * BLK * 1024);
+  const char* xsrc = base + ((size_t)blockIdx.x % 64) * 65536 + lane * 16;
+  constexpr int XPW = XKB > 0 ? (XKB + WAVES - 1) / WAVES : 0;   // x pieces (1 KB) per wave per block
+  const int nblk = (int)(per_wave / (BLK * 1024));
+  auto issue = [&](int b) __attribute__((always_inline)) {
+    const int slot = b % R;
+#pragma unroll
+    for (int e = 0; e < XPW; ++e) {
+      const int piece = (wave + e * WAVES) % (XKB > 0 ? XKB : 1);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc + ((size_t)(b & 15) * XKB + piece) * 1024 % 65536),
+                                       (__attribute__((address_space(3))) void*)(xring + slot * XKB * 1024 + piece * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < BLK; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + (size_t)b * BLK * 1024 + i * 1024),
+                                       (__attribute__((address_space(3))) void*)(ring + slot * BLK * 1024 + i * 1024), 16, 0, 2);
+  };
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  uint4 keep = make_uint4(0, 0, 0, 0);
+#pragma unroll
+  for (int b = 0; b < R - 1; ++b) issue(b);
+  for (int b = 0; b < nblk; ++b) {
+    if (b + R - 1 <= nblk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * (BLK + XPW)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (BAR) __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (b + R - 1 < nblk) issue(b + R - 1);
+    const int slot = b % R;
+    const uint32_t a0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)(ring + slot * BLK * 1024) + lane * 16;
+    const uint32_t x0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)(xring + slot * XKB * 1024) + lane * 16;
+#pragma unroll
+    for (int r = 0; r < RD; ++r) {
+      uint4 v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        // sweep 0 reads the wave's own weights, the following sweeps the shared activation block (or the weights again)
+        const uint32_t addr = (r == 0 || XKB == 0) ? a0 + i * 1024 : x0 + ((r - 1) * 4 + i) % XKB * 1024;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(v[i]) : "v"(addr));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (MF > 0 && r * 4 + i < MF) {
+          union { uint4 u; bf16x8 b; } fa, fb;
+          fa.u = v[i]; fb.u = v[(i + 1) & 3];
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.b, fb.b, acc, 0, 0, 0);
+        } else {
+          keep.x ^= v[i].x;
+        }
+      }
+    }
+  }
+  if (keep.x == 0x12345677u && acc[0] == 3.f) sink[threadIdx.x] = keep.x;
+}
+
 static std::vector<uint32_t> make_mask(int num_cus, int n, int xcds) {
   // n CUs spread over the first `xcds` XCDs (bit i -> XCD i % 8), n / xcds per XCD, lowest CU slots first
   std::vector<uint32_t> m((num_cus + 31) / 32, 0);
@@ -113,14 +185,15 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&sink, 4096));
   CK(hipMemset(buf, 1, span + per_wg));
   const int lds = 100 * 1024;
-  printf("# device CUs %d; every workgroup alone on its CU (100 KB LDS), 4 MB contiguous per workgroup, 4 workgroups per CU per launch\n", num_cus);
-  printf("# mode waves/CU in-flight-per-wave CUs XCDs | GB/s total | GB/s per CU\n");
-#define SETLDS(k) CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024))
+  if (argc <= 1 || (argc > 2 && atoi(argv[1]) == 8)) printf("# device CUs %d; every workgroup alone on its CU (100 KB LDS), 4 MB contiguous per workgroup, 4 workgroups per CU per launch\n", num_cus);
+  if (argc <= 1 || (argc > 2 && atoi(argv[1]) == 8)) printf("# mode waves/CU in-flight-per-wave CUs XCDs | GB/s total | GB/s per CU\n");
+#define SETLDS(k) CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
   struct Share { int n, xcds; };
-  const Share shares[] = {{8, 8}, {32, 8}, {64, 8}, {96, 8}, {128, 8}, {160, 8}, {192, 8}, {256, 8},
-                          {96, 4}, {96, 3}, {32, 1}, {32, 2}, {64, 2}};
+  // one share per invocation (a hang then costs one point, not the sweep):  hbm_cu_probe <CUs> <XCDs> | hbm_cu_probe pair
+  const bool pair_only = argc > 1 && argv[1][0] == 'p';
+  const Share shares[] = {{argc > 2 ? atoi(argv[1]) : 96, argc > 2 ? atoi(argv[2]) : 8}};
   for (const Share& sh : shares) {
-    if (sh.n > num_cus) continue;
+    if (sh.n > num_cus || pair_only) continue;
     std::vector<uint32_t> mask = make_mask(num_cus, sh.n, sh.xcds);
     hipStream_t st;
     CK(hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()));
@@ -133,7 +206,7 @@ int main(int argc, char** argv) {
       double t = time_it(st, [&](int i) { hipLaunchKernelGGL(kernel, dim3(wgs), dim3(64 * waves), ldsbytes, st,    \
                                                               (const char*)buf, span, per_wg, rot(i), sink); }, 10); \
       CK(hipGetLastError());                                                                                       \
-      printf("%-8s %d %3d KB  %3d %d | %7.0f | %6.1f\n", label, waves, inflight_kb, sh.n, sh.xcds, total / t / 1e9,      \
+      printf("%-8s | %d %3d KB  %3d %d | %7.0f | %6.1f\n", label, waves, inflight_kb, sh.n, sh.xcds, total / t / 1e9,      \
              total / t / 1e9 / sh.n);                                                                              \
       fflush(stdout);                                                                                              \
     }
@@ -152,10 +225,24 @@ int main(int argc, char** argv) {
     RUN("regs-nt", 8, 8, (read_regs<8, 8>), lds)
     RUN("regs-nt", 8, 16, (read_regs<8, 16>), lds)
     RUN("regs-nt", 16, 8, (read_regs<16, 8>), lds)
+    // the GEMM loop taken apart: 8 waves x ring of 3 x 4 KB, + barrier, + LDS sweeps, + MFMAs, + shared 8 KB activation ring
+    RUN("anat --------", 8, 8, (read_anat<8, 4, 3, 0, 0, 0, 0>), lds)
+    RUN("anat bar", 8, 8, (read_anat<8, 4, 3, 1, 0, 0, 0>), lds)
+    RUN("anat rd1", 8, 8, (read_anat<8, 4, 3, 0, 1, 0, 0>), lds)
+    RUN("anat rd3", 8, 8, (read_anat<8, 4, 3, 0, 3, 0, 0>), lds)
+    RUN("anat bar+rd3", 8, 8, (read_anat<8, 4, 3, 1, 3, 0, 0>), lds)
+    RUN("anat bar+rd3+mf8", 8, 8, (read_anat<8, 4, 3, 1, 3, 8, 0>), lds)
+    RUN("anat bar+x8", 8, 8, (read_anat<8, 4, 3, 1, 0, 0, 8>), 128 * 1024)
+    RUN("anat bar+x8+rd3", 8, 8, (read_anat<8, 4, 3, 1, 3, 0, 8>), 128 * 1024)
+    RUN("anat bar+x8+rd3+mf8 (= the GEMM at 32 rows)", 8, 8, (read_anat<8, 4, 3, 1, 3, 8, 8>), 128 * 1024)
+    RUN("anat bar+x8+rd2+mf8 (k-split waves)", 8, 8, (read_anat<8, 4, 3, 1, 2, 8, 8>), 128 * 1024)
+    RUN("anat bar+x16+rd5+mf16 (64 rows)", 8, 8, (read_anat<8, 4, 3, 1, 5, 16, 16>), 150 * 1024)
+    RUN("anat ring4 bar+x8+rd3+mf8", 8, 12, (read_anat<8, 4, 4, 1, 3, 8, 8>), 160 * 1024)
+    RUN("anat 4 waves x 8 KB blocks bar+x8+rd3+mf8", 4, 16, (read_anat<4, 8, 3, 1, 3, 8, 8>), 128 * 1024)
     CK(hipStreamDestroy(st));
   }
   // two disjoint shares streaming at the same time (decode-like 96 from the top, a second stream on the other 160)
-  {
+  if (pair_only) {
     std::vector<uint32_t> lo((num_cus + 31) / 32, 0), hi((num_cus + 31) / 32, 0);
     for (int i = 0; i < 160; ++i) lo[i >> 5] |= 1u << (i & 31);
     for (int i = 160; i < 256 && i < num_cus; ++i) hi[i >> 5] |= 1u << (i & 31);
