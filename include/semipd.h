@@ -561,6 +561,27 @@ int semipd_ar_all_reduce(void* comm, const void* in, void* out, size_t numel, in
  * logits_processor.py:426-427; here the decode graph then holds no RCCL node at all).
  * bytes_per_rank: multiple of 16, at most semipd_ar_max_bytes; out holds world * bytes_per_rank. */
 int semipd_ar_all_gather(void* comm, const void* in, void* out, size_t bytes_per_rank, void* stream);
+/* Expert-parallel all-to-all over the same regions and call sequence (BASELINE config 5).  The reference
+ * has none: its expert parallelism keeps every token on every rank and all-reduces the partial outputs
+ * (layers/moe/ep_moe/layer.py:190) -- these two calls are what would replace that all-reduce; their meaning is fixed by
+ * oracle/ops.py: ep_dispatch / ep_combine (an index permutation and the sum of moe_sum).
+ * semipd_ep_dispatch: this rank contributes `tokens` rows of `row_bytes` bytes (x), their routed GLOBAL expert ids
+ *   [tokens, top_k] and routing weights; expert e lives on rank e / experts_per_rank.  It receives one row per (token, j)
+ *   entry of ANY rank routed to one of its experts, ordered by sender rank, token, j: recv_x [max_recv, row_bytes],
+ *   recv_expert (local expert id), recv_weight; recv_count[0] = rows received (rows beyond max_recv are dropped: the caller
+ *   checks recv_count <= max_recv); send_within [tokens, top_k] = position of this rank's entry among its entries to the same
+ *   destination; counts_all [world, world] = entries every sender sends to every destination.  Every rank must call it in the
+ *   same sequence position; tokens may differ per rank (also 0).  Staging needs 256 + 3 * align256(4 tokens top_k) +
+ *   tokens * row_bytes bytes <= semipd_ar_max_bytes.  Capturable; does not synchronise.
+ * semipd_ep_combine: y = this rank's expert outputs for the rows it received, in the received order (already multiplied by
+ *   their routing weight); out[t] = T(sum over j, in j order, fp32, of the row that belongs to (t, j)): tokens, topk_ids,
+ *   send_within, counts_all as in / from the dispatch.  256 + max_recv * 2 * hidden bytes <= semipd_ar_max_bytes. */
+int semipd_ep_dispatch(void* comm, const void* x, const int32_t* topk_ids, const float* topk_weights, int64_t tokens, int top_k,
+                       int64_t row_bytes, int experts_per_rank, void* recv_x, int32_t* recv_expert, float* recv_weight,
+                       int64_t max_recv, int32_t* recv_count, int32_t* send_within, int32_t* counts_all, void* stream);
+int semipd_ep_combine(void* comm, const void* y, const int32_t* recv_count, int64_t max_recv, const int32_t* topk_ids,
+                      const int32_t* send_within, const int32_t* counts_all, void* out, int64_t tokens, int top_k, int64_t hidden,
+                      int experts_per_rank, int dtype, void* stream);
 /* replaces dispose (custom_all_reduce.hip:112-115); regions stay with their owners. */
 int semipd_ar_dispose(void* comm);
 

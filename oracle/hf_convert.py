@@ -60,9 +60,11 @@ def deepseek_v2_from_hf(sd: Dict[str, torch.Tensor], cfg) -> Dict[str, torch.Ten
            "lm_head.weight": sd["lm_head.weight"]}
     for i in range(cfg.num_hidden_layers):
         p = f"model.layers.{i}."
-        for k in ("self_attn.q_proj.weight", "self_attn.kv_a_proj_with_mqa.weight", "self_attn.kv_a_layernorm.weight",
-                  "self_attn.kv_b_proj.weight", "self_attn.o_proj.weight", "input_layernorm.weight",
-                  "post_attention_layernorm.weight"):
+        q_names = (("self_attn.q_a_proj.weight", "self_attn.q_a_layernorm.weight", "self_attn.q_b_proj.weight")
+                   if p + "self_attn.q_a_proj.weight" in sd else ("self_attn.q_proj.weight",))
+        for k in q_names + ("self_attn.kv_a_proj_with_mqa.weight", "self_attn.kv_a_layernorm.weight",
+                            "self_attn.kv_b_proj.weight", "self_attn.o_proj.weight", "input_layernorm.weight",
+                            "post_attention_layernorm.weight"):
             out[p + k] = sd[p + k]
         if p + "mlp.gate.weight" in sd:
             out[p + "mlp.gate.weight"] = sd[p + "mlp.gate.weight"]

@@ -351,7 +351,13 @@ class OracleDeepseekV2:
             else:
                 x, res = O.fused_add_rms_norm(h, res, self.w[p + "input_layernorm.weight"], c.rms_norm_eps)
             T = x.shape[0]
-            q = self._lin(x, p + "self_attn.q_proj.weight").view(T, self.H, self.nope + self.rope)
+            if p + "self_attn.q_a_proj.weight" in self.w:
+                # low-rank query (q_lora_rank; models/deepseek_v2.py: q_a_proj -> q_a_layernorm -> q_b_proj)
+                qa = O.rms_norm(self._lin(x, p + "self_attn.q_a_proj.weight"), self.w[p + "self_attn.q_a_layernorm.weight"],
+                                c.rms_norm_eps)
+                q = self._lin(qa, p + "self_attn.q_b_proj.weight").view(T, self.H, self.nope + self.rope)
+            else:
+                q = self._lin(x, p + "self_attn.q_proj.weight").view(T, self.H, self.nope + self.rope)
             latent = self._lin(x, p + "self_attn.kv_a_proj_with_mqa.weight")
             kv_a = O.rms_norm(latent[:, : self.lora], self.w[p + "self_attn.kv_a_layernorm.weight"], c.rms_norm_eps)
             q_pe, k_pe = O.apply_rope(positions, q[..., self.nope:].reshape(T, -1), latent[:, self.lora:],

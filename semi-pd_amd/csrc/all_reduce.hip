@@ -24,6 +24,8 @@
 
 #include <stdlib.h>
 
+#include <algorithm>
+
 namespace semipd {
 
 constexpr int kArMaxRanks = 8;
@@ -214,7 +216,218 @@ __global__ void __launch_bounds__(kArThreads) ar_all_gather_kernel(ArPeers p, co
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Expert-parallel all-to-all (BASELINE config 5) over the same peer-mapped regions and call sequence.
+// The reference has none (its expert parallelism keeps every token on every rank and all-reduces the partial outputs,
+// layers/moe/ep_moe/layer.py:190): this is new design, defined by oracle/ops.py: ep_dispatch / ep_combine.
+//   dispatch: rank s stages its token rows, their routed expert ids and routing weights in its slot; rank d PULLS one row
+//             per (token, j) entry routed to one of its experts, ordered by sender rank, token, j -- index and byte work;
+//   combine:  rank d stages its expert-output rows; rank s pulls, for each of its tokens, the k rows that belong to it and
+//             sums them in j order (fp32, one rounding) -- the arithmetic of moe_sum (csrc/elementwise.hip).
+// Pull, not push: a reader issues loads to all peers back to back over the 7 xGMI links, like the all-reduce above, and
+// nobody writes into memory another rank may still be reading.  Staging is a separate local launch in front of the
+// exchange kernel; the exchange kernel's per-block flag exchange (ar_block_barrier) then proves the peer's staging launch
+// complete (stream order on the peer), and the double buffering on the call number covers the way out as it does above.
+struct EpHeader {          // first 256 bytes of a staged slot
+  int32_t tokens, top_k, rows, pad;
+  int32_t counts[kArMaxRanks];   // entries this rank sends to each destination (dispatch) / unused (combine)
+  int32_t pad2[64 - 4 - kArMaxRanks];
+};
+static_assert(sizeof(EpHeader) == 256, "EpHeader is one 256-byte line");
+
+__device__ __forceinline__ size_t ep_align(size_t x) { return (x + 255) / 256 * 256; }
+// dispatch slot layout: [EpHeader | within int32[T k] | ids int32[T k] | w float[T k] | rows T x row_bytes], 256-aligned parts
+__device__ __forceinline__ char* ep_part(char* slot, int part, size_t entries) {
+  return slot + 256 + (size_t)part * ep_align(entries * 4);
+}
+
+// One workgroup, local: destination and position-within-(sender, destination) of every (token, j) entry in (t, j) order,
+// the per-destination counts, all staged in this rank's slot of the NEXT call together with the ids and weights.
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS) ep_prepare_kernel(ArPeers p, const int32_t* __restrict__ ids,
+                                                            const float* __restrict__ w, int tokens, int top_k,
+                                                            int experts_per_rank, int world, int32_t* __restrict__ within_out) {
+  __shared__ int32_t cnt[THREADS][kArMaxRanks];
+  __shared__ int32_t total[kArMaxRanks];
+  const uint32_t buf = (__hip_atomic_load(&ar_signal(p, p.rank)->call, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1) & 1u;
+  char* slot = reinterpret_cast<char*>(ar_in_slot(p, p.rank, buf));
+  const int entries = tokens * top_k;
+  const int per = (entries + THREADS - 1) / THREADS;
+  const int lo = min(entries, (int)threadIdx.x * per), hi = min(entries, lo + per);
+  int32_t mine[kArMaxRanks];
+#pragma unroll
+  for (int d = 0; d < kArMaxRanks; ++d) mine[d] = 0;
+  for (int e = lo; e < hi; ++e) {
+    const int d = ids[e] / experts_per_rank;
+#pragma unroll
+    for (int q = 0; q < kArMaxRanks; ++q) mine[q] += (q == d);
+  }
+#pragma unroll
+  for (int d = 0; d < kArMaxRanks; ++d) cnt[threadIdx.x][d] = mine[d];
+  __syncthreads();
+  if (threadIdx.x < kArMaxRanks) {   // exclusive scan over the threads' chunks, one destination per thread
+    int32_t run = 0;
+    for (int t = 0; t < THREADS; ++t) {
+      const int32_t c = cnt[t][threadIdx.x];
+      cnt[t][threadIdx.x] = run;
+      run += c;
+    }
+    total[threadIdx.x] = run;
+  }
+  __syncthreads();
+  int32_t* s_within = reinterpret_cast<int32_t*>(ep_part(slot, 0, entries));
+  int32_t* s_ids = reinterpret_cast<int32_t*>(ep_part(slot, 1, entries));
+  float* s_w = reinterpret_cast<float*>(ep_part(slot, 2, entries));
+  int32_t base[kArMaxRanks];
+#pragma unroll
+  for (int d = 0; d < kArMaxRanks; ++d) base[d] = cnt[threadIdx.x][d];
+  for (int e = lo; e < hi; ++e) {
+    const int id = ids[e];
+    const int d = id / experts_per_rank;
+    int32_t pos = 0;
+#pragma unroll
+    for (int q = 0; q < kArMaxRanks; ++q)
+      if (q == d) pos = base[q]++;
+    s_within[e] = pos;
+    within_out[e] = pos;
+    s_ids[e] = id;
+    s_w[e] = w[e];
+  }
+  if (threadIdx.x == 0) {
+    EpHeader* h = reinterpret_cast<EpHeader*>(slot);
+    h->tokens = tokens;
+    h->top_k = top_k;
+    h->rows = tokens;
+    for (int d = 0; d < kArMaxRanks; ++d) h->counts[d] = d < world ? total[d] : 0;
+  }
+}
+
+// local: rows [n_rows, row_bytes] -> this rank's slot of the NEXT call at byte offset `off`; n_rows read from the device
+// when `n_rows_dev` is given (the rows an earlier dispatch delivered).  With hdr != 0 also the header of a combine slot.
+__global__ void __launch_bounds__(256) ep_stage_rows_kernel(ArPeers p, const uint4* __restrict__ rows, int64_t n_rows,
+                                                           const int32_t* __restrict__ n_rows_dev, int64_t max_rows,
+                                                           int64_t row_vecs, size_t off, int hdr) {
+  const uint32_t buf = (__hip_atomic_load(&ar_signal(p, p.rank)->call, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1) & 1u;
+  char* slot = reinterpret_cast<char*>(ar_in_slot(p, p.rank, buf));
+  if (n_rows_dev) n_rows = min((int64_t)n_rows_dev[0], max_rows);
+  if (hdr && blockIdx.x == 0 && threadIdx.x == 0) {
+    EpHeader* h = reinterpret_cast<EpHeader*>(slot);
+    h->tokens = 0;
+    h->top_k = 0;
+    h->rows = (int32_t)n_rows;
+  }
+  uint4* dst = reinterpret_cast<uint4*>(slot + off);
+  const int64_t total = n_rows * row_vecs;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+    dst[i] = rows[i];
+}
+
+// exchange: rank `me` pulls the entries routed to its experts from every sender's staged slot
+template <int NR>
+__global__ void __launch_bounds__(kArThreads) ep_dispatch_pull_kernel(ArPeers p, int experts_per_rank, int64_t row_vecs,
+                                                                      uint4* __restrict__ recv_x, int32_t* __restrict__ recv_expert,
+                                                                      float* __restrict__ recv_w, int64_t max_recv,
+                                                                      int32_t* __restrict__ recv_count,
+                                                                      int32_t* __restrict__ counts_all) {
+  const uint32_t seq = ar_begin(p);
+  const uint32_t buf = seq & 1u;
+  ar_block_barrier<NR>(p, &ArSignal::start, seq);
+  ar_end(p, seq);
+  const int me = p.rank;
+  __shared__ int32_t s_off[NR], s_entries[NR], s_topk[NR];
+  if (threadIdx.x == 0) {
+    int32_t run = 0;
+    for (int s = 0; s < NR; ++s) {
+      const EpHeader* h = reinterpret_cast<const EpHeader*>(ar_in_slot(p, s, buf));
+      s_off[s] = run;
+      run += h->counts[me];
+      s_entries[s] = h->tokens * h->top_k;
+      s_topk[s] = h->top_k;
+      if (blockIdx.x == 0)
+        for (int d = 0; d < NR; ++d) counts_all[s * NR + d] = h->counts[d];
+    }
+    if (blockIdx.x == 0) recv_count[0] = run;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int gw = blockIdx.x * (kArThreads / 64) + (threadIdx.x >> 6), nw = gridDim.x * (kArThreads / 64);
+  for (int k = 1; k <= NR; ++k) {            // start with the next rank: spreads the pulls over the links
+    const int s = (me + k) % NR;
+    char* slot = reinterpret_cast<char*>(ar_in_slot(p, s, buf));
+    const int entries = s_entries[s], top_k = s_topk[s];
+    const int32_t* within = reinterpret_cast<const int32_t*>(ep_part(slot, 0, entries));
+    const int32_t* ids = reinterpret_cast<const int32_t*>(ep_part(slot, 1, entries));
+    const float* w = reinterpret_cast<const float*>(ep_part(slot, 2, entries));
+    const uint4* rows = reinterpret_cast<const uint4*>(ep_part(slot, 3, entries));
+    for (int e = gw; e < entries; e += nw) {
+      const int id = ids[e];
+      if (id / experts_per_rank != me) continue;
+      const int64_t pos = (int64_t)s_off[s] + within[e];
+      if (pos >= max_recv) continue;          // the caller sees recv_count > max_recv
+      const uint4* src = rows + (int64_t)(e / top_k) * row_vecs;
+      uint4* dst = recv_x + pos * row_vecs;
+      for (int64_t v = lane; v < row_vecs; v += 64) dst[v] = src[v];
+      if (lane == 0) {
+        recv_expert[pos] = id - me * experts_per_rank;
+        recv_w[pos] = w[e];
+      }
+    }
+  }
+}
+
+// the way back: out[t] = T(sum_j fp32(y_{dest(t, j)}[position of (t, j)])) in j order
+template <typename T, int NR>
+__global__ void __launch_bounds__(kArThreads) ep_combine_pull_kernel(ArPeers p, const int32_t* __restrict__ ids,
+                                                                     const int32_t* __restrict__ within,
+                                                                     const int32_t* __restrict__ counts_all, int tokens, int top_k,
+                                                                     int experts_per_rank, int64_t row_vecs, uint4* __restrict__ out) {
+  constexpr int V = Elem<T>::kVec;
+  const uint32_t seq = ar_begin(p);
+  const uint32_t buf = seq & 1u;
+  ar_block_barrier<NR>(p, &ArSignal::start, seq);
+  ar_end(p, seq);
+  const int me = p.rank;
+  __shared__ int32_t s_off[NR];            // where this rank's entries start in destination d's list
+  if (threadIdx.x < NR) {
+    int32_t run = 0;
+    for (int s = 0; s < me; ++s) run += counts_all[s * NR + threadIdx.x];
+    s_off[threadIdx.x] = run;
+  }
+  __syncthreads();
+  const uint4* ybase[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) ybase[r] = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(ar_in_slot(p, r, buf)) + 256);
+  const int64_t total = (int64_t)tokens * row_vecs;
+  for (int64_t i = (int64_t)blockIdx.x * kArThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kArThreads) {
+    const int t = (int)(i / row_vecs);
+    const int64_t c = i - (int64_t)t * row_vecs;
+    float acc[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) acc[q] = 0.f;
+    for (int j = 0; j < top_k; ++j) {
+      const int e = t * top_k + j;
+      const int d = ids[e] / experts_per_rank;
+      const int64_t pos = (int64_t)s_off[d] + within[e];
+      uint4 v = make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < NR; ++r)
+        if (r == d) v = ybase[r][pos * row_vecs + c];
+      const T* ev = reinterpret_cast<const T*>(&v);
+#pragma unroll
+      for (int q = 0; q < V; ++q) acc[q] += Elem<T>::to_f(ev[q]);
+    }
+    uint4 o;
+    T* eo = reinterpret_cast<T*>(&o);
+#pragma unroll
+    for (int q = 0; q < V; ++q) eo[q] = Elem<T>::from_f(acc[q]);
+    out[i] = o;
+  }
+}
+
 static size_t round_up(size_t x, size_t m) { return (x + m - 1) / m * m; }
+static size_t ep_dispatch_bytes(int64_t tokens, int top_k, int64_t row_bytes) {
+  return 256 + 3 * round_up((size_t)tokens * top_k * 4, 256) + (size_t)tokens * row_bytes;
+}
 
 template <int NR>
 static int ag_launch(const ArComm* c, const void* in, void* out, size_t bytes, hipStream_t stream) {
@@ -392,6 +605,84 @@ int semipd_ar_all_gather(void* comm, const void* in, void* out, size_t bytes_per
     case 6: return ag_launch<6>(c, in, out, bytes_per_rank, s);
     default: return ag_launch<8>(c, in, out, bytes_per_rank, s);
   }
+}
+
+int semipd_ep_dispatch(void* comm, const void* x, const int32_t* topk_ids, const float* topk_weights, int64_t tokens, int top_k,
+                       int64_t row_bytes, int experts_per_rank, void* recv_x, int32_t* recv_expert, float* recv_weight,
+                       int64_t max_recv, int32_t* recv_count, int32_t* send_within, int32_t* counts_all, void* stream) {
+  SEMIPD_CHECK_ARG(comm && recv_x && recv_expert && recv_weight && recv_count && send_within && counts_all, SEMIPD_EINVAL,
+                   "ep_dispatch: null pointer");
+  SEMIPD_CHECK_ARG(tokens >= 0 && top_k > 0 && top_k <= 64 && experts_per_rank > 0 && max_recv >= 0, SEMIPD_EINVAL,
+                   "ep_dispatch: bad sizes");
+  SEMIPD_CHECK_ARG(tokens == 0 || (x && topk_ids && topk_weights), SEMIPD_EINVAL, "ep_dispatch: null input");
+  SEMIPD_CHECK_ARG(row_bytes > 0 && row_bytes % 16 == 0 && aligned16(x) && aligned16(recv_x), SEMIPD_EALIGN,
+                   "ep_dispatch: rows must be a multiple of 16 bytes and 16-byte aligned");
+  const ArComm* c = static_cast<ArComm*>(comm);
+  SEMIPD_CHECK_ARG(tokens * top_k < (1 << 30) && ep_dispatch_bytes(tokens, top_k, row_bytes) <= c->peers.max_bytes, SEMIPD_ESHAPE,
+                   "ep_dispatch: %lld tokens of %lld bytes with top-%d need %zu bytes of staging, the region holds %zu",
+                   (long long)tokens, (long long)row_bytes, top_k, ep_dispatch_bytes(tokens, top_k, row_bytes), c->peers.max_bytes);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int entries = (int)(tokens * top_k);
+  hipLaunchKernelGGL((ep_prepare_kernel<512>), dim3(1), dim3(512), 0, s, c->peers, topk_ids, topk_weights, (int)tokens, top_k,
+                     experts_per_rank, c->world, send_within);
+  if (int rc = launch_status("ep_prepare_kernel")) return rc;
+  if (tokens > 0) {
+    const int64_t vecs = tokens * (row_bytes / 16);
+    const unsigned blocks = (unsigned)std::min<int64_t>((vecs + 255) / 256, 1024);
+    hipLaunchKernelGGL(ep_stage_rows_kernel, dim3(blocks), dim3(256), 0, s, c->peers, (const uint4*)x, tokens,
+                       (const int32_t*)nullptr, tokens, row_bytes / 16, (size_t)256 + 3 * round_up((size_t)entries * 4, 256), 0);
+    if (int rc = launch_status("ep_stage_rows_kernel")) return rc;
+  }
+#define EP_DISPATCH(NRV)                                                                                                   \
+  hipLaunchKernelGGL((ep_dispatch_pull_kernel<NRV>), dim3((unsigned)c->max_blocks), dim3(kArThreads), 0, s, c->peers,      \
+                     experts_per_rank, row_bytes / 16, (uint4*)recv_x, recv_expert, recv_weight, max_recv, recv_count, counts_all)
+  switch (c->world) {
+    case 2: EP_DISPATCH(2); break;
+    case 4: EP_DISPATCH(4); break;
+    case 6: EP_DISPATCH(6); break;
+    default: EP_DISPATCH(8); break;
+  }
+#undef EP_DISPATCH
+  return launch_status("ep_dispatch_pull_kernel");
+}
+
+int semipd_ep_combine(void* comm, const void* y, const int32_t* recv_count, int64_t max_recv, const int32_t* topk_ids,
+                      const int32_t* send_within, const int32_t* counts_all, void* out, int64_t tokens, int top_k, int64_t hidden,
+                      int experts_per_rank, int dtype, void* stream) {
+  SEMIPD_CHECK_ARG(comm && y && recv_count && counts_all, SEMIPD_EINVAL, "ep_combine: null pointer");
+  SEMIPD_CHECK_ARG(tokens >= 0 && top_k > 0 && hidden > 0 && experts_per_rank > 0 && max_recv >= 0, SEMIPD_EINVAL,
+                   "ep_combine: bad sizes");
+  SEMIPD_CHECK_ARG(tokens == 0 || (out && topk_ids && send_within), SEMIPD_EINVAL, "ep_combine: null pointer");
+  SEMIPD_CHECK_ARG(dtype == SEMIPD_BF16 || dtype == SEMIPD_F16, SEMIPD_EDTYPE, "ep_combine: bf16 / f16 rows only");
+  SEMIPD_CHECK_ARG(hidden % 8 == 0 && aligned16(y) && aligned16(out), SEMIPD_EALIGN,
+                   "ep_combine: hidden must be a multiple of 8 and the rows 16-byte aligned");
+  const ArComm* c = static_cast<ArComm*>(comm);
+  const int64_t row_bytes = hidden * 2;
+  SEMIPD_CHECK_ARG(256 + (size_t)max_recv * row_bytes <= c->peers.max_bytes, SEMIPD_ESHAPE,
+                   "ep_combine: %lld rows of %lld bytes do not fit the region's %zu bytes", (long long)max_recv,
+                   (long long)row_bytes, c->peers.max_bytes);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  {
+    const int64_t vecs = std::max<int64_t>(max_recv, 1) * (row_bytes / 16);
+    const unsigned blocks = (unsigned)std::min<int64_t>((vecs + 255) / 256, 1024);
+    hipLaunchKernelGGL(ep_stage_rows_kernel, dim3(blocks), dim3(256), 0, s, c->peers, (const uint4*)y, (int64_t)0, recv_count,
+                       max_recv, row_bytes / 16, (size_t)256, 1);
+    if (int rc = launch_status("ep_stage_rows_kernel")) return rc;
+  }
+#define EP_COMBINE(TT, NRV)                                                                                                 \
+  hipLaunchKernelGGL((ep_combine_pull_kernel<TT, NRV>), dim3((unsigned)c->max_blocks), dim3(kArThreads), 0, s, c->peers,    \
+                     topk_ids, send_within, counts_all, (int)tokens, top_k, experts_per_rank, row_bytes / 16, (uint4*)out)
+#define EP_COMBINE_W(TT)            \
+  switch (c->world) {               \
+    case 2: EP_COMBINE(TT, 2); break; \
+    case 4: EP_COMBINE(TT, 4); break; \
+    case 6: EP_COMBINE(TT, 6); break; \
+    default: EP_COMBINE(TT, 8); break; \
+  }
+  if (dtype == SEMIPD_BF16) { EP_COMBINE_W(bf16_t) } else { EP_COMBINE_W(f16_t) }
+#undef EP_COMBINE_W
+#undef EP_COMBINE
+  return launch_status("ep_combine_pull_kernel");
 }
 
 int semipd_ar_dispose(void* comm) {

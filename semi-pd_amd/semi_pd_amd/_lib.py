@@ -126,6 +126,8 @@ _SIGNATURES = {
     "semipd_ar_max_bytes": [_vp, _vp],
     "semipd_ar_all_reduce": [_vp, _vp, _vp, _sz, _i32, _vp],
     "semipd_ar_all_gather": [_vp, _vp, _vp, _sz, _vp],
+    "semipd_ep_dispatch": [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
+    "semipd_ep_combine": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _i32, _i32, _vp],
     "semipd_ar_dispose": [_vp],
 }
 _RESTYPES = {"semipd_last_error": C.c_char_p, "semipd_lm_head_argmax_workspace": _sz,

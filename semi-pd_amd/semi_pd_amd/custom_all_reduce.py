@@ -186,6 +186,47 @@ class CustomAllreduce:
                                             stream), "ar_all_gather")
         return out
 
+    # ------------------------------------------------------------------ expert-parallel all-to-all
+    def ep_dispatch(self, x: torch.Tensor, topk_ids: torch.Tensor, topk_weights: torch.Tensor, experts_per_rank: int,
+                    max_recv: int):
+        """csrc/all_reduce.hip: semipd_ep_dispatch (oracle/ops.py: ep_dispatch).  x [T, H] (this rank's tokens), topk_ids
+        [T, k] int32 GLOBAL expert ids, topk_weights [T, k] fp32.  Returns a state dict with the received rows (recv_x
+        [max_recv, H], recv_expert, recv_weight, recv_count on the device) and what ep_combine needs to find the way back."""
+        T, H = x.shape
+        k = topk_ids.shape[1]
+        assert x.is_contiguous() and topk_ids.dtype == torch.int32 and topk_weights.dtype == torch.float32
+        assert topk_ids.is_contiguous() and topk_weights.is_contiguous()
+        dev = x.device
+        st = {"recv_x": torch.empty((max_recv, H), dtype=x.dtype, device=dev),
+              "recv_expert": torch.zeros(max_recv, dtype=torch.int32, device=dev),
+              "recv_weight": torch.zeros(max_recv, dtype=torch.float32, device=dev),
+              "recv_count": torch.zeros(1, dtype=torch.int32, device=dev),
+              "send_within": torch.empty((T, k), dtype=torch.int32, device=dev),
+              "counts_all": torch.zeros((self.world_size, self.world_size), dtype=torch.int32, device=dev),
+              "topk_ids": topk_ids, "experts_per_rank": int(experts_per_rank), "max_recv": int(max_recv), "tokens": T, "top_k": k}
+        lib = _lib.load()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(lib.semipd_ep_dispatch(self._comm, _lib.ptr(x), _lib.ptr(topk_ids), _lib.ptr(topk_weights), T, k,
+                                          H * x.element_size(), int(experts_per_rank), _lib.ptr(st["recv_x"]),
+                                          _lib.ptr(st["recv_expert"]), _lib.ptr(st["recv_weight"]), int(max_recv),
+                                          _lib.ptr(st["recv_count"]), _lib.ptr(st["send_within"]), _lib.ptr(st["counts_all"]),
+                                          stream), "ep_dispatch")
+        return st
+
+    def ep_combine(self, y: torch.Tensor, st: dict) -> torch.Tensor:
+        """semipd_ep_combine: y [max_recv, H] = this rank's (weighted) expert outputs for the rows it received, in received
+        order; returns [tokens, H]: the sum over each token's k entries in j order, fp32, one rounding."""
+        H = y.shape[1]
+        assert y.is_contiguous() and y.shape[0] >= st["max_recv"]
+        out = torch.empty((st["tokens"], H), dtype=y.dtype, device=y.device)
+        lib = _lib.load()
+        stream = torch.cuda.current_stream(y.device).cuda_stream
+        _lib.check(lib.semipd_ep_combine(self._comm, _lib.ptr(y), _lib.ptr(st["recv_count"]), st["max_recv"],
+                                         _lib.ptr(st["topk_ids"]), _lib.ptr(st["send_within"]), _lib.ptr(st["counts_all"]),
+                                         _lib.ptr(out), st["tokens"], st["top_k"], H, st["experts_per_rank"],
+                                         _lib.dtype_code(y.dtype), stream), "ep_combine")
+        return out
+
     def custom_all_reduce(self, input: torch.Tensor) -> Optional[torch.Tensor]:
         """custom_all_reduce.py:529-552: None when the tensor does not qualify (the caller falls back to
         RCCL).  Nothing differs between eager and captured calls here."""

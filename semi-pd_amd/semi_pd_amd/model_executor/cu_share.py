@@ -22,6 +22,7 @@ from __future__ import annotations
 
 import ctypes as C
 import logging
+import os
 from typing import Dict, Optional
 
 import torch
@@ -59,6 +60,9 @@ class CuShare:
     # ---- which stream the next unit of work runs on ------------------------------------------------------------
     def choose(self) -> str:
         """The whole chip while the other instance is idle, the own share otherwise."""
+        force = os.environ.get("SEMIPD_CU_SHARE_FORCE")      # experiments: "share" / "full" whatever the board says
+        if force in (SHARE, FULL):
+            return force
         if self.board is None or self.cus[SHARE] == self.cus[FULL]:
             return SHARE
         return FULL if self.board.peer_busy(self.role) == 0 else SHARE

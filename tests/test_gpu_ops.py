@@ -1055,8 +1055,10 @@ def test_dense_gemm_with_measured_library_solution_matches_fp32(ops, device):
     report = ops.dense_gemm_report()
     mine = "".join(ln + "\n" for ln in report.splitlines() if " n=768 k=512 " in ln)
     assert mine.count("\n") == 4                                  # two row counts x two dtypes
-    moved = mine.replace("cus=0 ", "cus=77 ")
-    assert ops.dense_gemm_import(moved + "garbage line\ncus=77 dtype=2 n=768 k=512 rows=64 solution=-3 us=1 library_choice_us=1 "
+    import re
+    cur = int(re.match(r"cus=(\d+) ", mine).group(1))      # whatever share this process last declared
+    moved = re.sub(r"^cus=\d+ ", "cus=77 ", mine, flags=re.M)
+    assert ops.dense_gemm_import(moved + "garbage line\ncus=77 dtype=1 n=768 k=512 rows=64 solution=-3 us=1 library_choice_us=1 "
                                  "candidates=1 wrong_results_rejected=0\n", [(768, 512, torch.bfloat16)]) == 4
     assert "cus=77 " in ops.dense_gemm_report()
     try:
@@ -1065,7 +1067,7 @@ def test_dense_gemm_with_measured_library_solution_matches_fp32(ops, device):
         w = (torch.randn(768, 512, generator=g) * 0.05).to(torch.bfloat16).to(device)
         torch.testing.assert_close(ops.dense_gemm(x, w).float(), x.float() @ w.float().t(), rtol=2e-2, atol=2e-2)
     finally:
-        _lib.check(lib.semipd_dense_gemm_set_cus(0), "set_cus")
+        _lib.check(lib.semipd_dense_gemm_set_cus(cur), "set_cus")
 
 
 # --------------------------------------------------------------------------- tall decode batches: tiled ping-pong GEMM

@@ -66,9 +66,9 @@ def test_llama3_70b_tp8_rank_width_unified_and_semi_pd_match_the_oracle(device):
     prompts = make_prompts(cfg.vocab_size, LENS, seed=13)
     uni, sd = _generate(_args(cfg), prompts, want_sd=True)
     oracle = OracleLlama(cfg, sd)
-    check_against_oracle(oracle, prompts, uni, margin=MARGIN, min_discriminating=0.6)
+    check_against_oracle(oracle, prompts, uni, margin=MARGIN, min_discriminating=0.5)
     semi, _ = _generate(_args(cfg, enable_semi_pd=True, prefill_cu_percent=50, decode_cu_percent=50), prompts)
-    check_against_oracle(oracle, prompts, semi, margin=MARGIN, min_discriminating=0.6)
+    check_against_oracle(oracle, prompts, semi, margin=MARGIN, min_discriminating=0.5)
 
 
 def test_deepseek_v3_tp8_rank_width_block_fp8_unified_and_semi_pd_match_the_oracle(device):
@@ -102,7 +102,7 @@ def test_llama3_70b_width_tp2_on_one_gpu_matches_the_unsharded_oracle(device):
     # the unsharded weights come from a TP = 1 engine of the same seed (shards are slices of ONE full-size draw)
     uni, sd = _generate(_args(cfg), prompts, want_sd=True)
     oracle = OracleLlama(cfg, sd)
-    check_against_oracle(oracle, prompts, uni, margin=MARGIN, min_discriminating=0.6)
+    check_against_oracle(oracle, prompts, uni, margin=MARGIN, min_discriminating=0.5)
     tp2, _ = _generate(_args(cfg, tp_size=2, enable_semi_pd=True, prefill_cu_percent=50, decode_cu_percent=50,
                              dist_backend="gloo"), prompts, gpu_ids={0: 0, 1: 0})
-    check_against_oracle(oracle, prompts, tp2, margin=MARGIN, min_discriminating=0.6)
+    check_against_oracle(oracle, prompts, tp2, margin=MARGIN, min_discriminating=0.5)

@@ -66,14 +66,15 @@ def test_oracle_opt_matches_hf():
         torch.testing.assert_close(logits[b], want_logits, rtol=1e-4, atol=1e-4)
 
 
-def test_oracle_deepseek_v2_matches_hf():
+@pytest.mark.parametrize("q_lora_rank", [None, 24])
+def test_oracle_deepseek_v2_matches_hf(q_lora_rank):
     from oracle.hf_convert import deepseek_v2_from_hf
     from oracle.model import OracleDeepseekV2
     from semi_pd_amd.models.deepseek_v2 import DeepseekV2Config
     torch.manual_seed(2)
     kw = dict(vocab_size=300, hidden_size=64, intermediate_size=96, moe_intermediate_size=32, num_hidden_layers=3,
               num_attention_heads=4, n_shared_experts=2, n_routed_experts=8, num_experts_per_tok=3, kv_lora_rank=32,
-              q_lora_rank=None, qk_rope_head_dim=16, qk_nope_head_dim=16, v_head_dim=16, first_k_dense_replace=1,
+              q_lora_rank=q_lora_rank, qk_rope_head_dim=16, qk_nope_head_dim=16, v_head_dim=16, first_k_dense_replace=1,
               n_group=1, topk_group=1, topk_method="greedy", norm_topk_prob=False, routed_scaling_factor=1.0,
               max_position_embeddings=256, rms_norm_eps=1e-6)
     hf = transformers.DeepseekV2ForCausalLM(transformers.DeepseekV2Config(num_key_value_heads=4, **kw)).eval()
