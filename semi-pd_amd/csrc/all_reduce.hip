@@ -610,11 +610,11 @@ int semipd_ar_all_gather(void* comm, const void* in, void* out, size_t bytes_per
 int semipd_ep_dispatch(void* comm, const void* x, const int32_t* topk_ids, const float* topk_weights, int64_t tokens, int top_k,
                        int64_t row_bytes, int experts_per_rank, void* recv_x, int32_t* recv_expert, float* recv_weight,
                        int64_t max_recv, int32_t* recv_count, int32_t* send_within, int32_t* counts_all, void* stream) {
-  SEMIPD_CHECK_ARG(comm && recv_x && recv_expert && recv_weight && recv_count && send_within && counts_all, SEMIPD_EINVAL,
+  SEMIPD_CHECK_ARG(comm && recv_x && recv_expert && recv_weight && recv_count && counts_all, SEMIPD_EINVAL,
                    "ep_dispatch: null pointer");
   SEMIPD_CHECK_ARG(tokens >= 0 && top_k > 0 && top_k <= 64 && experts_per_rank > 0 && max_recv >= 0, SEMIPD_EINVAL,
                    "ep_dispatch: bad sizes");
-  SEMIPD_CHECK_ARG(tokens == 0 || (x && topk_ids && topk_weights), SEMIPD_EINVAL, "ep_dispatch: null input");
+  SEMIPD_CHECK_ARG(tokens == 0 || (x && topk_ids && topk_weights && send_within), SEMIPD_EINVAL, "ep_dispatch: null input");
   SEMIPD_CHECK_ARG(row_bytes > 0 && row_bytes % 16 == 0 && aligned16(x) && aligned16(recv_x), SEMIPD_EALIGN,
                    "ep_dispatch: rows must be a multiple of 16 bytes and 16-byte aligned");
   const ArComm* c = static_cast<ArComm*>(comm);

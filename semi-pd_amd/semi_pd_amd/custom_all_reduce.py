@@ -29,7 +29,11 @@ class CustomAllreduce:
     # custom_all_reduce.py:148-151: "crossover is at 16MB buffer size for ROCm"
     _MAX_CAR_SIZE = 2 * 8192 * 1024
 
-    def __init__(self, group: dist.ProcessGroup, device: torch.device, max_size: int = _MAX_CAR_SIZE) -> None:
+    def __init__(self, group: dist.ProcessGroup, device: torch.device, max_size: int = _MAX_CAR_SIZE,
+                 capacity: Optional[int] = None) -> None:
+        """max_size: largest all-reduce payload that takes the peer-memory kernel (above it RCCL is faster);
+        capacity (>= max_size, default = max_size): payload bytes one slot of the shared region holds -- the expert-parallel
+        all-to-all stages whole token chunks and wants more than an all-reduce ever should."""
         self.disabled = True
         self._comm = None
         self._region = None
@@ -44,6 +48,7 @@ class CustomAllreduce:
             return
         self.device = torch.device(device)
         self.max_size = int(max_size)
+        self.capacity = max(int(capacity or 0), self.max_size)
         lib = _lib.load()
 
         def agree(ok: bool) -> bool:
@@ -63,7 +68,7 @@ class CustomAllreduce:
         try:
             fail_here("export")
             with torch.cuda.device(self.device):
-                region_bytes = int(lib.semipd_ar_region_size(self.max_size))
+                region_bytes = int(lib.semipd_ar_region_size(self.capacity))
                 region = C.c_void_p()
                 _lib.check(lib.semipd_ar_alloc_shared(region_bytes, C.addressof(region)), "ar_alloc_shared")
                 self._region = region.value

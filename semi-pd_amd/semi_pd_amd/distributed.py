@@ -26,7 +26,8 @@ _CUSTOM_AR = None  # custom_all_reduce.CustomAllreduce, GPU ranks of one node on
 
 def init_distributed_environment(world_size: int, rank: int, distributed_init_method: str,
                                  backend: str = "nccl", device: Optional[torch.device] = None,
-                                 timeout_s: int = 600, use_custom_all_reduce: bool = True) -> None:
+                                 timeout_s: int = 600, use_custom_all_reduce: bool = True,
+                                 peer_region_capacity: Optional[int] = None) -> None:
     """model_runner.py:285-344 init_torch_distributed: one device group + one gloo group, and the
     peer-memory all-reduce on top of the gloo group (parallel_state.py:258-266 creates CustomAllreduce
     on the cpu_group unless --disable-custom-all-reduce)."""
@@ -59,7 +60,7 @@ def init_distributed_environment(world_size: int, rank: int, distributed_init_me
     if use_custom_all_reduce and device is not None and torch.device(device).type == "cuda" \
             and os.environ.get("SEMIPD_DISABLE_CUSTOM_ALL_REDUCE", "0") != "1":
         from semi_pd_amd.custom_all_reduce import CustomAllreduce
-        ar = CustomAllreduce(_CPU_GROUP, torch.device(device))
+        ar = CustomAllreduce(_CPU_GROUP, torch.device(device), capacity=peer_region_capacity)
         _CUSTOM_AR = None if ar.disabled else ar
 
 

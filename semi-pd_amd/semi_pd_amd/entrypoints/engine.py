@@ -46,6 +46,7 @@ def _build_runner(server_args: ServerArgs, gpu_id: int, tp_rank: int, role: Inst
         bypass_load_weight=bypass_load_weight, seed=server_args.random_seed, cu_percent=cu_percent,
         disable_cuda_graph=server_args.disable_cuda_graph, cuda_graph_max_bs=server_args.cuda_graph_max_bs,
         disable_custom_all_reduce=server_args.disable_custom_all_reduce, enable_ep_moe=server_args.enable_ep_moe,
+        enable_ep_all_to_all=server_args.enable_ep_all_to_all,
         disable_stream_linear=server_args.disable_stream_linear,
         num_kv_splits=server_args.triton_attention_num_kv_splits,
         dummy_lm_head_scale=server_args.dummy_lm_head_scale)
@@ -64,7 +65,8 @@ def _init_dynamic_share(server_args: ServerArgs, port_args: SemiPDPortArgs, mr, 
     if server_args.cu_mask_mode != "dynamic":
         return
     from semi_pd_amd.semi_pd.share_board import ShareBoard
-    board = ShareBoard(os.path.join(os.path.dirname(port_args.tokenizer_ipc_name), "share_board"), create=True)
+    # one board per tensor-parallel rank: rank r's prefill and decode process share GPU r
+    board = ShareBoard(os.path.join(os.path.dirname(port_args.tokenizer_ipc_name), f"share_board_{mr.tp_rank}"), create=True)
     percent = server_args.decode_cu_percent if role == InstanceRole.DECODE else server_args.prefill_cu_percent
     mr.init_cu_share(role, percent, board)
 
@@ -92,6 +94,14 @@ def run_scheduler_process(server_args: ServerArgs, port_args: SemiPDPortArgs, gp
         from semi_pd_amd.managers.semi_pd_prefill_scheduler import SemiPDPrefillScheduler
         rank0 = tp_rank == 0
         prio = server_args.decode_stream_priority if role == InstanceRole.DECODE else server_args.prefill_stream_priority
+        if role == InstanceRole.DECODE and os.environ.get("SEMIPD_DECODE_OWN_STREAM") == "1" and not prio:
+            # experiments: the decode instance on a created (non-blocking) stream instead of the NULL stream
+            import ctypes
+            from semi_pd_amd import _lib
+            torch.cuda.set_device(gpu_id)
+            raw = ctypes.c_void_p()
+            _lib.check(_lib.load().semipd_stream_create(gpu_id, ctypes.addressof(raw)), "stream_create")
+            torch.cuda.set_stream(torch.cuda.ExternalStream(raw.value, device=torch.device("cuda", gpu_id)))
         if prio:
             # the whole instance (weights, graphs, every launch) lives on one prioritised stream: the hardware
             # scheduler serves the queue of a high-priority stream first when both instances have work ready
@@ -240,7 +250,9 @@ class Engine:
             gpu_id = self.gpu_ids[tp_rank]
             reader, writer = ctx.Pipe(duplex=False)
             env_add = {}
-            if sa.cu_mask_mode == "env" and percent < 100:
+            # (SEMIPD_DYN_ALSO_ENV_MASK=1, experiments: dynamic mode with the process mask on top of the masked stream)
+            if (sa.cu_mask_mode == "env" or (sa.cu_mask_mode == "dynamic" and os.environ.get("SEMIPD_DYN_ALSO_ENV_MASK") == "1")) \
+                    and percent < 100:
                 env_add = cu_mask_env(gpu_id, self._num_cus(gpu_id), percent, from_top,
                                       library_grid=sa.library_gemm_grid)
             old = {k: os.environ.get(k) for k in env_add}

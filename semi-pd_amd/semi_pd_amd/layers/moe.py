@@ -36,6 +36,23 @@ def expert_parallel_enabled() -> bool:
     return _EXPERT_PARALLEL
 
 
+# --enable-ep-all-to-all (with --enable-ep-moe; no counterpart in the reference, whose expert parallelism keeps every token
+# on every rank and all-reduces the partial outputs, ep_moe/layer.py:190; SURVEY 8f-4 / BASELINE config 5): every rank
+# routes only its own slice of the tokens, the rows travel to the ranks that own their experts and back through the
+# peer-memory all-to-all (csrc/all_reduce.hip: semipd_ep_dispatch / semipd_ep_combine), the slices are all-gathered.
+_EP_ALL_TO_ALL = False
+EP_REGION_CAPACITY = int(os.environ.get("SEMIPD_EP_REGION_MB", "128")) << 20   # payload bytes of a peer-memory slot
+
+
+def set_expert_all_to_all(enabled: bool) -> None:
+    global _EP_ALL_TO_ALL
+    _EP_ALL_TO_ALL = bool(enabled)
+
+
+def expert_all_to_all_enabled() -> bool:
+    return _EP_ALL_TO_ALL
+
+
 def select_experts(hidden_states: torch.Tensor, router_logits: torch.Tensor, top_k: int,
                    use_grouped_topk: bool, renormalize: bool, topk_group: Optional[int] = None,
                    num_expert_group: Optional[int] = None, correction_bias: Optional[torch.Tensor] = None):
@@ -254,6 +271,56 @@ class FusedMoE(nn.Module):
             self.w13_weight_scale_inv.tp_full_shape = (E,) + scale_shape(2 * n, hidden_size, (bn, bk))
             self.w2_weight_scale_inv.tp_full_shape = (E,) + scale_shape(hidden_size, n, (bn, bk))
             self.w13_weight_scale_inv.tp_shard = self.w2_weight_scale_inv.tp_shard = lambda full: full[lo:hi].contiguous()
+
+    # ------------------------------------------------------------------ expert parallelism through the all-to-all
+    def all_to_all_comm(self):
+        """The peer-memory communicator when this layer routes through the expert all-to-all, else None."""
+        if not (self.expert_parallel and expert_all_to_all_enabled()):
+            return None
+        from semi_pd_amd.distributed import get_custom_all_reduce
+        return get_custom_all_reduce()
+
+    def forward_all_to_all(self, hidden_states: torch.Tensor, router_logits: torch.Tensor, comm) -> torch.Tensor:
+        """[T, H] replicated in, [T, H] replicated out, COMPLETE (every expert's contribution, not a partial sum): rank r
+        routes the tokens of its slice, ep_dispatch brings the rows routed to this rank's experts, the local experts run on
+        them as a top-1 problem (each received row has one expert and one weight), ep_combine takes the weighted rows back
+        and sums each token's k of them like moe_sum, the slices are all-gathered.  Chunked over tokens so that a chunk's
+        rows fit a slot of the peer-memory region."""
+        tp, rank = get_tensor_model_parallel_world_size(), get_tensor_model_parallel_rank()
+        T, H = hidden_states.shape
+        topk_weights, topk_ids = select_experts(hidden_states, router_logits, self.top_k, self.use_grouped_topk,
+                                                self.renormalize, self.topk_group, self.num_expert_group,
+                                                self.correction_bias)
+        k = topk_ids.shape[1]
+        e_local = self.w13_weight.shape[0]
+        cap = comm.capacity
+        chunk = max(tp, (cap - 8192) // (k * H * hidden_states.element_size()))
+        out = torch.empty_like(hidden_states)
+        for c0 in range(0, T, chunk):
+            c1 = min(T, c0 + chunk)
+            n = c1 - c0
+            per = -(-n // tp)                               # slice length (the last ranks' slices may be shorter or empty)
+            lo, hi = min(n, rank * per), min(n, (rank + 1) * per)
+            x = hidden_states[c0 + lo: c0 + hi].contiguous()
+            ids = topk_ids[c0 + lo: c0 + hi].to(torch.int32).contiguous()
+            w = topk_weights[c0 + lo: c0 + hi].float().contiguous()
+            max_recv = n * k
+            st = comm.ep_dispatch(x, ids, w, e_local, max_recv)
+            # rows that did not arrive (beyond recv_count) keep the out-of-range expert id and are dropped by moe_align
+            recv_e = torch.where(torch.arange(max_recv, device=x.device) < st["recv_count"], st["recv_expert"],
+                                 torch.full_like(st["recv_expert"], e_local)).view(-1, 1)
+            recv_w = st["recv_weight"].view(-1, 1)
+            if self.quant_config:
+                y = fused_experts_fp8(st["recv_x"], self.w13_weight, self.w2_weight, self.w13_weight_scale_inv,
+                                      self.w2_weight_scale_inv, recv_w, recv_e, self.quant_config.weight_block_size,
+                                      partial_experts=True)
+            else:
+                y = fused_experts(st["recv_x"], self.w13_weight, self.w2_weight, recv_w, recv_e, partial_experts=True)
+            mine = comm.ep_combine(y.contiguous(), st)      # [hi - lo, H]
+            padded = torch.zeros((per, H), dtype=mine.dtype, device=mine.device)
+            padded[: hi - lo] = mine
+            out[c0:c1] = comm.all_gather(padded).view(tp * per, H)[:n]
+        return out
 
     def forward(self, hidden_states: torch.Tensor, router_logits: torch.Tensor, x_quant=None, out_scale: float = 1.0,
                 out_addend: Optional[torch.Tensor] = None) -> torch.Tensor:

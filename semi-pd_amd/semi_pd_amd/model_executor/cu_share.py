@@ -6,10 +6,12 @@ GPU gets all of it.  HSA_CU_MASK is a hard, process-wide partition; `--cu-mask-m
 unmasked and gives it TWO streams instead:
 
     "share"   hipExtStreamCreateWithCUMask over the instance's own CUs (prefill: the lowest P %, decode: the highest D %),
-    "full"    an ordinary stream: every CU of the device,
+    "full"    the process's NULL stream: every CU of the device,
 
 and the instance runs each unit of work (a decode step = one hipGraph launch, a prefill batch = one forward) on "full" while
-the other instance has nothing in flight (semi_pd/share_board.py) and on "share" otherwise.  Kernels launched on a stream --
+the other instance has nothing in flight (semi_pd/share_board.py) and on "share" otherwise.  "full" is the NULL stream (see
+__init__); with the reference's shares (prefill 80 %, decode 100 %) the decode instance therefore never leaves the NULL
+stream, and the prefill instance moves between its masked stream and the NULL stream.  Kernels launched on a stream --
 and the nodes of a hipGraph launched on it -- inherit the stream's CU mask (tools/cu_mask_check.py --streams verifies this
 on the box).  Grids, K splits and split-KV counts are sized for the CUs of the stream they run on, so the decode instance
 keeps one set of graphs per stream.
@@ -47,12 +49,19 @@ class CuShare:
         self.cus: Dict[str, int] = {
             SHARE: sum(bin(w).count("1") for w in cu_mask_words(n, percent, from_top)) if percent < 100 else n,
             FULL: n}
-        raw = C.c_void_p()
-        _lib.check(_lib.load().semipd_stream_create(idx, C.addressof(raw)), "stream_create")
+        # The whole-chip stream is the process's NULL stream, on purpose: a decode instance whose graph launches go to a
+        # CREATED stream is a much worse neighbour than one on the NULL stream -- same masks, same kernels: decode step
+        # 6.4 -> 8.8 ms, TBT p99 12.4 -> 29.5 ms, prefill batch 29.8 -> 33.3 ms (profiles/r04_stream_kind_bisect.txt; it
+        # also explains round 2's "a prioritised decode stream made both medians worse": that stream was a created one).
+        # SEMIPD_DYN_FULL_ON_CREATED_STREAM=1 keeps the created stream for that A/B.
+        if os.environ.get("SEMIPD_DYN_FULL_ON_CREATED_STREAM") == "1":
+            raw = C.c_void_p()
+            _lib.check(_lib.load().semipd_stream_create(idx, C.addressof(raw)), "stream_create")
+            full = torch.cuda.ExternalStream(raw.value, device=dev)
+        else:
+            full = torch.cuda.default_stream(dev)
         self.streams: Dict[str, torch.cuda.Stream] = {
-            SHARE: cu_masked_stream(idx, percent, from_top) if percent < 100
-            else torch.cuda.ExternalStream(raw.value, device=dev),
-            FULL: torch.cuda.ExternalStream(raw.value, device=dev)}
+            SHARE: cu_masked_stream(idx, percent, from_top) if percent < 100 else full, FULL: full}
         self.active: Optional[str] = None
         self.taken = {SHARE: 0, FULL: 0}   # units of work run on each stream (statistics)
         self.activate(SHARE)

@@ -121,7 +121,7 @@ class ModelRunner:
                  disable_cuda_graph: bool = False, cuda_graph_max_bs: int = 256,
                  load_state_dict: Optional[Dict[str, torch.Tensor]] = None, model_path: Optional[str] = None,
                  load_format: str = "dummy", kv_cache_dtype: str = "auto", disable_custom_all_reduce: bool = False,
-                 enable_ep_moe: bool = False, disable_stream_linear: bool = False,
+                 enable_ep_moe: bool = False, enable_ep_all_to_all: bool = False, disable_stream_linear: bool = False,
                  num_kv_splits: Optional[int] = None, dummy_lm_head_scale: float = 1.0):
         self.model_config = model_config
         self.model_path = model_path
@@ -145,8 +145,10 @@ class ModelRunner:
         self.device = torch.device("cuda", gpu_id)
         torch.cuda.set_device(self.device)
         if tp_size > 1:
+            from semi_pd_amd.layers.moe import EP_REGION_CAPACITY
             init_distributed_environment(tp_size, tp_rank, nccl_init_method, dist_backend, self.device,
-                                         use_custom_all_reduce=not disable_custom_all_reduce)
+                                         use_custom_all_reduce=not disable_custom_all_reduce,
+                                         peer_region_capacity=EP_REGION_CAPACITY if (enable_ep_moe and enable_ep_all_to_all) else None)
         else:
             init_distributed_environment(1, 0, "", dist_backend)
         self.num_cus = get_device_sm_count(gpu_id)
@@ -171,8 +173,9 @@ class ModelRunner:
         set_stream_linear(not disable_stream_linear)
 
         # ---- model -------------------------------------------------------------------------
-        from semi_pd_amd.layers.moe import set_expert_parallel
+        from semi_pd_amd.layers.moe import set_expert_all_to_all, set_expert_parallel
         set_expert_parallel(enable_ep_moe)
+        set_expert_all_to_all(enable_ep_moe and enable_ep_all_to_all)
         torch.set_default_dtype(dtype)
         try:
             if bypass_load_weight:

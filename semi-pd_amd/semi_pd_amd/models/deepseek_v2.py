@@ -137,6 +137,16 @@ class DeepseekV2MoE(nn.Module):
             x_quant = quantize_activation(hidden_states, qc.weight_block_size)
         shared_output = self.shared_experts(hidden_states, x_quant=x_quant) if self.shared_experts is not None else None
         router_logits = self.gate(hidden_states)
+        comm = self.experts.all_to_all_comm() if (self.tp_size > 1 and hidden_states.dim() == 2) else None
+        if comm is not None:
+            # --enable-ep-all-to-all: the routed part comes back COMPLETE and replicated; only the (tensor-parallel)
+            # shared experts still hold a partial sum
+            out = self.experts.forward_all_to_all(hidden_states, router_logits, comm)
+            if self.routed_scaling_factor != 1.0:
+                out = out * self.routed_scaling_factor
+            if shared_output is not None:
+                out = out + tensor_model_parallel_all_reduce(shared_output)
+            return out
         if hidden_states.dim() == 2 and (shared_output is None or shared_output.is_contiguous()):
             # `* routed_scaling_factor` and `+ shared_output` ride in the launch that sums the top-k rows (same roundings)
             out = self.experts(hidden_states, router_logits, x_quant=x_quant, out_scale=float(self.routed_scaling_factor),

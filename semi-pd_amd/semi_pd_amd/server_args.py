@@ -41,6 +41,9 @@ class ServerArgs:
     disable_cuda_graph: bool = False
     disable_overlap_schedule: bool = False   # server_args.py --disable-overlap-schedule (decode instance of Semi-PD)
     enable_ep_moe: bool = False              # server_args.py --enable-ep-moe: routed experts partitioned by expert over TP
+    # with --enable-ep-moe: the routed tokens travel to the ranks that own their experts and back (peer-memory all-to-all,
+    # csrc/all_reduce.hip) instead of every rank computing on every token and all-reducing; no reference counterpart
+    enable_ep_all_to_all: bool = False
     disable_custom_all_reduce: bool = False  # server_args.py --disable-custom-all-reduce: TP all-reduce through RCCL only
     cuda_graph_max_bs: int = 256
     # server_args.py:168, 321-323 --triton-attention-num-kv-splits (8, 16 on HIP): given, the decode attention uses that
@@ -147,6 +150,9 @@ def add_cli_args(parser):
     p.add_argument("--disable-cuda-graph", action="store_true")
     p.add_argument("--enable-ep-moe", action="store_true",
                    help="expert parallelism for the routed experts: E / tp whole experts per rank (ep_moe/layer.py)")
+    p.add_argument("--enable-ep-all-to-all", action="store_true",
+                   help="with --enable-ep-moe: expert all-to-all over the peer-memory regions (xGMI) instead of the all-reduce "
+                        "of partial expert outputs")
     p.add_argument("--disable-custom-all-reduce", action="store_true",
                    help="TP all-reduce through RCCL only (default: peer-memory kernel up to 16 MB)")
     p.add_argument("--cuda-graph-max-bs", type=int, default=256)
@@ -188,7 +194,7 @@ def from_cli_args(args) -> ServerArgs:
         base_gpu_id=args.base_gpu_id, random_seed=args.random_seed, watchdog_timeout=args.watchdog_timeout,
         dist_init_addr=args.dist_init_addr, nccl_port_base=args.nccl_port,
         disable_cuda_graph=args.disable_cuda_graph, disable_custom_all_reduce=args.disable_custom_all_reduce,
-        enable_ep_moe=args.enable_ep_moe, disable_overlap_schedule=args.disable_overlap_schedule, cuda_graph_max_bs=args.cuda_graph_max_bs,
+        enable_ep_moe=args.enable_ep_moe, enable_ep_all_to_all=args.enable_ep_all_to_all, disable_overlap_schedule=args.disable_overlap_schedule, cuda_graph_max_bs=args.cuda_graph_max_bs,
         enable_semi_pd=args.enable_semi_pd, prefill_cu_percent=args.prefill_cu_percent,
         decode_cu_percent=args.decode_cu_percent, attention_backend=args.attention_backend,
         sampling_backend=args.sampling_backend, triton_attention_num_kv_splits=args.triton_attention_num_kv_splits)

@@ -228,3 +228,23 @@ def test_deepseek_tp2_expert_parallel_on_one_gpu(unified_deepseek):
             eng.shutdown()
         assert all(len(o) == 10 for o in got)
         check_against_oracle(oracle, prompts, got)
+
+
+def test_deepseek_tp2_expert_all_to_all_on_one_gpu(unified_deepseek):
+    """--enable-ep-moe --enable-ep-all-to-all with TP = 2, both ranks on the one GPU (gloo + the peer-memory regions): each
+    rank routes its half of the tokens, the rows travel to the rank that owns their expert and back (semipd_ep_dispatch /
+    semipd_ep_combine, csrc/all_reduce.hip), the halves are all-gathered; the decode steps run the same collectives from
+    their hipGraphs.  Same tokens as the oracle of the unsharded model, like the all-reduce form of expert parallelism
+    (test_deepseek_tp2_expert_parallel_on_one_gpu) that it replaces (the reference's only form: ep_moe/layer.py:190)."""
+    from semi_pd_amd.entrypoints.engine import Engine
+    from semi_pd_amd.managers.io_struct import SamplingParams
+    cfg, sd, prompts, outs, _ = unified_deepseek
+    oracle = OracleDeepseekV2(cfg, sd)
+    eng = Engine(server_args(cfg, tp_size=2, enable_semi_pd=True, prefill_cu_percent=50, decode_cu_percent=50,
+                             dist_backend="gloo", enable_ep_moe=True, enable_ep_all_to_all=True), gpu_ids={0: 0, 1: 0})
+    try:
+        got = eng.generate(prompts, SamplingParams(max_new_tokens=10, ignore_eos=True), timeout=600)
+    finally:
+        eng.shutdown()
+    assert all(len(o) == 10 for o in got)
+    check_against_oracle(oracle, prompts, got)

@@ -87,9 +87,10 @@ def test_deepseek_v3_tp8_rank_width_block_fp8_unified_and_semi_pd_match_the_orac
     prompts = make_prompts(cfg.vocab_size, lens, seed=17)
     uni, sd = _generate(_args(cfg), prompts, want_sd=True)
     oracle = OracleDeepseekV2(cfg, sd, act_dtype=torch.bfloat16, absorb_fp8=True)
-    # per-tensor activation scales of the bmm_fp8 absorption depend on which tokens share a step (as in the
-    # reference): the margin of test_gpu_deepseek.py's fp8 case (0.2 at head scale 1)
-    margin = 0.2
+    # fp8 quantisation noise is relative, so the logit margin scales with the logits' spread: test_gpu_deepseek.py's fp8
+    # case allows 0.2 where the logits' std is 0.02 sqrt(512) = 0.45; here it is 0.02 sqrt(7168) = 1.69 (per-tensor
+    # activation scales of the bmm_fp8 absorption also depend on which tokens share a step, as in the reference)
+    margin = 0.2 * (7168 / 512) ** 0.5
     check_against_oracle(oracle, prompts, uni, margin=margin)
     semi, _ = _generate(_args(cfg, enable_semi_pd=True, prefill_cu_percent=50, decode_cu_percent=50), prompts)
     check_against_oracle(oracle, prompts, semi, margin=margin)
