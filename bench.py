@@ -26,9 +26,11 @@ for _p in (ROOT, os.path.join(ROOT, "semi-pd_amd")):
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-# the masked Semi-PD operating point of the default line (see the --prefill-cu / --decode-cu help)
-DEFAULT_PREFILL_CU = 62
-DEFAULT_DECODE_CU = 38
+# the masked Semi-PD operating point of the default line (see the --prefill-cu / --decode-cu help): the reference's own
+# shares (semi_pd/utils.py:10-11: prefill 80 %, decode 100 %), i.e. nested CU masks, work-conserving (--cu-mask-mode dynamic)
+DEFAULT_PREFILL_CU = 80
+DEFAULT_DECODE_CU = 100
+DEFAULT_BACKLOG_FULL_TOKENS = 8192
 # BASELINE config 2: "Poisson QPS sweep" -- three points in the default line (in = 1024 / out = 256)
 DEFAULT_SWEEP_RATES = "8,16,32"
 SWEEP_OUTPUT_LEN = 256
@@ -270,24 +272,25 @@ def main():
     ap.add_argument("--output-len", type=int, default=128)
     ap.add_argument("--request-rate", type=float, default=32.0, help="Poisson arrivals per second (0 = all at once)")
     ap.add_argument("--mode", choices=["semi-pd", "unified"], default="semi-pd")
-    # CU shares of the two instances (HSA_CU_MASK per process: prefill takes its share from the bottom of the CU range,
-    # decode from the top).  The default is a MASKED policy -- the north star's compute isolation and BASELINE config 2
-    # ("CU split") -- with the shares this build measured best on the config-2 load (profiles/r03_policy_sweep_*.txt);
-    # `--prefill-cu 50 --decode-cu 50` is config 2's split as written, `--prefill-cu 100 --decode-cu 100` the unmasked
-    # round-2 default.  The literal 50 / 50 split is measured in the same invocation by a second engine (one warm-up +
-    # one timed wave, "static_split_50_50"; --no-static-split-wave skips it).
-    ap.add_argument("--prefill-cu", type=int, default=None, help=f"default {DEFAULT_PREFILL_CU} (MoE models: 50)")
-    ap.add_argument("--decode-cu", type=int, default=None, help=f"default {DEFAULT_DECODE_CU} (MoE models: 50)")
+    # CU shares of the two instances (prefill takes its share from the bottom of the CU range, decode from the top).  The
+    # default is a MASKED policy -- the north star's compute isolation and BASELINE config 2 ("CU split") -- with the
+    # reference's own shares, prefill 80 % / decode 100 % (nested: the decode instance has the top 20 % to itself and may
+    # use the rest), work-conserving (--cu-mask-mode dynamic; profiles/r04_policy_sweep.txt).  `--prefill-cu 50 --decode-cu 50
+    # --cu-mask-mode env` is config 2's split as written: it is measured in the same invocation by a second engine (one
+    # warm-up + one timed wave, "static_split_50_50"; --no-static-split-wave skips it); `--prefill-cu 100 --decode-cu 100`
+    # is the unmasked round-2 default.
+    ap.add_argument("--prefill-cu", type=int, default=DEFAULT_PREFILL_CU)
+    ap.add_argument("--decode-cu", type=int, default=DEFAULT_DECODE_CU)
     ap.add_argument("--no-static-split-wave", action="store_true",
                     help="N = 1 Semi-PD default run: do not start the second engine with BASELINE config 2's literal 50 / 50 split")
     ap.add_argument("--no-prefill-gemm-tuning", action="store_true",
                     help="prefill instance: the library's own GEMM choice instead of the solutions timed on its CU share")
     ap.add_argument("--tune-prefill-gemm", action="store_true",
                     help="time the library's GEMM solutions at start-up even when the prefill instance owns every CU")
-    ap.add_argument("--cu-mask-mode", default="env", choices=["env", "none", "dynamic"],
+    ap.add_argument("--cu-mask-mode", default="dynamic", choices=["env", "none", "dynamic"],
                     help="env: static HSA_CU_MASK per instance; dynamic: unmasked processes with a CU-masked stream over their "
                          "share and a stream over every CU, chosen per decode step / prefill batch (work-conserving shares)")
-    ap.add_argument("--prefill-backlog-full-tokens", type=int, default=0,
+    ap.add_argument("--prefill-backlog-full-tokens", type=int, default=DEFAULT_BACKLOG_FULL_TOKENS,
                     help="dynamic mode: waiting prompt tokens from which a prefill batch takes every CU (0 = never)")
     ap.add_argument("--prefill-priority", type=int, default=0, help="HIP stream priority of the prefill instance (-1 = high)")
     ap.add_argument("--decode-priority", type=int, default=0, help="HIP stream priority of the decode instance (-1 = high)")
@@ -329,12 +332,6 @@ def main():
     ap.add_argument("--sweep-num-requests", type=int, default=None, help="requests per sweep point (default: --num-requests)")
     args = ap.parse_args()
 
-    if args.prefill_cu is None or args.decode_cu is None:
-        # a decode step of the MoE models reads ~29 GB (every expert is touched at batch >= 20): their decode instance
-        # needs the bigger share (DeepSeek-V2-Lite: TBT p50 17.0 ms at 38 %, 13.6 ms at 50 %)
-        moe = args.model.startswith("deepseek")
-        args.prefill_cu = args.prefill_cu if args.prefill_cu is not None else (50 if moe else DEFAULT_PREFILL_CU)
-        args.decode_cu = args.decode_cu if args.decode_cu is not None else (50 if moe else DEFAULT_DECODE_CU)
     if args.rate_sweep is None:
         default_workload = (args.gpus == 1 and args.model == "llama3-8b" and args.mode == "semi-pd"
                             and args.input_len == 1024 and args.output_len == 128 and args.request_rate == 32.0)
@@ -462,7 +459,8 @@ def main():
             and (args.prefill_cu, args.decode_cu) != (50, 50)):
         # BASELINE config 2 as written: disjoint halves of the CUs, same load, one warm-up wave + one timed wave
         import dataclasses
-        eng2 = Engine(dataclasses.replace(sa, prefill_cu_percent=50, decode_cu_percent=50, collect_kernel_timing=False),
+        eng2 = Engine(dataclasses.replace(sa, prefill_cu_percent=50, decode_cu_percent=50, cu_mask_mode="env",
+                                          collect_kernel_timing=False),
                       gpu_ids={0: local_rank})
         try:
             run_wave(eng2, prompts, arrivals, args.output_len)
@@ -571,10 +569,12 @@ def main():
     if args.mode != "semi-pd":
         mask_text = "one process on every CU"
     elif args.cu_mask_mode == "dynamic":
-        mask_text = (f"dynamic CU shares P{args.prefill_cu}/D{args.decode_cu} (CU-masked streams: prefill the lowest "
-                     f"{args.prefill_cu} % of the CUs, decode the highest {args.decode_cu} %, each instance on every CU while "
-                     f"the other has nothing in flight"
-                     + (f" or, prefill, from {args.prefill_backlog_full_tokens} waiting prompt tokens" if args.prefill_backlog_full_tokens else "") + ")")
+        mask_text = (f"work-conserving CU shares P{args.prefill_cu}/D{args.decode_cu} (the reference's MPS percentages as CU masks: "
+                     f"prefill on a CU-masked stream over the lowest {args.prefill_cu} % of the CUs, decode on "
+                     + ("every CU" if args.decode_cu >= 100 else f"the highest {args.decode_cu} %")
+                     + "; an instance takes every CU while the other has nothing in flight"
+                     + (f", the prefill instance also from {args.prefill_backlog_full_tokens} waiting prompt tokens" if args.prefill_backlog_full_tokens else "")
+                     + "; BASELINE config 2's literal 50 / 50 split is the side field static_split_50_50)")
     elif (args.prefill_cu, args.decode_cu) == (100, 100) or args.cu_mask_mode != "env":
         mask_text = "CU shares P100/D100 (no mask: both instances on every CU)"
     else:
@@ -601,7 +601,8 @@ def main():
                    "prefill_gemm": ("library solutions timed on the prefill share at start-up (csrc/dense_gemm.hip)"
                                     + (", next to a replaying decode step" if (world == 1 or not args.tp) and
                                        os.environ.get("SEMIPD_TUNE_UNDER_DECODE_LOAD", "1") != "0" else "")
-                                    if (not args.no_prefill_gemm_tuning and args.prefill_cu < 100 and args.mode == "semi-pd")
+                                    if (not args.no_prefill_gemm_tuning and args.prefill_cu < 100 and args.mode == "semi-pd"
+                                        and args.cu_mask_mode in ("env", "dynamic"))
                                     else "library heuristic"),
                    "kv_cache_dtype": args.kv_cache_dtype},
         "roofline": roofline, "roofline_extra": extra, "cpu_baseline": cpu,

@@ -233,4 +233,15 @@ __device__ inline float block_sum(float v, float* red) {
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// decode attention on a q / k / v row that is still the K-slice planes of the qkv GEMM (decode_attention_mfma.hip, ROPE form)
+struct DecodeRopePlanes {
+  const float* planes;        // [n_planes][tokens][(Hq + 2 Hk) * D]
+  int n_planes;
+  int64_t plane_elems;        // elements between planes
+  int64_t row_elems;          // (Hq + 2 Hk) * D
+  const float* cache;         // [positions][D]: cos over the first half, sin over the second
+  const int64_t* positions;
+  const int64_t* loc;         // pool row of the step's token, per request
+};
+
 }  // namespace semipd

@@ -392,7 +392,7 @@ template <typename T, typename KV>
 int launch_decode_mfma(T* out, const T* q, const KV* k_buf, const KV* v_buf, const int32_t* kv_indptr,
                        const int32_t* kv_indices, float* attn_logits, int64_t batch, int Hq, int Hkv, int D,
                        int64_t q_stride, int64_t o_stride, int64_t kbuf_stride, int64_t vbuf_stride,
-                       int splits, float sm_scale, float logit_cap, hipStream_t st);
+                       int splits, float sm_scale, float logit_cap, hipStream_t st, const DecodeRopePlanes* rope = nullptr);
 
 // defined in mla_decode_attention.hip
 template <typename T, typename KV>
@@ -511,9 +511,80 @@ static int run_decode(void* out, const void* q, const void* k_buf, const void* v
   return rc;
 }
 
+// stage 2 of a split decode attention (shared by the two entry points)
+template <typename T>
+static int launch_stage2(void* out, float* attn_logits, const int32_t* kv_indptr, int64_t batch, int num_q_heads,
+                         int head_dim_v, int64_t o_stride, int num_kv_splits, hipStream_t st) {
+  dim3 grid((unsigned)batch, (unsigned)num_q_heads);
+  const int threads = head_dim_v <= 64 ? 64 : head_dim_v <= 128 ? 128 : 256;
+  hipLaunchKernelGGL((decode_stage2_kernel<T>), grid, dim3(threads), 0, st, (T*)out, attn_logits, kv_indptr, num_q_heads,
+                     head_dim_v, o_stride, num_kv_splits);
+  return launch_status("decode_stage2");
+}
+
+template <typename T>
+static int run_decode_rope(void* out, const DecodeRopePlanes& rp, void* k_buf, void* v_buf, const int32_t* kv_indptr,
+                           const int32_t* kv_indices, float* attn_logits, int64_t batch, int Hq, int Hkv, int D,
+                           int64_t o_stride, int64_t kbuf_stride, int64_t vbuf_stride, int splits, float sm_scale,
+                           float logit_cap, int dtype, int kv_dtype, hipStream_t st) {
+  int rc;
+  if (kv_dtype == dtype)
+    rc = launch_decode_mfma<T, T>((T*)out, (const T*)nullptr, (const T*)k_buf, (const T*)v_buf, kv_indptr, kv_indices,
+                                  attn_logits, batch, Hq, Hkv, D, 0, o_stride, kbuf_stride, vbuf_stride, splits, sm_scale,
+                                  logit_cap, st, &rp);
+  else if (kv_dtype == SEMIPD_F8E5M2)
+    rc = launch_decode_mfma<T, f8e5m2_t>((T*)out, (const T*)nullptr, (const f8e5m2_t*)k_buf, (const f8e5m2_t*)v_buf, kv_indptr,
+                                         kv_indices, attn_logits, batch, Hq, Hkv, D, 0, o_stride, kbuf_stride, vbuf_stride,
+                                         splits, sm_scale, logit_cap, st, &rp);
+  else if (kv_dtype == SEMIPD_F8E4M3)
+    rc = launch_decode_mfma<T, f8e4m3_t>((T*)out, (const T*)nullptr, (const f8e4m3_t*)k_buf, (const f8e4m3_t*)v_buf, kv_indptr,
+                                         kv_indices, attn_logits, batch, Hq, Hkv, D, 0, o_stride, kbuf_stride, vbuf_stride,
+                                         splits, sm_scale, logit_cap, st, &rp);
+  else {
+    set_error("decode_attention_rope_planes: unsupported kv_dtype %d", kv_dtype);
+    return SEMIPD_EDTYPE;
+  }
+  if (rc == 0 && splits > 1) rc = launch_stage2<T>(out, attn_logits, kv_indptr, batch, Hq, D, o_stride, splits, st);
+  return rc;
+}
+
 }  // namespace semipd
 
 using namespace semipd;
+
+extern "C" int semipd_decode_attention_rope_planes_supported(int num_q_heads, int num_kv_heads, int head_dim) {
+  if (num_q_heads <= 0 || num_kv_heads <= 0 || num_q_heads % num_kv_heads) return 0;
+  const int group = num_q_heads / num_kv_heads;
+  return group >= 2 && group <= 16 && (head_dim == 64 || head_dim == 96 || head_dim == 128);
+}
+
+extern "C" int semipd_decode_attention_rope_planes(void* out, const float* planes, int n_planes, int64_t plane_elems,
+                                                   void* k_buf, void* v_buf, const int64_t* loc, const float* cos_sin_cache,
+                                                   const int64_t* positions, const int32_t* kv_indptr,
+                                                   const int32_t* kv_indices, float* attn_logits, int64_t batch,
+                                                   int num_q_heads, int num_kv_heads, int head_dim, int64_t o_stride,
+                                                   int64_t kbuf_stride, int64_t vbuf_stride, int num_kv_splits, float sm_scale,
+                                                   float logit_cap, int dtype, int kv_dtype, void* stream) {
+  SEMIPD_CHECK_ARG(batch >= 0 && n_planes >= 1 && num_kv_splits > 0 && num_kv_splits <= 65535 && batch < 65536 * 16,
+                   SEMIPD_EINVAL, "decode_attention_rope_planes: bad sizes");
+  SEMIPD_CHECK_ARG(semipd_decode_attention_rope_planes_supported(num_q_heads, num_kv_heads, head_dim), SEMIPD_ESHAPE,
+                   "decode_attention_rope_planes: %d query heads per kv head of %d (2 .. 16 heads of 64 / 96 / 128 supported)",
+                   num_kv_heads ? num_q_heads / num_kv_heads : 0, head_dim);
+  if (batch == 0) return 0;
+  SEMIPD_CHECK_ARG(out && planes && k_buf && v_buf && loc && cos_sin_cache && positions && kv_indptr && kv_indices, SEMIPD_EINVAL,
+                   "decode_attention_rope_planes: null pointer");
+  SEMIPD_CHECK_ARG(num_kv_splits == 1 || attn_logits, SEMIPD_EINVAL,
+                   "decode_attention_rope_planes: attn_logits scratch required when num_kv_splits > 1");
+  SEMIPD_CHECK_ARG(dtype == SEMIPD_BF16 || dtype == SEMIPD_F16, SEMIPD_EDTYPE, "decode_attention_rope_planes: bf16 / f16 activations");
+  const int64_t row_elems = (int64_t)(num_q_heads + 2 * num_kv_heads) * head_dim;
+  SEMIPD_CHECK_ARG(plane_elems % 4 == 0 && plane_elems >= batch * row_elems && aligned16(planes) && aligned16(k_buf) &&
+                   aligned16(v_buf) && kbuf_stride % 16 == 0 && vbuf_stride % 16 == 0 && o_stride % 4 == 0 &&
+                   (reinterpret_cast<uintptr_t>(out) & 7u) == 0, SEMIPD_EALIGN,
+                   "decode_attention_rope_planes: 16-byte aligned planes / pool rows required");
+  DecodeRopePlanes rp{planes, n_planes, plane_elems, row_elems, cos_sin_cache, positions, loc};
+  SEMIPD_DISPATCH_HALF(dtype, T, return run_decode_rope<T>(out, rp, k_buf, v_buf, kv_indptr, kv_indices, attn_logits, batch, num_q_heads, num_kv_heads, head_dim, o_stride, kbuf_stride, vbuf_stride, num_kv_splits, sm_scale, logit_cap, dtype, kv_dtype, as_stream(stream)));
+  return 0;
+}
 
 extern "C" int semipd_decode_attention(void* out, const void* q, const void* k_buf, const void* v_buf,
                                        const int32_t* kv_indptr, const int32_t* kv_indices,

@@ -82,21 +82,26 @@ def test_the_bench_line_is_assembled_with_every_contract_field(monkeypatch, caps
     assert d["unit"] == "tokens/s" and d["dtype"] == "bf16" and d["data"] == "synthetic" and d["value"] > 0
     assert d["p50_ttft_ms"] == pytest.approx(40.0, abs=0.5) and d["p50_tbt_ms"] == pytest.approx(8.0, abs=0.5)
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["traffic"] is None
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    # HBM bytes per launch from the committed PMC pass (profiles/pmc_traffic.json), scaled to this launch
+    assert r["traffic"] == int(r["traffic_over_algorithmic"] * r["algorithmic_bytes_per_launch"]) and r["traffic_source"].startswith("profiles/")
     assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], abs=1e-4) and "stream_gemm_glds_kernel" in r["kernel"]
     pb = d["roofline_extra"]["prefill_batch_ms"]
     assert pb["launched_behind_a_running_batch"] == 287 and pb["results_sent_from_layer_hook"] == 271 and pb["batches"] == 568
     assert d["roofline_extra"]["extend_attention"]["bound"] == "mfma"
     cfgd = d["config"]
-    assert "workload" in cfgd and "model" not in cfgd and "HSA_CU_MASK" in cfgd["workload"]
+    assert "workload" in cfgd and "model" not in cfgd and "CU-masked stream" in cfgd["workload"] and "50 / 50" in cfgd["workload"]
     assert cfgd["prefill_gemm"].startswith("library solutions timed on the prefill share") and "decode step" in cfgd["prefill_gemm"]
     if expect_static:
-        assert (cfgd["prefill_cu_percent"], cfgd["decode_cu_percent"]) == (62, 38)
-        assert d["static_split_50_50"]["output_tok_s"] > 0 and len(FakeEngine.instances) == 2
+        assert (cfgd["prefill_cu_percent"], cfgd["decode_cu_percent"]) == (80, 100)
+        # the main engine, the literal 50 / 50 engine, and one engine each for BASELINE configs 1 and 3
+        assert d["static_split_50_50"]["output_tok_s"] > 0 and len(FakeEngine.instances) == 4
+        assert FakeEngine.instances[1].sa.cu_mask_mode == "env" and FakeEngine.instances[0].sa.cu_mask_mode == "dynamic"
+        assert d["config1_opt_125m"]["output_tok_s"] > 0 and d["config3_deepseek_v2_lite"]["output_tok_s"] > 0
         assert [s["request_rate"] for s in d["qps_sweep"]] == [8.0, 32.0] and d["qps_sweep"][0]["output_len"] == 6
         assert d["saturation"]["output_tokens"] == 6 * 4
         assert d["steps"] == 2 and d["warmup"] == 1
     else:
-        assert (cfgd["prefill_cu_percent"], cfgd["decode_cu_percent"]) == (50, 50)      # MoE models default to halves
-        assert "static_split_50_50" not in d and "saturation" not in d and "qps_sweep" not in d
+        assert (cfgd["prefill_cu_percent"], cfgd["decode_cu_percent"]) == (80, 100)
+        assert "saturation" not in d and "qps_sweep" not in d and "config1_opt_125m" not in d
         assert "mla_decode_kernel" in d["roofline_extra"]["decode_attention"]["kernel"]
