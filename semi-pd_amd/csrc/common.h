@@ -233,6 +233,62 @@ __device__ inline float block_sum(float v, float* red) {
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Sum of the fp32 K-slice planes of a split GEMM (csrc/stream_linear.hip, gemm8p.hip) at N float4 positions, IN SLICE ORDER
+// (the bits of splitk_planes_reduce), with the loads of up to four planes x N positions in flight at once: written as
+// `for z: acc += load(z)` the compiler waits for every plane before it asks for the next one (one full memory latency per
+// plane: the 5-6 us of the decode step's small kernels were mostly that).
+template <int N>
+__device__ __forceinline__ void planes_sum_f4(const float* const (&p)[N], int n_planes, int64_t plane_elems, float4 (&acc)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) acc[i] = *reinterpret_cast<const float4*>(p[i]);
+  int z = 1;
+  constexpr int CH = N <= 4 ? 4 : (N <= 8 ? 2 : 1);   // planes per batch: bounded by registers (CH x N float4)
+  for (; z + CH <= n_planes; z += CH) {
+    float4 t[CH][N];
+#pragma unroll
+    for (int u = 0; u < CH; ++u)
+#pragma unroll
+      for (int i = 0; i < N; ++i) t[u][i] = *reinterpret_cast<const float4*>(p[i] + (int64_t)(z + u) * plane_elems);
+#pragma unroll
+    for (int u = 0; u < CH; ++u)
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        acc[i].x += t[u][i].x; acc[i].y += t[u][i].y; acc[i].z += t[u][i].z; acc[i].w += t[u][i].w;
+      }
+  }
+  if (CH > 1 && z < n_planes) {            // the tail: up to CH - 1 planes, again all loads first
+    float4 t[CH > 1 ? CH - 1 : 1][N];
+#pragma unroll
+    for (int u = 0; u < CH - 1; ++u)
+#pragma unroll
+      for (int i = 0; i < N; ++i)
+        if (z + u < n_planes) t[u][i] = *reinterpret_cast<const float4*>(p[i] + (int64_t)(z + u) * plane_elems);
+#pragma unroll
+    for (int u = 0; u < CH - 1; ++u)
+#pragma unroll
+      for (int i = 0; i < N; ++i)
+        if (z + u < n_planes) {
+          acc[i].x += t[u][i].x; acc[i].y += t[u][i].y; acc[i].z += t[u][i].z; acc[i].w += t[u][i].w;
+        }
+  }
+}
+// 8 consecutive floats (two float4) of one row
+__device__ __forceinline__ void planes_sum8(const float* p, int n_planes, int64_t plane_elems, float (&f)[8]) {
+  const float* const pp[2] = {p, p + 4};
+  float4 a[2];
+  planes_sum_f4<2>(pp, n_planes, plane_elems, a);
+  f[0] = a[0].x; f[1] = a[0].y; f[2] = a[0].z; f[3] = a[0].w; f[4] = a[1].x; f[5] = a[1].y; f[6] = a[1].z; f[7] = a[1].w;
+}
+// two 8-float runs at once (the two halves of a rotary pair)
+__device__ __forceinline__ void planes_sum8x2(const float* pa, const float* pb, int n_planes, int64_t plane_elems, float (&fa)[8],
+                                              float (&fb)[8]) {
+  const float* const pp[4] = {pa, pa + 4, pb, pb + 4};
+  float4 a[4];
+  planes_sum_f4<4>(pp, n_planes, plane_elems, a);
+  fa[0] = a[0].x; fa[1] = a[0].y; fa[2] = a[0].z; fa[3] = a[0].w; fa[4] = a[1].x; fa[5] = a[1].y; fa[6] = a[1].z; fa[7] = a[1].w;
+  fb[0] = a[2].x; fb[1] = a[2].y; fb[2] = a[2].z; fb[3] = a[2].w; fb[4] = a[3].x; fb[5] = a[3].y; fb[6] = a[3].z; fb[7] = a[3].w;
+}
+
 // decode attention on a q / k / v row that is still the K-slice planes of the qkv GEMM (decode_attention_mfma.hip, ROPE form)
 struct DecodeRopePlanes {
   const float* planes;        // [n_planes][tokens][(Hq + 2 Hk) * D]

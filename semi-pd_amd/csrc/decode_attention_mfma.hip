@@ -115,21 +115,12 @@ decode_mfma_kernel(T* __restrict__ out, const T* __restrict__ q, KV* __restrict_
     const float* prow = rp.planes + (int64_t)b * rp.row_elems;
     const float* cs = rp.cache + rp.positions[b] * D;
     auto sum8 = [&](int64_t col, float (&f)[8]) {     // slice order, like splitk_planes_reduce / rope_planes_kernel
-      const float* p = prow + col;
-      float4 lo = *reinterpret_cast<const float4*>(p), hi = *reinterpret_cast<const float4*>(p + 4);
-      for (int z = 1; z < rp.n_planes; ++z) {
-        const float4 l2 = *reinterpret_cast<const float4*>(p + z * rp.plane_elems);
-        const float4 h2 = *reinterpret_cast<const float4*>(p + z * rp.plane_elems + 4);
-        lo.x += l2.x; lo.y += l2.y; lo.z += l2.z; lo.w += l2.w;
-        hi.x += h2.x; hi.y += h2.y; hi.z += h2.z; hi.w += h2.w;
-      }
-      f[0] = lo.x; f[1] = lo.y; f[2] = lo.z; f[3] = lo.w; f[4] = hi.x; f[5] = hi.y; f[6] = hi.z; f[7] = hi.w;
+      planes_sum8(prow + col, rp.n_planes, rp.plane_elems, f);
     };
     // rotated pair of 8-vectors of one head: first half (i0 .. i0 + 7) and second half (half + i0 ..)
     auto rotate = [&](int64_t head_col, int i0, uint16_t (&oa)[8], uint16_t (&ob)[8]) {
       float fa[8], fb[8];
-      sum8(head_col + i0, fa);
-      sum8(head_col + half + i0, fb);
+      planes_sum8x2(prow + head_col + i0, prow + head_col + half + i0, rp.n_planes, rp.plane_elems, fa, fb);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float c = cs[i0 + j], sn = cs[half + i0 + j];

@@ -51,24 +51,34 @@ rmsnorm_vec_kernel(T* __restrict__ out, T* __restrict__ in, T* __restrict__ res,
       if (v < nvec) wv[i] = load16(w + (int64_t)v * V);
     }
   }
+  // PLANES: the plane sums of ALL of this thread's vectors first, every load of a batch of planes in flight at once
+  // (planes_sum_f4, common.h); same summation order as before
+  float psum[PLANES ? MAXV : 1][8];
+  if constexpr (PLANES) {
+    static_assert(!PLANES || Elem<T>::kVec == 8, "plane input: 16-bit activations");
+    const float* pp[2 * MAXV];
+    float4 acc4[2 * MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int v = min(threadIdx.x + i * blockDim.x, (unsigned)(nvec - 1));   // (tail threads re-read the last vector)
+      pp[2 * i] = planes + row * (int64_t)hidden + (int64_t)v * V;
+      pp[2 * i + 1] = pp[2 * i] + 4;
+    }
+    planes_sum_f4<2 * MAXV>(pp, n_planes, plane_elems, acc4);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      psum[i][0] = acc4[2 * i].x; psum[i][1] = acc4[2 * i].y; psum[i][2] = acc4[2 * i].z; psum[i][3] = acc4[2 * i].w;
+      psum[i][4] = acc4[2 * i + 1].x; psum[i][5] = acc4[2 * i + 1].y; psum[i][6] = acc4[2 * i + 1].z; psum[i][7] = acc4[2 * i + 1].w;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int v = threadIdx.x + i * blockDim.x;
     if (v < nvec) {
       Vec16<T> a;
       if constexpr (PLANES) {
-        static_assert(!PLANES || Elem<T>::kVec == 8, "plane input: 16-bit activations");
-        const float* p = planes + row * (int64_t)hidden + (int64_t)v * V;
-        float4 lo = *reinterpret_cast<const float4*>(p), hi = *reinterpret_cast<const float4*>(p + 4);
-        for (int z = 1; z < n_planes; ++z) {
-          const float4 l2 = *reinterpret_cast<const float4*>(p + z * plane_elems);
-          const float4 h2 = *reinterpret_cast<const float4*>(p + z * plane_elems + 4);
-          lo.x += l2.x; lo.y += l2.y; lo.z += l2.z; lo.w += l2.w;
-          hi.x += h2.x; hi.y += h2.y; hi.z += h2.z; hi.w += h2.w;
-        }
-        const float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
-        for (int j = 0; j < V; ++j) a.e[j] = Elem<T>::from_f(f[j]);
+        for (int j = 0; j < V; ++j) a.e[j] = Elem<T>::from_f(psum[i][j]);
       } else {
         a = load16(in_row + (int64_t)v * V);
       }
@@ -336,23 +346,12 @@ __global__ void rope_planes_kernel(T* __restrict__ q_out, const float* __restric
   const int64_t dst = loc[t];
   const int half = head >> 1, items_per_head = half / V;
   const float* row = planes + t * row_elems;
-  auto sum8 = [&](int64_t col, float (&f)[8]) {
-    const float* p = row + col;
-    float4 lo = *reinterpret_cast<const float4*>(p), hi = *reinterpret_cast<const float4*>(p + 4);
-    for (int z = 1; z < n_planes; ++z) {
-      const float4 l2 = *reinterpret_cast<const float4*>(p + z * plane_elems);
-      const float4 h2 = *reinterpret_cast<const float4*>(p + z * plane_elems + 4);
-      lo.x += l2.x; lo.y += l2.y; lo.z += l2.z; lo.w += l2.w;
-      hi.x += h2.x; hi.y += h2.y; hi.z += h2.z; hi.w += h2.w;
-    }
-    f[0] = lo.x; f[1] = lo.y; f[2] = lo.z; f[3] = lo.w; f[4] = hi.x; f[5] = hi.y; f[6] = hi.z; f[7] = hi.w;
-  };
+  auto sum8 = [&](int64_t col, float (&f)[8]) { planes_sum8(row + col, n_planes, plane_elems, f); };
   const int qk_items = (Hq + Hk) * items_per_head;
   for (int it = threadIdx.x; it < qk_items; it += blockDim.x) {
     const int h = it / items_per_head, i0 = (it - h * items_per_head) * V;
     float fa[8], fb[8];
-    sum8((int64_t)h * head + i0, fa);
-    sum8((int64_t)h * head + half + i0, fb);
+    planes_sum8x2(row + (int64_t)h * head + i0, row + (int64_t)h * head + half + i0, n_planes, plane_elems, fa, fb);
     Vec16<T> oa, ob;
 #pragma unroll
     for (int j = 0; j < V; ++j) {

@@ -287,12 +287,24 @@ splitk_planes_reduce_kernel(T* __restrict__ out, const float* __restrict__ plane
   const int m = (int)(i / n4), n = (int)(i - (int64_t)m * n4) * 4;
   const int64_t plane = (int64_t)M * N;
   const float* src = planes + (int64_t)m * N + n;
-  sl_f32x4 a = *reinterpret_cast<const sl_f32x4*>(src);
-  for (int z = 1; z < ksplit; ++z) a += *reinterpret_cast<const sl_f32x4*>(src + z * plane);
-  float r[4] = {a[0], a[1], a[2], a[3]};
+  // every plane's load in flight at once (common.h: planes_sum_f4), slice order
+  float4 s4[EPI == SL_SILU_MUL ? 2 : 1];
   if (EPI == SL_SILU_MUL) {
-    sl_f32x4 u = *reinterpret_cast<const sl_f32x4*>(src + N / 2);
-    for (int z = 1; z < ksplit; ++z) u += *reinterpret_cast<const sl_f32x4*>(src + N / 2 + z * plane);
+    const float* const pp[2] = {src, src + N / 2};
+    float4 t2[2];
+    planes_sum_f4<2>(pp, ksplit, plane, t2);
+    s4[0] = t2[0];
+    s4[EPI == SL_SILU_MUL ? 1 : 0] = t2[1];
+  } else {
+    const float* const pp[1] = {src};
+    float4 t1[1];
+    planes_sum_f4<1>(pp, ksplit, plane, t1);
+    s4[0] = t1[0];
+  }
+  float r[4] = {s4[0].x, s4[0].y, s4[0].z, s4[0].w};
+  if (EPI == SL_SILU_MUL) {
+    const float4 u4 = s4[EPI == SL_SILU_MUL ? 1 : 0];
+    const float u[4] = {u4.x, u4.y, u4.z, u4.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float gq = Elem<T>::to_f(Elem<T>::from_f(r[j])), uq = Elem<T>::to_f(Elem<T>::from_f(u[j]));

@@ -52,8 +52,8 @@ def main():
     cases = [
         (1, [5, 0, 17, 3, 9, 1, 30, 2][:world], 2, 64, 4 * world, torch.bfloat16),
         (2, [16] * world, 8, 7168, 8 * world, torch.bfloat16),            # DeepSeek-V3 row width, top-8
-        (3, [1] + [0] * (world - 1), 6, 2048, 2 * world, torch.float16),  # one token in the whole group
-        (4, [64, 7, 128, 1, 0, 50, 3, 96][:world], 4, 512, world, torch.bfloat16),   # one expert per rank
+        (3, [1] + [0] * (world - 1), 6, 2048, 8 * world, torch.float16),  # one token in the whole group
+        (4, [64, 7, 128, 1, 0, 50, 3, 96][:world], 2, 512, world, torch.bfloat16),   # one expert per rank
         (5, [0] * world, 2, 128, 2 * world, torch.bfloat16),              # nobody has a token
     ]
     launched = []
