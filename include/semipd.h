@@ -167,22 +167,6 @@ int semipd_decode_attention(void* out, const void* q, const void* k_buf, const v
                             int64_t kbuf_stride, int64_t vbuf_stride, int num_kv_splits,
                             float sm_scale, float logit_cap, int dtype, int kv_dtype, void* stream);
 
-/* semipd_rope_kv_store_planes + semipd_decode_attention in ONE launch (one launch fewer per decoder layer of a decode step):
- * q, k, v of the step are the fp32 K-slice planes [n_planes][batch][(Hq + 2 Hkv) * head_dim] of the qkv GEMM
- * (semipd_stream_linear_planes).  Every wave of the MFMA decode kernel sums the planes of its query heads in slice
- * order, rounds, rotates (neox pairing over the whole head, cos_sin_cache [positions][head_dim] fp32) and uses the result as
- * its Q fragments; the wave whose KV split holds the step's own token also rotates and stores that token's K / V row into
- * the pool (k_buf / v_buf row loc[b], which kv_indices already names) before it reads it.  Same bits as the two calls
- * (rotary_embedding.py:143-169 + memory_pool.py:316-346 + decode_attention.py:234-531).  GQA / MQA with 2 .. 16 query heads per
- * kv head, head_dim 64 / 96 / 128 (semipd_decode_attention_rope_planes_supported); bf16 / f16 activations, pool rows in the
- * activation type or fp8. */
-int semipd_decode_attention_rope_planes_supported(int num_q_heads, int num_kv_heads, int head_dim);
-int semipd_decode_attention_rope_planes(void* out, const float* planes, int n_planes, int64_t plane_elems, void* k_buf,
-                                        void* v_buf, const int64_t* loc, const float* cos_sin_cache, const int64_t* positions,
-                                        const int32_t* kv_indptr, const int32_t* kv_indices, float* attn_logits, int64_t batch,
-                                        int num_q_heads, int num_kv_heads, int head_dim, int64_t o_stride, int64_t kbuf_stride,
-                                        int64_t vbuf_stride, int num_kv_splits, float sm_scale, float logit_cap, int dtype,
-                                        int kv_dtype, void* stream);
 
 /* ------------------------------------------------------------------ */
 /* a6  batched prefill (extend) attention                              */

@@ -289,15 +289,4 @@ __device__ __forceinline__ void planes_sum8x2(const float* pa, const float* pb, 
   fb[0] = a[2].x; fb[1] = a[2].y; fb[2] = a[2].z; fb[3] = a[2].w; fb[4] = a[3].x; fb[5] = a[3].y; fb[6] = a[3].z; fb[7] = a[3].w;
 }
 
-// decode attention on a q / k / v row that is still the K-slice planes of the qkv GEMM (decode_attention_mfma.hip, ROPE form)
-struct DecodeRopePlanes {
-  const float* planes;        // [n_planes][tokens][(Hq + 2 Hk) * D]
-  int n_planes;
-  int64_t plane_elems;        // elements between planes
-  int64_t row_elems;          // (Hq + 2 Hk) * D
-  const float* cache;         // [positions][D]: cos over the first half, sin over the second
-  const int64_t* positions;
-  const int64_t* loc;         // pool row of the step's token, per request
-};
-
 }  // namespace semipd

@@ -309,6 +309,60 @@ decode_stage1_generic_kernel(T* __restrict__ out, const T* __restrict__ q,
 }
 
 // Stage 2 (decode_attention.py:476-531): merge split partials.
+// The merge of one (request, head): weights w_s = exp(lse_s - max lse), out = sum_s w_s o_s / sum_s w_s, sums in split order.
+// Up to 64 splits the log-sum-exps are fetched by one load per lane and the partial rows eight splits at a time, so the
+// kernel waits for two or three memory latencies instead of one per split.
+template <typename T>
+__device__ __forceinline__ void stage2_merge(T* __restrict__ out_row, const float* __restrict__ base, int n_valid, int Dv,
+                                             int first_d, int step_d) {
+  const int lane = threadIdx.x & 63;
+  float e_max = -INFINITY, e_sum = 0.f;
+  if (n_valid <= 64) {
+    const float mine = lane < n_valid ? base[(int64_t)lane * (Dv + 1) + Dv] : -INFINITY;
+    float mx = mine;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    e_max = mx;
+    const float w = lane < n_valid ? __expf(mine - e_max) : 0.f;
+    for (int s = 0; s < n_valid; ++s) e_sum += __shfl(w, s, 64);          // split order, like the loop it replaces
+    const float inv = e_sum > 0.f ? 1.f / e_sum : 0.f;
+    // (every lane runs every iteration: the shuffles below read the weights from lanes 0 .. n_valid - 1)
+    for (int d0 = 0; d0 < Dv; d0 += step_d) {
+      const bool ok = d0 + first_d < Dv;
+      const int d = ok ? d0 + first_d : 0;
+      float acc = 0.f;
+      int s = 0;
+      for (; s + 8 <= n_valid; s += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = base[(int64_t)(s + u) * (Dv + 1) + d];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += __shfl(w, s + u, 64) * v[u];
+      }
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (s + u < n_valid) v[u] = base[(int64_t)(s + u) * (Dv + 1) + d];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (s + u < n_valid) acc += __shfl(w, s + u, 64) * v[u];
+      if (ok) out_row[d] = Elem<T>::from_f(acc * inv);
+    }
+    return;
+  }
+  // more than 64 splits: two passes so that the loads of the second one are independent of each other
+  for (int s = 0; s < n_valid; ++s) e_max = fmaxf(e_max, base[(int64_t)s * (Dv + 1) + Dv]);
+  for (int s = 0; s < n_valid; ++s) e_sum += __expf(base[(int64_t)s * (Dv + 1) + Dv] - e_max);
+  const float inv = e_sum > 0.f ? 1.f / e_sum : 0.f;
+  for (int d = first_d; d < Dv; d += step_d) {
+    float acc = 0.f;
+#pragma unroll 4
+    for (int s = 0; s < n_valid; ++s)
+      acc += __expf(base[(int64_t)s * (Dv + 1) + Dv] - e_max) * base[(int64_t)s * (Dv + 1) + d];
+    out_row[d] = Elem<T>::from_f(acc * inv);
+  }
+}
+
 template <typename T>
 __global__ void decode_stage2_kernel(T* __restrict__ out, const float* __restrict__ attn_logits,
                                      const int32_t* __restrict__ kv_indptr, int num_q_heads, int Dv,
@@ -317,21 +371,9 @@ __global__ void decode_stage2_kernel(T* __restrict__ out, const float* __restric
   const int seq_len = kv_indptr[b + 1] - kv_indptr[b];
   const int per_split = (seq_len + num_kv_splits - 1) / num_kv_splits;
   const float* base = attn_logits + ((int64_t)b * num_q_heads + hq) * num_kv_splits * (Dv + 1);
-  // splits [0, n_valid) are non-empty.  Two passes so that the loads of the second one are independent
-  // of each other (the running-max form of the reference serialises every split behind an exp).
+  // splits [0, n_valid) are non-empty
   const int n_valid = per_split > 0 ? min(num_kv_splits, (seq_len + per_split - 1) / per_split) : 0;
-  float e_max = -INFINITY;
-  for (int s = 0; s < n_valid; ++s) e_max = fmaxf(e_max, base[(int64_t)s * (Dv + 1) + Dv]);
-  float e_sum = 0.f;
-  for (int s = 0; s < n_valid; ++s) e_sum += __expf(base[(int64_t)s * (Dv + 1) + Dv] - e_max);
-  const float inv = e_sum > 0.f ? 1.f / e_sum : 0.f;
-  for (int d = threadIdx.x; d < Dv; d += blockDim.x) {
-    float acc = 0.f;
-#pragma unroll 4
-    for (int s = 0; s < n_valid; ++s)
-      acc += __expf(base[(int64_t)s * (Dv + 1) + Dv] - e_max) * base[(int64_t)s * (Dv + 1) + d];
-    out[(int64_t)b * o_stride + (int64_t)hq * Dv + d] = Elem<T>::from_f(acc * inv);
-  }
+  stage2_merge<T>(out + (int64_t)b * o_stride + (int64_t)hq * Dv, base, n_valid, Dv, threadIdx.x, blockDim.x);
 }
 
 // The same merge with one WAVE per head and four heads per workgroup: 128 heads x 128 requests of MLA decode are 16 k
@@ -347,18 +389,7 @@ decode_stage2_wave_kernel(T* __restrict__ out, const float* __restrict__ attn_lo
   const int per_split = (seq_len + num_kv_splits - 1) / num_kv_splits;
   const float* base = attn_logits + ((int64_t)b * num_q_heads + hq) * num_kv_splits * (Dv + 1);
   const int n_valid = per_split > 0 ? min(num_kv_splits, (seq_len + per_split - 1) / per_split) : 0;
-  float e_max = -INFINITY;
-  for (int s = 0; s < n_valid; ++s) e_max = fmaxf(e_max, base[(int64_t)s * (Dv + 1) + Dv]);
-  float e_sum = 0.f;
-  for (int s = 0; s < n_valid; ++s) e_sum += __expf(base[(int64_t)s * (Dv + 1) + Dv] - e_max);
-  const float inv = e_sum > 0.f ? 1.f / e_sum : 0.f;
-  for (int d = lane; d < Dv; d += 64) {
-    float acc = 0.f;
-#pragma unroll 4
-    for (int s = 0; s < n_valid; ++s)
-      acc += __expf(base[(int64_t)s * (Dv + 1) + Dv] - e_max) * base[(int64_t)s * (Dv + 1) + d];
-    out[(int64_t)b * o_stride + (int64_t)hq * Dv + d] = Elem<T>::from_f(acc * inv);
-  }
+  stage2_merge<T>(out + (int64_t)b * o_stride + (int64_t)hq * Dv, base, n_valid, Dv, lane, 64);
 }
 
 template <typename T, int LPR, typename KV = T>
@@ -392,7 +423,7 @@ template <typename T, typename KV>
 int launch_decode_mfma(T* out, const T* q, const KV* k_buf, const KV* v_buf, const int32_t* kv_indptr,
                        const int32_t* kv_indices, float* attn_logits, int64_t batch, int Hq, int Hkv, int D,
                        int64_t q_stride, int64_t o_stride, int64_t kbuf_stride, int64_t vbuf_stride,
-                       int splits, float sm_scale, float logit_cap, hipStream_t st, const DecodeRopePlanes* rope = nullptr);
+                       int splits, float sm_scale, float logit_cap, hipStream_t st);
 
 // defined in mla_decode_attention.hip
 template <typename T, typename KV>
@@ -511,80 +542,9 @@ static int run_decode(void* out, const void* q, const void* k_buf, const void* v
   return rc;
 }
 
-// stage 2 of a split decode attention (shared by the two entry points)
-template <typename T>
-static int launch_stage2(void* out, float* attn_logits, const int32_t* kv_indptr, int64_t batch, int num_q_heads,
-                         int head_dim_v, int64_t o_stride, int num_kv_splits, hipStream_t st) {
-  dim3 grid((unsigned)batch, (unsigned)num_q_heads);
-  const int threads = head_dim_v <= 64 ? 64 : head_dim_v <= 128 ? 128 : 256;
-  hipLaunchKernelGGL((decode_stage2_kernel<T>), grid, dim3(threads), 0, st, (T*)out, attn_logits, kv_indptr, num_q_heads,
-                     head_dim_v, o_stride, num_kv_splits);
-  return launch_status("decode_stage2");
-}
-
-template <typename T>
-static int run_decode_rope(void* out, const DecodeRopePlanes& rp, void* k_buf, void* v_buf, const int32_t* kv_indptr,
-                           const int32_t* kv_indices, float* attn_logits, int64_t batch, int Hq, int Hkv, int D,
-                           int64_t o_stride, int64_t kbuf_stride, int64_t vbuf_stride, int splits, float sm_scale,
-                           float logit_cap, int dtype, int kv_dtype, hipStream_t st) {
-  int rc;
-  if (kv_dtype == dtype)
-    rc = launch_decode_mfma<T, T>((T*)out, (const T*)nullptr, (const T*)k_buf, (const T*)v_buf, kv_indptr, kv_indices,
-                                  attn_logits, batch, Hq, Hkv, D, 0, o_stride, kbuf_stride, vbuf_stride, splits, sm_scale,
-                                  logit_cap, st, &rp);
-  else if (kv_dtype == SEMIPD_F8E5M2)
-    rc = launch_decode_mfma<T, f8e5m2_t>((T*)out, (const T*)nullptr, (const f8e5m2_t*)k_buf, (const f8e5m2_t*)v_buf, kv_indptr,
-                                         kv_indices, attn_logits, batch, Hq, Hkv, D, 0, o_stride, kbuf_stride, vbuf_stride,
-                                         splits, sm_scale, logit_cap, st, &rp);
-  else if (kv_dtype == SEMIPD_F8E4M3)
-    rc = launch_decode_mfma<T, f8e4m3_t>((T*)out, (const T*)nullptr, (const f8e4m3_t*)k_buf, (const f8e4m3_t*)v_buf, kv_indptr,
-                                         kv_indices, attn_logits, batch, Hq, Hkv, D, 0, o_stride, kbuf_stride, vbuf_stride,
-                                         splits, sm_scale, logit_cap, st, &rp);
-  else {
-    set_error("decode_attention_rope_planes: unsupported kv_dtype %d", kv_dtype);
-    return SEMIPD_EDTYPE;
-  }
-  if (rc == 0 && splits > 1) rc = launch_stage2<T>(out, attn_logits, kv_indptr, batch, Hq, D, o_stride, splits, st);
-  return rc;
-}
-
 }  // namespace semipd
 
 using namespace semipd;
-
-extern "C" int semipd_decode_attention_rope_planes_supported(int num_q_heads, int num_kv_heads, int head_dim) {
-  if (num_q_heads <= 0 || num_kv_heads <= 0 || num_q_heads % num_kv_heads) return 0;
-  const int group = num_q_heads / num_kv_heads;
-  return group >= 2 && group <= 16 && (head_dim == 64 || head_dim == 96 || head_dim == 128);
-}
-
-extern "C" int semipd_decode_attention_rope_planes(void* out, const float* planes, int n_planes, int64_t plane_elems,
-                                                   void* k_buf, void* v_buf, const int64_t* loc, const float* cos_sin_cache,
-                                                   const int64_t* positions, const int32_t* kv_indptr,
-                                                   const int32_t* kv_indices, float* attn_logits, int64_t batch,
-                                                   int num_q_heads, int num_kv_heads, int head_dim, int64_t o_stride,
-                                                   int64_t kbuf_stride, int64_t vbuf_stride, int num_kv_splits, float sm_scale,
-                                                   float logit_cap, int dtype, int kv_dtype, void* stream) {
-  SEMIPD_CHECK_ARG(batch >= 0 && n_planes >= 1 && num_kv_splits > 0 && num_kv_splits <= 65535 && batch < 65536 * 16,
-                   SEMIPD_EINVAL, "decode_attention_rope_planes: bad sizes");
-  SEMIPD_CHECK_ARG(semipd_decode_attention_rope_planes_supported(num_q_heads, num_kv_heads, head_dim), SEMIPD_ESHAPE,
-                   "decode_attention_rope_planes: %d query heads per kv head of %d (2 .. 16 heads of 64 / 96 / 128 supported)",
-                   num_kv_heads ? num_q_heads / num_kv_heads : 0, head_dim);
-  if (batch == 0) return 0;
-  SEMIPD_CHECK_ARG(out && planes && k_buf && v_buf && loc && cos_sin_cache && positions && kv_indptr && kv_indices, SEMIPD_EINVAL,
-                   "decode_attention_rope_planes: null pointer");
-  SEMIPD_CHECK_ARG(num_kv_splits == 1 || attn_logits, SEMIPD_EINVAL,
-                   "decode_attention_rope_planes: attn_logits scratch required when num_kv_splits > 1");
-  SEMIPD_CHECK_ARG(dtype == SEMIPD_BF16 || dtype == SEMIPD_F16, SEMIPD_EDTYPE, "decode_attention_rope_planes: bf16 / f16 activations");
-  const int64_t row_elems = (int64_t)(num_q_heads + 2 * num_kv_heads) * head_dim;
-  SEMIPD_CHECK_ARG(plane_elems % 4 == 0 && plane_elems >= batch * row_elems && aligned16(planes) && aligned16(k_buf) &&
-                   aligned16(v_buf) && kbuf_stride % 16 == 0 && vbuf_stride % 16 == 0 && o_stride % 4 == 0 &&
-                   (reinterpret_cast<uintptr_t>(out) & 7u) == 0, SEMIPD_EALIGN,
-                   "decode_attention_rope_planes: 16-byte aligned planes / pool rows required");
-  DecodeRopePlanes rp{planes, n_planes, plane_elems, row_elems, cos_sin_cache, positions, loc};
-  SEMIPD_DISPATCH_HALF(dtype, T, return run_decode_rope<T>(out, rp, k_buf, v_buf, kv_indptr, kv_indices, attn_logits, batch, num_q_heads, num_kv_heads, head_dim, o_stride, kbuf_stride, vbuf_stride, num_kv_splits, sm_scale, logit_cap, dtype, kv_dtype, as_stream(stream)));
-  return 0;
-}
 
 extern "C" int semipd_decode_attention(void* out, const void* q, const void* k_buf, const void* v_buf,
                                        const int32_t* kv_indptr, const int32_t* kv_indices,

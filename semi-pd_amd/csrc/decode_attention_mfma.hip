@@ -49,21 +49,14 @@ template <int D, typename Raw> struct KRegs {
   Raw k[2][D / 32];
 };
 
-// ROPE form (one launch fewer per decoder layer): q, k, v of the step are still the fp32 K-slice planes of the qkv GEMM
-// (csrc/stream_linear.hip).  Every wave sums the planes of ITS 16 query heads, rounds to T, rotates (neox pairing over the
-// whole head) and keeps the result as its Q^T fragments -- the bits semipd_rope_kv_store_planes would have written to q.
-// The wave whose split holds the step's own token also sums, rotates and stores that token's K / V row of its kv head
-// into the pool (row loc[b]) before it walks its tokens, so the row it then reads through kv_indices is the row it wrote;
-// no other wave reads that row (other splits end before it; a kv head with more than one 16-head tile is not fused).
-
-template <typename T, int D, typename KV, bool ROPE = false>
+template <typename T, int D, typename KV>
 __global__ void __launch_bounds__(256, D <= 128 ? 2 : 1)   // D = 256 needs > 256 registers: one workgroup per SIMD set instead of 672 B of scratch
-decode_mfma_kernel(T* __restrict__ out, const T* __restrict__ q, KV* __restrict__ k_buf,
-                   KV* __restrict__ v_buf, const int32_t* __restrict__ kv_indptr,
+decode_mfma_kernel(T* __restrict__ out, const T* __restrict__ q, const KV* __restrict__ k_buf,
+                   const KV* __restrict__ v_buf, const int32_t* __restrict__ kv_indptr,
                    const int32_t* __restrict__ kv_indices, float* __restrict__ attn_logits,
                    int num_q_heads, int num_kv_heads, int group, int tiles_per_kv, int64_t q_stride,
                    int64_t o_stride, int64_t kbuf_stride, int64_t vbuf_stride, int num_kv_splits,
-                   int64_t total_items, float sm_scale, float logit_cap, DecodeRopePlanes rp = DecodeRopePlanes()) {
+                   int64_t total_items, float sm_scale, float logit_cap) {
   constexpr int KS = D / 32, DT = D / 16, CPR = D / 8, NV = CPR / 2;
   using KVT = KVTraits<T, KV>;
   using Raw = typename KVT::Raw;
@@ -102,68 +95,12 @@ decode_mfma_kernel(T* __restrict__ out, const T* __restrict__ q, KV* __restrict_
 
   // Q^T fragments (B operand): lane = head c16, d = ks*32 + q4*8 .. +8
   FragD qf[KS];
-  if constexpr (!ROPE) {
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      qf[ks].u = make_uint4(0, 0, 0, 0);
-      if (head_ok)
-        qf[ks].u = *reinterpret_cast<const uint4*>(q + (int64_t)b * q_stride + (int64_t)(hq0 + c16) * D +
-                                                   ks * 32 + q4 * 8);
-    }
-  } else {
-    constexpr int half = D / 2;
-    const float* prow = rp.planes + (int64_t)b * rp.row_elems;
-    const float* cs = rp.cache + rp.positions[b] * D;
-    auto sum8 = [&](int64_t col, float (&f)[8]) {     // slice order, like splitk_planes_reduce / rope_planes_kernel
-      planes_sum8(prow + col, rp.n_planes, rp.plane_elems, f);
-    };
-    // rotated pair of 8-vectors of one head: first half (i0 .. i0 + 7) and second half (half + i0 ..)
-    auto rotate = [&](int64_t head_col, int i0, uint16_t (&oa)[8], uint16_t (&ob)[8]) {
-      float fa[8], fb[8];
-      planes_sum8x2(prow + head_col + i0, prow + head_col + half + i0, rp.n_planes, rp.plane_elems, fa, fb);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float c = cs[i0 + j], sn = cs[half + i0 + j];
-        const float x1 = Elem<T>::to_f(Elem<T>::from_f(fa[j])), x2 = Elem<T>::to_f(Elem<T>::from_f(fb[j]));
-        oa[j] = Elem<T>::from_f(x1 * c - x2 * sn).v;
-        ob[j] = Elem<T>::from_f(x2 * c + x1 * sn).v;
-      }
-    };
-    // ---- the step's own K / V row, by the wave whose split holds the last token ----
-    if (tile == 0 && s_end == seq_len) {
-      const int64_t dst = rp.loc[b];
-      const int64_t k_col = (int64_t)(num_q_heads + hk) * D, v_col = (int64_t)(num_q_heads + num_kv_heads + hk) * D;
-      if (lane < half / 8) {
-        uint16_t oa[8], ob[8];
-        rotate(k_col, lane * 8, oa, ob);
-        Vec16<T> va, vb;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) va.e[j].v = oa[j], vb.e[j].v = ob[j];
-        KV* kh = k_buf + dst * kbuf_stride + (int64_t)hk * D;
-        KVT::store8(kh + lane * 8, va);
-        KVT::store8(kh + half + lane * 8, vb);
-      } else if (lane >= 32 && lane < 32 + D / 8) {
-        float f[8];
-        sum8(v_col + (int64_t)(lane - 32) * 8, f);
-        Vec16<T> a;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) a.e[j] = Elem<T>::from_f(f[j]);
-        KVT::store8(v_buf + dst * vbuf_stride + (int64_t)hk * D + (lane - 32) * 8, a);
-      }
-      __threadfence();   // the row is read back below, by this wave, through kv_indices
-    }
-    // ---- this lane's Q^T fragments ----
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      qf[ks].u = make_uint4(0, 0, 0, 0);
-      if (head_ok) {
-        const int d0 = ks * 32 + q4 * 8;
-        uint16_t oa[8], ob[8];
-        rotate((int64_t)(hq0 + c16) * D, d0 < half ? d0 : d0 - half, oa, ob);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) qf[ks].e[j] = d0 < half ? oa[j] : ob[j];
-      }
-    }
+  for (int ks = 0; ks < KS; ++ks) {
+    qf[ks].u = make_uint4(0, 0, 0, 0);
+    if (head_ok)
+      qf[ks].u = *reinterpret_cast<const uint4*>(q + (int64_t)b * q_stride + (int64_t)(hq0 + c16) * D +
+                                                 ks * 32 + q4 * 8);
   }
 
   f32x4 o_acc[DT];
@@ -323,34 +260,14 @@ decode_mfma_kernel(T* __restrict__ out, const T* __restrict__ q, KV* __restrict_
 }
 
 template <typename T, typename KV>
-int launch_decode_mfma(T* out, const T* q, const KV* k_buf_c, const KV* v_buf_c, const int32_t* kv_indptr,
+int launch_decode_mfma(T* out, const T* q, const KV* k_buf, const KV* v_buf, const int32_t* kv_indptr,
                        const int32_t* kv_indices, float* attn_logits, int64_t batch, int Hq, int Hkv, int D,
                        int64_t q_stride, int64_t o_stride, int64_t kbuf_stride, int64_t vbuf_stride,
-                       int splits, float sm_scale, float logit_cap, hipStream_t st, const DecodeRopePlanes* rope) {
+                       int splits, float sm_scale, float logit_cap, hipStream_t st) {
   const int group = Hq / Hkv;
   const int tiles = (group + 15) / 16;
   const int64_t total = batch * Hkv * tiles * splits;
   dim3 grid((unsigned)((total + 3) / 4)), block(256);
-  KV* k_buf = const_cast<KV*>(k_buf_c);   // (written only by the ROPE form: the step's own row)
-  KV* v_buf = const_cast<KV*>(v_buf_c);
-  if (rope) {
-    if (tiles != 1) {
-      set_error("decode_mfma (rope planes): %d query heads per kv head need more than one 16-head tile", group);
-      return SEMIPD_ESHAPE;
-    }
-#define DMR(DD)                                                                                                      \
-  hipLaunchKernelGGL((decode_mfma_kernel<T, DD, KV, true>), grid, block, 0, st, out, q, k_buf, v_buf, kv_indptr,        \
-                     kv_indices, attn_logits, Hq, Hkv, group, tiles, q_stride, o_stride, kbuf_stride, vbuf_stride,      \
-                     splits, total, sm_scale, logit_cap, *rope)
-    switch (D) {
-      case 64: DMR(64); break;
-      case 96: DMR(96); break;
-      case 128: DMR(128); break;
-      default: set_error("decode_mfma (rope planes): head dim %d not instantiated", D); return SEMIPD_ESHAPE;
-    }
-#undef DMR
-    return launch_status("decode_mfma_rope");
-  }
 #define DM(DD)                                                                                      \
   hipLaunchKernelGGL((decode_mfma_kernel<T, DD, KV>), grid, block, 0, st, out, q, k_buf, v_buf, kv_indptr, \
                      kv_indices, attn_logits, Hq, Hkv, group, tiles, q_stride, o_stride, kbuf_stride,  \
@@ -369,7 +286,7 @@ int launch_decode_mfma(T* out, const T* q, const KV* k_buf_c, const KV* v_buf_c,
 #define DM_INST(T, KV)                                                                                  \
   template int launch_decode_mfma<T, KV>(T*, const T*, const KV*, const KV*, const int32_t*, const int32_t*, \
                                          float*, int64_t, int, int, int, int64_t, int64_t, int64_t, int64_t,   \
-                                         int, float, float, hipStream_t, const DecodeRopePlanes*);
+                                         int, float, float, hipStream_t);
 DM_INST(bf16_t, bf16_t)
 DM_INST(f16_t, f16_t)
 DM_INST(bf16_t, f8e5m2_t)

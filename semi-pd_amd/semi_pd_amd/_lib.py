@@ -48,9 +48,6 @@ _SIGNATURES = {
     "semipd_compute_positions": [_vp, _vp, _vp, _vp, _i64, _vp],
     "semipd_decode_attention": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i64,
                                 _i64, _i64, _i64, _i32, _f32, _f32, _i32, _i32, _vp],
-    "semipd_decode_attention_rope_planes_supported": [_i32, _i32, _i32],
-    "semipd_decode_attention_rope_planes": [_vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32,
-                                            _i64, _i64, _i64, _i32, _f32, _f32, _i32, _i32, _vp],
     "semipd_extend_attention": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32,
                                 _i64, _i64, _i64, _i64, _i64, _i64, _i32, _f32, _f32, _i32, _i32, _vp],
     "semipd_gather_rows": [_vp, _vp, _vp, _i64, _i64, _i64, _vp],

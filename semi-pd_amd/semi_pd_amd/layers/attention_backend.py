@@ -23,9 +23,6 @@ from semi_pd_amd.model_executor.forward_batch_info import ForwardBatch, ForwardM
 class AttentionBackend:
     """The ABC of the reference (base_attn_backend.py:14-108), kept verbatim in shape."""
 
-    def forward_decode_rope_planes(self, qkv_planes, positions, rotary_emb, layer, forward_batch):
-        return None   # (not part of the reference's ABC: a backend without the fused form runs the separate calls)
-
     def init_forward_metadata(self, forward_batch: ForwardBatch):
         raise NotImplementedError()
 
@@ -241,30 +238,6 @@ class HipAttnBackend(AttentionBackend):
             forward_batch.token_to_kv_pool.get_value_buffer(layer.layer_id),
             o.view(B, layer.tp_q_head_num, layer.v_head_dim),
             md.kv_indptr, md.kv_indices, md.attn_logits, md.num_kv_splits, layer.scaling, layer.logit_cap)
-        if kt:
-            kt.stop("decode_attention", t0, *self._algo, n_kernels=2 if md.num_kv_splits > 1 else 1)
-        return o
-
-
-    def forward_decode_rope_planes(self, qkv_planes, positions, rotary_emb, layer, forward_batch: ForwardBatch):
-        """Decode step of a Llama-shaped layer whose qkv row is still the K-slice planes of the streaming GEMM: RoPE, the
-        KV-pool store and the attention in one launch (+ stage 2).  None when the shape is not covered (the caller then runs
-        rope_and_store_kv_planes followed by forward_decode)."""
-        if not ops.decode_attention_rope_planes_supported(layer.tp_q_head_num, layer.tp_k_head_num, layer.qk_head_dim) \
-                or layer.v_head_dim != layer.qk_head_dim or os.environ.get("SEMIPD_FUSE_ROPE_DECODE", "1") == "0":
-            return None
-        md = self.forward_metadata
-        B = qkv_planes.rows
-        pool = forward_batch.token_to_kv_pool
-        o = torch.empty((B, layer.tp_q_head_num * layer.v_head_dim), dtype=qkv_planes.dtype, device=qkv_planes.planes.device)
-        kt = self._timing()
-        t0 = kt.start() if kt else None
-        ops.decode_attention_rope_planes(positions if positions.dtype == torch.int64 else positions.long(), qkv_planes,
-                                         layer.tp_q_head_num, layer.tp_k_head_num, layer.qk_head_dim, rotary_emb.cos_sin_cache,
-                                         pool.get_key_buffer(layer.layer_id), pool.get_value_buffer(layer.layer_id),
-                                         forward_batch.out_cache_loc, o.view(B, layer.tp_q_head_num, layer.v_head_dim),
-                                         md.kv_indptr, md.kv_indices, md.attn_logits, md.num_kv_splits, layer.scaling,
-                                         layer.logit_cap)
         if kt:
             kt.stop("decode_attention", t0, *self._algo, n_kernels=2 if md.num_kv_splits > 1 else 1)
         return o

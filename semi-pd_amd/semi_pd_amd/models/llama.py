@@ -83,11 +83,6 @@ class LlamaAttention(nn.Module):
             # decode: the qkv GEMM stops before its K-slice reduction and the RoPE + KV-store kernel sums the planes
             planes = self.qkv_proj.forward_planes(hidden_states)
             if planes is not None:
-                # RoPE, the KV-pool store and the attention in one launch where the kernel covers the head geometry
-                attn_output = forward_batch.attn_backend.forward_decode_rope_planes(planes, positions, self.rotary_emb,
-                                                                                    self.attn, forward_batch)
-                if attn_output is not None:
-                    return self.o_proj(attn_output, defer_reduce=True)
                 q = self.rotary_emb.forward_and_store_planes(positions, planes, self.num_heads, self.num_kv_heads,
                                                              pool.get_key_buffer(self.attn.layer_id),
                                                              pool.get_value_buffer(self.attn.layer_id),

@@ -254,39 +254,6 @@ def decode_attention_fwd(q: torch.Tensor, k_buffer: torch.Tensor, v_buffer: torc
           "decode_attention")
 
 
-def decode_attention_rope_planes_supported(num_q_heads: int, num_kv_heads: int, head_dim: int) -> bool:
-    return bool(_lib.load().semipd_decode_attention_rope_planes_supported(int(num_q_heads), int(num_kv_heads), int(head_dim)))
-
-
-def decode_attention_rope_planes(positions: torch.Tensor, qkv: "SplitKPlanes", num_q_heads: int, num_kv_heads: int,
-                                 head_size: int, cos_sin_cache: torch.Tensor, k_buffer: torch.Tensor, v_buffer: torch.Tensor,
-                                 loc: torch.Tensor, o: torch.Tensor, kv_indptr: torch.Tensor, kv_indices: torch.Tensor,
-                                 attn_logits: Optional[torch.Tensor], num_kv_splits: int, sm_scale: float,
-                                 logit_cap: float = 0.0) -> None:
-    """rope_and_store_kv_planes + decode_attention_fwd in one launch (semipd_decode_attention_rope_planes): the rotated q never
-    leaves the registers of the attention kernel, the step's K / V row is written by the wave that reads it.  o [B, Hq, D]."""
-    if cos_sin_cache.dtype != torch.float32 or cos_sin_cache.shape[1] != head_size:
-        raise RuntimeError("decode_attention_rope_planes: fp32 cos / sin cache over the whole head expected")
-    if qkv.n != (num_q_heads + 2 * num_kv_heads) * head_size:
-        raise RuntimeError("decode_attention_rope_planes: planes do not hold a [q | k | v] row")
-    if positions.dtype != torch.int64 or loc.dtype != torch.int64 or loc.numel() != qkv.rows or not loc.is_contiguous():
-        raise RuntimeError("decode_attention_rope_planes: int64 positions and one contiguous int64 pool row per token expected")
-    for name, buf in (("k_buffer", k_buffer), ("v_buffer", v_buffer)):
-        if buf.dim() != 3 or buf.shape[1:] != (num_kv_heads, head_size) or buf.stride(2) != 1 or buf.stride(1) != head_size:
-            raise RuntimeError(f"decode_attention_rope_planes: {name} must be [slots, kv heads, head] with dense rows")
-    B = qkv.rows
-    if o.shape != (B, num_q_heads, head_size) or o.stride(2) != 1 or o.stride(1) != head_size:
-        raise RuntimeError("decode_attention_rope_planes: o must be [B, Hq, head] with densely packed heads")
-    if attn_logits is not None:
-        assert num_kv_splits == attn_logits.shape[2] and B <= attn_logits.shape[0] and attn_logits.is_contiguous()
-    qkv.check_live("decode_attention_rope_planes")
-    check(_lib.load().semipd_decode_attention_rope_planes(
-        ptr(o), ptr(qkv.planes), qkv.ksplit, qkv.rows * qkv.n, ptr(k_buffer), ptr(v_buffer), ptr(loc), ptr(cos_sin_cache),
-        ptr(positions), ptr(kv_indptr), ptr(kv_indices), ptr(attn_logits), B, num_q_heads, num_kv_heads, head_size, o.stride(0),
-        k_buffer.stride(0), v_buffer.stride(0), int(num_kv_splits), float(sm_scale), float(logit_cap), dtype_code(qkv.dtype),
-        _lib.kv_dtype_code(k_buffer.dtype), current_stream(o.device)), "decode_attention_rope_planes")
-
-
 def extend_attention_fwd(q_extend: torch.Tensor, k_extend: torch.Tensor, v_extend: torch.Tensor,
                          o_extend: torch.Tensor, k_buffer: Optional[torch.Tensor],
                          v_buffer: Optional[torch.Tensor], qo_indptr: torch.Tensor,

@@ -16,6 +16,10 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # The CPU oracle runs on torch's intra-op pool.  On a GPU box with hundreds of hardware threads the default (one thread
+    # per hardware thread) collapses -- bench.py measured 3.2 s for ONE layer's decode step with 256 threads -- and the oracle
+    # side of the engine tests was most of the GPU suite's 20 minutes.  At most 32 threads, like bench.py's cpu_baseline.
+    torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
 
 
 def pytest_collection_modifyitems(config, items):

@@ -777,13 +777,18 @@ def test_moe_grouped_gemm_prefill_sized_rows(ops, device, T, topk, E, N, K, dtyp
     c = torch.full((numel, N), float("nan"), dtype=dtype, device=device)
     ops.moe_grouped_gemm(a.to(device), w.to(device), c, tw.flatten().contiguous() if routed else None, sorted_ids,
                          expert_ids, npp, numel, div, routed, 128)
-    flat_e = tid.flatten().cpu().long()
-    rows = torch.arange(numel) // div
-    want = torch.einsum("rk,rnk->rn", a.float()[rows], w.float()[flat_e])
+    # fp32 product per expert (on the device: gathering one weight matrix per routed row on the host was 70 GB of copies)
+    flat_e = tid.flatten().long()
+    rows = torch.arange(numel, device=device) // div
+    a32, w32 = a.to(device).float(), w.to(device).float()
+    want = torch.zeros(numel, N, device=device)
+    for e in flat_e.unique().tolist():
+        sel = (flat_e == e).nonzero().flatten()
+        want[sel] = a32[rows[sel]] @ w32[e].t()
     if routed:
-        want = want * tw.flatten().cpu().float()[:, None]
+        want = want * tw.flatten().float()[:, None]
     tol = 2e-2 if dtype == torch.bfloat16 else 4e-3
-    torch.testing.assert_close(c.float().cpu(), want, rtol=tol, atol=tol * float(want.abs().max()))
+    torch.testing.assert_close(c.float(), want, rtol=tol, atol=tol * float(want.abs().max()))
 
 
 @pytest.mark.parametrize("T,topk,E,Nh,K", [(512, 6, 64, 1408, 2048), (700, 4, 8, 352, 192), (2100, 1, 3, 96, 64)])
@@ -1018,50 +1023,6 @@ def test_rope_and_store_kv_from_the_qkv_planes(ops, device, M, dtype, kv_dtype):
     q2 = ops.rope_and_store_kv_planes(pos, planes, Hq, Hk, D, cache, kb2, vb2, loc)
     assert torch.equal(q2.view(torch.int16), q1.contiguous().view(torch.int16))
     assert torch.equal(kb2.view(torch.uint8), kb1.view(torch.uint8)) and torch.equal(vb2.view(torch.uint8), vb1.view(torch.uint8))
-
-
-@pytest.mark.parametrize("B,Hq,Hk,D,splits", [(1, 32, 8, 128, 1), (7, 32, 8, 128, 4), (33, 32, 8, 128, 8), (32, 8, 1, 128, 6),
-                                              (5, 16, 1, 64, 3), (9, 12, 4, 96, 2), (3, 4, 2, 128, 16)])
-@pytest.mark.parametrize("dtype,kv_dtype", [(torch.bfloat16, None), (torch.float16, None), (torch.bfloat16, torch.float8_e4m3fn)])
-def test_decode_attention_on_the_qkv_planes_has_the_bits_of_the_two_launches(ops, device, B, Hq, Hk, D, splits, dtype, kv_dtype):
-    """One launch (semipd_decode_attention_rope_planes: plane sum + RoPE + KV-pool store inside the MFMA decode kernel) against
-    the two it replaces (rope_and_store_kv_planes, then decode_attention_fwd): the attention output and the pool rows are the
-    same bits -- ragged contexts, a request whose context is only the step's own token, more splits than tokens, GQA groups
-    4 / 8 / 16 / 3 / 2, MQA, fp8 pool rows."""
-    torch.manual_seed(B * 131 + Hq)
-    K = 1024
-    x = torch.randn(B, K, device=device).to(dtype)
-    w = (torch.randn((Hq + 2 * Hk) * D, K, device=device) * 0.05).to(dtype)
-    inv = 1.0 / (10000 ** (torch.arange(0, D, 2, dtype=torch.float) / D))
-    fr = torch.einsum("i,j -> ij", torch.arange(4096, dtype=torch.float), inv)
-    cache = torch.cat((fr.cos(), fr.sin()), dim=-1).to(device)
-    pool_dtype = kv_dtype or dtype
-    lens = [1] + [int(v) for v in torch.randint(2, 300, (B - 1,))]          # request 0: only the step's own token
-    N = sum(lens) + 8
-    perm = torch.randperm(N - 1, device=device) + 1
-    kv_indices = perm[: sum(lens)].to(torch.int32)
-    kv_indptr = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device=device)
-    loc = torch.stack([kv_indices[int(kv_indptr[b + 1]) - 1] for b in range(B)]).to(torch.int64)   # the step's row = last of the context
-    pos = torch.tensor([n - 1 for n in lens], dtype=torch.int64, device=device)
-    base_k = (torch.randn(N, Hk, D, device=device)).to(pool_dtype)
-    base_v = (torch.randn(N, Hk, D, device=device)).to(pool_dtype)
-    planes = ops.stream_linear_planes(x, w)
-    logits = torch.empty((B, Hq, splits, D + 1), dtype=torch.float32, device=device) if splits > 1 else None
-    # the two launches
-    kb1, vb1 = base_k.clone(), base_v.clone()
-    q = ops.rope_and_store_kv_planes(pos, planes, Hq, Hk, D, cache, kb1, vb1, loc)
-    o1 = torch.empty((B, Hq, D), dtype=dtype, device=device)
-    ops.decode_attention_fwd(q.view(B, Hq, D), kb1, vb1, o1, kv_indptr, kv_indices, logits, splits, D ** -0.5)
-    # the one
-    kb2, vb2 = base_k.clone(), base_v.clone()
-    o2 = torch.empty((B, Hq, D), dtype=dtype, device=device)
-    assert ops.decode_attention_rope_planes_supported(Hq, Hk, D)
-    ops.decode_attention_rope_planes(pos, planes, Hq, Hk, D, cache, kb2, vb2, loc, o2, kv_indptr, kv_indices, logits, splits,
-                                     D ** -0.5)
-    torch.cuda.synchronize()
-    assert torch.equal(kb2.view(torch.uint8), kb1.view(torch.uint8)) and torch.equal(vb2.view(torch.uint8), vb1.view(torch.uint8))
-    assert torch.equal(o2.view(torch.int16), o1.view(torch.int16))
-    assert not ops.decode_attention_rope_planes_supported(32, 1, 128) and not ops.decode_attention_rope_planes_supported(8, 8, 128)
 
 
 # --------------------------------------------------------------------------- prefill-sized dense layers on a CU share

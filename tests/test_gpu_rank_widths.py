@@ -83,7 +83,7 @@ def test_deepseek_v3_tp8_rank_width_block_fp8_unified_and_semi_pd_match_the_orac
         rope_scaling={"type": "yarn", "factor": 40, "beta_fast": 32, "beta_slow": 1, "mscale": 1.0,
                       "mscale_all_dim": 1.0, "original_max_position_embeddings": 4096},
         architectures=("DeepseekV3ForCausalLM",), quantization_config=qc)
-    lens = [512, 100, 7]      # (the CPU oracle runs 256 experts per MoE layer)
+    lens = [192, 40, 7]       # (the CPU oracle loops over the routed rows of 256 experts per MoE layer)
     prompts = make_prompts(cfg.vocab_size, lens, seed=17)
     uni, sd = _generate(_args(cfg), prompts, want_sd=True)
     oracle = OracleDeepseekV2(cfg, sd, act_dtype=torch.bfloat16, absorb_fp8=True)
@@ -99,7 +99,7 @@ def test_deepseek_v3_tp8_rank_width_block_fp8_unified_and_semi_pd_match_the_orac
 def test_llama3_70b_width_tp2_on_one_gpu_matches_the_unsharded_oracle(device):
     from semi_pd_amd.models.llama import LLAMA3_70B
     cfg = dataclasses.replace(LLAMA3_70B, num_hidden_layers=2, vocab_size=32064, max_position_embeddings=2048)
-    prompts = make_prompts(cfg.vocab_size, LENS, seed=19)
+    prompts = make_prompts(cfg.vocab_size, [600, 100, 7], seed=19)
     # the unsharded weights come from a TP = 1 engine of the same seed (shards are slices of ONE full-size draw)
     uni, sd = _generate(_args(cfg), prompts, want_sd=True)
     oracle = OracleLlama(cfg, sd)
