@@ -105,6 +105,23 @@ int semipd_rope_kv_store(void* q, void* k, const void* v, void* k_buf, void* v_b
                          int64_t v_stride, int64_t kbuf_stride, int64_t vbuf_stride, int interleave,
                          int dtype, int kv_dtype, void* stream);
 
+/* MLA decode step (DeepseekV2AttentionMLA.forward_absorb): everything between the merged [q_proj | kv_a_proj_with_mqa] GEMM
+ * and the attention kernel in one launch.  planes [n_planes][num_tokens][Hq * (nope + rope) + lora + rope] fp32 are the
+ * K-slice planes of that GEMM (semipd_stream_linear_planes on the concatenated weight); each value is summed in slice order
+ * and rounded to dtype (the GEMM's own reduction), then: q_nope -> q_nope_out [num_tokens, Hq, nope] (dense); q_pe rotated
+ * (GPT-J pairs, cos_sin_cache [max_pos, rope] fp32) -> q_input[t, h, lora : lora + rope] (strides in elements); the latent
+ * normalised (RMSNorm * norm_weight, eps) and k_pe rotated -> kv_buf row loc[t] (lora + rope columns, kv_dtype = dtype or
+ * an fp8 pool type).  Same bits as the separate reduction, semipd_rmsnorm, semipd_rope_strided, the q_pe copy and
+ * semipd_kv_store_cvt.
+ * replaces kv_a_layernorm + rotary_emb + q_input[..., lora:] = q_pe + set_kv_buffer of forward_absorb
+ *   (models/deepseek_v2.py:633-706, the ROCm-only fused form at :708; layers/layernorm.py:47-76;
+ *    layers/rotary_embedding.py:143-169; mem_cache/memory_pool.py:439-452). */
+int semipd_mla_decode_prep(void* q_nope_out, void* q_input, void* kv_buf, const float* planes, int n_planes,
+                           int64_t plane_elems, const int64_t* loc, const float* cos_sin_cache, const int64_t* positions,
+                           const void* norm_weight, float eps, int64_t num_tokens, int num_q_heads, int nope_dim, int rope_dim,
+                           int lora_rank, int64_t q_input_token_stride, int64_t q_input_head_stride, int64_t kvbuf_stride,
+                           int dtype, int kv_dtype, void* stream);
+
 /* semipd_rope_kv_store for a decode batch whose qkv row is still the K-slice planes of semipd_stream_linear_planes:
  * planes [n_planes][num_tokens][(Hq + 2 Hk) * head] fp32 (plane stride plane_elems) are summed in slice order and
  * rounded to dtype -- the bits the GEMM's own reduction writes -- then q is rotated into q_out [num_tokens, q_stride],
@@ -597,6 +614,12 @@ int semipd_cu_mask_fill(int num_cus, int percent, int from_top, uint32_t* mask, 
 /* hipExtStreamCreateWithCUMask wrapper; *stream receives a hipStream_t. */
 int semipd_stream_create_cu_mask(int device, const uint32_t* mask, int words, void** stream);
 int semipd_stream_destroy(void* stream);
+/* A non-blocking stream with a HIP priority (hipStreamCreateWithPriority): -1 high, 0 normal, 1 low, clamped to the
+ * range of the device; *range receives {least, greatest} when not NULL.  The second isolation knob next to the CU shares:
+ * a prefill instance on a LOW-priority queue yields workgroup slots to the decode instance's kernels as they free up,
+ * whatever CUs the two share.  Stands where the reference relies on the MPS daemon's time slicing between the two
+ * processes (entrypoints/engine.py:588-593, 632-634). */
+int semipd_stream_create_with_priority(int device, int priority, void** stream, int* range);
 /* Read back the mask of a stream (hipExtStreamGetCUMask). */
 int semipd_stream_get_cu_mask(void* stream, uint32_t* mask, int words);
 

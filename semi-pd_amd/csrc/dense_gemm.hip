@@ -77,6 +77,10 @@ struct State {
   hipblasLtHandle_t handle = nullptr;
   void* workspace = nullptr;
   size_t workspace_bytes = 0;
+  // the library's split-K / stream-K solutions keep partial sums in the workspace while they RUN (the mutex below only
+  // covers the launch): every stream that serves GEMMs gets its own (an instance has two or three: its share, the whole
+  // chip, a communication stream), allocated the first time the stream is seen
+  std::map<hipStream_t, void*> stream_workspace;
   // (share, dtype, n, k) -> rows -> winner.  share = the CU count the calling process declared for the stream it is on
   // (semipd_dense_gemm_set_cus): an instance that moves between a masked stream and the whole chip keeps one table per
   // CU count, and a count nothing was tuned for gets the library's own choice
@@ -94,6 +98,25 @@ State& st() {
 }
 
 hipDataType hip_type(int dtype) { return dtype == SEMIPD_BF16 ? HIP_R_16BF : HIP_R_16F; }
+
+// (called with the mutex held) nullptr + error text when a further workspace cannot be allocated
+void* workspace_of(State& s, hipStream_t stream) {
+  if (s.stream_workspace.empty()) {
+    s.stream_workspace[stream] = s.workspace;   // the first stream takes the one semipd_dense_gemm_init allocated
+    return s.workspace;
+  }
+  auto it = s.stream_workspace.find(stream);
+  if (it != s.stream_workspace.end()) return it->second;
+  void* w = nullptr;
+  if (s.stream_workspace.size() >= 16 || hipMalloc(&w, s.workspace_bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    set_error("dense_gemm: cannot allocate a %zu-byte library workspace for stream %p (%zu streams have one)",
+              s.workspace_bytes, (void*)stream, s.stream_workspace.size());
+    return nullptr;
+  }
+  s.stream_workspace[stream] = w;
+  return w;
+}
 
 int ensure_init(State& s, size_t workspace_bytes) {
   if (s.handle) return 0;
@@ -220,7 +243,9 @@ int semipd_dense_gemm_init(size_t workspace_bytes) {
  * process owns and remember the winner per row count.  Candidates at every row count: the library's first
  * `num_heuristics` heuristic results (its ranking assumes the whole device; on a masked share the winner is typically
  * far down that list: profiles/r03_blaslt_probe_under_masks.txt) and, for the first `num_full_search` row counts, EVERY
- * solution the library supports for the problem (~2000 for bf16, ~20 s per row count: off by default) whose best
+ * solution the library supports for the problem (~2000 for bf16; 0 here turns it off, ModelRunner.tune_dense_gemms asks
+ * for the first two row counts: 11-28 s of a masked prefill instance's start-up, once per (arch, CUs, library, shapes) --
+ * the table is cached next to the model, semipd_dense_gemm_import) whose best
  * few then join the candidates of the remaining row counts.  Operands are scratch buffers allocated and freed here
  * (start-up only); the calling thread's current device is used. */
 int semipd_dense_gemm_tune(int64_t n, int64_t k, const int64_t* rows, int num_rows, int num_full_search, int dtype,
@@ -417,7 +442,9 @@ int semipd_dense_gemm(void* out, const void* x, const void* weight, const void* 
     Plan p;
     if (make_problem(p, dtype, rows, n, k, ldx, ldo, bias != nullptr)) return 1;
     auto tk = s.tuned.find(std::make_tuple(s.share, dtype, n, k));
-    if (tk != s.tuned.end() && !tk->second.empty()) {
+    // a measured winner was checked against the library's own choice in ONE layout (dense rows, no bias): only calls in
+    // that layout are routed to it, everything else keeps the library's choice
+    if (tk != s.tuned.end() && !tk->second.empty() && ldx == k && ldo == n && !bias) {
       const Tuned* bestt = nullptr;
       double bestd = 1e30;
       for (auto& kv : tk->second) {
@@ -446,8 +473,10 @@ int semipd_dense_gemm(void* out, const void* x, const void* weight, const void* 
   Plan& p = it->second;
   if (bias) hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias));
   float alpha = 1.f, beta = 0.f;
+  void* const ws = workspace_of(s, (hipStream_t)stream);
+  if (!ws) return 1;
   const hipblasStatus_t rc = hipblasLtMatmul(s.handle, p.desc, &alpha, weight, p.la, x, p.lb, &beta, out, p.lc, out, p.lc,
-                                             &p.algo, s.workspace, s.workspace_bytes, (hipStream_t)stream);
+                                             &p.algo, ws, s.workspace_bytes, (hipStream_t)stream);
   if (rc != HIPBLAS_STATUS_SUCCESS) {
     set_error("dense_gemm: hipblasLtMatmul failed with status %d (solution %d)", (int)rc, p.solution_index);
     return 1;

@@ -382,6 +382,96 @@ __global__ void rope_planes_kernel(T* __restrict__ q_out, const float* __restric
   }
 }
 
+// MLA decode step, everything between the merged [q | kv_a] GEMM and the attention in ONE launch (one workgroup per token).
+// The GEMM output is still the fp32 K-slice planes [n_planes][tokens][Hq * (nope + rope) + lora + rope]; every value is
+// first summed in slice order and rounded to T -- the bits the GEMM's own reduction writes -- then
+//   q_nope [t, h, 0:nope]                 -> q_nope_out (dense, the operand of the W_kc absorption)
+//   q_pe   [t, h, nope:nope+rope]         -> RoPE (GPT-J pairs) -> q_input[t, h, lora : lora + rope]
+//   latent [t, 0:lora]                    -> RMSNorm * kv_a_layernorm -> pool row loc[t], columns 0 : lora
+//   k_pe   [t, lora:lora+rope]            -> RoPE -> pool row loc[t], columns lora : lora + rope
+// i.e. the two reductions, ops.rmsnorm, apply_rope_strided_inplace, the q_pe copy into q_input and set_kv_buffer of
+// DeepseekV2AttentionMLA.forward_absorb (models/deepseek_v2.py:633-706 in the reference): six launches.  The norm is the
+// one-wave form of rmsnorm_vec_kernel (lora = 512: lane v owns vector v), the rotation is rope_item's: same bits.
+template <typename T, typename KV = T>
+__global__ void __launch_bounds__(256)
+mla_decode_prep_kernel(T* __restrict__ q_nope_out, T* __restrict__ q_input, KV* __restrict__ kv_buf,
+                       const float* __restrict__ planes, int n_planes, int64_t plane_elems, int64_t row_elems,
+                       const int64_t* __restrict__ loc, const float* __restrict__ cache, const int64_t* __restrict__ positions,
+                       const T* __restrict__ norm_w, float eps, int Hq, int nope, int rope, int lora, int64_t q_input_ts,
+                       int64_t q_input_hs, int64_t kvbuf_stride) {
+  constexpr int V = Elem<T>::kVec;
+  static_assert(V == 8, "16-bit activations");
+  const int64_t t = blockIdx.x;
+  const float* row = planes + t * row_elems;
+  const int qk = nope + rope;
+  const int64_t kv_col0 = (int64_t)Hq * qk;
+  KV* pool_row = kv_buf + loc[t] * kvbuf_stride;
+  const float* cs = cache + positions[t] * rope;
+  const int half = rope >> 1;
+  auto sum8_T = [&](int64_t col) __attribute__((always_inline)) {
+    float f[8];
+    planes_sum8(row + col, n_planes, plane_elems, f);
+    Vec16<T> a;
+#pragma unroll
+    for (int j = 0; j < V; ++j) a.e[j] = Elem<T>::from_f(f[j]);
+    return a;
+  };
+  // the rotation of rope_item<T, true> on a vector already in registers (element base e0 inside the rotary slice)
+  auto rotate = [&](const Vec16<T>& a, int e0) __attribute__((always_inline)) {
+    Vec16<T> o;
+#pragma unroll
+    for (int j = 0; j < V / 2; ++j) {
+      const int p = (e0 >> 1) + j;
+      const float c = cs[p], s = cs[half + p];
+      const float x1 = Elem<T>::to_f(a.e[2 * j]), x2 = Elem<T>::to_f(a.e[2 * j + 1]);
+      o.e[2 * j] = Elem<T>::from_f(x1 * c - x2 * s);
+      o.e[2 * j + 1] = Elem<T>::from_f(x2 * c + x1 * s);
+    }
+    return o;
+  };
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (wave == 0) {
+    // latent: lane v owns vector v (lora / 8 <= 64 vectors), the one-wave rmsnorm_vec_kernel<T, 1, false>
+    const int nvec = lora / V;
+    float x[V];
+    float ss = 0.f;
+    if (lane < nvec) {
+      const Vec16<T> a = sum8_T(kv_col0 + (int64_t)lane * V);
+#pragma unroll
+      for (int j = 0; j < V; ++j) x[j] = Elem<T>::to_f(a.e[j]);
+#pragma unroll
+      for (int j = 0; j < V; ++j) ss += x[j] * x[j];
+    }
+    ss = wave_sum(ss);
+    const float rs = rsqrtf(ss / (float)lora + eps);
+    if (lane < nvec) {
+      const Vec16<T> ww = load16(norm_w + (int64_t)lane * V);
+      Vec16<T> o;
+#pragma unroll
+      for (int j = 0; j < V; ++j) o.e[j] = Elem<T>::from_f(x[j] * rs * Elem<T>::to_f(ww.e[j]));
+      KVTraits<T, KV>::store8(pool_row + (int64_t)lane * V, o);
+    }
+    // k_pe: rope / 8 vectors
+    if (lane < rope / V) {
+      const Vec16<T> a = sum8_T(kv_col0 + lora + (int64_t)lane * V);
+      KVTraits<T, KV>::store8(pool_row + lora + (int64_t)lane * V, rotate(a, lane * V));
+    }
+    return;
+  }
+  // waves 1 .. 3: the q heads -- nope / 8 plain vectors and rope / 8 rotated vectors per head
+  const int per_head = qk / V, nope_v = nope / V;
+  for (int it = threadIdx.x - 64; it < Hq * per_head; it += blockDim.x - 64) {
+    const int h = it / per_head, i = it - h * per_head;
+    const Vec16<T> a = sum8_T((int64_t)h * qk + (int64_t)i * V);
+    if (i < nope_v) {
+      store16(q_nope_out + (t * Hq + h) * (int64_t)nope + (int64_t)i * V, a);
+    } else {
+      const int e0 = (i - nope_v) * V;
+      store16(q_input + t * q_input_ts + h * q_input_hs + lora + e0, rotate(a, e0));
+    }
+  }
+}
+
 // scalar fallback: any rot_dim (even), any alignment
 template <typename T, bool STORE, typename KV = T>
 __global__ void rope_scalar_kernel(T* __restrict__ q, T* __restrict__ k, const T* __restrict__ v,
@@ -958,6 +1048,42 @@ int semipd_rope_kv_store_planes(void* q_out, const float* planes, int n_planes, 
   });
 #undef RPK
   return launch_status("rope_kv_store_planes");
+}
+
+int semipd_mla_decode_prep(void* q_nope_out, void* q_input, void* kv_buf, const float* planes, int n_planes,
+                           int64_t plane_elems, const int64_t* loc, const float* cos_sin_cache, const int64_t* positions,
+                           const void* norm_weight, float eps, int64_t num_tokens, int num_q_heads, int nope_dim, int rope_dim,
+                           int lora_rank, int64_t q_input_token_stride, int64_t q_input_head_stride, int64_t kvbuf_stride,
+                           int dtype, int kv_dtype, void* stream) {
+  SEMIPD_CHECK_ARG(num_tokens >= 0 && n_planes >= 1 && n_planes <= 64 && num_q_heads > 0 && nope_dim > 0 && rope_dim > 0 &&
+                   lora_rank > 0, SEMIPD_EINVAL, "mla_decode_prep: bad sizes");
+  if (num_tokens == 0) return 0;
+  SEMIPD_CHECK_ARG(q_nope_out && q_input && kv_buf && planes && loc && cos_sin_cache && positions && norm_weight, SEMIPD_EINVAL,
+                   "mla_decode_prep: null pointer");
+  SEMIPD_CHECK_ARG(dtype == SEMIPD_BF16 || dtype == SEMIPD_F16, SEMIPD_EDTYPE, "mla_decode_prep: bf16 / f16 activations");
+  const int64_t row_elems = (int64_t)num_q_heads * (nope_dim + rope_dim) + lora_rank + rope_dim;
+  SEMIPD_CHECK_ARG(nope_dim % 8 == 0 && rope_dim % 16 == 0 && lora_rank % 8 == 0 && lora_rank <= 512 && rope_dim <= 512 &&
+                   q_input_token_stride % 8 == 0 && q_input_head_stride % 8 == 0 && kvbuf_stride % 16 == 0 &&
+                   plane_elems % 4 == 0 && plane_elems >= num_tokens * row_elems && aligned16(q_nope_out) && aligned16(q_input) &&
+                   aligned16(kv_buf) && aligned16(planes) && aligned16(norm_weight),
+                   SEMIPD_EALIGN, "mla_decode_prep: nope %% 8, rope %% 16, lora %% 8 (<= 512), 16-byte aligned rows required");
+  hipStream_t st = as_stream(stream);
+  dim3 grid((unsigned)num_tokens), block(256);
+#define MDP(TT, KVT)                                                                                                     \
+  hipLaunchKernelGGL((mla_decode_prep_kernel<TT, KVT>), grid, block, 0, st, (TT*)q_nope_out, (TT*)q_input, (KVT*)kv_buf,  \
+                     planes, n_planes, plane_elems, row_elems, loc, cos_sin_cache, positions, (const TT*)norm_weight, eps, \
+                     num_q_heads, nope_dim, rope_dim, lora_rank, q_input_token_stride, q_input_head_stride, kvbuf_stride)
+  SEMIPD_DISPATCH_HALF(dtype, T, {
+    if (kv_dtype == dtype) MDP(T, T);
+    else if (kv_dtype == SEMIPD_F8E5M2) MDP(T, f8e5m2_t);
+    else if (kv_dtype == SEMIPD_F8E4M3) MDP(T, f8e4m3_t);
+    else {
+      set_error("mla_decode_prep: unsupported kv_dtype %d", kv_dtype);
+      return SEMIPD_EDTYPE;
+    }
+  });
+#undef MDP
+  return launch_status("mla_decode_prep");
 }
 
 int semipd_kv_store_cvt(void* buf, const void* src, const int64_t* loc, int64_t num_tokens, int64_t row_elems,

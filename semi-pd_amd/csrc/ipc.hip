@@ -226,6 +226,29 @@ int semipd_stream_create_cu_mask(int device, const uint32_t* mask, int words, vo
   return 0;
 }
 
+int semipd_stream_create_with_priority(int device, int priority, void** stream, int* range) {
+  SEMIPD_CHECK_ARG(stream, SEMIPD_EINVAL, "stream_create_with_priority: null pointer");
+  int prev = -1;
+  SEMIPD_HIP(hipGetDevice(&prev));
+  if (device >= 0 && device != prev) SEMIPD_HIP(hipSetDevice(device));
+  int least = 0, greatest = 0;   // numerically: least >= greatest
+  hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+  hipStream_t s = nullptr;
+  if (e == hipSuccess) {
+    if (range) range[0] = least, range[1] = greatest;
+    const int p = priority > least ? least : (priority < greatest ? greatest : priority);
+    e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, p);
+  }
+  if (device >= 0 && device != prev) (void)hipSetDevice(prev);
+  if (e != hipSuccess) {
+    set_error("hipStreamCreateWithPriority(%d) failed: %s", priority, hipGetErrorString(e));
+    (void)hipGetLastError();
+    return (int)e;
+  }
+  *stream = (void*)s;
+  return 0;
+}
+
 int semipd_stream_destroy(void* stream) {
   SEMIPD_CHECK_ARG(stream, SEMIPD_EINVAL, "stream_destroy: null stream");
   SEMIPD_HIP(hipStreamDestroy(as_stream(stream)));

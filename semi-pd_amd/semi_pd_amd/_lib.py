@@ -107,6 +107,9 @@ _SIGNATURES = {
     "semipd_device_cu_count": [_i32, _vp],
     "semipd_cu_mask_fill": [_i32, _i32, _i32, _vp, _i32],
     "semipd_stream_create_cu_mask": [_i32, _vp, _i32, _vp],
+    "semipd_stream_create_with_priority": [_i32, _i32, _vp, _vp],
+    "semipd_mla_decode_prep": [_vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _f32, _i64, _i32, _i32, _i32, _i32, _i64,
+                               _i64, _i64, _i32, _i32, _vp],
     "semipd_stream_destroy": [_vp],
     "semipd_stream_get_cu_mask": [_vp, _vp, _i32],
     "semipd_share_board_open": [C.c_char_p, _i32, _vp],

@@ -85,11 +85,12 @@ def run_scheduler_process(server_args: ServerArgs, port_args: SemiPDPortArgs, gp
     parent = os.getppid()
     try:
         import torch
-        if os.environ.get("SEMIPD_TEST_PLUGIN"):
+        if server_args.test_plugin:
             # tests reach into the scheduler processes through a plugin file executed at start-up (fault injection
-            # lives in tests/, not in the serving code)
+            # lives in tests/, not in the serving code); an explicit ServerArgs field the tests set -- no command-line
+            # flag, no environment variable: nothing in a production launch can name a file to run
             import runpy
-            runpy.run_path(os.environ["SEMIPD_TEST_PLUGIN"], run_name="semipd_test_plugin")
+            runpy.run_path(server_args.test_plugin, run_name="semipd_test_plugin")
         from semi_pd_amd.managers.semi_pd_decode_scheduler import SemiPDDecodeScheduler
         from semi_pd_amd.managers.semi_pd_prefill_scheduler import SemiPDPrefillScheduler
         rank0 = tp_rank == 0
@@ -105,8 +106,16 @@ def run_scheduler_process(server_args: ServerArgs, port_args: SemiPDPortArgs, gp
         if prio:
             # the whole instance (weights, graphs, every launch) lives on one prioritised stream: the hardware
             # scheduler serves the queue of a high-priority stream first when both instances have work ready
+            # (created through the C-ABI: torch clamps positive -- LOW -- priorities to 0)
+            import ctypes
+            from semi_pd_amd import _lib
             torch.cuda.set_device(gpu_id)
-            torch.cuda.set_stream(torch.cuda.Stream(device=torch.device("cuda", gpu_id), priority=int(prio)))
+            raw, rng = ctypes.c_void_p(), (ctypes.c_int * 2)()
+            _lib.check(_lib.load().semipd_stream_create_with_priority(gpu_id, int(prio), ctypes.addressof(raw),
+                                                                      ctypes.addressof(rng)), "stream_create_with_priority")
+            logging.getLogger(__name__).warning("%s instance on a stream of priority %d (device range %d .. %d)", role.name,
+                                                int(prio), rng[0], rng[1])
+            torch.cuda.set_stream(torch.cuda.ExternalStream(raw.value, device=torch.device("cuda", gpu_id)))
         if role == InstanceRole.DECODE:
             mr = _build_runner(server_args, gpu_id, tp_rank, role, port_args.d_nccl_port,
                                max_total_tokens=server_args.max_total_tokens,

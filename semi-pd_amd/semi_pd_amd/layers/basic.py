@@ -201,6 +201,10 @@ def get_rope(head_size: int, rotary_dim: int, max_position: int, base: float, is
 _STREAM_LINEAR = {"enabled": False, "timing": None}
 
 
+def stream_linear_enabled() -> bool:
+    return bool(_STREAM_LINEAR["enabled"])
+
+
 def set_stream_linear(enabled: bool):
     """Called once per process by the model runner."""
     _STREAM_LINEAR["enabled"] = bool(enabled)

@@ -101,6 +101,8 @@ def fused_experts(hidden_states: torch.Tensor, w1: torch.Tensor, w2: torch.Tenso
     topk_ids = _local_ids(topk_ids, expert_offset)
     T, K = hidden_states.shape
     E, N2, _ = w1.shape
+    if T == 0:   # an empty batch (an idle DP / EP rank): nothing to route, and no block size to divide by
+        return out_addend if out_addend is not None else hidden_states.new_zeros((0, K))
     topk = topk_ids.shape[1]
     dev, dt = hidden_states.device, hidden_states.dtype
     numel = T * topk

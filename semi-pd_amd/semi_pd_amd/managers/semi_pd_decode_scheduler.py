@@ -303,6 +303,7 @@ class SemiPDDecodeScheduler(SchedulerBase):
         reqs, out_cache_loc, host_ids, ev, logits_output = pending
         if ev is not None:
             self._wait_servicing(ev)           # step k and its copy are done; step k + 1 keeps the GPU busy
+            ttft_trace.mark("d_step_done", [str(len(reqs))])
         ids = host_ids.tolist()
         logprobs = self.extract_logprobs(logits_output)
         alloc = self.token_to_kv_pool_allocator

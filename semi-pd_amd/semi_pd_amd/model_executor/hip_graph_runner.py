@@ -24,7 +24,7 @@ def get_batch_sizes_to_capture(max_bs: int) -> List[int]:
 _PARKED: list = []   # see _capture_one
 
 # fault injection for tests: a callable (bs, outputs) run inside the capture.  Installed only by a test plugin that the
-# scheduler process loads at start-up (entrypoints/engine.py: SEMIPD_TEST_PLUGIN); never set in production.
+# scheduler process loads at start-up (entrypoints/engine.py: ServerArgs.test_plugin); never set in production.
 capture_fault_hook = None
 
 

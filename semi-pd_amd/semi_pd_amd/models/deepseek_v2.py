@@ -24,7 +24,7 @@ from torch import nn
 from semi_pd_amd import ops
 from semi_pd_amd.distributed import (get_tensor_model_parallel_world_size, tensor_model_parallel_all_reduce)
 from semi_pd_amd.layers.attention_backend import RadixAttention
-from semi_pd_amd.layers.basic import (ColumnParallelLinear, LogitsProcessor, MergedColumnParallelLinear,
+from semi_pd_amd.layers.basic import (stream_linear_enabled, ColumnParallelLinear, LogitsProcessor, MergedColumnParallelLinear,
                                       ParallelLMHead, ReplicatedLinear, RMSNorm, RowParallelLinear, SiluAndMul,
                                       VocabParallelEmbedding, gate_up_silu, get_rope, yarn_get_mscale)
 from semi_pd_amd.layers.fp8 import (FP8_DTYPE, Fp8Config, block_dequantize_weight, block_quant_to_tensor_quant,
@@ -211,10 +211,21 @@ class DeepseekV2AttentionMLA(nn.Module):
         self.register_buffer("w_vc", torch.empty(0, dtype=wdt), persistent=False)
         if self.absorb_fp8:
             self.register_buffer("w_scale", torch.empty(1, dtype=torch.float32), persistent=False)
+        # decode batches of an unquantised model without q_lora: q_proj and kv_a_proj_with_mqa read the same row, so they
+        # run as ONE weight-streaming GEMM on the concatenated weight (post_load_weights) whose K-slice planes go straight
+        # into ops.mla_decode_prep; a buffer like W_kc / W_vc so that both instances see it through IPC
+        self.merged_qkv_a = (qc is None and self.q_lora_rank is None and self.kv_lora_rank <= 512 and
+                             self.kv_lora_rank % 8 == 0 and self.qk_nope_head_dim % 8 == 0 and
+                             self.qk_rope_head_dim % 16 == 0 and os.environ.get("SEMIPD_MLA_MERGED_QKV_A", "1") != "0")
+        if self.merged_qkv_a:
+            self.register_buffer("w_qkv_a", torch.empty(0, dtype=dtype), persistent=False)
 
     def post_load_weights(self):
         """deepseek_v2.py:1228-1249: W_kc [H,128,512] and W_vc [H,512,128] out of kv_b_proj."""
         w = self.kv_b_proj.weight
+        if self.merged_qkv_a:
+            # rows: this rank's q heads, then the (replicated) latent + k_pe rows
+            self.w_qkv_a = torch.cat([self.q_proj.weight.data, self.kv_a_proj_with_mqa.weight.data], 0).contiguous()
         if self.absorb_fp8:
             # deepseek_v2.py:1195-1209: the block-quantised kv_b_proj re-quantised per tensor; W_kc / W_vc stay fp8 and
             # go through the fp8 matrix cores (ops.bmm_fp8).  Stored column-major for the product they are used in:
@@ -279,7 +290,37 @@ class DeepseekV2AttentionMLA(nn.Module):
                                     forward_batch, save_kv_cache=False)
         return self.o_proj(attn_output)
 
+    def _decode_prep_fused(self, positions, hidden_states, forward_batch):
+        """Decode batch: ONE GEMM for q and the latent, then ONE launch for everything up to the attention
+        (ops.mla_decode_prep): returns (q_nope [T, H, nope], q_input with its rope columns filled), or None when this
+        call is not eligible."""
+        if not (self.merged_qkv_a and forward_batch.forward_mode.is_decode() and self.w_qkv_a.numel()
+                and hidden_states.dim() == 2 and hidden_states.shape[0] <= ops.STREAM_LINEAR_MAX_ROWS
+                and stream_linear_enabled() and ops.stream_linear_is_supported(hidden_states, self.w_qkv_a)
+                and self.w_qkv_a.shape[0] % 8 == 0):
+            return None
+        T = hidden_states.shape[0]
+        planes = ops.stream_linear_planes(hidden_states, self.w_qkv_a)
+        q_input = torch.empty((T, self.num_local_heads, self.kv_lora_rank + self.qk_rope_head_dim),
+                              dtype=hidden_states.dtype, device=hidden_states.device)
+        pool = forward_batch.token_to_kv_pool
+        q_nope = ops.mla_decode_prep(planes, positions, self.rotary_emb.cos_sin_cache, self.kv_a_layernorm.weight.data,
+                                     self.kv_a_layernorm.variance_epsilon, self.num_local_heads, self.qk_nope_head_dim,
+                                     self.qk_rope_head_dim, self.kv_lora_rank, pool.get_key_buffer(self.layer_id),
+                                     forward_batch.out_cache_loc, q_input)
+        return q_nope, q_input
+
     def forward_absorb(self, positions, hidden_states, forward_batch, x_quant=None):
+        fused = self._decode_prep_fused(positions, hidden_states, forward_batch) if x_quant is None else None
+        if fused is not None:
+            q_nope, q_input = fused
+            T = q_nope.shape[0]
+            torch.bmm(q_nope.transpose(0, 1), self.w_kc, out=q_input[..., : self.kv_lora_rank].transpose(0, 1))
+            attn_output = self.attn_mqa(q_input.view(T, -1), None, None, forward_batch, save_kv_cache=False)
+            attn_output = attn_output.view(T, self.num_local_heads, self.kv_lora_rank)
+            out = torch.empty((T, self.num_local_heads, self.v_head_dim), dtype=q_nope.dtype, device=q_nope.device)
+            torch.bmm(attn_output.transpose(0, 1), self.w_vc, out=out.transpose(0, 1))
+            return self.o_proj(out.view(T, -1), defer_reduce=True)
         xq = x_quant if x_quant is not None else self._x_quant(hidden_states)
         q = self._q(hidden_states, xq)
         T = q.shape[0]

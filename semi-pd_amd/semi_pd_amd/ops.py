@@ -581,6 +581,35 @@ def rope_and_store_kv_planes(positions: torch.Tensor, qkv: SplitKPlanes, num_q_h
     return q
 
 
+def mla_decode_prep(qkv_a: SplitKPlanes, positions: torch.Tensor, cos_sin_cache: torch.Tensor, norm_weight: torch.Tensor,
+                    eps: float, num_heads: int, nope_dim: int, rope_dim: int, lora_rank: int, kv_buffer: torch.Tensor,
+                    loc: torch.Tensor, q_input: torch.Tensor) -> torch.Tensor:
+    """MLA decode step between the merged [q | kv_a] GEMM (still K-slice planes) and the attention: returns q_nope
+    [tokens, heads, nope]; the rotated q_pe goes to q_input[..., lora:], the normalised latent + rotated k_pe to the pool
+    rows `loc` (semipd_mla_decode_prep).  One launch for two reductions, RMSNorm, RoPE, the q_pe copy and the KV store."""
+    if qkv_a.n != num_heads * (nope_dim + rope_dim) + lora_rank + rope_dim:
+        raise RuntimeError("mla_decode_prep: planes do not hold a [q | latent | k_pe] row")
+    if cos_sin_cache.dtype != torch.float32 or cos_sin_cache.shape[1] != rope_dim or not cos_sin_cache.is_contiguous():
+        raise RuntimeError("mla_decode_prep: contiguous fp32 cos / sin cache [max_pos, rope] expected")
+    if positions.dtype != torch.int64:
+        positions = positions.long()
+    if loc.dtype != torch.int64 or loc.numel() != qkv_a.rows or not loc.is_contiguous():
+        raise RuntimeError("mla_decode_prep: one contiguous int64 pool row per token expected")
+    if q_input.shape != (qkv_a.rows, num_heads, lora_rank + rope_dim) or q_input.stride(2) != 1 or q_input.dtype != qkv_a.dtype:
+        raise RuntimeError("mla_decode_prep: q_input must be [tokens, heads, lora + rope] of the GEMM's dtype")
+    if kv_buffer.dim() != 3 or kv_buffer.shape[1:] != (1, lora_rank + rope_dim) or kv_buffer.stride(2) != 1:
+        raise RuntimeError("mla_decode_prep: kv_buffer must be [slots, 1, lora + rope] with dense rows")
+    qkv_a.check_live("mla_decode_prep")
+    q_nope = torch.empty((qkv_a.rows, num_heads, nope_dim), dtype=qkv_a.dtype, device=qkv_a.planes.device)
+    check(_lib.load().semipd_mla_decode_prep(ptr(q_nope), ptr(q_input), ptr(kv_buffer), ptr(qkv_a.planes), qkv_a.ksplit,
+                                             qkv_a.rows * qkv_a.n, ptr(loc), ptr(cos_sin_cache), ptr(positions),
+                                             ptr(norm_weight), float(eps), qkv_a.rows, num_heads, nope_dim, rope_dim, lora_rank,
+                                             q_input.stride(0), q_input.stride(1), kv_buffer.stride(0),
+                                             dtype_code(qkv_a.dtype), _lib.kv_dtype_code(kv_buffer.dtype), current_stream(q_input.device)),
+          "mla_decode_prep")
+    return q_nope
+
+
 def fused_add_rmsnorm_planes(p: SplitKPlanes, residual: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
     """residual += T(sum of the planes); returns RMSNorm(residual) * weight -- fused_add_rmsnorm on the GEMM output
     that was never written (layers/layernorm.py:47-76)."""

@@ -64,6 +64,7 @@ class ServerArgs:
     # dynamic mode: from this many waiting prompt tokens on a prefill batch takes every CU even while the decode
     # instance is busy (an overloaded GPU: throughput first).  0 = never
     prefill_backlog_full_tokens: int = 0
+    test_plugin: Optional[str] = None        # tests only: a file every scheduler process executes at start-up (fault injection)
     prefill_stream_priority: int = 0         # HIP stream priority of the instance's compute stream: 0 normal, -1 high
     decode_stream_priority: int = 0
     # prefill-sized dense layers: time the library's GEMM solutions on the instance's own CU share at start-up and use

@@ -1,4 +1,4 @@
-"""Test plugin (SEMIPD_TEST_PLUGIN): makes the capture of the small decode graphs fail inside every scheduler process
+"""Test plugin (ServerArgs.test_plugin): makes the capture of the small decode graphs fail inside every scheduler process
 that loads it -- a synchronising call invalidates a stream capture, like a collective that refuses to be captured."""
 from semi_pd_amd.model_executor import hip_graph_runner
 

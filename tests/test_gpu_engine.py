@@ -376,9 +376,9 @@ def test_tp2_falls_back_to_eager_decode_when_a_capture_fails(unified_llama, monk
     from semi_pd_amd.managers.io_struct import SamplingParams
     cfg, sd, prompts, outs, _ = unified_llama
     oracle = OracleLlama(cfg, sd)
-    monkeypatch.setenv("SEMIPD_TEST_PLUGIN", os.path.join(os.path.dirname(os.path.abspath(__file__)),
-                                                          "plugin_fail_capture.py"))
-    eng = Engine(server_args(cfg, tp_size=2, enable_semi_pd=True, dist_backend="gloo"), gpu_ids={0: 0, 1: 0})
+    plugin = os.path.join(os.path.dirname(os.path.abspath(__file__)), "plugin_fail_capture.py")
+    eng = Engine(server_args(cfg, tp_size=2, enable_semi_pd=True, dist_backend="gloo", test_plugin=plugin),
+                 gpu_ids={0: 0, 1: 0})
     try:
         semi = eng.generate(prompts, SamplingParams(max_new_tokens=8, ignore_eos=True), timeout=600)
         assert all(len(o) == 8 for o in semi)

@@ -1,0 +1,53 @@
+"""MLA decode step: the merged [q_proj | kv_a_proj_with_mqa] GEMM's planes through ONE launch (ops.mla_decode_prep) against the
+launches it replaces -- the GEMM's reduction, kv_a_layernorm, the strided RoPE, the q_pe copy and set_kv_buffer of
+DeepseekV2AttentionMLA.forward_absorb (models/deepseek_v2.py:633-706 in the reference).  Bit for bit."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from semi_pd_amd import ops as _ops
+    return _ops
+
+
+@pytest.mark.parametrize("T", [1, 7, 32, 64])
+@pytest.mark.parametrize("H,hidden", [(16, 2048), (128, 1024)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("kv_dtype", [None, torch.float8_e4m3fn])
+def test_mla_decode_prep_has_the_bits_of_the_launches_it_replaces(ops, T, H, hidden, dtype, kv_dtype):
+    dev = torch.device("cuda:0")
+    nope, rope, lora = 128, 64, 512
+    g = torch.Generator().manual_seed(T * 131 + H)
+    x = torch.randn(T, hidden, generator=g).to(dtype).to(dev)
+    w = (torch.randn(H * (nope + rope) + lora + rope, hidden, generator=g) * 0.05).to(dtype).to(dev)
+    nw = (torch.rand(lora, generator=g) + 0.5).to(dtype).to(dev)
+    positions = torch.randint(0, 4000, (T,), generator=g).to(dev)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, rope, 2, dtype=torch.float32) / rope))
+    fr = torch.arange(4096, dtype=torch.float32)[:, None] * inv[None, :]
+    cache = torch.cat([fr.cos(), fr.sin()], -1).contiguous().to(dev)
+    slots = 300
+    loc = torch.randperm(slots, generator=g)[:T].to(torch.int64).to(dev)
+    pool_dtype = kv_dtype or dtype
+    pool_a = torch.zeros((slots, 1, lora + rope), dtype=dtype, device=dev).to(pool_dtype)
+    pool_b = pool_a.clone()
+    # the launches it replaces, on the same GEMM
+    y = ops.stream_linear(x, w)
+    q = y[:, : H * (nope + rope)].view(T, H, nope + rope)
+    latent = y[:, H * (nope + rope):].contiguous()
+    ops.rmsnorm(latent[:, :lora], nw, 1e-6, out=latent[:, :lora])
+    latent = latent.unsqueeze(1)
+    ops.apply_rope_strided_inplace(positions, q[..., nope:], latent[..., lora:], cache, False)
+    q_input_ref = torch.zeros((T, H, lora + rope), dtype=dtype, device=dev)
+    q_input_ref[..., lora:] = q[..., nope:]
+    ops.store_kv_rows(pool_a, loc, latent)
+    # one launch
+    planes = ops.stream_linear_planes(x, w)
+    q_input = torch.zeros((T, H, lora + rope), dtype=dtype, device=dev)
+    q_nope = ops.mla_decode_prep(planes, positions, cache, nw, 1e-6, H, nope, rope, lora, pool_b, loc, q_input)
+    assert torch.equal(q_nope, q[..., :nope].contiguous())
+    assert torch.equal(q_input, q_input_ref)
+    assert torch.equal(pool_a.view(torch.uint8), pool_b.view(torch.uint8))
+    assert pool_b.float().abs().sum() > 0
