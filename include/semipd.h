@@ -343,6 +343,16 @@ int semipd_fused_add_rmsnorm_planes(void* out, void* residual, const void* weigh
                                     int64_t plane_elems, int64_t num_tokens, int64_t hidden, float eps, int dtype,
                                     void* stream);
 
+/* out[b, m, n] = dtype(sum_k X[b, m, k] * W[b, n, k]) for the MLA weight absorption of an UNQUANTISED model's decode batches:
+ * X [batch, M, K] and W [batch, N, K] with K contiguous (16-byte fragments straight into v_mfma_f32_16x16x32_{bf16,f16}),
+ * out through (batch, row) strides so that it lands in its consumer's layout (q_input[T, H, 576], the o_proj input).
+ * k % 32 == 0, 16-byte aligned rows, bf16 / f16.
+ * replaces torch.bmm(q_nope.transpose(0, 1), self.w_kc) and torch.bmm(attn_output.transpose(0, 1), self.w_vc)
+ *   (models/deepseek_v2.py:655-667, 690-700). */
+int semipd_bmm_nk(void* out, const void* x, const void* w, int64_t batch, int64_t m, int64_t n, int64_t k,
+                  int64_t x_batch_stride, int64_t x_row_stride, int64_t w_batch_stride, int64_t w_col_stride,
+                  int64_t out_batch_stride, int64_t out_row_stride, int dtype, void* stream);
+
 /* Per-tensor fp8 for the MLA weight absorption of a block-fp8 DeepSeek model.
  * semipd_input_to_float8: q = fp8(clamp(x * scale)), scale = T(fp8_max / amax(|x|)) over the WHOLE tensor,
  *   *scale_inv = 1 / scale; x is [batch, m, k] through (batch, row) strides (a transposed view is fine), q is

@@ -76,6 +76,78 @@ bmm_fp8_kernel(OutT* __restrict__ out, const uint8_t* __restrict__ x, const uint
   }
 }
 
+// ---- the same product for an UNQUANTISED model's decode batches (bf16 / f16 operands, v_mfma_f32_16x16x32_{bf16,f16}) ----
+// torch.bmm(q_nope^T, W_kc) and torch.bmm(attn^T, W_vc) of forward_absorb (models/deepseek_v2.py:655-667, 690-700) are
+// [H, <= 64, 128] x [H, 128, 512] and [H, <= 64, 512] x [H, 512, 128]: the library's batched GEMM takes 11-12 us for each
+// (profiles/r04_decode_step_deepseek_v2_lite_kernels.txt), all launch and pipeline fill.  Here the weights are kept K-contiguous
+// ([H, N, K], like the fp8 buffers above) so that both operands are read as 16-byte MFMA fragments straight from L2.
+typedef __bf16 bm_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 bm_f16x8 __attribute__((ext_vector_type(8)));
+union BmFrag {
+  uint4 u;
+  bm_bf16x8 b;
+  bm_f16x8 f;
+};
+template <typename T> __device__ inline bm_f32x4 bm_mma16(const BmFrag& a, const BmFrag& b, bm_f32x4 c);
+template <> __device__ inline bm_f32x4 bm_mma16<bf16_t>(const BmFrag& a, const BmFrag& b, bm_f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.b, b.b, c, 0, 0, 0);
+}
+template <> __device__ inline bm_f32x4 bm_mma16<f16_t>(const BmFrag& a, const BmFrag& b, bm_f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a.f, b.f, c, 0, 0, 0);
+}
+
+// out[b, m, n] = T(sum_k X[b, m, k] * W[b, n, k]); grid (N / 64, ceil(M / (16 MT)), batch), 4 waves of 16 columns each.
+template <typename T, int MT>
+__global__ void __launch_bounds__(256)
+bmm_nk_kernel(T* __restrict__ out, const T* __restrict__ x, const T* __restrict__ w, int M, int N, int K, int64_t x_bs,
+              int64_t x_rs, int64_t w_bs, int64_t w_ns, int64_t o_bs, int64_t o_rs) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c16 = lane & 15, q4 = lane >> 4;
+  const int b = blockIdx.z;
+  const int n0 = blockIdx.x * 64 + wave * 16;
+  const int m0 = blockIdx.y * (16 * MT);
+  if (n0 >= N) return;
+  const T* wp = w + b * w_bs + (int64_t)min(n0 + c16, N - 1) * w_ns + q4 * 8;
+  const T* xp[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) xp[t] = x + b * x_bs + (int64_t)min(m0 + t * 16 + c16, M - 1) * x_rs + q4 * 8;
+  bm_f32x4 acc[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) acc[t] = bm_f32x4{0.f, 0.f, 0.f, 0.f};
+  // four k-steps (128 k) of fragments in flight before their MFMAs: the loop is a chain of L2 latencies otherwise
+  for (int k0 = 0; k0 < K; k0 += 128) {
+    BmFrag a[4], bb[4][MT];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const bool ok = k0 + s * 32 < K;
+      a[s].u = ok ? *reinterpret_cast<const uint4*>(wp + k0 + s * 32) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+        bb[s][t].u = ok ? *reinterpret_cast<const uint4*>(xp[t] + k0 + s * 32) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int t = 0; t < MT; ++t) acc[t] = bm_mma16<T>(a[s], bb[s][t], acc[t]);
+  }
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const int m = m0 + t * 16 + c16, n = n0 + q4 * 4;
+    if (m >= M || n >= N) continue;
+    T* dst = out + b * o_bs + (int64_t)m * o_rs + n;
+    if (n + 4 <= N && (o_rs % 4 == 0) && (o_bs % 4 == 0)) {
+      uint2 p;
+      p.x = (uint32_t)Elem<T>::from_f(acc[t][0]).v | ((uint32_t)Elem<T>::from_f(acc[t][1]).v << 16);
+      p.y = (uint32_t)Elem<T>::from_f(acc[t][2]).v | ((uint32_t)Elem<T>::from_f(acc[t][3]).v << 16);
+      *reinterpret_cast<uint2*>(dst) = p;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (n + r < N) dst[r] = Elem<T>::from_f(acc[t][r]);
+    }
+  }
+}
+
 // ---- input_to_float8: amax over the tensor, then x * (fp8_max / amax) clamped and rounded (RNE) ----
 template <typename T>
 __global__ void __launch_bounds__(256)
@@ -177,6 +249,27 @@ int semipd_input_to_float8(void* q, float* scale_inv, void* amax_workspace, cons
                          (const float*)amax_workspace, (int)grid, (const T*)x, rows, (int)k, (int)m, x_batch_stride, x_row_stride);
   });
   return launch_status("input_to_float8");
+}
+
+int semipd_bmm_nk(void* out, const void* x, const void* w, int64_t batch, int64_t m, int64_t n, int64_t k,
+                  int64_t x_batch_stride, int64_t x_row_stride, int64_t w_batch_stride, int64_t w_col_stride,
+                  int64_t out_batch_stride, int64_t out_row_stride, int dtype, void* stream) {
+  SEMIPD_CHECK_ARG(batch > 0 && m > 0 && n > 0 && k > 0 && batch <= 65535 && m <= 65535 * 16, SEMIPD_EINVAL, "bmm_nk: bad sizes");
+  SEMIPD_CHECK_ARG(out && x && w, SEMIPD_EINVAL, "bmm_nk: null pointer");
+  SEMIPD_CHECK_ARG(dtype == SEMIPD_BF16 || dtype == SEMIPD_F16, SEMIPD_EDTYPE, "bmm_nk: bf16 / f16 only");
+  SEMIPD_CHECK_ARG(k % 32 == 0 && x_row_stride % 8 == 0 && x_batch_stride % 8 == 0 && w_col_stride % 8 == 0 &&
+                   w_batch_stride % 8 == 0 && aligned16(x) && aligned16(w) && (reinterpret_cast<uintptr_t>(out) & 1u) == 0,
+                   SEMIPD_EALIGN, "bmm_nk: k %% 32 and 16-byte aligned rows required (X [B, M, K] and W [B, N, K], K contiguous)");
+  hipStream_t st = as_stream(stream);
+  const int mt = m > 48 ? 4 : (int)((m + 15) / 16);
+  dim3 grid((unsigned)((n + 63) / 64), (unsigned)((m + 16 * mt - 1) / (16 * mt)), (unsigned)batch);
+#define BNK(MTV)                                                                                                        \
+  SEMIPD_DISPATCH_HALF(dtype, T, hipLaunchKernelGGL((bmm_nk_kernel<T, MTV>), grid, dim3(256), 0, st, (T*)out, (const T*)x, \
+                                                    (const T*)w, (int)m, (int)n, (int)k, x_batch_stride, x_row_stride,    \
+                                                    w_batch_stride, w_col_stride, out_batch_stride, out_row_stride))
+  if (mt == 1) { BNK(1); } else if (mt == 2) { BNK(2); } else if (mt == 3) { BNK(3); } else { BNK(4); }
+#undef BNK
+  return launch_status("bmm_nk");
 }
 
 int semipd_bmm_fp8(void* out, const void* a, const void* b, const float* a_scale, const float* b_scale, int64_t batch,

@@ -186,6 +186,20 @@ template <typename T> struct KVTraits<T, T> {                 // same type: byte
   __device__ static inline void store1(T* p, T x) { *p = x; }
 };
 
+// One rotary pair with its roundings pinned: the products with the sine are rounded on their own, the products with the
+// cosine are fused into the sums.  Left to the compiler, `x1 * c - x2 * s` is contracted one way or the other depending on
+// the surrounding code, and kernels that must write the same bits (the fused decode-step forms against the launches they
+// replace) then disagree in the last place of a few outputs.  Every rotation of the library goes through here.
+__device__ __forceinline__ void rope_pair(float x1, float x2, float c, float s, float& o1, float& o2) {
+  float p = x2 * s, q = x1 * s;
+  asm volatile("" : "+v"(p), "+v"(q));
+  o1 = __builtin_fmaf(x1, c, -p);
+  o2 = __builtin_fmaf(x2, c, q);
+  // fp32 VALUES: with an f16 destination the compiler may otherwise fold the fma and the conversion into one
+  // v_fma_mixlo_f16 (a single rounding) in one kernel and not in the other
+  asm volatile("" : "+v"(o1), "+v"(o2));
+}
+
 // ---- wave / block reductions ----------------------------------------------
 __device__ inline float wave_sum(float v) {
 #pragma unroll

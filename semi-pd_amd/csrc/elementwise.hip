@@ -256,8 +256,10 @@ __device__ inline void rope_item(T* __restrict__ head_ptr, KV* __restrict__ mirr
     for (int j = 0; j < V; ++j) {
       const float c = cs[i0 + j], s = cs[half + i0 + j];
       const float x1 = Elem<T>::to_f(a.e[j]), x2 = Elem<T>::to_f(b.e[j]);
-      oa.e[j] = Elem<T>::from_f(x1 * c - x2 * s);
-      ob.e[j] = Elem<T>::from_f(x2 * c + x1 * s);
+      float r1, r2;
+      rope_pair(x1, x2, c, s, r1, r2);
+      oa.e[j] = Elem<T>::from_f(r1);
+      ob.e[j] = Elem<T>::from_f(r2);
     }
     store16(head_ptr + i0, oa);
     store16(head_ptr + half + i0, ob);
@@ -274,8 +276,10 @@ __device__ inline void rope_item(T* __restrict__ head_ptr, KV* __restrict__ mirr
       const int p = (e0 >> 1) + j;
       const float c = cs[p], s = cs[half + p];
       const float x1 = Elem<T>::to_f(a.e[2 * j]), x2 = Elem<T>::to_f(a.e[2 * j + 1]);
-      o.e[2 * j] = Elem<T>::from_f(x1 * c - x2 * s);
-      o.e[2 * j + 1] = Elem<T>::from_f(x2 * c + x1 * s);
+      float r1, r2;
+      rope_pair(x1, x2, c, s, r1, r2);
+      o.e[2 * j] = Elem<T>::from_f(r1);
+      o.e[2 * j + 1] = Elem<T>::from_f(r2);
     }
     store16(head_ptr + e0, o);
     if (mirror_ptr) KVTraits<T, KV>::store8(mirror_ptr + e0, o);
@@ -357,8 +361,10 @@ __global__ void rope_planes_kernel(T* __restrict__ q_out, const float* __restric
     for (int j = 0; j < V; ++j) {
       const float c = cs[i0 + j], sn = cs[half + i0 + j];
       const float x1 = Elem<T>::to_f(Elem<T>::from_f(fa[j])), x2 = Elem<T>::to_f(Elem<T>::from_f(fb[j]));
-      oa.e[j] = Elem<T>::from_f(x1 * c - x2 * sn);
-      ob.e[j] = Elem<T>::from_f(x2 * c + x1 * sn);
+      float r1, r2;
+      rope_pair(x1, x2, c, sn, r1, r2);
+      oa.e[j] = Elem<T>::from_f(r1);
+      ob.e[j] = Elem<T>::from_f(r2);
     }
     if (h < Hq) {
       T* qh = q_out + t * q_stride + (int64_t)h * head;
@@ -424,8 +430,10 @@ mla_decode_prep_kernel(T* __restrict__ q_nope_out, T* __restrict__ q_input, KV* 
       const int p = (e0 >> 1) + j;
       const float c = cs[p], s = cs[half + p];
       const float x1 = Elem<T>::to_f(a.e[2 * j]), x2 = Elem<T>::to_f(a.e[2 * j + 1]);
-      o.e[2 * j] = Elem<T>::from_f(x1 * c - x2 * s);
-      o.e[2 * j + 1] = Elem<T>::from_f(x2 * c + x1 * s);
+      float r1, r2;
+      rope_pair(x1, x2, c, s, r1, r2);
+      o.e[2 * j] = Elem<T>::from_f(r1);
+      o.e[2 * j + 1] = Elem<T>::from_f(r2);
     }
     return o;
   };
@@ -494,7 +502,9 @@ __global__ void rope_scalar_kernel(T* __restrict__ q, T* __restrict__ k, const T
     const int i1 = interleave ? 2 * p : p, i2 = interleave ? 2 * p + 1 : p + half;
     const float c = cs[p], s = cs[half + p];
     const float x1 = Elem<T>::to_f(row[i1]), x2 = Elem<T>::to_f(row[i2]);
-    const T o1 = Elem<T>::from_f(x1 * c - x2 * s), o2 = Elem<T>::from_f(x2 * c + x1 * s);
+    float r1, r2;
+    rope_pair(x1, x2, c, s, r1, r2);
+    const T o1 = Elem<T>::from_f(r1), o2 = Elem<T>::from_f(r2);
     row[i1] = o1;
     row[i2] = o2;
     if (STORE && h >= Hq) {
@@ -540,8 +550,10 @@ __global__ void rope_strided_kernel(T* __restrict__ q, T* __restrict__ k, const 
       const int i1 = INTERLEAVE ? 2 * p : p, i2 = INTERLEAVE ? 2 * p + 1 : p + half;
       const float c = cs[p], s = cs[half + p];
       const float x1 = Elem<T>::to_f(hp[i1]), x2 = Elem<T>::to_f(hp[i2]);
-      hp[i1] = Elem<T>::from_f(x1 * c - x2 * s);
-      hp[i2] = Elem<T>::from_f(x2 * c + x1 * s);
+      float r1, r2;
+      rope_pair(x1, x2, c, s, r1, r2);
+      hp[i1] = Elem<T>::from_f(r1);
+      hp[i2] = Elem<T>::from_f(r2);
     }
   }
 }

@@ -219,6 +219,9 @@ class DeepseekV2AttentionMLA(nn.Module):
                              self.qk_rope_head_dim % 16 == 0 and os.environ.get("SEMIPD_MLA_MERGED_QKV_A", "1") != "0")
         if self.merged_qkv_a:
             self.register_buffer("w_qkv_a", torch.empty(0, dtype=dtype), persistent=False)
+            # W_kc / W_vc once more with K contiguous ([H, 512, 128], [H, 128, 512]) for ops.bmm_nk: decode batches
+            self.register_buffer("w_kc_nk", torch.empty(0, dtype=dtype), persistent=False)
+            self.register_buffer("w_vc_nk", torch.empty(0, dtype=dtype), persistent=False)
 
     def post_load_weights(self):
         """deepseek_v2.py:1228-1249: W_kc [H,128,512] and W_vc [H,512,128] out of kv_b_proj."""
@@ -243,6 +246,9 @@ class DeepseekV2AttentionMLA(nn.Module):
             [self.qk_nope_head_dim, self.v_head_dim], dim=1)
         self.w_kc = w_kc.contiguous()                    # [H, 128, 512]
         self.w_vc = w_vc.transpose(1, 2).contiguous()    # [H, 512, 128]
+        if self.merged_qkv_a:
+            self.w_kc_nk = w_kc.transpose(1, 2).contiguous()   # [H, 512, 128]
+            self.w_vc_nk = w_vc.contiguous()                   # [H, 128, 512]
 
     def _x_quant(self, hidden_states):
         """block-fp8: q_(a_)proj and kv_a_proj_with_mqa read the same activation: quantise it once."""
@@ -315,11 +321,18 @@ class DeepseekV2AttentionMLA(nn.Module):
         if fused is not None:
             q_nope, q_input = fused
             T = q_nope.shape[0]
-            torch.bmm(q_nope.transpose(0, 1), self.w_kc, out=q_input[..., : self.kv_lora_rank].transpose(0, 1))
+            own_bmm = self.w_kc_nk.numel() and os.environ.get("SEMIPD_MLA_OWN_BMM", "1") != "0"
+            if own_bmm:
+                ops.bmm_nk(q_nope.transpose(0, 1), self.w_kc_nk, out=q_input[..., : self.kv_lora_rank].transpose(0, 1))
+            else:
+                torch.bmm(q_nope.transpose(0, 1), self.w_kc, out=q_input[..., : self.kv_lora_rank].transpose(0, 1))
             attn_output = self.attn_mqa(q_input.view(T, -1), None, None, forward_batch, save_kv_cache=False)
             attn_output = attn_output.view(T, self.num_local_heads, self.kv_lora_rank)
             out = torch.empty((T, self.num_local_heads, self.v_head_dim), dtype=q_nope.dtype, device=q_nope.device)
-            torch.bmm(attn_output.transpose(0, 1), self.w_vc, out=out.transpose(0, 1))
+            if own_bmm:
+                ops.bmm_nk(attn_output.transpose(0, 1), self.w_vc_nk, out=out.transpose(0, 1))
+            else:
+                torch.bmm(attn_output.transpose(0, 1), self.w_vc, out=out.transpose(0, 1))
             return self.o_proj(out.view(T, -1), defer_reduce=True)
         xq = x_quant if x_quant is not None else self._x_quant(hidden_states)
         q = self._q(hidden_states, xq)

@@ -981,6 +981,28 @@ def bmm_fp8(A: torch.Tensor, B: torch.Tensor, A_scale: torch.Tensor, B_scale: to
     return out
 
 
+def bmm_nk(x: torch.Tensor, w_nk: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[b] = x[b] @ w_nk[b].T for decode batches of an unquantised MLA model (semipd_bmm_nk): x [b, m, k] and w_nk
+    [b, n, k] with k contiguous (any batch / row strides), out [b, m, n] any view whose last dimension is contiguous.
+    Stands where forward_absorb calls torch.bmm (models/deepseek_v2.py:655-667, 690-700)."""
+    if x.dim() != 3 or w_nk.dim() != 3 or x.shape[0] != w_nk.shape[0] or x.shape[2] != w_nk.shape[2]:
+        raise RuntimeError("bmm_nk: x [b, m, k] and w_nk [b, n, k] expected")
+    if x.dtype != w_nk.dtype or x.dtype not in (torch.bfloat16, torch.float16):
+        raise RuntimeError("bmm_nk: bf16 / f16 operands of one dtype expected")
+    if x.stride(2) != 1 or w_nk.stride(2) != 1:
+        raise RuntimeError("bmm_nk: k must be contiguous in both operands")
+    b, m, k = x.shape
+    n = w_nk.shape[1]
+    if out is None:
+        out = torch.empty((b, m, n), dtype=x.dtype, device=x.device)
+    elif out.shape != (b, m, n) or out.dtype != x.dtype or out.stride(2) != 1:
+        raise RuntimeError("bmm_nk: bad out tensor")
+    check(_lib.load().semipd_bmm_nk(ptr(out), ptr(x), ptr(w_nk), b, m, n, k, x.stride(0), x.stride(1), w_nk.stride(0),
+                                    w_nk.stride(1), out.stride(0), out.stride(1), dtype_code(x.dtype),
+                                    current_stream(x.device)), "bmm_nk")
+    return out
+
+
 def fused_add_rmsnorm_quant_fp8(input: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float,
                                 group_size: int, q_eps: float = 1e-10):
     """fused_add_rmsnorm (in place on input / residual) plus per_token_group_quant_fp8 of the normalised rows in

@@ -51,3 +51,22 @@ def test_mla_decode_prep_has_the_bits_of_the_launches_it_replaces(ops, T, H, hid
     assert torch.equal(q_input, q_input_ref)
     assert torch.equal(pool_a.view(torch.uint8), pool_b.view(torch.uint8))
     assert pool_b.float().abs().sum() > 0
+
+
+@pytest.mark.parametrize("M", [1, 16, 33, 64])
+@pytest.mark.parametrize("H,N,K", [(16, 512, 128), (16, 128, 512), (3, 96, 160)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_bmm_nk_matches_fp32_through_the_strides_of_forward_absorb(ops, M, H, N, K, dtype):
+    """ops.bmm_nk in the two layouts DeepseekV2AttentionMLA.forward_absorb uses it in: x = a [T, H, K] tensor seen as
+    [H, T, K], out = the [H, T, N] view of a [T, H, N + pad] tensor (q_input[..., :512])."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, H, K, generator=g).to(dtype).to(dev)
+    w_nk = (torch.randn(H, N, K, generator=g) * 0.1).to(dtype).to(dev)
+    holder = torch.full((M, H, N + 64), 7.0, dtype=dtype, device=dev)
+    ops.bmm_nk(x.transpose(0, 1), w_nk, out=holder[..., :N].transpose(0, 1))
+    want = torch.einsum("mhk,hnk->mhn", x.float(), w_nk.float())
+    torch.testing.assert_close(holder[..., :N].float(), want, rtol=2e-2, atol=2e-2)
+    assert torch.all(holder[..., N:] == 7.0)                  # nothing written past the view
+    lib = torch.bmm(x.transpose(0, 1), w_nk.transpose(1, 2)).transpose(0, 1)
+    torch.testing.assert_close(holder[..., :N].float(), lib.float(), rtol=2e-2, atol=2e-2)
