@@ -27,7 +27,8 @@ from semi_pd_amd.layers.attention_backend import RadixAttention
 from semi_pd_amd.layers.basic import (stream_linear_enabled, ColumnParallelLinear, LogitsProcessor, MergedColumnParallelLinear,
                                       ParallelLMHead, ReplicatedLinear, RMSNorm, RowParallelLinear, SiluAndMul,
                                       VocabParallelEmbedding, gate_up_silu, get_rope, yarn_get_mscale)
-from semi_pd_amd.layers.fp8 import (FP8_DTYPE, Fp8Config, block_dequantize_weight, block_quant_to_tensor_quant,
+from semi_pd_amd.layers.fp8 import (FP8_DTYPE, Fp8Config, apply_w8a8_block_fp8_linear, block_dequantize_weight,
+                                    block_quant_to_tensor_quant,
                                     quantize_activation)
 from semi_pd_amd.layers.moe import FusedMoE
 
@@ -217,6 +218,15 @@ class DeepseekV2AttentionMLA(nn.Module):
         self.merged_qkv_a = (qc is None and self.q_lora_rank is None and self.kv_lora_rank <= 512 and
                              self.kv_lora_rank % 8 == 0 and self.qk_nope_head_dim % 8 == 0 and
                              self.qk_rope_head_dim % 16 == 0 and os.environ.get("SEMIPD_MLA_MERGED_QKV_A", "1") != "0")
+        # block-fp8 with q_lora (DeepSeek-V3): q_a_proj and kv_a_proj_with_mqa read the same quantised row -- one block-fp8
+        # GEMM on the concatenated weight for decode batches (q_lora_rank is a multiple of the scale block, so the two
+        # scale tables concatenate as well): one GEMM and one K-slice reduction less per layer
+        self.merged_qkv_a_fp8 = (qc is not None and self.q_lora_rank is not None and
+                                 self.q_lora_rank % int(qc.weight_block_size[0]) == 0 and
+                                 os.environ.get("SEMIPD_MLA_MERGED_QKV_A", "1") != "0")
+        if self.merged_qkv_a_fp8:
+            self.register_buffer("w_qkv_a_fp8", torch.empty(0, dtype=FP8_DTYPE), persistent=False)
+            self.register_buffer("s_qkv_a_fp8", torch.empty(0, dtype=torch.float32), persistent=False)
         if self.merged_qkv_a:
             self.register_buffer("w_qkv_a", torch.empty(0, dtype=dtype), persistent=False)
             # W_kc / W_vc once more with K contiguous ([H, 512, 128], [H, 128, 512]) for ops.bmm_nk: decode batches
@@ -226,6 +236,10 @@ class DeepseekV2AttentionMLA(nn.Module):
     def post_load_weights(self):
         """deepseek_v2.py:1228-1249: W_kc [H,128,512] and W_vc [H,512,128] out of kv_b_proj."""
         w = self.kv_b_proj.weight
+        if self.merged_qkv_a_fp8:
+            self.w_qkv_a_fp8 = torch.cat([self.q_a_proj.weight.data, self.kv_a_proj_with_mqa.weight.data], 0).contiguous()
+            self.s_qkv_a_fp8 = torch.cat([self.q_a_proj.weight_scale_inv.data,
+                                          self.kv_a_proj_with_mqa.weight_scale_inv.data], 0).contiguous()
         if self.merged_qkv_a:
             # rows: this rank's q heads, then the (replicated) latent + k_pe rows
             self.w_qkv_a = torch.cat([self.q_proj.weight.data, self.kv_a_proj_with_mqa.weight.data], 0).contiguous()
@@ -256,17 +270,29 @@ class DeepseekV2AttentionMLA(nn.Module):
             return None
         return quantize_activation(hidden_states, self.quant_config.weight_block_size)
 
-    def _q(self, hidden_states, x_quant=None):
+    def _qkv_a_fp8(self, hidden_states, x_quant):
+        """(q_a [T, q_lora], latent [T, 576]) as views of ONE block-fp8 GEMM's output for decode batches, or (None, None)."""
+        if not (self.merged_qkv_a_fp8 and self.w_qkv_a_fp8.numel() and hidden_states.dim() == 2
+                and 0 < hidden_states.shape[0] <= ops.STREAM_LINEAR_MAX_ROWS):
+            return None, None
+        y = apply_w8a8_block_fp8_linear(hidden_states, self.w_qkv_a_fp8, self.quant_config.weight_block_size,
+                                        self.s_qkv_a_fp8, None, x_quant=x_quant)
+        return y[:, : self.q_lora_rank], y[:, self.q_lora_rank:]
+
+    def _q(self, hidden_states, x_quant=None, q_a=None):
         if self.q_lora_rank is not None:
-            q = self.q_b_proj(self.q_a_layernorm(self.q_a_proj(hidden_states, x_quant=x_quant)))
+            if q_a is None:
+                q_a = self.q_a_proj(hidden_states, x_quant=x_quant)
+            q = self.q_b_proj(self.q_a_layernorm(q_a))
         else:
             q = self.q_proj(hidden_states, x_quant=x_quant)
         return q.view(-1, self.num_local_heads, self.qk_head_dim)
 
-    def _latent(self, hidden_states, positions, q, x_quant=None):
+    def _latent(self, hidden_states, positions, q, x_quant=None, latent=None):
         """kv_a_proj -> RMSNorm on the 512 latent dims -> RoPE on the 64 rope dims (and on q_pe);
         returns the finished latent rows [T, 1, 576]."""
-        latent = self.kv_a_proj_with_mqa(hidden_states, x_quant=x_quant)  # [T, 576]
+        if latent is None:
+            latent = self.kv_a_proj_with_mqa(hidden_states, x_quant=x_quant)  # [T, 576]
         kv_a = ops.rmsnorm(latent[:, : self.kv_lora_rank], self.kv_a_layernorm.weight.data,
                            self.kv_a_layernorm.variance_epsilon, out=latent[:, : self.kv_lora_rank])
         del kv_a
@@ -283,8 +309,9 @@ class DeepseekV2AttentionMLA(nn.Module):
 
     def forward_normal(self, positions, hidden_states, forward_batch, x_quant=None):
         xq = x_quant if x_quant is not None else self._x_quant(hidden_states)
-        q = self._q(hidden_states, xq)
-        latent = self._latent(hidden_states, positions, q, xq)
+        q_a, lat = self._qkv_a_fp8(hidden_states, xq)
+        q = self._q(hidden_states, xq, q_a)
+        latent = self._latent(hidden_states, positions, q, xq, lat)
         forward_batch.token_to_kv_pool.set_kv_buffer(self.attn_mha, forward_batch.out_cache_loc, latent, None)
         kv = self.kv_b_proj(latent[:, 0, : self.kv_lora_rank])
         kv = kv.view(-1, self.num_local_heads, self.qk_nope_head_dim + self.v_head_dim)
@@ -335,9 +362,10 @@ class DeepseekV2AttentionMLA(nn.Module):
                 torch.bmm(attn_output.transpose(0, 1), self.w_vc, out=out.transpose(0, 1))
             return self.o_proj(out.view(T, -1), defer_reduce=True)
         xq = x_quant if x_quant is not None else self._x_quant(hidden_states)
-        q = self._q(hidden_states, xq)
+        q_a, lat = self._qkv_a_fp8(hidden_states, xq)
+        q = self._q(hidden_states, xq, q_a)
         T = q.shape[0]
-        latent = self._latent(hidden_states, positions, q, xq)
+        latent = self._latent(hidden_states, positions, q, xq, lat)
         q_input = torch.empty((T, self.num_local_heads, self.kv_lora_rank + self.qk_rope_head_dim),
                               dtype=q.dtype, device=q.device)
         if self.absorb_fp8:
