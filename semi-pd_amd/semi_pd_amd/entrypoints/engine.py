@@ -475,8 +475,10 @@ class Engine:
                 self.send_to_scheduler.send_pyobj(ShutdownReq())
         except Exception:
             pass
+        # (a profiler attached to the scheduler processes writes its trace at exit: SEMIPD_SHUTDOWN_JOIN_S gives it time)
+        join_s = float(os.environ.get("SEMIPD_SHUTDOWN_JOIN_S", "20"))
         for p in self.procs:
-            p.join(timeout=20)
+            p.join(timeout=join_s)
         for p in self.procs:
             if p.is_alive():
                 p.terminate()
