@@ -122,6 +122,18 @@ int semipd_mla_decode_prep(void* q_nope_out, void* q_input, void* kv_buf, const 
                            int lora_rank, int64_t q_input_token_stride, int64_t q_input_head_stride, int64_t kvbuf_stride,
                            int dtype, int kv_dtype, void* stream);
 
+/* The same launch for rows that are already tensors (the q_lora / block-fp8 path: q [num_tokens, Hq, nope + rope] out of
+ * q_b_proj, latent [num_tokens, lora + rope] out of kv_a_proj_with_mqa, through their strides): kv_a_layernorm on the latent,
+ * RoPE on q_pe and k_pe, q_pe -> q_input[t, h, lora : lora + rope], the finished latent row -> kv_buf row loc[t].  q and
+ * latent are not modified.  Same bits as semipd_rmsnorm + semipd_rope_inplace_strided + the q_pe copy + semipd_kv_store_cvt.
+ * replaces the same four statements of forward_absorb (models/deepseek_v2.py:670-684). */
+int semipd_mla_decode_prep_rows(void* q_input, void* kv_buf, const void* q, const void* latent, const int64_t* loc,
+                                const float* cos_sin_cache, const int64_t* positions, const void* norm_weight, float eps,
+                                int64_t num_tokens, int num_q_heads, int nope_dim, int rope_dim, int lora_rank,
+                                int64_t q_token_stride, int64_t q_head_stride, int64_t latent_token_stride,
+                                int64_t q_input_token_stride, int64_t q_input_head_stride, int64_t kvbuf_stride, int dtype,
+                                int kv_dtype, void* stream);
+
 /* semipd_rope_kv_store for a decode batch whose qkv row is still the K-slice planes of semipd_stream_linear_planes:
  * planes [n_planes][num_tokens][(Hq + 2 Hk) * head] fp32 (plane stride plane_elems) are summed in slice order and
  * rounded to dtype -- the bits the GEMM's own reduction writes -- then q is rotated into q_out [num_tokens, q_stride],

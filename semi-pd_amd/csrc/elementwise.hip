@@ -404,7 +404,11 @@ mla_decode_prep_kernel(T* __restrict__ q_nope_out, T* __restrict__ q_input, KV* 
                        const float* __restrict__ planes, int n_planes, int64_t plane_elems, int64_t row_elems,
                        const int64_t* __restrict__ loc, const float* __restrict__ cache, const int64_t* __restrict__ positions,
                        const T* __restrict__ norm_w, float eps, int Hq, int nope, int rope, int lora, int64_t q_input_ts,
-                       int64_t q_input_hs, int64_t kvbuf_stride) {
+                       int64_t q_input_hs, int64_t kvbuf_stride, const T* __restrict__ q_src = nullptr, int64_t q_src_ts = 0,
+                       int64_t q_src_hs = 0, const T* __restrict__ lat_src = nullptr, int64_t lat_src_ts = 0) {
+  // n_planes == 0: the rows are already tensors of T -- q_src [tokens, Hq, nope + rope] and lat_src [tokens, lora + rope]
+  // through their strides (the q_lora / block-fp8 path, whose GEMMs reduce themselves): same work minus the plane sums,
+  // q_nope stays where it is (q_nope_out unused)
   constexpr int V = Elem<T>::kVec;
   static_assert(V == 8, "16-bit activations");
   const int64_t t = blockIdx.x;
@@ -414,7 +418,13 @@ mla_decode_prep_kernel(T* __restrict__ q_nope_out, T* __restrict__ q_input, KV* 
   KV* pool_row = kv_buf + loc[t] * kvbuf_stride;
   const float* cs = cache + positions[t] * rope;
   const int half = rope >> 1;
+  const bool from_rows = n_planes == 0;
   auto sum8_T = [&](int64_t col) __attribute__((always_inline)) {
+    if (from_rows) {
+      if (col >= kv_col0) return load16(lat_src + t * lat_src_ts + (col - kv_col0));
+      const int h = (int)(col / qk);
+      return load16(q_src + t * q_src_ts + h * q_src_hs + (col - (int64_t)h * qk));
+    }
     float f[8];
     planes_sum8(row + col, n_planes, plane_elems, f);
     Vec16<T> a;
@@ -470,6 +480,7 @@ mla_decode_prep_kernel(T* __restrict__ q_nope_out, T* __restrict__ q_input, KV* 
   const int per_head = qk / V, nope_v = nope / V;
   for (int it = threadIdx.x - 64; it < Hq * per_head; it += blockDim.x - 64) {
     const int h = it / per_head, i = it - h * per_head;
+    if (from_rows && i < nope_v) continue;
     const Vec16<T> a = sum8_T((int64_t)h * qk + (int64_t)i * V);
     if (i < nope_v) {
       store16(q_nope_out + (t * Hq + h) * (int64_t)nope + (int64_t)i * V, a);
@@ -1096,6 +1107,43 @@ int semipd_mla_decode_prep(void* q_nope_out, void* q_input, void* kv_buf, const 
   });
 #undef MDP
   return launch_status("mla_decode_prep");
+}
+
+int semipd_mla_decode_prep_rows(void* q_input, void* kv_buf, const void* q, const void* latent, const int64_t* loc,
+                                const float* cos_sin_cache, const int64_t* positions, const void* norm_weight, float eps,
+                                int64_t num_tokens, int num_q_heads, int nope_dim, int rope_dim, int lora_rank,
+                                int64_t q_token_stride, int64_t q_head_stride, int64_t latent_token_stride,
+                                int64_t q_input_token_stride, int64_t q_input_head_stride, int64_t kvbuf_stride, int dtype,
+                                int kv_dtype, void* stream) {
+  SEMIPD_CHECK_ARG(num_tokens >= 0 && num_q_heads > 0 && nope_dim > 0 && rope_dim > 0 && lora_rank > 0, SEMIPD_EINVAL,
+                   "mla_decode_prep_rows: bad sizes");
+  if (num_tokens == 0) return 0;
+  SEMIPD_CHECK_ARG(q_input && kv_buf && q && latent && loc && cos_sin_cache && positions && norm_weight, SEMIPD_EINVAL,
+                   "mla_decode_prep_rows: null pointer");
+  SEMIPD_CHECK_ARG(dtype == SEMIPD_BF16 || dtype == SEMIPD_F16, SEMIPD_EDTYPE, "mla_decode_prep_rows: bf16 / f16 activations");
+  SEMIPD_CHECK_ARG(nope_dim % 8 == 0 && rope_dim % 16 == 0 && lora_rank % 8 == 0 && lora_rank <= 512 && rope_dim <= 512 &&
+                   q_token_stride % 8 == 0 && q_head_stride % 8 == 0 && latent_token_stride % 8 == 0 &&
+                   q_input_token_stride % 8 == 0 && q_input_head_stride % 8 == 0 && kvbuf_stride % 16 == 0 && aligned16(q) &&
+                   aligned16(latent) && aligned16(q_input) && aligned16(kv_buf) && aligned16(norm_weight),
+                   SEMIPD_EALIGN, "mla_decode_prep_rows: nope %% 8, rope %% 16, lora %% 8 (<= 512), 16-byte aligned rows required");
+  hipStream_t st = as_stream(stream);
+  dim3 grid((unsigned)num_tokens), block(256);
+#define MDR(TT, KVT)                                                                                                       \
+  hipLaunchKernelGGL((mla_decode_prep_kernel<TT, KVT>), grid, block, 0, st, (TT*)nullptr, (TT*)q_input, (KVT*)kv_buf,       \
+                     (const float*)nullptr, 0, (int64_t)0, (int64_t)0, loc, cos_sin_cache, positions, (const TT*)norm_weight, \
+                     eps, num_q_heads, nope_dim, rope_dim, lora_rank, q_input_token_stride, q_input_head_stride, kvbuf_stride, \
+                     (const TT*)q, q_token_stride, q_head_stride, (const TT*)latent, latent_token_stride)
+  SEMIPD_DISPATCH_HALF(dtype, T, {
+    if (kv_dtype == dtype) MDR(T, T);
+    else if (kv_dtype == SEMIPD_F8E5M2) MDR(T, f8e5m2_t);
+    else if (kv_dtype == SEMIPD_F8E4M3) MDR(T, f8e4m3_t);
+    else {
+      set_error("mla_decode_prep_rows: unsupported kv_dtype %d", kv_dtype);
+      return SEMIPD_EDTYPE;
+    }
+  });
+#undef MDR
+  return launch_status("mla_decode_prep_rows");
 }
 
 int semipd_kv_store_cvt(void* buf, const void* src, const int64_t* loc, int64_t num_tokens, int64_t row_elems,

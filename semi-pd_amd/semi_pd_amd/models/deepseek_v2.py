@@ -365,9 +365,22 @@ class DeepseekV2AttentionMLA(nn.Module):
         q_a, lat = self._qkv_a_fp8(hidden_states, xq)
         q = self._q(hidden_states, xq, q_a)
         T = q.shape[0]
-        latent = self._latent(hidden_states, positions, q, xq, lat)
         q_input = torch.empty((T, self.num_local_heads, self.kv_lora_rank + self.qk_rope_head_dim),
                               dtype=q.dtype, device=q.device)
+        # decode batches: kv_a_layernorm, RoPE (q_pe, k_pe), q_pe -> q_input and the KV-pool store in ONE launch
+        # (ops.mla_decode_prep_rows; the bf16 path without q_lora goes through _decode_prep_fused above)
+        prep_rows = (forward_batch.forward_mode.is_decode() and hidden_states.dim() == 2 and self.kv_lora_rank <= 512
+                     and self.kv_lora_rank % 8 == 0 and self.qk_nope_head_dim % 8 == 0 and self.qk_rope_head_dim % 16 == 0
+                     and q.dtype in (torch.bfloat16, torch.float16) and os.environ.get("SEMIPD_MLA_PREP_ROWS", "1") != "0")
+        if prep_rows:
+            lat_raw = lat if lat is not None else self.kv_a_proj_with_mqa(hidden_states, x_quant=xq)
+            ops.mla_decode_prep_rows(q, lat_raw, positions, self.rotary_emb.cos_sin_cache, self.kv_a_layernorm.weight.data,
+                                     self.kv_a_layernorm.variance_epsilon, self.qk_nope_head_dim, self.kv_lora_rank,
+                                     forward_batch.token_to_kv_pool.get_key_buffer(self.layer_id),
+                                     forward_batch.out_cache_loc, q_input)
+            latent = None
+        else:
+            latent = self._latent(hidden_states, positions, q, xq, lat)
         if self.absorb_fp8:
             # q_nope quantised per tensor, fp8 x fp8 on the matrix cores, written straight into q_input's layout
             q_val, q_scale = ops.input_to_float8(q[..., : self.qk_nope_head_dim].transpose(0, 1), FP8_DTYPE)
@@ -377,10 +390,13 @@ class DeepseekV2AttentionMLA(nn.Module):
             # [H, T, 512], written through the strides of q_input's layout (no copy behind the batched GEMM)
             torch.bmm(q[..., : self.qk_nope_head_dim].transpose(0, 1), self.w_kc,
                       out=q_input[..., : self.kv_lora_rank].transpose(0, 1))
-        q_input[..., self.kv_lora_rank:] = q[..., self.qk_nope_head_dim:]
-        forward_batch.token_to_kv_pool.set_kv_buffer(self.attn_mqa, forward_batch.out_cache_loc, latent, None)
-        attn_output = self.attn_mqa(q_input.view(T, -1), latent.view(T, -1), latent[..., : self.kv_lora_rank],
-                                    forward_batch, save_kv_cache=False)
+        if latent is not None:
+            q_input[..., self.kv_lora_rank:] = q[..., self.qk_nope_head_dim:]
+            forward_batch.token_to_kv_pool.set_kv_buffer(self.attn_mqa, forward_batch.out_cache_loc, latent, None)
+            attn_output = self.attn_mqa(q_input.view(T, -1), latent.view(T, -1), latent[..., : self.kv_lora_rank],
+                                        forward_batch, save_kv_cache=False)
+        else:
+            attn_output = self.attn_mqa(q_input.view(T, -1), None, None, forward_batch, save_kv_cache=False)
         attn_output = attn_output.view(T, self.num_local_heads, self.kv_lora_rank)
         if self.absorb_fp8:
             a_val, a_scale = ops.input_to_float8(attn_output.transpose(0, 1), FP8_DTYPE)

@@ -610,6 +610,34 @@ def mla_decode_prep(qkv_a: SplitKPlanes, positions: torch.Tensor, cos_sin_cache:
     return q_nope
 
 
+def mla_decode_prep_rows(q: torch.Tensor, latent: torch.Tensor, positions: torch.Tensor, cos_sin_cache: torch.Tensor,
+                         norm_weight: torch.Tensor, eps: float, nope_dim: int, lora_rank: int, kv_buffer: torch.Tensor,
+                         loc: torch.Tensor, q_input: torch.Tensor) -> None:
+    """mla_decode_prep for rows that are already tensors: q [T, H, nope + rope], latent [T, lora + rope] (any row strides);
+    fills q_input[..., lora:] with the rotated q_pe and the pool rows `loc` with the normalised latent + rotated k_pe
+    (semipd_mla_decode_prep_rows).  q and latent are left as they are."""
+    T, H, qk = q.shape
+    rope_dim = qk - nope_dim
+    if latent.shape != (T, lora_rank + rope_dim) or q.stride(2) != 1 or latent.stride(1) != 1 or q.dtype != latent.dtype:
+        raise RuntimeError("mla_decode_prep_rows: q [T, H, nope + rope] and latent [T, lora + rope] of one dtype expected")
+    if cos_sin_cache.dtype != torch.float32 or cos_sin_cache.shape[1] != rope_dim or not cos_sin_cache.is_contiguous():
+        raise RuntimeError("mla_decode_prep_rows: contiguous fp32 cos / sin cache [max_pos, rope] expected")
+    if positions.dtype != torch.int64:
+        positions = positions.long()
+    if loc.dtype != torch.int64 or loc.numel() != T or not loc.is_contiguous():
+        raise RuntimeError("mla_decode_prep_rows: one contiguous int64 pool row per token expected")
+    if q_input.shape != (T, H, lora_rank + rope_dim) or q_input.stride(2) != 1 or q_input.dtype != q.dtype:
+        raise RuntimeError("mla_decode_prep_rows: q_input must be [tokens, heads, lora + rope] of q's dtype")
+    if kv_buffer.dim() != 3 or kv_buffer.shape[1:] != (1, lora_rank + rope_dim) or kv_buffer.stride(2) != 1:
+        raise RuntimeError("mla_decode_prep_rows: kv_buffer must be [slots, 1, lora + rope] with dense rows")
+    check(_lib.load().semipd_mla_decode_prep_rows(ptr(q_input), ptr(kv_buffer), ptr(q), ptr(latent), ptr(loc), ptr(cos_sin_cache),
+                                                  ptr(positions), ptr(norm_weight), float(eps), T, H, nope_dim, rope_dim,
+                                                  lora_rank, q.stride(0), q.stride(1), latent.stride(0), q_input.stride(0),
+                                                  q_input.stride(1), kv_buffer.stride(0), dtype_code(q.dtype),
+                                                  _lib.kv_dtype_code(kv_buffer.dtype), current_stream(q.device)),
+          "mla_decode_prep_rows")
+
+
 def fused_add_rmsnorm_planes(p: SplitKPlanes, residual: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
     """residual += T(sum of the planes); returns RMSNorm(residual) * weight -- fused_add_rmsnorm on the GEMM output
     that was never written (layers/layernorm.py:47-76)."""

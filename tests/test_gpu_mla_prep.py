@@ -70,3 +70,43 @@ def test_bmm_nk_matches_fp32_through_the_strides_of_forward_absorb(ops, M, H, N,
     assert torch.all(holder[..., N:] == 7.0)                  # nothing written past the view
     lib = torch.bmm(x.transpose(0, 1), w_nk.transpose(1, 2)).transpose(0, 1)
     torch.testing.assert_close(holder[..., :N].float(), lib.float(), rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("T", [1, 32, 64])
+@pytest.mark.parametrize("H", [16, 128])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("kv_dtype", [None, torch.float8_e5m2])
+def test_mla_decode_prep_rows_has_the_bits_of_the_launches_it_replaces(ops, T, H, dtype, kv_dtype):
+    """The q_lora / block-fp8 path: q and the latent are tensors already (strided views of wider GEMM outputs)."""
+    dev = torch.device("cuda:0")
+    nope, rope, lora = 128, 64, 512
+    g = torch.Generator().manual_seed(T * 17 + H)
+    q_wide = torch.randn(T, H * (nope + rope) + 64, generator=g).to(dtype).to(dev)
+    q = q_wide[:, : H * (nope + rope)].view(T, H, nope + rope)                      # row stride wider than the row
+    y = torch.randn(T, 1536 + lora + rope, generator=g).to(dtype).to(dev)
+    lat = y[:, 1536:]                                                               # the tail of a merged q_a | kv_a output
+    nw = (torch.rand(lora, generator=g) + 0.5).to(dtype).to(dev)
+    positions = torch.randint(0, 4000, (T,), generator=g).to(dev)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, rope, 2, dtype=torch.float32) / rope))
+    fr = torch.arange(4096, dtype=torch.float32)[:, None] * inv[None, :]
+    cache = torch.cat([fr.cos(), fr.sin()], -1).contiguous().to(dev)
+    slots = 200
+    loc = torch.randperm(slots, generator=g)[:T].to(torch.int64).to(dev)
+    pool_dtype = kv_dtype or dtype
+    pool_a = torch.zeros((slots, 1, lora + rope), dtype=dtype, device=dev).to(pool_dtype)
+    pool_b = pool_a.clone()
+    q_before, lat_before = q.clone(), lat.clone()
+    # one launch (first: the separate launches below work in place)
+    q_input = torch.zeros((T, H, lora + rope), dtype=dtype, device=dev)
+    ops.mla_decode_prep_rows(q, lat, positions, cache, nw, 1e-6, nope, lora, pool_b, loc, q_input)
+    assert torch.equal(q, q_before) and torch.equal(lat, lat_before)
+    # the launches it replaces
+    q1, l1 = q.clone(), lat.clone()
+    ops.rmsnorm(l1[:, :lora], nw, 1e-6, out=l1[:, :lora])
+    l1 = l1.unsqueeze(1)
+    ops.apply_rope_strided_inplace(positions, q1[..., nope:], l1[..., lora:], cache, False)
+    q_input_ref = torch.zeros((T, H, lora + rope), dtype=dtype, device=dev)
+    q_input_ref[..., lora:] = q1[..., nope:]
+    ops.store_kv_rows(pool_a, loc, l1)
+    assert torch.equal(q_input, q_input_ref)
+    assert torch.equal(pool_a.view(torch.uint8), pool_b.view(torch.uint8))
