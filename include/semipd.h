@@ -436,6 +436,16 @@ int semipd_grouped_topk(const void* gating, const float* correction_bias, float*
                         int num_expert_group, int topk_group, int renormalize, int scoring,
                         int dtype, void* stream);
 
+/* semipd_grouped_topk on router logits that are still the fp32 K-slice planes [n_planes][num_tokens][num_experts] of the
+ * router GEMM (semipd_stream_linear_planes on MoEGate.weight): summed in slice order and rounded to dtype inside the
+ * routing kernel -- the bits of the GEMM's own reduction, one launch less, and for decode batches the weight-streaming
+ * GEMM instead of the library's (18 us at 256 experts x 7168).
+ * replaces MoEGate.forward's F.linear output write + grouped_topk / biased_grouped_topk
+ *   (models/deepseek_v2.py:100-160, layers/moe/topk.py:79-160). */
+int semipd_grouped_topk_planes(const float* planes, int n_planes, int64_t plane_elems, const float* correction_bias,
+                               float* topk_weights, int32_t* topk_ids, int64_t num_tokens, int num_experts, int topk,
+                               int num_expert_group, int topk_group, int renormalize, int scoring, int dtype, void* stream);
+
 /* Counting sort of the T*k expert ids padded per expert to block_size.
  * replaces torch.ops.sgl_kernel.moe_align_block_size
  *   (torch_extension.cc:115-118; csrc/moe/moe_align_kernel.cu:27-161).

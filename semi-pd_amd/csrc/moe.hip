@@ -53,22 +53,36 @@ template <typename T>
 __global__ void __launch_bounds__(64)
 moe_topk_kernel(const T* __restrict__ gating, const float* __restrict__ bias,
                 float* __restrict__ topk_weights, int32_t* __restrict__ topk_ids, int E, int topk,
-                int num_group, int topk_group, int renormalize, int scoring, int grouped) {
+                int num_group, int topk_group, int renormalize, int scoring, int grouped,
+                const float* __restrict__ planes = nullptr, int n_planes = 0, int64_t plane_elems = 0) {
   __shared__ float score[kMaxExperts];   // unbiased scores (weights come from these)
   __shared__ float choice[kMaxExperts];  // scores used for selection (biased / masked)
   __shared__ float gscore[64];
   __shared__ int gsel[64];
   const int64_t t = blockIdx.x;
   const int lane = threadIdx.x;
-  const T* g = gating + t * E;
+  // the router logits of this token as T values: from the [tokens, E] tensor, or -- planes != nullptr -- from the fp32 K-slice
+  // planes [n_planes][tokens][E] of the router GEMM (csrc/stream_linear.hip), summed in slice order and rounded to T: the
+  // bits that GEMM's own reduction would have written.  Staged in `choice` (every lane reads back what it wrote)
+  if (planes) {
+    for (int e = lane; e < E; e += 64) {
+      const float* p = planes + t * E + e;
+      float acc = p[0];
+      for (int z = 1; z < n_planes; ++z) acc += p[(int64_t)z * plane_elems];
+      choice[e] = Elem<T>::to_f(Elem<T>::from_f(acc));
+    }
+  } else {
+    const T* g = gating + t * E;
+    for (int e = lane; e < E; e += 64) choice[e] = Elem<T>::to_f(g[e]);
+  }
   // scores
   if (scoring == 0) {
     float mx = -INFINITY;
-    for (int e = lane; e < E; e += 64) mx = fmaxf(mx, Elem<T>::to_f(g[e]));
+    for (int e = lane; e < E; e += 64) mx = fmaxf(mx, choice[e]);
     mx = wave_max(mx);
     float sum = 0.f;
     for (int e = lane; e < E; e += 64) {
-      const float x = expf(Elem<T>::to_f(g[e]) - mx);
+      const float x = expf(choice[e] - mx);
       score[e] = x;
       sum += x;
     }
@@ -76,7 +90,7 @@ moe_topk_kernel(const T* __restrict__ gating, const float* __restrict__ bias,
     const float inv = 1.f / sum;
     for (int e = lane; e < E; e += 64) score[e] *= inv;
   } else {
-    for (int e = lane; e < E; e += 64) score[e] = 1.f / (1.f + expf(-Elem<T>::to_f(g[e])));
+    for (int e = lane; e < E; e += 64) score[e] = 1.f / (1.f + expf(-choice[e]));
   }
   // grouped_topk / biased_grouped_topk run softmax / sigmoid in the gating dtype (topk.py:91-94,
   // 132): scores are rounded to T before any comparison so the selection matches bit for bit.
@@ -484,6 +498,24 @@ int semipd_grouped_topk(const void* gating, const float* correction_bias, float*
   const int sc = correction_bias ? 1 : scoring;  // biased_grouped_topk always uses sigmoid
   SEMIPD_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((moe_topk_kernel<T>), dim3((unsigned)num_tokens), dim3(64), 0, as_stream(stream), (const T*)gating, correction_bias, topk_weights, topk_ids, num_experts, topk, num_expert_group, topk_group, renormalize, sc, 1));
   return launch_status("grouped_topk");
+}
+
+int semipd_grouped_topk_planes(const float* planes, int n_planes, int64_t plane_elems, const float* correction_bias,
+                               float* topk_weights, int32_t* topk_ids, int64_t num_tokens, int num_experts, int topk,
+                               int num_expert_group, int topk_group, int renormalize, int scoring, int dtype, void* stream) {
+  SEMIPD_CHECK_ARG(num_tokens >= 0 && num_experts > 0 && num_experts <= kMaxExperts && topk > 0 &&
+                       topk <= kMaxTopk && topk <= num_experts && num_expert_group > 0 &&
+                       num_expert_group <= 64 && num_experts % num_expert_group == 0 &&
+                       topk_group > 0 && topk_group <= num_expert_group && n_planes >= 1 && n_planes <= 64 &&
+                       plane_elems >= num_tokens * num_experts,
+                   SEMIPD_EINVAL, "grouped_topk_planes: bad sizes");
+  if (num_tokens == 0) return 0;
+  SEMIPD_CHECK_ARG(planes && topk_weights && topk_ids, SEMIPD_EINVAL, "grouped_topk_planes: null pointer");
+  SEMIPD_CHECK_ARG(dtype == SEMIPD_BF16 || dtype == SEMIPD_F16, SEMIPD_EDTYPE, "grouped_topk_planes: the router GEMM's "
+                   "dtype (bf16 / f16) expected");
+  const int sc = correction_bias ? 1 : scoring;
+  SEMIPD_DISPATCH_HALF(dtype, T, hipLaunchKernelGGL((moe_topk_kernel<T>), dim3((unsigned)num_tokens), dim3(64), 0, as_stream(stream), (const T*)nullptr, correction_bias, topk_weights, topk_ids, num_experts, topk, num_expert_group, topk_group, renormalize, sc, 1, planes, n_planes, plane_elems));
+  return launch_status("grouped_topk_planes");
 }
 
 int semipd_moe_align_block_size(const int32_t* topk_ids, int64_t numel, int num_experts,

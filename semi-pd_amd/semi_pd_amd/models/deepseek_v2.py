@@ -109,7 +109,14 @@ class MoEGate(nn.Module):
         else:
             self.e_score_correction_bias = None
 
-    def forward(self, hidden_states):
+    def forward(self, hidden_states, planes_ok: bool = False):
+        # decode batches: the weight-streaming GEMM, stopped before its K-slice reduction -- the routing kernel sums the
+        # planes (ops.grouped_topk on a SplitKPlanes): the library GEMM takes 10-18 us for these shapes
+        if (planes_ok and hidden_states.dim() == 2 and stream_linear_enabled()
+                and hidden_states.shape[0] <= ops.STREAM_LINEAR_MAX_ROWS and self.weight.shape[0] % 8 == 0
+                and ops.stream_linear_is_supported(hidden_states, self.weight)
+                and os.environ.get("SEMIPD_MOE_GATE_PLANES", "1") != "0"):
+            return ops.stream_linear_planes(hidden_states, self.weight)
         return F.linear(hidden_states, self.weight, None)
 
 
@@ -137,8 +144,9 @@ class DeepseekV2MoE(nn.Module):
         if x_quant is None and qc is not None and self.shared_experts is not None and hidden_states.dim() == 2:
             x_quant = quantize_activation(hidden_states, qc.weight_block_size)
         shared_output = self.shared_experts(hidden_states, x_quant=x_quant) if self.shared_experts is not None else None
-        router_logits = self.gate(hidden_states)
         comm = self.experts.all_to_all_comm() if (self.tp_size > 1 and hidden_states.dim() == 2) else None
+        # (the planes must be consumed by the next user of the GEMM workspace: the routing kernel at the top of self.experts)
+        router_logits = self.gate(hidden_states, planes_ok=comm is None and self.experts.use_grouped_topk)
         if comm is not None:
             # --enable-ep-all-to-all: the routed part comes back COMPLETE and replicated; only the (tensor-parallel)
             # shared experts still hold a partial sum

@@ -776,6 +776,21 @@ def grouped_topk(gating_output: torch.Tensor, topk: int, renormalize: bool, num_
     """grouped_topk / biased_grouped_topk (layers/moe/topk.py:79-160)."""
     if scoring_func not in ("softmax", "sigmoid"):
         raise ValueError(f"Scoring function '{scoring_func}' is not supported.")
+    if isinstance(gating_output, SplitKPlanes):
+        # the router GEMM stopped before its K-slice reduction (MoEGate on the weight-streaming kernel): the routing kernel
+        # sums the planes itself
+        p = gating_output
+        p.check_live("grouped_topk")
+        T, E = p.rows, p.n
+        dev = p.planes.device
+        w = torch.empty((T, topk), dtype=torch.float32, device=dev)
+        ids = torch.empty((T, topk), dtype=torch.int32, device=dev)
+        bias = correction_bias.float().contiguous() if correction_bias is not None else None
+        check(_lib.load().semipd_grouped_topk_planes(ptr(p.planes), p.ksplit, p.rows * p.n, ptr(bias), ptr(w), ptr(ids), T, E,
+                                                     topk, num_expert_group, topk_group, int(renormalize),
+                                                     1 if scoring_func == "sigmoid" else 0, dtype_code(p.dtype),
+                                                     current_stream(dev)), "grouped_topk_planes")
+        return w, ids
     T, E = gating_output.shape
     w = torch.empty((T, topk), dtype=torch.float32, device=gating_output.device)
     ids = torch.empty((T, topk), dtype=torch.int32, device=gating_output.device)

@@ -110,3 +110,23 @@ def test_mla_decode_prep_rows_has_the_bits_of_the_launches_it_replaces(ops, T, H
     ops.store_kv_rows(pool_a, loc, l1)
     assert torch.equal(q_input, q_input_ref)
     assert torch.equal(pool_a.view(torch.uint8), pool_b.view(torch.uint8))
+
+
+@pytest.mark.parametrize("T", [1, 32, 64])
+@pytest.mark.parametrize("E,K,topk,groups,topk_group,biased", [(64, 2048, 6, 1, 1, False), (256, 7168, 8, 8, 4, True),
+                                                               (160, 1024, 6, 8, 3, False)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_grouped_topk_on_the_router_gemms_planes_equals_the_two_launches(ops, T, E, K, topk, groups, topk_group, biased, dtype):
+    """MoEGate on the weight-streaming GEMM, stopped before its K-slice reduction, + the routing kernel that sums the planes
+    (DeepseekV2MoE.forward for decode batches) against the finished GEMM + grouped_topk: same ids, same weights."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(T + E)
+    x = torch.randn(T, K, generator=g).to(dtype).to(dev)
+    w = (torch.randn(E, K, generator=g) * 0.05).to(dtype).to(dev)
+    bias = (torch.randn(E, generator=g) * 0.1).float().to(dev) if biased else None
+    scoring = "sigmoid" if biased else "softmax"
+    logits = ops.stream_linear(x, w)
+    w1, i1 = ops.grouped_topk(logits, topk, True, groups, topk_group, bias, scoring)
+    planes = ops.stream_linear_planes(x, w)
+    w2, i2 = ops.grouped_topk(planes, topk, True, groups, topk_group, bias, scoring)
+    assert torch.equal(i1, i2) and torch.equal(w1, w2)
