@@ -488,6 +488,13 @@ int semipd_moe_grouped_gemm_silu(void* c, const void* a, const void* w, const in
  * NULL.  Every intermediate is rounded to the activation type like the separate kernels round it. */
 int semipd_moe_sum_scale_add(void* out, const void* in, const void* addend, int64_t num_tokens, int topk, int64_t hidden,
                              float scale, int apply_scale, int dtype, void* stream);
+/* The same with the addend still in the fp32 K-slice planes [n_planes][num_tokens][hidden] of the GEMM that produces it
+ * (semipd_stream_linear_planes: the shared experts' down_proj of a decode batch): summed in slice order and rounded to
+ * dtype inside this launch -- that GEMM's own reduction -- then added.  Same bits, one launch less.  bf16 / f16.
+ * replaces DeepseekV2MLP.down_proj's output write + the tail of DeepseekV2MoE.forward (models/deepseek_v2.py:139-160). */
+int semipd_moe_sum_scale_add_planes(void* out, const void* in, const float* add_planes, int n_planes, int64_t plane_elems,
+                                    int64_t num_tokens, int topk, int64_t hidden, float scale, int apply_scale, int dtype,
+                                    void* stream);
 
 /* out[t,:] = sum_j in[t,j,:]   (vllm moe_sum, fused_moe.py:1144-1148) */
 int semipd_moe_sum(void* out, const void* in, int64_t num_tokens, int topk, int64_t hidden,

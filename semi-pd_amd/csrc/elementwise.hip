@@ -771,10 +771,13 @@ argmax_kernel(const T* __restrict__ logits, void* __restrict__ out, int64_t voca
 // moe_sum: out[t,:] = sum_j in[t,j,:]; the fused form continues in registers with the two element-wise ops that follow
 // it in DeepseekV2MoE.forward (models/deepseek_v2.py:139-160): * routed_scaling_factor, + shared_output -- each rounded to T
 // like the separate kernels round it, so the bits are those of the three-launch sequence
+// add_planes: the addend is still the fp32 K-slice planes [n_planes][tokens][hidden] of the GEMM that produces it (the shared
+// experts' down_proj on the weight-streaming kernel): summed in slice order and rounded to T here -- that GEMM's reduction
 template <typename T>
 __global__ void moe_sum_kernel(T* __restrict__ out, const T* __restrict__ in, int64_t num_tokens,
                                int topk, int hvec, float scale = 1.f, const T* __restrict__ addend = nullptr,
-                               int apply_scale = 0) {
+                               int apply_scale = 0, const float* __restrict__ add_planes = nullptr, int n_planes = 0,
+                               int64_t plane_elems = 0) {
   constexpr int V = Elem<T>::kVec;
   const int64_t total = num_tokens * hvec;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -800,6 +803,15 @@ __global__ void moe_sum_kernel(T* __restrict__ out, const T* __restrict__ in, in
       const Vec16<T> b = load16(addend + (t * hvec + c) * V);
 #pragma unroll
       for (int j = 0; j < V; ++j) o.e[j] = Elem<T>::from_f(Elem<T>::to_f(o.e[j]) + Elem<T>::to_f(b.e[j]));
+    }
+    if constexpr (V == 8) {
+      if (add_planes != nullptr) {
+        float f[8];
+        planes_sum8(add_planes + (t * hvec + c) * V, n_planes, plane_elems, f);
+#pragma unroll
+        for (int j = 0; j < V; ++j)
+          o.e[j] = Elem<T>::from_f(Elem<T>::to_f(o.e[j]) + Elem<T>::to_f(Elem<T>::from_f(f[j])));
+      }
     }
     store16(out + (t * hvec + c) * V, o);
   }
@@ -1254,6 +1266,28 @@ int semipd_moe_sum_scale_add(void* out, const void* in, const void* addend, int6
                        num_tokens, topk, (int)(hidden / V), scale, (const T*)addend, apply_scale);
   });
   return launch_status("moe_sum_scale_add");
+}
+
+/* semipd_moe_sum_scale_add whose addend is still the K-slice planes [n_planes][num_tokens][hidden] of the GEMM that produces
+ * it (semipd_stream_linear_planes: the shared experts' down_proj of a decode batch): one launch less, same bits. */
+int semipd_moe_sum_scale_add_planes(void* out, const void* in, const float* add_planes, int n_planes, int64_t plane_elems,
+                                    int64_t num_tokens, int topk, int64_t hidden, float scale, int apply_scale, int dtype,
+                                    void* stream) {
+  SEMIPD_CHECK_ARG(num_tokens >= 0 && topk > 0 && hidden > 0 && n_planes >= 1 && n_planes <= 64 &&
+                   plane_elems >= num_tokens * hidden, SEMIPD_EINVAL, "moe_sum_scale_add_planes: bad sizes");
+  if (num_tokens == 0) return 0;
+  SEMIPD_CHECK_ARG(out && in && add_planes, SEMIPD_EINVAL, "moe_sum_scale_add_planes: null pointer");
+  SEMIPD_CHECK_ARG(hidden % 8 == 0 && plane_elems % 4 == 0 && aligned16(out) && aligned16(in) && aligned16(add_planes), SEMIPD_EALIGN,
+                   "moe_sum_scale_add_planes: hidden %% 8 and 16-byte aligned pointers required");
+  SEMIPD_DISPATCH_HALF(dtype, T, {
+    const int64_t nv = num_tokens * (hidden / 8);
+    int blocks = (int)((nv + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL((moe_sum_kernel<T>), dim3(blocks), dim3(256), 0, as_stream(stream), (T*)out, (const T*)in,
+                       num_tokens, topk, (int)(hidden / 8), scale, (const T*)nullptr, apply_scale, add_planes, n_planes,
+                       plane_elems);
+  });
+  return launch_status("moe_sum_scale_add_planes");
 }
 
 }  // extern "C"

@@ -324,15 +324,19 @@ class FusedMoE(nn.Module):
             out[c0:c1] = comm.all_gather(padded).view(tp * per, H)[:n]
         return out
 
+    def route(self, hidden_states: torch.Tensor, router_logits):
+        """(topk_weights, topk_ids) of this layer's routing rule; router_logits a tensor or the router GEMM's K-slice planes."""
+        return select_experts(hidden_states, router_logits, self.top_k, self.use_grouped_topk, self.renormalize,
+                              self.topk_group, self.num_expert_group, self.correction_bias)
+
     def forward(self, hidden_states: torch.Tensor, router_logits: torch.Tensor, x_quant=None, out_scale: float = 1.0,
-                out_addend: Optional[torch.Tensor] = None) -> torch.Tensor:
+                out_addend: Optional[torch.Tensor] = None, topk=None) -> torch.Tensor:
         """out_scale / out_addend: `experts(x) * out_scale + out_addend` with the roundings of the separate element-wise
-        ops, in the launch that sums the top-k rows (not combined with reduce_results: the caller reduces afterwards)."""
+        ops, in the launch that sums the top-k rows (not combined with reduce_results: the caller reduces afterwards).
+        topk: (topk_weights, topk_ids) from self.route when the caller has routed already."""
         if (out_scale != 1.0 or out_addend is not None) and self.reduce_results and get_tensor_model_parallel_world_size() > 1:
             raise RuntimeError("FusedMoE: out_scale / out_addend cannot be combined with reduce_results")
-        topk_weights, topk_ids = select_experts(hidden_states, router_logits, self.top_k, self.use_grouped_topk,
-                                                self.renormalize, self.topk_group, self.num_expert_group,
-                                                self.correction_bias)
+        topk_weights, topk_ids = topk if topk is not None else self.route(hidden_states, router_logits)
         if self.quant_config:
             out = fused_experts_fp8(hidden_states, self.w13_weight, self.w2_weight, self.w13_weight_scale_inv,
                                     self.w2_weight_scale_inv, topk_weights, topk_ids, self.quant_config.weight_block_size,

@@ -86,10 +86,12 @@ class DeepseekV2MLP(nn.Module):
                                            params_dtype=dtype, quant_config=quant_config)
         self.act_fn = SiluAndMul()
 
-    def forward(self, x, x_quant=None):
+    def forward(self, x, x_quant=None, defer_down: bool = False):
+        """defer_down: the caller sums down_proj's K-slice planes itself (ops.SplitKPlanes for decode batches, a tensor
+        otherwise)."""
         qc = self.down_proj.quant_config
         if qc is None and self.gate_up_proj.quant_config is None:
-            return self.down_proj(gate_up_silu(x, self.gate_up_proj, self.act_fn))
+            return self.down_proj(gate_up_silu(x, self.gate_up_proj, self.act_fn), defer_reduce=defer_down)
         gate_up = self.gate_up_proj(x, x_quant=x_quant)
         if qc is not None and gate_up.dim() == 2:
             # block-fp8: SiLU * mul and the quantisation in front of down_proj in one kernel
@@ -143,8 +145,17 @@ class DeepseekV2MoE(nn.Module):
         qc = self.experts.quant_config
         if x_quant is None and qc is not None and self.shared_experts is not None and hidden_states.dim() == 2:
             x_quant = quantize_activation(hidden_states, qc.weight_block_size)
-        shared_output = self.shared_experts(hidden_states, x_quant=x_quant) if self.shared_experts is not None else None
         comm = self.experts.all_to_all_comm() if (self.tp_size > 1 and hidden_states.dim() == 2) else None
+        if (comm is None and self.experts.use_grouped_topk and qc is None and hidden_states.dim() == 2 and self.tp_size == 1
+                and hidden_states.shape[0] <= ops.STREAM_LINEAR_MAX_ROWS and stream_linear_enabled()
+                and os.environ.get("SEMIPD_MOE_SHARED_PLANES", "1") != "0"):
+            # decode batch of an unquantised model on one GPU: route first (the routing kernel sums the router GEMM's planes),
+            # then the shared experts, whose down_proj planes are summed by the launch that sums the top-k rows -- nothing
+            # else touches the GEMM workspace in between (the expert GEMMs have none)
+            topk = self.experts.route(hidden_states, self.gate(hidden_states, planes_ok=True))
+            shared = self.shared_experts(hidden_states, defer_down=True) if self.shared_experts is not None else None
+            return self.experts(hidden_states, None, out_scale=float(self.routed_scaling_factor), out_addend=shared, topk=topk)
+        shared_output = self.shared_experts(hidden_states, x_quant=x_quant) if self.shared_experts is not None else None
         # (the planes must be consumed by the next user of the GEMM workspace: the routing kernel at the top of self.experts)
         router_logits = self.gate(hidden_states, planes_ok=comm is None and self.experts.use_grouped_topk)
         if comm is not None:

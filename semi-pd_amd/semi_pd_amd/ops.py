@@ -859,6 +859,16 @@ def moe_sum_scale_add(x: torch.Tensor, scale: float = 1.0, addend: Optional[torc
     models/deepseek_v2.py:139-160): x [T, topk, H]; the multiply is skipped for scale == 1 like the model skips it."""
     T, k, H = x.shape
     out = torch.empty((T, H), dtype=x.dtype, device=x.device)
+    if isinstance(addend, SplitKPlanes):
+        # the addend's GEMM stopped before its K-slice reduction (the shared experts' down_proj): summed in this launch
+        if addend.shape != (T, H) or addend.dtype != x.dtype:
+            raise RuntimeError("moe_sum_scale_add: the addend's planes must hold a [T, H] result of the same dtype")
+        addend.check_live("moe_sum_scale_add")
+        check(_lib.load().semipd_moe_sum_scale_add_planes(ptr(out), ptr(x.contiguous()), ptr(addend.planes), addend.ksplit,
+                                                          addend.rows * addend.n, T, k, H, float(scale), int(scale != 1.0),
+                                                          dtype_code(x.dtype), current_stream(x.device)),
+              "moe_sum_scale_add_planes")
+        return out
     if addend is not None and (addend.shape != (T, H) or addend.dtype != x.dtype or not addend.is_contiguous()):
         raise RuntimeError("moe_sum_scale_add: addend must be a contiguous [T, H] tensor of the same dtype")
     check(_lib.load().semipd_moe_sum_scale_add(ptr(out), ptr(x.contiguous()), ptr(addend), T, k, H, float(scale),

@@ -130,3 +130,20 @@ def test_grouped_topk_on_the_router_gemms_planes_equals_the_two_launches(ops, T,
     planes = ops.stream_linear_planes(x, w)
     w2, i2 = ops.grouped_topk(planes, topk, True, groups, topk_group, bias, scoring)
     assert torch.equal(i1, i2) and torch.equal(w1, w2)
+
+
+@pytest.mark.parametrize("T", [1, 32, 64])
+@pytest.mark.parametrize("topk,H,K", [(6, 2048, 2816), (8, 7168, 256)])
+@pytest.mark.parametrize("scale", [1.0, 2.5])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_moe_sum_with_the_addends_planes_equals_the_finished_addend(ops, T, topk, H, K, scale, dtype):
+    """The tail of DeepseekV2MoE.forward with the shared experts' down_proj still in K-slice planes: the launch that sums the
+    top-k rows sums the planes too -- the bits of stream_linear followed by moe_sum_scale_add."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(T * topk + H)
+    x = torch.randn(T, topk, H, generator=g).to(dtype).to(dev)
+    a = torch.randn(T, K, generator=g).to(dtype).to(dev)
+    w = (torch.randn(H, K, generator=g) * 0.05).to(dtype).to(dev)
+    want = ops.moe_sum_scale_add(x, scale, ops.stream_linear(a, w))
+    got = ops.moe_sum_scale_add(x, scale, ops.stream_linear_planes(a, w))
+    assert torch.equal(got, want)
