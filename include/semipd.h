@@ -518,6 +518,13 @@ int semipd_per_token_group_quant_fp8(void* q, float* s, const void* x, int64_t n
 int semipd_fused_add_rmsnorm_quant_fp8(void* inout, void* residual, const void* weight, void* q, float* qs,
                                        int64_t num_tokens, int64_t hidden, float eps, int group_size, float q_eps,
                                        int dtype, void* stream);
+/* RMSNorm (no residual) of rows with a row stride, and the per-token-group fp8 quantisation of the result for the block-fp8
+ * layer behind it, in one kernel: out [num_tokens, hidden] (row stride out_stride), q [num_tokens, hidden] e4m3fn dense,
+ * qs [num_tokens, hidden / group_size].  The bytes of semipd_rmsnorm followed by semipd_per_token_group_quant_fp8.
+ * replaces q_a_layernorm + the quantisation in front of q_b_proj (models/deepseek_v2.py:640-650; fp8_utils.py:91-134). */
+int semipd_rmsnorm_quant_fp8(void* out, const void* input, const void* weight, void* q, float* qs, int64_t num_tokens,
+                             int64_t hidden, int64_t in_stride, int64_t out_stride, float eps, int group_size, float q_eps,
+                             int dtype, void* stream);
 /* SiluAndMul (layers/activation.py:41-44) and per_token_group_quant_fp8 of its output in one pass, as
  * fused_experts_impl runs them back to back between its two GEMMs (fused_moe.py:1104-1125):
  * x [num_rows, 2*d] (gate | up) bf16/f16 -> q [num_rows, d] fp8, s [num_rows, d / group_size].  Bytes and

@@ -1085,6 +1085,43 @@ int semipd_rope_kv_store_planes(void* q_out, const float* planes, int n_planes, 
   return launch_status("rope_kv_store_planes");
 }
 
+int semipd_rmsnorm_quant_fp8(void* out, const void* input, const void* weight, void* q, float* qs, int64_t num_tokens,
+                             int64_t hidden, int64_t in_stride, int64_t out_stride, float eps, int group_size, float q_eps,
+                             int dtype, void* stream) {
+  SEMIPD_CHECK_ARG(num_tokens >= 0 && hidden > 0 && num_tokens < (1ll << 31) && in_stride >= hidden && out_stride >= hidden,
+                   SEMIPD_EINVAL, "rmsnorm_quant_fp8: bad sizes");
+  if (num_tokens == 0) return 0;
+  SEMIPD_CHECK_ARG(out && input && weight && q && qs, SEMIPD_EINVAL, "rmsnorm_quant_fp8: null pointer");
+  SEMIPD_CHECK_ARG(group_size == 64 || group_size == 128 || group_size == 256 || group_size == 512, SEMIPD_ESHAPE,
+                   "rmsnorm_quant_fp8: group size %d is not one of 64, 128, 256, 512", group_size);
+  SEMIPD_CHECK_ARG(hidden % group_size == 0 && hidden <= 8 * 512 * 2, SEMIPD_ESHAPE,
+                   "rmsnorm_quant_fp8: hidden size %lld must be a multiple of the group size and at most 8192", (long long)hidden);
+  SEMIPD_CHECK_ARG(dtype == SEMIPD_BF16 || dtype == SEMIPD_F16, SEMIPD_EDTYPE, "rmsnorm_quant_fp8: bf16 / f16 only");
+  SEMIPD_CHECK_ARG(aligned16(out) && aligned16(input) && aligned16(weight) && in_stride % 8 == 0 && out_stride % 8 == 0 &&
+                       (reinterpret_cast<uintptr_t>(q) & 7u) == 0,
+                   SEMIPD_EALIGN, "rmsnorm_quant_fp8: unaligned pointer / row stride");
+  const int nvec = (int)(hidden / 8), lpg = group_size / 8;
+  // the launch shape of launch_rmsnorm: same reduction order, same bits as the unfused kernel
+  const int threads = nvec <= 64 ? 64 : nvec <= 128 ? 128 : nvec <= 1024 ? 256 : 512;
+  const int per = (nvec + threads - 1) / threads;
+  dim3 grid((unsigned)num_tokens), block(threads);
+  hipStream_t st = as_stream(stream);
+#define RNQ(T, MV)                                                                                                \
+  hipLaunchKernelGGL((rmsnorm_vec_kernel<T, MV, false, true>), grid, block, 0, st, (T*)out, (T*)const_cast<void*>(input), \
+                     (T*)nullptr, (const T*)weight, in_stride, out_stride, nvec, (int)hidden, eps, (uint8_t*)q, qs, lpg, q_eps)
+  if (dtype == SEMIPD_BF16) {
+    if (per <= 1) RNQ(bf16_t, 1);
+    else if (per <= 2) RNQ(bf16_t, 2);
+    else RNQ(bf16_t, 4);
+  } else {
+    if (per <= 1) RNQ(f16_t, 1);
+    else if (per <= 2) RNQ(f16_t, 2);
+    else RNQ(f16_t, 4);
+  }
+#undef RNQ
+  return launch_status("rmsnorm_quant_fp8");
+}
+
 int semipd_mla_decode_prep(void* q_nope_out, void* q_input, void* kv_buf, const float* planes, int n_planes,
                            int64_t plane_elems, const int64_t* loc, const float* cos_sin_cache, const int64_t* positions,
                            const void* norm_weight, float eps, int64_t num_tokens, int num_q_heads, int nope_dim, int rope_dim,

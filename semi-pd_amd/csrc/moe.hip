@@ -36,16 +36,28 @@ template <> struct MfmaG<f16_t> {
 constexpr int kMaxExperts = 512;
 constexpr int kMaxTopk = 32;
 
+// Wave-wide argmax (largest value, smallest index among equals) with DPP moves instead of ds_bpermute: the routing kernel
+// is one wave per token and a chain of ~100 dependent cross-lane steps (8 argmaxes of 12 shuffles each at top-8); a
+// ds_bpermute costs an LDS-crossbar round trip, a DPP move a few cycles.  quad_perm [1,0,3,2] / [2,3,0,1], row_half_mirror,
+// row_mirror make every row of 16 lanes uniform; row_bcast:15 (rows 1, 3) and row_bcast:31 (rows 2, 3) carry the result to
+// lane 63, which every lane reads.  max / argmax are exact, so the order of the combination does not matter.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void argmax_dpp_step(float& v, int& i) {
+  const float ov = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+  const int oi = __builtin_amdgcn_update_dpp(i, i, CTRL, ROW_MASK, 0xf, false);
+  const bool take = ov > v || (ov == v && oi < i);
+  v = take ? ov : v;
+  i = take ? oi : i;
+}
 __device__ inline void wave_argmax(float& v, int& i) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const float ov = __shfl_xor(v, o, 64);
-    const int oi = __shfl_xor(i, o, 64);
-    if (ov > v || (ov == v && oi < i)) {
-      v = ov;
-      i = oi;
-    }
-  }
+  argmax_dpp_step<0xB1, 0xf>(v, i);    // quad_perm [1,0,3,2]
+  argmax_dpp_step<0x4E, 0xf>(v, i);    // quad_perm [2,3,0,1]
+  argmax_dpp_step<0x141, 0xf>(v, i);   // row_half_mirror
+  argmax_dpp_step<0x140, 0xf>(v, i);   // row_mirror
+  argmax_dpp_step<0x142, 0xa>(v, i);   // row_bcast:15 into rows 1 and 3
+  argmax_dpp_step<0x143, 0xc>(v, i);   // row_bcast:31 into rows 2 and 3
+  v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+  i = __builtin_amdgcn_readlane(i, 63);
 }
 
 // mode: 0 = plain softmax top-k (fused_topk); 1 = grouped (grouped_topk / biased_grouped_topk)
@@ -101,18 +113,16 @@ moe_topk_kernel(const T* __restrict__ gating, const float* __restrict__ bias,
   __syncthreads();
   for (int e = lane; e < E; e += 64) choice[e] = score[e] + (bias ? bias[e] : 0.f);
   __syncthreads();
-  if (grouped) {
+  // (one group: it is the group that is selected and nothing is masked -- DeepSeek-V2-Lite; the scan below is a serial
+  //  walk over the group's experts by one lane per group)
+  if (grouped && num_group > 1) {
     const int gs = E / num_group;
     if (lane < num_group) {
       float best = -INFINITY, second = -INFINITY;
-      for (int j = 0; j < gs; ++j) {
+      for (int j = 0; j < gs; ++j) {   // branch-free top two: the loads pipeline
         const float x = choice[lane * gs + j];
-        if (x > best) {
-          second = best;
-          best = x;
-        } else if (x > second) {
-          second = x;
-        }
+        second = fmaxf(second, fminf(best, x));
+        best = fmaxf(best, x);
       }
       gscore[lane] = bias ? best + second : best;  // topk.py:140-144 vs :98-100
       gsel[lane] = 0;

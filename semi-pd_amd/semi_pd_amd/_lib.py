@@ -112,6 +112,7 @@ _SIGNATURES = {
                                     _i64, _i64, _i64, _i64, _i32, _i32, _vp],
     "semipd_grouped_topk_planes": [_vp, _i32, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "semipd_moe_sum_scale_add_planes": [_vp, _vp, _vp, _i32, _i64, _i64, _i32, _i64, _f32, _i32, _i32, _vp],
+    "semipd_rmsnorm_quant_fp8": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _i32, _f32, _i32, _vp],
     "semipd_bmm_nk": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp],
     "semipd_mla_decode_prep": [_vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _f32, _i64, _i32, _i32, _i32, _i32, _i64,
                                _i64, _i64, _i32, _i32, _vp],

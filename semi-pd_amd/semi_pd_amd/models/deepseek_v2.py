@@ -302,7 +302,16 @@ class DeepseekV2AttentionMLA(nn.Module):
         if self.q_lora_rank is not None:
             if q_a is None:
                 q_a = self.q_a_proj(hidden_states, x_quant=x_quant)
-            q = self.q_b_proj(self.q_a_layernorm(q_a))
+            qc = self.quant_config
+            if (qc is not None and q_a.dim() == 2 and q_a.shape[0] > 0 and self.q_lora_rank % int(qc.weight_block_size[1]) == 0
+                    and int(qc.weight_block_size[1]) in (64, 128, 256, 512) and self.q_lora_rank <= 8192
+                    and os.environ.get("SEMIPD_MLA_QA_NORM_QUANT", "1") != "0"):
+                # block-fp8: q_a_layernorm and the quantisation in front of q_b_proj in one kernel
+                x, xq = ops.rmsnorm_quant_fp8(q_a, self.q_a_layernorm.weight.data, self.q_a_layernorm.variance_epsilon,
+                                              int(qc.weight_block_size[1]))
+                q = self.q_b_proj(x, x_quant=xq)
+            else:
+                q = self.q_b_proj(self.q_a_layernorm(q_a))
         else:
             q = self.q_proj(hidden_states, x_quant=x_quant)
         return q.view(-1, self.num_local_heads, self.qk_head_dim)

@@ -1074,6 +1074,21 @@ def fused_add_rmsnorm_quant_fp8(input: torch.Tensor, residual: torch.Tensor, wei
     return x_q, x_s
 
 
+def rmsnorm_quant_fp8(input: torch.Tensor, weight: torch.Tensor, eps: float, group_size: int, q_eps: float = 1e-10):
+    """rmsnorm(input) plus per_token_group_quant_fp8 of the result in one kernel: (out, (x_q, x_s)); input may be a view
+    with a row stride (the q_a part of a merged GEMM output).  Same bytes as the two calls (semipd_rmsnorm_quant_fp8)."""
+    if input.dim() != 2 or input.stride(1) != 1 or weight.shape != (input.shape[1],) or weight.dtype != input.dtype:
+        raise RuntimeError("rmsnorm_quant_fp8: a 2-D input with contiguous rows and a matching weight expected")
+    T, H = input.shape
+    out = torch.empty((T, H), dtype=input.dtype, device=input.device)
+    x_q = torch.empty((T, H), dtype=FP8_DTYPE, device=input.device)
+    x_s = torch.empty((T, H // group_size), dtype=torch.float32, device=input.device)
+    check(_lib.load().semipd_rmsnorm_quant_fp8(ptr(out), ptr(input), ptr(weight), ptr(x_q), ptr(x_s), T, H, input.stride(0),
+                                               out.stride(0), float(eps), int(group_size), float(q_eps),
+                                               dtype_code(input.dtype), current_stream(input.device)), "rmsnorm_quant_fp8")
+    return out, (x_q, x_s)
+
+
 def silu_and_mul_quant_fp8(x: torch.Tensor, group_size: int, eps: float = 1e-10):
     """silu_and_mul(x) followed by per_token_group_quant_fp8(., group_size) in one kernel: (x_q [..., d], x_s
     [..., d / group_size]) for x [..., 2 d]; the same bytes as the two calls (fused_moe.py:1104-1125)."""

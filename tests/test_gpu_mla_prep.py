@@ -147,3 +147,20 @@ def test_moe_sum_with_the_addends_planes_equals_the_finished_addend(ops, T, topk
     want = ops.moe_sum_scale_add(x, scale, ops.stream_linear(a, w))
     got = ops.moe_sum_scale_add(x, scale, ops.stream_linear_planes(a, w))
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("T", [1, 33, 64, 300])
+@pytest.mark.parametrize("H,group", [(1536, 128), (512, 64), (4096, 128)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_rmsnorm_quant_fp8_has_the_bytes_of_the_two_launches(ops, T, H, group, dtype):
+    """q_a_layernorm + the per-token-group quantisation in front of q_b_proj (block-fp8 DeepSeek-V3), on a strided view."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(T + H)
+    wide = torch.randn(T, H + 576, generator=g).to(dtype).to(dev)
+    x = wide[:, :H]
+    w = (torch.rand(H, generator=g) + 0.5).to(dtype).to(dev)
+    want = ops.rmsnorm(x, w, 1e-6)
+    want_q, want_s = ops.per_token_group_quant_fp8(want.contiguous(), group)
+    out, (xq, xs) = ops.rmsnorm_quant_fp8(x, w, 1e-6, group)
+    assert torch.equal(out, want)
+    assert torch.equal(xq.view(torch.uint8), want_q.view(torch.uint8)) and torch.equal(xs, want_s)
