@@ -241,6 +241,10 @@ def dense_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
             and not ops.dense_gemm_is_tuned(weight) and ops.gemm_tall_is_supported(x, weight)):
         # tall decode batch (65 .. 256 rows): the tiled ping-pong GEMM (csrc/gemm8p.hip)
         return ops.gemm_tall(x, weight)
+    if (_STREAM_LINEAR["enabled"] and bias is None and x.dim() == 2 and x.shape[0] > GEMM_TALL_MAX_ROWS
+            and ops.tall_preferred(weight, x.shape[0]) and ops.gemm_tall_is_supported(x, weight)):
+        # prefill-sized batch of a shape for which the tiled GEMM beat the library's measured winner on this share
+        return ops.gemm_tall(x, weight)
     if x.dim() == 2 and x.shape[0] > 0 and ops.dense_gemm_is_tuned(weight) and x.stride(1) == 1:
         # prefill-sized batch of a layer whose library solutions were timed on this process's CU share at start-up
         # (ModelRunner.tune_dense_gemms): the measured winner instead of the library's whole-device heuristic
@@ -261,6 +265,12 @@ def gate_up_silu(x: torch.Tensor, gate_up_proj: "MergedColumnParallelLinear", ac
             and not ops.dense_gemm_is_tuned(gate_up_proj.weight)
             and ops.gemm_tall_is_supported(x, gate_up_proj.weight, fuse_silu_mul=True)):
         return ops.gemm_tall(x, gate_up_proj.weight, fuse_silu_mul=True)   # SiLU * mul in the GEMM's epilogue
+    if (_STREAM_LINEAR["enabled"] and gate_up_proj.quant_config is None and gate_up_proj.bias is None
+            and isinstance(act_fn, SiluAndMul) and x.dim() == 2 and x.shape[0] > GEMM_TALL_MAX_ROWS
+            and ops.tall_preferred(gate_up_proj.weight, x.shape[0], fuse_silu_mul=True)
+            and ops.gemm_tall_is_supported(x, gate_up_proj.weight, fuse_silu_mul=True)):
+        # prefill-sized batch: the tiled GEMM with the SiLU epilogue beat the library's winner + silu_and_mul on this share
+        return ops.gemm_tall(x, gate_up_proj.weight, fuse_silu_mul=True)
     return act_fn(gate_up_proj(x))
 
 

@@ -436,10 +436,12 @@ class ModelRunner:
                     continue
                 if ops.dense_gemm_import(text, shapes) > 0:
                     logger.warning("library GEMM table for %d CUs taken from %s", self.num_cus_owned, os.path.join(d, name))
+                    self.time_tall_against_library()
                     return ops.dense_gemm_report()
         with torch.cuda.device(self.device):
             for n, k, dt in shapes:
                 ops.dense_gemm_tune(n, k, list(rows), dt, num_full_search=num_full_search)
+        self.time_tall_against_library()
         report = ops.dense_gemm_report()
         if os.environ.get("SEMIPD_DG_CACHE", "1") != "0":
             mine = "".join(ln + "\n" for ln in report.splitlines() if ln.startswith(f"cus={self.num_cus_owned} "))
@@ -454,6 +456,57 @@ class ModelRunner:
                 except OSError:
                     continue
         return ops.dense_gemm_report()
+
+    def time_tall_against_library(self, rows=(512, 1024, 1536, 2048, 3072, 4096, 8192)) -> str:
+        """For every dense weight of the model: the tiled ping-pong GEMM (csrc/gemm8p.hip; with its SiLU * mul epilogue for a
+        merged gate_up weight) against the library's measured winner (+ silu_and_mul) at prefill row counts, on this process's
+        CUs and next to whatever runs beside it right now; where it wins by 3 % the layer takes it (ops.tall_preferred).
+        A fraction of a second per start: not cached.  SEMIPD_TALL_PREFILL=0 turns it off."""
+        import os
+        from semi_pd_amd import ops
+        from semi_pd_amd.layers.basic import ColumnParallelLinear, MergedColumnParallelLinear, RowParallelLinear
+        if os.environ.get("SEMIPD_TALL_PREFILL", "1") == "0":
+            return ""
+        seen, lines = set(), []
+
+        def timed(fn, iters=3):
+            fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1) / iters * 1e3
+
+        with torch.cuda.device(self.device):
+            for m in self.model.modules():
+                if not isinstance(m, (ColumnParallelLinear, RowParallelLinear)) or getattr(m, "quant_config", None) is not None:
+                    continue
+                w = m.weight
+                if w.dim() != 2 or w.dtype not in (torch.bfloat16, torch.float16) or w.device.type != "cuda" or m.bias is not None:
+                    continue
+                for silu in ((False, True) if isinstance(m, MergedColumnParallelLinear) and w.shape[0] % 2 == 0 else (False,)):
+                    key = (int(w.shape[0]), int(w.shape[1]), w.dtype, silu)
+                    if key in seen or not ops.dense_gemm_is_tuned(w):
+                        continue
+                    seen.add(key)
+                    wins = []
+                    for r in rows:
+                        x = torch.randn(r, w.shape[1], device=self.device, dtype=torch.float32).to(w.dtype)
+                        if not ops.gemm_tall_is_supported(x, w, fuse_silu_mul=silu):
+                            continue
+                        t_lib = timed((lambda: ops.silu_and_mul(ops.dense_gemm(x, w))) if silu else (lambda: ops.dense_gemm(x, w)))
+                        t_tall = timed(lambda: ops.gemm_tall(x, w, fuse_silu_mul=silu))
+                        wins.append((r, t_tall < 0.97 * t_lib))
+                        lines.append(f"n={w.shape[0]} k={w.shape[1]} silu={int(silu)} rows={r}: library {t_lib:.1f} us, tiled {t_tall:.1f} us"
+                                     f"{'  <- tiled' if wins[-1][1] else ''}")
+                        del x
+                    ops.set_tall_preference(w.shape[0], w.shape[1], w.dtype, silu, wins)
+        text = "\n".join(lines)
+        if lines:
+            logger.warning("tiled GEMM against the library's measured winners on %d CUs:\n%s", self.num_cus_owned, text)
+        return text
 
     # ------------------------------------------------------------------------------------ backend / graphs
     def init_attention_backend(self):

@@ -442,6 +442,26 @@ def dense_gemm_is_tuned(weight: torch.Tensor) -> bool:
     return _DENSE_GEMM["ready"] and (weight.shape[0], weight.shape[1], weight.dtype) in _DENSE_GEMM["tuned"]
 
 
+# Prefill-sized batches of a layer whose weight shape was timed at start-up: where the tiled ping-pong GEMM (csrc/gemm8p.hip)
+# beat the library's measured winner on this process's CU share (ModelRunner.tune_dense_gemms: e.g. down_proj at 1024 rows on
+# 208 CUs, 117 us against 155; gate_up + SiLU at 2048 rows, 443 against 457 + 50).  (n, k, dtype, fuse_silu) -> [(rows, bool)]
+_TALL_PREF = {}
+
+
+def set_tall_preference(n: int, k: int, dtype: torch.dtype, fuse_silu_mul: bool, rows_and_wins) -> None:
+    _TALL_PREF[(int(n), int(k), dtype, bool(fuse_silu_mul))] = sorted((int(r), bool(w)) for r, w in rows_and_wins)
+
+
+def tall_preferred(weight: torch.Tensor, rows: int, fuse_silu_mul: bool = False) -> bool:
+    """Did gemm_tall win at the timed row count nearest (in log distance) to `rows` for this weight's shape?"""
+    ent = _TALL_PREF.get((weight.shape[0], weight.shape[1], weight.dtype, bool(fuse_silu_mul)))
+    if not ent:
+        return False
+    import math
+    best = min(ent, key=lambda rw: abs(math.log2(rw[0]) - math.log2(max(1, rows))))
+    return best[1]
+
+
 def dense_gemm_report() -> str:
     import ctypes as _C
     lib = _lib.load()
