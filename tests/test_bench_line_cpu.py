@@ -94,9 +94,10 @@ def test_the_bench_line_is_assembled_with_every_contract_field(monkeypatch, caps
     assert cfgd["prefill_gemm"].startswith("library solutions timed on the prefill share") and "decode step" in cfgd["prefill_gemm"]
     if expect_static:
         assert (cfgd["prefill_cu_percent"], cfgd["decode_cu_percent"]) == (80, 100)
-        # the main engine, the literal 50 / 50 engine, and one engine each for BASELINE configs 1 and 3
-        assert d["static_split_50_50"]["output_tok_s"] > 0 and len(FakeEngine.instances) == 4
+        # the main engine, the literal 50 / 50 engine, the P88 / D100 engine, and one engine each for BASELINE configs 1 and 3
+        assert d["static_split_50_50"]["output_tok_s"] > 0 and len(FakeEngine.instances) == 5
         assert FakeEngine.instances[1].sa.cu_mask_mode == "env" and FakeEngine.instances[0].sa.cu_mask_mode == "dynamic"
+        assert d["prefill_share_88"]["output_tok_s"] > 0 and FakeEngine.instances[2].sa.prefill_cu_percent == 88
         assert d["config1_opt_125m"]["output_tok_s"] > 0 and d["config3_deepseek_v2_lite"]["output_tok_s"] > 0
         assert [s["request_rate"] for s in d["qps_sweep"]] == [8.0, 32.0] and d["qps_sweep"][0]["output_len"] == 6
         assert d["saturation"]["output_tokens"] == 6 * 4
