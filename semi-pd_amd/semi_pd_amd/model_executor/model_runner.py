@@ -468,6 +468,7 @@ class ModelRunner:
         if os.environ.get("SEMIPD_TALL_PREFILL", "1") == "0":
             return ""
         seen, lines = set(), []
+        margin = float(os.environ.get("SEMIPD_TALL_MARGIN", "0.97"))   # the tiled kernel is taken below margin x the library's time
 
         def timed(fn, iters=3):
             fn()
@@ -498,7 +499,7 @@ class ModelRunner:
                             continue
                         t_lib = timed((lambda: ops.silu_and_mul(ops.dense_gemm(x, w))) if silu else (lambda: ops.dense_gemm(x, w)))
                         t_tall = timed(lambda: ops.gemm_tall(x, w, fuse_silu_mul=silu))
-                        wins.append((r, t_tall < 0.97 * t_lib))
+                        wins.append((r, t_tall < margin * t_lib))
                         lines.append(f"n={w.shape[0]} k={w.shape[1]} silu={int(silu)} rows={r}: library {t_lib:.1f} us, tiled {t_tall:.1f} us"
                                      f"{'  <- tiled' if wins[-1][1] else ''}")
                         del x
