@@ -633,13 +633,16 @@ int semipd_ar_all_gather(void* comm, const void* in, void* out, size_t bytes_per
  *   [tokens, top_k] and routing weights; expert e lives on rank e / experts_per_rank.  It receives one row per (token, j)
  *   entry of ANY rank routed to one of its experts, ordered by sender rank, token, j: recv_x [max_recv, row_bytes],
  *   recv_expert (local expert id), recv_weight; recv_count[0] = rows received (rows beyond max_recv are dropped: the caller
- *   checks recv_count <= max_recv); send_within [tokens, top_k] = position of this rank's entry among its entries to the same
+ *   checks recv_count <= max_recv; max_recv MUST be the same number on every rank -- the way back relies on it); send_within [tokens, top_k] = position of this rank's entry among its entries to the same
  *   destination; counts_all [world, world] = entries every sender sends to every destination.  Every rank must call it in the
  *   same sequence position; tokens may differ per rank (also 0).  Staging needs 256 + 3 * align256(4 tokens top_k) +
  *   tokens * row_bytes bytes <= semipd_ar_max_bytes.  Capturable; does not synchronise.
  * semipd_ep_combine: y = this rank's expert outputs for the rows it received, in the received order (already multiplied by
  *   their routing weight); out[t] = T(sum over j, in j order, fp32, of the row that belongs to (t, j)): tokens, topk_ids,
- *   send_within, counts_all as in / from the dispatch.  256 + max_recv * 2 * hidden bytes <= semipd_ar_max_bytes. */
+ *   send_within, counts_all as in / from the dispatch; max_recv = the dispatch's (the same on every rank): an entry whose
+ *   position at its destination is >= max_recv was dropped there and contributes ZERO here (never a read behind the staged
+ *   rows) -- a caller that can overflow checks recv_count after the dispatch.  256 + max_recv * 2 * hidden bytes <=
+ *   semipd_ar_max_bytes. */
 int semipd_ep_dispatch(void* comm, const void* x, const int32_t* topk_ids, const float* topk_weights, int64_t tokens, int top_k,
                        int64_t row_bytes, int experts_per_rank, void* recv_x, int32_t* recv_expert, float* recv_weight,
                        int64_t max_recv, int32_t* recv_count, int32_t* send_within, int32_t* counts_all, void* stream);

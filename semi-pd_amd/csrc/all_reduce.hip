@@ -380,7 +380,8 @@ template <typename T, int NR>
 __global__ void __launch_bounds__(kArThreads) ep_combine_pull_kernel(ArPeers p, const int32_t* __restrict__ ids,
                                                                      const int32_t* __restrict__ within,
                                                                      const int32_t* __restrict__ counts_all, int tokens, int top_k,
-                                                                     int experts_per_rank, int64_t row_vecs, uint4* __restrict__ out) {
+                                                                     int experts_per_rank, int64_t row_vecs, int64_t max_recv,
+                                                                     uint4* __restrict__ out) {
   constexpr int V = Elem<T>::kVec;
   const uint32_t seq = ar_begin(p);
   const uint32_t buf = seq & 1u;
@@ -409,9 +410,13 @@ __global__ void __launch_bounds__(kArThreads) ep_combine_pull_kernel(ArPeers p, 
       const int d = ids[e] / experts_per_rank;
       const int64_t pos = (int64_t)s_off[d] + within[e];
       uint4 v = make_uint4(0, 0, 0, 0);
+      // an entry the destination's dispatch dropped (position >= max_recv, the same bound on every rank) was never
+      // computed and never staged: it contributes zero instead of whatever lies behind the staged rows
+      if (pos < max_recv) {
 #pragma unroll
-      for (int r = 0; r < NR; ++r)
-        if (r == d) v = ybase[r][pos * row_vecs + c];
+        for (int r = 0; r < NR; ++r)
+          if (r == d) v = ybase[r][pos * row_vecs + c];
+      }
       const T* ev = reinterpret_cast<const T*>(&v);
 #pragma unroll
       for (int q = 0; q < V; ++q) acc[q] += Elem<T>::to_f(ev[q]);
@@ -671,7 +676,7 @@ int semipd_ep_combine(void* comm, const void* y, const int32_t* recv_count, int6
   }
 #define EP_COMBINE(TT, NRV)                                                                                                 \
   hipLaunchKernelGGL((ep_combine_pull_kernel<TT, NRV>), dim3((unsigned)c->max_blocks), dim3(kArThreads), 0, s, c->peers,    \
-                     topk_ids, send_within, counts_all, (int)tokens, top_k, experts_per_rank, row_bytes / 16, (uint4*)out)
+                     topk_ids, send_within, counts_all, (int)tokens, top_k, experts_per_rank, row_bytes / 16, max_recv, (uint4*)out)
 #define EP_COMBINE_W(TT)            \
   switch (c->world) {               \
     case 2: EP_COMBINE(TT, 2); break; \

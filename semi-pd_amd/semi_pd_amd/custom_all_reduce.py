@@ -193,10 +193,13 @@ class CustomAllreduce:
 
     # ------------------------------------------------------------------ expert-parallel all-to-all
     def ep_dispatch(self, x: torch.Tensor, topk_ids: torch.Tensor, topk_weights: torch.Tensor, experts_per_rank: int,
-                    max_recv: int):
+                    max_recv: int, check_overflow: Optional[bool] = None):
         """csrc/all_reduce.hip: semipd_ep_dispatch (oracle/ops.py: ep_dispatch).  x [T, H] (this rank's tokens), topk_ids
         [T, k] int32 GLOBAL expert ids, topk_weights [T, k] fp32.  Returns a state dict with the received rows (recv_x
-        [max_recv, H], recv_expert, recv_weight, recv_count on the device) and what ep_combine needs to find the way back."""
+        [max_recv, H], recv_expert, recv_weight, recv_count on the device) and what ep_combine needs to find the way back.
+        max_recv must be the SAME on every rank.  Rows beyond it are dropped (and contribute zero in ep_combine): with
+        check_overflow (default: outside graph capture, whenever max_recv is below world x T x k, the most this rank could
+        receive from ranks with as many tokens) the call reads recv_count back and raises instead."""
         T, H = x.shape
         k = topk_ids.shape[1]
         assert x.is_contiguous() and topk_ids.dtype == torch.int32 and topk_weights.dtype == torch.float32
@@ -216,6 +219,13 @@ class CustomAllreduce:
                                           _lib.ptr(st["recv_expert"]), _lib.ptr(st["recv_weight"]), int(max_recv),
                                           _lib.ptr(st["recv_count"]), _lib.ptr(st["send_within"]), _lib.ptr(st["counts_all"]),
                                           stream), "ep_dispatch")
+        if check_overflow is None:
+            check_overflow = max_recv < self.world_size * T * k and not torch.cuda.is_current_stream_capturing()
+        if check_overflow:
+            got = int(st["recv_count"].item())
+            if got > max_recv:
+                raise RuntimeError(f"ep_dispatch: {got} rows routed to rank {self.rank}'s experts, max_recv = {max_recv}: "
+                                   "rows were dropped (size max_recv for the worst case or check recv_count yourself)")
         return st
 
     def ep_combine(self, y: torch.Tensor, st: dict) -> torch.Tensor:

@@ -173,6 +173,10 @@ def run_scheduler_process(server_args: ServerArgs, port_args: SemiPDPortArgs, gp
                           "tp_rank": tp_rank, "hsa_cu_mask": os.environ.get("HSA_CU_MASK", ""),
                           "custom_all_reduce": get_custom_all_reduce() is not None})
         sched.event_loop_normal()
+        # orderly end: nothing in flight, the created streams gone before the runtime's exit handlers run
+        torch.cuda.synchronize()
+        if getattr(mr, "cu_share", None) is not None:
+            mr.cu_share.close()
     except Exception:
         msg = traceback.format_exc()
         logger.error("scheduler hit an exception: %s", msg)
@@ -267,7 +271,7 @@ class Engine:
             old = {k: os.environ.get(k) for k in env_add}
             os.environ.update(env_add)   # like engine.py:591-593: set the share, then fork
             try:
-                p = ctx.Process(target=run_scheduler_process,
+                p = ctx.Process(target=run_scheduler_process, name=f"semipd-{role.name.lower()}-tp{tp_rank}",
                                 args=(sa, self.port_args, gpu_id, tp_rank, role, queues[tp_rank], writer, paths))
                 p.start()
             finally:
@@ -481,8 +485,12 @@ class Engine:
             p.join(timeout=join_s)
         for p in self.procs:
             if p.is_alive():
+                logger.warning("scheduler process %s still alive %.0f s after the shutdown request: terminating it", p.name, join_s)
                 p.terminate()
                 p.join(timeout=5)
+            elif p.exitcode not in (0, None):
+                # (a process that dies on the way out also loses whatever a profiler attached to it would have written)
+                logger.warning("scheduler process %s exited with code %s", p.name, p.exitcode)
         if self.is_driver and hasattr(self, "recv_from_scheduler"):
             self.recv_from_scheduler.close()
 

@@ -92,6 +92,20 @@ class CuShare:
     def step(self) -> str:
         return self.activate(self.choose())
 
+    def close(self) -> None:
+        """Orderly end of the instance: everything queued has run, torch is back on the NULL stream and the CU-masked stream
+        is destroyed while the runtime is still up (a masked stream left to the process's exit handlers took the prefill
+        process down with SIGSEGV inside __cxa_finalize -- and with it whatever a profiler attached to it had collected)."""
+        dev = self.mr.device
+        torch.cuda.synchronize(dev)
+        full = torch.cuda.default_stream(dev)
+        torch.cuda.set_stream(full)
+        self.active = None
+        for name, st in list(self.streams.items()):
+            if isinstance(st, torch.cuda.ExternalStream) and st.cuda_stream != full.cuda_stream:
+                _lib.check(_lib.load().semipd_stream_destroy(C.c_void_p(st.cuda_stream)), "stream_destroy")
+            self.streams[name] = full
+
     def publish(self, busy: int) -> None:
         if self.board is not None:
             self.board.publish(self.role, busy)

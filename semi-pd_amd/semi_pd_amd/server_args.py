@@ -13,6 +13,9 @@ import torch
 from semi_pd_amd.semi_pd.utils import DECODE_ENGINE_SM_PERCENTILE, PREFILL_ENGINE_SM_PERCENTILE
 
 
+CU_MASK_MODES = ("env", "none", "dynamic")
+
+
 @dataclasses.dataclass
 class ServerArgs:
     model_config: Any = None                 # LlamaConfig / OPTConfig / DeepseekV2Config; read from
@@ -59,11 +62,12 @@ class ServerArgs:
     decode_cu_percent: int = DECODE_ENGINE_SM_PERCENTILE
     # "env": process-wide HSA_CU_MASK per instance (static shares) | "none" | "dynamic": unmasked processes, each with a
     # CU-masked stream over its share and a stream over every CU, chosen per decode step / prefill batch from what the
-    # other instance has in flight (semi_pd/share_board.py, model_executor/cu_share.py)
-    cu_mask_mode: str = "env"
+    # other instance has in flight (semi_pd/share_board.py, model_executor/cu_share.py).  The default is the policy the
+    # bench line reports (bench.py: P80 / D100 work-conserving): a server launched from the CLI runs what was measured
+    cu_mask_mode: str = "dynamic"
     # dynamic mode: from this many waiting prompt tokens on a prefill batch takes every CU even while the decode
     # instance is busy (an overloaded GPU: throughput first).  0 = never
-    prefill_backlog_full_tokens: int = 0
+    prefill_backlog_full_tokens: int = 8192
     test_plugin: Optional[str] = None        # tests only: a file every scheduler process executes at start-up (fault injection)
     prefill_stream_priority: int = 0         # HIP stream priority of the instance's compute stream: 0 normal, -1 high
     decode_stream_priority: int = 0
@@ -78,6 +82,18 @@ class ServerArgs:
     collect_kernel_timing: bool = False
 
     def __post_init__(self):
+        if self.cu_mask_mode not in CU_MASK_MODES:
+            raise ValueError(f"cu_mask_mode must be one of {CU_MASK_MODES}, got {self.cu_mask_mode!r}")
+        if self.prefill_backlog_full_tokens < 0:
+            raise ValueError("prefill_backlog_full_tokens must be >= 0 (0 = never take every CU because of the backlog)")
+        for name in ("prefill_cu_percent", "decode_cu_percent"):
+            if not 1 <= int(getattr(self, name)) <= 100:
+                raise ValueError(f"{name} must be in 1 .. 100, got {getattr(self, name)}")
+        if self.cu_mask_mode == "dynamic" and self.enable_semi_pd and (self.prefill_stream_priority or self.decode_stream_priority):
+            # model_executor/cu_share.py installs the NULL stream / the CU-masked stream as the instance's current stream:
+            # a prioritised stream set up before it would be silently dropped
+            raise ValueError("stream priorities need --cu-mask-mode env or none: in dynamic mode every instance runs on its "
+                             "CU-masked stream or the NULL stream (model_executor/cu_share.py)")
         if self.model_config is None and self.model_path:
             from semi_pd_amd.model_loader import load_hf_config
             self.model_config = load_hf_config(self.model_path)
@@ -162,6 +178,16 @@ def add_cli_args(parser):
                    help="share of the CUs given to the prefill instance (SEMI_PD_PREFILL_SM_PERCENTILE)")
     p.add_argument("--decode-cu-percent", type=int, default=DECODE_ENGINE_SM_PERCENTILE,
                    help="share of the CUs given to the decode instance (SEMI_PD_DECODE_SM_PERCENTILE)")
+    p.add_argument("--cu-mask-mode", type=str, default="dynamic", choices=list(CU_MASK_MODES),
+                   help="how the shares are enforced: dynamic = unmasked processes, a CU-masked stream per instance, every CU "
+                        "while the other instance is idle (the measured default); env = static HSA_CU_MASK per process; "
+                        "none = no mask")
+    p.add_argument("--prefill-backlog-full-tokens", type=int, default=8192,
+                   help="dynamic mode: waiting prompt tokens from which a prefill batch takes every CU (0 = never)")
+    p.add_argument("--prefill-stream-priority", type=int, default=0, choices=[-1, 0, 1],
+                   help="HIP stream priority of the prefill instance (env / none modes; -1 = high)")
+    p.add_argument("--decode-stream-priority", type=int, default=0, choices=[-1, 0, 1],
+                   help="HIP stream priority of the decode instance (env / none modes; -1 = high)")
     p.add_argument("--quantization", type=str, default=None, choices=[None, "fp8"],
                    help="fp8 = block-scaled e4m3fn checkpoint (quantization_config with weight_block_size); with "
                         "--load-format dummy it makes the seeded weights block-quantised")
@@ -197,7 +223,10 @@ def from_cli_args(args) -> ServerArgs:
         disable_cuda_graph=args.disable_cuda_graph, disable_custom_all_reduce=args.disable_custom_all_reduce,
         enable_ep_moe=args.enable_ep_moe, enable_ep_all_to_all=args.enable_ep_all_to_all, disable_overlap_schedule=args.disable_overlap_schedule, cuda_graph_max_bs=args.cuda_graph_max_bs,
         enable_semi_pd=args.enable_semi_pd, prefill_cu_percent=args.prefill_cu_percent,
-        decode_cu_percent=args.decode_cu_percent, attention_backend=args.attention_backend,
+        decode_cu_percent=args.decode_cu_percent, cu_mask_mode=args.cu_mask_mode,
+        prefill_backlog_full_tokens=args.prefill_backlog_full_tokens,
+        prefill_stream_priority=args.prefill_stream_priority, decode_stream_priority=args.decode_stream_priority,
+        attention_backend=args.attention_backend,
         sampling_backend=args.sampling_backend, triton_attention_num_kv_splits=args.triton_attention_num_kv_splits)
     if args.quantization == "fp8":
         # server_args.py --quantization: the checkpoint decides (config.json: quantization_config); the flag

@@ -83,6 +83,36 @@ def main():
         same(f"case {seed}: all-reduce after", ar.all_reduce(v[rank].to(dev)), all_reduce_sum(v, torch.bfloat16))
         launched.append(seed)
 
+    # overflow: max_recv (the same on every rank) below what the routing sends -- the dispatch keeps the first max_recv rows
+    # and reports the full count, the way back counts the dropped entries as zero rows (never a read behind the staged rows),
+    # and the wrapper's check raises on the ranks that overflowed
+    seed, tpr, k, H, E, dtype = 6, [24] * world, 2, 128, 2 * world, torch.bfloat16
+    xs, ids, ws = make_case(seed, tpr, k, H, E, dtype)
+    epr, max_recv = E // world, 8
+    want_x, want_e, want_w, counts, pos = ep_dispatch(xs, ids, ws, epr)
+    st = ar.ep_dispatch(xs[rank].to(dev), ids[rank].to(dev), ws[rank].to(dev), epr, max_recv, check_overflow=False)
+    n = int(st["recv_count"].item())
+    same("overflow: count", torch.tensor([n]), torch.tensor([want_x[rank].shape[0]]))
+    kept = min(n, max_recv)
+    same("overflow: kept rows", st["recv_x"][:kept], want_x[rank][:kept])
+    y = torch.zeros(max_recv, H, dtype=dtype, device=dev)
+    y[:kept] = expert_fn(st["recv_x"][:kept], st["recv_expert"][:kept], st["recv_weight"][:kept], dtype)
+    ys = []
+    for d in range(world):
+        yd = expert_fn(want_x[d], want_e[d], want_w[d], dtype)
+        yd[max_recv:] = 0
+        ys.append(yd)
+    same("overflow: combined", ar.ep_combine(y, st), ep_combine(ys, ids, pos, epr, dtype)[rank])
+    raised = False
+    try:
+        st = ar.ep_dispatch(xs[rank].to(dev), ids[rank].to(dev), ws[rank].to(dev), epr, max_recv)
+    except RuntimeError as e:
+        raised = "rows were dropped" in str(e)
+    same("overflow: the wrapper raises where rows were dropped", torch.tensor([raised]), torch.tensor([n > max_recv]))
+    # (keep the call sequence of the ranks aligned: the dispatch above was launched on every rank before any raise; `st`
+    #  is the first dispatch's state where the second raised -- the same routing)
+    ar.ep_combine(torch.zeros(max_recv, H, dtype=dtype, device=dev), st)
+
     # back to back without host synchronisation: 12 dispatch + combine rounds, alternating shapes, results checked at the end
     pending = []
     for i in range(12):

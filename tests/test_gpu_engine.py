@@ -34,8 +34,10 @@ def tiny_llama():
 
 def server_args(cfg, **kw):
     from semi_pd_amd.server_args import ServerArgs
+    # (static HSA_CU_MASK shares unless a test asks otherwise: one set of decode graphs per engine; the work-conserving
+    #  default of ServerArgs is exercised by test_gpu_cu_share.py, test_gpu_full_depth.py and the launch_server test)
     base = dict(model_config=cfg, context_length=384, max_running_requests=24, max_total_tokens=6000,
-                cuda_graph_max_bs=16, chunked_prefill_size=8192, watchdog_timeout=120.0)
+                cuda_graph_max_bs=16, chunked_prefill_size=8192, watchdog_timeout=120.0, cu_mask_mode="env")
     base.update(kw)
     return ServerArgs(**base)
 

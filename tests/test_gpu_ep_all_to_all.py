@@ -15,4 +15,4 @@ def test_dispatch_and_combine_match_the_oracle_permutation_bit_for_bit(device, w
     reports = run_world(world, worker="ep_worker.py", timeout=300)
     assert sorted(r["rank"] for r in reports) == list(range(world))
     for r in reports:
-        assert r["cases"] == 5 * 8 + 12 + 3 and not r["bad"], r["bad"][:6]
+        assert r["cases"] == 5 * 8 + 4 + 12 + 3 and not r["bad"], r["bad"][:6]

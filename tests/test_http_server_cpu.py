@@ -217,6 +217,20 @@ def test_cli_flags_of_the_reference_parse(tmp_path):
     assert sa.triton_attention_num_kv_splits is None          # split count chosen per batch unless the flag is given
     sa = from_cli_args(add_cli_args(argparse.ArgumentParser()).parse_args(argv + ["--triton-attention-num-kv-splits", "16"]))
     assert sa.triton_attention_num_kv_splits == 16            # server_args.py:979-981
+    # the CU policy of a CLI launch is the one the bench line measures (work-conserving shares, the reference's percentages)
+    import bench
+    assert (sa.cu_mask_mode, sa.prefill_backlog_full_tokens) == ("dynamic", bench.DEFAULT_BACKLOG_FULL_TOKENS)
+    assert (sa.prefill_cu_percent, sa.decode_cu_percent) == (bench.DEFAULT_PREFILL_CU, bench.DEFAULT_DECODE_CU)
+    sa = from_cli_args(add_cli_args(argparse.ArgumentParser()).parse_args(
+        argv + ["--cu-mask-mode", "env", "--prefill-backlog-full-tokens", "0", "--prefill-cu-percent", "50",
+                "--decode-cu-percent", "50", "--decode-stream-priority", "-1"]))
+    assert (sa.cu_mask_mode, sa.prefill_backlog_full_tokens, sa.decode_stream_priority) == ("env", 0, -1)
+    with pytest.raises(SystemExit):
+        add_cli_args(argparse.ArgumentParser()).parse_args(argv + ["--cu-mask-mode", "static"])
+    with pytest.raises(ValueError, match="cu_mask_mode"):
+        ServerArgs(model_config=sa.model_config, cu_mask_mode="static")
+    with pytest.raises(ValueError, match="stream priorities"):   # cu_share.py would drop the prioritised stream
+        from_cli_args(add_cli_args(argparse.ArgumentParser()).parse_args(argv + ["--decode-stream-priority", "-1"]))
 
 
 def test_logprobs_native_and_openai(client):

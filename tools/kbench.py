@@ -272,6 +272,108 @@ def bench_stream_linear():
             del ws
 
 
+def bench_stream_planes():
+    """The decode GEMM kernel ALONE (ops.stream_linear_planes: no reduction launch -- in a decode step the planes are summed by
+    the consumer), Llama-3-8B and 70B-rank shapes, K slices swept through SEMIPD_SL_KS; KBENCH_NUM_CUS = CUs declared.
+    Weights cycle through > 1 GB so that neither L2 nor the 256 MB MALL holds them."""
+    ncu = int(os.environ.get("KBENCH_NUM_CUS", "0"))
+    print("# stream_linear_planes M x [N, K]: default us GB/s | per KS us   HSA_CU_MASK=%s num_cus=%d SEMIPD_SL_RING=%s"
+          % (os.environ.get("HSA_CU_MASK", "-"), ncu, os.environ.get("SEMIPD_SL_RING", "3")))
+    if ncu:
+        from semi_pd_amd import _lib
+        _lib.load().semipd_stream_linear_set_cus(ncu)
+    shapes = ((4096, 4096), (6144, 4096), (4096, 14336), (28672, 4096), (1280, 8192), (8192, 1024))
+    for M in [int(v) for v in os.environ.get("KBENCH_MS", "32").split(",")]:
+        for (N, K) in shapes:
+            copies = max(2, int(1.2e9 // (N * K * 2)))
+            ws = [torch.randn(N, K, device=dev, dtype=torch.bfloat16) * 0.02 for _ in range(copies)]
+            x = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
+            it = [0]
+
+            def f():
+                it[0] += 1
+                return ops.stream_linear_planes(x, ws[it[0] % copies])
+            os.environ.pop("SEMIPD_SL_KS", None)
+            t0 = timeit(f, iters=3 * copies)
+            ks0 = f().ksplit
+            res = {}
+            for ksp in (1, 2, 4, 8, 16):
+                os.environ["SEMIPD_SL_KS"] = str(ksp)
+                res[ksp] = timeit(f, iters=2 * copies)
+            os.environ.pop("SEMIPD_SL_KS", None)
+            by = N * K * 2
+            print(f"M={M:3d} N={N:6d} K={K:6d}: default KS={ks0} {t0 * 1e6:6.1f} us {by / t0 / 1e9:5.0f} GB/s | "
+                  + " ".join(f"{k}:{v * 1e6:.1f}" for k, v in sorted(res.items())), flush=True)
+            del ws
+
+
+def graph_time(fn, launches, replays=5):
+    """Seconds per launch of `fn` inside a hipGraph of `launches` calls (device time: no host launch cost between them)."""
+    fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.graph(g, stream=side):
+        for _ in range(launches):
+            fn()
+    torch.cuda.synchronize()
+    g.replay()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(replays):
+        g.replay()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) * 1e-3 / (replays * launches)
+
+
+def bench_stream_planes_graph():
+    """bench_stream_planes with the launches inside a hipGraph: what a decode step pays per GEMM kernel (the eager loop of
+    bench_stream_planes is bound by ~11 us of host work per call for the small shapes).  `+norm`: GEMM -> fused add + norm on
+    the planes, the pair a decode layer runs for o_proj / down_proj."""
+    ncu = int(os.environ.get("KBENCH_NUM_CUS", "0"))
+    print("# stream_linear_planes in a hipGraph, M x [N, K]: KS -> us per launch (GB/s of weights) | with the consumer   HSA_CU_MASK=%s "
+          "num_cus=%d SEMIPD_SL_RING=%s" % (os.environ.get("HSA_CU_MASK", "-"), ncu, os.environ.get("SEMIPD_SL_RING", "3")))
+    if ncu:
+        from semi_pd_amd import _lib
+        _lib.load().semipd_stream_linear_set_cus(ncu)
+    shapes = ((4096, 4096), (6144, 4096), (4096, 14336), (28672, 4096), (1280, 8192), (8192, 1024))
+    for M in [int(v) for v in os.environ.get("KBENCH_MS", "32").split(",")]:
+        for (N, K) in shapes:
+            copies = max(4, int(1.2e9 // (N * K * 2)))
+            ws = [torch.randn(N, K, device=dev, dtype=torch.bfloat16) * 0.02 for _ in range(copies)]
+            x = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
+            it = [0]
+
+            def f():
+                it[0] += 1
+                return ops.stream_linear_planes(x, ws[it[0] % copies])
+            res = {}
+            for ksp in (0, 1, 2, 4, 8, 16):
+                if ksp:
+                    os.environ["SEMIPD_SL_KS"] = str(ksp)
+                else:
+                    os.environ.pop("SEMIPD_SL_KS", None)
+                res[ksp if ksp else "default=%d" % f().ksplit] = graph_time(f, copies)
+            os.environ.pop("SEMIPD_SL_KS", None)
+            by = N * K * 2
+            line = f"M={M:3d} N={N:6d} K={K:6d}: " + " ".join(f"{k}:{v * 1e6:.1f}" for k, v in res.items())
+            best = min(res.values())
+            line += f" | best {best * 1e6:.1f} us {by / best / 1e9:5.0f} GB/s"
+            if N == 4096:
+                res_n = torch.randn(M, N, device=dev, dtype=torch.bfloat16)
+                wn = torch.ones(N, device=dev, dtype=torch.bfloat16)
+
+                def fn():
+                    it[0] += 1
+                    return ops.fused_add_rmsnorm_planes(ops.stream_linear_planes(x, ws[it[0] % copies]), res_n, wn, 1e-5)
+                line += f" | +norm {graph_time(fn, copies) * 1e6:.1f} us per pair"
+            print(line, flush=True)
+            del ws
+
+
 def bench_gemm_tall():
     """ops.gemm_tall (csrc/gemm8p.hip) vs hipBLASLt at Llama-3-8B layer shapes and the lm_head: tall decode batches
     (weight-stream bound: GB/s of weights) up to prefill-sized ones (TFLOP/s)."""
@@ -424,6 +526,10 @@ if __name__ == "__main__":
         bench_linear()
     if which == "stream_linear":
         bench_stream_linear()
+    if which == "stream_planes":
+        bench_stream_planes()
+    if which == "stream_planes_graph":
+        bench_stream_planes_graph()
     if which == "gemm_tall":
         bench_gemm_tall()
     if which == "linear_prefill":
