@@ -253,15 +253,6 @@ int semipd_linear(void* out, const void* x, const void* weight, void* workspace,
                   int64_t rows, int64_t n, int64_t k, int64_t ldx, int64_t ldo, int num_cus, int dtype,
                   void* stream);
 
-/* Dense layer of the DECODE instance on its CU share: out[rows, n_out] = x[rows, k] . weight[n, k]^T, rows <= 64
- * (bf16/f16, fp32 accumulate).  Weights are streamed once through LDS-DMA rings; the launch is n / 128 row
- * batches x KS slices of K, KS a function of the shape only (about one workgroup per CU of a half-chip share), so
- * every process computes the same bits whatever its CU mask.  With KS > 1 the slices write fp32 planes
- * [KS][rows][n] into `workspace` and a second small launch sums them in slice order; `workspace` NULL = no K split.  fuse_silu_mul != 0: `weight` is a merged [gate; up]
- * matrix (rows [0, n/2) gate, [n/2, n) up) and out[rows, n/2] = SiLU(gate) * up with both GEMM outputs rounded
- * to the activation type first, i.e. the value the unfused pair of ops produces.  k % 128 == 0.
- * replaces UnquantizedLinearMethod.apply -> F.linear (layers/linear.py:165-172) and, fused, LlamaMLP's
- *   gate_up_proj + SiluAndMul (models/llama.py:88-92, layers/activation.py:41-53) at decode batch sizes. */
 /* ---- tall decode batches (65 rows and up) and vocabulary-sized heads: the tiled ping-pong GEMM (csrc/gemm8p.hip) ------
  * out[rows, n_out] = x[rows, k] @ weight[n, k]^T; fuse_silu_mul: weight = merged [gate; up], n_out = n / 2 and the result
  * is SiluAndMul of the product rounded to dtype (the bits of the unfused pair).  256 x 256 output tiles, K in steps of
@@ -332,9 +323,21 @@ size_t semipd_dense_gemm_report(char* buf, size_t len);
 int semipd_stream_linear_f32(float* out, const void* x, const void* weight, int64_t rows, int64_t n, int64_t k, int64_t ldx,
                              int dtype, void* stream);
 
-/* Compute units of the share this process runs its decode-sized GEMMs on (its HSA_CU_MASK / stream mask); 0 = default
- * (128, half a chip).  The K split of semipd_stream_linear / _planes fills whole rounds of that many CUs.  The split
- * sets the order of the fp32 partial sums: processes that must produce identical bits declare the same share.
+/* Dense layer of a decode batch: out[rows, n_out] = x[rows, k] . weight[n, k]^T, rows <= 64 (bf16 / f16, fp32
+ * accumulate).  Weights are streamed once through LDS-DMA rings; the launch is (n / 128 row batches) x KS slices of K.
+ * KS is a function of the shape AND of the CU count declared with semipd_stream_linear_set_cus (whole rounds of that
+ * many workgroups): the slices set the order of the fp32 partial sums, so two processes produce the same bits exactly
+ * when they declare the same count -- every instance of the engine declares the DEVICE's CU count for that reason
+ * (ModelRunner.set_owned_cus; --k-split-by-share opts out).  With KS > 1 the slices write fp32 planes [KS][rows][n]
+ * into `workspace` and a second small launch sums them in slice order; `workspace` NULL = no K split.  fuse_silu_mul
+ * != 0: `weight` is a merged [gate; up] matrix (rows [0, n/2) gate, [n/2, n) up) and out[rows, n/2] = SiLU(gate) * up
+ * with both GEMM outputs rounded to the activation type first, i.e. the value the unfused pair of ops produces.
+ * k % 128 == 0.
+ * replaces UnquantizedLinearMethod.apply -> F.linear (layers/linear.py:165-172) and, fused, LlamaMLP's
+ *   gate_up_proj + SiluAndMul (models/llama.py:88-92, layers/activation.py:41-53) at decode batch sizes. */
+/* Compute units the K split of semipd_stream_linear / _planes is sized for (whole rounds of that many workgroups);
+ * 0 = default (128, half a chip).  The split sets the order of the fp32 partial sums: processes that must produce
+ * identical bits declare the same count (the engine: the device's CU count in every instance).
  * Replaces nothing in the reference (its shares are MPS percentages, entrypoints/engine.py:591-593, 632-634, and its
  * GEMMs do not know them). */
 int semipd_stream_linear_set_cus(int cus);

@@ -103,7 +103,7 @@ struct SgGroup {
   int num_valid, top_k_div, mul_routed_weight;
 };
 
-template <typename T, int MT, int NG, int NW, int R, int EPI, bool GR = false>
+template <typename T, int MT, int NG, int NW, int R, int EPI, bool GR = false, bool ROT = true>
 __global__ void __launch_bounds__(64 * NW)
 stream_gemm_glds_kernel(T* __restrict__ out, float* __restrict__ planes, const T* __restrict__ x,
                         const T* __restrict__ w, int M, int N, int K, int64_t ldx, int64_t ldo, int kb_per_slice,
@@ -158,9 +158,18 @@ stream_gemm_glds_kernel(T* __restrict__ out, float* __restrict__ planes, const T
   char* const wring = sg_smem + L::kXRing + wave * (R * L::kWSlot);
   const uint32_t xring_addr = sg_lds_addr(xring), wring_addr = sg_lds_addr(wring);
 
+  // Workgroups do not walk K in lock-step: workgroup i starts at block rot(i) of its slice and wraps around.  Every
+  // row of W starts at the same offset modulo the row pitch (8 KB for K = 4096), so workgroups that all read k-block b
+  // of their rows at the same moment put their whole load on the few HBM channels that hold byte range b of a pitch:
+  // on a 48-CU share the kernel was pinned at 1.35 TB/s however many of the CUs streamed
+  // (profiles/r05_kbench_stream_planes_graph_48cus_v0.txt).  The rotation changes the order of a workgroup's fp32
+  // sums over k (a function of blockIdx only: the same bits on every run, grid and CU mask).
+  const int rot = ROT ? (int)(((uint32_t)(blockIdx.x + 1) * 0x9E3779B1u >> 16) % (uint32_t)nkb) : 0;
   auto issue = [&](int kb) __attribute__((always_inline)) {   // block kb of this slice -> ring position kb % R
     const int slot = kb % R;
-    const int64_t koff = (int64_t)kb * 128;
+    int kk = kb + rot;
+    if (kk >= nkb) kk -= nkb;
+    const int64_t koff = (int64_t)kk * 128;
 #pragma unroll
     for (int e = 0; e < L::kNX; ++e) SG_GLDS(xsrc[e] + koff, xring + slot * L::kXStage + xdst[e], 0);
 #pragma unroll
@@ -364,10 +373,19 @@ static int sg_launch(T* out, float* planes, size_t planes_bytes, const T* x, con
   const int per = (nkb + ksp - 1) / ksp;
   ksp = (nkb + per - 1) / per;
   static std::atomic<uint64_t> lds_ok{0};  // one per instantiation, one bit per device
+  static const bool rot_off = [] { const char* e = getenv("SEMIPD_SL_ROT"); return e && atoi(e) == 0; }();   // A/B knob
+  if (rot_off) {
+    static std::atomic<uint64_t> lds_ok0{0};
+    if (ensure_dynamic_lds((const void*)stream_gemm_glds_kernel<T, MT, NG, NW, R, EPI, false, false>, L::kBytes, lds_ok0, "stream_gemm_glds"))
+      return 1;
+    hipLaunchKernelGGL((stream_gemm_glds_kernel<T, MT, NG, NW, R, EPI, false, false>), dim3(n_rb, ksp), dim3(64 * NW), L::kBytes, st,
+                       out, planes, x, w, M, N, K, ldx, ldo, per, planes_only_ks ? 1 : 0);
+  } else {
   if (ensure_dynamic_lds((const void*)stream_gemm_glds_kernel<T, MT, NG, NW, R, EPI>, L::kBytes, lds_ok, "stream_gemm_glds"))
     return 1;
   hipLaunchKernelGGL((stream_gemm_glds_kernel<T, MT, NG, NW, R, EPI>), dim3(n_rb, ksp), dim3(64 * NW), L::kBytes, st,
                      out, planes, x, w, M, N, K, ldx, ldo, per, planes_only_ks ? 1 : 0);
+  }
   int rc = launch_status("stream_gemm_glds");
   if (planes_only_ks) {   // the consumer sums the planes (e.g. semipd_fused_add_rmsnorm_planes)
     *planes_only_ks = ksp;

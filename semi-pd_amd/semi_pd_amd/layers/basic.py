@@ -232,24 +232,31 @@ def _timed_stream(fn, x: torch.Tensor, weight: torch.Tensor, n_out: int, n_kerne
 GEMM_TALL_MAX_ROWS = 256   # above: the library GEMM (prefill-sized; its solution timed on the share where that was asked for)
 
 
-def dense_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """UnquantizedLinearMethod.apply (layers/linear.py:165-172)."""
+def dense_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """UnquantizedLinearMethod.apply (layers/linear.py:165-172).  `out`: a [rows, n] view with unit inner stride to write
+    into (the token chunks of RowParallelLinear._forward_overlapped)."""
     if (_STREAM_LINEAR["enabled"] and bias is None and x.dim() == 2 and x.shape[0] <= ops.STREAM_LINEAR_MAX_ROWS
             and ops.stream_linear_is_supported(x, weight)):
-        return _timed_stream(lambda: ops.stream_linear(x, weight), x, weight, weight.shape[0], 2)
+        return _timed_stream(lambda: ops.stream_linear(x, weight, out=out), x, weight, weight.shape[0], 2)
     if (_STREAM_LINEAR["enabled"] and bias is None and x.dim() == 2 and ops.STREAM_LINEAR_MAX_ROWS < x.shape[0] <= GEMM_TALL_MAX_ROWS
             and not ops.dense_gemm_is_tuned(weight) and ops.gemm_tall_is_supported(x, weight)):
         # tall decode batch (65 .. 256 rows): the tiled ping-pong GEMM (csrc/gemm8p.hip)
-        return ops.gemm_tall(x, weight)
+        return ops.gemm_tall(x, weight, out=out)
     if (_STREAM_LINEAR["enabled"] and bias is None and x.dim() == 2 and x.shape[0] > GEMM_TALL_MAX_ROWS
             and ops.tall_preferred(weight, x.shape[0]) and ops.gemm_tall_is_supported(x, weight)):
         # prefill-sized batch of a shape for which the tiled GEMM beat the library's measured winner on this share
-        return ops.gemm_tall(x, weight)
+        return ops.gemm_tall(x, weight, out=out)
     if x.dim() == 2 and x.shape[0] > 0 and ops.dense_gemm_is_tuned(weight) and x.stride(1) == 1:
         # prefill-sized batch of a layer whose library solutions were timed on this process's CU share at start-up
         # (ModelRunner.tune_dense_gemms): the measured winner instead of the library's whole-device heuristic
-        return ops.dense_gemm(x, weight, bias)
-    return F.linear(x, weight, bias)
+        return ops.dense_gemm(x, weight, bias, out=out)
+    if out is None:
+        return F.linear(x, weight, bias)
+    # one rounding, like F.linear (mm + a separate add would round twice)
+    if bias is not None:
+        return torch.addmm(bias, x, weight.t(), out=out)
+    return torch.mm(x, weight.t(), out=out)
 
 
 def gate_up_silu(x: torch.Tensor, gate_up_proj: "MergedColumnParallelLinear", act_fn) -> torch.Tensor:
@@ -470,8 +477,10 @@ class RowParallelLinear(nn.Module):
 
     def _forward_overlapped(self, x: torch.Tensor, bias: Optional[torch.Tensor], chunks: int) -> torch.Tensor:
         """Prefill-sized call under tensor parallelism: the all-reduce of token chunk i (communication stream) runs
-        while the GEMM of chunk i + 1 runs (compute stream).  Same bits as the blocking form on the same chunks:
-        the reduce is element-wise."""
+        while the GEMM of chunk i + 1 runs (compute stream).  The reduce is element-wise, so chunking it changes no bit;
+        every chunk goes through dense_linear like the blocking form (round 5: it used torch.mm, which bypassed the GEMMs
+        chosen on the instance's CU share exactly where they matter, at >= 1024 tokens).  A GEMM whose algorithm depends
+        on the row count may round a chunk differently from the whole batch -- as any two batch sizes may."""
         T = x.shape[0]
         out = torch.empty((T, self.weight.shape[0]), dtype=x.dtype, device=x.device)
         step = -(-T // chunks)
@@ -479,11 +488,9 @@ class RowParallelLinear(nn.Module):
         pending = []
         for a in range(0, T, step):
             o = out[a:a + step]
-            if bias is not None:
-                # one rounding, like F.linear / addmm in the blocking form (mm + a separate add would round twice)
-                torch.addmm(bias, x[a:a + step], self.weight.t(), out=o)
-            else:
-                torch.mm(x[a:a + step], self.weight.t(), out=o)
+            # the same GEMM choice as the blocking form makes for rows of this count (share-tuned library solution,
+            # tiled kernel, ...): dense_linear, writing into the chunk's rows of `out`
+            dense_linear(x[a:a + step], self.weight, bias, out=o)
             pending.append(tensor_model_parallel_all_reduce_async(o))
         for p in pending:
             p.wait()

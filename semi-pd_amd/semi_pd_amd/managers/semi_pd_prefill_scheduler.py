@@ -330,7 +330,8 @@ class SemiPDPrefillScheduler(SchedulerBase):
         share.publish(self._share_inflight)
         backlog = sum(len(r.origin_input_ids) for r in self.waiting_queue)
         from semi_pd_amd.model_executor.cu_share import FULL
-        name = FULL if (self.backlog_full_tokens and backlog >= self.backlog_full_tokens) else share.choose()
+        # (one decision per forward: under tensor parallelism rank 0's, CuShare.decide)
+        name = share.decide(FULL if (self.backlog_full_tokens and backlog >= self.backlog_full_tokens) else None)
         share.activate(name)
         self.stats["batches_on_" + name] = self.stats.get("batches_on_" + name, 0) + 1
 

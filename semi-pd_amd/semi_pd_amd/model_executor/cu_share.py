@@ -37,6 +37,16 @@ logger = logging.getLogger(__name__)
 SHARE, FULL = "share", "full"
 
 
+def agree_on_rank0(name: str, tp_rank: int, group) -> str:
+    """Tensor parallelism: ONE stream choice per unit of work for all ranks of an instance -- rank 0's, sent with a
+    broadcast on the gloo CPU group like the batch itself (managers/scheduler.py:645-659 broadcasts the scheduler's
+    decisions the same way).  Each rank reads its own GPU's share board, and the boards need not agree at the instant
+    they are read: ranks of one forward on different CU counts are harmless for the bits (the collectives do not care)
+    but the slowest rank sets the time of every all-reduce."""
+    from semi_pd_amd.distributed import broadcast_pyobj
+    return broadcast_pyobj([name], tp_rank, group, src=0)[0]
+
+
 class CuShare:
     def __init__(self, model_runner, role: InstanceRole, percent: int, board=None):
         self.mr = model_runner
@@ -64,6 +74,13 @@ class CuShare:
             SHARE: cu_masked_stream(idx, percent, from_top) if percent < 100 else full, FULL: full}
         self.active: Optional[str] = None
         self.taken = {SHARE: 0, FULL: 0}   # units of work run on each stream (statistics)
+        # tensor parallelism: (tp_rank, gloo group) -- the choice is rank 0's for every rank (ModelRunner.init_cu_share)
+        self.tp = None
+        # the communication stream of the overlapped all-reduce (distributed.py) follows the compute stream: collectives
+        # of an instance on its share run on a stream with the SAME CU mask (the reference's per-process MPS percentage
+        # confines NCCL too, entrypoints/engine.py:591-593, 632-634), on an unmasked created stream on the whole chip
+        self.comm_streams: Dict[str, Optional[torch.cuda.Stream]] = {
+            SHARE: cu_masked_stream(idx, percent, from_top) if percent < 100 else None, FULL: None}
         self.activate(SHARE)
 
     # ---- which stream the next unit of work runs on ------------------------------------------------------------
@@ -76,6 +93,14 @@ class CuShare:
             return SHARE
         return FULL if self.board.peer_busy(self.role) == 0 else SHARE
 
+    def decide(self, prefer: Optional[str] = None) -> str:
+        """The stream of the next unit of work: `prefer` (the caller's own reason to take a stream, e.g. the prefill
+        backlog) or choose(); under tensor parallelism rank 0's decision for every rank.  No GPU call in here."""
+        name = prefer if prefer in (SHARE, FULL) else self.choose()
+        if self.tp is not None and self.cus[SHARE] != self.cus[FULL]:
+            name = agree_on_rank0(name, self.tp[0], self.tp[1])
+        return name
+
     def activate(self, name: str) -> str:
         """Make `name` the stream every following launch of this thread goes to (torch's current stream; the C-ABI calls
         take it from there) and tell the kernels how many CUs it has."""
@@ -86,11 +111,14 @@ class CuShare:
             torch.cuda.set_stream(new)
             self.active = name
             self.mr.set_owned_cus(self.cus[name])
+            from semi_pd_amd import distributed
+            distributed.set_comm_stream(self.mr.device.index or 0, self.comm_streams[name],
+                                        confined=self.cus[name] < self.cus[FULL])
         self.taken[name] += 1
         return name
 
     def step(self) -> str:
-        return self.activate(self.choose())
+        return self.activate(self.decide())
 
     def close(self) -> None:
         """Orderly end of the instance: everything queued has run, torch is back on the NULL stream and the CU-masked stream
@@ -101,10 +129,13 @@ class CuShare:
         full = torch.cuda.default_stream(dev)
         torch.cuda.set_stream(full)
         self.active = None
-        for name, st in list(self.streams.items()):
-            if isinstance(st, torch.cuda.ExternalStream) and st.cuda_stream != full.cuda_stream:
-                _lib.check(_lib.load().semipd_stream_destroy(C.c_void_p(st.cuda_stream)), "stream_destroy")
-            self.streams[name] = full
+        from semi_pd_amd import distributed
+        distributed.set_comm_stream(dev.index or 0, None, confined=False)
+        for table in (self.streams, self.comm_streams):
+            for name, st in list(table.items()):
+                if isinstance(st, torch.cuda.ExternalStream) and st.cuda_stream != full.cuda_stream:
+                    _lib.check(_lib.load().semipd_stream_destroy(C.c_void_p(st.cuda_stream)), "stream_destroy")
+                table[name] = full if table is self.streams else None
 
     def publish(self, busy: int) -> None:
         if self.board is not None:

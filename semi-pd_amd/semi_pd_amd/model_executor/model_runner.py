@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import hashlib
 import logging
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -122,8 +123,11 @@ class ModelRunner:
                  load_state_dict: Optional[Dict[str, torch.Tensor]] = None, model_path: Optional[str] = None,
                  load_format: str = "dummy", kv_cache_dtype: str = "auto", disable_custom_all_reduce: bool = False,
                  enable_ep_moe: bool = False, enable_ep_all_to_all: bool = False, disable_stream_linear: bool = False,
-                 num_kv_splits: Optional[int] = None, dummy_lm_head_scale: float = 1.0):
+                 num_kv_splits: Optional[int] = None, dummy_lm_head_scale: float = 1.0, k_split_by_share: bool = False):
         self.model_config = model_config
+        # the K split of the decode-sized streaming GEMM (and with it the order of its fp32 partial sums) is sized for the
+        # DEVICE's CU count in every instance unless this is set: see set_owned_cus
+        self.k_split_by_share = bool(k_split_by_share) or os.environ.get("SEMIPD_KSPLIT_BY_SHARE") == "1"
         self.model_path = model_path
         self.num_kv_splits = num_kv_splits        # --triton-attention-num-kv-splits; None = per batch
         self.gpu_id, self.tp_rank, self.tp_size = gpu_id, tp_rank, tp_size
@@ -237,7 +241,14 @@ class ModelRunner:
         if over:
             cus = int(over)
         self.num_cus_owned = int(cus)
-        _lib.check(lib.semipd_stream_linear_set_cus(int(cus)), "stream_linear_set_cus")
+        # The weight-streaming GEMM of batches of at most 64 rows cuts K into slices by the CU count it is told, and the
+        # slices set the order of its fp32 sums.  Every instance on a GPU -- prefill on its share or on every CU, decode,
+        # the unified engine -- declares the DEVICE's count, so a decode-sized batch has the same bits wherever it runs (a
+        # short prompt in the prefill instance, the same rows in a decode step).  --k-split-by-share sizes the split for
+        # the share instead: one round of workgroups on a small static share, at the price of that guarantee.  (First
+        # this call, then gemm_tall's: both record the owned count for the kernels that size grids by it, the last wins.)
+        _lib.check(lib.semipd_stream_linear_set_cus(int(cus) if self.k_split_by_share else int(self.num_cus)),
+                   "stream_linear_set_cus")
         _lib.check(lib.semipd_gemm_tall_set_cus(int(cus)), "gemm_tall_set_cus")
         _lib.check(lib.semipd_dense_gemm_set_cus(int(cus)), "dense_gemm_set_cus")
 
@@ -247,6 +258,9 @@ class ModelRunner:
         from semi_pd_amd.model_executor.cu_share import CuShare
         torch.cuda.synchronize(self.device)
         self.cu_share = CuShare(self, role, percent, board)
+        if self.tp_size > 1:
+            from semi_pd_amd.distributed import get_tp_cpu_group
+            self.cu_share.tp = (self.tp_rank, get_tp_cpu_group())
         return self.cu_share
 
     # ------------------------------------------------------------------------------------ memory

@@ -74,6 +74,9 @@ class ServerArgs:
     # prefill-sized dense layers: time the library's GEMM solutions on the instance's own CU share at start-up and use
     # the winners (csrc/dense_gemm.hip).  None = when the instance that prefills runs under a CU mask
     tune_prefill_gemm: Optional[bool] = None
+    # decode-sized GEMMs: size the K split for the instance's own CU share instead of the device (one round of workgroups on
+    # a small static share; the last bit of a sum may then differ between the instances: ModelRunner.set_owned_cus)
+    k_split_by_share: bool = False
     disable_stream_linear: bool = False      # dense layers of decode batches through hipBLASLt instead of csrc/stream_linear.hip
     library_gemm_grid: bool = False          # also size hipBLASLt's stream-K grids to the share (TENSILE_STREAMK_MAX_CUS)
     dist_init_addr: str = "127.0.0.1"
@@ -188,6 +191,9 @@ def add_cli_args(parser):
                    help="HIP stream priority of the prefill instance (env / none modes; -1 = high)")
     p.add_argument("--decode-stream-priority", type=int, default=0, choices=[-1, 0, 1],
                    help="HIP stream priority of the decode instance (env / none modes; -1 = high)")
+    p.add_argument("--k-split-by-share", action="store_true",
+                   help="decode-sized GEMMs: K split sized for the instance's CU share instead of the device (faster on small "
+                        "static shares; gives up bit-equal sums between the instances)")
     p.add_argument("--quantization", type=str, default=None, choices=[None, "fp8"],
                    help="fp8 = block-scaled e4m3fn checkpoint (quantization_config with weight_block_size); with "
                         "--load-format dummy it makes the seeded weights block-quantised")
@@ -226,6 +232,7 @@ def from_cli_args(args) -> ServerArgs:
         decode_cu_percent=args.decode_cu_percent, cu_mask_mode=args.cu_mask_mode,
         prefill_backlog_full_tokens=args.prefill_backlog_full_tokens,
         prefill_stream_priority=args.prefill_stream_priority, decode_stream_priority=args.decode_stream_priority,
+        k_split_by_share=args.k_split_by_share,
         attention_backend=args.attention_backend,
         sampling_backend=args.sampling_backend, triton_attention_num_kv_splits=args.triton_attention_num_kv_splits)
     if args.quantization == "fp8":

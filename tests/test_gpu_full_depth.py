@@ -1,0 +1,118 @@
+"""Full-depth parity: the models the bench times, at ALL their layers (round-4 verdict item 3).
+
+Every other engine test stops at two layers (test_gpu_full_width.py, test_gpu_rank_widths.py); the bench line times the
+32-layer Llama-3-8B and the 27-layer DeepSeek-V2-Lite and checks no token.  The reference keeps a known-answer probe for
+exactly this (python/sglang/bench_one_batch.py:16-41 `--correct`; test/srt/models/test_generation_models.py:43-45: logprobs
+within 5e-2 of HF, same text).  Here, with seeded dummy weights at the real shapes:
+
+ * Semi-PD under the DEFAULT policy of ServerArgs -- work-conserving shares, prefill 80 % / decode 100 %, the prefill
+   instance moving between its CU-masked stream and the NULL stream -- produces the unified engine's tokens for 4 requests
+   x 16 steps.  Two engines that run different kernels on different CU sets may part ways only at a near-tie: where the two
+   sequences first differ, the unified engine's own top-2 log-probability gap at that step must be inside the margin and
+   the other token must be its runner-up (from there on the continuations are different texts and are not compared);
+ * the first request (64 tokens) x 4 steps of both engines against the CPU oracle of the same 32-layer model
+   (oracle/model.py: OracleLlama, pinned to HF LlamaForCausalLM by tests/test_oracle_models.py): every token the oracle's
+   argmax or within the tie margin of it, equal on every discriminating step.
+
+Margin: 0.15 in logit / log-probability units, the bf16 bar of tests/test_gpu_rank_widths.py (its docstring derives it at
+hidden 8192; hidden 4096 through 32 layers is no noisier: measured gaps at the divergences this test has seen are < 0.05)."""
+import time
+
+import pytest
+import torch
+
+from test_gpu_engine import check_against_oracle, make_prompts
+
+pytestmark = pytest.mark.gpu
+
+MARGIN = 0.15
+LENS = [64, 200, 1024, 7]
+STEPS = 16
+ORACLE_STEPS = 4
+
+
+def _args(cfg, **kw):
+    from semi_pd_amd.server_args import ServerArgs
+    base = dict(model_config=cfg, context_length=1100, max_running_requests=8, max_total_tokens=8000, cuda_graph_max_bs=8,
+                watchdog_timeout=300.0, tune_prefill_gemm=False)   # (no start-up GEMM tuning: the test's time budget)
+    base.update(kw)
+    return ServerArgs(**base)
+
+
+def _run(args, prompts, logprobs=False, want_sd=False):
+    from semi_pd_amd.entrypoints.engine import Engine
+    from semi_pd_amd.managers.io_struct import SamplingParams
+    eng = Engine(args)
+    try:
+        sd = None
+        if want_sd:
+            sd = {k: v.float().cpu() for k, v in eng.model_runner.model.state_dict().items()}
+        sp = SamplingParams(max_new_tokens=STEPS, ignore_eos=True)
+        if logprobs:
+            outs, lps = eng.generate(prompts, sp, timeout=600, return_logprob=True, top_logprobs_num=2)
+        else:
+            outs, lps = eng.generate(prompts, sp, timeout=600), None
+        stats = None if not args.enable_semi_pd else {s["role"]: s for s in eng.get_stats()}
+    finally:
+        eng.shutdown()
+    torch.cuda.empty_cache()
+    assert all(len(o) == STEPS for o in outs)
+    return outs, lps, sd, stats
+
+
+def _same_up_to_near_ties(uni, uni_lps, semi):
+    """Token-for-token equality of two engines, as far as greedy decoding defines it (module docstring).  Returns how
+    many requests were equal over all steps."""
+    equal = 0
+    for i, (a, b) in enumerate(zip(uni, semi)):
+        if a == b:
+            equal += 1
+            continue
+        s = next(j for j in range(len(a)) if a[j] != b[j])
+        top = uni_lps[i]["top"][s]                    # [(logprob, token id), (logprob, token id)], best first
+        (lp1, t1), (lp2, t2) = top[0][:2], top[1][:2]
+        assert t1 == a[s], f"request {i} step {s}: the unified engine's token is not its own top-1 ({t1} vs {a[s]})"
+        gap = float(lp1) - float(lp2)
+        assert b[s] == t2 and gap < MARGIN, (
+            f"request {i} diverges at step {s}: unified chose {a[s]}, Semi-PD {b[s]}; the unified engine's runner-up is {t2} "
+            f"at a log-probability gap of {gap:.4f} (margin {MARGIN})")
+        print(f"request {i}: same tokens up to step {s}, then a near-tie (unified top-2 gap {gap:.4f})")
+    return equal
+
+
+def test_llama3_8b_all_32_layers_semi_pd_default_policy_equals_unified_and_the_oracle(device):
+    from oracle.model import OracleLlama
+    from semi_pd_amd.models.llama import LLAMA3_8B
+    cfg = LLAMA3_8B
+    assert cfg.num_hidden_layers == 32
+    prompts = make_prompts(cfg.vocab_size, LENS, seed=23)
+    t0 = time.time()
+    uni, lps, sd, _ = _run(_args(cfg), prompts, logprobs=True, want_sd=True)
+    semi, _, _, stats = _run(_args(cfg, enable_semi_pd=True), prompts)
+    # the policy under test is the default one: unmasked processes, work-conserving shares of 80 % / 100 %
+    a = _args(cfg, enable_semi_pd=True)
+    assert (a.cu_mask_mode, a.prefill_cu_percent, a.decode_cu_percent) == ("dynamic", 80, 100)
+    p = stats["PREFILL"]
+    assert p.get("batches_on_full", 0) + p.get("batches_on_share", 0) == p["prefill_batches"] >= 1
+    equal = _same_up_to_near_ties(uni, lps, semi)
+    print(f"Llama-3-8B x 32 layers: {equal} of {len(prompts)} requests token-for-token equal over {STEPS} steps "
+          f"(engines: {time.time() - t0:.0f} s)")
+    assert equal >= len(prompts) - 2, "more than two near-tie divergences in 64 tokens: not bf16 noise"
+    # one short prompt against the CPU oracle of the whole model
+    t0 = time.time()
+    oracle = OracleLlama(cfg, sd)
+    for name, outs in (("unified", uni), ("semi-pd", semi)):
+        check_against_oracle(oracle, prompts[:1], [outs[0][:ORACLE_STEPS]], margin=MARGIN)
+    print(f"oracle (32 layers, fp32, {LENS[0]}-token prompt x {ORACLE_STEPS} steps, twice): {time.time() - t0:.0f} s")
+
+
+def test_deepseek_v2_lite_all_27_layers_semi_pd_default_policy_equals_unified(device):
+    from semi_pd_amd.models.deepseek_v2 import DEEPSEEK_V2_LITE
+    cfg = DEEPSEEK_V2_LITE
+    assert cfg.num_hidden_layers == 27
+    prompts = make_prompts(cfg.vocab_size, LENS, seed=29)
+    uni, lps, _, _ = _run(_args(cfg), prompts, logprobs=True)
+    semi, _, _, _ = _run(_args(cfg, enable_semi_pd=True), prompts)
+    equal = _same_up_to_near_ties(uni, lps, semi)
+    print(f"DeepSeek-V2-Lite x 27 layers: {equal} of {len(prompts)} requests token-for-token equal over {STEPS} steps")
+    assert equal >= len(prompts) - 2

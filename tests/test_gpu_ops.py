@@ -898,9 +898,11 @@ def test_stream_linear_fused_silu_mul(ops, device, M, inter, K, dtype):
     assert got.shape == (M, inter)
     tol = dict(rtol=2e-2, atol=2e-2) if dtype == torch.bfloat16 else dict(rtol=4e-3, atol=4e-3)
     torch.testing.assert_close(got.cpu().float(), want.float(), **tol)
-    # and the unfused product path: stream_linear, then the activation kernel (same K slicing -> same GEMM bits)
+    # and the unfused product path: stream_linear, then the activation kernel.  Same K slicing; since round 5 every workgroup
+    # walks its k-blocks from its own starting block (csrc/stream_linear.hip: rot) and the two kernels cut the rows into
+    # workgroups differently, so a GEMM output may round the other way before the activation: the oracle's tolerance
     two_step = ops.silu_and_mul(ops.stream_linear(x.to(device), w.to(device)))
-    torch.testing.assert_close(got.float(), two_step.float(), rtol=1.6e-2 if dtype == torch.bfloat16 else 2e-3, atol=1e-3)
+    torch.testing.assert_close(got.float(), two_step.float(), **tol)
 
 
 def test_stream_linear_strided_rows_and_limits(ops, device):

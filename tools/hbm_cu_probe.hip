@@ -148,6 +148,42 @@ __global__ void __launch_bounds__(64 * WAVES) read_anat(const char* __restrict__
   if (keep.x == 0x12345677u && acc[0] == 3.f) sink[threadIdx.x] = keep.x;
 }
 
+// The weight-streaming GEMM's ACCESS PATTERN without its arithmetic: a workgroup of WAVES waves reads 16 WAVES rows of a
+// row-major matrix with `pitch` bytes per row, wave w rows 16 w .. 16 w + 15, 256 bytes of each row per block (one block =
+// 4 DMA instructions of 4 rows x 256 B), ring of R blocks per wave.  bytes_per_wg / (16 WAVES pitch) row groups per workgroup.
+template <int WAVES, int R>
+__global__ void __launch_bounds__(64 * WAVES) read_rows(const char* __restrict__ base, size_t span, size_t bytes_per_wg,
+                                                        size_t rot, uint32_t* __restrict__ sink, int pitch) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  char* ring = smem + wave * (R * 4096);
+  const size_t group_bytes = (size_t)16 * WAVES * pitch;
+  const int groups = (int)(bytes_per_wg / group_bytes);
+  const int nblk = pitch / 256;
+  for (int g = 0; g < groups; ++g) {
+    const size_t off = ((size_t)blockIdx.x * bytes_per_wg + rot + (size_t)g * group_bytes) % span;
+    const char* p = base + off + (size_t)(wave * 16 + (lane >> 4)) * pitch + (lane & 15) * 16;
+    auto issue = [&](int b) __attribute__((always_inline)) {
+      const int slot = b % R;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + (size_t)(4 * j) * pitch + (size_t)b * 256),
+                                         (__attribute__((address_space(3))) void*)(ring + slot * 4096 + j * 1024), 16, 0, 2);
+    };
+#pragma unroll
+    for (int b = 0; b < R - 1; ++b) issue(b);
+    for (int b = 0; b < nblk; ++b) {
+      if (b + R - 1 < nblk) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * 4) : "memory");
+        issue(b + R - 1);
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    }
+  }
+  if (sink == (uint32_t*)1) sink[threadIdx.x] = smem[lane];
+}
+
 static std::vector<uint32_t> make_mask(int num_cus, int n, int xcds) {
   // n CUs spread over the first `xcds` XCDs (bit i -> XCD i % 8), n / xcds per XCD, lowest CU slots first
   std::vector<uint32_t> m((num_cus + 31) / 32, 0);
@@ -188,6 +224,56 @@ int main(int argc, char** argv) {
   if (argc <= 1 || (argc > 2 && atoi(argv[1]) == 8)) printf("# device CUs %d; every workgroup alone on its CU (100 KB LDS), 4 MB contiguous per workgroup, 4 workgroups per CU per launch\n", num_cus);
   if (argc <= 1 || (argc > 2 && atoi(argv[1]) == 8)) printf("# mode waves/CU in-flight-per-wave CUs XCDs | GB/s total | GB/s per CU\n");
 #define SETLDS(k) CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+  // hbm_cu_probe range <lo> <hi> [<lo2> <hi2> ...]: the logical CUs lo .. hi (KFD mask bits, bit i = XCD i % 8) -- e.g. the decode
+  // instance's private CUs 208 .. 255 -- contiguous streaming, the GEMM's loop, and the GEMM's row-pitched access pattern
+  if (argc > 3 && argv[1][0] == 'r') {
+    std::vector<uint32_t> mask((num_cus + 31) / 32, 0);
+    int n = 0;
+    for (int a = 2; a + 1 < argc; a += 2)
+      for (int i = atoi(argv[a]); i <= atoi(argv[a + 1]) && i < num_cus; ++i)
+        if (!(mask[i >> 5] >> (i & 31) & 1)) { mask[i >> 5] |= 1u << (i & 31); ++n; }
+    hipStream_t st;
+    CK(hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()));
+    printf("# CUs");
+    for (int a = 2; a + 1 < argc; a += 2) printf(" %s-%s", argv[a], argv[a + 1]);
+    printf(" (%d CUs): mode | waves in-flight-per-wave CUs - | GB/s total | GB/s per CU\n", n);
+    struct { int n, xcds; } sh = {n, 0};
+    const int wgs = n * 4;
+    const size_t total = (size_t)wgs * per_wg;
+    auto rot = [&](int i) { return ((size_t)i * total) % span; };
+#define RUNP(label, waves, kernel, ldsbytes, pitch)                                                               \
+    {                                                                                                              \
+      SETLDS(kernel);                                                                                              \
+      double t = time_it(st, [&](int i) { hipLaunchKernelGGL(kernel, dim3(wgs), dim3(64 * waves), ldsbytes, st,    \
+                                                              (const char*)buf, span, per_wg, rot(i), sink, pitch); }, 10); \
+      CK(hipGetLastError());                                                                                       \
+      printf("%-8s | %d pitch %5d  %3d - | %7.0f | %6.1f\n", label, waves, pitch, n, total / t / 1e9, total / t / 1e9 / n); \
+      fflush(stdout);                                                                                              \
+    }
+#define RUN(label, waves, inflight_kb, kernel, ldsbytes)                                                          \
+    {                                                                                                              \
+      SETLDS(kernel);                                                                                              \
+      double t = time_it(st, [&](int i) { hipLaunchKernelGGL(kernel, dim3(wgs), dim3(64 * waves), ldsbytes, st,    \
+                                                              (const char*)buf, span, per_wg, rot(i), sink); }, 10); \
+      CK(hipGetLastError());                                                                                       \
+      printf("%-8s | %d %3d KB  %3d %d | %7.0f | %6.1f\n", label, waves, inflight_kb, sh.n, sh.xcds, total / t / 1e9,      \
+             total / t / 1e9 / sh.n);                                                                              \
+      fflush(stdout);                                                                                              \
+    }
+    RUN("lds-nt", 8, 8, (read_lds<8, 4, 3, 2>), lds)
+    RUN("lds-nt", 4, 24, (read_lds<4, 8, 4, 2>), 128 * 1024)
+    RUN("regs-nt", 8, 8, (read_regs<8, 8>), lds)
+    RUN("anat bar+x8+rd3+mf8 (= the GEMM at 32 rows)", 8, 8, (read_anat<8, 4, 3, 1, 3, 8, 8>), 128 * 1024)
+    RUNP("rows r3", 8, (read_rows<8, 3>), lds, 8192)
+    RUNP("rows r3", 8, (read_rows<8, 3>), lds, 28672)
+    RUNP("rows r3", 8, (read_rows<8, 3>), lds, 2048)
+    RUNP("rows r5", 8, (read_rows<8, 5>), 160 * 1024, 8192)
+    RUNP("rows r3 4w", 4, (read_rows<4, 3>), lds, 8192)
+#undef RUN
+#undef RUNP
+    CK(hipStreamDestroy(st));
+    return 0;
+  }
   struct Share { int n, xcds; };
   // one share per invocation (a hang then costs one point, not the sweep):  hbm_cu_probe <CUs> <XCDs> | hbm_cu_probe pair
   const bool pair_only = argc > 1 && argv[1][0] == 'p';
