@@ -31,6 +31,9 @@ import torch  # noqa: E402
 DEFAULT_PREFILL_CU = 80
 DEFAULT_DECODE_CU = 100
 DEFAULT_BACKLOG_FULL_TOKENS = 8192
+# decode-step deadline gate (semi_pd/step_clock.py): a decode step older than this holds the prefill instance at its next
+# layer boundary until the step is over.  0 = off
+DEFAULT_DEADLINE_MS = 0.0
 # BASELINE config 2: "Poisson QPS sweep" -- three points in the default line (in = 1024 / out = 256)
 DEFAULT_SWEEP_RATES = "8,16,32"
 SWEEP_OUTPUT_LEN = 256
@@ -171,7 +174,9 @@ def pmc_traffic(kernel: str, algorithmic_bytes: float) -> dict:
         table = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         for name, rec in table.items():
             if name in kernel:
-                return {"traffic": int(rec["traffic_over_algorithmic"] * algorithmic_bytes),
+                # (not counters of THIS run: the ratio measured by the committed rocprofv3 --pmc pass of the same kernel,
+                #  times this launch's algorithmic bytes -- `traffic_estimated` says so)
+                return {"traffic": int(rec["traffic_over_algorithmic"] * algorithmic_bytes), "traffic_estimated": True,
                         "traffic_over_algorithmic": rec["traffic_over_algorithmic"], "traffic_source": rec["source"]}
     except (OSError, ValueError, KeyError):
         pass
@@ -283,6 +288,8 @@ def main():
     ap.add_argument("--decode-cu", type=int, default=DEFAULT_DECODE_CU)
     ap.add_argument("--no-static-split-wave", action="store_true",
                     help="N = 1 Semi-PD default run: do not start the second engine with BASELINE config 2's literal 50 / 50 split")
+    ap.add_argument("--no-unified-wave", action="store_true",
+                    help="N = 1 Semi-PD run: do not start the unified engine on the same requests afterwards (unified_same_load)")
     ap.add_argument("--no-prefill-gemm-tuning", action="store_true",
                     help="prefill instance: the library's own GEMM choice instead of the solutions timed on its CU share")
     ap.add_argument("--tune-prefill-gemm", action="store_true",
@@ -292,6 +299,9 @@ def main():
                          "share and a stream over every CU, chosen per decode step / prefill batch (work-conserving shares)")
     ap.add_argument("--prefill-backlog-full-tokens", type=int, default=DEFAULT_BACKLOG_FULL_TOKENS,
                     help="dynamic mode: waiting prompt tokens from which a prefill batch takes every CU (0 = never)")
+    ap.add_argument("--decode-step-deadline-ms", type=float, default=DEFAULT_DEADLINE_MS,
+                    help="Semi-PD: a decode step older than this makes the prefill instance yield at its next layer boundary "
+                         "until the step is over (0 = no gate)")
     ap.add_argument("--prefill-priority", type=int, default=0, help="HIP stream priority of the prefill instance (-1 = high)")
     ap.add_argument("--decode-priority", type=int, default=0, help="HIP stream priority of the decode instance (-1 = high)")
     ap.add_argument("--disable-stream-linear", action="store_true",
@@ -384,6 +394,7 @@ def main():
                     max_total_tokens=args.max_total_tokens, prefill_cu_percent=args.prefill_cu,
                     decode_cu_percent=args.decode_cu, cu_mask_mode=args.cu_mask_mode,
                     prefill_backlog_full_tokens=args.prefill_backlog_full_tokens,
+                    decode_step_deadline_ms=args.decode_step_deadline_ms,
                     library_gemm_grid=args.library_gemm_grid, disable_stream_linear=args.disable_stream_linear,
                     tune_prefill_gemm=(False if args.no_prefill_gemm_tuning else (True if args.tune_prefill_gemm else None)),
                     prefill_stream_priority=args.prefill_priority, decode_stream_priority=args.decode_priority,
@@ -454,43 +465,50 @@ def main():
     finally:
         engine.shutdown()
 
+    def side_waves(eng, n_timed):
+        """One warm-up wave, then n_timed timed waves of the headline's requests on another engine; summary over them."""
+        run_wave(eng, prompts, arrivals, args.output_len)
+        recs_all, t0 = [], time.time()
+        for _ in range(n_timed):
+            recs, _ = run_wave(eng, prompts, arrivals, args.output_len)
+            recs_all.extend(recs)
+        sm = summarize(recs_all, time.time() - t0)
+        return {"warmup_waves": 1, "timed_waves": n_timed, **{k: (round(v, 2) if isinstance(v, float) else v) for k, v in sm.items()}}
+
+    # side engines run the headline's load for at most this many timed waves (the driver's 20-step line would otherwise
+    # spend as long on each of them as on the headline)
+    n_side = max(1, min(args.steps, 5))
     static_split = None
     if (world == 1 and args.mode == "semi-pd" and not args.no_static_split_wave
             and (args.prefill_cu, args.decode_cu) != (50, 50)):
-        # BASELINE config 2 as written: disjoint halves of the CUs, same load, one warm-up wave + one timed wave
+        # BASELINE config 2 as written: disjoint halves of the CUs, same requests and rate as the headline
         import dataclasses
         eng2 = Engine(dataclasses.replace(sa, prefill_cu_percent=50, decode_cu_percent=50, cu_mask_mode="env",
-                                          collect_kernel_timing=False),
+                                          decode_step_deadline_ms=0.0, collect_kernel_timing=False),
                       gpu_ids={0: local_rank})
         try:
-            run_wave(eng2, prompts, arrivals, args.output_len)
-            recs, dur = run_wave(eng2, prompts, arrivals, args.output_len)
-            sm = summarize(recs, dur)
             static_split = {"workload": "same requests and rate, HSA_CU_MASK halves: prefill CUs 0-127, decode CUs 128-255",
-                            **{k: (round(v, 2) if isinstance(v, float) else v) for k, v in sm.items()}}
+                            **side_waves(eng2, n_side)}
+        except Exception as e:  # a side wave must never take the measured line down with it
+            static_split = {"error": repr(e)}
         finally:
             eng2.shutdown()
 
-    # The neighbouring operating point of the same policy: the prefill instance on 224 of the 256 CUs (88 %).  The library's
-    # prefill GEMMs lose a whole round of tiles below 224 CUs (Llama-3-8B, 1024 rows: 448 tiles of gate_up), so this point
-    # has the better medians (TTFT p50 -25 %, TBT p50 -15 %) and the longer TBT tail (p99 15 ms against 11): the headline
-    # keeps the reference's own percentages (80 / 100), this wave reports the other side of the trade.
-    wide_share = None
-    if (world == 1 and args.mode == "semi-pd" and not args.no_static_split_wave and args.cu_mask_mode == "dynamic"
-            and (args.prefill_cu, args.decode_cu) == (DEFAULT_PREFILL_CU, DEFAULT_DECODE_CU) and DEFAULT_PREFILL_CU < 88):
+    # The reference's claim is Semi-PD against the unified engine at equal load (README.md:105, evaluation/show_result.py:
+    # 50-66): the same requests and arrival times through ONE process that interleaves prefill batches and decode steps
+    # on every CU.
+    unified = None
+    if world == 1 and args.mode == "semi-pd" and not args.no_unified_wave:
         import dataclasses
-        eng4 = Engine(dataclasses.replace(sa, prefill_cu_percent=88, decode_cu_percent=100, collect_kernel_timing=False),
+        eng5 = Engine(dataclasses.replace(sa, enable_semi_pd=False, collect_kernel_timing=False, mem_fraction_static=None),
                       gpu_ids={0: local_rank})
         try:
-            run_wave(eng4, prompts, arrivals, args.output_len)
-            recs, dur = run_wave(eng4, prompts, arrivals, args.output_len)
-            sm = summarize(recs, dur)
-            wide_share = {"workload": "same requests and rate, work-conserving shares P88 / D100 (prefill on 224 of 256 CUs)",
-                          **{k: (round(v, 2) if isinstance(v, float) else v) for k, v in sm.items()}}
-        except Exception as e:  # a side wave must never take the measured line down with it
-            wide_share = {"error": repr(e)}
+            unified = {"workload": "same requests and rate, the unified engine (one process, chunked prefill and decode "
+                                   "interleaved on every CU; --mode unified)", **side_waves(eng5, min(n_side, 2))}
+        except Exception as e:
+            unified = {"error": repr(e)}
         finally:
-            eng4.shutdown()
+            eng5.shutdown()
 
     # BASELINE configs 1 and 3, one wave each, in the same invocation (they are parity-test cases, not the bench line:
     # extra keys only).  Config 1 runs the reference's own CPU-runnable case whole, with the CPU oracle timed on the same
@@ -547,7 +565,9 @@ def main():
                                          # running batches had their first tokens sent from a layer hook of that launch
                                          "launched_behind_a_running_batch": int(s.get("late_bound_launches", 0)),
                                          "results_sent_from_layer_hook": int(s.get("results_sent_from_layer_hook", 0)),
-                                         **{k: int(v) for k, v in s.items() if k.startswith("batches_on_")}}
+                                         **{k: int(v) for k, v in s.items() if k.startswith("batches_on_")},
+                                         # the decode-step deadline gate: launches, how many held the stream, for how long
+                                         **({"step_gate": s["step_gate"]} if s.get("step_gate") else {})}
         kt = s.get("kernel_timing") or {}
         def hbm_line(k, kernel):
             return {"bound": "hbm", "kernel": kernel, "achieved": round(k["gbps"], 1),
@@ -595,6 +615,8 @@ def main():
                      + ("every CU" if args.decode_cu >= 100 else f"the highest {args.decode_cu} %")
                      + "; an instance takes every CU while the other has nothing in flight"
                      + (f", the prefill instance also from {args.prefill_backlog_full_tokens} waiting prompt tokens" if args.prefill_backlog_full_tokens else "")
+                     + (f"; a decode step older than {args.decode_step_deadline_ms:g} ms holds the prefill instance at its next "
+                        "layer boundary until the step is over" if args.decode_step_deadline_ms > 0 else "")
                      + "; BASELINE config 2's literal 50 / 50 split is the side field static_split_50_50)")
     elif (args.prefill_cu, args.decode_cu) == (100, 100) or args.cu_mask_mode != "env":
         mask_text = "CU shares P100/D100 (no mask: both instances on every CU)"
@@ -625,13 +647,14 @@ def main():
                                     if (not args.no_prefill_gemm_tuning and args.prefill_cu < 100 and args.mode == "semi-pd"
                                         and args.cu_mask_mode in ("env", "dynamic"))
                                     else "library heuristic"),
+                   "decode_step_deadline_ms": args.decode_step_deadline_ms,
                    "kv_cache_dtype": args.kv_cache_dtype},
         "roofline": roofline, "roofline_extra": extra, "cpu_baseline": cpu,
     }
     if static_split:
         out["static_split_50_50"] = static_split
-    if wide_share is not None:
-        out["prefill_share_88"] = wide_share
+    if unified is not None:
+        out["unified_same_load"] = unified
     out.update(side)
     if saturation:
         out["saturation"] = {"note": "extra wave, every request sent at t = 0: output tok/s here is the engine's capacity; "

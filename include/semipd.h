@@ -652,8 +652,30 @@ int semipd_ep_dispatch(void* comm, const void* x, const int32_t* topk_ids, const
 int semipd_ep_combine(void* comm, const void* y, const int32_t* recv_count, int64_t max_recv, const int32_t* topk_ids,
                       const int32_t* send_within, const int32_t* counts_all, void* out, int64_t tokens, int top_k, int64_t hidden,
                       int experts_per_rank, int dtype, void* stream);
+/* tests: from now on every block of every kernel launched on `comm` marks buf[xcc * 256 + hardware CU id] = 1 (buf: 2048
+ * uint32 of device memory the caller zeroed; NULL = off): where a collective launched on a CU-masked stream really ran.
+ * No counterpart in the reference (its MPS percentage confines NCCL implicitly, entrypoints/engine.py:591-593). */
+int semipd_ar_set_cu_trace(void* comm, uint32_t* buf);
 /* replaces dispose (custom_all_reduce.hip:112-115); regions stay with their owners. */
 int semipd_ar_dispose(void* comm);
+
+/* ------------------------------------------------------------------ */
+/* a16  Decode-step deadline gate (csrc/step_clock.hip): the dynamic side of the compute split.  The reference fixes the
+ *      two MPS percentages at launch (semi_pd/utils.py:10-11, entrypoints/engine.py:588-634) and the decode tail under a
+ *      prefill batch is what the non-shared percentage delivers; here the prefill instance may hold a large share and
+ *      yields at a layer boundary while a decode step is overdue.  No counterpart call in the reference.             */
+/* ------------------------------------------------------------------ */
+/* slot: 64 bytes of device memory both instances map (semipd_ar_alloc_shared: uncached; exported with
+ * semipd_ipc_get_handle), zeroed.  semipd_step_clock_mark(begin = 1): one-wave kernel that stamps the slot with the
+ * device's wall clock (the first node of a decode step); begin = 0 clears it (the last node).
+ * semipd_step_clock_gate: one-wave kernel for the OTHER instance's compute stream: if the slot holds a stamp older than
+ * deadline_ticks it sleeps until the stamp changes or max_wait_ticks have passed, holding everything queued behind it on
+ * that stream; otherwise it returns at once.  stats (4 x uint64 in the caller's own device memory): gates passed, gates
+ * that held, ticks held, holds ended by max_wait.  Both are capturable; neither synchronises.
+ * semipd_step_clock_ticks_per_ms: the rate of that clock (hipDeviceAttributeWallClockRate). */
+int semipd_step_clock_mark(void* slot, int begin, void* stream);
+int semipd_step_clock_gate(const void* slot, uint64_t deadline_ticks, uint64_t max_wait_ticks, void* stats, void* stream);
+int semipd_step_clock_ticks_per_ms(int device, uint64_t* ticks);
 
 /* ------------------------------------------------------------------ */
 /* a16  CU-mask compute isolation (replaces CUDA_MPS_ACTIVE_THREAD_PERCENTAGE,

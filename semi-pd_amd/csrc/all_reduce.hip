@@ -47,6 +47,7 @@ struct ArPeers {
   char* region[kArMaxRanks];  // peer-mapped base of every rank's shared region (own region at [rank])
   size_t max_bytes;           // payload capacity of one slot
   uint64_t timeout_ticks;     // 100 MHz ticks a flag wait may take; 0 = wait for ever (normal operation)
+  uint32_t* cu_trace;         // tests: [8 XCCs][256 hardware CU ids] -- every block of every kernel marks where it ran; null = off
   int rank;
 };
 
@@ -116,6 +117,12 @@ __device__ __forceinline__ uint4 ar_sum(const uint4 (&v)[NR]) {
 // previous launch has finished, and launches of one rank are ordered by its stream.
 __device__ __forceinline__ uint32_t ar_begin(const ArPeers& p) {
   __shared__ uint32_t s_seq;
+  if (threadIdx.x == 0 && p.cu_trace) {
+    // HW_REG_XCC_ID (id 20) bits [3:0]; HW_REG_HW_ID (id 4): CU id bits [11:8], SH bit 12, SE bits [15:13] (csrc/ipc.hip's probe)
+    const unsigned xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 0xf;
+    const unsigned hw = (__builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4) >> 8) & 0xff;
+    p.cu_trace[(xcc & 7) * 256 + hw] = 1u;
+  }
   if (threadIdx.x == 0) s_seq = __hip_atomic_load(&ar_signal(p, p.rank)->call, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
   __syncthreads();
   return s_seq;
@@ -538,6 +545,7 @@ int semipd_ar_init(void* const* regions, size_t region_bytes, int rank, int worl
   c->peers.max_bytes = (region_bytes - kArMetaBytes) / 4 / kArLine * kArLine;
   c->peers.rank = rank;
   c->peers.timeout_ticks = 0;
+  c->peers.cu_trace = nullptr;
   c->world = world;
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
@@ -688,6 +696,15 @@ int semipd_ep_combine(void* comm, const void* y, const int32_t* recv_count, int6
 #undef EP_COMBINE_W
 #undef EP_COMBINE
   return launch_status("ep_combine_pull_kernel");
+}
+
+/* tests: every block of every kernel launched on this communicator from now on marks buf[xcc * 256 + hardware CU id] = 1
+ * (buf: 2048 x uint32 of device memory, zeroed by the caller; NULL switches the trace off).  The evidence that collectives
+ * launched on a CU-masked stream stay inside the mask (tests/test_gpu_comm_confined.py). */
+int semipd_ar_set_cu_trace(void* comm, uint32_t* buf) {
+  SEMIPD_CHECK_ARG(comm, SEMIPD_EINVAL, "ar_set_cu_trace: null communicator");
+  static_cast<ArComm*>(comm)->peers.cu_trace = buf;
+  return 0;
 }
 
 int semipd_ar_dispose(void* comm) {

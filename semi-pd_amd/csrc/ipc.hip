@@ -196,13 +196,21 @@ int semipd_cu_mask_fill(int num_cus, int percent, int from_top, uint32_t* mask, 
   // the complementary share from the bottom leaves (num_cus - bottom(100 - percent)): the two roundings of a pair like
   // 62 / 38 can then never claim the same group (on 304 CUs they did: 192 + 120), and on 256 CUs nothing changes for
   // the pairs in use (160 / 96, 128 / 128, 192 / 64).
-  auto bottom = [num_cus](int pct) {
+  // Granule (round 5): 32 logical CUs = one per shader engine of every XCD (8 XCDs x 4 SEs) wherever the device's CU count
+  // allows it.  The dispatcher deals a kernel's workgroups to the shader engines round-robin, not to whichever CU is
+  // free, so a share with 6 CUs per XCD (two SEs with 2, two with 1) runs at the pace of its one-CU engines: measured,
+  // any 48 CUs stream 1.82 TB/s where 32 stream 1.83 and 64 stream 3.4 (profiles/r05_hbm_probe_cu_ranges.txt), and
+  // prefill shares of 208 / 216 CUs served exactly like 192, 232 / 240 exactly like 224 (profiles/r04_policy_sweep_3.txt).
+  // 80 % of 256 CUs is therefore 192, not 208: the 16 CUs in between were held by the prefill instance without making it
+  // faster and are worth a second private CU per shader engine to the decode instance.
+  const int g = (num_cus % 32 == 0 && num_cus >= 256) ? 32 : 8;   // (8 XCDs x 4 SEs: the MI300 / MI355 layout)
+  auto bottom = [num_cus, g](int pct) {
     int m = (num_cus * pct + 50) / 100;
-    m = (m + 4) / 8 * 8;
+    m = (m + g / 2) / g * g;
     return m > num_cus ? num_cus : m;
   };
   int n = from_top ? num_cus - bottom(100 - percent) : bottom(percent);
-  if (n < 8) n = 8;
+  if (n < g) n = g;
   if (n > num_cus) n = num_cus;
   for (int w = 0; w < words; ++w) mask[w] = 0;
   const int lo = from_top ? num_cus - n : 0;

@@ -117,6 +117,9 @@ _SIGNATURES = {
     "semipd_mla_decode_prep": [_vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _f32, _i64, _i32, _i32, _i32, _i32, _i64,
                                _i64, _i64, _i32, _i32, _vp],
     "semipd_stream_destroy": [_vp],
+    "semipd_step_clock_mark": [_vp, _i32, _vp],
+    "semipd_step_clock_gate": [_vp, C.c_uint64, C.c_uint64, _vp, _vp],
+    "semipd_step_clock_ticks_per_ms": [_i32, _vp],
     "semipd_stream_get_cu_mask": [_vp, _vp, _i32],
     "semipd_share_board_open": [C.c_char_p, _i32, _vp],
     "semipd_share_board_close": [_vp],
@@ -128,6 +131,7 @@ _SIGNATURES = {
     "semipd_ar_meta_size": [],
     "semipd_ar_region_size": [_sz],
     "semipd_ar_alloc_shared": [_sz, _vp],
+    "semipd_ar_set_cu_trace": [_vp, _vp],
     "semipd_ar_free_shared": [_vp],
     "semipd_ar_init": [_vp, _sz, _i32, _i32, _vp],
     "semipd_ar_set_timeout_ms": [_vp, C.c_uint32],

@@ -165,6 +165,31 @@ class CustomAllreduce:
             return False
         return size <= self.max_size
 
+    def too_big_only(self, inp: torch.Tensor) -> bool:
+        """A tensor should_custom_ar turns down for its size alone (all_reduce_in_pieces takes it)."""
+        if self.disabled or not inp.is_cuda or inp.dtype not in (torch.float32, torch.bfloat16, torch.float16):
+            return False
+        size = inp.numel() * inp.element_size()
+        return size > self.max_size and size % 16 == 0 and inp.is_contiguous() and inp.data_ptr() % 16 == 0
+
+    def all_reduce_in_pieces(self, inp: torch.Tensor) -> torch.Tensor:
+        """In-place SUM of a tensor larger than max_size as consecutive peer-memory calls on pieces of at most max_size
+        (element-wise reduce: cutting it changes no bit).  For an instance confined to a CU share: the kernels run on the
+        CU-masked stream they are launched on, where the backend's own collectives would run on its internal, unmasked
+        stream (distributed.py: set_comm_stream)."""
+        flat = inp.view(-1)
+        step = (self.max_size // 256) * 256 // inp.element_size()
+        for a in range(0, flat.numel(), step):
+            piece = flat[a:a + step]
+            self.all_reduce(piece, out=piece)
+        return inp
+
+    def set_cu_trace(self, buf: Optional[torch.Tensor]) -> None:
+        """tests: every block of every collective kernel marks buf[xcc * 256 + hardware CU id] (int32 [2048], zeroed)."""
+        if buf is not None:
+            assert buf.is_cuda and buf.dtype == torch.int32 and buf.numel() >= 2048 and buf.is_contiguous()
+        _lib.check(_lib.load().semipd_ar_set_cu_trace(self._comm, _lib.ptr(buf) if buf is not None else None), "ar_set_cu_trace")
+
     # ------------------------------------------------------------------ calls
     def all_reduce(self, inp: torch.Tensor, *, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Out-of-place SUM (custom_all_reduce.py:503-527); `out=inp` reduces in place."""

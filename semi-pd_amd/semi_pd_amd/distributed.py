@@ -93,6 +93,11 @@ def tensor_model_parallel_all_reduce(input_: torch.Tensor) -> torch.Tensor:
     if _CUSTOM_AR is not None and _CUSTOM_AR.should_custom_ar(input_):
         # parallel_state.py:395-410: the peer-memory kernel first, RCCL for what it does not take
         return _CUSTOM_AR.all_reduce(input_, out=input_)
+    if _CUSTOM_AR is not None and _CONFINED["on"] and _CUSTOM_AR.too_big_only(input_):
+        # an instance on its CU share: also the payloads above the peer-memory kernels' limit stay on them, piece by
+        # piece, on the (masked) stream of the caller -- RCCL would launch on its own unmasked stream, i.e. on the CUs
+        # the policy keeps for the other instance (the reference's MPS percentage confines NCCL too: engine.py:591-593)
+        return _CUSTOM_AR.all_reduce_in_pieces(input_)
     dist.all_reduce(input_, group=_DEVICE_GROUP)
     return input_
 
@@ -106,7 +111,32 @@ def get_custom_all_reduce():
 # layer here is cut into token chunks: the all-reduce of chunk i runs on a communication stream while the GEMM of
 # chunk i + 1 runs on the compute stream (RowParallelLinear.forward).  The reduce is element-wise, so the chunking
 # does not change a single bit of the result.
-_COMM_STREAMS = {}
+_COMM_STREAMS = {}      # device index -> the communication stream in use (set_comm_stream; lazily a plain created stream)
+_COMM_PLAIN = {}        # device index -> the plain (unmasked) created stream, kept for when the instance is on the whole chip
+_CONFINED = {"on": False}
+
+
+def set_comm_stream(device_index: int, stream, confined: bool = False) -> None:
+    """model_executor/cu_share.py: the communication stream follows the compute stream.  While the instance runs on its CU
+    share `stream` carries the SAME CU mask (the all-reduce overlapped with the GEMMs must not spill onto the CUs the
+    policy keeps for the other instance) and `confined` routes every all-reduce through the peer-memory kernels; on the
+    whole chip (`stream` None) a plain created stream is used."""
+    if stream is None:
+        _COMM_STREAMS.pop(device_index, None)
+    else:
+        _COMM_STREAMS[device_index] = stream
+    _CONFINED["on"] = bool(confined)
+
+
+def _comm_stream(dev: torch.device):
+    st = _COMM_STREAMS.get(dev.index)
+    if st is None:
+        st = _COMM_PLAIN.get(dev.index)
+        if st is None:
+            st = _COMM_PLAIN[dev.index] = torch.cuda.Stream(device=dev)
+    return st
+
+
 OVERLAP_MIN_TOKENS = int(os.environ.get("SEMIPD_AR_OVERLAP_MIN_TOKENS", "1024"))   # below: one blocking call
 _OVERLAP = {"enabled": os.environ.get("SEMIPD_DISABLE_AR_OVERLAP", "0") != "1"}
 # what the overlapped path did in this process (reported with the scheduler's stats): chunk reduces issued next to a
@@ -152,12 +182,20 @@ def tensor_model_parallel_all_reduce_async(input_: torch.Tensor) -> _Pending:
     if _CUSTOM_AR is not None and _CUSTOM_AR.should_custom_ar(input_):
         OVERLAP_STATS["overlapped_reduces_peer_memory_kernel"] += 1
         dev = input_.device
-        comm = _COMM_STREAMS.get(dev.index)
-        if comm is None:
-            comm = _COMM_STREAMS[dev.index] = torch.cuda.Stream(device=dev)
+        comm = _comm_stream(dev)
         comm.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(comm):
             _CUSTOM_AR.all_reduce(input_, out=input_)
+            ev = comm.record_event()
+        input_.record_stream(comm)
+        return _Pending(event=ev)
+    if _CUSTOM_AR is not None and _CONFINED["on"] and _CUSTOM_AR.too_big_only(input_):
+        OVERLAP_STATS["overlapped_reduces_peer_memory_kernel"] += 1
+        dev = input_.device
+        comm = _comm_stream(dev)
+        comm.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(comm):
+            _CUSTOM_AR.all_reduce_in_pieces(input_)
             ev = comm.record_event()
         input_.record_stream(comm)
         return _Pending(event=ev)

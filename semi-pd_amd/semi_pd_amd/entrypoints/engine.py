@@ -49,7 +49,8 @@ def _build_runner(server_args: ServerArgs, gpu_id: int, tp_rank: int, role: Inst
         enable_ep_all_to_all=server_args.enable_ep_all_to_all,
         disable_stream_linear=server_args.disable_stream_linear,
         num_kv_splits=server_args.triton_attention_num_kv_splits,
-        dummy_lm_head_scale=server_args.dummy_lm_head_scale, k_split_by_share=server_args.k_split_by_share)
+        dummy_lm_head_scale=server_args.dummy_lm_head_scale, k_split_by_share=server_args.k_split_by_share,
+        step_deadline_ms=(server_args.decode_step_deadline_ms if server_args.enable_semi_pd else 0.0))
     if server_args.collect_kernel_timing:
         from semi_pd_amd.model_executor.kernel_timing import KernelTiming
         mr.kernel_timing = KernelTiming()
@@ -177,6 +178,8 @@ def run_scheduler_process(server_args: ServerArgs, port_args: SemiPDPortArgs, gp
         torch.cuda.synchronize()
         if getattr(mr, "cu_share", None) is not None:
             mr.cu_share.close()
+        if getattr(mr, "step_clock", None) is not None and not mr.step_clock.owner:
+            mr.step_clock.close()     # (the decode instance's slot stays mapped until its process is gone: the peer may poll it)
     except Exception:
         msg = traceback.format_exc()
         logger.error("scheduler hit an exception: %s", msg)

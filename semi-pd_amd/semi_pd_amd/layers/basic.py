@@ -598,6 +598,12 @@ class LogitsProcessor(nn.Module):
             # rows: 268 us against the library's 307 on the whole chip, 494 against 552 on a 96-CU share); logits in the
             # activation type like the reference's matmul (logits_processor.py:394-445)
             logits = ops.gemm_tall(pruned, lm_head.weight)
+        elif (_STREAM_LINEAR["enabled"] and pruned.dim() == 2 and pruned.shape[0] <= ops.STREAM_LINEAR_MAX_ROWS
+              and ops.stream_linear_is_supported(pruned.contiguous(), lm_head.weight)):
+            # at most 64 rows that the fused lm_head + argmax call above did not take (tensor parallelism: every rank holds
+            # a slice of the vocabulary; soft-capped logits): the weight-streaming kernel on the rank's rows, logits in the
+            # activation type like the reference's matmul
+            logits = ops.stream_linear(pruned.contiguous(), lm_head.weight)
         else:
             logits = torch.matmul(pruned, lm_head.weight.T)
         logits = tensor_model_parallel_all_gather(logits)

@@ -123,8 +123,13 @@ class ModelRunner:
                  load_state_dict: Optional[Dict[str, torch.Tensor]] = None, model_path: Optional[str] = None,
                  load_format: str = "dummy", kv_cache_dtype: str = "auto", disable_custom_all_reduce: bool = False,
                  enable_ep_moe: bool = False, enable_ep_all_to_all: bool = False, disable_stream_linear: bool = False,
-                 num_kv_splits: Optional[int] = None, dummy_lm_head_scale: float = 1.0, k_split_by_share: bool = False):
+                 num_kv_splits: Optional[int] = None, dummy_lm_head_scale: float = 1.0, k_split_by_share: bool = False,
+                 step_deadline_ms: float = 0.0):
         self.model_config = model_config
+        # decode-step deadline gate (semi_pd/step_clock.py): the decode instance owns the slot and stamps it around every
+        # step, the prefill instance opens it from the IPC info and gates its layers on it
+        self.step_deadline_ms = float(step_deadline_ms)
+        self.step_clock = None
         # the K split of the decode-sized streaming GEMM (and with it the order of its fp32 partial sums) is sized for the
         # DEVICE's CU count in every instance unless this is set: see set_owned_cus
         self.k_split_by_share = bool(k_split_by_share) or os.environ.get("SEMIPD_KSPLIT_BY_SHARE") == "1"
@@ -359,6 +364,10 @@ class ModelRunner:
             kv_info = {"kind": "mla", "shape": tuple(pool.kv_buffer[0].shape), "dtype": pool.dtype,
                        "numel": pool.kv_buffer[0].numel(), "layer_num": pool.layer_num}
         kv_info["max_total_num_tokens"] = self.max_total_num_tokens
+        if self.step_deadline_ms > 0 and self.instance_role == InstanceRole.DECODE:
+            from semi_pd_amd.semi_pd.step_clock import StepClock
+            self.step_clock = StepClock.create(self.device)
+            kv_info["step_clock"] = self.step_clock.export()
         r2t = self.req_to_token_pool.req_to_token
         return IPCInfo(params_info=params_info, weight_handles=weight_handles,
                        register_buffer_handles=buffer_handles, kv_cache_handles=kv_handles,
@@ -404,6 +413,11 @@ class ModelRunner:
         if left:
             raise RuntimeError(f"tensors not covered by the IPC info: {left[:5]}")
         kvi = ipc_info.kvcache_info
+        if self.step_deadline_ms > 0 and kvi.get("step_clock"):
+            from semi_pd_amd.semi_pd.step_clock import StepClock
+            self.step_clock = StepClock.open(self.device, kvi["step_clock"])
+            self.step_clock.set_deadline_ms(self.step_deadline_ms)
+            self._install_step_gates()
         info = {"numel": kvi["numel"], "dtype": kvi["dtype"], "shape": kvi["shape"], "contiguous": True}
         pool = self.token_to_kv_pool
         if kvi["kind"] == "mha":
@@ -570,8 +584,27 @@ class ModelRunner:
                 kt.end_step()
 
     def forward_decode(self, forward_batch: ForwardBatch):
+        clock = self.step_clock if (self.step_clock is not None and self.step_clock.owner) else None
+        if clock is not None:
+            clock.mark(True)      # (the graph runner stamps inside its graphs: hip_graph_runner.py)
         self.attn_backend.init_forward_metadata(forward_batch)
-        return self.model.forward(forward_batch.input_ids, forward_batch.positions, forward_batch)
+        out = self.model.forward(forward_batch.input_ids, forward_batch.positions, forward_batch)
+        if clock is not None:
+            clock.mark(False)
+        return out
+
+    def _install_step_gates(self) -> None:
+        """Prefill instance: one gate launch in front of every decoder layer (semi_pd/step_clock.py).  A layer of a 1 k-token
+        batch is ~0.8 ms of GPU work, so an overdue decode step is noticed within that; the launch itself is one wave."""
+        clock = self.step_clock
+        n = 0
+        for name, m in self.model.named_modules():
+            if isinstance(m, nn.ModuleList) and name.split(".")[-1] == "layers":
+                for layer in m:
+                    layer.register_forward_pre_hook(lambda mod, args, _c=clock: _c.gate())
+                    n += 1
+        if n == 0:
+            raise RuntimeError("decode-step deadline gate: the model has no `layers` ModuleList to gate")
 
     def forward_extend(self, forward_batch: ForwardBatch):
         self.attn_backend.init_forward_metadata(forward_batch)

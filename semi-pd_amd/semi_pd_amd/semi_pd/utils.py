@@ -22,8 +22,8 @@ import semi_pd_ipc
 from semi_pd_amd import _lib
 
 # The reference's defaults (semi_pd/utils.py:10-11): prefill 80 % of the SMs, decode 100 % -- overlapping shares.  With CU masks
-# that is a NESTED pair: the prefill instance keeps to the lowest 80 % of the CUs (208 of 256), the decode instance may
-# use every CU and has the remaining 20 % to itself.  Measured on MI355X with the prefill GEMMs chosen on the share
+# that is a NESTED pair: the prefill instance keeps to the lowest 80 % of the CUs (192 of 256: whole groups of 32, one CU per
+# shader engine of every XCD, csrc/ipc.hip: semipd_cu_mask_fill), the decode instance may use every CU and has the rest to itself.  Measured on MI355X with the prefill GEMMs chosen on the share
 # (csrc/dense_gemm.hip), Llama-3-8B at 32 req/s: TTFT p50 39 ms / TBT p50 6.1, p99 12.0 ms, against 41.7 / 8.5 / 14.7 for the
 # disjoint 62 / 38 pair of round 3 (profiles/r04_policy_sweep.txt).
 PREFILL_ENGINE_SM_PERCENTILE = int(os.getenv("SEMI_PD_PREFILL_SM_PERCENTILE", 80))

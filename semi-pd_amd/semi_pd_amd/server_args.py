@@ -68,6 +68,9 @@ class ServerArgs:
     # dynamic mode: from this many waiting prompt tokens on a prefill batch takes every CU even while the decode
     # instance is busy (an overloaded GPU: throughput first).  0 = never
     prefill_backlog_full_tokens: int = 8192
+    # Semi-PD: a decode step older than this many milliseconds makes the prefill instance hold its compute stream at the next
+    # layer boundary until the step is over (semi_pd/step_clock.py, csrc/step_clock.hip); 0 = no gate
+    decode_step_deadline_ms: float = 0.0
     test_plugin: Optional[str] = None        # tests only: a file every scheduler process executes at start-up (fault injection)
     prefill_stream_priority: int = 0         # HIP stream priority of the instance's compute stream: 0 normal, -1 high
     decode_stream_priority: int = 0
@@ -87,6 +90,8 @@ class ServerArgs:
     def __post_init__(self):
         if self.cu_mask_mode not in CU_MASK_MODES:
             raise ValueError(f"cu_mask_mode must be one of {CU_MASK_MODES}, got {self.cu_mask_mode!r}")
+        if self.decode_step_deadline_ms < 0:
+            raise ValueError("decode_step_deadline_ms must be >= 0 (0 = no deadline gate)")
         if self.prefill_backlog_full_tokens < 0:
             raise ValueError("prefill_backlog_full_tokens must be >= 0 (0 = never take every CU because of the backlog)")
         for name in ("prefill_cu_percent", "decode_cu_percent"):
@@ -191,6 +196,9 @@ def add_cli_args(parser):
                    help="HIP stream priority of the prefill instance (env / none modes; -1 = high)")
     p.add_argument("--decode-stream-priority", type=int, default=0, choices=[-1, 0, 1],
                    help="HIP stream priority of the decode instance (env / none modes; -1 = high)")
+    p.add_argument("--decode-step-deadline-ms", type=float, default=0.0,
+                   help="a decode step older than this makes the prefill instance yield at its next layer boundary until the "
+                        "step is over (0 = off)")
     p.add_argument("--k-split-by-share", action="store_true",
                    help="decode-sized GEMMs: K split sized for the instance's CU share instead of the device (faster on small "
                         "static shares; gives up bit-equal sums between the instances)")
@@ -232,7 +240,7 @@ def from_cli_args(args) -> ServerArgs:
         decode_cu_percent=args.decode_cu_percent, cu_mask_mode=args.cu_mask_mode,
         prefill_backlog_full_tokens=args.prefill_backlog_full_tokens,
         prefill_stream_priority=args.prefill_stream_priority, decode_stream_priority=args.decode_stream_priority,
-        k_split_by_share=args.k_split_by_share,
+        k_split_by_share=args.k_split_by_share, decode_step_deadline_ms=args.decode_step_deadline_ms,
         attention_backend=args.attention_backend,
         sampling_backend=args.sampling_backend, triton_attention_num_kv_splits=args.triton_attention_num_kv_splits)
     if args.quantization == "fp8":

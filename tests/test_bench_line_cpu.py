@@ -85,6 +85,7 @@ def test_the_bench_line_is_assembled_with_every_contract_field(monkeypatch, caps
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     # HBM bytes per launch from the committed PMC pass (profiles/pmc_traffic.json), scaled to this launch
     assert r["traffic"] == int(r["traffic_over_algorithmic"] * r["algorithmic_bytes_per_launch"]) and r["traffic_source"].startswith("profiles/")
+    assert r["traffic_estimated"] is True      # counters of a committed --pmc pass, not of this run: the line says so
     assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], abs=1e-4) and "stream_gemm_glds_kernel" in r["kernel"]
     pb = d["roofline_extra"]["prefill_batch_ms"]
     assert pb["launched_behind_a_running_batch"] == 287 and pb["results_sent_from_layer_hook"] == 271 and pb["batches"] == 568
@@ -94,10 +95,16 @@ def test_the_bench_line_is_assembled_with_every_contract_field(monkeypatch, caps
     assert cfgd["prefill_gemm"].startswith("library solutions timed on the prefill share") and "decode step" in cfgd["prefill_gemm"]
     if expect_static:
         assert (cfgd["prefill_cu_percent"], cfgd["decode_cu_percent"]) == (80, 100)
-        # the main engine, the literal 50 / 50 engine, the P88 / D100 engine, and one engine each for BASELINE configs 1 and 3
+        # the main engine, the literal 50 / 50 engine, the unified engine, and one engine each for BASELINE configs 1 and 3
         assert d["static_split_50_50"]["output_tok_s"] > 0 and len(FakeEngine.instances) == 5
         assert FakeEngine.instances[1].sa.cu_mask_mode == "env" and FakeEngine.instances[0].sa.cu_mask_mode == "dynamic"
-        assert d["prefill_share_88"]["output_tok_s"] > 0 and FakeEngine.instances[2].sa.prefill_cu_percent == 88
+        # the 50 / 50 engine runs the headline's kind of measurement: a warm-up wave + min(steps, 5) timed waves
+        assert (d["static_split_50_50"]["warmup_waves"], d["static_split_50_50"]["timed_waves"]) == (1, 2)
+        assert d["static_split_50_50"]["output_tokens"] == 2 * 6 * 4
+        # Semi-PD against the unified engine at equal load: the same requests through --mode unified
+        assert d["unified_same_load"]["output_tok_s"] > 0 and FakeEngine.instances[2].sa.enable_semi_pd is False
+        assert FakeEngine.instances[0].sa.decode_step_deadline_ms == bench.DEFAULT_DEADLINE_MS
+        assert cfgd["decode_step_deadline_ms"] == bench.DEFAULT_DEADLINE_MS
         assert d["config1_opt_125m"]["output_tok_s"] > 0 and d["config3_deepseek_v2_lite"]["output_tok_s"] > 0
         assert [s["request_rate"] for s in d["qps_sweep"]] == [8.0, 32.0] and d["qps_sweep"][0]["output_len"] == 6
         assert d["saturation"]["output_tokens"] == 6 * 4
