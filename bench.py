@@ -31,7 +31,7 @@ import torch  # noqa: E402
 DEFAULT_PREFILL_CU = 80
 DEFAULT_DECODE_CU = 100
 DEFAULT_BACKLOG_FULL_TOKENS = 8192
-# decode-step deadline gate (semi_pd/step_clock.py): a decode step older than this holds the prefill instance at its next
+# decode-step deadline gate (semi_pd/step_pacer.py): a decode step older than this holds the prefill instance at its next
 # layer boundary until the step is over.  0 = off
 DEFAULT_DEADLINE_MS = 0.0
 # BASELINE config 2: "Poisson QPS sweep" -- three points in the default line (in = 1024 / out = 256)

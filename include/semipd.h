@@ -660,30 +660,15 @@ int semipd_ar_set_cu_trace(void* comm, uint32_t* buf);
 int semipd_ar_dispose(void* comm);
 
 /* ------------------------------------------------------------------ */
-/* a16  Decode-step deadline gate (csrc/step_clock.hip): the dynamic side of the compute split.  The reference fixes the
- *      two MPS percentages at launch (semi_pd/utils.py:10-11, entrypoints/engine.py:588-634) and the decode tail under a
- *      prefill batch is what the non-shared percentage delivers; here the prefill instance may hold a large share and
- *      yields at a layer boundary while a decode step is overdue.  No counterpart call in the reference.             */
-/* ------------------------------------------------------------------ */
-/* slot: 64 bytes of device memory both instances map (semipd_ar_alloc_shared: uncached; exported with
- * semipd_ipc_get_handle), zeroed.  semipd_step_clock_mark(begin = 1): one-wave kernel that stamps the slot with the
- * device's wall clock (the first node of a decode step); begin = 0 clears it (the last node).
- * semipd_step_clock_gate: one-wave kernel for the OTHER instance's compute stream: if the slot holds a stamp older than
- * deadline_ticks it sleeps until the stamp changes or max_wait_ticks have passed, holding everything queued behind it on
- * that stream; otherwise it returns at once.  stats (4 x uint64 in the caller's own device memory): gates passed, gates
- * that held, ticks held, holds ended by max_wait.  Both are capturable; neither synchronises.
- * semipd_step_clock_ticks_per_ms: the rate of that clock (hipDeviceAttributeWallClockRate). */
-int semipd_step_clock_mark(void* slot, int begin, void* stream);
-int semipd_step_clock_gate(const void* slot, uint64_t deadline_ticks, uint64_t max_wait_ticks, void* stats, void* stream);
-int semipd_step_clock_ticks_per_ms(int device, uint64_t* ticks);
-
-/* ------------------------------------------------------------------ */
 /* a16  CU-mask compute isolation (replaces CUDA_MPS_ACTIVE_THREAD_PERCENTAGE,
  *      entrypoints/engine.py:591-593, 632-634; semi_pd/utils.py:10-11)     */
 /* ------------------------------------------------------------------ */
-/* Fill mask words so that `percent` of the device's CUs are enabled, spread
- * evenly over the XCDs; from_top selects the complementary (upper) range so a
- * prefill/decode pair can be disjoint.  words = ceil(num_cus/32). */
+/* Fill mask words so that `percent` of the device's CUs are enabled, spread evenly over the XCDs AND over the shader
+ * engines of every XCD: on a 256-CU device the share is a whole number of groups of 32 logical CUs (8 XCDs x 4 shader
+ * engines; bit i = XCD i % 8, shader engine (i / 8) % 4), elsewhere of groups of 8.  The dispatcher deals a kernel's
+ * workgroups to the shader engines round-robin, so a share runs at the pace of its smallest engine: 48 or 56 CUs stream
+ * like 32, 208 like 192 (profiles/r05_hbm_probe_shader_engine_balance.txt).  from_top selects the complementary (upper)
+ * range so a prefill / decode pair can be disjoint.  Returns the number of CUs enabled.  words = ceil(num_cus / 32). */
 int semipd_cu_mask_fill(int num_cus, int percent, int from_top, uint32_t* mask, int words);
 /* hipExtStreamCreateWithCUMask wrapper; *stream receives a hipStream_t. */
 int semipd_stream_create_cu_mask(int device, const uint32_t* mask, int words, void** stream);

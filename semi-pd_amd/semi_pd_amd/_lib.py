@@ -117,9 +117,6 @@ _SIGNATURES = {
     "semipd_mla_decode_prep": [_vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _f32, _i64, _i32, _i32, _i32, _i32, _i64,
                                _i64, _i64, _i32, _i32, _vp],
     "semipd_stream_destroy": [_vp],
-    "semipd_step_clock_mark": [_vp, _i32, _vp],
-    "semipd_step_clock_gate": [_vp, C.c_uint64, C.c_uint64, _vp, _vp],
-    "semipd_step_clock_ticks_per_ms": [_i32, _vp],
     "semipd_stream_get_cu_mask": [_vp, _vp, _i32],
     "semipd_share_board_open": [C.c_char_p, _i32, _vp],
     "semipd_share_board_close": [_vp],

@@ -70,6 +70,8 @@ def _init_dynamic_share(server_args: ServerArgs, port_args: SemiPDPortArgs, mr, 
     board = ShareBoard(os.path.join(os.path.dirname(port_args.tokenizer_ipc_name), f"share_board_{mr.tp_rank}"), create=True)
     percent = server_args.decode_cu_percent if role == InstanceRole.DECODE else server_args.prefill_cu_percent
     mr.init_cu_share(role, percent, board)
+    if role == InstanceRole.PREFILL and server_args.decode_step_deadline_ms > 0:
+        mr.init_step_pacer(board)
 
 
 def run_scheduler_process(server_args: ServerArgs, port_args: SemiPDPortArgs, gpu_id: int, tp_rank: int,
@@ -178,8 +180,6 @@ def run_scheduler_process(server_args: ServerArgs, port_args: SemiPDPortArgs, gp
         torch.cuda.synchronize()
         if getattr(mr, "cu_share", None) is not None:
             mr.cu_share.close()
-        if getattr(mr, "step_clock", None) is not None and not mr.step_clock.owner:
-            mr.step_clock.close()     # (the decode instance's slot stays mapped until its process is gone: the peer may poll it)
     except Exception:
         msg = traceback.format_exc()
         logger.error("scheduler hit an exception: %s", msg)

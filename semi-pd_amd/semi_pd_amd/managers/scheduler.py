@@ -160,12 +160,12 @@ class SchedulerBase:
                     extra.reset()
             from semi_pd_amd.distributed import OVERLAP_STATS
             out["all_reduce_overlap"] = dict(OVERLAP_STATS)
-            clock = getattr(self.model_runner, "step_clock", None)
-            if clock is not None and not clock.owner:
-                # the prefill instance's deadline gate (semi_pd/step_clock.py): gates passed, holds, time held
-                out["step_gate"] = clock.stats()
+            pacer = getattr(self.model_runner, "step_pacer", None)
+            if pacer is not None:
+                # the prefill instance's decode-step deadline (semi_pd/step_pacer.py): layer gates passed, holds, time held
+                out["step_gate"] = pacer.stats()
                 if recv_req.reset:
-                    clock.reset_stats()
+                    pacer.reset_stats()
             self.send_to_detokenizer.send_pyobj(("stats", out))
         if recv_req.reset:
             for k in self.stats:

@@ -213,6 +213,14 @@ class SemiPDDecodeScheduler(SchedulerBase):
             name = share.step()
             self.stats["steps_on_" + name] = self.stats.get("steps_on_" + name, 0) + 1
 
+    def _publish_step(self, started: bool) -> None:
+        """The share board's STEP_START_NS / STEP_SEQ: when the decode step in flight began on the GPU (the prefill
+        instance's step pacer holds its launches while that step is overdue, semi_pd/step_pacer.py)."""
+        share = getattr(self.model_runner, "cu_share", None)
+        board = getattr(share, "board", None) if share is not None else None
+        if board is not None:
+            board.publish_step(time.monotonic_ns() if started else 0)
+
     # ---------------------------------------------------------------------------- loop
     def step(self) -> bool:
         if self.enable_overlap:
@@ -227,10 +235,12 @@ class SemiPDDecodeScheduler(SchedulerBase):
             return bool(recv)
         t1 = time.perf_counter()
         self._share_step(len(batch.reqs))
+        self._publish_step(True)       # (plain loop: the GPU is idle when a step is launched)
         logits_output, next_token_ids = self.run_batch(batch)  # asynchronous: one hipGraph launch
         batch.output_ids = next_token_ids
         self.flush_stream_output()     # tokens of the previous step: pickle + send while the GPU works
         ids = next_token_ids.tolist()  # the only device sync of a decode step
+        self._publish_step(False)
         t2 = time.perf_counter()
         self.process_batch_result_decode(batch, ids, self.extract_logprobs(logits_output))
         t3 = time.perf_counter()
@@ -268,6 +278,8 @@ class SemiPDDecodeScheduler(SchedulerBase):
             return bool(recv) or had
         t1 = time.perf_counter()
         self._share_step(len(batch.reqs))
+        if self._pending is None:
+            self._publish_step(True)   # nothing in flight: this step begins now (otherwise: when its predecessor ends)
         logits_output, next_token_ids = self.run_batch(batch)  # asynchronous: one hipGraph launch
         batch.output_ids = next_token_ids
         bs = len(batch.reqs)
@@ -303,6 +315,8 @@ class SemiPDDecodeScheduler(SchedulerBase):
         reqs, out_cache_loc, host_ids, ev, logits_output = pending
         if ev is not None:
             self._wait_servicing(ev)           # step k and its copy are done; step k + 1 keeps the GPU busy
+            # step k + 1 (if one was launched behind k) began on the GPU just now; otherwise nothing is in flight
+            self._publish_step(self._pending is not None)
             ttft_trace.mark("d_step_done", [str(len(reqs))])
         ids = host_ids.tolist()
         logprobs = self.extract_logprobs(logits_output)

@@ -331,8 +331,12 @@ class SemiPDPrefillScheduler(SchedulerBase):
         backlog = sum(len(r.origin_input_ids) for r in self.waiting_queue)
         from semi_pd_amd.model_executor.cu_share import FULL
         # (one decision per forward: under tensor parallelism rank 0's, CuShare.decide)
-        name = share.decide(FULL if (self.backlog_full_tokens and backlog >= self.backlog_full_tokens) else None)
+        overloaded = bool(self.backlog_full_tokens and backlog >= self.backlog_full_tokens)
+        name = share.decide(FULL if overloaded else None)
         share.activate(name)
+        pacer = getattr(self.model_runner, "step_pacer", None)
+        if pacer is not None:
+            pacer.hold_enabled = not overloaded      # throughput first: no holds for decode steps that are all overdue
         self.stats["batches_on_" + name] = self.stats.get("batches_on_" + name, 0) + 1
 
     def _share_done(self):

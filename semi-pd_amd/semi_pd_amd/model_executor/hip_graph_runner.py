@@ -120,19 +120,12 @@ class HipGraphRunner:
             req_to_token_pool=mr.req_to_token_pool, token_to_kv_pool=mr.token_to_kv_pool,
             attn_backend=mr.attn_backend)
 
-        clock = getattr(mr, "step_clock", None)
-        clock = clock if (clock is not None and clock.owner) else None
-
         def run_once():
-            if clock is not None:
-                clock.mark(True)    # first node of the step: the stamp the prefill instance's gates read (semi_pd/step_clock.py)
             torch.clamp(self.seq_lens[:bs] - 1, min=0, out=self.positions[:bs])
             mr.attn_backend.init_forward_metadata_capture_cuda_graph(
                 bs, bs, self.req_pool_indices[:bs], self.seq_lens[:bs], None, ForwardMode.DECODE, None)
             out = mr.model.forward(fb.input_ids, fb.positions, fb)
             ids = out.next_token_ids if out.next_token_ids is not None else mr.sampler(out)
-            if clock is not None:
-                clock.mark(False)   # last node: no step in flight
             return out.next_token_logits, ids
 
         self.stream.wait_stream(torch.cuda.current_stream())

@@ -126,10 +126,10 @@ class ModelRunner:
                  num_kv_splits: Optional[int] = None, dummy_lm_head_scale: float = 1.0, k_split_by_share: bool = False,
                  step_deadline_ms: float = 0.0):
         self.model_config = model_config
-        # decode-step deadline gate (semi_pd/step_clock.py): the decode instance owns the slot and stamps it around every
-        # step, the prefill instance opens it from the IPC info and gates its layers on it
+        # decode-step deadline (semi_pd/step_pacer.py): the prefill instance paces its launches layer by layer and stops
+        # launching while the decode instance's step in flight is older than this (init_step_pacer)
         self.step_deadline_ms = float(step_deadline_ms)
-        self.step_clock = None
+        self.step_pacer = None
         # the K split of the decode-sized streaming GEMM (and with it the order of its fp32 partial sums) is sized for the
         # DEVICE's CU count in every instance unless this is set: see set_owned_cus
         self.k_split_by_share = bool(k_split_by_share) or os.environ.get("SEMIPD_KSPLIT_BY_SHARE") == "1"
@@ -364,10 +364,6 @@ class ModelRunner:
             kv_info = {"kind": "mla", "shape": tuple(pool.kv_buffer[0].shape), "dtype": pool.dtype,
                        "numel": pool.kv_buffer[0].numel(), "layer_num": pool.layer_num}
         kv_info["max_total_num_tokens"] = self.max_total_num_tokens
-        if self.step_deadline_ms > 0 and self.instance_role == InstanceRole.DECODE:
-            from semi_pd_amd.semi_pd.step_clock import StepClock
-            self.step_clock = StepClock.create(self.device)
-            kv_info["step_clock"] = self.step_clock.export()
         r2t = self.req_to_token_pool.req_to_token
         return IPCInfo(params_info=params_info, weight_handles=weight_handles,
                        register_buffer_handles=buffer_handles, kv_cache_handles=kv_handles,
@@ -413,11 +409,6 @@ class ModelRunner:
         if left:
             raise RuntimeError(f"tensors not covered by the IPC info: {left[:5]}")
         kvi = ipc_info.kvcache_info
-        if self.step_deadline_ms > 0 and kvi.get("step_clock"):
-            from semi_pd_amd.semi_pd.step_clock import StepClock
-            self.step_clock = StepClock.open(self.device, kvi["step_clock"])
-            self.step_clock.set_deadline_ms(self.step_deadline_ms)
-            self._install_step_gates()
         info = {"numel": kvi["numel"], "dtype": kvi["dtype"], "shape": kvi["shape"], "contiguous": True}
         pool = self.token_to_kv_pool
         if kvi["kind"] == "mha":
@@ -584,27 +575,23 @@ class ModelRunner:
                 kt.end_step()
 
     def forward_decode(self, forward_batch: ForwardBatch):
-        clock = self.step_clock if (self.step_clock is not None and self.step_clock.owner) else None
-        if clock is not None:
-            clock.mark(True)      # (the graph runner stamps inside its graphs: hip_graph_runner.py)
         self.attn_backend.init_forward_metadata(forward_batch)
-        out = self.model.forward(forward_batch.input_ids, forward_batch.positions, forward_batch)
-        if clock is not None:
-            clock.mark(False)
-        return out
+        return self.model.forward(forward_batch.input_ids, forward_batch.positions, forward_batch)
 
-    def _install_step_gates(self) -> None:
-        """Prefill instance: one gate launch in front of every decoder layer (semi_pd/step_clock.py).  A layer of a 1 k-token
-        batch is ~0.8 ms of GPU work, so an overdue decode step is noticed within that; the launch itself is one wave."""
-        clock = self.step_clock
+    def init_step_pacer(self, board) -> None:
+        """Prefill instance with a decode-step deadline: a forward pre-hook in front of every decoder layer that (1) keeps the
+        host at most two layers ahead of the GPU and (2) stops launching while the decode instance's step in flight is older
+        than the deadline (semi_pd/step_pacer.py)."""
+        from semi_pd_amd.semi_pd.step_pacer import StepPacer
+        self.step_pacer = StepPacer(board, self.step_deadline_ms, self.device)
         n = 0
         for name, m in self.model.named_modules():
             if isinstance(m, nn.ModuleList) and name.split(".")[-1] == "layers":
-                for layer in m:
-                    layer.register_forward_pre_hook(lambda mod, args, _c=clock: _c.gate())
+                for i, layer in enumerate(m):
+                    layer.register_forward_pre_hook(lambda mod, args, _p=self.step_pacer, _i=i: _p.before_layer(_i))
                     n += 1
         if n == 0:
-            raise RuntimeError("decode-step deadline gate: the model has no `layers` ModuleList to gate")
+            raise RuntimeError("decode-step deadline: the model has no `layers` ModuleList to pace")
 
     def forward_extend(self, forward_batch: ForwardBatch):
         self.attn_backend.init_forward_metadata(forward_batch)

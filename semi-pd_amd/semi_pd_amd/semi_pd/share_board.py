@@ -11,6 +11,8 @@ Slots (int64 each, one writer per slot):
     BUSY_DECODE    requests in the decode instance's running batch (0 = no step in flight)
     BEAT_*         time.monotonic_ns() of the writer's last update (a reader treats a silent peer as idle after `stale_s`)
     TAKEN_*        counters for the statistics: steps / batches the instance ran on the whole chip
+    STEP_START_NS  time.monotonic_ns() at which the decode step in flight began on the GPU (0 = none), STEP_SEQ its number:
+                   what the prefill instance's step pacer reads (semi_pd/step_pacer.py)
 """
 from __future__ import annotations
 
@@ -20,7 +22,7 @@ import time
 from semi_pd_amd import _lib
 from semi_pd_amd.semi_pd.utils import InstanceRole
 
-BUSY_PREFILL, BUSY_DECODE, BEAT_PREFILL, BEAT_DECODE, TAKEN_PREFILL, TAKEN_DECODE = range(6)
+BUSY_PREFILL, BUSY_DECODE, BEAT_PREFILL, BEAT_DECODE, TAKEN_PREFILL, TAKEN_DECODE, STEP_START_NS, STEP_SEQ = range(8)
 
 
 class ShareBoard:
@@ -60,6 +62,17 @@ class ShareBoard:
         b, t = self._slots(role)
         self.store(t, time.monotonic_ns())
         self.store(b, busy)
+
+    # ---- the decode step in flight (written by the decode instance's host, read by the prefill instance's pacer) ----
+    def publish_step(self, started_ns: int) -> None:
+        """A decode step began on the GPU at `started_ns` (time.monotonic_ns(); 0 = no step in flight)."""
+        if started_ns:
+            self.add(STEP_SEQ, 1)
+        self.store(STEP_START_NS, int(started_ns))
+
+    def step_in_flight(self):
+        """(start in monotonic ns or 0, sequence number) of the decode step in flight."""
+        return self.load(STEP_START_NS), self.load(STEP_SEQ)
 
     def peer_busy(self, role: InstanceRole) -> int:
         """Work the OTHER instance has in flight (0 = idle, or silent for longer than stale_s: a peer that died while busy

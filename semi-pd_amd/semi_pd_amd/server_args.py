@@ -68,8 +68,8 @@ class ServerArgs:
     # dynamic mode: from this many waiting prompt tokens on a prefill batch takes every CU even while the decode
     # instance is busy (an overloaded GPU: throughput first).  0 = never
     prefill_backlog_full_tokens: int = 8192
-    # Semi-PD: a decode step older than this many milliseconds makes the prefill instance hold its compute stream at the next
-    # layer boundary until the step is over (semi_pd/step_clock.py, csrc/step_clock.hip); 0 = no gate
+    # Semi-PD, dynamic mode: a decode step older than this many milliseconds makes the prefill instance stop launching at its
+    # next layer boundary until the step is over (semi_pd/step_pacer.py: host-side pacing over the share board); 0 = off
     decode_step_deadline_ms: float = 0.0
     test_plugin: Optional[str] = None        # tests only: a file every scheduler process executes at start-up (fault injection)
     prefill_stream_priority: int = 0         # HIP stream priority of the instance's compute stream: 0 normal, -1 high
@@ -91,7 +91,9 @@ class ServerArgs:
         if self.cu_mask_mode not in CU_MASK_MODES:
             raise ValueError(f"cu_mask_mode must be one of {CU_MASK_MODES}, got {self.cu_mask_mode!r}")
         if self.decode_step_deadline_ms < 0:
-            raise ValueError("decode_step_deadline_ms must be >= 0 (0 = no deadline gate)")
+            raise ValueError("decode_step_deadline_ms must be >= 0 (0 = no deadline)")
+        if self.decode_step_deadline_ms > 0 and self.enable_semi_pd and self.cu_mask_mode != "dynamic":
+            raise ValueError("decode_step_deadline_ms needs --cu-mask-mode dynamic (the instances meet on the share board)")
         if self.prefill_backlog_full_tokens < 0:
             raise ValueError("prefill_backlog_full_tokens must be >= 0 (0 = never take every CU because of the backlog)")
         for name in ("prefill_cu_percent", "decode_cu_percent"):
