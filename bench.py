@@ -26,14 +26,17 @@ for _p in (ROOT, os.path.join(ROOT, "semi-pd_amd")):
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-# the masked Semi-PD operating point of the default line (see the --prefill-cu / --decode-cu help): the reference's own
-# shares (semi_pd/utils.py:10-11: prefill 80 %, decode 100 %), i.e. nested CU masks, work-conserving (--cu-mask-mode dynamic)
-DEFAULT_PREFILL_CU = 80
+# the masked Semi-PD operating point of the default line (see the --prefill-cu / --decode-cu help): nested CU masks like the
+# reference's overlapping MPS percentages (semi_pd/utils.py:10-11: prefill 80 %, decode 100 %), work-conserving
+# (--cu-mask-mode dynamic).  Shares come in whole groups of 32 CUs (one per shader engine of every XCD), so the choice on 256
+# CUs is 192 or 224 for the prefill instance: 224 (88 %) with the decode-step deadline below
+DEFAULT_PREFILL_CU = 88
 DEFAULT_DECODE_CU = 100
 DEFAULT_BACKLOG_FULL_TOKENS = 8192
 # decode-step deadline gate (semi_pd/step_pacer.py): a decode step older than this holds the prefill instance at its next
 # layer boundary until the step is over.  0 = off
-DEFAULT_DEADLINE_MS = 0.0
+DEFAULT_DEADLINE_MS = 9.0
+DEFAULT_TBT_SLO_MS = 12.0
 # BASELINE config 2: "Poisson QPS sweep" -- three points in the default line (in = 1024 / out = 256)
 DEFAULT_SWEEP_RATES = "8,16,32"
 SWEEP_OUTPUT_LEN = 256
@@ -279,7 +282,7 @@ def main():
     ap.add_argument("--mode", choices=["semi-pd", "unified"], default="semi-pd")
     # CU shares of the two instances (prefill takes its share from the bottom of the CU range, decode from the top).  The
     # default is a MASKED policy -- the north star's compute isolation and BASELINE config 2 ("CU split") -- with the
-    # reference's own shares, prefill 80 % / decode 100 % (nested: the decode instance has the top 20 % to itself and may
+    # nested shares, prefill 88 % / decode 100 % (the decode instance has the top 32 CUs to itself and may
     # use the rest), work-conserving (--cu-mask-mode dynamic; profiles/r04_policy_sweep.txt).  `--prefill-cu 50 --decode-cu 50
     # --cu-mask-mode env` is config 2's split as written: it is measured in the same invocation by a second engine (one
     # warm-up + one timed wave, "static_split_50_50"; --no-static-split-wave skips it); `--prefill-cu 100 --decode-cu 100`
@@ -302,6 +305,8 @@ def main():
     ap.add_argument("--decode-step-deadline-ms", type=float, default=DEFAULT_DEADLINE_MS,
                     help="Semi-PD: a decode step older than this makes the prefill instance yield at its next layer boundary "
                          "until the step is over (0 = no gate)")
+    ap.add_argument("--decode-tbt-slo-ms", type=float, default=DEFAULT_TBT_SLO_MS,
+                    help="with a deadline: adapt it so that the 99th percentile of the time between tokens meets this (0 = fixed)")
     ap.add_argument("--prefill-priority", type=int, default=0, help="HIP stream priority of the prefill instance (-1 = high)")
     ap.add_argument("--decode-priority", type=int, default=0, help="HIP stream priority of the decode instance (-1 = high)")
     ap.add_argument("--disable-stream-linear", action="store_true",
@@ -395,6 +400,7 @@ def main():
                     decode_cu_percent=args.decode_cu, cu_mask_mode=args.cu_mask_mode,
                     prefill_backlog_full_tokens=args.prefill_backlog_full_tokens,
                     decode_step_deadline_ms=args.decode_step_deadline_ms,
+                    decode_tbt_slo_ms=(args.decode_tbt_slo_ms if args.decode_step_deadline_ms > 0 else 0.0),
                     library_gemm_grid=args.library_gemm_grid, disable_stream_linear=args.disable_stream_linear,
                     tune_prefill_gemm=(False if args.no_prefill_gemm_tuning else (True if args.tune_prefill_gemm else None)),
                     prefill_stream_priority=args.prefill_priority, decode_stream_priority=args.decode_priority,
@@ -484,7 +490,7 @@ def main():
         # BASELINE config 2 as written: disjoint halves of the CUs, same requests and rate as the headline
         import dataclasses
         eng2 = Engine(dataclasses.replace(sa, prefill_cu_percent=50, decode_cu_percent=50, cu_mask_mode="env",
-                                          decode_step_deadline_ms=0.0, collect_kernel_timing=False),
+                                          decode_step_deadline_ms=0.0, decode_tbt_slo_ms=0.0, collect_kernel_timing=False),
                       gpu_ids={0: local_rank})
         try:
             static_split = {"workload": "same requests and rate, HSA_CU_MASK halves: prefill CUs 0-127, decode CUs 128-255",
@@ -647,7 +653,7 @@ def main():
                                     if (not args.no_prefill_gemm_tuning and args.prefill_cu < 100 and args.mode == "semi-pd"
                                         and args.cu_mask_mode in ("env", "dynamic"))
                                     else "library heuristic"),
-                   "decode_step_deadline_ms": args.decode_step_deadline_ms,
+                   "decode_step_deadline_ms": args.decode_step_deadline_ms, "decode_tbt_slo_ms": args.decode_tbt_slo_ms,
                    "kv_cache_dtype": args.kv_cache_dtype},
         "roofline": roofline, "roofline_extra": extra, "cpu_baseline": cpu,
     }

@@ -50,7 +50,8 @@ def _build_runner(server_args: ServerArgs, gpu_id: int, tp_rank: int, role: Inst
         disable_stream_linear=server_args.disable_stream_linear,
         num_kv_splits=server_args.triton_attention_num_kv_splits,
         dummy_lm_head_scale=server_args.dummy_lm_head_scale, k_split_by_share=server_args.k_split_by_share,
-        step_deadline_ms=(server_args.decode_step_deadline_ms if server_args.enable_semi_pd else 0.0))
+        step_deadline_ms=(server_args.decode_step_deadline_ms if server_args.enable_semi_pd else 0.0),
+        tbt_slo_ms=server_args.decode_tbt_slo_ms)
     if server_args.collect_kernel_timing:
         from semi_pd_amd.model_executor.kernel_timing import KernelTiming
         mr.kernel_timing = KernelTiming()

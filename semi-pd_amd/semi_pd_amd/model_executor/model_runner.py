@@ -124,11 +124,12 @@ class ModelRunner:
                  load_format: str = "dummy", kv_cache_dtype: str = "auto", disable_custom_all_reduce: bool = False,
                  enable_ep_moe: bool = False, enable_ep_all_to_all: bool = False, disable_stream_linear: bool = False,
                  num_kv_splits: Optional[int] = None, dummy_lm_head_scale: float = 1.0, k_split_by_share: bool = False,
-                 step_deadline_ms: float = 0.0):
+                 step_deadline_ms: float = 0.0, tbt_slo_ms: float = 0.0):
         self.model_config = model_config
         # decode-step deadline (semi_pd/step_pacer.py): the prefill instance paces its launches layer by layer and stops
         # launching while the decode instance's step in flight is older than this (init_step_pacer)
         self.step_deadline_ms = float(step_deadline_ms)
+        self.tbt_slo_ms = float(tbt_slo_ms or 0.0)
         self.step_pacer = None
         # the K split of the decode-sized streaming GEMM (and with it the order of its fp32 partial sums) is sized for the
         # DEVICE's CU count in every instance unless this is set: see set_owned_cus
@@ -583,7 +584,7 @@ class ModelRunner:
         host at most two layers ahead of the GPU and (2) stops launching while the decode instance's step in flight is older
         than the deadline (semi_pd/step_pacer.py)."""
         from semi_pd_amd.semi_pd.step_pacer import StepPacer
-        self.step_pacer = StepPacer(board, self.step_deadline_ms, self.device)
+        self.step_pacer = StepPacer(board, self.step_deadline_ms, self.device, slo_ms=self.tbt_slo_ms)
         n = 0
         for name, m in self.model.named_modules():
             if isinstance(m, nn.ModuleList) and name.split(".")[-1] == "layers":

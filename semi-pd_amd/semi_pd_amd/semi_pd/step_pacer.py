@@ -6,7 +6,7 @@ delivers.  On MI355X that is a hard trade: next to a 224-CU pref
 through the 32 CUs the share leaves free and takes 11-15 ms instead of 4.5 -- TTFT p50 29 ms, TBT p99 15.6 ms -- while the
 192-CU share that keeps the tail at 11.6 ms costs 11 ms of TTFT.  A deadline cuts the tail where it forms instead of paying
 for it with CUs all the time: when the decode step in flight is older than `deadline_ms`, the prefill instance stops
-launching at its next layer boundary, the GPU drains its queue (at most `RUN_AHEAD` layers), the step finishes on the whole
+launching at its next layer boundary, the GPU drains its queue (at most `RUN_AHEAD` layers: one), the step finishes on the whole
 chip, and launching resumes with the next step's stamp.
 
 How.  Entirely on the host (a GPU-side hold -- a sleeping wave in the prefill stream -- was built first and made the decode
@@ -21,6 +21,12 @@ instance three times slower during the very holds that should have freed it; pro
       2. the deadline: if the published step is older than the deadline the hook sleeps until the stamp changes (the step
          ended: the next one began, or none is in flight) or MAX_WAIT_MS have passed (a decode instance that died must not
          stall its neighbour).
+Optionally the deadline follows a service-level objective (`slo_ms`, ServerArgs.decode_tbt_slo_ms): the hooks see every
+decode step that overlaps prefill work begin (STEP_SEQ / STEP_START_NS), so the pacer knows how long each of them took and
+how many steps there were in all; every SLO_WINDOW steps it compares the share of token gaps above the objective (steps
+weighted by their batch size, BUSY_DECODE) with 1 % and moves the deadline by SLO_STEP_MS towards the point where the 99th
+percentile sits on the objective -- the latest deadline, i.e. the fewest and shortest holds, that still keeps the tail.
+
 A hold is therefore an EMPTY prefill queue: the state between two prefill batches, in which the decode instance is known to
 run at full speed.  The late-binding loop of the prefill scheduler keeps working: the forward now returns RUN_AHEAD layers
 before the GPU finishes the batch instead of ~20 ms before, which is still ahead of the moment the next batch is proposed.
@@ -34,14 +40,22 @@ import torch
 
 import os
 
-RUN_AHEAD = int(os.environ.get("SEMIPD_PACER_RUN_AHEAD", "2"))   # decoder layers the host may be ahead of the GPU
+RUN_AHEAD = int(os.environ.get("SEMIPD_PACER_RUN_AHEAD", "1"))   # decoder layers the host may be ahead of the GPU
 MAX_WAIT_MS = 50.0      # a hold never lasts longer than this
+SLO_WINDOW = 512        # decode steps per adjustment of the deadline (about 3 s at 6 ms per step)
+SLO_STEP_MS = 0.25
+SLO_MARGIN_MS = 0.3     # the client's token gap is the step plus host work of the decode instance
+DEADLINE_RANGE_MS = (5.0, 16.0)
 
 
 class StepPacer:
-    def __init__(self, board, deadline_ms: float, device, run_ahead: int = RUN_AHEAD, clock=time.monotonic_ns, sleep=time.sleep):
+    def __init__(self, board, deadline_ms: float, device, run_ahead: int = RUN_AHEAD, clock=time.monotonic_ns, sleep=time.sleep,
+                 slo_ms: float = 0.0):
         self.board = board
         self.deadline_ns = int(deadline_ms * 1e6)
+        self.slo_ns = int(max(0.0, slo_ms - SLO_MARGIN_MS) * 1e6) if slo_ms and slo_ms > 0 else 0
+        self._seen = None                 # (start, seq, batch) of the step last seen in flight
+        self._win = [0, 0.0, 0.0]         # this window: first seq, token gaps in all, token gaps above the objective
         self.device = device
         self.run_ahead = int(run_ahead)
         self._clock, self._sleep = clock, sleep
@@ -80,6 +94,8 @@ class StepPacer:
         if self.board is None or self.deadline_ns <= 0 or not self.hold_enabled:
             return
         start, seq = self.board.step_in_flight()
+        if self.slo_ns:
+            self._observe(start, seq)
         if not start:
             return
         t0 = self._clock()
@@ -99,13 +115,43 @@ class StepPacer:
                 break
         st["held_ms"] += (now - t0) / 1e6
 
+    # ---- the deadline follows the objective ------------------------------------------------------------------------
+    def _observe(self, start: int, seq: int) -> None:
+        """Called with what the board shows at a hook.  A step whose successor's stamp is seen has a known duration."""
+        from semi_pd_amd.semi_pd.share_board import BUSY_DECODE
+        prev = self._seen
+        if prev is not None and seq != prev[1]:
+            if start and seq == prev[1] + 1 and prev[0]:
+                dur = start - prev[0]                       # step prev ended where its successor began
+                if dur > self.slo_ns:
+                    self._win[2] += prev[2]
+            self._seen = None
+        if start and self._seen is None:
+            self._seen = (start, seq, max(1, self.board.load(BUSY_DECODE)))
+        if self._win[0] == 0:
+            self._win[0] = seq
+        steps = seq - self._win[0]
+        if steps >= SLO_WINDOW:
+            # token gaps in the window: steps x the batch size seen last (steps nobody watched ran without prefill work
+            # next to them: short ones)
+            batch = self._seen[2] if self._seen else max(1, self.board.load(BUSY_DECODE))
+            total = max(1.0, steps * float(batch))
+            over = self._win[2] / total
+            lo, hi = DEADLINE_RANGE_MS
+            d = self.deadline_ns / 1e6 + (-SLO_STEP_MS if over > 0.01 else SLO_STEP_MS / 2)
+            self.deadline_ns = int(min(hi, max(lo, d)) * 1e6)
+            self._stats["slo_adjustments"] = self._stats.get("slo_adjustments", 0) + 1
+            self._stats["share_of_gaps_over_slo"] = round(over, 4)
+            self._win = [seq, 0.0, 0.0]
+
     # ---- statistics --------------------------------------------------------------------------------------------------
     def stats(self) -> dict:
         out = dict(self._stats)
         out["held_ms"] = round(out["held_ms"], 3)
         out["run_ahead_waits_ms"] = round(out["run_ahead_waits_ms"], 3)
+        out["deadline_ms"] = round(self.deadline_ns / 1e6, 3)
         return out
 
     def reset_stats(self) -> None:
-        for k in self._stats:
+        for k in list(self._stats):
             self._stats[k] = 0 if isinstance(self._stats[k], int) else 0.0

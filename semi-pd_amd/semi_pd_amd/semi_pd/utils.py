@@ -21,12 +21,14 @@ import torch
 import semi_pd_ipc
 from semi_pd_amd import _lib
 
-# The reference's defaults (semi_pd/utils.py:10-11): prefill 80 % of the SMs, decode 100 % -- overlapping shares.  With CU masks
-# that is a NESTED pair: the prefill instance keeps to the lowest 80 % of the CUs (192 of 256: whole groups of 32, one CU per
-# shader engine of every XCD, csrc/ipc.hip: semipd_cu_mask_fill), the decode instance may use every CU and has the rest to itself.  Measured on MI355X with the prefill GEMMs chosen on the share
-# (csrc/dense_gemm.hip), Llama-3-8B at 32 req/s: TTFT p50 39 ms / TBT p50 6.1, p99 12.0 ms, against 41.7 / 8.5 / 14.7 for the
-# disjoint 62 / 38 pair of round 3 (profiles/r04_policy_sweep.txt).
-PREFILL_ENGINE_SM_PERCENTILE = int(os.getenv("SEMI_PD_PREFILL_SM_PERCENTILE", 80))
+# The reference's defaults (semi_pd/utils.py:10-11) are prefill 80 % of the SMs, decode 100 %: overlapping shares.  With CU masks
+# that is a NESTED pair: the prefill instance keeps to the lowest CUs, the decode instance may use every CU and has the rest to
+# itself.  Shares are whole groups of 32 CUs (one per shader engine of every XCD, csrc/ipc.hip: semipd_cu_mask_fill), so on
+# an MI355X the choice is between 192 CUs (75 .. 81 %) and 224 (82 .. 93 %); measured, Llama-3-8B at 32 req/s (DESIGN.md 4.4,
+# 4.5): 192 CUs TTFT p50 40.7 ms / TBT p99 11.6 ms, 224 CUs 29.4 / 15.6 -- and 224 CUs with the decode-step deadline of
+# semi_pd/step_pacer.py 33.6 / 11.9.  The default here is therefore 88 % (224 CUs) where the reference has 80; the
+# environment variables of the reference still override it.
+PREFILL_ENGINE_SM_PERCENTILE = int(os.getenv("SEMI_PD_PREFILL_SM_PERCENTILE", 88))
 DECODE_ENGINE_SM_PERCENTILE = int(os.getenv("SEMI_PD_DECODE_SM_PERCENTILE", 100))
 
 

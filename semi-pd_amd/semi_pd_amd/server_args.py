@@ -14,6 +14,11 @@ from semi_pd_amd.semi_pd.utils import DECODE_ENGINE_SM_PERCENTILE, PREFILL_ENGIN
 
 
 CU_MASK_MODES = ("env", "none", "dynamic")
+# The operating point the bench line reports (profiles/r05_step_pacer_sweep_v2.txt, r05_step_pacer_slo_sweep.txt): prefill on 224
+# of 256 CUs, a decode step older than 9 ms holds the prefill instance's launches, the deadline then follows a 12 ms
+# objective for the 99th percentile of the time between tokens
+DEFAULT_DECODE_STEP_DEADLINE_MS = 9.0
+DEFAULT_DECODE_TBT_SLO_MS = 12.0
 
 
 @dataclasses.dataclass
@@ -70,7 +75,11 @@ class ServerArgs:
     prefill_backlog_full_tokens: int = 8192
     # Semi-PD, dynamic mode: a decode step older than this many milliseconds makes the prefill instance stop launching at its
     # next layer boundary until the step is over (semi_pd/step_pacer.py: host-side pacing over the share board); 0 = off
-    decode_step_deadline_ms: float = 0.0
+    # None = the measured default in dynamic mode (DEFAULT_DECODE_STEP_DEADLINE_MS), off otherwise
+    decode_step_deadline_ms: Optional[float] = None
+    # with a deadline: let it follow this objective for the 99th percentile of the time between tokens (ms; 0 = fixed
+    # deadline): the latest deadline whose tail still meets it.  None = DEFAULT_DECODE_TBT_SLO_MS with the default deadline
+    decode_tbt_slo_ms: Optional[float] = None
     test_plugin: Optional[str] = None        # tests only: a file every scheduler process executes at start-up (fault injection)
     prefill_stream_priority: int = 0         # HIP stream priority of the instance's compute stream: 0 normal, -1 high
     decode_stream_priority: int = 0
@@ -90,8 +99,17 @@ class ServerArgs:
     def __post_init__(self):
         if self.cu_mask_mode not in CU_MASK_MODES:
             raise ValueError(f"cu_mask_mode must be one of {CU_MASK_MODES}, got {self.cu_mask_mode!r}")
+        paced = self.enable_semi_pd and self.cu_mask_mode == "dynamic"
+        if self.decode_step_deadline_ms is None:
+            self.decode_step_deadline_ms = DEFAULT_DECODE_STEP_DEADLINE_MS if paced else 0.0
+            if self.decode_tbt_slo_ms is None:
+                self.decode_tbt_slo_ms = DEFAULT_DECODE_TBT_SLO_MS if paced else 0.0
+        if self.decode_tbt_slo_ms is None:
+            self.decode_tbt_slo_ms = 0.0
         if self.decode_step_deadline_ms < 0:
             raise ValueError("decode_step_deadline_ms must be >= 0 (0 = no deadline)")
+        if self.decode_tbt_slo_ms < 0 or (self.decode_tbt_slo_ms > 0 and self.decode_step_deadline_ms <= 0):
+            raise ValueError("decode_tbt_slo_ms adapts decode_step_deadline_ms: give a positive starting deadline with it")
         if self.decode_step_deadline_ms > 0 and self.enable_semi_pd and self.cu_mask_mode != "dynamic":
             raise ValueError("decode_step_deadline_ms needs --cu-mask-mode dynamic (the instances meet on the share board)")
         if self.prefill_backlog_full_tokens < 0:
@@ -198,9 +216,12 @@ def add_cli_args(parser):
                    help="HIP stream priority of the prefill instance (env / none modes; -1 = high)")
     p.add_argument("--decode-stream-priority", type=int, default=0, choices=[-1, 0, 1],
                    help="HIP stream priority of the decode instance (env / none modes; -1 = high)")
-    p.add_argument("--decode-step-deadline-ms", type=float, default=0.0,
+    p.add_argument("--decode-step-deadline-ms", type=float, default=None,
                    help="a decode step older than this makes the prefill instance yield at its next layer boundary until the "
                         "step is over (0 = off)")
+    p.add_argument("--decode-tbt-slo-ms", type=float, default=None,
+                   help="with --decode-step-deadline-ms: adapt the deadline so that the 99th percentile of the time between tokens "
+                        "meets this objective (0 = keep the deadline fixed)")
     p.add_argument("--k-split-by-share", action="store_true",
                    help="decode-sized GEMMs: K split sized for the instance's CU share instead of the device (faster on small "
                         "static shares; gives up bit-equal sums between the instances)")
@@ -243,6 +264,7 @@ def from_cli_args(args) -> ServerArgs:
         prefill_backlog_full_tokens=args.prefill_backlog_full_tokens,
         prefill_stream_priority=args.prefill_stream_priority, decode_stream_priority=args.decode_stream_priority,
         k_split_by_share=args.k_split_by_share, decode_step_deadline_ms=args.decode_step_deadline_ms,
+        decode_tbt_slo_ms=args.decode_tbt_slo_ms,
         attention_backend=args.attention_backend,
         sampling_backend=args.sampling_backend, triton_attention_num_kv_splits=args.triton_attention_num_kv_splits)
     if args.quantization == "fp8":

@@ -94,7 +94,7 @@ def test_the_bench_line_is_assembled_with_every_contract_field(monkeypatch, caps
     assert "workload" in cfgd and "model" not in cfgd and "CU-masked stream" in cfgd["workload"] and "50 / 50" in cfgd["workload"]
     assert cfgd["prefill_gemm"].startswith("library solutions timed on the prefill share") and "decode step" in cfgd["prefill_gemm"]
     if expect_static:
-        assert (cfgd["prefill_cu_percent"], cfgd["decode_cu_percent"]) == (80, 100)
+        assert (cfgd["prefill_cu_percent"], cfgd["decode_cu_percent"]) == (bench.DEFAULT_PREFILL_CU, 100)
         # the main engine, the literal 50 / 50 engine, the unified engine, and one engine each for BASELINE configs 1 and 3
         assert d["static_split_50_50"]["output_tok_s"] > 0 and len(FakeEngine.instances) == 5
         assert FakeEngine.instances[1].sa.cu_mask_mode == "env" and FakeEngine.instances[0].sa.cu_mask_mode == "dynamic"
@@ -110,6 +110,6 @@ def test_the_bench_line_is_assembled_with_every_contract_field(monkeypatch, caps
         assert d["saturation"]["output_tokens"] == 6 * 4
         assert d["steps"] == 2 and d["warmup"] == 1
     else:
-        assert (cfgd["prefill_cu_percent"], cfgd["decode_cu_percent"]) == (80, 100)
+        assert (cfgd["prefill_cu_percent"], cfgd["decode_cu_percent"]) == (bench.DEFAULT_PREFILL_CU, 100)
         assert "saturation" not in d and "qps_sweep" not in d and "config1_opt_125m" not in d
         assert "mla_decode_kernel" in d["roofline_extra"]["decode_attention"]["kernel"]

@@ -47,8 +47,9 @@ def test_default_shares_of_an_mi355x():
 
 
 def test_defaults_of_the_reference_environment_variables():
-    """SEMI_PD_PREFILL_SM_PERCENTILE / SEMI_PD_DECODE_SM_PERCENTILE (semi_pd/utils.py:10-11) exist with the reference's
-    own defaults: prefill 80 %, decode 100 % (nested shares)."""
+    """SEMI_PD_PREFILL_SM_PERCENTILE / SEMI_PD_DECODE_SM_PERCENTILE (semi_pd/utils.py:10-11) exist; the defaults are nested
+    shares like the reference's (prefill 80 %, decode 100 %) at the share the MI355X measurements chose: 88 % = 224 CUs with
+    the decode-step deadline (semi_pd/utils.py)."""
     from semi_pd_amd.semi_pd import utils
-    assert (utils.PREFILL_ENGINE_SM_PERCENTILE, utils.DECODE_ENGINE_SM_PERCENTILE) == (80, 100) or \
+    assert (utils.PREFILL_ENGINE_SM_PERCENTILE, utils.DECODE_ENGINE_SM_PERCENTILE) == (88, 100) or \
         "SEMI_PD_PREFILL_SM_PERCENTILE" in __import__("os").environ

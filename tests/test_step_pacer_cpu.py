@@ -89,3 +89,51 @@ def test_a_deadline_needs_the_share_board():
     with pytest.raises(ValueError, match="dynamic"):
         ServerArgs(enable_semi_pd=True, cu_mask_mode="env", decode_step_deadline_ms=8.0)
     assert ServerArgs(enable_semi_pd=True, decode_step_deadline_ms=8.0).cu_mask_mode == "dynamic"
+
+
+def test_the_deadline_follows_the_objective(boards):
+    """slo_ms: the pacer sees the steps that overlap prefill work begin and end, counts the token gaps above the objective
+    against all steps of a window and moves the deadline towards the point where 1 % of the gaps exceed it."""
+    from semi_pd_amd.semi_pd.share_board import BUSY_DECODE
+    d, p = boards
+    t = FakeTime()
+    pacer = SP.StepPacer(p, deadline_ms=9.0, device=None, clock=t.clock, sleep=t.sleep, slo_ms=12.0)
+    d.store(BUSY_DECODE, 24)
+
+    def run_window(long_every):
+        """SLO_WINDOW steps; every `long_every`-th lasts 14 ms (above the objective), the others 5 ms; the hook looks at the
+        board once per step (a young step: no hold)."""
+        for k in range(SP.SLO_WINDOW + 1):
+            dur = 14_000_000 if (long_every and k % long_every == 0) else 5_000_000
+            d.publish_step(t.ns)
+            pacer.before_layer(1)
+            t.ns += dur
+    # 1 step in 20 is long: 5 % of the gaps above the objective -> the deadline comes down
+    run_window(20)
+    st = pacer.stats()
+    assert st["slo_adjustments"] == 1 and st["share_of_gaps_over_slo"] == pytest.approx(0.05, abs=0.01)
+    assert st["deadline_ms"] == pytest.approx(9.0 - SP.SLO_STEP_MS)
+    run_window(20)
+    assert pacer.stats()["deadline_ms"] == pytest.approx(9.0 - 2 * SP.SLO_STEP_MS)
+    # no long steps: it creeps back up (half as fast), and stays inside its range
+    run_window(0)
+    assert pacer.stats()["deadline_ms"] == pytest.approx(9.0 - 1.5 * SP.SLO_STEP_MS)
+    for _ in range(80):
+        run_window(0)
+    assert pacer.stats()["deadline_ms"] == SP.DEADLINE_RANGE_MS[1]
+    for _ in range(80):
+        run_window(2)
+    assert pacer.stats()["deadline_ms"] == SP.DEADLINE_RANGE_MS[0]
+    # without an objective the deadline is what was given
+    fixed = SP.StepPacer(p, deadline_ms=9.0, device=None, clock=t.clock, sleep=t.sleep)
+    run = fixed.stats()["deadline_ms"]
+    assert run == 9.0 and "slo_adjustments" not in fixed.stats()
+    from semi_pd_amd.server_args import ServerArgs
+    with pytest.raises(ValueError, match="starting deadline"):
+        ServerArgs(enable_semi_pd=True, decode_step_deadline_ms=0.0, decode_tbt_slo_ms=12.0)
+    # the defaults: the measured operating point in dynamic mode, nothing where there is no share board
+    from semi_pd_amd import server_args as SA
+    a = ServerArgs(enable_semi_pd=True)
+    assert (a.decode_step_deadline_ms, a.decode_tbt_slo_ms) == (SA.DEFAULT_DECODE_STEP_DEADLINE_MS, SA.DEFAULT_DECODE_TBT_SLO_MS)
+    b = ServerArgs(enable_semi_pd=True, cu_mask_mode="env")
+    assert (b.decode_step_deadline_ms, b.decode_tbt_slo_ms) == (0.0, 0.0) and ServerArgs().decode_step_deadline_ms == 0.0
