@@ -164,7 +164,9 @@ stream_gemm_glds_kernel(T* __restrict__ out, float* __restrict__ planes, const T
   // on a 48-CU share the kernel was pinned at 1.35 TB/s however many of the CUs streamed
   // (profiles/r05_kbench_stream_planes_graph_48cus_v0.txt).  The rotation changes the order of a workgroup's fp32
   // sums over k (a function of blockIdx only: the same bits on every run, grid and CU mask).
-  const int rot = ROT ? (int)(((uint32_t)(blockIdx.x + 1) * 0x9E3779B1u >> 16) % (uint32_t)nkb) : 0;
+  // (not in the grouped form: its experts' fused and plain launches promise equal bits, tests/test_gpu_ops.py
+  //  test_moe_stream_gemm_matches_fp32_per_expert, and its workgroups start at different experts' weights anyway)
+  const int rot = (ROT && !GR) ? (int)(((uint32_t)(blockIdx.x + 1) * 0x9E3779B1u >> 16) % (uint32_t)nkb) : 0;
   auto issue = [&](int kb) __attribute__((always_inline)) {   // block kb of this slice -> ring position kb % R
     const int slot = kb % R;
     int kk = kb + rot;

@@ -113,3 +113,24 @@ def test_the_bench_line_is_assembled_with_every_contract_field(monkeypatch, caps
         assert (cfgd["prefill_cu_percent"], cfgd["decode_cu_percent"]) == (bench.DEFAULT_PREFILL_CU, 100)
         assert "saturation" not in d and "qps_sweep" not in d and "config1_opt_125m" not in d
         assert "mla_decode_kernel" in d["roofline_extra"]["decode_attention"]["kernel"]
+
+
+def test_a_sweep_only_invocation_prints_a_line(monkeypatch, capsys):
+    """`--steps 0 --warmup 0 --rate-sweep ...` (how SURVEY 8d.2's lambda sweep is run, tools/runs/r05_s19.sh): no timed step, the
+    sweep points in qps_sweep, still one JSON line."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from semi_pd_amd.entrypoints import engine as engine_mod
+    monkeypatch.setattr(engine_mod, "Engine", FakeEngine)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "0", "--warmup", "0", "--rate-sweep", "200,400", "--sweep-num-requests", "5",
+                                      "--input-len", "16", "--output-len", "4", "--sweep-output-len", "4", "--no-saturation-wave",
+                                      "--no-static-split-wave", "--no-unified-wave", "--no-side-configs", "--no-cpu-baseline",
+                                      "--no-kernel-timing"])
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    FakeEngine.instances.clear()
+    bench.main()
+    d = json.loads([ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("{")][-1])
+    assert d["steps"] == 0 and d["value"] == 0 and d["p50_ttft_ms"] is None
+    assert [(s["request_rate"], s["num_requests"], s["output_tokens"]) for s in d["qps_sweep"]] == [(200.0, 5, 20), (400.0, 5, 20)]
+    assert len(FakeEngine.instances) == 1

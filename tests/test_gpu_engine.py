@@ -37,7 +37,10 @@ def server_args(cfg, **kw):
     # (static HSA_CU_MASK shares unless a test asks otherwise: one set of decode graphs per engine; the work-conserving
     #  default of ServerArgs is exercised by test_gpu_cu_share.py, test_gpu_full_depth.py and the launch_server test)
     base = dict(model_config=cfg, context_length=384, max_running_requests=24, max_total_tokens=6000,
-                cuda_graph_max_bs=16, chunked_prefill_size=8192, watchdog_timeout=120.0, cu_mask_mode="env")
+                cuda_graph_max_bs=16, chunked_prefill_size=8192, watchdog_timeout=120.0, cu_mask_mode="env",
+                # (no start-up timing of the library's GEMM solutions on the prefill share: minutes for a model with many
+                #  shapes, once per box; test_semi_pd_matches_unified keeps it on, and so does every bench run)
+                tune_prefill_gemm=False)
     base.update(kw)
     return ServerArgs(**base)
 
@@ -187,7 +190,7 @@ def test_semi_pd_matches_unified(unified_llama):
     from semi_pd_amd.entrypoints.engine import Engine
     from semi_pd_amd.managers.io_struct import SamplingParams
     cfg, sd, prompts, outs, _ = unified_llama
-    eng = Engine(server_args(cfg, enable_semi_pd=True, prefill_cu_percent=50, decode_cu_percent=50))
+    eng = Engine(server_args(cfg, enable_semi_pd=True, prefill_cu_percent=50, decode_cu_percent=50, tune_prefill_gemm=None))
     try:
         masks = {i["role"]: i["hsa_cu_mask"] for i in eng.ready_infos}
         assert masks["PREFILL"] and masks["DECODE"] and masks["PREFILL"] != masks["DECODE"]

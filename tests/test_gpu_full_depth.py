@@ -5,8 +5,8 @@ Every other engine test stops at two layers (test_gpu_full_width.py, test_gpu_ra
 exactly this (python/sglang/bench_one_batch.py:16-41 `--correct`; test/srt/models/test_generation_models.py:43-45: logprobs
 within 5e-2 of HF, same text).  Here, with seeded dummy weights at the real shapes:
 
- * Semi-PD under the DEFAULT policy of ServerArgs -- work-conserving shares, prefill 80 % / decode 100 %, the prefill
-   instance moving between its CU-masked stream and the NULL stream -- produces the unified engine's tokens for 4 requests
+ * Semi-PD under the DEFAULT policy of ServerArgs -- work-conserving shares, prefill 88 % / decode 100 %, the prefill
+   instance moving between its CU-masked stream and the NULL stream, pacing its layers on the decode-step deadline -- produces the unified engine's tokens for 4 requests
    x 16 steps.  Two engines that run different kernels on different CU sets may part ways only at a near-tie: where the two
    sequences first differ, the unified engine's own top-2 log-probability gap at that step must be inside the margin and
    the other token must be its runner-up (from there on the continuations are different texts and are not compared);
@@ -89,9 +89,11 @@ def test_llama3_8b_all_32_layers_semi_pd_default_policy_equals_unified_and_the_o
     t0 = time.time()
     uni, lps, sd, _ = _run(_args(cfg), prompts, logprobs=True, want_sd=True)
     semi, _, _, stats = _run(_args(cfg, enable_semi_pd=True), prompts)
-    # the policy under test is the default one: unmasked processes, work-conserving shares of 80 % / 100 %
+    # the policy under test is the default one: unmasked processes, work-conserving shares of 88 % / 100 %, the decode-step
+    # deadline following its objective
     a = _args(cfg, enable_semi_pd=True)
-    assert (a.cu_mask_mode, a.prefill_cu_percent, a.decode_cu_percent) == ("dynamic", 80, 100)
+    assert (a.cu_mask_mode, a.prefill_cu_percent, a.decode_cu_percent) == ("dynamic", 88, 100)
+    assert a.decode_step_deadline_ms > 0 and a.decode_tbt_slo_ms > 0 and "step_gate" in stats["PREFILL"]
     p = stats["PREFILL"]
     assert p.get("batches_on_full", 0) + p.get("batches_on_share", 0) == p["prefill_batches"] >= 1
     equal = _same_up_to_near_ties(uni, lps, semi)

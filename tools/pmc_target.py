@@ -20,6 +20,24 @@ if which == "decode":
     for _ in range(5):
         ops.decode_attention_fwd(q, kb, vb, o, indptr, idx, None, splits, D ** -0.5)
     print("algorithmic_bytes_per_launch", B * ctx * Hkv * 2 * D * 2 + 2 * B * Hq * D * 2)
+elif which == "decode32":
+    # the decode attention as the serving line runs it: B = 32, ctx 1100, Llama-3-8B heads, the split count of the engine
+    from semi_pd_amd.layers.attention_backend import choose_kv_splits
+    B, ctx, Hq, Hkv, D = 32, 1100, 32, 8, 128
+    splits = choose_kv_splits(B, Hkv, 2048, 256, 32)
+    N = B * ctx + 1
+    sets = []
+    for _ in range(3):   # three KV pools in rotation: 3 x 144 MB is beyond the Infinity Cache
+        sets.append((torch.randn(N, Hkv, D, device=dev, dtype=torch.bfloat16), torch.randn(N, Hkv, D, device=dev, dtype=torch.bfloat16)))
+    q = torch.randn(B, Hq, D, device=dev, dtype=torch.bfloat16)
+    o = torch.empty_like(q)
+    indptr = torch.arange(B + 1, device=dev, dtype=torch.int32) * ctx
+    idx = (torch.randperm(N - 1, device=dev)[: B * ctx] + 1).to(torch.int32)
+    lg = torch.empty(B, Hq, splits, D + 1, device=dev, dtype=torch.float32)
+    for i in range(12):
+        kb, vb = sets[i % 3]
+        ops.decode_attention_fwd(q, kb, vb, o, indptr, idx, lg, splits, D ** -0.5)
+    print("splits", splits, "algorithmic_bytes_per_launch", B * ctx * Hkv * 2 * D * 2 + 2 * B * Hq * D * 2)
 elif which == "mla":
     B, ctx, H, splits = 128, 8192, 16, 4
     N = B * ctx + 1
