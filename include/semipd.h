@@ -309,8 +309,11 @@ int semipd_moe_gemm_tall(void* c, const void* a, const void* w, const float* top
 int semipd_dense_gemm_init(size_t workspace_bytes);
 int semipd_dense_gemm_set_cus(int cus);
 /* Load a table written by semipd_dense_gemm_report instead of timing again (start-up cache, keyed by the caller on
- * architecture, CU count and library version); *loaded = entries taken.  Indices this build does not know are skipped. */
+ * architecture, CU count and library version: semipd_dense_gemm_library_version); *loaded = entries taken.  Skipped: indices
+ * this build does not know, solutions that do not support the problem, and indices whose kernel NAME here differs from the
+ * one recorded in the line (a table from another build of the library). */
 int semipd_dense_gemm_import(const char* text, int* loaded);
+int semipd_dense_gemm_library_version(int* version);
 int semipd_dense_gemm_tune(int64_t n, int64_t k, const int64_t* rows, int num_rows, int num_full_search, int dtype,
                            int num_heuristics, int max_solutions, void* stream);
 int semipd_dense_gemm(void* out, const void* x, const void* weight, const void* bias, int64_t rows, int64_t n, int64_t k,

@@ -539,6 +539,11 @@ int semipd_dense_gemm_import(const char* text, int* loaded) {
     const bool ok = supported(s, pl, a);
     destroy_problem(pl);
     if (!ok) continue;
+    // an index is only meaningful inside one build of the library: the table carries the winner's kernel name, and an
+    // index that names another kernel here (a table written by another hipBLASLt, a file someone else put there) is skipped
+    const std::string have = hipblaslt_ext::getSolutionNameFromAlgo(s.handle, a);
+    const size_t kpos = line.find(" kernel=");
+    if (kpos != std::string::npos && line.substr(kpos + 8) != have) continue;
     Tuned t;
     t.algo = a;
     t.solution_index = sol;
@@ -546,13 +551,26 @@ int semipd_dense_gemm_import(const char* text, int* loaded) {
     t.us_default = us_def;
     t.candidates = cand;
     t.rejected = rej;
-    t.name = hipblaslt_ext::getSolutionNameFromAlgo(s.handle, a);
+    t.name = have;
     s.tuned[std::make_tuple(cus, dtype, (int64_t)n, (int64_t)k)][(int64_t)rows] = t;
     ++taken;
   }
   for (auto& kv : s.plans) destroy_problem(kv.second);
   s.plans.clear();
   if (loaded) *loaded = taken;
+  return 0;
+}
+
+/* hipblasLtGetVersion of the library this process runs (part of the key of a cached tuning table: solution indices
+ * are per build). */
+int semipd_dense_gemm_library_version(int* version) {
+  SEMIPD_CHECK_ARG(version, SEMIPD_EINVAL, "dense_gemm_library_version: null pointer");
+  State& s = st();
+  std::lock_guard<std::mutex> g(s.mu);
+  if (ensure_init(s, 0)) return 1;
+  int v = 0;
+  if (hipblasLtGetVersion(s.handle, &v) != HIPBLAS_STATUS_SUCCESS) v = -1;
+  *version = v;
   return 0;
 }
 

@@ -74,6 +74,7 @@ _SIGNATURES = {
     "semipd_dense_gemm_init": [_sz],
     "semipd_dense_gemm_set_cus": [_i32],
     "semipd_dense_gemm_import": [C.c_char_p, _vp],
+    "semipd_dense_gemm_library_version": [_vp],
     "semipd_dense_gemm_tune": [_i64, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "semipd_dense_gemm": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32, _vp],
     "semipd_dense_gemm_report": [_vp, _sz],

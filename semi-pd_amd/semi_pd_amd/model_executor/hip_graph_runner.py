@@ -170,7 +170,11 @@ class HipGraphRunner:
         self.req_pool_indices[:raw_bs].copy_(forward_batch.req_pool_indices)
         self.seq_lens[:raw_bs].copy_(forward_batch.seq_lens)
         self.out_cache_loc[:raw_bs].copy_(forward_batch.out_cache_loc)
-        key = (self.mr.num_cus_owned if len(self.variants) > 1 else self.variants[0], bs)
+        # the variant of the stream the instance is on (its OWN CU count: an experiment that declares another count to the
+        # kernels, SEMIPD_DECLARED_CUS_*, must not change which graph is found)
+        share = getattr(self.mr, "cu_share", None)
+        cus = share.cus[share.active] if (share is not None and share.active and len(self.variants) > 1) else self.variants[0]
+        key = (cus, bs)
         self.graphs[key].replay()
         logits, ids = self.outputs[key]
         return LogitsProcessorOutput(logits[:raw_bs] if logits is not None else None, next_token_ids=ids[:raw_bs])

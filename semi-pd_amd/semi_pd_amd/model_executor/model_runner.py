@@ -257,6 +257,7 @@ class ModelRunner:
                    "stream_linear_set_cus")
         _lib.check(lib.semipd_gemm_tall_set_cus(int(cus)), "gemm_tall_set_cus")
         _lib.check(lib.semipd_dense_gemm_set_cus(int(cus)), "dense_gemm_set_cus")
+        ops.set_declared_cus(int(cus))
 
     def init_cu_share(self, role: InstanceRole, percent: int, board=None):
         """--cu-mask-mode dynamic: this (unmasked) process gets a CU-masked stream over its own share next to a stream over
@@ -440,12 +441,14 @@ class ModelRunner:
         # start-up cache: the table is a property of (architecture, CUs of the share, library build, shapes, row counts);
         # it is kept under $SEMIPD_CACHE_DIR (default ~/.cache/semipd) and next to the model when there is a model path
         import hashlib, os
-        lib_ver = torch.version.hip or "?"
+        lib_ver = (torch.version.hip or "?", ops.dense_gemm_library_version())   # solution indices are per library build
         arch = torch.cuda.get_device_properties(self.device).gcnArchName.split(":")[0]
         key = hashlib.sha256(repr((arch, self.num_cus, self.num_cus_owned, lib_ver, sorted((n, k, str(dt)) for n, k, dt in shapes),
                                    tuple(rows), int(num_full_search), os.environ.get("SEMIPD_DG_FINAL_US", ""))).encode()).hexdigest()[:16]
         dirs = [os.environ.get("SEMIPD_CACHE_DIR") or os.path.join(os.path.expanduser("~"), ".cache", "semipd")]
-        if getattr(self, "model_path", None) and os.path.isdir(self.model_path):
+        # (a model directory may be shared and is not ours to write into or to trust: only on request)
+        if os.environ.get("SEMIPD_DG_CACHE_IN_MODEL_DIR") == "1" and getattr(self, "model_path", None) \
+                and os.path.isdir(self.model_path):
             dirs.insert(0, self.model_path)
         name = f"dense_gemm_{arch}_{self.num_cus_owned}cus_{key}.txt"
         if os.environ.get("SEMIPD_DG_CACHE", "1") != "0":

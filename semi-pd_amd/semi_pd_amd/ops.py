@@ -403,7 +403,21 @@ def gemm_tall(x: torch.Tensor, weight: torch.Tensor, fuse_silu_mul: bool = False
 
 
 # --------------------------------------------------------------------------- prefill-sized dense layers on a CU share
-_DENSE_GEMM = {"ready": False, "tuned": set()}
+_DENSE_GEMM = {"ready": False, "tuned": set(), "cus": 0}
+
+
+def set_declared_cus(cus: int) -> None:
+    """The CU count of the stream the following GEMM choices are made for (ModelRunner.set_owned_cus): what was timed on the
+    prefill share says nothing about the whole chip, so the tuned flag and the tiled-GEMM preference are filed per count
+    like the C table (semipd_dense_gemm_set_cus)."""
+    _DENSE_GEMM["cus"] = int(cus)
+
+
+def dense_gemm_library_version() -> int:
+    import ctypes as _C
+    v = _C.c_int(0)
+    check(_lib.load().semipd_dense_gemm_library_version(_C.addressof(v)), "dense_gemm_library_version")
+    return int(v.value)
 
 
 def dense_gemm_tune(n: int, k: int, rows, dtype: torch.dtype, num_full_search: int = 0, num_heuristics: int = 64,
@@ -419,7 +433,7 @@ def dense_gemm_tune(n: int, k: int, rows, dtype: torch.dtype, num_full_search: i
                                      int(num_heuristics), int(max_solutions), current_stream(None)), "dense_gemm_tune")
     torch.cuda.synchronize()
     _DENSE_GEMM["ready"] = True
-    _DENSE_GEMM["tuned"].add((int(n), int(k), dtype))
+    _DENSE_GEMM["tuned"].add((_DENSE_GEMM["cus"], int(n), int(k), dtype))
 
 
 def dense_gemm_import(text: str, shapes) -> int:
@@ -433,13 +447,14 @@ def dense_gemm_import(text: str, shapes) -> int:
     if got.value:
         _DENSE_GEMM["ready"] = True
         for n, k, dt in shapes:
-            if f" n={int(n)} k={int(k)} " in text:
-                _DENSE_GEMM["tuned"].add((int(n), int(k), dt))
+            for line in text.splitlines():
+                if f" n={int(n)} k={int(k)} " in line and line.startswith("cus="):
+                    _DENSE_GEMM["tuned"].add((int(line.split()[0][4:]), int(n), int(k), dt))
     return int(got.value)
 
 
 def dense_gemm_is_tuned(weight: torch.Tensor) -> bool:
-    return _DENSE_GEMM["ready"] and (weight.shape[0], weight.shape[1], weight.dtype) in _DENSE_GEMM["tuned"]
+    return _DENSE_GEMM["ready"] and (_DENSE_GEMM["cus"], weight.shape[0], weight.shape[1], weight.dtype) in _DENSE_GEMM["tuned"]
 
 
 # Prefill-sized batches of a layer whose weight shape was timed at start-up: where the tiled ping-pong GEMM (csrc/gemm8p.hip)
@@ -449,12 +464,12 @@ _TALL_PREF = {}
 
 
 def set_tall_preference(n: int, k: int, dtype: torch.dtype, fuse_silu_mul: bool, rows_and_wins) -> None:
-    _TALL_PREF[(int(n), int(k), dtype, bool(fuse_silu_mul))] = sorted((int(r), bool(w)) for r, w in rows_and_wins)
+    _TALL_PREF[(_DENSE_GEMM["cus"], int(n), int(k), dtype, bool(fuse_silu_mul))] = sorted((int(r), bool(w)) for r, w in rows_and_wins)
 
 
 def tall_preferred(weight: torch.Tensor, rows: int, fuse_silu_mul: bool = False) -> bool:
     """Did gemm_tall win at the timed row count nearest (in log distance) to `rows` for this weight's shape?"""
-    ent = _TALL_PREF.get((weight.shape[0], weight.shape[1], weight.dtype, bool(fuse_silu_mul)))
+    ent = _TALL_PREF.get((_DENSE_GEMM["cus"], weight.shape[0], weight.shape[1], weight.dtype, bool(fuse_silu_mul)))
     if not ent:
         return False
     import math
