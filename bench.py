@@ -35,7 +35,7 @@ DEFAULT_DECODE_CU = 100
 DEFAULT_BACKLOG_FULL_TOKENS = 8192
 # decode-step deadline gate (semi_pd/step_pacer.py): a decode step older than this holds the prefill instance at its next
 # layer boundary until the step is over.  0 = off
-DEFAULT_DEADLINE_MS = 9.0
+DEFAULT_DEADLINE_MS = 8.5
 DEFAULT_TBT_SLO_MS = 12.0
 # BASELINE config 2: "Poisson QPS sweep" -- three points in the default line (in = 1024 / out = 256)
 DEFAULT_SWEEP_RATES = "8,16,32"
@@ -483,7 +483,7 @@ def main():
 
     # side engines run the headline's load for at most this many timed waves (the driver's 20-step line would otherwise
     # spend as long on each of them as on the headline)
-    n_side = max(1, min(args.steps, 5))
+    n_side = max(1, min(args.steps, 3))
     static_split = None
     if (world == 1 and args.mode == "semi-pd" and not args.no_static_split_wave
             and (args.prefill_cu, args.decode_cu) != (50, 50)):

@@ -24,7 +24,7 @@ instance three times slower during the very holds that should have freed it; pro
 Optionally the deadline follows a service-level objective (`slo_ms`, ServerArgs.decode_tbt_slo_ms): the hooks see every
 decode step that overlaps prefill work begin (STEP_SEQ / STEP_START_NS), so the pacer knows how long each of them took and
 how many steps there were in all; every SLO_WINDOW steps it compares the share of token gaps above the objective (steps
-weighted by their batch size, BUSY_DECODE) with 1 % and moves the deadline by SLO_STEP_MS towards the point where the 99th
+weighted by their batch size, BUSY_DECODE) with 1 % and moves the deadline by SLO_STEP_MS (twice that when far off) towards the point where the 99th
 percentile sits on the objective -- the latest deadline, i.e. the fewest and shortest holds, that still keeps the tail.
 
 A hold is therefore an EMPTY prefill queue: the state between two prefill batches, in which the decode instance is known to
@@ -42,7 +42,7 @@ import os
 
 RUN_AHEAD = int(os.environ.get("SEMIPD_PACER_RUN_AHEAD", "1"))   # decoder layers the host may be ahead of the GPU
 MAX_WAIT_MS = 50.0      # a hold never lasts longer than this
-SLO_WINDOW = 512        # decode steps per adjustment of the deadline (about 3 s at 6 ms per step)
+SLO_WINDOW = 256        # decode steps per adjustment of the deadline (about 1.5 s at 6 ms per step)
 SLO_STEP_MS = 0.25
 SLO_MARGIN_MS = 0.3     # the client's token gap is the step plus host work of the decode instance
 DEADLINE_RANGE_MS = (5.0, 16.0)
@@ -138,7 +138,8 @@ class StepPacer:
             total = max(1.0, steps * float(batch))
             over = self._win[2] / total
             lo, hi = DEADLINE_RANGE_MS
-            d = self.deadline_ns / 1e6 + (-SLO_STEP_MS if over > 0.01 else SLO_STEP_MS / 2)
+            # down by one step while more than 1 % of the gaps exceed the objective (two steps from 2.5 %), up by half a step
+            d = self.deadline_ns / 1e6 + (-2 * SLO_STEP_MS if over > 0.025 else -SLO_STEP_MS if over > 0.01 else SLO_STEP_MS / 2)
             self.deadline_ns = int(min(hi, max(lo, d)) * 1e6)
             self._stats["slo_adjustments"] = self._stats.get("slo_adjustments", 0) + 1
             self._stats["share_of_gaps_over_slo"] = round(over, 4)

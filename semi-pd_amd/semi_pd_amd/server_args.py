@@ -15,9 +15,9 @@ from semi_pd_amd.semi_pd.utils import DECODE_ENGINE_SM_PERCENTILE, PREFILL_ENGIN
 
 CU_MASK_MODES = ("env", "none", "dynamic")
 # The operating point the bench line reports (profiles/r05_step_pacer_sweep_v2.txt, r05_step_pacer_slo_sweep.txt): prefill on 224
-# of 256 CUs, a decode step older than 9 ms holds the prefill instance's launches, the deadline then follows a 12 ms
+# of 256 CUs, a decode step older than 8.5 ms holds the prefill instance's launches, the deadline then follows a 12 ms
 # objective for the 99th percentile of the time between tokens
-DEFAULT_DECODE_STEP_DEADLINE_MS = 9.0
+DEFAULT_DECODE_STEP_DEADLINE_MS = 8.5
 DEFAULT_DECODE_TBT_SLO_MS = 12.0
 
 

@@ -108,16 +108,17 @@ def test_the_deadline_follows_the_objective(boards):
             d.publish_step(t.ns)
             pacer.before_layer(1)
             t.ns += dur
-    # 1 step in 20 is long: 5 % of the gaps above the objective -> the deadline comes down
+    # 1 step in 20 is long: 5 % of the gaps above the objective -> the deadline comes down, two steps at once
     run_window(20)
     st = pacer.stats()
     assert st["slo_adjustments"] == 1 and st["share_of_gaps_over_slo"] == pytest.approx(0.05, abs=0.01)
-    assert st["deadline_ms"] == pytest.approx(9.0 - SP.SLO_STEP_MS)
-    run_window(20)
-    assert pacer.stats()["deadline_ms"] == pytest.approx(9.0 - 2 * SP.SLO_STEP_MS)
-    # no long steps: it creeps back up (half as fast), and stays inside its range
+    assert st["deadline_ms"] == pytest.approx(9.0 - 2 * SP.SLO_STEP_MS)
+    # 1 in 60: 1.7 % -> one step
+    run_window(60)
+    assert pacer.stats()["deadline_ms"] == pytest.approx(9.0 - 3 * SP.SLO_STEP_MS)
+    # no long steps: it creeps back up (half a step), and stays inside its range
     run_window(0)
-    assert pacer.stats()["deadline_ms"] == pytest.approx(9.0 - 1.5 * SP.SLO_STEP_MS)
+    assert pacer.stats()["deadline_ms"] == pytest.approx(9.0 - 2.5 * SP.SLO_STEP_MS)
     for _ in range(80):
         run_window(0)
     assert pacer.stats()["deadline_ms"] == SP.DEADLINE_RANGE_MS[1]
