@@ -13,6 +13,8 @@ Slots (int64 each, one writer per slot):
     TAKEN_*        counters for the statistics: steps / batches the instance ran on the whole chip
     STEP_START_NS  time.monotonic_ns() at which the decode step in flight began on the GPU (0 = none), STEP_SEQ its number:
                    what the prefill instance's step pacer reads (semi_pd/step_pacer.py)
+    STEP_FAST_NS   how long a decode step takes when nothing is in its way: the 10th percentile of the decode instance's
+                   recent step times (a deadline below a small multiple of it could never be met: the pacer's floor)
 """
 from __future__ import annotations
 
@@ -22,7 +24,7 @@ import time
 from semi_pd_amd import _lib
 from semi_pd_amd.semi_pd.utils import InstanceRole
 
-BUSY_PREFILL, BUSY_DECODE, BEAT_PREFILL, BEAT_DECODE, TAKEN_PREFILL, TAKEN_DECODE, STEP_START_NS, STEP_SEQ = range(8)
+BUSY_PREFILL, BUSY_DECODE, BEAT_PREFILL, BEAT_DECODE, TAKEN_PREFILL, TAKEN_DECODE, STEP_START_NS, STEP_SEQ, STEP_FAST_NS = range(9)
 
 
 class ShareBoard:
@@ -69,6 +71,12 @@ class ShareBoard:
         if started_ns:
             self.add(STEP_SEQ, 1)
         self.store(STEP_START_NS, int(started_ns))
+
+    def publish_fast_step(self, ns: int) -> None:
+        self.store(STEP_FAST_NS, int(ns))
+
+    def fast_step_ns(self) -> int:
+        return self.load(STEP_FAST_NS)
 
     def step_in_flight(self):
         """(start in monotonic ns or 0, sequence number) of the decode step in flight."""

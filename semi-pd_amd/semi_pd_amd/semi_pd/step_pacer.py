@@ -46,6 +46,11 @@ SLO_WINDOW = 256        # decode steps per adjustment of the deadline (about 1.5
 SLO_STEP_MS = 0.25
 SLO_MARGIN_MS = 0.3     # the client's token gap is the step plus host work of the decode instance
 DEADLINE_RANGE_MS = (5.0, 16.0)
+# Nothing can be asked of a decode step that it could not do alone: the deadline in force is at least FLOOR_DEADLINE times, the
+# objective at least FLOOR_SLO times the decode instance's fast step (STEP_FAST_NS: Llama-3-8B ~4.4 ms, DeepSeek-V2-Lite
+# ~8 ms -- with a fixed 8.5 ms every one of its steps would be "overdue" and the prefill instance held for nothing)
+FLOOR_DEADLINE = 1.4
+FLOOR_SLO = 1.8
 
 
 class StepPacer:
@@ -99,7 +104,8 @@ class StepPacer:
         if not start:
             return
         t0 = self._clock()
-        if t0 - start < self.deadline_ns:
+        fast = self.board.fast_step_ns()
+        if t0 - start < max(self.deadline_ns, int(FLOOR_DEADLINE * fast)):
             return
         st = self._stats
         st["holds"] += 1
@@ -123,7 +129,7 @@ class StepPacer:
         if prev is not None and seq != prev[1]:
             if start and seq == prev[1] + 1 and prev[0]:
                 dur = start - prev[0]                       # step prev ended where its successor began
-                if dur > self.slo_ns:
+                if dur > max(self.slo_ns, int(FLOOR_SLO * self.board.fast_step_ns())):
                     self._win[2] += prev[2]
             self._seen = None
         if start and self._seen is None:

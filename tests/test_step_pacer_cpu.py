@@ -138,3 +138,43 @@ def test_the_deadline_follows_the_objective(boards):
     assert (a.decode_step_deadline_ms, a.decode_tbt_slo_ms) == (SA.DEFAULT_DECODE_STEP_DEADLINE_MS, SA.DEFAULT_DECODE_TBT_SLO_MS)
     b = ServerArgs(enable_semi_pd=True, cu_mask_mode="env")
     assert (b.decode_step_deadline_ms, b.decode_tbt_slo_ms) == (0.0, 0.0) and ServerArgs().decode_step_deadline_ms == 0.0
+
+
+def test_nothing_is_asked_of_a_step_that_it_could_not_do_alone(boards):
+    """STEP_FAST_NS (the decode instance's 10th-percentile step time) floors the deadline and the objective: a model whose
+    step takes 8 ms alone is not held at 8.5 ms, and its 10 ms steps do not count against a 12 ms objective."""
+    d, p = boards
+    t = FakeTime()
+    pacer = SP.StepPacer(p, deadline_ms=8.5, device=None, clock=t.clock, sleep=t.sleep, slo_ms=12.0)
+    d.publish_fast_step(8_000_000)
+    d.publish_step(t.ns - 10_000_000)          # 10 ms old: past the fixed deadline, inside 1.4 x 8 ms
+    pacer.before_layer(0)
+    assert pacer.stats()["holds"] == 0
+    d.publish_step(t.ns - 12_000_000)          # past 11.2 ms: held
+    t.on_sleep = lambda ft: d.publish_step(ft.ns)
+    pacer.before_layer(1)
+    assert pacer.stats()["holds"] == 1
+    d.publish_fast_step(4_400_000)             # a Llama-3-8B-sized step: the fixed deadline is the one in force
+    d.publish_step(t.ns - 9_000_000)
+    t.on_sleep = lambda ft: d.publish_step(ft.ns)
+    pacer.before_layer(2)
+    assert pacer.stats()["holds"] == 2
+
+
+def test_the_decode_scheduler_publishes_its_fast_step(boards, monkeypatch):
+    """managers/semi_pd_decode_scheduler.py: _publish_step keeps the step stamps and, every 64 steps, the 10th percentile of
+    the step times on the board."""
+    import time as _time
+    from types import SimpleNamespace
+    from semi_pd_amd.managers.semi_pd_decode_scheduler import SemiPDDecodeScheduler
+    d, p = boards
+    now = [5_000_000_000]
+    monkeypatch.setattr(_time, "monotonic_ns", lambda: now[0])
+    sched = SemiPDDecodeScheduler.__new__(SemiPDDecodeScheduler)
+    sched.model_runner = SimpleNamespace(cu_share=SimpleNamespace(board=d))
+    for k in range(65):
+        sched._publish_step(True)
+        now[0] += 4_000_000 if k % 2 else 9_000_000     # half the steps 9 ms, half 4 ms
+    assert p.fast_step_ns() == 4_000_000 and p.step_in_flight()[1] == 65
+    sched._publish_step(False)
+    assert p.step_in_flight()[0] == 0
