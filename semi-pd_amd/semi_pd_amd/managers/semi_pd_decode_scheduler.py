@@ -67,6 +67,7 @@ class SemiPDDecodeScheduler(SchedulerBase):
     def on_retract(self, retracted: List[Req]):
         """semi_pd_decode_scheduler.py:117-139: a retracted request goes back to the front of D's
         queue and is re-sent to P with its generated tokens appended to the prompt."""
+        self.stats["retracted_reqs"] = self.stats.get("retracted_reqs", 0) + len(retracted)
         for req in retracted:
             message = TokenizedGenerateReqInput(
                 rid=req.rid, input_text=None, input_ids=req.origin_input_ids + req.output_ids,

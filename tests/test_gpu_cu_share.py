@@ -121,3 +121,38 @@ def test_semi_pd_with_a_decode_step_deadline_paces_the_prefill_instance_and_matc
     # on a tiny model (steps of ~1 ms), so the plumbing is asserted: hooks counted, no hold ended by the time-out
     assert gate["gates"] >= cfg.num_hidden_layers * stats["PREFILL"]["prefill_batches"] > 0 and gate["timeouts"] == 0
     print("step pacer:", gate)
+
+
+def test_retract_and_re_prefill_under_the_default_policy_keeps_the_tokens(device):
+    """Round-4 verdict item 5: a request the decode instance retracts (SGLANG_TEST_RETRACT, test_retract_decode.py) goes back
+    through the prefill instance -- on its share or on the whole chip, whatever the board says at that moment -- and continues
+    with the tokens the oracle expects: every token the oracle's argmax or within the tie margin, equal on the
+    discriminating steps.  (Bits are not promised across the two instances' kernels; tokens are.)"""
+    import os
+    from semi_pd_amd.entrypoints.engine import Engine
+    from semi_pd_amd.managers.io_struct import SamplingParams
+    cfg = tiny_llama()
+    # short prompts, long answers: the decode batch grows past the 10 requests from which SGLANG_TEST_RETRACT retracts two
+    prompts = make_prompts(cfg.vocab_size, [15, 20, 33, 9, 27, 30, 11, 40, 31, 10, 45, 8, 14, 22, 36, 12, 25, 18], seed=11)
+    uni = Engine(server_args(cfg))
+    try:
+        sd = {k: v.float().cpu() for k, v in uni.model_runner.model.state_dict().items()}
+    finally:
+        uni.shutdown()
+    oracle = OracleLlama(cfg, sd)
+    os.environ["SGLANG_TEST_RETRACT"] = "1"
+    try:
+        # the defaults of ServerArgs: dynamic shares 88 / 100, backlog rule, decode-step deadline
+        eng = Engine(server_args(cfg, enable_semi_pd=True, cu_mask_mode="dynamic", prefill_cu_percent=88, decode_cu_percent=100))
+    finally:
+        os.environ.pop("SGLANG_TEST_RETRACT", None)
+    try:
+        outs = eng.generate(prompts, SamplingParams(max_new_tokens=40, ignore_eos=True), timeout=600)
+        stats = {s["role"]: s for s in eng.get_stats()}
+    finally:
+        eng.shutdown()
+    assert all(len(o) == 40 for o in outs)
+    check_against_oracle(oracle, prompts, outs)
+    assert stats["DECODE"].get("retracted_reqs", 0) >= 1, "SGLANG_TEST_RETRACT retracted nothing"
+    p = stats["PREFILL"]
+    assert p.get("batches_on_full", 0) + p.get("batches_on_share", 0) == p["prefill_batches"] and "step_gate" in p
