@@ -37,7 +37,12 @@ class KernelTiming:
     def begin_step(self) -> bool:
         """Called once per forward; returns True when this step is a sampled (eager, timed) one."""
         self._step += 1
-        self.active = (self._step % self.sample_every == 0) and len(self._pending) < self.max_pending
+        # A function of the step count ALONE.  A sampled step runs eagerly on the raw batch, the others replay a graph
+        # captured for a padded batch size: under tensor parallelism every rank must take the same path for the same step,
+        # or the peer-memory collectives of the two paths (different payloads -> different block counts) wait for each other
+        # for ever.  (Until round 5 a full `_pending` list switched sampling off -- on the ranks that nobody asks for
+        # statistics it fills up, on rank 0 it is drained: after ~8 k steps the ranks disagreed and an N = 2 run hung.)
+        self.active = self._step % self.sample_every == 0
         self.linear_budget = 4 if self.active else 0
         return self.active
 
@@ -84,6 +89,8 @@ class KernelTiming:
         return e
 
     def stop(self, name: str, start: torch.cuda.Event, nbytes: float, flops: float = 0.0, n_kernels: int = 1):
+        if len(self._pending) >= self.max_pending:
+            return                     # nobody has collected for a long time: this sample is dropped (the step stays a sampled one)
         e = torch.cuda.Event(enable_timing=True)
         e.record(torch.cuda.current_stream())
         self._pending.append((name, start, e, float(nbytes), float(flops), int(n_kernels)))

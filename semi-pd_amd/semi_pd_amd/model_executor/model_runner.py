@@ -430,6 +430,8 @@ class ModelRunner:
         two rounds on any partial share.  Returns the tuning table as text."""
         from semi_pd_amd import ops
         from semi_pd_amd.layers.basic import ColumnParallelLinear, RowParallelLinear
+        # (SEMIPD_DG_NUM_FULL_SEARCH: how many row counts get the exhaustive search, ~20 s each per weight shape; tests use 0)
+        num_full_search = int(os.environ.get("SEMIPD_DG_NUM_FULL_SEARCH", num_full_search))
         shapes = []
         for m in self.model.modules():
             if isinstance(m, (ColumnParallelLinear, RowParallelLinear)) and getattr(m, "quant_config", None) is None:

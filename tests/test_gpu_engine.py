@@ -190,7 +190,13 @@ def test_semi_pd_matches_unified(unified_llama):
     from semi_pd_amd.entrypoints.engine import Engine
     from semi_pd_amd.managers.io_struct import SamplingParams
     cfg, sd, prompts, outs, _ = unified_llama
-    eng = Engine(server_args(cfg, enable_semi_pd=True, prefill_cu_percent=50, decode_cu_percent=50, tune_prefill_gemm=None))
+    # (the one engine test that times the library's GEMM solutions on the prefill share at start-up: heuristic candidates only,
+    #  the exhaustive search of two row counts per shape takes minutes)
+    os.environ["SEMIPD_DG_NUM_FULL_SEARCH"] = "0"
+    try:
+        eng = Engine(server_args(cfg, enable_semi_pd=True, prefill_cu_percent=50, decode_cu_percent=50, tune_prefill_gemm=None))
+    finally:
+        os.environ.pop("SEMIPD_DG_NUM_FULL_SEARCH", None)
     try:
         masks = {i["role"]: i["hsa_cu_mask"] for i in eng.ready_infos}
         assert masks["PREFILL"] and masks["DECODE"] and masks["PREFILL"] != masks["DECODE"]

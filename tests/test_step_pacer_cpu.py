@@ -178,3 +178,18 @@ def test_the_decode_scheduler_publishes_its_fast_step(boards, monkeypatch):
     assert p.fast_step_ns() == 4_000_000 and p.step_in_flight()[1] == 65
     sched._publish_step(False)
     assert p.step_in_flight()[0] == 0
+
+
+def test_which_steps_are_sampled_depends_on_the_step_count_alone():
+    """model_executor/kernel_timing.py: a sampled step runs eagerly on the raw batch, the others replay a graph of a padded
+    batch; under tensor parallelism all ranks must agree on which is which (the peer-memory collectives of the two paths have
+    different block counts).  A rank whose samples nobody collects (a full pending list) samples the SAME steps as rank 0 --
+    it only stops recording."""
+    from semi_pd_amd.model_executor.kernel_timing import KernelTiming
+    drained, full = KernelTiming(sample_every=4, max_pending=8), KernelTiming(sample_every=4, max_pending=8)
+    full._pending = [None] * 8
+    seq_a = [drained.begin_step() for _ in range(40)]
+    seq_b = [full.begin_step() for _ in range(40)]
+    assert seq_a == seq_b and sum(seq_a) == 10
+    full.stop("x", None, 1.0)          # dropped: no event is created for it (none could be on this CPU)
+    assert len(full._pending) == 8
