@@ -37,8 +37,10 @@ DEFAULT_BACKLOG_FULL_TOKENS = 8192
 # layer boundary until the step is over.  0 = off
 DEFAULT_DEADLINE_MS = 8.5
 DEFAULT_TBT_SLO_MS = 12.0
-# BASELINE config 2: "Poisson QPS sweep" -- three points in the default line (in = 1024 / out = 256)
-DEFAULT_SWEEP_RATES = "8,16,32"
+# BASELINE config 2: "Poisson QPS sweep" -- two points in the default line (in = 1024 / out = 256); the whole sweep
+# (lambda 2 .. 16, 512 requests per point, both length pairs, default policy and the literal 50 / 50 split) is
+# profiles/r05_qps_sweep_config2.txt -- the 8 req/s point alone cost the driver's run 34 s
+DEFAULT_SWEEP_RATES = "16,32"
 SWEEP_OUTPUT_LEN = 256
 
 HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
