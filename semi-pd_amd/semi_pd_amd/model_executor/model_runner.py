@@ -442,7 +442,7 @@ class ModelRunner:
                         shapes.append(key)
         # start-up cache: the table is a property of (architecture, CUs of the share, library build, shapes, row counts);
         # it is kept under $SEMIPD_CACHE_DIR (default ~/.cache/semipd) and next to the model when there is a model path
-        import hashlib, os
+        import hashlib
         lib_ver = (torch.version.hip or "?", ops.dense_gemm_library_version())   # solution indices are per library build
         arch = torch.cuda.get_device_properties(self.device).gcnArchName.split(":")[0]
         key = hashlib.sha256(repr((arch, self.num_cus, self.num_cus_owned, lib_ver, sorted((n, k, str(dt)) for n, k, dt in shapes),
