@@ -82,6 +82,11 @@ class SemiPDPrefillScheduler(SchedulerBase):
         self._deferred_input: list = []   # messages a wait set aside for the loop top
         if self.late_bind:
             self._install_layer_hooks(model_runner)
+            pacer = getattr(model_runner, "step_pacer", None)
+            if pacer is not None:
+                # the paced forward spends most of its time waiting inside the layer hooks: look for the end of the batch
+                # that ran before it there as well (semi_pd/step_pacer.py)
+                pacer.while_waiting = lambda: self._between_layers(None, None)
         self._share_inflight = 0          # batches launched and not finished (published on the share board)
         # prompt tokens waiting from which a batch takes every CU whatever the decode instance does (0 = never)
         self.backlog_full_tokens = int(getattr(server_args, "prefill_backlog_full_tokens", 0) or 0)

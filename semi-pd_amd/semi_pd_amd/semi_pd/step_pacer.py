@@ -67,6 +67,9 @@ class StepPacer:
         # the scheduler switches holds off for a batch it runs under the backlog rule (an overloaded GPU: throughput first --
         # every step of an overloaded decode instance is overdue, and holding for each of them costs 15 % of the capacity)
         self.hold_enabled = True
+        # called while the hook waits (for the GPU or for an overdue step): the prefill scheduler sends the first tokens of the
+        # batch that ran before this one the moment its event fires, instead of at the next layer boundary (~0.8 ms later)
+        self.while_waiting = None
         self._ring = collections.deque()
         self._free = []
         self._stats = {"gates": 0, "holds": 0, "held_ms": 0.0, "timeouts": 0, "run_ahead_waits_ms": 0.0}
@@ -91,7 +94,12 @@ class StepPacer:
             old = self._ring.popleft()
             if not old.query():
                 t0 = time.perf_counter()
-                old.synchronize()
+                if self.while_waiting is None:
+                    old.synchronize()
+                else:
+                    while not old.query():
+                        self.while_waiting()
+                        time.sleep(20e-6)
                 self._stats["run_ahead_waits_ms"] += (time.perf_counter() - t0) * 1e3
             self._free.append(old)
 
@@ -114,6 +122,8 @@ class StepPacer:
             s2, q2 = self.board.step_in_flight()
             if s2 != start or q2 != seq:
                 break
+            if self.while_waiting is not None:
+                self.while_waiting()
             self._sleep(50e-6)
             now = self._clock()
             if (now - t0) > MAX_WAIT_MS * 1e6:
