@@ -83,7 +83,7 @@ class SemiPDPrefillScheduler(SchedulerBase):
         if self.late_bind:
             self._install_layer_hooks(model_runner)
             pacer = getattr(model_runner, "step_pacer", None)
-            if pacer is not None:
+            if pacer is not None and os.environ.get("SEMIPD_PACER_NO_WAIT_HOOK") != "1":   # (A / B knob)
                 # the paced forward spends most of its time waiting inside the layer hooks: look for the end of the batch
                 # that ran before it there as well (semi_pd/step_pacer.py)
                 pacer.while_waiting = lambda: self._between_layers(None, None)
