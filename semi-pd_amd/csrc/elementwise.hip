@@ -305,30 +305,37 @@ __global__ void rope_vec_kernel(T* __restrict__ q, T* __restrict__ k, const T* _
   T* k_row = k + t * k_stride;
   int64_t dst = 0;
   if (STORE) dst = loc[t];
-  for (int it = threadIdx.x; it < q_items + k_items; it += blockDim.x) {
+  // ONE pass over every kind of work item of the token -- q rotations, k rotations (+ pool), k pass-through (+ pool), v rows
+  // (+ pool) -- with a block as wide as the item count (launch_rope): every lane issues its loads at once and the token
+  // costs one memory latency.  (Until round 5: three loops one after the other on 256 threads, i.e. up to five dependent
+  // load -> store rounds per token; 20 us alone / 34 us next to a decode instance for a 1.3 k-token Llama-3-8B batch.)
+  const int n_rot = q_items + k_items;
+  const int pass_vec = STORE ? (head - rot_dim) / V : 0;
+  const int n_pass = Hk * pass_vec;
+  const int v_vec = STORE ? Hk * vhead / V : 0;
+  const int total = n_rot + n_pass + v_vec;
+  for (int it = threadIdx.x; it < total; it += blockDim.x) {
     if (it < q_items) {
       const int h = it / items_per_head, i = it - h * items_per_head;
       rope_item<T, INTERLEAVE, KV>(q_row + h * head, (KV*)nullptr, cs, rot_dim, i);
-    } else {
+    } else if (it < n_rot) {
       const int kk = it - q_items;
       const int h = kk / items_per_head, i = kk - h * items_per_head;
       KV* mirror = STORE ? k_buf + dst * kbuf_stride + h * head : nullptr;
       rope_item<T, INTERLEAVE, KV>(k_row + h * head, mirror, cs, rot_dim, i);
-    }
-  }
-  if (STORE) {
-    // pass-through part of k (rot_dim < head) and the whole v row
-    const int pass_vec = (head - rot_dim) / V;
-    for (int it = threadIdx.x; it < Hk * pass_vec; it += blockDim.x) {
-      const int h = it / pass_vec, i = it - h * pass_vec;
-      Vec16<T> a = load16(k_row + h * head + rot_dim + i * V);
-      KVTraits<T, KV>::store8(k_buf + dst * kbuf_stride + h * head + rot_dim + i * V, a);
-    }
-    const int v_vec = Hk * vhead / V;
-    const T* v_row = v + t * v_stride;
-    for (int it = threadIdx.x; it < v_vec; it += blockDim.x) {
-      Vec16<T> a = load16(v_row + it * V);
-      KVTraits<T, KV>::store8(v_buf + dst * vbuf_stride + it * V, a);
+    } else if constexpr (STORE) {
+      if (it < n_rot + n_pass) {
+        // pass-through part of k (rot_dim < head)
+        const int pp = it - n_rot;
+        const int h = pp / pass_vec, i = pp - h * pass_vec;
+        Vec16<T> a = load16(k_row + h * head + rot_dim + i * V);
+        KVTraits<T, KV>::store8(k_buf + dst * kbuf_stride + h * head + rot_dim + i * V, a);
+      } else {
+        const int vv = it - n_rot - n_pass;
+        const T* v_row = v + t * v_stride;
+        Vec16<T> a = load16(v_row + vv * V);
+        KVTraits<T, KV>::store8(v_buf + dst * vbuf_stride + vv * V, a);
+      }
     }
   }
 }
@@ -352,39 +359,44 @@ __global__ void rope_planes_kernel(T* __restrict__ q_out, const float* __restric
   const float* row = planes + t * row_elems;
   auto sum8 = [&](int64_t col, float (&f)[8]) { planes_sum8(row + col, n_planes, plane_elems, f); };
   const int qk_items = (Hq + Hk) * items_per_head;
-  for (int it = threadIdx.x; it < qk_items; it += blockDim.x) {
-    const int h = it / items_per_head, i0 = (it - h * items_per_head) * V;
-    float fa[8], fb[8];
-    planes_sum8x2(row + (int64_t)h * head + i0, row + (int64_t)h * head + half + i0, n_planes, plane_elems, fa, fb);
-    Vec16<T> oa, ob;
-#pragma unroll
-    for (int j = 0; j < V; ++j) {
-      const float c = cs[i0 + j], sn = cs[half + i0 + j];
-      const float x1 = Elem<T>::to_f(Elem<T>::from_f(fa[j])), x2 = Elem<T>::to_f(Elem<T>::from_f(fb[j]));
-      float r1, r2;
-      rope_pair(x1, x2, c, sn, r1, r2);
-      oa.e[j] = Elem<T>::from_f(r1);
-      ob.e[j] = Elem<T>::from_f(r2);
-    }
-    if (h < Hq) {
-      T* qh = q_out + t * q_stride + (int64_t)h * head;
-      store16(qh + i0, oa);
-      store16(qh + half + i0, ob);
-    } else {
-      KV* kh = k_buf + dst * kbuf_stride + (int64_t)(h - Hq) * head;
-      KVTraits<T, KV>::store8(kh + i0, oa);
-      KVTraits<T, KV>::store8(kh + half + i0, ob);
-    }
-  }
   const int v_vec = Hk * head / V;
   const int64_t v_col0 = (int64_t)(Hq + Hk) * head;
-  for (int it = threadIdx.x; it < v_vec; it += blockDim.x) {
-    float f[8];
-    sum8(v_col0 + (int64_t)it * V, f);
-    Vec16<T> a;
+  // grid = (tokens, parts): the items of a token -- rotations of q and k, then the v vectors -- are independent, so a
+  // decode batch of 32 tokens spreads over 32 x parts workgroups instead of 32 (a workgroup's plane reads, n_planes x
+  // 24 KB per Llama-3-8B token, were bound by what ONE CU can pull), and a lane has one item: one memory latency.
+  for (int it = blockIdx.y * blockDim.x + threadIdx.x; it < qk_items + v_vec; it += gridDim.y * blockDim.x) {
+    if (it < qk_items) {
+      const int h = it / items_per_head, i0 = (it - h * items_per_head) * V;
+      float fa[8], fb[8];
+      planes_sum8x2(row + (int64_t)h * head + i0, row + (int64_t)h * head + half + i0, n_planes, plane_elems, fa, fb);
+      Vec16<T> oa, ob;
 #pragma unroll
-    for (int j = 0; j < V; ++j) a.e[j] = Elem<T>::from_f(f[j]);
-    KVTraits<T, KV>::store8(v_buf + dst * vbuf_stride + (int64_t)it * V, a);
+      for (int j = 0; j < V; ++j) {
+        const float c = cs[i0 + j], sn = cs[half + i0 + j];
+        const float x1 = Elem<T>::to_f(Elem<T>::from_f(fa[j])), x2 = Elem<T>::to_f(Elem<T>::from_f(fb[j]));
+        float r1, r2;
+        rope_pair(x1, x2, c, sn, r1, r2);
+        oa.e[j] = Elem<T>::from_f(r1);
+        ob.e[j] = Elem<T>::from_f(r2);
+      }
+      if (h < Hq) {
+        T* qh = q_out + t * q_stride + (int64_t)h * head;
+        store16(qh + i0, oa);
+        store16(qh + half + i0, ob);
+      } else {
+        KV* kh = k_buf + dst * kbuf_stride + (int64_t)(h - Hq) * head;
+        KVTraits<T, KV>::store8(kh + i0, oa);
+        KVTraits<T, KV>::store8(kh + half + i0, ob);
+      }
+    } else {
+      const int vv = it - qk_items;
+      float f[8];
+      sum8(v_col0 + (int64_t)vv * V, f);
+      Vec16<T> a;
+#pragma unroll
+      for (int j = 0; j < V; ++j) a.e[j] = Elem<T>::from_f(f[j]);
+      KVTraits<T, KV>::store8(v_buf + dst * vbuf_stride + (int64_t)vv * V, a);
+    }
   }
 }
 
@@ -603,6 +615,10 @@ static int launch_rope(T* q, T* k, const T* v, KV* k_buf, KV* v_buf, const int64
              (vhead % V == 0) && (KVTraits<T, KV>::kF8 ? V == 8 : true);
   dim3 grid((unsigned)num_tokens), block(256);
   if (vec_ok) {
+    // one lane per work item of a token, whole waves, at most 1024 (rope_vec_kernel walks what is left over)
+    const int per_head = interleave ? rot_dim / V : (rot_dim / 2) / V;
+    const int items = (Hq + Hk) * per_head + (STORE ? Hk * ((head - rot_dim) / V) + Hk * vhead / V : 0);
+    block = dim3((unsigned)std::min(1024, std::max(64, (items + 63) / 64 * 64)));
     if (interleave)
       hipLaunchKernelGGL((rope_vec_kernel<T, true, STORE, KV>), grid, block, 0, st, q, k, v, k_buf, v_buf,
                          loc, cache, positions, Hq, Hk, head, vhead, rot_dim, q_stride, k_stride,
@@ -1067,7 +1083,13 @@ int semipd_rope_kv_store_planes(void* q_out, const float* planes, int n_planes, 
                    "rope_kv_store_planes: head_size %% 16, 16-byte aligned rows required");
   SEMIPD_CHECK_ARG(dtype == SEMIPD_BF16 || dtype == SEMIPD_F16, SEMIPD_EDTYPE, "rope_kv_store_planes: bf16 / f16 activations");
   hipStream_t st = as_stream(stream);
-  dim3 grid((unsigned)num_tokens), block(256);
+  // items of one token: (Hq + Hk) * head / 16 rotations + Hk * head / 8 v vectors; workgroups of 64..256 lanes, about 256
+  // of them for a decode-sized batch (rope_planes_kernel)
+  const int items = (num_q_heads + num_k_heads) * (head_size / 16) + num_k_heads * head_size / 8;
+  int parts = (int)std::max<int64_t>(1, std::min<int64_t>((items + 63) / 64, 256 / num_tokens));
+  int per_part = (items + parts - 1) / parts;
+  int threads = std::min(256, (per_part + 63) / 64 * 64);
+  dim3 grid((unsigned)num_tokens, (unsigned)parts), block((unsigned)threads);
 #define RPK(TT, KVT)                                                                                                  \
   hipLaunchKernelGGL((rope_planes_kernel<TT, KVT>), grid, block, 0, st, (TT*)q_out, planes, n_planes, plane_elems,      \
                      row_elems, (KVT*)k_buf, (KVT*)v_buf, loc, cos_sin_cache, positions, num_q_heads, num_k_heads,     \

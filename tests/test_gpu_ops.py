@@ -998,11 +998,13 @@ def test_abort_of_a_failed_stream_capture(device):
 @pytest.mark.parametrize("M", [1, 7, 33, 64])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("kv_dtype", [None, torch.float8_e4m3fn])
-def test_rope_and_store_kv_from_the_qkv_planes(ops, device, M, dtype, kv_dtype):
+@pytest.mark.parametrize("heads", [(32, 8), (8, 1)], ids=["llama3_8b", "llama3_70b_tp8_rank"])
+def test_rope_and_store_kv_from_the_qkv_planes(ops, device, M, dtype, kv_dtype, heads):
     """Decode step: the qkv GEMM stopped before its K-slice reduction + ONE kernel that sums the planes, rotates q / k
-    and stores k / v has the bits of stream_linear followed by rope_and_store_kv (q, and the pool rows)."""
+    and stores k / v has the bits of stream_linear followed by rope_and_store_kv (q, and the pool rows).  (The kernel
+    spreads a token's items over 1 .. 7 workgroups by the batch size: M and the head counts walk through the shapes.)"""
     torch.manual_seed(M)
-    Hq, Hk, D, K = 32, 8, 128, 4096
+    (Hq, Hk), D, K = heads, 128, 4096
     x = torch.randn(M, K, device=device).to(dtype)
     w = (torch.randn((Hq + 2 * Hk) * D, K, device=device) * 0.03).to(dtype)
     pos = torch.randint(0, 4000, (M,), device=device, dtype=torch.int64)
