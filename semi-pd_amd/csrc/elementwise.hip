@@ -26,8 +26,18 @@ void set_error(const char* fmt, ...) {
 // PLANES: the input row is not in `in` but the sum, in slice order, of `n_planes` fp32 planes [rows, hidden]
 // (the K slices of csrc/stream_linear.hip), rounded to T first -- exactly the row the GEMM's own reduction
 // launch would have written, so the fusion changes no bit and saves that launch.
+// Workgroup width of every form of the kernel (the plain, fused-add, plane-summing and quantising launches must agree: the
+// order of the sum of squares, hence the bits, follows from it).  One 16-byte vector per lane up to hidden 8192: a row is
+// one workgroup = one CU, and what bounds a decode-sized call is how many loads that CU has in flight (hidden 8192 with
+// two planes: 6.4 us on 256 lanes x 4 vectors; SEMIPD_RMS_WIDE=0 restores that rule for A/B runs).
+static int rms_threads(int nvec) {
+  static const bool wide = [] { const char* e = getenv("SEMIPD_RMS_WIDE"); return !(e && atoi(e) == 0); }();
+  if (!wide) return nvec <= 64 ? 64 : nvec <= 128 ? 128 : nvec <= 1024 ? 256 : 512;
+  return nvec <= 64 ? 64 : nvec <= 128 ? 128 : nvec <= 256 ? 256 : nvec <= 512 ? 512 : nvec <= 2048 ? 1024 : 512;
+}
+
 template <typename T, int MAXV, bool FUSED, bool QUANT = false, bool PLANES = false>
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(MAXV <= 2 ? 1024 : 512)
 rmsnorm_vec_kernel(T* __restrict__ out, T* __restrict__ in, T* __restrict__ res,
                    const T* __restrict__ w, int64_t in_stride, int64_t out_stride, int nvec,
                    int hidden, float eps, uint8_t* __restrict__ q = nullptr, float* __restrict__ qs = nullptr,
@@ -177,7 +187,7 @@ static int launch_rmsnorm(T* out, T* in, T* res, const T* w, int64_t T_rows, int
                       aligned16(out) && aligned16(in) && aligned16(w) && (!FUSED || aligned16(res));
   const int nvec = (int)(hidden / V);
   if (vec_ok && nvec <= 512 * 16) {
-    int threads = nvec <= 64 ? 64 : nvec <= 128 ? 128 : nvec <= 1024 ? 256 : 512;
+    int threads = rms_threads(nvec);
     // small rows: fewer threads, each with one vector
     int per = (nvec + threads - 1) / threads;
     dim3 grid((unsigned)T_rows), block(threads);
@@ -942,7 +952,7 @@ int semipd_fused_add_rmsnorm_planes(void* out, void* residual, const void* weigh
                    SEMIPD_EALIGN, "fused_add_rmsnorm_planes: hidden %% 8, 16-byte aligned rows required");
   const int nvec = (int)(hidden / 8);
   // the launch shape of launch_rmsnorm: same reduction order, hence the same bits as the unfused pair of launches
-  const int threads = nvec <= 64 ? 64 : nvec <= 128 ? 128 : nvec <= 1024 ? 256 : 512;
+  const int threads = rms_threads(nvec);
   const int per = (nvec + threads - 1) / threads;
   dim3 grid((unsigned)num_tokens), block(threads);
 #define RMSP_LAUNCH(MV)                                                                                              \
@@ -980,7 +990,7 @@ int semipd_fused_add_rmsnorm_quant_fp8(void* inout, void* residual, const void* 
   const int nvec = (int)(hidden / 8), lpg = group_size / 8;
   // the launch shape of launch_rmsnorm, so that the reduction order — hence every output bit — is the same as in
   // the unfused kernel
-  const int threads = nvec <= 64 ? 64 : nvec <= 128 ? 128 : nvec <= 1024 ? 256 : 512;
+  const int threads = rms_threads(nvec);
   const int per = (nvec + threads - 1) / threads;
   dim3 grid((unsigned)num_tokens), block(threads);
   hipStream_t st = as_stream(stream);
@@ -1124,7 +1134,7 @@ int semipd_rmsnorm_quant_fp8(void* out, const void* input, const void* weight, v
                    SEMIPD_EALIGN, "rmsnorm_quant_fp8: unaligned pointer / row stride");
   const int nvec = (int)(hidden / 8), lpg = group_size / 8;
   // the launch shape of launch_rmsnorm: same reduction order, same bits as the unfused kernel
-  const int threads = nvec <= 64 ? 64 : nvec <= 128 ? 128 : nvec <= 1024 ? 256 : 512;
+  const int threads = rms_threads(nvec);
   const int per = (nvec + threads - 1) / threads;
   dim3 grid((unsigned)num_tokens), block(threads);
   hipStream_t st = as_stream(stream);
