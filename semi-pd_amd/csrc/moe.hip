@@ -61,62 +61,108 @@ __device__ inline void wave_argmax(float& v, int& i) {
 }
 
 // mode: 0 = plain softmax top-k (fused_topk); 1 = grouped (grouped_topk / biased_grouped_topk)
+// One wave per token; lane l owns experts l, l + 64, ... (up to kMaxExperts / 64 = 8) and keeps their logits, scores and
+// selection values in REGISTERS: the routing of a decode batch is a chain of dependent steps, and every LDS round trip in
+// it (the first form of this kernel kept everything in LDS: ~60 of them, 16.5 us at 256 experts in 8 groups) costs more
+// than the arithmetic.  LDS is left for the group stage only (a group's experts sit in other lanes).
 template <typename T>
 __global__ void __launch_bounds__(64)
 moe_topk_kernel(const T* __restrict__ gating, const float* __restrict__ bias,
                 float* __restrict__ topk_weights, int32_t* __restrict__ topk_ids, int E, int topk,
                 int num_group, int topk_group, int renormalize, int scoring, int grouped,
                 const float* __restrict__ planes = nullptr, int n_planes = 0, int64_t plane_elems = 0) {
-  __shared__ float score[kMaxExperts];   // unbiased scores (weights come from these)
-  __shared__ float choice[kMaxExperts];  // scores used for selection (biased / masked)
+  constexpr int NE = kMaxExperts / 64;
+  __shared__ float choice[kMaxExperts];  // group stage: the selection values of every expert
   __shared__ float gscore[64];
   __shared__ int gsel[64];
   const int64_t t = blockIdx.x;
   const int lane = threadIdx.x;
+  float logit[NE], score[NE], ch[NE];
+#pragma unroll
+  for (int i = 0; i < NE; ++i) logit[i] = 0.f;
   // the router logits of this token as T values: from the [tokens, E] tensor, or -- planes != nullptr -- from the fp32 K-slice
   // planes [n_planes][tokens][E] of the router GEMM (csrc/stream_linear.hip), summed in slice order and rounded to T: the
-  // bits that GEMM's own reduction would have written.  Staged in `choice` (every lane reads back what it wrote)
+  // bits that GEMM's own reduction would have written
   if (planes) {
-    for (int e = lane; e < E; e += 64) {
-      const float* p = planes + t * E + e;
-      float acc = p[0];
-      for (int z = 1; z < n_planes; ++z) acc += p[(int64_t)z * plane_elems];
-      choice[e] = Elem<T>::to_f(Elem<T>::from_f(acc));
+    // 4 experts x 8 planes of loads in flight per lane, added in slice order.  (A plain loop over the planes waits for every
+    // load before it issues the next: 4 experts x 14 planes of DeepSeek-V3's router were 56 round trips, 21 us.)
+#pragma unroll
+    for (int i0 = 0; i0 < NE; i0 += 4) {
+      if (i0 * 64 >= E) break;
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int z0 = 0; z0 < n_planes; z0 += 8) {
+        float v[4][8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int e = lane + (i0 + i) * 64;
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            v[i][j] = (e < E && z0 + j < n_planes) ? planes[(int64_t)(z0 + j) * plane_elems + t * E + e] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if (z0 + j == 0) acc[i] = v[i][j];            // (the first plane is the start value, as in splitk_planes_reduce)
+            else if (z0 + j < n_planes) acc[i] += v[i][j];
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) logit[i0 + i] = Elem<T>::to_f(Elem<T>::from_f(acc[i]));
     }
   } else {
     const T* g = gating + t * E;
-    for (int e = lane; e < E; e += 64) choice[e] = Elem<T>::to_f(g[e]);
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const int e = lane + i * 64;
+      logit[i] = e < E ? Elem<T>::to_f(g[e]) : 0.f;
+    }
   }
-  // scores
+  // scores (unbiased: the weights come from these)
   if (scoring == 0) {
     float mx = -INFINITY;
-    for (int e = lane; e < E; e += 64) mx = fmaxf(mx, choice[e]);
+#pragma unroll
+    for (int i = 0; i < NE; ++i)
+      if (lane + i * 64 < E) mx = fmaxf(mx, logit[i]);
     mx = wave_max(mx);
     float sum = 0.f;
-    for (int e = lane; e < E; e += 64) {
-      const float x = expf(choice[e] - mx);
-      score[e] = x;
-      sum += x;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      score[i] = 0.f;
+      if (lane + i * 64 < E) {
+        score[i] = expf(logit[i] - mx);
+        sum += score[i];
+      }
     }
     sum = wave_sum(sum);
     const float inv = 1.f / sum;
-    for (int e = lane; e < E; e += 64) score[e] *= inv;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) score[i] *= inv;
   } else {
-    for (int e = lane; e < E; e += 64) score[e] = 1.f / (1.f + expf(-choice[e]));
+#pragma unroll
+    for (int i = 0; i < NE; ++i) score[i] = 1.f / (1.f + expf(-logit[i]));
   }
   // grouped_topk / biased_grouped_topk run softmax / sigmoid in the gating dtype (topk.py:91-94,
   // 132): scores are rounded to T before any comparison so the selection matches bit for bit.
   if (grouped) {
-    __syncthreads();
-    for (int e = lane; e < E; e += 64) score[e] = Elem<T>::to_f(Elem<T>::from_f(score[e]));
+#pragma unroll
+    for (int i = 0; i < NE; ++i) score[i] = Elem<T>::to_f(Elem<T>::from_f(score[i]));
   }
-  __syncthreads();
-  for (int e = lane; e < E; e += 64) choice[e] = score[e] + (bias ? bias[e] : 0.f);
-  __syncthreads();
-  // (one group: it is the group that is selected and nothing is masked -- DeepSeek-V2-Lite; the scan below is a serial
-  //  walk over the group's experts by one lane per group)
+  // selection values (biased / masked)
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    const int e = lane + i * 64;
+    ch[i] = e < E ? score[i] + (bias ? bias[e] : 0.f) : -INFINITY;
+  }
+  // (one group: it is the group that is selected and nothing is masked -- DeepSeek-V2-Lite)
   if (grouped && num_group > 1) {
     const int gs = E / num_group;
+#pragma unroll
+    for (int i = 0; i < NE; ++i)
+      if (lane + i * 64 < E) choice[lane + i * 64] = ch[i];
+    __syncthreads();
+    float mine = -INFINITY;
     if (lane < num_group) {
       float best = -INFINITY, second = -INFINITY;
       for (int j = 0; j < gs; ++j) {   // branch-free top two: the loads pipeline
@@ -124,53 +170,60 @@ moe_topk_kernel(const T* __restrict__ gating, const float* __restrict__ bias,
         second = fmaxf(second, fminf(best, x));
         best = fmaxf(best, x);
       }
-      gscore[lane] = bias ? best + second : best;  // topk.py:140-144 vs :98-100
-      gsel[lane] = 0;
+      mine = bias ? best + second : best;  // topk.py:140-144 vs :98-100
+      gscore[lane] = mine;
     }
     __syncthreads();
-    if (lane == 0) {
-      for (int k = 0; k < topk_group; ++k) {
-        float bv = -INFINITY;
-        int bi = -1;
-        for (int j = 0; j < num_group; ++j)
-          if (!gsel[j] && (bi < 0 || gscore[j] > bv)) {
-            bv = gscore[j];
-            bi = j;
-          }
-        if (bi >= 0) gsel[bi] = 1;
+    // the topk_group best groups, ties to the lower index (torch.topk on the group scores as the serial argmax chain took
+    // them): group g is selected when fewer than topk_group groups come before it in that order -- every lane ranks its own
+    if (lane < num_group) {
+      int before = 0;
+      for (int j = 0; j < num_group; ++j) {
+        const float o = gscore[j];
+        before += (o > mine || (o == mine && j < lane)) ? 1 : 0;
       }
+      gsel[lane] = before < topk_group ? 1 : 0;
     }
     __syncthreads();
     const float fill = bias ? -INFINITY : 0.f;  // masked_fill value (topk.py:151-153 vs :110)
-    for (int e = lane; e < E; e += 64)
-      if (!gsel[e / gs]) choice[e] = fill;
-    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const int e = lane + i * 64;
+      if (e < E && !gsel[e / gs]) ch[i] = fill;
+    }
   }
-  // iterative top-k over `choice`
+  // iterative top-k over the selection values
   float wsum = 0.f;
   float my_w = 0.f;
   int my_id = 0;
   for (int k = 0; k < topk; ++k) {
     float bv = -INFINITY;
     int bi = 0x7fffffff;
-    for (int e = lane; e < E; e += 64) {
-      const float x = choice[e];
-      if (x > bv || (x == bv && e < bi)) {
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const int e = lane + i * 64;
+      const float x = ch[i];
+      if (e < E && (x > bv || (x == bv && e < bi))) {
         bv = x;
         bi = e;
       }
     }
     wave_argmax(bv, bi);
     if (bi == 0x7fffffff) bi = 0;
-    const float w = score[bi];
+    const int owner = bi & 63, slot = bi >> 6;   // (uniform: wave_argmax ends in a readlane)
+    float w = 0.f;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      if (i == slot) {
+        w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(score[i]), owner));
+        if (lane == owner) ch[i] = -INFINITY;
+      }
+    }
     wsum += w;
     if (lane == k) {
       my_w = w;
       my_id = bi;
     }
-    __syncthreads();
-    if (lane == 0) choice[bi] = -INFINITY;
-    __syncthreads();
   }
   if (lane < topk) {
     float wgt = my_w;
