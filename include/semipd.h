@@ -205,8 +205,8 @@ int semipd_decode_attention(void* out, const void* q, const void* k_buf, const v
  * into k_buf/v_buf; qo_indptr int32 [B+1]; causal inside the extend part;
  * out [T,Hq,Dv].  replaces extend_attention_fwd
  *   (layers/attention/triton_ops/extend_attention.py:41-288, 291-410);
- * custom masks are not supported (speculative decoding is off in Semi-PD,
- * managers/scheduler.py:272-275). */
+ * custom_mask == None of that call; semipd_extend_attention_masked below is the
+ * call with a custom mask. */
 int semipd_extend_attention(void* out, const void* q_extend, const void* k_extend,
                             const void* v_extend, const void* k_buf, const void* v_buf,
                             const int32_t* qo_indptr, const int32_t* kv_indptr,
@@ -216,6 +216,30 @@ int semipd_extend_attention(void* out, const void* q_extend, const void* k_exten
                             int64_t kbuf_stride, int64_t vbuf_stride, int max_len_extend,
                             float sm_scale, float logit_cap, int dtype, int kv_dtype,
                             void* stream);
+
+/* extend_attention_fwd with its custom_mask / mask_indptr / skip_prefix_custom_mask
+ * arguments (extend_attention.py:291-307; kernel :91-92, :164-177, :233-252): the
+ * target-verify step of speculative decoding (triton_backend.py:136-149; off in
+ * Semi-PD mode, managers/scheduler.py:272-275, so no caller inside this package).
+ * custom_mask: one byte (torch.bool) per (new token, kv position), sequence b's
+ * [len_extend_b][len_prefix_b + len_extend_b] block starting at mask_indptr[b]
+ * (int64 [B+1]); a zero byte removes the key for that query.  With
+ * skip_prefix_custom_mask != 0 (the reference default) the prefix columns are
+ * not read: every prefix key is visible.  In the extend part the mask is AND-ed
+ * with the causal triangle (the reference walks the keys up to the end of the
+ * query's BLOCK_M tile there, so a bit above the diagonal counts or not with
+ * the tile size of its launch; tree masks are sub-causal and unaffected).
+ * A query whose every key is masked gets NaN, as in the reference. */
+int semipd_extend_attention_masked(void* out, const void* q_extend, const void* k_extend,
+                                   const void* v_extend, const void* k_buf, const void* v_buf,
+                                   const int32_t* qo_indptr, const int32_t* kv_indptr,
+                                   const int32_t* kv_indices, const uint8_t* custom_mask,
+                                   const int64_t* mask_indptr, int skip_prefix_custom_mask,
+                                   int64_t batch, int num_q_heads, int num_kv_heads, int head_dim_k,
+                                   int head_dim_v, int64_t q_stride, int64_t k_stride,
+                                   int64_t v_stride, int64_t o_stride, int64_t kbuf_stride,
+                                   int64_t vbuf_stride, int max_len_extend, float sm_scale,
+                                   float logit_cap, int dtype, int kv_dtype, void* stream);
 
 /* ------------------------------------------------------------------ */
 /* a8/a9  logits post-processing and greedy sampling                   */

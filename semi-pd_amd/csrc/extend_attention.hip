@@ -48,7 +48,18 @@ typedef int ext_i32x4 __attribute__((ext_vector_type(4)));
 // fetched with buffer loads -- descriptor per (sequence, kv head) whose size ends at the last row the tile may
 // see, so rows past the end read as zero in hardware; per-thread offsets are computed once, the tile offset is a
 // scalar -- and the softmax scale is folded into the exponent's fma.
-template <typename T, int DKP, int DVP, bool VEC, bool CAP, typename KV = T, bool FAST = false>
+// custom_mask of extend_attention_fwd (extend_attention.py:291-307): one byte per (new token, kv position) of every
+// sequence, rows of prefix + extend entries starting at mask_indptr[seq] (:91-92, :165-175, :234-245).  The prefix
+// columns are read only when skip_prefix == 0 (SKIP_PREFIX_CUSTOM_MASK, :164); in the triangle the mask is AND-ed with
+// j <= i: the reference visits the keys up to the end of the query's BLOCK_M tile there, so a bit above the diagonal
+// would count or not with the tile size of the launch -- tree masks of speculative verification are sub-causal.
+struct ExtMask {
+  const uint8_t* mask;
+  const int64_t* indptr;
+  int skip_prefix;
+};
+
+template <typename T, int DKP, int DVP, bool VEC, bool CAP, typename KV = T, bool FAST = false, bool MASK = false>
 __global__ void __launch_bounds__(256, (VEC && !CAP && DKP <= 128) ? 2 : 1)
 extend_attn_kernel(T* __restrict__ out, const T* __restrict__ q_ext, const T* __restrict__ k_ext,
                    const T* __restrict__ v_ext, const KV* __restrict__ k_buf,
@@ -56,7 +67,8 @@ extend_attn_kernel(T* __restrict__ out, const T* __restrict__ q_ext, const T* __
                    const int32_t* __restrict__ kv_indptr, const int32_t* __restrict__ kv_indices,
                    int group, int Dk, int Dv, int64_t q_stride, int64_t k_stride, int64_t v_stride,
                    int64_t o_stride, int64_t kbuf_stride, int64_t vbuf_stride, float sm_scale,
-                   float logit_cap) {
+                   float logit_cap, ExtMask mk = ExtMask()) {
+  static_assert(!(MASK && FAST), "the masked form is an instantiation of the general kernel");
   constexpr int BM = 128, BN = 64;
   constexpr int KS = DKP + 8;  // K tile row stride in elements (16 B pad)
   // V tile row stride in elements: row bytes == 64 (mod 128), i.e. 16 or 48 dwords (mod 64), which
@@ -79,6 +91,8 @@ extend_attn_kernel(T* __restrict__ out, const T* __restrict__ q_ext, const T* __
   const int col = lane & 31, hi = lane >> 5;
   const int q_local = q0 + wave * 32 + col;  // this lane's query row inside the extend part
   const bool q_valid = q_local < ext_len;
+  const uint8_t* mk_row = nullptr;  // MASK: this lane's query row of the sequence's mask
+  if constexpr (MASK) mk_row = mk.mask + mk.indptr[seq] + (int64_t)(q_valid ? q_local : 0) * (pre_len + ext_len);
 
   // Q^T fragments (B operand): lane holds Q[q_local][ks*16 + hi*8 .. +8]
   Frag16 qf[KSTEPS];
@@ -301,7 +315,21 @@ extend_attn_kernel(T* __restrict__ out, const T* __restrict__ q_ext, const T* __
 #pragma unroll
         for (int r = 0; r < 16; ++r) s_acc[kt][r] *= qk_scale;
     }  // FAST: raw scores; qk_scale > 0 is applied to the row maximum and inside the exponent's fma below
-    if (need_mask) {
+    if constexpr (MASK) {
+      const bool use_cm = !pre || !mk.skip_prefix;   // wave-uniform
+      if (need_mask || use_cm) {
+        const uint8_t* mrow = mk_row + (pre ? 0 : pre_len);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int n = n0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            bool ok = n < n_end && (pre || n <= q_local);
+            if (use_cm && ok && q_valid) ok = mrow[n] != 0;
+            s_acc[kt][r] = ok ? s_acc[kt][r] : -INFINITY;
+          }
+      }
+    } else if (need_mask) {
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -406,7 +434,7 @@ extend_attn_generic_kernel(T* __restrict__ out, const T* __restrict__ q_ext,
                            const int32_t* __restrict__ kv_indices, int group, int Dk, int Dv,
                            int64_t q_stride, int64_t k_stride, int64_t v_stride, int64_t o_stride,
                            int64_t kbuf_stride, int64_t vbuf_stride, float sm_scale,
-                           float logit_cap) {
+                           float logit_cap, ExtMask mk = ExtMask()) {
   constexpr int MAXR = 9;
   const int seq = blockIdx.z, hq = blockIdx.y, qi = blockIdx.x;
   const int hk = hq / group;
@@ -425,8 +453,10 @@ extend_attn_generic_kernel(T* __restrict__ out, const T* __restrict__ q_ext,
   }
   float m = -INFINITY, l = 0.f;
   const int total = pre_len + qi + 1;
+  const uint8_t* mk_row = mk.mask ? mk.mask + mk.indptr[seq] + (int64_t)qi * (pre_len + ext_len) : nullptr;
   for (int t = 0; t < total; ++t) {
     const bool pooled = t < pre_len;  // prefix rows live in the pool (possibly fp8), the rest in the extend tensors
+    if (mk_row && !(pooled && mk.skip_prefix) && mk_row[t] == 0) continue;   // custom mask: the key does not exist for this row
     const T *kr = nullptr, *vr = nullptr;
     const KV *kp = nullptr, *vp = nullptr;
     if (pooled) {
@@ -465,25 +495,25 @@ extend_attn_generic_kernel(T* __restrict__ out, const T* __restrict__ q_ext,
   }
 }
 
-template <typename T, bool VEC, bool CAP, typename KV = T>
+template <typename T, bool VEC, bool CAP, typename KV = T, bool MASK = false>
 static int launch_extend_variant(void* out, const void* q, const void* k, const void* v, const void* k_buf,
                                  const void* v_buf, const int32_t* qo_indptr, const int32_t* kv_indptr,
                                  const int32_t* kv_indices, int64_t batch, int Hq, int group, int Dk, int Dv,
                                  int64_t q_stride, int64_t k_stride, int64_t v_stride, int64_t o_stride,
                                  int64_t kbuf_stride, int64_t vbuf_stride, int max_len_extend, float sm_scale,
-                                 float logit_cap, hipStream_t st) {
+                                 float logit_cap, hipStream_t st, ExtMask mk = ExtMask()) {
   const int dkp = (Dk + 15) / 16 * 16, dvp = (Dv + 31) / 32 * 32;
   // x = head (fastest), y = query tile: dispatch order is x-major, so every head of the longest
   // (last, causal) query tile starts first and the short tiles fill the tail
   dim3 grid((unsigned)Hq, (unsigned)((max_len_extend + 127) / 128), (unsigned)batch), block(256);
 #define EXT_(DKP, DVP, FASTV)                                                                             \
-  hipLaunchKernelGGL((extend_attn_kernel<T, DKP, DVP, VEC, CAP, KV, FASTV>), grid, block, 0, st, (T*)out, \
+  hipLaunchKernelGGL((extend_attn_kernel<T, DKP, DVP, VEC, CAP, KV, FASTV, MASK>), grid, block, 0, st, (T*)out, \
                      (const T*)q, (const T*)k, (const T*)v, (const KV*)k_buf, (const KV*)v_buf,            \
                      qo_indptr, kv_indptr, kv_indices, group, Dk, Dv, q_stride, k_stride, v_stride,        \
-                     o_stride, kbuf_stride, vbuf_stride, sm_scale, logit_cap)
+                     o_stride, kbuf_stride, vbuf_stride, sm_scale, logit_cap, mk)
 #define EXT(DKP, DVP) EXT_(DKP, DVP, false)
   // FAST: exact head dims, activation-type rows, no cap, extend rows addressable by a 32-bit buffer offset
-  constexpr bool kFastType = VEC && !CAP && !KVTraits<T, KV>::kF8;
+  constexpr bool kFastType = VEC && !CAP && !MASK && !KVTraits<T, KV>::kF8;
   const bool fast = kFastType && (int64_t)max_len_extend * std::max(k_stride, v_stride) * 2 < (1ll << 31);
   if (dkp <= 16 && dvp <= 32) EXT(16, 32);
   else if (dkp <= 64 && dvp <= 64) {
@@ -517,7 +547,7 @@ static int run_extend(void* out, const void* q, const void* k, const void* v, co
                       const int32_t* kv_indices, int64_t batch, int Hq, int Hkv, int Dk, int Dv,
                       int64_t q_stride, int64_t k_stride, int64_t v_stride, int64_t o_stride,
                       int64_t kbuf_stride, int64_t vbuf_stride, int max_len_extend, float sm_scale,
-                      float logit_cap, int dtype, int kv_dtype, hipStream_t st) {
+                      float logit_cap, int dtype, int kv_dtype, hipStream_t st, ExtMask mk = ExtMask()) {
   const int group = Hq / Hkv;
   const bool vec_ok = Dk % 8 == 0 && Dv % 8 == 0 && q_stride % 8 == 0 && k_stride % 8 == 0 &&
                       v_stride % 8 == 0 && o_stride % 4 == 0 && kbuf_stride % 8 == 0 &&
@@ -527,7 +557,7 @@ static int run_extend(void* out, const void* q, const void* k, const void* v, co
     // fp8 prefix rows (mem_cache/memory_pool.py:205-209): vectorised, cap-free instantiations only
     SEMIPD_CHECK_ARG(kv_dtype == SEMIPD_F8E5M2 || kv_dtype == SEMIPD_F8E4M3, SEMIPD_EDTYPE,
                      "extend_attention: unsupported kv_dtype %d", kv_dtype);
-    if (!(vec_ok && !(logit_cap > 0.f) && Dk <= 128 && Dv <= 128)) {
+    if (mk.mask || !(vec_ok && !(logit_cap > 0.f) && Dk <= 128 && Dv <= 128)) {
       // everything else (MLA's 576 / 512 latent rows behind a chunked prefill, logit caps, ragged heads): the
       // one-wave-per-(token, head) kernel reads pool rows element by element in either storage type
       dim3 g2((unsigned)max_len_extend, (unsigned)Hq, (unsigned)batch);
@@ -535,12 +565,12 @@ static int run_extend(void* out, const void* q, const void* k, const void* v, co
         hipLaunchKernelGGL((extend_attn_generic_kernel<T, f8e5m2_t>), g2, dim3(64), 0, st, (T*)out, (const T*)q,
                            (const T*)k, (const T*)v, (const f8e5m2_t*)k_buf, (const f8e5m2_t*)v_buf, qo_indptr, kv_indptr,
                            kv_indices, group, Dk, Dv, q_stride, k_stride, v_stride, o_stride, kbuf_stride, vbuf_stride,
-                           sm_scale, logit_cap);
+                           sm_scale, logit_cap, mk);
       else
         hipLaunchKernelGGL((extend_attn_generic_kernel<T, f8e4m3_t>), g2, dim3(64), 0, st, (T*)out, (const T*)q,
                            (const T*)k, (const T*)v, (const f8e4m3_t*)k_buf, (const f8e4m3_t*)v_buf, qo_indptr, kv_indptr,
                            kv_indices, group, Dk, Dv, q_stride, k_stride, v_stride, o_stride, kbuf_stride, vbuf_stride,
-                           sm_scale, logit_cap);
+                           sm_scale, logit_cap, mk);
       return launch_status("extend_attention(generic, fp8 pool)");
     }
     int miss8;
@@ -560,7 +590,7 @@ static int run_extend(void* out, const void* q, const void* k, const void* v, co
   // Llama-shaped heads (128 / 128, rows in the activation type, no cap): the shared-KV kernel
   // (extend_attention_shared_kv.hip); SEMIPD_EXTEND_SHARED_KV=0 keeps the one-head-per-workgroup kernel
   static const bool shared_kv_on = [] { const char* e = getenv("SEMIPD_EXTEND_SHARED_KV"); return !(e && e[0] == '0'); }();
-  if (shared_kv_on && vec_ok && !(logit_cap > 0.f) && Dk == 128 && Dv == 128 &&
+  if (shared_kv_on && !mk.mask && vec_ok && !(logit_cap > 0.f) && Dk == 128 && Dv == 128 &&
       (int64_t)max_len_extend * std::max(k_stride, v_stride) * 2 < (1ll << 31)) {
     if (launch_extend_shared_kv<T>(out, q, k, v, k_buf, v_buf, qo_indptr, kv_indptr, kv_indices, batch, Hq, Hkv, q_stride,
                                    k_stride, v_stride, o_stride, kbuf_stride, vbuf_stride, max_len_extend, sm_scale, st) == 0)
@@ -571,7 +601,15 @@ static int run_extend(void* out, const void* q, const void* k, const void* v, co
   launch_extend_variant<T, V, C>(out, q, k, v, k_buf, v_buf, qo_indptr, kv_indptr, kv_indices, batch, Hq, \
                                  group, Dk, Dv, q_stride, k_stride, v_stride, o_stride, kbuf_stride,      \
                                  vbuf_stride, max_len_extend, sm_scale, logit_cap, st)
-  if (vec_ok && !(logit_cap > 0.f)) miss = VARIANT(true, false);
+  // a custom mask: the general tile kernel's masked instantiation (vectorised rows; with or without a cap), else the
+  // one-wave-per-(token, head) kernel, which reads the mask byte of every key it visits
+  if (mk.mask)
+    miss = vec_ok ? launch_extend_variant<T, true, true, T, true>(out, q, k, v, k_buf, v_buf, qo_indptr, kv_indptr, kv_indices,
+                                                                  batch, Hq, group, Dk, Dv, q_stride, k_stride, v_stride,
+                                                                  o_stride, kbuf_stride, vbuf_stride, max_len_extend,
+                                                                  sm_scale, logit_cap, st, mk)
+                  : 1;
+  else if (vec_ok && !(logit_cap > 0.f)) miss = VARIANT(true, false);
   else if (vec_ok) miss = VARIANT(true, true);
   else miss = VARIANT(false, true);
 #undef VARIANT
@@ -580,7 +618,7 @@ static int run_extend(void* out, const void* q, const void* k, const void* v, co
     hipLaunchKernelGGL((extend_attn_generic_kernel<T>), g2, dim3(64), 0, st, (T*)out, (const T*)q,
                        (const T*)k, (const T*)v, (const T*)k_buf, (const T*)v_buf, qo_indptr,
                        kv_indptr, kv_indices, group, Dk, Dv, q_stride, k_stride, v_stride, o_stride,
-                       kbuf_stride, vbuf_stride, sm_scale, logit_cap);
+                       kbuf_stride, vbuf_stride, sm_scale, logit_cap, mk);
   }
   return launch_status("extend_attention");
 }
@@ -611,5 +649,38 @@ extern "C" int semipd_extend_attention(void* out, const void* q_extend, const vo
   SEMIPD_CHECK_ARG(out && q_extend && k_extend && v_extend && qo_indptr && kv_indptr, SEMIPD_EINVAL,
                    "extend_attention: null pointer");
   SEMIPD_DISPATCH_HALF(dtype, T, return run_extend<T>(out, q_extend, k_extend, v_extend, k_buf, v_buf, qo_indptr, kv_indptr, kv_indices, batch, num_q_heads, num_kv_heads, head_dim_k, head_dim_v, q_stride, k_stride, v_stride, o_stride, kbuf_stride, vbuf_stride, max_len_extend, sm_scale, logit_cap, dtype, kv_dtype, as_stream(stream)));
+  return 0;
+}
+
+/* The same launch under extend_attention_fwd's custom_mask / mask_indptr / skip_prefix_custom_mask arguments
+ * (extend_attention.py:291-307; the target-verify step of speculative decoding, triton_backend.py:136-149). */
+extern "C" int semipd_extend_attention_masked(void* out, const void* q_extend, const void* k_extend,
+                                              const void* v_extend, const void* k_buf, const void* v_buf,
+                                              const int32_t* qo_indptr, const int32_t* kv_indptr,
+                                              const int32_t* kv_indices, const uint8_t* custom_mask,
+                                              const int64_t* mask_indptr, int skip_prefix_custom_mask, int64_t batch,
+                                              int num_q_heads, int num_kv_heads, int head_dim_k, int head_dim_v,
+                                              int64_t q_stride, int64_t k_stride, int64_t v_stride, int64_t o_stride,
+                                              int64_t kbuf_stride, int64_t vbuf_stride, int max_len_extend,
+                                              float sm_scale, float logit_cap, int dtype, int kv_dtype, void* stream) {
+  SEMIPD_CHECK_ARG(batch >= 0 && num_q_heads > 0 && num_kv_heads > 0 && head_dim_k > 0 && head_dim_v > 0 &&
+                       max_len_extend >= 0,
+                   SEMIPD_EINVAL, "extend_attention_masked: bad sizes");
+  SEMIPD_CHECK_ARG(num_q_heads % num_kv_heads == 0, SEMIPD_ESHAPE,
+                   "extend_attention_masked: Hq %d not a multiple of Hkv %d", num_q_heads, num_kv_heads);
+  SEMIPD_CHECK_ARG(head_dim_k <= 576 && head_dim_v <= 576, SEMIPD_ESHAPE,
+                   "extend_attention_masked: head dims up to 576 supported");
+  SEMIPD_CHECK_ARG(batch <= 65535 && num_q_heads <= 65535, SEMIPD_EINVAL, "extend_attention_masked: grid too large");
+  if (batch == 0 || max_len_extend == 0) return 0;
+  SEMIPD_CHECK_ARG(out && q_extend && k_extend && v_extend && qo_indptr && kv_indptr, SEMIPD_EINVAL,
+                   "extend_attention_masked: null pointer");
+  SEMIPD_CHECK_ARG(custom_mask && mask_indptr, SEMIPD_EINVAL,
+                   "extend_attention_masked: custom_mask and mask_indptr are both required (semipd_extend_attention "
+                   "is the unmasked launch)");
+  ExtMask mk;
+  mk.mask = custom_mask;
+  mk.indptr = mask_indptr;
+  mk.skip_prefix = skip_prefix_custom_mask ? 1 : 0;
+  SEMIPD_DISPATCH_HALF(dtype, T, return run_extend<T>(out, q_extend, k_extend, v_extend, k_buf, v_buf, qo_indptr, kv_indptr, kv_indices, batch, num_q_heads, num_kv_heads, head_dim_k, head_dim_v, q_stride, k_stride, v_stride, o_stride, kbuf_stride, vbuf_stride, max_len_extend, sm_scale, logit_cap, dtype, kv_dtype, as_stream(stream), mk));
   return 0;
 }

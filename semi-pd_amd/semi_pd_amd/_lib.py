@@ -50,6 +50,8 @@ _SIGNATURES = {
                                 _i64, _i64, _i64, _i32, _f32, _f32, _i32, _i32, _vp],
     "semipd_extend_attention": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32,
                                 _i64, _i64, _i64, _i64, _i64, _i64, _i32, _f32, _f32, _i32, _i32, _vp],
+    "semipd_extend_attention_masked": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32,
+                                       _i32, _i32, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _f32, _f32, _i32, _i32, _vp],
     "semipd_gather_rows": [_vp, _vp, _vp, _i64, _i64, _i64, _vp],
     "semipd_argmax": [_vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp],
     "semipd_lm_head_argmax": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp],

@@ -261,10 +261,9 @@ def extend_attention_fwd(q_extend: torch.Tensor, k_extend: torch.Tensor, v_exten
                          custom_mask: Optional[torch.Tensor], mask_indptr: Optional[torch.Tensor],
                          max_len_extend: int, sm_scale: Optional[float] = None, logit_cap: float = 0.0,
                          skip_prefix_custom_mask: bool = True) -> None:
-    """q_extend [T,Hq,Dk], k_extend [T,Hkv,Dk], v_extend [T,Hkv,Dv], o_extend [T,Hq,Dv]."""
-    if custom_mask is not None:
-        raise RuntimeError("extend_attention_fwd: custom_mask is not supported (speculative "
-                           "decoding is disabled in Semi-PD mode, managers/scheduler.py:272-275)")
+    """q_extend [T,Hq,Dk], k_extend [T,Hkv,Dk], v_extend [T,Hkv,Dv], o_extend [T,Hq,Dv].
+    custom_mask (bool / uint8, flat) + mask_indptr (int64 [B+1]) + skip_prefix_custom_mask: the arguments of the
+    reference call (triton_ops/extend_attention.py:291-307), see include/semipd.h: semipd_extend_attention_masked."""
     T, Hq, Dk = q_extend.shape
     Hkv, Dv = v_extend.shape[1], v_extend.shape[2]
     sm_scale = sm_scale or 1.0 / (Dk ** 0.5)
@@ -276,14 +275,29 @@ def extend_attention_fwd(q_extend: torch.Tensor, k_extend: torch.Tensor, v_exten
     vb_stride = v_buffer.stride(0) if v_buffer is not None else 0
     B = qo_indptr.shape[0] - 1
     lib = _lib.load()
+    tail = (B, Hq, Hkv, Dk, Dv, q_extend.stride(0), k_extend.stride(0), v_extend.stride(0), o_extend.stride(0),
+            kb_stride, vb_stride, int(max_len_extend), sm_scale, logit_cap, dtype_code(q_extend.dtype),
+            _lib.kv_dtype_code(k_buffer.dtype if k_buffer is not None else q_extend.dtype),
+            current_stream(q_extend.device))
+    if custom_mask is not None:
+        if mask_indptr is None:
+            raise RuntimeError("extend_attention_fwd: custom_mask needs mask_indptr")
+        if custom_mask.dtype not in (torch.bool, torch.uint8) or custom_mask.dim() != 1 or not custom_mask.is_contiguous():
+            raise RuntimeError("extend_attention_fwd: custom_mask must be a flat, contiguous bool / uint8 tensor")
+        if mask_indptr.dtype != torch.int64 or mask_indptr.dim() != 1 or mask_indptr.shape[0] < B + 1 \
+                or not mask_indptr.is_contiguous():
+            raise RuntimeError("extend_attention_fwd: mask_indptr must be a contiguous int64 tensor of batch + 1 entries")
+        if custom_mask.device != q_extend.device or mask_indptr.device != q_extend.device:
+            raise RuntimeError("extend_attention_fwd: custom_mask / mask_indptr on another device")
+        check(lib.semipd_extend_attention_masked(ptr(o_extend), ptr(q_extend), ptr(k_extend), ptr(v_extend),
+                                                 ptr(k_buffer), ptr(v_buffer), ptr(qo_indptr), ptr(kv_indptr),
+                                                 ptr(kv_indices), ptr(custom_mask), ptr(mask_indptr),
+                                                 1 if skip_prefix_custom_mask else 0, *tail),
+              "extend_attention_masked")
+        return
     check(lib.semipd_extend_attention(ptr(o_extend), ptr(q_extend), ptr(k_extend), ptr(v_extend),
                                       ptr(k_buffer), ptr(v_buffer), ptr(qo_indptr), ptr(kv_indptr),
-                                      ptr(kv_indices), B, Hq, Hkv, Dk, Dv, q_extend.stride(0),
-                                      k_extend.stride(0), v_extend.stride(0), o_extend.stride(0),
-                                      kb_stride, vb_stride, int(max_len_extend), sm_scale, logit_cap,
-                                      dtype_code(q_extend.dtype),
-                                      _lib.kv_dtype_code(k_buffer.dtype if k_buffer is not None else q_extend.dtype),
-                                      current_stream(q_extend.device)),
+                                      ptr(kv_indices), *tail),
           "extend_attention")
 
 

@@ -692,9 +692,73 @@ def gen_penalties():
     save("penalties", **arrs)
 
 
+# ---------------------------------------------------------------- extend attention under a custom mask
+def tree_mask(g, pre, ext, prefix_bits):
+    """[ext][pre + ext] bool: a sub-causal triangle with the diagonal kept (every token sees itself: the shape of a
+    speculative tree mask, triton_backend.py:136-149), prefix columns all ones or random (first column kept)."""
+    tri = torch.tril(torch.rand(ext, ext, generator=g) < 0.55)
+    tri |= torch.eye(ext, dtype=torch.bool)
+    if prefix_bits:
+        pm = torch.rand(ext, pre, generator=g) < 0.6
+        if pre:
+            pm[:, 0] = True
+    else:
+        pm = torch.ones(ext, pre, dtype=torch.bool)
+    return torch.cat([pm, tri], 1)
+
+
+def gen_extend_mask():
+    """extend_attention_fwd with custom_mask / mask_indptr / skip_prefix_custom_mask (extend_attention.py:291-307,
+    :164-177, :233-252; the reference's own test builds the mask the same way, test_triton_attention_kernels.py:121-139)."""
+    g = torch.Generator().manual_seed(11)
+    arrs = {}
+    cases = [
+        # name, prefix lens, extend lens, Hq, Hkv, Dk, Dv, logit_cap, skip_prefix_custom_mask
+        ("tree_gqa_d64_skip", [0, 13, 40], [20, 7, 70], 4, 2, 64, 64, 0.0, True),
+        ("tree_gqa_d64_prefix_bits", [5, 13, 40], [20, 7, 70], 4, 2, 64, 64, 0.0, False),
+        ("tree_d128_skip", [9, 0], [33, 140], 4, 1, 128, 128, 0.0, True),
+        ("tree_d128_cap_prefix_bits", [70], [66], 2, 1, 128, 128, 25.0, False),
+        ("tree_dk96_dv64", [6, 0], [10, 3], 2, 1, 96, 64, 0.0, False),
+        ("causal_as_mask_mha_d32", [3, 0], [5, 130], 2, 2, 32, 32, 0.0, True),
+    ]
+    for name, pre, ext, Hq, Hkv, Dk, Dv, cap, skip in cases:
+        dt = torch.float32
+        B = len(pre)
+        k_buf, v_buf, kv_indptr, kv_indices = make_paged(g, B, pre, Hkv, Dk, Dv, dt)
+        T = sum(ext)
+        qo_indptr = torch.zeros(B + 1, dtype=torch.int32)
+        qo_indptr[1:] = torch.cumsum(torch.tensor(ext), 0)
+        q = torch.randn(T, Hq, Dk, generator=g).to(dt)
+        k = torch.randn(T, Hkv, Dk, generator=g).to(dt)
+        v = torch.randn(T, Hkv, Dv, generator=g).to(dt)
+        o = torch.zeros(T, Hq, Dv, dtype=dt)
+        sm_scale = 1.0 / (Dk ** 0.5)
+        blocks = []
+        for b in range(B):
+            if name.startswith("causal_as_mask"):
+                blocks.append(torch.cat([torch.ones(ext[b], pre[b], dtype=torch.bool),
+                                         torch.tril(torch.ones(ext[b], ext[b], dtype=torch.bool))], 1).flatten())
+            else:
+                blocks.append(tree_mask(g, pre[b], ext[b], not skip).flatten())
+        custom_mask = torch.cat(blocks)
+        mask_indptr = torch.zeros(B + 1, dtype=torch.int64)
+        mask_indptr[1:] = torch.cumsum(torch.tensor([m.numel() for m in blocks]), 0)
+        extend_attention_fwd(q, k, v, o, k_buf, v_buf, qo_indptr, kv_indptr, kv_indices, custom_mask, mask_indptr,
+                             max(ext), sm_scale, cap, skip)
+        assert torch.isfinite(o).all(), name
+        arrs.update({f"{name}_q": q.numpy(), f"{name}_k": k.numpy(), f"{name}_v": v.numpy(),
+                     f"{name}_kbuf": k_buf.numpy(), f"{name}_vbuf": v_buf.numpy(),
+                     f"{name}_qo_indptr": qo_indptr.numpy(), f"{name}_kv_indptr": kv_indptr.numpy(),
+                     f"{name}_kv_indices": kv_indices.numpy(), f"{name}_o": o.numpy(),
+                     f"{name}_mask": custom_mask.numpy().astype(np.uint8), f"{name}_mask_indptr": mask_indptr.numpy(),
+                     f"{name}_meta": np.array([sm_scale, cap, 1.0 if skip else 0.0], dtype=np.float64)})
+    arrs["names"] = np.array([c[0] for c in cases])
+    save("extend_attention_mask", **arrs)
+
+
 GENERATORS = {"rmsnorm": gen_rmsnorm, "rope": gen_rope, "kv_indices": gen_kv_indices, "topk": gen_topk,
               "decode": gen_decode, "extend": gen_extend, "sampling": gen_sampling, "fp8": gen_fp8,
-              "penalties": gen_penalties, "decode_8c": gen_decode_8c, "extend_8c": gen_extend_8c, "silu": gen_silu,
+              "penalties": gen_penalties, "decode_8c": gen_decode_8c, "extend_8c": gen_extend_8c, "extend_mask": gen_extend_mask, "silu": gen_silu,
               "moe_align": gen_moe_align, "fused_moe": gen_fused_moe, "bmm_fp8": gen_bmm_fp8}
 
 

@@ -508,6 +508,112 @@ def test_extend_attention_golden(ops, device, fixture):
         _close(o, torch.from_numpy(g[name + "_o"]), torch.bfloat16, rtol=3e-2, atol=3e-2)
 
 
+def _tree_masks(g, pre, ext, prefix_bits):
+    """Flat custom_mask + mask_indptr of a batch: sub-causal triangles with the diagonal kept, prefix columns all
+    ones or random with the first column kept (the layout of test_triton_attention_kernels.py:121-139)."""
+    blocks = []
+    for p, e in zip(pre, ext):
+        tri = torch.tril(torch.rand(e, e, generator=g) < 0.5) | torch.eye(e, dtype=torch.bool)
+        pm = torch.rand(e, p, generator=g) < 0.6 if prefix_bits else torch.ones(e, p, dtype=torch.bool)
+        if p:
+            pm[:, 0] = True
+        blocks.append(torch.cat([pm, tri], 1).flatten())
+    indptr = torch.zeros(len(pre) + 1, dtype=torch.int64)
+    indptr[1:] = torch.cumsum(torch.tensor([b.numel() for b in blocks]), 0)
+    return torch.cat(blocks), indptr
+
+
+def test_extend_attention_custom_mask_golden(ops, device):
+    """HIP under a custom mask vs what the reference's Triton kernel wrote for the same inputs."""
+    g = load_golden("extend_attention_mask")
+    for name in g["names"]:
+        name = str(name)
+        q, k, v = (torch.from_numpy(g[f"{name}_{x}"]).to(torch.bfloat16) for x in ("q", "k", "v"))
+        kb, vb = (torch.from_numpy(g[f"{name}_{x}"]).to(torch.bfloat16) for x in ("kbuf", "vbuf"))
+        sm_scale, cap, skip = g[name + "_meta"]
+        qo = torch.from_numpy(g[name + "_qo_indptr"])
+        o = torch.empty(q.shape[0], q.shape[1], v.shape[2], dtype=torch.bfloat16, device=device)
+        ext = (qo[1:] - qo[:-1]).max().item()
+        ops.extend_attention_fwd(q.to(device), k.to(device), v.to(device), o, kb.to(device), vb.to(device),
+                                 qo.to(device), torch.from_numpy(g[name + "_kv_indptr"]).to(device),
+                                 torch.from_numpy(g[name + "_kv_indices"]).to(device),
+                                 torch.from_numpy(g[name + "_mask"]).to(device).to(torch.bool),
+                                 torch.from_numpy(g[name + "_mask_indptr"]).to(device), ext,
+                                 float(sm_scale), float(cap), bool(skip))
+        _close(o, torch.from_numpy(g[name + "_o"]), torch.bfloat16, rtol=3e-2, atol=3e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("skip_prefix", [True, False])
+@pytest.mark.parametrize("pre,ext,Hq,Hkv,Dk,Dv,cap", [
+    ([0, 13, 40], [20, 7, 70], 4, 2, 64, 64, 0.0),        # tile kernel, masked instantiation
+    ([130, 0, 65], [64, 129, 300], 8, 2, 128, 128, 0.0),  # Llama heads: the masked form, not the shared-KV kernel
+    ([9], [33], 4, 1, 128, 128, 25.0),                    # with a logit cap
+    ([6, 0], [10, 3], 2, 1, 96, 64, 0.0),                 # 96 / 64
+    ([40, 3], [17, 200], 2, 1, 192, 128, 0.0),            # MLA prefill shape
+    ([5, 2], [9, 4], 2, 1, 80, 13, 0.0),                  # ragged head sizes: the one-wave kernel reads the mask
+    ([7], [12], 2, 2, 256, 256, 0.0),                     # no MFMA instantiation: one-wave kernel
+])
+def test_extend_attention_custom_mask(ops, device, pre, ext, Hq, Hkv, Dk, Dv, cap, skip_prefix, dtype):
+    g = torch.Generator().manual_seed(17)
+    B, T = len(pre), sum(ext)
+    k_buf, v_buf, kv_indptr, kv_indices = _paged(B, pre, Hkv, Dk, Dv, dtype, seed=Hq + Dk)
+    q = (torch.randn(T, Hq, Dk, generator=g)).to(dtype)
+    k = (torch.randn(T, Hkv, Dk, generator=g)).to(dtype)
+    v = (torch.randn(T, Hkv, Dv, generator=g)).to(dtype)
+    qo_indptr = torch.zeros(B + 1, dtype=torch.int32)
+    qo_indptr[1:] = torch.cumsum(torch.tensor(ext), 0)
+    mask, mask_indptr = _tree_masks(g, pre, ext, not skip_prefix)
+    sm_scale = Dk ** -0.5
+    o = torch.full((T, Hq, Dv), float("nan"), dtype=dtype, device=device)
+    ops.extend_attention_fwd(q.to(device), k.to(device), v.to(device), o, k_buf.to(device), v_buf.to(device),
+                             qo_indptr.to(device), kv_indptr.to(device), kv_indices.to(device), mask.to(device),
+                             mask_indptr.to(device), max(ext), sm_scale, cap, skip_prefix)
+    want = O.extend_attention(q, k, v, k_buf, v_buf, qo_indptr, kv_indptr, kv_indices, sm_scale, cap, mask, mask_indptr,
+                              skip_prefix)
+    _close(o, want, dtype, rtol=2e-2, atol=4e-3 if dtype == torch.float16 else 1.5e-2)
+
+
+def test_extend_attention_custom_mask_properties(ops, device):
+    """Size-independent properties at Llama-3-8B heads: (1) the mask that spells the default out (prefix ones + the
+    causal triangle) gives what the unmasked launch gives; (2) with skip_prefix_custom_mask the prefix bits are not read
+    (zeros there change nothing); (3) uint8 and bool masks are the same bytes; (4) a mask without mask_indptr is refused."""
+    dtype = torch.bfloat16
+    Hq, Hkv, D = 32, 8, 128
+    pre, ext = [700, 0, 129], [64, 300, 5]
+    g = torch.Generator().manual_seed(5)
+    B, T = len(pre), sum(ext)
+    k_buf, v_buf, kv_indptr, kv_indices = _paged(B, pre, Hkv, D, D, dtype, seed=3)
+    q, k, v = (torch.randn(T, h, D, generator=g).to(dtype).to(device) for h in (Hq, Hkv, Hkv))
+    qo = torch.zeros(B + 1, dtype=torch.int32)
+    qo[1:] = torch.cumsum(torch.tensor(ext), 0)
+    blocks = [torch.cat([torch.ones(e, p, dtype=torch.bool), torch.tril(torch.ones(e, e, dtype=torch.bool))], 1).flatten()
+              for p, e in zip(pre, ext)]
+    indptr = torch.zeros(B + 1, dtype=torch.int64)
+    indptr[1:] = torch.cumsum(torch.tensor([b.numel() for b in blocks]), 0)
+    causal = torch.cat(blocks)
+    common = (k_buf.to(device), v_buf.to(device), qo.to(device), kv_indptr.to(device), kv_indices.to(device))
+
+    def run(mask, mp, skip=True):
+        o = torch.empty(T, Hq, D, dtype=dtype, device=device)
+        ops.extend_attention_fwd(q, k, v, o, *common, None if mask is None else mask.to(device),
+                                 None if mp is None else mp.to(device), max(ext), D ** -0.5, 0.0, skip)
+        return o.float().cpu()
+
+    plain = run(None, None)
+    for skip in (True, False):
+        torch.testing.assert_close(run(causal, indptr, skip), plain, rtol=2e-2, atol=1e-2)   # two kernels, one answer
+    holes = causal.clone()
+    off = 0
+    for p, e in zip(pre, ext):      # zero every prefix bit
+        holes[off:off + e * (p + e)].view(e, p + e)[:, :p] = False
+        off += e * (p + e)
+    assert torch.equal(run(holes, indptr, True), run(causal, indptr, True))
+    assert torch.equal(run(causal.to(torch.uint8), indptr, False), run(causal, indptr, False))
+    with pytest.raises(RuntimeError, match="mask_indptr"):
+        run(causal, None)
+
+
 def test_extend_equals_decode_on_last_token(ops, device):
     """Size-independent property at a BASELINE-sized shape (Llama-3-8B heads, ctx 4k): the last query
     row of an extend over [prefix | new tokens] equals decode attention over the same KV rows."""

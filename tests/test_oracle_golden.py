@@ -87,6 +87,26 @@ def test_extend_attention_matches_reference_triton_kernel():
         torch.testing.assert_close(o, torch.from_numpy(g[name + "_o"]), rtol=2e-5, atol=2e-5)
 
 
+def test_extend_attention_custom_mask_matches_reference_triton_kernel():
+    """custom_mask / mask_indptr / skip_prefix_custom_mask (extend_attention.py:291-307): tree masks with and
+    without prefix bits, a logit cap, ragged head sizes, extends that cross the reference's BLOCK_M."""
+    g = load_golden("extend_attention_mask")
+    for name in g["names"]:
+        name = str(name)
+        q, k, v = (torch.from_numpy(g[f"{name}_{x}"]) for x in ("q", "k", "v"))
+        kb, vb = torch.from_numpy(g[name + "_kbuf"]), torch.from_numpy(g[name + "_vbuf"])
+        sm_scale, cap, skip = g[name + "_meta"]
+        args = (q, k, v, kb, vb, torch.from_numpy(g[name + "_qo_indptr"]), torch.from_numpy(g[name + "_kv_indptr"]),
+                torch.from_numpy(g[name + "_kv_indices"]), float(sm_scale), float(cap))
+        o = O.extend_attention(*args, torch.from_numpy(g[name + "_mask"]), torch.from_numpy(g[name + "_mask_indptr"]),
+                               bool(skip))
+        torch.testing.assert_close(o, torch.from_numpy(g[name + "_o"]), rtol=2e-5, atol=2e-5)
+        if name.startswith("causal_as_mask"):   # the mask that spells the default out changes nothing
+            torch.testing.assert_close(o, O.extend_attention(*args), rtol=0, atol=0)
+        else:                                   # and a tree mask does change the answer
+            assert (o - O.extend_attention(*args)).abs().max() > 1e-3
+
+
 def _same_topk(w, ids, rw, rids, rtol=1e-6, atol=1e-6):
     """Order inside the top-k is unspecified (sorted=False in the reference): compare as sets."""
     for t in range(ids.shape[0]):
