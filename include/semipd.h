@@ -288,6 +288,14 @@ int semipd_linear(void* out, const void* x, const void* weight, void* workspace,
 int semipd_gemm_tall_set_cus(int cus);
 int semipd_gemm_tall(void* out, const void* x, const void* weight, void* workspace, size_t workspace_bytes, int64_t rows,
                      int64_t n, int64_t k, int64_t ldx, int64_t ldo, int fuse_silu_mul, int dtype, void* stream);
+/* The same GEMM (plain epilogue) stopped before the reduction over its K slices, for a row-parallel layer whose result
+ * goes straight into RMSNorm(x, residual) (o_proj / down_proj of a prefill batch: python/sglang/srt/models/llama.py:279-302,
+ * layers/linear.py:1258-1268 with tp_size == 1).  The split is the one semipd_gemm_tall would pick.  *ksplit > 1: fp32
+ * planes [*ksplit][rows][n] in `planes`, `out` untouched; the consumer (semipd_fused_add_rmsnorm_planes) sums them in
+ * slice order and rounds to dtype: the bits of semipd_gemm_tall + semipd_fused_add_rmsnorm.  *ksplit == 1: `out` holds
+ * the result and `planes` is untouched. */
+int semipd_gemm_tall_planes(void* out, float* planes, size_t planes_bytes, const void* x, const void* weight, int64_t rows,
+                            int64_t n, int64_t k, int64_t ldx, int64_t ldo, int dtype, int* ksplit, void* stream);
 
 /* The grouped form of the LDS-DMA streaming kernel for the expert GEMMs of DECODE-sized fused-MoE calls
  * (invoke_fused_moe_kernel, python/sglang/srt/layers/moe/fused_moe_triton/fused_moe.py:501-612): every touched expert's

@@ -404,7 +404,7 @@ static int g8_pick_ksplit(int tiles, int nkt, int M, int N, size_t planes_bytes)
 
 template <typename T, int EPI, int XH>
 static int g8_launch_geo(T* out, float* planes, size_t planes_bytes, const T* x, const T* w, int M, int N, int K, int64_t ldx,
-                         int64_t ldo, int force_ks, hipStream_t st) {
+                         int64_t ldo, int force_ks, hipStream_t st, int* planes_only_ks = nullptr) {
   using G = G8Geo<XH>;
   const int n_cols = EPI == G8_SILU_MUL ? N / 2 : N;
   const int cols_per_tile = EPI == G8_SILU_MUL ? G::WH : G::BN;
@@ -439,6 +439,10 @@ static int g8_launch_geo(T* out, float* planes, size_t planes_bytes, const T* x,
     }
   }
   int rc = launch_status("gemm8p");
+  if (planes_only_ks) {   // the consumer sums the K-slice planes (semipd_fused_add_rmsnorm_planes); one slice: `out` is written
+    *planes_only_ks = ksp;
+    return rc;
+  }
   if (rc || ksp == 1) return rc;
   const int64_t items = (int64_t)M * (n_cols / 4);
   hipLaunchKernelGGL((gemm8p_reduce_kernel<T, EPI>), dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, out,
@@ -448,11 +452,11 @@ static int g8_launch_geo(T* out, float* planes, size_t planes_bytes, const T* x,
 
 template <typename T, int EPI>
 static int g8_launch(T* out, float* planes, size_t planes_bytes, const T* x, const T* w, int M, int N, int K, int64_t ldx,
-                     int64_t ldo, int force_ks, int force_geo, hipStream_t st) {
+                     int64_t ldo, int force_ks, int force_geo, hipStream_t st, int* planes_only_ks = nullptr) {
   // up to 128 rows: the 128 x 512 tile (no matrix work on padding rows, twice the weight rows per MFMA)
   const bool narrow = force_geo ? force_geo == 64 : M <= 128;
-  if (narrow) return g8_launch_geo<T, EPI, 64>(out, planes, planes_bytes, x, w, M, N, K, ldx, ldo, force_ks, st);
-  return g8_launch_geo<T, EPI, 128>(out, planes, planes_bytes, x, w, M, N, K, ldx, ldo, force_ks, st);
+  if (narrow) return g8_launch_geo<T, EPI, 64>(out, planes, planes_bytes, x, w, M, N, K, ldx, ldo, force_ks, st, planes_only_ks);
+  return g8_launch_geo<T, EPI, 128>(out, planes, planes_bytes, x, w, M, N, K, ldx, ldo, force_ks, st, planes_only_ks);
 }
 
 template <typename T, int EPI, int XH>
@@ -509,6 +513,31 @@ int semipd_gemm_tall(void* out, const void* x, const void* weight, void* workspa
                                                                 (const T*)weight, (int)rows, (int)n, (int)k, ldx, ldo, force_ks,
                                                                 force_geo, st)));
   }
+  return rc;
+}
+
+/* The same GEMM (plain epilogue), stopped before the reduction over its K slices: the split is chosen as semipd_gemm_tall
+ * chooses it; *ksplit > 1: fp32 planes [*ksplit][rows][n] in `planes` and `out` untouched -- the consumer sums them in slice
+ * order and rounds to dtype (semipd_fused_add_rmsnorm_planes: the bits of semipd_gemm_tall followed by the fused add + norm,
+ * one launch and one round trip of the [rows, n] result fewer); *ksplit == 1: `out` holds the result.  The row-parallel layers
+ * of a prefill batch (o_proj / down_proj -> RMSNorm(x, residual), models/llama.py:279-302) where the tiled GEMM is preferred. */
+int semipd_gemm_tall_planes(void* out, float* planes, size_t planes_bytes, const void* x, const void* weight, int64_t rows,
+                            int64_t n, int64_t k, int64_t ldx, int64_t ldo, int dtype, int* ksplit, void* stream) {
+  SEMIPD_CHECK_ARG(rows > 0 && n > 0 && k > 0 && ldx >= k && ldo >= n && ksplit, SEMIPD_EINVAL, "gemm_tall_planes: bad sizes");
+  SEMIPD_CHECK_ARG(out && planes && x && weight, SEMIPD_EINVAL, "gemm_tall_planes: null pointer");
+  SEMIPD_CHECK_ARG(k % 64 == 0 && ldx % 8 == 0 && n % 16 == 0 && ldo % 4 == 0 && aligned16(x) && aligned16(weight) &&
+                       aligned16(planes) && (reinterpret_cast<uintptr_t>(out) & 7u) == 0 && n < (1 << 30) && k < (1 << 30) &&
+                       rows < (1 << 30),
+                   SEMIPD_EALIGN, "gemm_tall_planes: k %% 64, n %% 16, 16-byte aligned rows required");
+  hipStream_t st = as_stream(stream);
+  const char* e = getenv("SEMIPD_G8_KS");
+  const int force_ks = e ? atoi(e) : 0;
+  const char* eg = getenv("SEMIPD_G8_XH");
+  const int force_geo = eg ? atoi(eg) : 0;
+  int rc = 0;
+  SEMIPD_DISPATCH_HALF(dtype, T, rc = (g8_launch<T, G8_PLAIN>((T*)out, planes, planes_bytes, (const T*)x, (const T*)weight,
+                                                              (int)rows, (int)n, (int)k, ldx, ldo, force_ks, force_geo, st,
+                                                              ksplit)));
   return rc;
 }
 

@@ -259,6 +259,18 @@ def dense_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
     return torch.mm(x, weight.t(), out=out)
 
 
+# RowParallelLinear.forward(defer_reduce=True) above the streaming kernel's rows; SEMIPD_TALL_PLANES=0: the reducing form
+_TALL_PLANES = os.environ.get("SEMIPD_TALL_PLANES", "1") != "0"
+
+
+def _takes_tiled_gemm(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    """dense_linear's two conditions for ops.gemm_tall, bias-free call."""
+    rows = x.shape[0]
+    if ops.STREAM_LINEAR_MAX_ROWS < rows <= GEMM_TALL_MAX_ROWS:
+        return not ops.dense_gemm_is_tuned(weight) and ops.gemm_tall_is_supported(x, weight)
+    return rows > GEMM_TALL_MAX_ROWS and ops.tall_preferred(weight, rows) and ops.gemm_tall_is_supported(x, weight)
+
+
 def gate_up_silu(x: torch.Tensor, gate_up_proj: "MergedColumnParallelLinear", act_fn) -> torch.Tensor:
     """act_fn(gate_up_proj(x)) (models/llama.py:88-92); one launch for decode batches of a bf16 / f16 layer."""
     if (_STREAM_LINEAR["enabled"] and gate_up_proj.quant_config is None and gate_up_proj.bias is None
@@ -461,6 +473,12 @@ class RowParallelLinear(nn.Module):
                 and x.shape[0] <= ops.STREAM_LINEAR_MAX_ROWS and self.weight.shape[0] % 8 == 0
                 and ops.stream_linear_is_supported(x, self.weight)):
             return _timed_stream(lambda: ops.stream_linear_planes(x, self.weight), x, self.weight, self.weight.shape[0], 1)
+        if (defer_reduce and _TALL_PLANES and _STREAM_LINEAR["enabled"] and self.quant_config is None and self.bias is None
+                and get_tensor_model_parallel_world_size() == 1 and x.dim() == 2
+                and _takes_tiled_gemm(x, self.weight)):
+            # taller batches where dense_linear would take the tiled GEMM (the same choice, the same kernel): its K-slice
+            # planes go to the norm as they are -- no reduction launch, no round trip of the [rows, n] result
+            return ops.gemm_tall_planes(x, self.weight)
         # bias is added on rank 0 only so that the sum over ranks adds it once (linear.py:1258-1262)
         bias = self.bias if (self.bias is not None and get_tensor_model_parallel_rank() == 0) else None
         if self.quant_config:

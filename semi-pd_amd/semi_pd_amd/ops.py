@@ -416,6 +416,27 @@ def gemm_tall(x: torch.Tensor, weight: torch.Tensor, fuse_silu_mul: bool = False
     return out
 
 
+def gemm_tall_planes(x: torch.Tensor, weight: torch.Tensor):
+    """gemm_tall stopped before the reduction over its K slices (semipd_gemm_tall_planes): a SplitKPlanes for
+    fused_add_rmsnorm_planes when the launch sliced K, the [rows, n] tensor when it did not."""
+    if not gemm_tall_is_supported(x, weight):
+        raise RuntimeError("gemm_tall_planes: unsupported shapes / dtypes / strides")
+    M, K = x.shape
+    N = weight.shape[0]
+    out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    ent = _linear_workspace_entry(x.device)
+    ws = ent[0]
+    import ctypes as _C
+    ks = _C.c_int(0)
+    stream = current_stream(x.device)
+    check(_lib.load().semipd_gemm_tall_planes(ptr(out), ptr(ws), ws.numel(), ptr(x), ptr(weight), M, N, K, x.stride(0),
+                                              out.stride(0), dtype_code(x.dtype), _C.addressof(ks), stream),
+          "gemm_tall_planes")
+    if int(ks.value) <= 1:
+        return out
+    return SplitKPlanes(ws, int(ks.value), M, N, x.dtype, ent, stream)
+
+
 # --------------------------------------------------------------------------- prefill-sized dense layers on a CU share
 _DENSE_GEMM = {"ready": False, "tuned": set(), "cus": 0}
 

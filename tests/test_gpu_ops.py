@@ -1050,6 +1050,96 @@ def test_stream_linear_planes_into_fused_add_rmsnorm(ops, device, M, N, K, dtype
     _close(r2, want_res, dtype, rtol=2e-2, atol=2e-2 * float(want_res.float().abs().max()))
 
 
+@pytest.mark.parametrize("M,N,K", [(1357, 4096, 14336), (1024, 4096, 4096), (300, 768, 512), (129, 272, 1024), (2048, 4096, 14336),
+                                   (65, 256, 128)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_gemm_tall_planes_into_fused_add_rmsnorm(ops, device, M, N, K, dtype):
+    """o_proj / down_proj of a prefill batch -> fused add + RMSNorm with the tiled GEMM's K-slice reduction done by the norm
+    kernel (ops.gemm_tall_planes): the bits of gemm_tall followed by fused_add_rmsnorm for the split the launch picks by
+    itself and for forced splits (one slice: the tensor comes back, no planes), and the oracle's values."""
+    import os
+    torch.manual_seed(M + N + K)
+    x = torch.randn(M, K).to(dtype)
+    w = (torch.randn(N, K) * K ** -0.5).to(dtype)
+    res = torch.randn(M, N).to(dtype)
+    nw = (torch.rand(N) + 0.5).to(dtype)
+    xd, wd, nwd = x.to(device), w.to(device), nw.to(device)
+    seen = set()
+    try:
+        for ks in ("0", "1", "2", "3", "4"):
+            os.environ["SEMIPD_G8_KS"] = ks
+            y = ops.gemm_tall(xd, wd)
+            r1 = res.to(device).clone()
+            ops.fused_add_rmsnorm(y, r1, nwd, 1e-5)
+            p = ops.gemm_tall_planes(xd, wd)
+            r2 = res.to(device).clone()
+            if isinstance(p, ops.SplitKPlanes):
+                assert p.ksplit > 1 and p.shape == (M, N)
+                seen.add(p.ksplit)
+                out = ops.fused_add_rmsnorm_planes(p, r2, nwd, 1e-5)
+            else:                                   # the launch did not slice K: a finished [M, N] tensor
+                assert tuple(p.shape) == (M, N)
+                seen.add(1)
+                out = p
+                ops.fused_add_rmsnorm(out, r2, nwd, 1e-5)
+            assert torch.equal(r1, r2) and torch.equal(y, out), ks
+    finally:
+        os.environ.pop("SEMIPD_G8_KS", None)
+    assert 1 in seen
+    if (M, N, K) == (1357, 4096, 14336):
+        assert 2 in seen
+    if (M, N, K) == (2048, 4096, 14336):
+        assert max(seen) == 2            # two planes of 2048 x 4096 fill the 64 MiB workspace: a forced 3 or 4 comes back as 2
+    gemm = (x.float() @ w.float().T).to(dtype)
+    want, want_res = O.fused_add_rms_norm(gemm, res, nw, 1e-5)
+    _close(out, want, dtype, rtol=3e-2, atol=3e-2)
+    _close(r2, want_res, dtype, rtol=2e-2, atol=2e-2 * float(want_res.float().abs().max()))
+
+
+def test_gemm_tall_planes_must_be_consumed_before_the_next_gemm(ops, device):
+    """The planes live in the stream's GEMM workspace: a GEMM in between makes the consumer refuse them."""
+    import os
+    x = torch.randn(300, 1024, device=device, dtype=torch.bfloat16)
+    w = torch.randn(512, 1024, device=device, dtype=torch.bfloat16) * 0.03
+    os.environ["SEMIPD_G8_KS"] = "2"
+    try:
+        p = ops.gemm_tall_planes(x, w)
+        assert isinstance(p, ops.SplitKPlanes) and p.ksplit == 2
+        ops.gemm_tall(x, w)
+        with pytest.raises(RuntimeError, match="overwritten"):
+            ops.fused_add_rmsnorm_planes(p, torch.zeros(300, 512, device=device, dtype=torch.bfloat16),
+                                         torch.ones(512, device=device, dtype=torch.bfloat16), 1e-5)
+    finally:
+        os.environ.pop("SEMIPD_G8_KS", None)
+
+
+def test_row_parallel_layer_defers_the_tiled_gemms_reduction_to_the_norm(ops, device, monkeypatch):
+    """RowParallelLinear.forward(defer_reduce=True) above the streaming kernel's rows: where dense_linear takes the tiled
+    GEMM the layer hands its planes to RMSNorm(x, residual) -- the bits of the reducing form (SEMIPD_TALL_PLANES=0)."""
+    from semi_pd_amd.layers import basic as L
+    torch.manual_seed(3)
+    layer = L.RowParallelLinear(2048, 1024, params_dtype=torch.bfloat16).to(device)
+    layer.weight.data.copy_((torch.randn(1024, 2048) * 0.02).to(torch.bfloat16))
+    norm = L.RMSNorm(1024).to(device)
+    norm.weight.data = (torch.rand(1024, device=device) + 0.5).to(torch.bfloat16)
+    x = torch.randn(200, 2048, device=device, dtype=torch.bfloat16)
+    res = torch.randn(200, 1024, device=device, dtype=torch.bfloat16)
+    monkeypatch.setenv("SEMIPD_G8_KS", "2")
+    assert L._takes_tiled_gemm(x, layer.weight)       # 65 .. 256 rows of an untuned layer: the tiled GEMM
+    monkeypatch.setitem(L._STREAM_LINEAR, "enabled", True)   # what the model runner sets for the process
+    monkeypatch.setattr(L, "_TALL_PLANES", True)
+    p = layer(x, defer_reduce=True)
+    assert isinstance(p, ops.SplitKPlanes)
+    r1 = res.clone()
+    y1, r1 = norm(p, r1)
+    monkeypatch.setattr(L, "_TALL_PLANES", False)
+    t = layer(x, defer_reduce=True)
+    assert isinstance(t, torch.Tensor)
+    r2 = res.clone()
+    y2, r2 = norm(t, r2)
+    assert torch.equal(y1, y2) and torch.equal(r1, r2)
+
+
 _KEEP_ALIVE = []
 
 
