@@ -259,8 +259,11 @@ def dense_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
     return torch.mm(x, weight.t(), out=out)
 
 
-# RowParallelLinear.forward(defer_reduce=True) above the streaming kernel's rows; SEMIPD_TALL_PLANES=0: the reducing form
-_TALL_PLANES = os.environ.get("SEMIPD_TALL_PLANES", "1") != "0"
+# RowParallelLinear.forward(defer_reduce=True) above the streaming kernel's rows: SEMIPD_TALL_PLANES=1 hands the tiled GEMM's
+# K-slice planes to the norm.  OFF by default: alone the pair is 4-12 us shorter per layer, next to a running decode instance
+# the serving run is slower with it (six alternating runs on two boxes, profiles/r05_tall_planes_in_situ_ab.txt: prefill batch
+# 27.2-27.6 -> 27.8-28.9 ms, TTFT p50 36.5-37.9 -> 38.1-39.1, TBT p50 4.9-5.1 -> 5.5)
+_TALL_PLANES = os.environ.get("SEMIPD_TALL_PLANES", "0") == "1"
 
 
 def _takes_tiled_gemm(x: torch.Tensor, weight: torch.Tensor) -> bool:
