@@ -134,3 +134,21 @@ def test_a_sweep_only_invocation_prints_a_line(monkeypatch, capsys):
     assert d["steps"] == 0 and d["value"] == 0 and d["p50_ttft_ms"] is None
     assert [(s["request_rate"], s["num_requests"], s["output_tokens"]) for s in d["qps_sweep"]] == [(200.0, 5, 20), (400.0, 5, 20)]
     assert len(FakeEngine.instances) == 1
+
+
+def test_cpu_baseline_runs_the_full_depth_on_a_small_model():
+    """bench.py's `cpu_baseline` object of the headline: the oracle at the model's full depth (every layer executed, one
+    layer's weights under every layer's name), one prefill + 3 decode steps, the fields of the contract and the sample
+    spelled out.  A small Llama shape here; the headline runs Llama-3-8B's 32 layers in ~30 s on the GPU box's host."""
+    import types
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "semi-pd_amd")]
+    import bench
+    cfg = types.SimpleNamespace(hidden_size=128, intermediate_size=256, head_size=32, num_attention_heads=4,
+                                num_key_value_heads=2, num_hidden_layers=5, vocab_size=512, rope_scaling=None,
+                                rope_theta=10000.0, max_position_embeddings=512, rms_norm_eps=1e-5)
+    got = bench.cpu_baseline(cfg, input_len=48, output_len=8)
+    assert got["kind"] == "port" and got["unit"] == "output tokens/s" and got["value"] > 0 and 1 <= got["cores"] <= 32
+    assert "all 5 layers executed" in got["sample"] and "in=48" in got["sample"] and "out=8" in got["sample"]
+    # a budget no probe can meet: one request instead of two, still the whole depth
+    one = bench.cpu_baseline(cfg, input_len=48, output_len=8, budget_s=0.0)
+    assert "1 request(s)" in one["sample"] and "all 5 layers executed" in one["sample"]
