@@ -720,6 +720,7 @@ def gen_extend_mask():
         ("tree_d128_cap_prefix_bits", [70], [66], 2, 1, 128, 128, 25.0, False),
         ("tree_dk96_dv64", [6, 0], [10, 3], 2, 1, 96, 64, 0.0, False),
         ("causal_as_mask_mha_d32", [3, 0], [5, 130], 2, 2, 32, 32, 0.0, True),
+        ("tree_mla_576_512", [11, 2], [6, 14], 4, 1, 576, 512, 0.0, False),   # the absorbed-MLA row: BLOCK_DMODEL 512 + DPE 64
     ]
     for name, pre, ext, Hq, Hkv, Dk, Dv, cap, skip in cases:
         dt = torch.float32

@@ -553,6 +553,7 @@ def test_extend_attention_custom_mask_golden(ops, device):
     ([40, 3], [17, 200], 2, 1, 192, 128, 0.0),            # MLA prefill shape
     ([5, 2], [9, 4], 2, 1, 80, 13, 0.0),                  # ragged head sizes: the one-wave kernel reads the mask
     ([7], [12], 2, 2, 256, 256, 0.0),                     # no MFMA instantiation: one-wave kernel
+    ([11, 2], [6, 14], 4, 1, 576, 512, 0.0),              # MLA absorbed rows behind a chunked prefill: one-wave kernel
 ])
 def test_extend_attention_custom_mask(ops, device, pre, ext, Hq, Hkv, Dk, Dv, cap, skip_prefix, dtype):
     g = torch.Generator().manual_seed(17)
