@@ -239,13 +239,9 @@ def dense_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
     if (_STREAM_LINEAR["enabled"] and bias is None and x.dim() == 2 and x.shape[0] <= ops.STREAM_LINEAR_MAX_ROWS
             and ops.stream_linear_is_supported(x, weight)):
         return _timed_stream(lambda: ops.stream_linear(x, weight, out=out), x, weight, weight.shape[0], 2)
-    if (_STREAM_LINEAR["enabled"] and bias is None and x.dim() == 2 and ops.STREAM_LINEAR_MAX_ROWS < x.shape[0] <= GEMM_TALL_MAX_ROWS
-            and not ops.dense_gemm_is_tuned(weight) and ops.gemm_tall_is_supported(x, weight)):
-        # tall decode batch (65 .. 256 rows): the tiled ping-pong GEMM (csrc/gemm8p.hip)
-        return ops.gemm_tall(x, weight, out=out)
-    if (_STREAM_LINEAR["enabled"] and bias is None and x.dim() == 2 and x.shape[0] > GEMM_TALL_MAX_ROWS
-            and ops.tall_preferred(weight, x.shape[0]) and ops.gemm_tall_is_supported(x, weight)):
-        # prefill-sized batch of a shape for which the tiled GEMM beat the library's measured winner on this share
+    if _STREAM_LINEAR["enabled"] and bias is None and x.dim() == 2 and _takes_tiled_gemm(x, weight):
+        # the tiled ping-pong GEMM (csrc/gemm8p.hip): a tall decode batch (65 .. 256 rows) of an untuned layer, or a
+        # prefill-sized batch of a shape for which it beat the library's measured winner on this share
         return ops.gemm_tall(x, weight, out=out)
     if x.dim() == 2 and x.shape[0] > 0 and ops.dense_gemm_is_tuned(weight) and x.stride(1) == 1:
         # prefill-sized batch of a layer whose library solutions were timed on this process's CU share at start-up
