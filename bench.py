@@ -37,11 +37,26 @@ DEFAULT_BACKLOG_FULL_TOKENS = 8192
 # layer boundary until the step is over.  0 = off
 DEFAULT_DEADLINE_MS = 8.5
 DEFAULT_TBT_SLO_MS = 12.0
-# BASELINE config 2: "Poisson QPS sweep" -- two points in the default line (in = 1024 / out = 256); the whole sweep
-# (lambda 2 .. 16, 512 requests per point, both length pairs, default policy and the literal 50 / 50 split) is
-# profiles/r05_qps_sweep_config2.txt -- the 8 req/s point alone cost the driver's run 34 s
-DEFAULT_SWEEP_RATES = "16,32"
-SWEEP_OUTPUT_LEN = 256
+# BASELINE config 2: "Poisson QPS sweep".  The default line sweeps a fixed grid of rates for BOTH engines -- Semi-PD under the
+# default policy and the unified engine -- at the headline's lengths (in = 1024 / out = 128), and states the GOODPUT of each:
+# the highest rate of the grid that meets a service-level objective (the reference's result form: latency against rate for
+# both engines and the rate at which each breaks its SLO, README.md:105, evaluation/show_result.py:50-66; sweep loop
+# python/sglang/bench_serving.py:1413-1438).  (SURVEY 8d.2's lambda 2 .. 16 x two length pairs x two policies tables are
+# profiles/r05_qps_sweep_config2.txt.)  Points below 16 req/s send 16 s worth of requests instead of all of them.
+DEFAULT_SWEEP_RATES = "8,16,24,32,40,48"
+SWEEP_OUTPUT_LEN = None          # = --output-len
+# the objectives of `goodput` (ms): the 99th percentile of the time to the first token, and either the 99th percentile of
+# every gap between two tokens ("itl": streaming smoothness -- what Semi-PD's isolation is about) or the 99th percentile over
+# requests of a request's MEAN gap ("tpot": the reference's evaluation metric, show_result.py:36-45, 55-58)
+SLO_TTFT_P99_MS = 200.0
+SLO_ITL_P99_MS = 15.0
+SLO_TPOT_P99_MS = 15.0
+# token check of the timed engines (bench_one_batch.py:16-41 `--correct` keeps a known-answer probe for the same purpose):
+# requests of these lengths, this many greedy tokens each, Semi-PD against the unified engine; they may part ways only at a
+# near-tie of the unified engine's own top-2 log-probabilities (tests/test_gpu_full_depth.py: same rule, same margin)
+TOKEN_CHECK_LENS = (64, 200, 1024, 7)
+TOKEN_CHECK_STEPS = 8
+TOKEN_CHECK_MARGIN = 0.15
 
 HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 MFMA_BF16_PEAK_TFLOPS = 2500.0
@@ -157,19 +172,117 @@ def combine_ranks(records, elapsed, rank, world, replicas):
 
 
 def summarize(records, duration):
-    ttft, itl, out_tokens = [], [], 0
+    ttft, itl, tpot, out_tokens = [], [], [], 0
     for r in records:
         tt = r["token_times"]
         out_tokens += len(r["output_ids"])
         if tt:
             ttft.append(tt[0] - r["send"])
-            itl.extend(np.diff(tt).tolist())
+            gaps = np.diff(tt)
+            itl.extend(gaps.tolist())
+            if len(gaps):
+                tpot.append(float(gaps.mean()))     # a request's mean gap (show_result.py:36-45)
     return {"output_tokens": out_tokens, "duration_s": duration,
             "output_tok_s": out_tokens / duration if duration > 0 else 0.0,
             "p50_ttft_ms": float(np.median(ttft) * 1e3) if ttft else None,
             "p99_ttft_ms": float(np.percentile(ttft, 99) * 1e3) if ttft else None,
             "p50_tbt_ms": float(np.median(itl) * 1e3) if itl else None,
-            "p99_tbt_ms": float(np.percentile(itl, 99) * 1e3) if itl else None}
+            "p99_tbt_ms": float(np.percentile(itl, 99) * 1e3) if itl else None,
+            "p99_tpot_ms": float(np.percentile(tpot, 99) * 1e3) if tpot else None}
+
+
+def _rounded(sm):
+    return {k: (round(v, 2) if isinstance(v, float) else v) for k, v in sm.items()}
+
+
+def sweep_point(sm, rate, n, input_len, output_len, source=None):
+    """One row of a rate sweep, with the verdicts of the two objectives."""
+    ttft_ok = sm["p99_ttft_ms"] is not None and sm["p99_ttft_ms"] <= SLO_TTFT_P99_MS
+    row = {"request_rate": rate, "num_requests": n, "input_len": input_len, "output_len": output_len, **_rounded(sm),
+           "meets_slo_itl": bool(ttft_ok and sm["p99_tbt_ms"] is not None and sm["p99_tbt_ms"] <= SLO_ITL_P99_MS),
+           "meets_slo_tpot": bool(ttft_ok and sm["p99_tpot_ms"] is not None and sm["p99_tpot_ms"] <= SLO_TPOT_P99_MS)}
+    if source:
+        row["source"] = source
+    return row
+
+
+def goodput_of(points, key):
+    """The highest rate of the grid whose point meets the objective (0 when none does)."""
+    ok = [p["request_rate"] for p in points if p.get(key)]
+    return max(ok) if ok else 0.0
+
+
+def sweep_requests(rate, num_requests):
+    """Requests of one sweep point: all of them from 16 req/s up, 16 s worth below (a 256-request wave at 8 req/s is 32 s)."""
+    return max(1, min(num_requests, int(round(16 * rate)))) if rate > 0 else num_requests
+
+
+def token_probe(engine, vocab, seed, logprobs=False):
+    """TOKEN_CHECK_STEPS greedy tokens for requests of TOKEN_CHECK_LENS tokens (ids by bench_serving.py's rule)."""
+    from semi_pd_amd.managers.io_struct import SamplingParams
+    rs = np.random.RandomState(seed + 77)
+    prompts = [[int((o + j) % vocab) for j in range(n)] for o, n in zip(rs.randint(0, vocab, size=len(TOKEN_CHECK_LENS)), TOKEN_CHECK_LENS)]
+    sp = SamplingParams(max_new_tokens=TOKEN_CHECK_STEPS, ignore_eos=True)
+    if logprobs:
+        return engine.generate(prompts, sp, timeout=300, return_logprob=True, top_logprobs_num=2)
+    return engine.generate(prompts, sp, timeout=300), None
+
+
+def compare_tokens(name, got, ref, ref_lps):
+    """`got` (an engine under test) against `ref` (the unified engine, with its top-2 log-probabilities per step): equal, or
+    parting at a step where the other token is the reference's runner-up within TOKEN_CHECK_MARGIN."""
+    out = {"engine": name, "requests": len(ref), "tokens_per_request": TOKEN_CHECK_STEPS, "equal_requests": 0,
+           "near_tie_divergences": [], "errors": []}
+    for i, (a, b) in enumerate(zip(ref, got)):
+        if list(a) == list(b):
+            out["equal_requests"] += 1
+            continue
+        if len(a) != len(b):
+            out["errors"].append(f"request {i}: {len(b)} tokens instead of {len(a)}")
+            continue
+        s = next(j for j in range(len(a)) if a[j] != b[j])
+        try:
+            top = ref_lps[i]["top"][s]
+            (lp1, t1), (lp2, t2) = top[0][:2], top[1][:2]
+            gap = float(lp1) - float(lp2)
+        except Exception as e:   # no log-probabilities to judge the divergence by: it counts as an error
+            out["errors"].append(f"request {i} step {s}: {a[s]} vs {b[s]} and no top-2 log-probabilities ({e!r})")
+            continue
+        if t1 == a[s] and b[s] == t2 and gap < TOKEN_CHECK_MARGIN:
+            out["near_tie_divergences"].append({"request": i, "step": s, "top2_logprob_gap": round(gap, 4)})
+        else:
+            out["errors"].append(f"request {i} step {s}: unified {a[s]} (top-2 {t1}, {t2}, gap {gap:.4f}), {name} {b[s]}")
+    out["ok"] = not out["errors"]
+    return out
+
+
+def prefill_accounting(s: dict, n: int, num_layers: int) -> dict:
+    """Where a prefill batch's time on the GPU goes (ms per batch, means over the timed steps):
+      gpu_owned            from the moment the batch has the GPU (its launch, or the end of the batch it was queued behind) to
+                           its ids on the host -- what the prefill queue's service time is
+      layers_without_hold  num_layers x the mean GPU time between two consecutive layer hooks at which no hold happened: one
+                           decoder layer's kernels plus the launch gaps inside it (HIP events of the step pacer's run-ahead
+                           bound; the per-kernel split is the prefill process's rocprofv3 table under profiles/)
+      held                 the decode-step deadline's holds (an empty prefill queue while an overdue decode step finishes)
+      outside_layers       the rest: embedding, final norm, lm_head + sampling of the last tokens, the copy of the ids, and
+                           whatever the GPU idled between this batch and its predecessor
+      pacer_wait_host      host time inside the hooks waiting for the GPU (bounded run-ahead): NOT GPU time, listed so that
+                           nobody adds it"""
+    if not s.get("t_gpu_owned_s"):
+        return {}
+    gate = s.get("step_gate") or {}
+    owned = 1e3 * s["t_gpu_owned_s"] / n
+    out = {"gpu_owned": round(owned, 3)}
+    held = gate.get("held_ms", 0.0) / n
+    if gate.get("layer_ms_without_hold"):
+        layers = num_layers * gate["layer_ms_without_hold"]
+        out.update({"layers_without_hold": round(layers, 3), "held": round(held, 3),
+                    "outside_layers": round(owned - layers - held, 3)})
+    elif gate:
+        out["held"] = round(held, 3)
+    if gate.get("run_ahead_waits_ms") is not None:
+        out["pacer_wait_host"] = round(gate["run_ahead_waits_ms"] / n, 3)
+    return out
 
 
 def pmc_traffic(kernel: str, algorithmic_bytes: float) -> dict:
@@ -336,6 +449,8 @@ def main():
     ap.add_argument("--kv-cache-dtype", default="auto", choices=["auto", "fp8_e5m2", "fp8_e4m3"],
                     help="KV pool rows: activation type (the measured default) or OCP fp8")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-token-check", action="store_true",
+                    help="N = 1 Semi-PD run: skip the comparison of the timed engines' first tokens with the unified engine's")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--fixed-load", action="store_true", help="N > 1 (tensor parallel): do not scale requests / rate with N")
@@ -349,9 +464,11 @@ def main():
     ap.add_argument("--no-saturation-wave", action="store_true",
                     help="skip the extra (untimed for `value`) wave with all requests sent at once")
     ap.add_argument("--rate-sweep", default=None, help="comma-separated Poisson rates; one extra (untimed for "
-                    "`value`) wave per rate after the timed steps, reported under qps_sweep (BASELINE config 2).  Default: "
-                    f"{DEFAULT_SWEEP_RATES} for the default N = 1 Llama-3-8B workload, none otherwise; '' = none")
-    ap.add_argument("--sweep-output-len", type=int, default=SWEEP_OUTPUT_LEN)
+                    "`value`) wave per rate after the timed steps, reported under qps_sweep (BASELINE config 2) with the goodput "
+                    "under the objectives named in config.slo; the unified engine of the default line runs the same grid "
+                    f"(qps_sweep_unified).  Default: {DEFAULT_SWEEP_RATES} for the default N = 1 Llama-3-8B workload, none "
+                    "otherwise; '' = none")
+    ap.add_argument("--sweep-output-len", type=int, default=SWEEP_OUTPUT_LEN, help="default: --output-len")
     ap.add_argument("--sweep-num-requests", type=int, default=None, help="requests per sweep point (default: --num-requests)")
     args = ap.parse_args()
 
@@ -359,6 +476,8 @@ def main():
         default_workload = (args.gpus == 1 and args.model == "llama3-8b" and args.mode == "semi-pd"
                             and args.input_len == 1024 and args.output_len == 128 and args.request_rate == 32.0)
         args.rate_sweep = DEFAULT_SWEEP_RATES if default_workload else ""
+    if args.sweep_output_len is None:
+        args.sweep_output_len = args.output_len
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("SEMIPD_BENCH_ALL_ON_GPU0") == "1":
@@ -458,15 +577,31 @@ def main():
         n_sweep = args.sweep_num_requests or args.num_requests
         sweep_prompts = prompts if n_sweep == args.num_requests else make_requests(n_sweep, args.input_len, cfg.vocab_size,
                                                                                   args.seed + 1000 * replica)
-        for rate in sweep_rates:
-            barrier()
-            if driver:
-                recs, dur = run_wave(engine, sweep_prompts, arrival_times(n_sweep, rate * (world if args.tp and not args.fixed_load else 1), args.seed),
-                                     args.sweep_output_len)
-                sm = summarize(recs, dur)
-                sweep.append({"request_rate": rate, "num_requests": n_sweep, "input_len": args.input_len,
-                              "output_len": args.sweep_output_len,
-                              **{k: (round(v, 2) if isinstance(v, float) else v) for k, v in sm.items()}})
+        rate_scale = world if (args.tp and not args.fixed_load) else 1
+
+        def run_sweep(eng, rates, skip_rate=None):
+            """One wave per rate on `eng` (sweep_requests(rate) requests of the sweep's lengths); skip_rate: a rate that was
+            measured already (the timed steps of the headline) and is filled in by the caller."""
+            rows = []
+            for rate in rates:
+                if skip_rate is not None and rate == skip_rate:
+                    continue
+                n = sweep_requests(rate, n_sweep) if not args.sweep_num_requests else n_sweep
+                recs, dur = run_wave(eng, sweep_prompts[:n], arrival_times(n, rate * rate_scale, args.seed), args.sweep_output_len)
+                rows.append(sweep_point(summarize(recs, dur), rate, n, args.input_len, args.sweep_output_len))
+            return rows
+
+        # the headline's rate is a point of the grid that the timed steps have measured already (same lengths, all requests)
+        headline_in_grid = (args.steps > 0 and args.sweep_output_len == args.output_len and not args.sweep_num_requests
+                            and args.request_rate in sweep_rates)
+        barrier()
+        if driver and sweep_rates:
+            sweep = run_sweep(engine, sweep_rates, skip_rate=args.request_rate if headline_in_grid else None)
+            if headline_in_grid:
+                sweep.append(sweep_point(summarize(all_records, sum(w["duration_s"] for w in wave_summaries)), args.request_rate,
+                                         args.num_requests, args.input_len, args.output_len,
+                                         source=f"the {args.steps} timed step(s) of the headline"))
+                sweep.sort(key=lambda r: r["request_rate"])
         saturation = None
         if not args.no_saturation_wave and args.request_rate > 0:
             # capacity next to the load-bound headline: the same requests, all sent at once
@@ -474,7 +609,13 @@ def main():
             if driver:
                 recs, dur = run_wave(engine, prompts, arrival_times(args.num_requests, 0.0, args.seed), args.output_len)
                 sm = summarize(recs, dur)
-                saturation = {k: (round(v, 2) if isinstance(v, float) else v) for k, v in sm.items()}
+                saturation = _rounded(sm)
+        # token check, first half: the engine that was just timed produces TOKEN_CHECK_STEPS tokens for four requests; the
+        # unified engine below is the reference they are compared with
+        probes = {}
+        want_token_check = (world == 1 and args.mode == "semi-pd" and not args.no_unified_wave and not args.no_token_check)
+        if want_token_check and driver:
+            probes["semi-pd"] = token_probe(engine, cfg.vocab_size, args.seed)[0]
         barrier()
     finally:
         engine.shutdown()
@@ -487,11 +628,11 @@ def main():
             recs, _ = run_wave(eng, prompts, arrivals, args.output_len)
             recs_all.extend(recs)
         sm = summarize(recs_all, time.time() - t0)
-        return {"warmup_waves": 1, "timed_waves": n_timed, **{k: (round(v, 2) if isinstance(v, float) else v) for k, v in sm.items()}}
+        return {"warmup_waves": 1, "timed_waves": n_timed, **_rounded(sm)}
 
     # side engines run the headline's load for at most this many timed waves (the driver's 20-step line would otherwise
     # spend as long on each of them as on the headline)
-    n_side = max(1, min(args.steps, 3))
+    n_side = max(1, min(args.steps, 2))
     static_split = None
     if (world == 1 and args.mode == "semi-pd" and not args.no_static_split_wave
             and (args.prefill_cu, args.decode_cu) != (50, 50)):
@@ -503,6 +644,8 @@ def main():
         try:
             static_split = {"workload": "same requests and rate, HSA_CU_MASK halves: prefill CUs 0-127, decode CUs 128-255",
                             **side_waves(eng2, n_side)}
+            if want_token_check:
+                probes["semi-pd 50/50"] = token_probe(eng2, cfg.vocab_size, args.seed)[0]
         except Exception as e:  # a side wave must never take the measured line down with it
             static_split = {"error": repr(e)}
         finally:
@@ -511,16 +654,38 @@ def main():
     # The reference's claim is Semi-PD against the unified engine at equal load (README.md:105, evaluation/show_result.py:
     # 50-66): the same requests and arrival times through ONE process that interleaves prefill batches and decode steps
     # on every CU.
-    unified = None
+    unified, sweep_unified, token_check = None, [], None
     if world == 1 and args.mode == "semi-pd" and not args.no_unified_wave:
         import dataclasses
-        eng5 = Engine(dataclasses.replace(sa, enable_semi_pd=False, collect_kernel_timing=False, mem_fraction_static=None),
+        eng5 = Engine(dataclasses.replace(sa, enable_semi_pd=False, collect_kernel_timing=False, mem_fraction_static=None,
+                                          decode_step_deadline_ms=0.0, decode_tbt_slo_ms=0.0),
                       gpu_ids={0: local_rank})
         try:
             unified = {"workload": "same requests and rate, the unified engine (one process, chunked prefill and decode "
-                                   "interleaved on every CU; --mode unified)", **side_waves(eng5, min(n_side, 2))}
+                                   "interleaved on every CU; --mode unified)", **side_waves(eng5, n_side)}
+            if sweep_rates:
+                # the same grid of rates as the Semi-PD engine above; the headline's rate = the waves just timed
+                in_grid = headline_in_grid
+                sweep_unified = run_sweep(eng5, sweep_rates, skip_rate=args.request_rate if in_grid else None)
+                if in_grid:
+                    pt = {k: unified[k] for k in ("output_tokens", "duration_s", "output_tok_s", "p50_ttft_ms", "p99_ttft_ms",
+                                                  "p50_tbt_ms", "p99_tbt_ms", "p99_tpot_ms")}
+                    sweep_unified.append(sweep_point(pt, args.request_rate, args.num_requests, args.input_len, args.output_len,
+                                                     source=f"the {n_side} timed wave(s) of unified_same_load"))
+                    sweep_unified.sort(key=lambda r: r["request_rate"])
+            if not args.no_saturation_wave and args.request_rate > 0:
+                recs, dur = run_wave(eng5, prompts, arrival_times(args.num_requests, 0.0, args.seed), args.output_len)
+                unified["saturation"] = _rounded(summarize(recs, dur))
+            if want_token_check:
+                ref, ref_lps = token_probe(eng5, cfg.vocab_size, args.seed, logprobs=True)
+                checks = [compare_tokens(name, got, ref, ref_lps) for name, got in probes.items()]
+                token_check = {"reference": "the unified engine's tokens and top-2 log-probabilities",
+                               "prompt_lens": list(TOKEN_CHECK_LENS), "margin": TOKEN_CHECK_MARGIN, "engines": checks,
+                               "ok": all(c["ok"] for c in checks)}
         except Exception as e:
             unified = {"error": repr(e)}
+            if want_token_check:
+                token_check = {"ok": False, "error": f"the unified engine failed: {e!r}"}
         finally:
             eng5.shutdown()
 
@@ -574,7 +739,10 @@ def main():
             extra["prefill_batch_ms"] = {"batches": int(n), "avg_tokens": round(s["prefill_tokens"] / n, 1),
                                          "avg_requests": round(s.get("prefill_reqs", 0) / n, 2),
                                          "wait_admission": round(1e3 * s.get("t_wait_admission_s", 0) / n, 3),
+                                         # from the launch to the ids on the host: for a batch launched behind a running one
+                                         # this includes the rest of THAT batch (up to SEMIPD_PREFILL_LEAD_MS)
                                          "forward_and_sync": round(1e3 * s.get("t_forward_s", 0) / n, 3),
+                                         **prefill_accounting(s, n, cfg.num_hidden_layers),
                                          # batches queued behind a running one by the late-binding loop, and how many
                                          # running batches had their first tokens sent from a layer hook of that launch
                                          "launched_behind_a_running_batch": int(s.get("late_bound_launches", 0)),
@@ -662,13 +830,27 @@ def main():
                                         and args.cu_mask_mode in ("env", "dynamic"))
                                     else "library heuristic"),
                    "decode_step_deadline_ms": args.decode_step_deadline_ms, "decode_tbt_slo_ms": args.decode_tbt_slo_ms,
-                   "kv_cache_dtype": args.kv_cache_dtype},
+                   "kv_cache_dtype": args.kv_cache_dtype,
+                   **({"slo": {"p99_ttft_ms": SLO_TTFT_P99_MS, "itl": {"p99_tbt_ms": SLO_ITL_P99_MS},
+                               "tpot": {"p99_tpot_ms": SLO_TPOT_P99_MS},
+                               "goodput": "highest Poisson rate of qps_sweep's grid whose wave meets p99 TTFT and the named "
+                                          "objective for the gaps between tokens (itl: every gap; tpot: a request's mean gap)"}}
+                      if sweep else {})},
         "roofline": roofline, "roofline_extra": extra, "cpu_baseline": cpu,
     }
     if static_split:
         out["static_split_50_50"] = static_split
     if unified is not None:
         out["unified_same_load"] = unified
+    if sweep:
+        gp = {"semi_pd": {"itl": goodput_of(sweep, "meets_slo_itl"), "tpot": goodput_of(sweep, "meets_slo_tpot")}}
+        if sweep_unified:
+            gp["unified"] = {"itl": goodput_of(sweep_unified, "meets_slo_itl"), "tpot": goodput_of(sweep_unified, "meets_slo_tpot")}
+            out["qps_sweep_unified"] = sweep_unified
+        out["goodput_req_s"] = gp["semi_pd"]["itl"]      # Semi-PD, the tail-of-every-gap objective (config.slo)
+        out["goodput"] = {"unit": "requests/s", "rates": sweep_rates, **gp}
+    if token_check is not None:
+        out["token_check"] = token_check
     out.update(side)
     if saturation:
         out["saturation"] = {"note": "extra wave, every request sent at t = 0: output tok/s here is the engine's capacity; "
@@ -683,6 +865,10 @@ def main():
     if sweep:
         out["qps_sweep"] = sweep
     print(json.dumps(out), flush=True)
+    if token_check is not None and not token_check.get("ok"):
+        # a timed engine whose tokens are not the unified engine's (beyond near-ties) has measured something else: the run fails
+        print("bench.py: token check FAILED: " + json.dumps(token_check), file=sys.stderr, flush=True)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

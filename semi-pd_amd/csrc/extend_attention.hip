@@ -391,7 +391,9 @@ extend_attn_kernel(T* __restrict__ out, const T* __restrict__ q_ext, const T* __
 
   // ---- epilogue: O[q][dv] = O^T / l ----
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+  // a query whose every key a custom mask removed: NaN, as the reference's kernel writes (exp(-inf - -inf) in its rescale)
+  // and as the one-wave kernel below does (acc / 0); without a mask every query sees at least itself
+  const float inv = l_tot > 0.f ? 1.f / l_tot : (MASK ? __builtin_nanf("") : 0.f);
   if (q_valid) {
     T* orow = out + (int64_t)(q_start + q_local) * o_stride + (int64_t)hq * Dv;
 #pragma unroll

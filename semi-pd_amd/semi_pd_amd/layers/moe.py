@@ -306,8 +306,11 @@ class FusedMoE(nn.Module):
             x = hidden_states[c0 + lo: c0 + hi].contiguous()
             ids = topk_ids[c0 + lo: c0 + hi].to(torch.int32).contiguous()
             w = topk_weights[c0 + lo: c0 + hi].float().contiguous()
+            # the chunk routes n x k rows in all, so no rank can receive more: overflow is impossible and the read-back of
+            # recv_count (a host synchronisation per MoE layer -- and only on the ranks whose slice is a full one when n does
+            # not divide by tp, i.e. ranks running out of step) is switched off
             max_recv = n * k
-            st = comm.ep_dispatch(x, ids, w, e_local, max_recv)
+            st = comm.ep_dispatch(x, ids, w, e_local, max_recv, check_overflow=False)
             # rows that did not arrive (beyond recv_count) keep the out-of-range expert id and are dropped by moe_align
             recv_e = torch.where(torch.arange(max_recv, device=x.device) < st["recv_count"], st["recv_expert"],
                                  torch.full_like(st["recv_expert"], e_local)).view(-1, 1)

@@ -377,7 +377,11 @@ class SemiPDPrefillScheduler(SchedulerBase):
         ttft_trace.mark("p_done", [r.rid for r in batch.reqs])
         if ev is not None:
             # this batch had the GPU from its launch, or from the end of the batch it was queued behind
-            self._batch_time.update(batch.extend_num_tokens, t_done - max(t0, self._gpu_free_at))
+            owned = t_done - max(t0, self._gpu_free_at)
+            self._batch_time.update(batch.extend_num_tokens, owned)
+            # (t_forward_s below runs from the launch: for a batch queued behind a running one it includes the rest of THAT
+            #  batch -- up to `lead_s` -- which is not GPU time of this one; bench.py reports both)
+            self.stats["t_gpu_owned_s"] = self.stats.get("t_gpu_owned_s", 0.0) + owned
         self._gpu_free_at = t_done
         self.process_batch_result_prefill(batch, host_ids, logits_output)
         self.stats["t_forward_s"] = self.stats.get("t_forward_s", 0.0) + time.perf_counter() - t0

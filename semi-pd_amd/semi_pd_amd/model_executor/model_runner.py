@@ -560,6 +560,13 @@ class ModelRunner:
             # the runner has destroyed its capture stream and parked what lived on it (hip_graph_runner.py)
             from semi_pd_amd.model_executor.hip_graph_runner import recover_after_failed_capture
             recover_after_failed_capture(self.device)
+        # graph or eager is ONE decision for the whole tensor-parallel group: a rank that replays while another launches
+        # eagerly runs collectives with different payloads (padded vs raw batch) against each other and both wait for ever
+        from semi_pd_amd.distributed import all_ranks_agree
+        if not all_ranks_agree(self.graph_runner is not None) and self.graph_runner is not None:
+            logger.warning("decode hipGraphs dropped on rank %d: another tensor-parallel rank failed to capture", self.tp_rank)
+            self._unused_graph_runner = self.graph_runner      # (kept alive: its graphs own pool memory other tensors share)
+            self.graph_runner = None
 
     # ------------------------------------------------------------------------------------ forward
     @torch.no_grad()
@@ -590,6 +597,8 @@ class ModelRunner:
         than the deadline (semi_pd/step_pacer.py)."""
         from semi_pd_amd.semi_pd.step_pacer import StepPacer
         self.step_pacer = StepPacer(board, self.step_deadline_ms, self.device, slo_ms=self.tbt_slo_ms)
+        # bench.py's accounting of a prefill batch (roofline_extra.prefill_batch_ms): GPU time per layer from the hooks' events
+        self.step_pacer.time_layers = getattr(self, "kernel_timing", None) is not None
         n = 0
         for name, m in self.model.named_modules():
             if isinstance(m, nn.ModuleList) and name.split(".")[-1] == "layers":

@@ -481,10 +481,18 @@ def dense_gemm_import(text: str, shapes) -> int:
     check(lib.semipd_dense_gemm_import(text.encode(), _C.addressof(got)), "dense_gemm_import")
     if got.value:
         _DENSE_GEMM["ready"] = True
-        for n, k, dt in shapes:
-            for line in text.splitlines():
-                if f" n={int(n)} k={int(k)} " in line and line.startswith("cus="):
-                    _DENSE_GEMM["tuned"].add((int(line.split()[0][4:]), int(n), int(k), dt))
+        # what counts as tuned is what the C side HOLDS after the import (it skips a line whose solution does not validate or
+        # whose kernel name does not match this library build), read back through its own report -- not what the text says
+        want = {(int(n), int(k), dt) for n, k, dt in shapes}
+        codes = {dtype_code(dt): dt for dt in (torch.bfloat16, torch.float16)}
+        for line in dense_gemm_report().splitlines():
+            f = dict(kv.split("=", 1) for kv in line.split() if "=" in kv)
+            try:
+                key = (int(f["n"]), int(f["k"]), codes[int(f["dtype"])])
+                if key in want:
+                    _DENSE_GEMM["tuned"].add((int(f["cus"]),) + key)
+            except (KeyError, ValueError):
+                continue
     return int(got.value)
 
 

@@ -26,6 +26,10 @@ decode step that overlaps prefill work begin (STEP_SEQ / STEP_START_NS), so the 
 how many steps there were in all; every SLO_WINDOW steps it compares the share of token gaps above the objective (steps
 weighted by their batch size, BUSY_DECODE) with 1 % and moves the deadline by SLO_STEP_MS (twice that when far off) towards the point where the 99th
 percentile sits on the objective -- the latest deadline, i.e. the fewest and shortest holds, that still keeps the tail.
+The controller is BOUNDED around the deadline it was started with (MAX_TIGHTEN_MS below, MAX_RELAX_MS above): on the frontier of
+DESIGN.md 4.5 a millisecond of TBT tail costs ~4 ms of TTFT p50, and on a slow box an unbounded controller bought 0.3 ms of
+tail with 1.25 ms of deadline and ~5 ms of TTFT (BENCH_r05: 8.5 -> 7.25 ms in 100 adjustments); bounded, what it can trade
+is at most ~2 ms of TTFT.  Every adjustment is kept (stats()["deadline_trajectory"]) so that a run shows where it went.
 
 A hold is therefore an EMPTY prefill queue: the state between two prefill batches, in which the decode instance is known to
 run at full speed.  The late-binding loop of the prefill scheduler keeps working: the forward now returns RUN_AHEAD layers
@@ -46,6 +50,10 @@ SLO_WINDOW = 256        # decode steps per adjustment of the deadline (about 1.5
 SLO_STEP_MS = 0.25
 SLO_MARGIN_MS = 0.3     # the client's token gap is the step plus host work of the decode instance
 DEADLINE_RANGE_MS = (5.0, 16.0)
+# ... and the objective may move the deadline this far from the one the pacer was started with, no further
+MAX_TIGHTEN_MS = 0.5
+MAX_RELAX_MS = 2.0
+TRAJECTORY_KEEP = 64    # adjustments remembered for the statistics (first + the most recent ones)
 # Nothing can be asked of a decode step that it could not do alone: the deadline in force is at least FLOOR_DEADLINE times, the
 # objective at least FLOOR_SLO times the decode instance's fast step (STEP_FAST_NS: Llama-3-8B ~4.4 ms, DeepSeek-V2-Lite
 # ~8 ms -- with a fixed 8.5 ms every one of its steps would be "overdue" and the prefill instance held for nothing)
@@ -58,6 +66,12 @@ class StepPacer:
                  slo_ms: float = 0.0):
         self.board = board
         self.deadline_ns = int(deadline_ms * 1e6)
+        lo, hi = DEADLINE_RANGE_MS
+        # the controller's range: the absolute one, cut to [start - MAX_TIGHTEN_MS, start + MAX_RELAX_MS] (a start outside the
+        # absolute range stays where it was put: the range then is that single point's side of it)
+        self._range_ms = (min(deadline_ms, max(lo, deadline_ms - MAX_TIGHTEN_MS)), max(deadline_ms, min(hi, deadline_ms + MAX_RELAX_MS)))
+        self._trajectory = []             # (decode step number, deadline in ms) after every adjustment
+        self._gave_up = None              # (start, seq) of a step a hold timed out on: its owner is taken for dead
         self.slo_ns = int(max(0.0, slo_ms - SLO_MARGIN_MS) * 1e6) if slo_ms and slo_ms > 0 else 0
         self._seen = None                 # (start, seq, batch) of the step last seen in flight
         self._win = [0, 0.0, 0.0]         # this window: first seq, token gaps in all, token gaps above the objective
@@ -73,25 +87,40 @@ class StepPacer:
         self._ring = collections.deque()
         self._free = []
         self._stats = {"gates": 0, "holds": 0, "held_ms": 0.0, "timeouts": 0, "run_ahead_waits_ms": 0.0}
+        # time_layers (bench.py's accounting of a prefill batch; ModelRunner.init_step_pacer with kernel timing collected): the
+        # events of the run-ahead bound carry timestamps, and the GPU time between two consecutive hooks -- one decoder layer's
+        # kernels and the launch gaps inside it, plus the idle time of a hold at the first of the two -- is summed separately for
+        # intervals with and without a hold
+        self.time_layers = False
+        self._last_done = None            # (event, hook index, held at that hook) of the newest completed hook
+        self._held_at = set()             # hook indices of this forward at which a hold happened
+        self._layers = {"intervals": 0, "ms": 0.0, "held_intervals": 0, "held_interval_ms": 0.0}
 
     # ---- the hook ----------------------------------------------------------------------------------------------------
     def before_layer(self, index: int) -> None:
         st = self._stats
         st["gates"] += 1
         if index == 0:                       # a new forward: nothing of the previous one bounds this one
-            self._free.extend(self._ring)
+            self._free.extend(e for e, _ in self._ring)
             self._ring.clear()
-        self._bound_run_ahead()
+            if self._last_done is not None:
+                self._free.append(self._last_done[0])
+                self._last_done = None
+            self._held_at.clear()
+        self._bound_run_ahead(index)
+        holds = self._stats["holds"]
         self._hold_while_overdue()
+        if self.time_layers and self._stats["holds"] != holds:
+            self._held_at.add(index)
 
-    def _bound_run_ahead(self) -> None:
+    def _bound_run_ahead(self, index: int = 0) -> None:
         if self.run_ahead <= 0 or self.device is None or torch.device(self.device).type != "cuda":
             return
-        ev = self._free.pop() if self._free else torch.cuda.Event()
+        ev = self._free.pop() if self._free else torch.cuda.Event(enable_timing=self.time_layers)
         ev.record()                          # everything launched so far = the layers before this hook
-        self._ring.append(ev)
+        self._ring.append((ev, index))
         if len(self._ring) > self.run_ahead:
-            old = self._ring.popleft()
+            old, old_index = self._ring.popleft()
             if not old.query():
                 t0 = time.perf_counter()
                 if self.while_waiting is None:
@@ -101,7 +130,23 @@ class StepPacer:
                         self.while_waiting()
                         time.sleep(20e-6)
                 self._stats["run_ahead_waits_ms"] += (time.perf_counter() - t0) * 1e3
-            self._free.append(old)
+            if not self.time_layers:
+                self._free.append(old)
+                return
+            prev = self._last_done
+            if prev is not None and prev[1] + 1 == old_index:
+                # hook prev -> hook old: layer `prev[1]` on the GPU (+ the idle time of a hold at hook prev[1])
+                dt = prev[0].elapsed_time(old)
+                acc = self._layers
+                if prev[1] in self._held_at:
+                    acc["held_intervals"] += 1
+                    acc["held_interval_ms"] += dt
+                else:
+                    acc["intervals"] += 1
+                    acc["ms"] += dt
+            if prev is not None:
+                self._free.append(prev[0])
+            self._last_done = (old, old_index)
 
     def _hold_while_overdue(self) -> None:
         if self.board is None or self.deadline_ns <= 0 or not self.hold_enabled:
@@ -111,7 +156,15 @@ class StepPacer:
             self._observe(start, seq)
         if not start:
             return
+        if self._gave_up is not None:
+            # a hold on this very stamp ran into MAX_WAIT_MS: the decode instance died or hangs with a step published.  One
+            # timeout is the price; every later layer passes until the stamp changes (32 layers x 50 ms per batch otherwise)
+            if self._gave_up == (start, seq):
+                return
+            self._gave_up = None
         t0 = self._clock()
+        if self._decode_silent(t0):
+            return
         fast = self.board.fast_step_ns()
         if t0 - start < max(self.deadline_ns, int(FLOOR_DEADLINE * fast)):
             return
@@ -128,8 +181,20 @@ class StepPacer:
             now = self._clock()
             if (now - t0) > MAX_WAIT_MS * 1e6:
                 st["timeouts"] += 1
+                self._gave_up = (start, seq)
                 break
         st["held_ms"] += (now - t0) / 1e6
+
+    def _decode_silent(self, now_ns: int) -> bool:
+        """The decode instance's heartbeat (BEAT_DECODE, written with every step it publishes) is older than the board's
+        staleness bound: whatever STEP_START_NS says, no step of a live instance is in flight (share_board.peer_busy applies
+        the same rule to BUSY_DECODE)."""
+        from semi_pd_amd.semi_pd.share_board import BEAT_DECODE
+        stale = getattr(self.board, "stale_ns", 0)
+        if not stale:
+            return False
+        beat = self.board.load(BEAT_DECODE)
+        return bool(beat) and now_ns - beat > stale
 
     # ---- the deadline follows the objective ------------------------------------------------------------------------
     def _observe(self, start: int, seq: int) -> None:
@@ -153,12 +218,15 @@ class StepPacer:
             batch = self._seen[2] if self._seen else max(1, self.board.load(BUSY_DECODE))
             total = max(1.0, steps * float(batch))
             over = self._win[2] / total
-            lo, hi = DEADLINE_RANGE_MS
+            lo, hi = self._range_ms
             # down by one step while more than 1 % of the gaps exceed the objective (two steps from 2.5 %), up by half a step
             d = self.deadline_ns / 1e6 + (-2 * SLO_STEP_MS if over > 0.025 else -SLO_STEP_MS if over > 0.01 else SLO_STEP_MS / 2)
             self.deadline_ns = int(min(hi, max(lo, d)) * 1e6)
             self._stats["slo_adjustments"] = self._stats.get("slo_adjustments", 0) + 1
             self._stats["share_of_gaps_over_slo"] = round(over, 4)
+            self._trajectory.append((int(seq), round(self.deadline_ns / 1e6, 3)))
+            if len(self._trajectory) > TRAJECTORY_KEEP:
+                del self._trajectory[1]      # keep the first adjustment and the most recent ones
             self._win = [seq, 0.0, 0.0]
 
     # ---- statistics --------------------------------------------------------------------------------------------------
@@ -167,8 +235,21 @@ class StepPacer:
         out["held_ms"] = round(out["held_ms"], 3)
         out["run_ahead_waits_ms"] = round(out["run_ahead_waits_ms"], 3)
         out["deadline_ms"] = round(self.deadline_ns / 1e6, 3)
+        if self.slo_ns:
+            out["deadline_range_ms"] = [round(self._range_ms[0], 3), round(self._range_ms[1], 3)]
+            out["deadline_trajectory"] = [list(x) for x in self._trajectory]
+        if self.time_layers and self._layers["intervals"]:
+            a = self._layers
+            out["layer_ms_without_hold"] = round(a["ms"] / a["intervals"], 4)
+            out["layer_intervals_timed"] = a["intervals"]
+            if a["held_intervals"]:
+                out["layer_ms_with_hold"] = round(a["held_interval_ms"] / a["held_intervals"], 4)
+                out["layer_intervals_with_hold"] = a["held_intervals"]
         return out
 
     def reset_stats(self) -> None:
         for k in list(self._stats):
             self._stats[k] = 0 if isinstance(self._stats[k], int) else 0.0
+        self._trajectory = []
+        self._layers = {"intervals": 0, "ms": 0.0, "held_intervals": 0, "held_interval_ms": 0.0}
+        self._layers = {"intervals": 0, "ms": 0.0, "held_intervals": 0, "held_interval_ms": 0.0}

@@ -99,7 +99,11 @@ class ServerArgs:
     def __post_init__(self):
         if self.cu_mask_mode not in CU_MASK_MODES:
             raise ValueError(f"cu_mask_mode must be one of {CU_MASK_MODES}, got {self.cu_mask_mode!r}")
-        paced = self.enable_semi_pd and self.cu_mask_mode == "dynamic"
+        # (one GPU per instance only: under tensor parallelism every rank would hold on its own GPU's board while the other
+        #  ranks have already launched the layer's peer-memory all-reduce, whose blocks then spin next to the decode instance
+        #  the hold is meant to relieve; a rank-0 decision broadcast per layer -- as CuShare.decide does per forward -- is
+        #  not built, so tp_size > 1 runs the static frontier point)
+        paced = self.enable_semi_pd and self.cu_mask_mode == "dynamic" and self.tp_size == 1
         if self.decode_step_deadline_ms is None:
             self.decode_step_deadline_ms = DEFAULT_DECODE_STEP_DEADLINE_MS if paced else 0.0
             if self.decode_tbt_slo_ms is None:
@@ -110,8 +114,16 @@ class ServerArgs:
             raise ValueError("decode_step_deadline_ms must be >= 0 (0 = no deadline)")
         if self.decode_tbt_slo_ms < 0 or (self.decode_tbt_slo_ms > 0 and self.decode_step_deadline_ms <= 0):
             raise ValueError("decode_tbt_slo_ms adapts decode_step_deadline_ms: give a positive starting deadline with it")
+        if self.decode_step_deadline_ms > 0 and self.enable_semi_pd and self.tp_size > 1:
+            raise ValueError("decode_step_deadline_ms is for tp_size 1: the ranks of a tensor-parallel prefill instance have no "
+                             "agreement on a hold (each would wait on its own GPU's board inside a layer whose all-reduce the "
+                             "others have launched)")
         if self.decode_step_deadline_ms > 0 and self.enable_semi_pd and self.cu_mask_mode != "dynamic":
             raise ValueError("decode_step_deadline_ms needs --cu-mask-mode dynamic (the instances meet on the share board)")
+        if self.enable_semi_pd and self.cu_mask_mode == "dynamic" and self.tp_size > 1 and self.disable_custom_all_reduce:
+            raise ValueError("--disable-custom-all-reduce with --cu-mask-mode dynamic and tp_size > 1: the backend's collectives "
+                             "run on their own unmasked stream and would leave the instance's CU share; use --cu-mask-mode "
+                             "env or none with it")
         if self.prefill_backlog_full_tokens < 0:
             raise ValueError("prefill_backlog_full_tokens must be >= 0 (0 = never take every CU because of the backlog)")
         for name in ("prefill_cu_percent", "decode_cu_percent"):
@@ -203,13 +215,14 @@ def add_cli_args(parser):
     p.add_argument("--cuda-graph-max-bs", type=int, default=256)
     p.add_argument("--enable-semi-pd", action="store_true", help="prefill and decode instance on the same GPUs")
     p.add_argument("--prefill-cu-percent", type=int, default=PREFILL_ENGINE_SM_PERCENTILE,
-                   help="share of the CUs given to the prefill instance (SEMI_PD_PREFILL_SM_PERCENTILE)")
+                   help="share of the CUs given to the prefill instance (SEMI_PD_PREFILL_SM_PERCENTILE).  Default 88 (224 of 256 "
+                        "CUs; the reference's MPS default is 80): shares come in whole groups of 32 CUs, 80 would be 192")
     p.add_argument("--decode-cu-percent", type=int, default=DECODE_ENGINE_SM_PERCENTILE,
                    help="share of the CUs given to the decode instance (SEMI_PD_DECODE_SM_PERCENTILE)")
     p.add_argument("--cu-mask-mode", type=str, default="dynamic", choices=list(CU_MASK_MODES),
                    help="how the shares are enforced: dynamic = unmasked processes, a CU-masked stream per instance, every CU "
-                        "while the other instance is idle (the measured default); env = static HSA_CU_MASK per process; "
-                        "none = no mask")
+                        "while the other instance is idle (the measured default; the reference's shares are static: env); "
+                        "env = static HSA_CU_MASK per process; none = no mask.  dynamic refuses --*-stream-priority")
     p.add_argument("--prefill-backlog-full-tokens", type=int, default=8192,
                    help="dynamic mode: waiting prompt tokens from which a prefill batch takes every CU (0 = never)")
     p.add_argument("--prefill-stream-priority", type=int, default=0, choices=[-1, 0, 1],
@@ -218,10 +231,12 @@ def add_cli_args(parser):
                    help="HIP stream priority of the decode instance (env / none modes; -1 = high)")
     p.add_argument("--decode-step-deadline-ms", type=float, default=None,
                    help="a decode step older than this makes the prefill instance yield at its next layer boundary until the "
-                        "step is over (0 = off)")
+                        f"step is over (0 = off).  Default: {DEFAULT_DECODE_STEP_DEADLINE_MS} with --cu-mask-mode dynamic and --tp-size 1 "
+                        "(no reference counterpart), off otherwise; refused with --tp-size > 1")
     p.add_argument("--decode-tbt-slo-ms", type=float, default=None,
                    help="with --decode-step-deadline-ms: adapt the deadline so that the 99th percentile of the time between tokens "
-                        "meets this objective (0 = keep the deadline fixed)")
+                        f"meets this objective (0 = keep the deadline fixed).  Default {DEFAULT_DECODE_TBT_SLO_MS} with the default "
+                        "deadline; the deadline moves at most 0.5 ms down / 2 ms up from where it started")
     p.add_argument("--k-split-by-share", action="store_true",
                    help="decode-sized GEMMs: K split sized for the instance's CU share instead of the device (faster on small "
                         "static shares; gives up bit-equal sums between the instances)")

@@ -14,6 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 class FakeEngine:
     instances = []
+    diverge = {}      # (enable_semi_pd, cu_mask_mode) -> (request, step, token) at which that engine's tokens part
+    gap = 0.02        # the unified engine's top-2 log-probability gap at every step
 
     def __init__(self, server_args, local_tp_ranks=None, gpu_ids=None, ready_timeout=0.0):
         self.sa = server_args
@@ -35,6 +37,20 @@ class FakeEngine:
     def poll(self, timeout=0.0):
         return False
 
+    def generate(self, prompts, sampling_params, timeout=0.0, return_logprob=False, top_logprobs_num=0):
+        # every engine "generates" the same tokens; the Semi-PD engine of the static split parts from the unified one at a
+        # near-tie of request 1, step 2 (scripted through FakeEngine.diverge)
+        n = sampling_params.max_new_tokens
+        outs = [[(7 * i + j) % 100 for j in range(n)] for i in range(len(prompts))]
+        div = FakeEngine.diverge.get((self.sa.enable_semi_pd, self.sa.cu_mask_mode))
+        if div:
+            i, st, tok = div
+            outs[i][st:] = [tok] * (n - st)
+        if not return_logprob:
+            return outs
+        lps = [{"token": [-0.1] * n, "top": [[(-0.10, o[j]), (-0.10 - FakeEngine.gap, 99)] for j in range(n)]} for o in outs]
+        return outs, lps
+
     def check_children(self):
         pass
 
@@ -51,7 +67,10 @@ class FakeEngine:
                  "t_output_s": 0.09, "kernel_timing": kt},
                 {"role": "PREFILL", "prefill_batches": 568, "prefill_tokens": 786432, "prefill_reqs": 768,
                  "t_wait_admission_s": 0.12, "t_forward_s": 16.9, "late_bound_launches": 287,
-                 "results_sent_from_layer_hook": 271, "kernel_timing": {}}]
+                 "results_sent_from_layer_hook": 271, "kernel_timing": {}, "t_gpu_owned_s": 14.2,
+                 "step_gate": {"gates": 18176, "holds": 900, "held_ms": 1420.0, "timeouts": 0, "run_ahead_waits_ms": 9000.0,
+                               "deadline_ms": 8.25, "deadline_range_ms": [8.0, 10.5], "deadline_trajectory": [[300, 8.25]],
+                               "layer_ms_without_hold": 0.62, "layer_intervals_timed": 17000}}]
 
     def shutdown(self):
         pass
@@ -72,6 +91,8 @@ def test_the_bench_line_is_assembled_with_every_contract_field(monkeypatch, caps
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         monkeypatch.delenv(k, raising=False)
     FakeEngine.instances.clear()
+    FakeEngine.diverge = {(True, "env"): (1, 2, 99)}     # the 50 / 50 engine takes the unified engine's runner-up once
+    FakeEngine.gap = 0.02
     bench.main()
     line = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
@@ -89,6 +110,12 @@ def test_the_bench_line_is_assembled_with_every_contract_field(monkeypatch, caps
     assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], abs=1e-4) and "stream_gemm_glds_kernel" in r["kernel"]
     pb = d["roofline_extra"]["prefill_batch_ms"]
     assert pb["launched_behind_a_running_batch"] == 287 and pb["results_sent_from_layer_hook"] == 271 and pb["batches"] == 568
+    # where a batch's GPU time goes: owned = layers (no hold) + held + the rest; the host's waits are listed apart
+    assert pb["gpu_owned"] == pytest.approx(25.0, abs=0.01) and pb["held"] == pytest.approx(2.5, abs=0.01)
+    nl = 32 if expect_static else 27
+    assert pb["layers_without_hold"] == pytest.approx(nl * 0.62, abs=0.01)
+    assert pb["outside_layers"] == pytest.approx(25.0 - 2.5 - nl * 0.62, abs=0.02) and pb["pacer_wait_host"] > 0
+    assert pb["step_gate"]["deadline_trajectory"] == [[300, 8.25]] and pb["step_gate"]["deadline_range_ms"] == [8.0, 10.5]
     assert d["roofline_extra"]["extend_attention"]["bound"] == "mfma"
     cfgd = d["config"]
     assert "workload" in cfgd and "model" not in cfgd and "CU-masked stream" in cfgd["workload"] and "50 / 50" in cfgd["workload"]
@@ -107,11 +134,24 @@ def test_the_bench_line_is_assembled_with_every_contract_field(monkeypatch, caps
         assert cfgd["decode_step_deadline_ms"] == bench.DEFAULT_DEADLINE_MS
         assert d["config1_opt_125m"]["output_tok_s"] > 0 and d["config3_deepseek_v2_lite"]["output_tok_s"] > 0
         assert [s["request_rate"] for s in d["qps_sweep"]] == [8.0, 32.0] and d["qps_sweep"][0]["output_len"] == 6
+        # the same grid through the unified engine, and the goodput of both under the objectives the config names
+        assert [s["request_rate"] for s in d["qps_sweep_unified"]] == [8.0, 32.0]
+        assert all(s["meets_slo_itl"] and s["meets_slo_tpot"] and s["p99_tpot_ms"] == pytest.approx(8.0, abs=0.5) for s in d["qps_sweep"])
+        assert d["goodput"] == {"unit": "requests/s", "rates": [8.0, 32.0], "semi_pd": {"itl": 32.0, "tpot": 32.0},
+                                "unified": {"itl": 32.0, "tpot": 32.0}} and d["goodput_req_s"] == 32.0
+        assert cfgd["slo"]["p99_ttft_ms"] == bench.SLO_TTFT_P99_MS and cfgd["slo"]["itl"]["p99_tbt_ms"] == bench.SLO_ITL_P99_MS
+        assert d["unified_same_load"]["saturation"]["output_tokens"] == 6 * 4
+        # the token check: both Semi-PD engines against the unified engine's tokens; the scripted near-tie is accepted as one
+        tc = d["token_check"]
+        assert tc["ok"] and [c["engine"] for c in tc["engines"]] == ["semi-pd", "semi-pd 50/50"]
+        assert tc["engines"][0]["equal_requests"] == 4 and tc["engines"][0]["near_tie_divergences"] == []
+        assert tc["engines"][1]["equal_requests"] == 3
+        assert tc["engines"][1]["near_tie_divergences"] == [{"request": 1, "step": 2, "top2_logprob_gap": 0.02}]
         assert d["saturation"]["output_tokens"] == 6 * 4
         assert d["steps"] == 2 and d["warmup"] == 1
     else:
         assert (cfgd["prefill_cu_percent"], cfgd["decode_cu_percent"]) == (bench.DEFAULT_PREFILL_CU, 100)
-        assert "saturation" not in d and "qps_sweep" not in d and "config1_opt_125m" not in d
+        assert "saturation" not in d and "qps_sweep" not in d and "config1_opt_125m" not in d and "goodput" not in d
         assert "mla_decode_kernel" in d["roofline_extra"]["decode_attention"]["kernel"]
 
 
@@ -152,3 +192,30 @@ def test_cpu_baseline_runs_the_full_depth_on_a_small_model():
     # a budget no probe can meet: one request instead of two, still the whole depth
     one = bench.cpu_baseline(cfg, input_len=48, output_len=8, budget_s=0.0)
     assert "1 request(s)" in one["sample"] and "all 5 layers executed" in one["sample"]
+
+
+def test_a_token_divergence_that_is_no_near_tie_fails_the_run(monkeypatch, capsys):
+    """bench_one_batch.py:16-41 keeps a known-answer probe for the engine it times; here the timed Semi-PD engine's first
+    tokens must be the unified engine's up to near-ties: a clear divergence prints the line, names it and exits non-zero."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from semi_pd_amd.entrypoints import engine as engine_mod
+    monkeypatch.setattr(engine_mod, "Engine", FakeEngine)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--num-requests", "4", "--input-len", "16", "--output-len", "4", "--steps", "1",
+                                      "--warmup", "0", "--no-cpu-baseline", "--request-rate", "500", "--no-saturation-wave",
+                                      "--no-static-split-wave", "--no-side-configs", "--rate-sweep", ""])
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    FakeEngine.instances.clear()
+    FakeEngine.diverge = {(True, "dynamic"): (2, 1, 99)}
+    FakeEngine.gap = 0.9                                  # the unified engine was sure of its token
+    try:
+        with pytest.raises(SystemExit) as ex:
+            bench.main()
+    finally:
+        FakeEngine.diverge, FakeEngine.gap = {}, 0.02
+    assert ex.value.code == 3
+    cap = capsys.readouterr()
+    d = json.loads([ln for ln in cap.out.splitlines() if ln.startswith("{")][-1])
+    assert d["token_check"]["ok"] is False and "request 2 step 1" in d["token_check"]["engines"][0]["errors"][0]
+    assert "token check FAILED" in cap.err

@@ -575,6 +575,37 @@ def test_extend_attention_custom_mask(ops, device, pre, ext, Hq, Hkv, Dk, Dv, ca
     _close(o, want, dtype, rtol=2e-2, atol=4e-3 if dtype == torch.float16 else 1.5e-2)
 
 
+@pytest.mark.parametrize("Hq,Hkv,Dk,Dv", [(4, 2, 128, 128), (2, 1, 80, 13)])   # the tile kernel | the one-wave kernel
+def test_extend_attention_fully_masked_row_is_nan_on_every_route(ops, device, Hq, Hkv, Dk, Dv):
+    """A query whose every key the custom mask removes gets NaN -- the reference's kernel computes exp(-inf - -inf) in its
+    rescale (triton_ops/extend_attention.py:233-262), the oracle's softmax of an all -inf row is NaN too, and both HIP
+    routes agree (the tile kernel wrote 0 where the one-wave kernel wrote NaN); the other rows are untouched."""
+    dtype = torch.bfloat16
+    pre, ext = [0, 3], [9, 6]
+    g = torch.Generator().manual_seed(31)
+    B, T = len(pre), sum(ext)
+    k_buf, v_buf, kv_indptr, kv_indices = _paged(B, pre, Hkv, Dk, Dv, dtype, seed=9)
+    q, k, v = (torch.randn(T, h, d, generator=g).to(dtype) for h, d in ((Hq, Dk), (Hkv, Dk), (Hkv, Dv)))
+    qo = torch.zeros(B + 1, dtype=torch.int32)
+    qo[1:] = torch.cumsum(torch.tensor(ext), 0)
+    blocks = [torch.cat([torch.ones(e, p, dtype=torch.bool), torch.tril(torch.ones(e, e, dtype=torch.bool))], 1) for p, e in zip(pre, ext)]
+    blocks[0][4, :] = False          # sequence 0 has no prefix: row 4 sees nothing at all
+    blocks[1][2, :] = False          # sequence 1: row 2 loses its prefix bits too (skip_prefix_custom_mask = False)
+    indptr = torch.zeros(B + 1, dtype=torch.int64)
+    indptr[1:] = torch.cumsum(torch.tensor([b.numel() for b in blocks]), 0)
+    mask = torch.cat([b.flatten() for b in blocks])
+    o = torch.zeros(T, Hq, Dv, dtype=dtype, device=device)
+    ops.extend_attention_fwd(q.to(device), k.to(device), v.to(device), o, k_buf.to(device), v_buf.to(device), qo.to(device),
+                             kv_indptr.to(device), kv_indices.to(device), mask.to(device), indptr.to(device), max(ext),
+                             Dk ** -0.5, 0.0, False)
+    want = O.extend_attention(q, k, v, k_buf, v_buf, qo, kv_indptr, kv_indices, Dk ** -0.5, 0.0, mask, indptr, False)
+    dead = [4, ext[0] + 2]
+    assert torch.isnan(want[dead]).all() and torch.isnan(o[dead].float()).all()
+    live = [i for i in range(T) if i not in dead]
+    assert not torch.isnan(o[live].float()).any()
+    _close(o[live], want[live], dtype, rtol=2e-2, atol=1.5e-2)
+
+
 def test_extend_attention_custom_mask_properties(ops, device):
     """Size-independent properties at Llama-3-8B heads: (1) the mask that spells the default out (prefix ones + the
     causal triangle) gives what the unmasked launch gives; (2) with skip_prefix_custom_mask the prefix bits are not read
@@ -1265,8 +1296,15 @@ def test_dense_gemm_with_measured_library_solution_matches_fp32(ops, device):
     cur = int(re.match(r"cus=(\d+) ", mine).group(1))      # whatever share this process last declared
     moved = re.sub(r"^cus=\d+ ", "cus=77 ", mine, flags=re.M)
     assert ops.dense_gemm_import(moved + "garbage line\ncus=77 dtype=1 n=768 k=512 rows=64 solution=-3 us=1 library_choice_us=1 "
-                                 "candidates=1 wrong_results_rejected=0\n", [(768, 512, torch.bfloat16)]) == 4
+                                 "candidates=1 wrong_results_rejected=0\n"
+                                 "cus=77 dtype=1 n=1024 k=512 rows=64 solution=-3 us=1 library_choice_us=1 candidates=1 "
+                                 "wrong_results_rejected=0\n", [(768, 512, torch.bfloat16), (1024, 512, torch.bfloat16)]) == 4
     assert "cus=77 " in ops.dense_gemm_report()
+    # tuned = what the C side took: the shape whose only line it refused is NOT routed to ops.dense_gemm, and the
+    # f16 lines that were taken do not mark a dtype nobody asked for
+    from semi_pd_amd.ops import _DENSE_GEMM
+    assert (77, 768, 512, torch.bfloat16) in _DENSE_GEMM["tuned"] and (77, 1024, 512, torch.bfloat16) not in _DENSE_GEMM["tuned"]
+    assert (77, 768, 512, torch.float16) not in _DENSE_GEMM["tuned"]
     try:
         _lib.check(lib.semipd_dense_gemm_set_cus(77), "set_cus")
         x = torch.randn(256, 512, generator=g).to(torch.bfloat16).to(device)

@@ -75,6 +75,12 @@ def test_the_hook_passes_holds_and_times_out(boards):
     pacer.before_layer(4)
     st = pacer.stats()
     assert st["holds"] == 2 and st["timeouts"] == 1 and SP.MAX_WAIT_MS <= st["held_ms"] - 2.0 <= SP.MAX_WAIT_MS + 1.0, st
+    # ... and ONE timeout is the price: the later layers of this and every following forward pass at once while that stamp
+    # stands (32 layers x 50 ms per batch otherwise)
+    n = t.sleeps
+    for layer in range(5, 40):
+        pacer.before_layer(layer % 32)
+    assert t.sleeps == n and pacer.stats()["holds"] == 2 and pacer.stats()["timeouts"] == 1
     # a step that merely ENDS (no successor) releases a hold as well
     d.publish_step(t.ns - 9_000_000)
     t.on_sleep = lambda ft: d.publish_step(0)
@@ -113,18 +119,28 @@ def test_the_deadline_follows_the_objective(boards):
     st = pacer.stats()
     assert st["slo_adjustments"] == 1 and st["share_of_gaps_over_slo"] == pytest.approx(0.05, abs=0.01)
     assert st["deadline_ms"] == pytest.approx(9.0 - 2 * SP.SLO_STEP_MS)
-    # 1 in 60: 1.7 % -> one step
-    run_window(60)
-    assert pacer.stats()["deadline_ms"] == pytest.approx(9.0 - 3 * SP.SLO_STEP_MS)
-    # no long steps: it creeps back up (half a step), and stays inside its range
+    # no long steps: it creeps back up (half a step)
     run_window(0)
-    assert pacer.stats()["deadline_ms"] == pytest.approx(9.0 - 2.5 * SP.SLO_STEP_MS)
+    assert pacer.stats()["deadline_ms"] == pytest.approx(9.0 - 1.5 * SP.SLO_STEP_MS)
+    # 1 in 60: 1.7 % -> one step down
+    run_window(60)
+    assert pacer.stats()["deadline_ms"] == pytest.approx(max(9.0 - 2.5 * SP.SLO_STEP_MS, 9.0 - SP.MAX_TIGHTEN_MS))
+    # the controller is bounded around the deadline it was started with: what it may trade is a bounded amount of TTFT
     for _ in range(80):
         run_window(0)
-    assert pacer.stats()["deadline_ms"] == SP.DEADLINE_RANGE_MS[1]
+    assert pacer.stats()["deadline_ms"] == pytest.approx(9.0 + SP.MAX_RELAX_MS)
     for _ in range(80):
         run_window(2)
-    assert pacer.stats()["deadline_ms"] == SP.DEADLINE_RANGE_MS[0]
+    st = pacer.stats()
+    assert st["deadline_ms"] == pytest.approx(9.0 - SP.MAX_TIGHTEN_MS)
+    assert st["deadline_range_ms"] == [pytest.approx(9.0 - SP.MAX_TIGHTEN_MS), pytest.approx(9.0 + SP.MAX_RELAX_MS)]
+    # every adjustment is on record (bounded: the first one and the most recent ones), as (decode step number, deadline)
+    traj = st["deadline_trajectory"]
+    assert 2 <= len(traj) <= SP.TRAJECTORY_KEEP and traj[0][1] == pytest.approx(9.0 - 2 * SP.SLO_STEP_MS)
+    assert traj[-1][1] == st["deadline_ms"] and all(a[0] < b[0] for a, b in zip(traj, traj[1:]))
+    # a start at the edge of the absolute range stays inside it
+    edge = SP.StepPacer(p, deadline_ms=SP.DEADLINE_RANGE_MS[0], device=None, clock=t.clock, sleep=t.sleep, slo_ms=12.0)
+    assert edge.stats()["deadline_range_ms"][0] == SP.DEADLINE_RANGE_MS[0]
     # without an objective the deadline is what was given
     fixed = SP.StepPacer(p, deadline_ms=9.0, device=None, clock=t.clock, sleep=t.sleep)
     run = fixed.stats()["deadline_ms"]
@@ -159,6 +175,34 @@ def test_nothing_is_asked_of_a_step_that_it_could_not_do_alone(boards):
     t.on_sleep = lambda ft: d.publish_step(ft.ns)
     pacer.before_layer(2)
     assert pacer.stats()["holds"] == 2
+
+
+def test_a_silent_decode_instance_holds_nobody(boards):
+    """A decode instance that died with a step published: its heartbeat (BEAT_DECODE, refreshed with every step) goes stale and
+    the hooks stop holding for its stamp -- share_board.peer_busy's rule for BUSY_DECODE, applied to STEP_START_NS."""
+    from semi_pd_amd.semi_pd.share_board import BEAT_DECODE
+    d, p = boards
+    t = FakeTime()
+    pacer = SP.StepPacer(p, deadline_ms=8.0, device=None, clock=t.clock, sleep=t.sleep)
+    d.store(BEAT_DECODE, t.ns - 3_000_000_000)          # last heard of 3 s ago (stale_s = 2)
+    d.publish_step(t.ns - 20_000_000)
+    pacer.before_layer(0)
+    assert pacer.stats()["holds"] == 0 and t.sleeps == 0
+    d.store(BEAT_DECODE, t.ns - 1_000_000)              # alive: the same stamp holds
+    t.on_sleep = lambda ft: d.publish_step(ft.ns)
+    pacer.before_layer(1)
+    assert pacer.stats()["holds"] == 1 and pacer.stats()["timeouts"] == 0
+
+
+def test_the_pacer_is_off_under_tensor_parallelism():
+    """every rank would hold on its own board with no agreement while the others have launched the layer's
+    peer-memory all-reduce.  Until a rank-0 decision is broadcast (as CuShare.decide does for the share), tp_size > 1 runs
+    without the deadline; asking for one is refused."""
+    from semi_pd_amd.server_args import ServerArgs
+    a = ServerArgs(enable_semi_pd=True, tp_size=2)
+    assert (a.decode_step_deadline_ms, a.decode_tbt_slo_ms) == (0.0, 0.0)
+    with pytest.raises(ValueError, match="tp_size"):
+        ServerArgs(enable_semi_pd=True, tp_size=2, decode_step_deadline_ms=8.5)
 
 
 def test_the_decode_scheduler_publishes_its_fast_step(boards, monkeypatch):

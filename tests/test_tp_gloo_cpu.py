@@ -294,3 +294,190 @@ def test_rendezvous_of_the_tp_groups_under_a_torchrun_environment(monkeypatch):
     monkeypatch.setenv("TORCHELASTIC_RESTART_COUNT", "0")
     res = _spawn("_just_rendezvous", timeout=60)
     assert res == {0: 3.0, 1: 3.0}
+
+
+# ------------------------------------------------------------------------------ rank-divergent host state
+def _divergent_host_state(rank, world):
+    """Every rank gets host state the other does not have -- rank 1's hipGraph capture fails, rank 0's kernel-timing sample list
+    is full and never drained -- and then both run the SAME 24 decode steps through ModelRunner.forward.  Returns the path
+    ("graph" / "eager") each step took."""
+    from types import SimpleNamespace
+    from semi_pd_amd.model_executor import hip_graph_runner as HG
+    from semi_pd_amd.model_executor import model_runner as MR
+    from semi_pd_amd.model_executor.forward_batch_info import ForwardMode
+    from semi_pd_amd.model_executor.kernel_timing import KernelTiming
+
+    class Runner:
+        def __init__(self, mr):
+            if rank == 1:
+                raise RuntimeError("this rank's collective refused stream capture")
+
+        def can_run(self, fb):
+            return True
+
+        def replay(self, fb):
+            return "graph"
+
+    HG.HipGraphRunner = Runner
+    HG.recover_after_failed_capture = lambda device: None
+    mr = MR.ModelRunner.__new__(MR.ModelRunner)
+    mr.disable_cuda_graph, mr.cu_share, mr.tp_size, mr.tp_rank, mr.device = False, None, world, rank, "cpu"
+    mr.graph_runner = None
+    mr.init_cuda_graphs()
+    mr.forward_decode = lambda fb: "eager"
+    mr.kernel_timing = KernelTiming(sample_every=4, max_pending=8)
+    if rank == 0:
+        mr.kernel_timing._pending = [None] * 8          # nobody collects this rank's samples
+    fb = SimpleNamespace(forward_mode=ForwardMode.DECODE, batch_size=3)
+    return {"graphs": mr.graph_runner is not None, "paths": [mr.forward(fb) for _ in range(24)]}
+
+
+def _all_captures_succeed(rank, world):
+    from types import SimpleNamespace
+    from semi_pd_amd.model_executor import hip_graph_runner as HG
+    from semi_pd_amd.model_executor import model_runner as MR
+    from semi_pd_amd.model_executor.forward_batch_info import ForwardMode
+
+    class Runner:
+        def __init__(self, mr):
+            pass
+
+        def can_run(self, fb):
+            return True
+
+        def replay(self, fb):
+            return "graph"
+
+    HG.HipGraphRunner = Runner
+    mr = MR.ModelRunner.__new__(MR.ModelRunner)
+    mr.disable_cuda_graph, mr.cu_share, mr.tp_size, mr.tp_rank, mr.device = False, None, world, rank, "cpu"
+    mr.graph_runner = None
+    mr.init_cuda_graphs()
+    mr.forward_decode = lambda fb: "eager"
+    from semi_pd_amd.model_executor.kernel_timing import KernelTiming
+    mr.kernel_timing = KernelTiming(sample_every=4, max_pending=8)
+    if rank == 0:
+        mr.kernel_timing._pending = [None] * 8          # a full sample list on ONE rank: it samples the same steps anyway
+    fb = SimpleNamespace(forward_mode=ForwardMode.DECODE, batch_size=3)
+    return {"graphs": mr.graph_runner is not None, "paths": [mr.forward(fb) for _ in range(24)]}
+
+
+def test_ranks_with_divergent_host_state_take_the_same_path():
+    """The class of bug commit 19e5420 fixed (an N = 2 run hung after ~8 k steps: one rank sampled a step eagerly while the
+    other replayed its graph, and the logits all-gather of the two paths has different block counts): whatever only ONE rank
+    knows -- a failed capture, a sample list nobody drains -- must not choose between launch sequences.  Reference: the
+    ranks of a TP group share every scheduling input by broadcast (managers/scheduler.py:645-659); here the start-up state
+    is agreed on the CPU group as well (distributed.all_ranks_agree)."""
+    res = _spawn("_divergent_host_state")
+    assert res[0]["paths"] == res[1]["paths"], (res[0]["paths"], res[1]["paths"])
+    assert not res[0]["graphs"] and not res[1]["graphs"]             # one failed capture: nobody replays
+    assert set(res[0]["paths"]) == {"eager"}
+    ok = _spawn("_all_captures_succeed")
+    want = ["eager" if (i + 1) % 4 == 0 else "graph" for i in range(24)]    # every 4th step is a sampled (eager) one
+    assert ok[0]["graphs"] and ok[1]["graphs"] and ok[0]["paths"] == ok[1]["paths"] == want
+
+
+# ------------------------------------------------------------------------------ confined all-reduce: no fall-through
+def _confined_reduce(rank, world):
+    """distributed._confined_all_reduce with a stand-in for the peer-memory communicator (it sums over gloo and, like the real
+    one, takes only contiguous 16-byte multiples up to max_size): odd shapes go through the staging buffer, big ones in pieces,
+    the backend's own all-reduce is never called."""
+    import torch.distributed as dist
+    from semi_pd_amd import distributed as D
+    backend_all_reduce = dist.all_reduce
+
+    class FakeAR:
+        max_size, disabled = 256, False
+        calls = []
+
+        def should_custom_ar(self, t):
+            size = t.numel() * t.element_size()
+            return t.dtype in (torch.float32, torch.bfloat16, torch.float16) and size > 0 and size % 16 == 0 \
+                and t.is_contiguous() and size <= self.max_size
+
+        def too_big_only(self, t):
+            size = t.numel() * t.element_size()
+            return t.dtype in (torch.float32, torch.bfloat16, torch.float16) and size > self.max_size and size % 16 == 0 \
+                and t.is_contiguous()
+
+        def all_reduce(self, t, out=None):
+            assert self.should_custom_ar(t), "the kernel was handed a tensor it does not take"
+            self.calls.append(t.numel())
+            backend_all_reduce(t, group=D._DEVICE_GROUP)
+            return t
+
+        def all_reduce_in_pieces(self, t):
+            flat = t.view(-1)
+            step = self.max_size // t.element_size()
+            for a in range(0, flat.numel(), step):
+                self.all_reduce(flat[a:a + step])
+            return t
+
+        def should_custom_ag(self, t):
+            size = t.numel() * t.element_size()
+            return t.is_contiguous() and size > 0 and size % 16 == 0 and size <= self.max_size
+
+        def all_gather(self, t):
+            assert self.should_custom_ag(t), "the kernel was handed a tensor it does not take"
+            out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype)
+            backend_all_gather(list(out.unbind(0)), t.contiguous(), group=D._DEVICE_GROUP)
+            return out
+
+    backend_all_gather, backend_gather_into = dist.all_gather, dist.all_gather_into_tensor
+    D._CUSTOM_AR = FakeAR()
+    D._CONFINED["on"] = True
+
+    def refuse(*a, **k):
+        raise AssertionError("fell through to the backend's all-reduce on a confined instance")
+    dist.all_reduce = refuse
+    dist.all_gather = dist.all_gather_into_tensor = refuse
+    try:
+        g = torch.Generator().manual_seed(rank)
+        out = {}
+        odd = torch.randn(7, 5, generator=g)                    # 140 bytes: not a multiple of 16
+        strided = torch.randn(6, 16, generator=g)[:, ::2]       # not contiguous
+        big_odd = torch.randn(33, 5, generator=g)               # 660 bytes: staged AND in pieces
+        big = torch.randn(32, 8, generator=g)                   # 1024 bytes: in pieces
+        for name, t in (("odd", odd), ("strided", strided), ("big_odd", big_odd), ("big", big)):
+            want = t.clone()
+            r = D.tensor_model_parallel_all_reduce(t)
+            assert r is t
+            out[name] = (want, t.clone())
+        pending = D.tensor_model_parallel_all_reduce_async(odd) if torch.cuda.is_available() else None
+        del pending
+        try:
+            D.tensor_model_parallel_all_reduce(torch.ones(3, dtype=torch.int64))
+            out["int_refused"] = False
+        except RuntimeError as e:
+            out["int_refused"] = "CU-confined" in str(e)
+        # the logits all-gather: a payload above the kernels' limit and one that is no multiple of 16 bytes
+        for name, t in (("gather_big", torch.randn(3, 100, generator=g)), ("gather_odd", torch.randn(2, 3, generator=g))):
+            out[name] = (t.clone(), D.tensor_model_parallel_all_gather(t))
+        out["stats"] = dict(D.CONFINED_STATS)
+        return out
+    finally:
+        dist.all_reduce, dist.all_gather, dist.all_gather_into_tensor = backend_all_reduce, backend_all_gather, backend_gather_into
+        D._CUSTOM_AR, D._CONFINED["on"] = None, False
+
+
+def test_a_confined_instance_never_falls_through_to_the_backends_all_reduce():
+    """Round-5 verdict, multi-GPU item: in dynamic mode the RCCL fallback (non-contiguous / odd sizes) ran on RCCL's own
+    unmasked stream.  Now every payload of a confined instance goes through the peer-memory kernels -- staged when its shape
+    is odd -- and a dtype they cannot sum is refused.  parallel_state.py:376-436 is the reference's dispatch (custom kernel
+    first, the backend for the rest)."""
+    res = _spawn("_confined_reduce")
+    for name in ("odd", "strided", "big_odd", "big"):
+        total = res[0][name][0] + res[1][name][0]
+        for r in (0, 1):
+            assert torch.equal(res[r][name][1], total), name
+    assert res[0]["int_refused"] and res[1]["int_refused"]
+    for name in ("gather_big", "gather_odd"):
+        want = torch.cat([res[0][name][0], res[1][name][0]], dim=-1)
+        for r in (0, 1):
+            assert torch.equal(res[r][name][1], want), name
+    assert res[0]["stats"] == {"in_pieces": 1, "staged": 3, "gathered_in_pieces": 2}
+
+    from semi_pd_amd.server_args import ServerArgs
+    with pytest.raises(ValueError, match="disable-custom-all-reduce"):
+        ServerArgs(enable_semi_pd=True, tp_size=2, disable_custom_all_reduce=True)
+    ServerArgs(enable_semi_pd=True, tp_size=2, disable_custom_all_reduce=True, cu_mask_mode="env")
