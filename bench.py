@@ -263,9 +263,11 @@ def prefill_accounting(s: dict, n: int, num_layers: int) -> dict:
       layers_without_hold  num_layers x the mean GPU time between two consecutive layer hooks at which no hold happened: one
                            decoder layer's kernels plus the launch gaps inside it (HIP events of the step pacer's run-ahead
                            bound; the per-kernel split is the prefill process's rocprofv3 table under profiles/)
-      held                 the decode-step deadline's holds (an empty prefill queue while an overdue decode step finishes)
+      held_gpu_idle        what the decode-step deadline's holds cost the batch ON THE GPU: (hook intervals with a hold per
+                           batch) x (their mean length - the mean length of an interval without one)
       outside_layers       the rest: embedding, final norm, lm_head + sampling of the last tokens, the copy of the ids, and
                            whatever the GPU idled between this batch and its predecessor
+      held_host            wall time the hooks spent in holds (includes the tail of the layer still running when a hold began)
       pacer_wait_host      host time inside the hooks waiting for the GPU (bounded run-ahead): NOT GPU time, listed so that
                            nobody adds it"""
     if not s.get("t_gpu_owned_s"):
@@ -273,13 +275,17 @@ def prefill_accounting(s: dict, n: int, num_layers: int) -> dict:
     gate = s.get("step_gate") or {}
     owned = 1e3 * s["t_gpu_owned_s"] / n
     out = {"gpu_owned": round(owned, 3)}
-    held = gate.get("held_ms", 0.0) / n
     if gate.get("layer_ms_without_hold"):
-        layers = num_layers * gate["layer_ms_without_hold"]
-        out.update({"layers_without_hold": round(layers, 3), "held": round(held, 3),
-                    "outside_layers": round(owned - layers - held, 3)})
-    elif gate:
-        out["held"] = round(held, 3)
+        per_layer = gate["layer_ms_without_hold"]
+        layers = num_layers * per_layer
+        timed = gate.get("layer_intervals_timed", 0) + gate.get("layer_intervals_with_hold", 0)
+        # (the last run-ahead intervals of a forward are not timed: scale the count of held intervals to all hooks)
+        held_per_batch = gate.get("layer_intervals_with_hold", 0) * (gate.get("gates", timed) / max(timed, 1)) / n
+        held_gpu = held_per_batch * max(0.0, gate.get("layer_ms_with_hold", per_layer) - per_layer)
+        out.update({"layers_without_hold": round(layers, 3), "held_gpu_idle": round(held_gpu, 3),
+                    "outside_layers": round(owned - layers - held_gpu, 3)})
+    if gate:
+        out["held_host"] = round(gate.get("held_ms", 0.0) / n, 3)
     if gate.get("run_ahead_waits_ms") is not None:
         out["pacer_wait_host"] = round(gate["run_ahead_waits_ms"] / n, 3)
     return out

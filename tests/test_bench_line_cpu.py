@@ -70,7 +70,8 @@ class FakeEngine:
                  "results_sent_from_layer_hook": 271, "kernel_timing": {}, "t_gpu_owned_s": 14.2,
                  "step_gate": {"gates": 18176, "holds": 900, "held_ms": 1420.0, "timeouts": 0, "run_ahead_waits_ms": 9000.0,
                                "deadline_ms": 8.25, "deadline_range_ms": [8.0, 10.5], "deadline_trajectory": [[300, 8.25]],
-                               "layer_ms_without_hold": 0.62, "layer_intervals_timed": 17000}}]
+                               "layer_ms_without_hold": 0.62, "layer_intervals_timed": 16276, "layer_ms_with_hold": 1.87,
+                               "layer_intervals_with_hold": 764}}]
 
     def shutdown(self):
         pass
@@ -111,10 +112,13 @@ def test_the_bench_line_is_assembled_with_every_contract_field(monkeypatch, caps
     pb = d["roofline_extra"]["prefill_batch_ms"]
     assert pb["launched_behind_a_running_batch"] == 287 and pb["results_sent_from_layer_hook"] == 271 and pb["batches"] == 568
     # where a batch's GPU time goes: owned = layers (no hold) + held + the rest; the host's waits are listed apart
-    assert pb["gpu_owned"] == pytest.approx(25.0, abs=0.01) and pb["held"] == pytest.approx(2.5, abs=0.01)
+    assert pb["gpu_owned"] == pytest.approx(25.0, abs=0.01) and pb["held_host"] == pytest.approx(2.5, abs=0.01)
     nl = 32 if expect_static else 27
     assert pb["layers_without_hold"] == pytest.approx(nl * 0.62, abs=0.01)
-    assert pb["outside_layers"] == pytest.approx(25.0 - 2.5 - nl * 0.62, abs=0.02) and pb["pacer_wait_host"] > 0
+    # 764 timed intervals with a hold of 17040 timed ones, scaled to the 18176 hooks, over 568 batches, 1.25 ms longer each
+    held = 764 * (18176 / 17040) / 568 * 1.25
+    assert pb["held_gpu_idle"] == pytest.approx(held, abs=0.01)
+    assert pb["outside_layers"] == pytest.approx(25.0 - held - nl * 0.62, abs=0.02) and pb["pacer_wait_host"] > 0
     assert pb["step_gate"]["deadline_trajectory"] == [[300, 8.25]] and pb["step_gate"]["deadline_range_ms"] == [8.0, 10.5]
     assert d["roofline_extra"]["extend_attention"]["bound"] == "mfma"
     cfgd = d["config"]

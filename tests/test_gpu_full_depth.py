@@ -14,8 +14,12 @@ within 5e-2 of HF, same text).  Here, with seeded dummy weights at the real shap
    (oracle/model.py: OracleLlama, pinned to HF LlamaForCausalLM by tests/test_oracle_models.py): every token the oracle's
    argmax or within the tie margin of it, equal on every discriminating step.
 
-Margin: 0.15 in logit / log-probability units, the bf16 bar of tests/test_gpu_rank_widths.py (its docstring derives it at
-hidden 8192; hidden 4096 through 32 layers is no noisier: measured gaps at the divergences this test has seen are < 0.05)."""
+Margin: 0.15 in logit / log-probability units against the ORACLE, the bf16 bar of tests/test_gpu_rank_widths.py (its docstring
+derives it at hidden 8192).  Between the two ENGINES the bar is tighter (round 6): at most ONE of the four requests may part
+from the unified engine's tokens, and only at a unified top-2 gap below TIGHT_MARGIN = 0.08 -- in the round's runs all four
+requests of both models were equal over all 16 steps (profiles/r06_full_depth_parity.txt), and the engines' tokens sat within
+0.003 of the oracle's maximum on the 64-token request.  DeepSeek-V2-Lite's 64-token request x 4 steps is checked against the
+27-layer CPU oracle too (OracleDeepseekV2: non-absorbed MLA, naive experts; ~95 s of host time)."""
 import time
 
 import pytest
@@ -108,7 +112,7 @@ def test_llama3_8b_all_32_layers_semi_pd_default_policy_equals_unified_and_the_o
     equal = _same_up_to_near_ties(uni, lps, semi, gaps)
     print(f"Llama-3-8B x 32 layers: {equal} of {len(prompts)} requests token-for-token equal over {STEPS} steps "
           f"(engines: {time.time() - t0:.0f} s); top-2 gaps at the divergences {[round(g, 4) for g in gaps]}")
-    assert equal >= len(prompts) - 2, "more than two near-tie divergences in 64 tokens: not bf16 noise"
+    assert equal >= len(prompts) - 1, "more than one near-tie divergence in 64 tokens: not bf16 noise"
     assert all(g < TIGHT_MARGIN for g in gaps), f"a divergence at a top-2 gap of {max(gaps):.4f}: not a bf16 near-tie"
     # one short prompt against the CPU oracle of the whole model
     t0 = time.time()
@@ -129,7 +133,7 @@ def test_deepseek_v2_lite_all_27_layers_semi_pd_default_policy_equals_unified(de
     equal = _same_up_to_near_ties(uni, lps, semi, gaps)
     print(f"DeepSeek-V2-Lite x 27 layers: {equal} of {len(prompts)} requests token-for-token equal over {STEPS} steps; "
           f"top-2 gaps at the divergences {[round(g, 4) for g in gaps]}")
-    assert equal >= len(prompts) - 2
+    assert equal >= len(prompts) - 1
     assert all(g < TIGHT_MARGIN for g in gaps), f"a divergence at a top-2 gap of {max(gaps):.4f}: not a bf16 near-tie"
     # the 64-token prompt x 4 steps of both engines against the CPU oracle of all 27 layers (non-absorbed MLA, naive experts:
     # oracle/model.py OracleDeepseekV2, pinned to HF by tests/test_oracle_models.py); test/srt/models/
