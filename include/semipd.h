@@ -284,8 +284,13 @@ int semipd_linear(void* out, const void* x, const void* weight, void* workspace,
  * alone do not fill the share declared with semipd_gemm_tall_set_cus (0 = 256).  Replaces F.linear (+ SiluAndMul) of
  * UnquantizedLinearMethod.apply for decode batches above the streaming kernel's 64 rows
  * (python/sglang/srt/layers/linear.py:165-172, models/llama.py:88-92, layers/activation.py:41-53) and the logits GEMM
- * of _get_logits (layers/logits_processor.py:394-445).  k % 64 == 0, n_out % 16 == 0, bf16 / f16. */
+ * of _get_logits (layers/logits_processor.py:394-445).  k % 64 == 0, n_out % 16 == 0, bf16 / f16.
+ * semipd_gemm_tall_set_form(0 | 4 | 8): which of the two kernels runs the 256 x 256 tiles -- the 8-wave ping-pong kernel
+ * or the 4-wave one (one 128 x 128 quarter of the tile per wave, a third less LDS traffic per K step; round 6); 0 (the
+ * default) = four waves for the plain / planes epilogue, eight for SiLU * mul.  The same products, summed in the same
+ * order per output element: the two forms agree bit for bit without a K split. */
 int semipd_gemm_tall_set_cus(int cus);
+int semipd_gemm_tall_set_form(int waves);
 int semipd_gemm_tall(void* out, const void* x, const void* weight, void* workspace, size_t workspace_bytes, int64_t rows,
                      int64_t n, int64_t k, int64_t ldx, int64_t ldo, int fuse_silu_mul, int dtype, void* stream);
 /* The same GEMM (plain epilogue) stopped before the reduction over its K slices, for a row-parallel layer whose result

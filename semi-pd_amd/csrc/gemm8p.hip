@@ -350,6 +350,269 @@ gemm8p_kernel(T* __restrict__ out, float* __restrict__ planes, const T* __restri
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same 256 x 256 x 64 tile on FOUR waves (round 6): one wave per SIMD, each with a 128 x 128 quarter of the tile --
+// 8 x 8 accumulator tiles = 256 registers, which the compiler keeps in the accumulation half of the unified register file.
+// Why: the 8-wave form reads (128 + 64) rows x 128 B of fragments per wave and K step, 192 KB per CU, and its LDS-DMA writes
+// another 64 KB: 2048 cycles of the LDS's 128 B / cycle -- exactly the 2048 cycles the K step's MFMAs take.  The kernel is
+// bound by LDS bandwidth as much as by the matrix pipe (1.5-1.66 us per K step measured where the pipe needs 1.37 at the
+// ~1.5 GHz the chip sustains under it).  A 128 x 128 wave tile needs (128 + 128) rows per K step: 128 KB per CU + 64 KB of
+// DMA = 1536 cycles.
+//   * LDS image, DMA and swizzle as above (half-tiles of 128 rows, 2 parities x 4 half-tiles = 128 KB), except that the W
+//     half-tiles hold rows 0-63 / 64-127 of each of TWO 128-row wave columns;
+//   * a K step is four phases of 32 MFMAs (one 64 x 64 quadrant, both k halves).  There is no partner wave on the SIMD to
+//     cover the fragment reads, so the wave covers them itself: all four operand halves (x0, x1, W0, W1: 4 x 32 registers)
+//     live in registers, every phase reads ONE half for a LATER phase while its own MFMAs run, and the phase order
+//     alternates between K steps so that exactly one half falls free per phase:
+//         even step  (x0,W0) (x0,W1) (x1,W1) (x1,W0)     reads  W1(k) x1(k) x0(k+1) W1(k+1)
+//         odd step   (x0,W1) (x0,W0) (x1,W0) (x1,W1)     reads  W0(k) x1(k) x0(k+1) W0(k+1)
+//   * a half-tile's LDS slot is re-filled (for K step + 2) in the phase after it was read and is read 8 phases after that:
+//     7 phases (~2 us of matrix work) of flight, six younger half-tiles behind every wait: s_waitcnt vmcnt(24);
+//   * phase = { vmcnt(24): my share of the half to read now; lgkmcnt(0): last phase's reads; s_barrier; 8 ds_read_b128;
+//     4 DMA; 32 MFMAs }.
+// The MFMAs of the 4-wave kernel as inline asm with the accumulator tile tied to an ACCUMULATION register ("+a"): 256 of the
+// wave's 512 registers are accumulators, and left to itself the register allocator moves fragments into the accumulation half
+// too, spills accumulators and copies them around (1.2 KB of scratch per lane, ~370 v_accvgpr moves inside the K loop in the
+// first build).  With the classes fixed -- accumulators in a[0:255], fragments and addresses in v[0:255] -- nothing spills.
+// asm volatile also keeps the issue order of a phase: the fragment reads and the DMA first, then the 32 MFMAs.
+template <typename T> struct G4Mfma;
+template <> struct G4Mfma<bf16_t> {
+  __device__ static inline void mma(g8_f32x4& c, const G8Frag& a, const G8Frag& b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a.b), "v"(b.b));
+  }
+};
+template <> struct G4Mfma<f16_t> {
+  __device__ static inline void mma(g8_f32x4& c, const G8Frag& a, const G8Frag& b) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a.f), "v"(b.f));
+  }
+};
+
+template <typename T, int EPI, bool NT, bool GR = false, int ORDER = 0>
+__global__ void __launch_bounds__(256)
+gemm4w_kernel(T* __restrict__ out, float* __restrict__ planes, const T* __restrict__ x, const T* __restrict__ w, int M, int N,
+              int K, int64_t ldx, int64_t ldo, int kt_per_slice, G8Group grp = G8Group()) {
+  constexpr int kHalf = 128 * 128;            // a half-tile: 128 rows x 128 B
+  constexpr int kParity = 4 * kHalf;          // x0 x1 W0 W1 of one K-step parity
+  constexpr int L = 4;                        // DMA instructions per wave and half-tile (16 pieces of 8 rows, 4 waves)
+  extern __shared__ __attribute__((aligned(16))) char g8_smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int c16 = lane & 15, q4 = lane >> 4;
+  const int n_cols = EPI == G8_SILU_MUL ? N / 2 : N;
+  constexpr int cols_per_tile = EPI == G8_SILU_MUL ? 128 : 256;
+  const int tiles_n = (n_cols + cols_per_tile - 1) / cols_per_tile;
+  int tile_m, tile_n;
+  if (GR || ORDER == 0) {
+    tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+  } else {
+    const int nwg = gridDim.x, id = blockIdx.x, xcd = id & 7, q = nwg >> 3, r = nwg & 7;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+    const int tiles_m = nwg / tiles_n;
+    tile_n = logical / tiles_m, tile_m = logical - tile_n * tiles_m;
+  }
+  const int m0 = tile_m * 256, n0 = tile_n * cols_per_tile;
+  const int ks = blockIdx.y;
+  const int nkt_total = K >> 6;
+  const int kt0 = ks * kt_per_slice;
+  const int nkt = min(kt_per_slice, nkt_total - kt0);
+  if (GR) {
+    if (m0 >= grp.num_post_pad[0]) return;
+    w += (int64_t)grp.expert_ids[tile_m] * N * K;
+  }
+
+  // ---- DMA sources: piece p = wave * L + e fills LDS rows 8 p + (lane >> 3) of a half-tile ----
+  const T* srcx[2][L];
+  const T* srcw[2][L];
+#pragma unroll
+  for (int e = 0; e < L; ++e) {
+    const int rp = 8 * (wave * L + e) + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((rp >> 1) & 7);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int xrow = m0 + 128 * (rp >> 6) + 64 * h + (rp & 63);       // rows 64 h .. + 63 of both 128-row wave bands
+      if (GR) {
+        const int id = grp.sorted_ids[xrow];
+        xrow = id < grp.num_valid ? id / grp.top_k_div : 0;
+      } else {
+        xrow = min(xrow, M - 1);
+      }
+      srcx[h][e] = x + (int64_t)xrow * ldx + (int64_t)kt0 * 64 + chunk * 8;
+      int wrow, wlim;
+      if (EPI == G8_SILU_MUL) {
+        wrow = h * (N / 2) + n0 + 64 * (rp >> 6) + (rp & 63);     // half 0 = gate rows, half 1 = the up rows of the same columns
+        wlim = (h + 1) * (N / 2) - 1;
+      } else {
+        wrow = n0 + 128 * (rp >> 6) + 64 * h + (rp & 63);         // rows 64 h .. + 63 of both 128-row wave columns
+        wlim = N - 1;
+      }
+      srcw[h][e] = w + (int64_t)min(wrow, wlim) * K + (int64_t)kt0 * 64 + chunk * 8;
+    }
+  }
+  char* const dst0 = g8_smem + (wave * L) * 1024;
+  const int last_kt = nkt - 1;
+  // half id: 0 = x0, 1 = x1, 2 = W0, 3 = W1 (the order of the slots inside a parity)
+  auto stage = [&](int half, int kt) __attribute__((always_inline)) {
+    const int64_t k = (int64_t)min(kt, last_kt) * 64;               // past the end: the last step again (nobody multiplies it)
+    char* dst = dst0 + (kt & 1) * kParity + half * kHalf;
+#pragma unroll
+    for (int e = 0; e < L; ++e) {
+      if (half < 2) G8_GLDS(srcx[half][e] + k, dst + e * 1024, 0);
+      else if (NT) G8_GLDS(srcw[half - 2][e] + k, dst + e * 1024, 2);
+      else G8_GLDS(srcw[half - 2][e] + k, dst + e * 1024, 0);
+    }
+  };
+
+  const uint32_t smem_addr = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)g8_smem;
+  const int swz = (c16 >> 1) & 7;
+  uint32_t off_s[2];
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) off_s[s2] = c16 * 128 + (((4 * s2 + q4) ^ swz) << 4);
+  const uint32_t xa = smem_addr + wr * (64 * 128);                  // this wave's 64 rows of an x half-tile
+  const uint32_t wa = smem_addr + 2 * kHalf + wc * (64 * 128);      // this wave's 64 rows of a W half-tile
+
+  g8_f32x4 acc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = g8_f32x4{0.f, 0.f, 0.f, 0.f};
+  G8Frag fx0[4][2], fx1[4][2], fw0[4][2], fw1[4][2];
+
+#define G4_READ(F, BASE)                                                              \
+  _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_)                                    \
+    _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) F[t_][s_].u = g8_lds_read16((BASE) + off_s[s_], t_ * 2048)
+#define G4_SYNC()                 \
+  g8_wait_vm<24>();               \
+  g8_wait_lgkm0();                \
+  g8_barrier()
+  // One phase: 32 MFMAs (quadrant I0, J0 from the fragments XF, WF) with the reads of half-tile RF (8 ds_read_b128) and the
+  // DMA of one half-tile (4 instructions) issued BETWEEN them -- the matrix pipe starts right behind the barrier instead of
+  // after ~100 cycles of issue, and nothing of this phase's MFMAs depends on what is read or staged here.
+#define G4_PHASE(RF, RBASE, SHALF, SKT, XF, WF, I0, J0)                                                             \
+  do {                                                                                                             \
+    G4_SYNC();                                                                                                     \
+    const int64_t k_ = (int64_t)min((SKT), last_kt) * 64;                                                          \
+    char* const d_ = dst0 + ((SKT) & 1) * kParity + (SHALF) * kHalf;                                               \
+    _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                                               \
+      _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                           \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                           \
+          G4Mfma<T>::mma(acc[(I0) + i_][(J0) + j_], WF[j_][s_], XF[i_][s_]);                                       \
+        if (s_ == 0) {                                                                                             \
+          RF[i_][0].u = g8_lds_read16((RBASE) + off_s[0], i_ * 2048);                                              \
+          RF[i_][1].u = g8_lds_read16((RBASE) + off_s[1], i_ * 2048);                                              \
+        } else if ((SHALF) < 2) {                                                                                  \
+          G8_GLDS(srcx[(SHALF) & 1][i_] + k_, d_ + i_ * 1024, 0);                                                  \
+        } else if (NT) {                                                                                           \
+          G8_GLDS(srcw[(SHALF) & 1][i_] + k_, d_ + i_ * 1024, 2);                                                  \
+        } else {                                                                                                   \
+          G8_GLDS(srcw[(SHALF) & 1][i_] + k_, d_ + i_ * 1024, 0);                                                  \
+        }                                                                                                          \
+      }                                                                                                            \
+  } while (0)
+
+  // ---- prologue: the first eight half-tiles in the order they are read ----
+  stage(0, 0), stage(2, 0), stage(3, 0), stage(1, 0), stage(0, 1), stage(3, 1), stage(2, 1), stage(1, 1);
+  g8_wait_vm<28>();
+  g8_barrier();
+  G4_READ(fx0, xa);                                   // x0(0)
+  G4_SYNC();
+  G4_READ(fw0, wa);                                   // W0(0)
+  stage(0, 2);                                        // x0(0) has been read by everybody: its slot takes x0(2)
+
+  for (int kt = 0; kt < nkt; kt += 2) {
+    const uint32_t pa = (kt & 1) * kParity, pb = pa ^ kParity;     // parity of this step | of the next one
+    // ---- even step: (x0,W0) (x0,W1) (x1,W1) (x1,W0); each phase reads one half-tile for a later phase and re-fills the
+    //      slot of the half-tile read one phase ago (K step + 2) ----
+    G4_PHASE(fw1, wa + pa + kHalf, 2, kt + 2, fx0, fw0, 0, 0);      // reads W1(kt);     W0(kt) -> W0(kt + 2)
+    G4_PHASE(fx1, xa + pa + kHalf, 3, kt + 2, fx0, fw1, 0, 4);      // reads x1(kt);     W1(kt) -> W1(kt + 2)
+    G4_PHASE(fx0, xa + pb, 1, kt + 2, fx1, fw1, 4, 4);              // reads x0(kt + 1); x1(kt) -> x1(kt + 2)
+    G4_PHASE(fw1, wa + pb + kHalf, 0, kt + 3, fx1, fw0, 4, 0);      // reads W1(kt + 1); x0(kt + 1) -> x0(kt + 3)
+    // ---- odd step: (x0,W1) (x0,W0) (x1,W0) (x1,W1).  A slice is an EVEN count of K steps (the launcher sees to it: one loop
+    //      exit and no branch around the MFMAs -- with either, the register allocator parks accumulators in scratch) ----
+    G4_PHASE(fw0, wa + pb, 3, kt + 3, fx0, fw1, 0, 4);              // reads W0(kt + 1); W1(kt + 1) -> W1(kt + 3)
+    G4_PHASE(fx1, xa + pb + kHalf, 2, kt + 3, fx0, fw0, 0, 0);      // reads x1(kt + 1); W0(kt + 1) -> W0(kt + 3)
+    G4_PHASE(fx0, xa + pa, 1, kt + 3, fx1, fw0, 4, 0);              // reads x0(kt + 2); x1(kt + 1) -> x1(kt + 3)
+    G4_PHASE(fw0, wa + pa, 0, kt + 4, fx1, fw1, 4, 4);              // reads W0(kt + 2); x0(kt + 2) -> x0(kt + 4)
+  }
+#undef G4_READ
+#undef G4_PHASE
+#undef G4_SYNC
+  g8_wait_vm<0>();                    // no DMA may land in LDS that the next workgroup owns
+  g8_wait_lgkm0();
+  // the last MFMAs retire before their accumulators are read: the compiler knows nothing of the hazards of an asm MFMA, and
+  // only an asm that DEFINES the registers keeps its v_accvgpr_reads behind it (the first build read acc[7][7] one k-half short)
+  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+a"(acc[7][4]), "+a"(acc[7][5]), "+a"(acc[7][6]), "+a"(acc[7][7]));
+
+  // ---- epilogue: lane holds out[m = m0 + 128 wr + 16 i + c16][n = n0 + 128 wc + 16 j + 4 q4 + r] ----
+  const int mb = m0 + 128 * wr + c16;
+  if (planes != nullptr) {
+    float* pl = planes + (int64_t)ks * M * N;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int m = mb + 16 * i;
+        int n, nlim;
+        if (EPI == G8_SILU_MUL) {
+          n = (j / 4) * (N / 2) + n0 + 64 * wc + 16 * (j % 4) + 4 * q4;
+          nlim = ((j / 4) + 1) * (N / 2);
+        } else {
+          n = n0 + 128 * wc + 16 * j + 4 * q4;
+          nlim = N;
+        }
+        if (m < M && n < nlim) *reinterpret_cast<g8_f32x4*>(pl + (int64_t)m * N + n) = acc[i][j];
+      }
+    return;
+  }
+  if (EPI == G8_PLAIN) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      int m = mb + 16 * i;
+      float scale = 1.f;
+      if (GR) {
+        m = grp.sorted_ids[m];
+        if (m < grp.num_valid && grp.mul_routed_weight) scale = grp.topk_weights[m];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int n = n0 + 128 * wc + 16 * j + 4 * q4;
+        if (m < M && n < N) {
+          g8_f32x4 v = acc[i][j];
+          if (GR) v *= scale;
+          uint2 p;
+          p.x = (uint32_t)Elem<T>::from_f(v[0]).v | ((uint32_t)Elem<T>::from_f(v[1]).v << 16);
+          p.y = (uint32_t)Elem<T>::from_f(v[2]).v | ((uint32_t)Elem<T>::from_f(v[3]).v << 16);
+          *reinterpret_cast<uint2*>(out + (int64_t)m * ldo + n) = p;
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      int m = mb + 16 * i;
+      if (GR) m = grp.sorted_ids[m];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + 64 * wc + 16 * j + 4 * q4;
+        if (m < M && n < n_cols) {
+          float r[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            // the unfused pair rounds the GEMM output to T before the activation reads it
+            const float gq = Elem<T>::to_f(Elem<T>::from_f(acc[i][j][e])), uq = Elem<T>::to_f(Elem<T>::from_f(acc[i][4 + j][e]));
+            r[e] = gq / (1.f + __expf(-gq)) * uq;
+            asm volatile("" : "+v"(r[e]));   // (see gemm8p_kernel's epilogue: two roundings, not one fused one)
+          }
+          uint2 p;
+          p.x = (uint32_t)Elem<T>::from_f(r[0]).v | ((uint32_t)Elem<T>::from_f(r[1]).v << 16);
+          p.y = (uint32_t)Elem<T>::from_f(r[2]).v | ((uint32_t)Elem<T>::from_f(r[3]).v << 16);
+          *reinterpret_cast<uint2*>(out + (int64_t)m * ldo + n) = p;
+        }
+      }
+    }
+  }
+}
+
 // out[m, n] = T(sum_z planes[z][m][n]) in slice order (SiLU * mul variant: gate / up columns n, n + N / 2)
 template <typename T, int EPI>
 __global__ void __launch_bounds__(256)
@@ -381,6 +644,20 @@ gemm8p_reduce_kernel(T* __restrict__ out, const float* __restrict__ planes, int 
 }
 
 static std::atomic<int> g_g8_cus{256};
+
+// Which kernel runs the 256 x 256 tiles: 0 (default) = by epilogue -- four waves (gemm4w_kernel) for the plain and the
+// planes epilogue, where it is 2-8 % ahead on every Llama-3-8B layer shape, eight waves for SiLU * mul, where the two tie
+// (profiles/r06_kbench_gemm_forms_*.txt); 4 / 8 force one (SEMIPD_G8_FORM, semipd_gemm_tall_set_form)
+static std::atomic<int> g_g8_form{-1};
+static bool g8_four_waves(int epi) {
+  int f = g_g8_form.load(std::memory_order_relaxed);
+  if (f < 0) {
+    const char* e = getenv("SEMIPD_G8_FORM");
+    f = e ? atoi(e) : 0;
+    g_g8_form.store(f, std::memory_order_relaxed);
+  }
+  return f == 4 || (f == 0 && epi == G8_PLAIN);
+}
 
 // K slices: the tiles x slices workgroups run in whole rounds of the share's CUs (one workgroup per CU); pick the
 // split with the least (rounds x K steps per slice), charging each extra slice its fp32 plane round trip.
@@ -416,11 +693,26 @@ static int g8_launch_geo(T* out, float* planes, size_t planes_bytes, const T* x,
   while (ksp > 1 && (size_t)ksp * M * N * 4 > planes_bytes) --ksp;
   const int per = (nkt + ksp - 1) / ksp;
   ksp = (nkt + per - 1) / per;
+  // 256 x 256 tiles: the 8-wave ping-pong kernel or the 4-wave one (one 128 x 128 quarter per wave; see gemm4w_kernel), which
+  // walks K two steps at a time: only where every slice is an even count of K steps.  The K partition itself never depends on
+  // the form (the SiLU epilogue on eight waves and the plain one on four must sum the same slices: fused == unfused pair)
+  const bool four = XH == 128 && g8_four_waves(EPI) && nkt % 2 == 0 && per % 2 == 0;
   static std::atomic<uint64_t> lds_ok_nt{0}, lds_ok{0};
+#define G8_GO(K8, K4, OK)                                                                                              \
+  do {                                                                                                                 \
+    if (four) {                                                                                                        \
+      static std::atomic<uint64_t> ok4{0};                                                                             \
+      if (ensure_dynamic_lds((const void*)K4, G::kLds, ok4, "gemm4w")) return 1;                                      \
+      hipLaunchKernelGGL(K4, dim3(tiles, ksp), dim3(256), G::kLds, st, out, ksp > 1 ? planes : (float*)nullptr, x, w, M, N, \
+                         K, ldx, ldo, per);                                                                            \
+    } else {                                                                                                           \
+      if (ensure_dynamic_lds((const void*)K8, G::kLds, OK, "gemm8p")) return 1;                                       \
+      hipLaunchKernelGGL(K8, dim3(tiles, ksp), dim3(512), G::kLds, st, out, ksp > 1 ? planes : (float*)nullptr, x, w, M, N, \
+                         K, ldx, ldo, per);                                                                            \
+    }                                                                                                                  \
+  } while (0)
   if (tiles_m == 1) {
-    if (ensure_dynamic_lds((const void*)gemm8p_kernel<T, EPI, true, XH>, G::kLds, lds_ok_nt, "gemm8p")) return 1;
-    hipLaunchKernelGGL((gemm8p_kernel<T, EPI, true, XH>), dim3(tiles, ksp), dim3(512), G::kLds, st, out,
-                       ksp > 1 ? planes : (float*)nullptr, x, w, M, N, K, ldx, ldo, per);
+    G8_GO((gemm8p_kernel<T, EPI, true, XH>), (gemm4w_kernel<T, EPI, true>), lds_ok_nt);
   } else {
     // XCD-contiguous order pays where the weight does not fit the caches between row tiles (vocabulary-sized heads:
     // 128 256 x 4096 at 1024 rows 1073 -> 834 us) and is neutral to slightly negative for layer-sized weights
@@ -429,15 +721,12 @@ static int g8_launch_geo(T* out, float* planes, size_t planes_bytes, const T* x,
     const bool xcd_order = xcd_knob >= 0 ? xcd_knob != 0 : n_cols >= 32768;
     static std::atomic<uint64_t> lds_ok_x{0};
     if (xcd_order) {
-      if (ensure_dynamic_lds((const void*)gemm8p_kernel<T, EPI, false, XH, false, 1>, G::kLds, lds_ok_x, "gemm8p")) return 1;
-      hipLaunchKernelGGL((gemm8p_kernel<T, EPI, false, XH, false, 1>), dim3(tiles, ksp), dim3(512), G::kLds, st, out,
-                         ksp > 1 ? planes : (float*)nullptr, x, w, M, N, K, ldx, ldo, per);
+      G8_GO((gemm8p_kernel<T, EPI, false, XH, false, 1>), (gemm4w_kernel<T, EPI, false, false, 1>), lds_ok_x);
     } else {
-      if (ensure_dynamic_lds((const void*)gemm8p_kernel<T, EPI, false, XH>, G::kLds, lds_ok, "gemm8p")) return 1;
-      hipLaunchKernelGGL((gemm8p_kernel<T, EPI, false, XH>), dim3(tiles, ksp), dim3(512), G::kLds, st, out,
-                         ksp > 1 ? planes : (float*)nullptr, x, w, M, N, K, ldx, ldo, per);
+      G8_GO((gemm8p_kernel<T, EPI, false, XH>), (gemm4w_kernel<T, EPI, false>), lds_ok);
     }
   }
+#undef G8_GO
   int rc = launch_status("gemm8p");
   if (planes_only_ks) {   // the consumer sums the K-slice planes (semipd_fused_add_rmsnorm_planes); one slice: `out` is written
     *planes_only_ks = ksp;
@@ -468,6 +757,13 @@ static int g8_launch_grouped(T* c, const T* a, const T* w, const G8Group& grp, i
   const int tiles_n = (n_cols + cols_per_tile - 1) / cols_per_tile, tiles_m = (int)(max_sorted / G::BM);
   if (tiles_m == 0) return 0;
   static std::atomic<uint64_t> lds_ok{0};
+  if (XH == 128 && g8_four_waves(-1) && (K / 64) % 2 == 0) {   // (grouped tiles: 22-32 K steps, the longer prologue costs more than the loop gains: only when forced)
+    static std::atomic<uint64_t> ok4{0};
+    if (ensure_dynamic_lds((const void*)gemm4w_kernel<T, EPI, false, true>, G::kLds, ok4, "gemm4w_grouped")) return 1;
+    hipLaunchKernelGGL((gemm4w_kernel<T, EPI, false, true>), dim3(tiles_m * tiles_n, 1), dim3(256), G::kLds, st, c,
+                       (float*)nullptr, a, w, grp.num_valid, N, K, lda, ldc, K / 64, grp);
+    return launch_status("gemm4w_grouped");
+  }
   if (ensure_dynamic_lds((const void*)gemm8p_kernel<T, EPI, false, XH, true>, G::kLds, lds_ok, "gemm8p_grouped")) return 1;
   hipLaunchKernelGGL((gemm8p_kernel<T, EPI, false, XH, true>), dim3(tiles_m * tiles_n, 1), dim3(512), G::kLds, st, c,
                      (float*)nullptr, a, w, grp.num_valid, N, K, lda, ldc, K / 64, grp);
@@ -484,6 +780,13 @@ int semipd_gemm_tall_set_cus(int cus) {
   SEMIPD_CHECK_ARG(cus >= 0 && cus <= 4096, SEMIPD_EINVAL, "gemm_tall_set_cus: bad CU count %d", cus);
   g_g8_cus.store(cus == 0 ? 256 : cus, std::memory_order_relaxed);
   owned_cus().store(cus, std::memory_order_relaxed);
+  return 0;
+}
+
+/* 8 = the 8-wave ping-pong kernel for 256 x 256 tiles, 4 = the 4-wave one (gemm4w_kernel), 0 = by epilogue (the default) */
+int semipd_gemm_tall_set_form(int waves) {
+  SEMIPD_CHECK_ARG(waves == 0 || waves == 4 || waves == 8, SEMIPD_EINVAL, "gemm_tall_set_form: 0 (by epilogue), 4 or 8, got %d", waves);
+  g_g8_form.store(waves, std::memory_order_relaxed);
   return 0;
 }
 

@@ -69,6 +69,7 @@ _SIGNATURES = {
     "semipd_stream_linear_set_cus": [_i32],
     "semipd_stream_linear_f32": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp],
     "semipd_gemm_tall_set_cus": [_i32],
+    "semipd_gemm_tall_set_form": [_i32],
     "semipd_gemm_tall": [_vp, _vp, _vp, _vp, _sz, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _vp],
     "semipd_gemm_tall_planes": [_vp, _vp, _sz, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32, _vp, _vp],
     "semipd_moe_stream_gemm": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp],

@@ -395,6 +395,11 @@ def gemm_tall_is_supported(x: torch.Tensor, weight: torch.Tensor, fuse_silu_mul:
             and x.data_ptr() % 16 == 0)
 
 
+def gemm_tall_set_form(waves: int) -> None:
+    """0 | 4 | 8: which kernel runs gemm_tall's 256 x 256 tiles (csrc/gemm8p.hip: gemm4w_kernel | gemm8p_kernel; 0 = by epilogue)."""
+    check(_lib.load().semipd_gemm_tall_set_form(int(waves)), "gemm_tall_set_form")
+
+
 def gemm_tall(x: torch.Tensor, weight: torch.Tensor, fuse_silu_mul: bool = False,
               out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x @ weight.T (optionally SiluAndMul of it) with the 256 x 256 ping-pong tile kernel (csrc/gemm8p.hip): decode

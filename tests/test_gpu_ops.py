@@ -1373,6 +1373,97 @@ def test_gemm_tall_silu_mul_equals_the_unfused_pair(ops, device, dtype, M, I, K)
     torch.testing.assert_close(fused.float().cpu(), want.float(), rtol=tol, atol=tol)
 
 
+@pytest.fixture
+def four_wave_form(ops):
+    """ops.gemm_tall's 256 x 256 tiles on the 4-wave kernel (csrc/gemm8p.hip: gemm4w_kernel) for the duration of a test."""
+    import os
+    ops.gemm_tall_set_form(4)
+    os.environ["SEMIPD_G8_XH"] = "128"         # the 256 x 256 geometry whatever the row count
+    try:
+        yield
+    finally:
+        ops.gemm_tall_set_form(0)
+        os.environ.pop("SEMIPD_G8_XH", None)
+        os.environ.pop("SEMIPD_G8_KS", None)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K", [(256, 512, 512), (200, 4096, 4096), (96, 1024, 14336), (300, 768, 256), (1024, 1280, 1024),
+                                   (1411, 6144, 4096), (129, 272, 64), (1, 16, 128), (513, 272, 3200)])
+def test_gemm_tall_four_wave_form_matches_fp32_and_the_eight_wave_form(ops, device, four_wave_form, dtype, M, N, K):
+    """The 4-wave form of the tiled GEMM (one 128 x 128 quarter of the 256 x 256 tile per wave, accumulators in the
+    accumulation registers, round 6) = F.linear (layers/linear.py:165-172): against the fp32 product for every K split, and
+    -- without a split -- the BITS of the 8-wave form (the same MFMAs in the same order per output element).  K = 64 (an odd
+    count of K steps) and the odd slices a split would give stay on the 8-wave kernel: covered by falling through."""
+    import os
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N + K)
+    x = (torch.randn(M, K, generator=g)).to(dtype).to(device)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(dtype).to(device)
+    want = x.float() @ w.float().t()
+    tol = 2e-2 if dtype == torch.bfloat16 else 3e-3
+    for ks in ("0", "1", "2", "4"):
+        os.environ["SEMIPD_G8_KS"] = ks
+        got = ops.gemm_tall(x, w)
+        torch.testing.assert_close(got.float(), want, rtol=tol, atol=tol)
+    os.environ["SEMIPD_G8_KS"] = "1"
+    four = ops.gemm_tall(x, w)
+    ops.gemm_tall_set_form(8)
+    assert torch.equal(four, ops.gemm_tall(x, w))
+    ops.gemm_tall_set_form(4)
+    # strided x, caller-provided out with a row stride
+    xw = torch.zeros(M, K + 64, dtype=dtype, device=device)
+    xw[:, 16:16 + K] = x
+    buf = torch.full((M, N + 8), 7.0, dtype=dtype, device=device)
+    ops.gemm_tall(xw[:, 16:16 + K], w, out=buf[:, :N])
+    assert torch.equal(buf[:, :N], four)
+    assert float(buf[:, N:].float().min()) == 7.0 and float(buf[:, N:].float().max()) == 7.0
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,I,K", [(256, 1408, 2048), (130, 14336, 4096), (256, 176, 256), (1100, 2816, 1024)])
+def test_gemm_tall_four_wave_form_silu_mul_equals_the_unfused_pair(ops, device, four_wave_form, dtype, M, I, K):
+    import os
+    g = torch.Generator(device="cpu").manual_seed(M + I + K)
+    x = (torch.randn(M, K, generator=g)).to(dtype).to(device)
+    w = (torch.randn(2 * I, K, generator=g) * K ** -0.5).to(dtype).to(device)
+    for ks in ("1", "2"):
+        os.environ["SEMIPD_G8_KS"] = ks
+        fused = ops.gemm_tall(x, w, fuse_silu_mul=True)
+        plain = ops.gemm_tall(x, w)
+        assert torch.equal(fused, ops.silu_and_mul(plain))
+    want = O.silu_and_mul((x.float().cpu() @ w.float().cpu().t()).to(dtype))
+    tol = 3e-2 if dtype == torch.bfloat16 else 4e-3
+    torch.testing.assert_close(fused.float().cpu(), want.float(), rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("M,N,K,silu", [(256, 4096, 4096, False), (1024, 2048, 2048, False), (700, 1024, 512, True), (1411, 4096, 14336, False)])
+def test_gemm_tall_four_wave_form_race_screen(ops, device, four_wave_form, M, N, K, silu):
+    """The race screen of the 8-wave kernel (below) for the 4-wave form: its half-tile slots are re-filled ONE phase after
+    their last read and read eight phases later, on hand-counted vmcnt(24) waits -- 150 launches next to a stream that
+    saturates HBM must all give the bits of the first one, and that one the fp32 product."""
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(device)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(torch.bfloat16).to(device)
+    want = x.float() @ w.float().t()
+    if silu:
+        want = O.silu_and_mul(want.to(torch.bfloat16).cpu()).float().to(device)
+    first = ops.gemm_tall(x, w, fuse_silu_mul=silu).clone()
+    torch.testing.assert_close(first.float(), want, rtol=3e-2, atol=3e-2)
+    junk_a = torch.empty(64 << 20, dtype=torch.uint8, device=device)
+    junk_b = torch.empty_like(junk_a)
+    side = torch.cuda.Stream(device=device)
+    outs = []
+    for i in range(150):
+        if i % 3 == 0:
+            with torch.cuda.stream(side):
+                junk_b.copy_(junk_a)
+                junk_a.copy_(junk_b)
+        outs.append(ops.gemm_tall(x, w, fuse_silu_mul=silu))
+    torch.cuda.synchronize()
+    bad = [i for i, o in enumerate(outs) if not torch.equal(o, first)]
+    assert not bad, f"launches {bad[:8]} of 150 differ from the first one"
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("T,E,topk,K,N", [(700, 8, 2, 256, 192), (1500, 16, 6, 2048, 1408), (300, 4, 1, 128, 64)])
 @pytest.mark.parametrize("bm", [256, 128])
