@@ -337,7 +337,8 @@ __device__ __forceinline__ void stage2_merge(T* __restrict__ out_row, const floa
 #pragma unroll
         for (int u = 0; u < 8; ++u) v[u] = base[(int64_t)(s + u) * (Dv + 1) + d];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc += __shfl(w, s + u, 64) * v[u];
+        for (int u = 0; u < 8; ++u) acc = __builtin_fmaf(__shfl(w, s + u, 64), v[u], acc);   // pinned: left to itself the
+                                       // compiler multiplies pairs (v_pk_mul) and adds here but fuses in the tail below
       }
       float v[8];
 #pragma unroll
@@ -345,7 +346,7 @@ __device__ __forceinline__ void stage2_merge(T* __restrict__ out_row, const floa
         if (s + u < n_valid) v[u] = base[(int64_t)(s + u) * (Dv + 1) + d];
 #pragma unroll
       for (int u = 0; u < 8; ++u)
-        if (s + u < n_valid) acc += __shfl(w, s + u, 64) * v[u];
+        if (s + u < n_valid) acc = __builtin_fmaf(__shfl(w, s + u, 64), v[u], acc);
       if (ok) out_row[d] = Elem<T>::from_f(acc * inv);
     }
     return;

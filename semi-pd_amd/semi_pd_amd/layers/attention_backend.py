@@ -112,6 +112,7 @@ class HipAttnBackend(AttentionBackend):
         self.cuda_graph_attn_logits = None
         self.model_runner = model_runner
         self._algo = (0.0, 0.0)  # algorithmic (bytes, flops) per layer call of the current batch
+        self._fused_decode_ok = {}
 
     @property
     def num_cus(self) -> int:
@@ -240,6 +241,43 @@ class HipAttnBackend(AttentionBackend):
             md.kv_indptr, md.kv_indices, md.attn_logits, md.num_kv_splits, layer.scaling, layer.logit_cap)
         if kt:
             kt.stop("decode_attention", t0, *self._algo, n_kernels=2 if md.num_kv_splits > 1 else 1)
+        return o
+
+
+    # ---- decode: RoPE + KV store + attention + split merge in one launch -------------------------
+    def fused_decode_waves(self, bs: int, head_dim: int) -> int:
+        """How a decode batch of `bs` requests goes from the qkv GEMM's planes to o_proj's input: 0 = the separate
+        launches (rope_and_store_kv_planes, decode_attention_fwd: stage 1 + stage 2), 4 / 8 = ONE launch whose
+        workgroups are (request, kv head) pairs with that many waves as kv splits (ops.decode_rope_attention_planes,
+        csrc/decode_attention_fused.hip).  The fused form needs about one workgroup per two CUs to fill the chip;
+        smaller batches keep the separate launches, whose split count is free (choose_kv_splits).
+        SEMIPD_FUSED_DECODE_ATTN=0 turns it off; a fixed --triton-attention-num-kv-splits keeps the reference's form."""
+        if self.is_mla or self.fixed_kv_splits or os.environ.get("SEMIPD_FUSED_DECODE_ATTN", "1") == "0":
+            return 0
+        key = (head_dim,)
+        ok = self._fused_decode_ok.get(key)
+        if ok is None:
+            kv_dtype = getattr(self.model_runner, "kv_cache_dtype", None) or self.model_runner.dtype
+            ok = self._fused_decode_ok[key] = ops.decode_rope_attention_planes_supported(
+                self.num_head, self.num_kv_head, head_dim, self.model_runner.dtype, kv_dtype)
+        if not ok:
+            return 0
+        wgs, cus = bs * self.num_kv_head, max(1, self.num_cus)
+        if wgs >= 2 * cus:
+            return 4
+        return 8 if 2 * wgs >= cus else 0
+
+    def forward_decode_rope_planes(self, positions, qkv_planes, rotary_emb, layer, forward_batch: ForwardBatch, waves: int):
+        md = self.forward_metadata
+        pool = forward_batch.token_to_kv_pool
+        kt = self._timing()
+        t0 = kt.start() if kt else None
+        o = ops.decode_rope_attention_planes(
+            positions, qkv_planes, layer.tp_q_head_num, layer.tp_k_head_num, layer.head_dim, rotary_emb.cos_sin_cache,
+            pool.get_key_buffer(layer.layer_id), pool.get_value_buffer(layer.layer_id), forward_batch.out_cache_loc,
+            md.kv_indptr, md.kv_indices, waves, layer.scaling, layer.logit_cap)
+        if kt:
+            kt.stop("decode_attention", t0, *self._algo, n_kernels=1)
         return o
 
 

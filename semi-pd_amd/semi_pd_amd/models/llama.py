@@ -83,6 +83,13 @@ class LlamaAttention(nn.Module):
             # decode: the qkv GEMM stops before its K-slice reduction and the RoPE + KV-store kernel sums the planes
             planes = self.qkv_proj.forward_planes(hidden_states)
             if planes is not None:
+                backend = forward_batch.attn_backend
+                waves = backend.fused_decode_waves(planes.rows, self.head_dim)
+                if waves:
+                    # ... and the same kernel walks the KV rows and merges its splits: one launch up to o_proj's input
+                    attn_output = backend.forward_decode_rope_planes(positions, planes, self.rotary_emb, self.attn,
+                                                                     forward_batch, waves)
+                    return self.o_proj(attn_output, defer_reduce=True)
                 q = self.rotary_emb.forward_and_store_planes(positions, planes, self.num_heads, self.num_kv_heads,
                                                              pool.get_key_buffer(self.attn.layer_id),
                                                              pool.get_value_buffer(self.attn.layer_id),

@@ -664,6 +664,49 @@ def rope_and_store_kv_planes(positions: torch.Tensor, qkv: SplitKPlanes, num_q_h
     return q
 
 
+def decode_rope_attention_planes_supported(num_q_heads: int, num_kv_heads: int, head_size: int, dtype: torch.dtype,
+                                           kv_dtype: torch.dtype) -> bool:
+    """Whether semipd_decode_rope_attention_planes is instantiated for this head geometry (csrc/decode_attention_fused.hip)."""
+    return bool(_lib.load().semipd_decode_rope_attention_planes_supported(
+        num_q_heads, num_kv_heads, head_size, dtype_code(dtype), _lib.kv_dtype_code(kv_dtype)))
+
+
+def decode_rope_attention_planes(positions: torch.Tensor, qkv: SplitKPlanes, num_q_heads: int, num_kv_heads: int,
+                                 head_size: int, cos_sin_cache: torch.Tensor, k_buffer: torch.Tensor, v_buffer: torch.Tensor,
+                                 loc: torch.Tensor, kv_indptr: torch.Tensor, kv_indices: torch.Tensor, waves: int,
+                                 sm_scale: float, logit_cap: float = 0.0) -> torch.Tensor:
+    """rope_and_store_kv_planes + decode_attention_fwd (`waves` kv splits, both stages) in ONE launch: the qkv row is
+    still the K-slice planes of the decode GEMM; rotated k and v go to the pool rows `loc` (the last row of each request
+    in kv_indices); returns the attention output [tokens, Hq * head] (semipd_decode_rope_attention_planes).  Same bits
+    as the separate calls."""
+    if cos_sin_cache.dtype != torch.float32 or cos_sin_cache.shape[1] != head_size or not cos_sin_cache.is_contiguous():
+        raise RuntimeError("decode_rope_attention_planes: contiguous fp32 cos / sin cache over the whole head expected")
+    if qkv.n != (num_q_heads + 2 * num_kv_heads) * head_size:
+        raise RuntimeError("decode_rope_attention_planes: planes do not hold a [q | k | v] row")
+    if positions.dtype != torch.int64:
+        positions = positions.long()
+    if loc.dtype != torch.int64 or loc.numel() != qkv.rows or not loc.is_contiguous():
+        raise RuntimeError("decode_rope_attention_planes: one contiguous int64 pool row index per token expected")
+    if positions.numel() != qkv.rows or not positions.is_contiguous():
+        raise RuntimeError("decode_rope_attention_planes: one contiguous position per token expected")
+    for name, buf in (("k_buffer", k_buffer), ("v_buffer", v_buffer)):
+        if buf.dim() != 3 or buf.shape[1:] != (num_kv_heads, head_size) or buf.stride(2) != 1 \
+                or buf.stride(1) != head_size:
+            raise RuntimeError(f"decode_rope_attention_planes: {name} must be [slots, kv heads, head] with dense rows")
+    if k_buffer.dtype != v_buffer.dtype:
+        raise RuntimeError("decode_rope_attention_planes: k_buffer / v_buffer dtype mismatch")
+    if kv_indptr.dtype != torch.int32 or kv_indices.dtype != torch.int32 or qkv.rows > kv_indptr.shape[0] - 1:
+        raise RuntimeError("decode_rope_attention_planes: int32 kv_indptr [tokens + 1] / kv_indices expected")
+    qkv.check_live("decode_rope_attention_planes")
+    o = torch.empty((qkv.rows, num_q_heads * head_size), dtype=qkv.dtype, device=qkv.planes.device)
+    check(_lib.load().semipd_decode_rope_attention_planes(
+        ptr(o), ptr(qkv.planes), qkv.ksplit, qkv.rows * qkv.n, ptr(k_buffer), ptr(v_buffer), ptr(loc), ptr(cos_sin_cache),
+        ptr(positions), ptr(kv_indptr), ptr(kv_indices), qkv.rows, num_q_heads, num_kv_heads, head_size, o.stride(0),
+        k_buffer.stride(0), v_buffer.stride(0), waves, sm_scale, logit_cap, dtype_code(qkv.dtype),
+        _lib.kv_dtype_code(k_buffer.dtype), current_stream(o.device)), "decode_rope_attention_planes")
+    return o
+
+
 def mla_decode_prep(qkv_a: SplitKPlanes, positions: torch.Tensor, cos_sin_cache: torch.Tensor, norm_weight: torch.Tensor,
                     eps: float, num_heads: int, nope_dim: int, rope_dim: int, lora_rank: int, kv_buffer: torch.Tensor,
                     loc: torch.Tensor, q_input: torch.Tensor) -> torch.Tensor:

@@ -1257,6 +1257,83 @@ def test_rope_and_store_kv_from_the_qkv_planes(ops, device, M, dtype, kv_dtype, 
     assert torch.equal(kb2.view(torch.uint8), kb1.view(torch.uint8)) and torch.equal(vb2.view(torch.uint8), vb1.view(torch.uint8))
 
 
+FUSED_DECODE_LENS = [
+    [5, 33, 700],
+    [1, 2, 3, 8, 9, 31, 32, 33, 34, 64, 255, 256, 257, 258, 1000],   # the new token alone, in a wave's first tile, on tile edges
+    [2048, 1100],
+]
+
+
+@pytest.mark.parametrize("lens", FUSED_DECODE_LENS, ids=["three", "edges", "long"])
+@pytest.mark.parametrize("heads", [(32, 8, 128, 4096), (8, 1, 128, 8192), (12, 6, 64, 768), (32, 2, 64, 2048)],
+                         ids=["llama3_8b", "llama3_70b_tp8_rank", "g2_d64", "g16_d64"])
+@pytest.mark.parametrize("waves", [4, 8])
+@pytest.mark.parametrize("dtype,kv_dtype,cap", [(torch.bfloat16, None, 0.0), (torch.float16, None, 30.0),
+                                                 (torch.bfloat16, torch.float8_e4m3fn, 0.0)],
+                         ids=["bf16", "f16_cap", "bf16_fp8kv"])
+def test_decode_rope_attention_planes_has_the_bits_of_the_three_launches(ops, device, lens, heads, waves, dtype, kv_dtype, cap):
+    """Decode step between the qkv GEMM and o_proj in ONE launch (csrc/decode_attention_fused.hip: plane sum + RoPE + KV
+    store + paged attention + merge of the kv splits inside the workgroup) against the launches it replaces --
+    rope_and_store_kv_planes, then decode_attention_fwd with as many splits as the fused kernel has waves: same output
+    bits, same pool rows -- and against the oracle's attention over the pool it left behind.  The new token is the last
+    row of every request (layers/attention/triton_backend.py:96-118: kv_indices of a decode batch end at out_cache_loc)."""
+    Hq, Hk, D, K = heads
+    B = len(lens)
+    assert ops.decode_rope_attention_planes_supported(Hq, Hk, D, dtype, kv_dtype or dtype)
+    g = torch.Generator().manual_seed(sum(lens) + Hq + waves)
+    total = int(sum(lens))
+    slots = total + 13
+    perm = (torch.randperm(slots - 1, generator=g)[:total] + 1).to(torch.int32)
+    indptr = torch.zeros(B + 1, dtype=torch.int32)
+    indptr[1:] = torch.cumsum(torch.tensor(lens), 0)
+    loc = perm[(indptr[1:] - 1).long()].to(torch.int64)            # each request's last row = where the new token goes
+    pool_dtype = kv_dtype or dtype
+    k0 = torch.randn(slots, Hk, D, generator=g).to(dtype).to(pool_dtype)
+    v0 = torch.randn(slots, Hk, D, generator=g).to(dtype).to(pool_dtype)
+    x = torch.randn(B, K, generator=g).to(dtype).to(device)
+    w = (torch.randn((Hq + 2 * Hk) * D, K, generator=g) * 0.03).to(dtype).to(device)
+    pos = (torch.tensor(lens) - 1).to(torch.int64).to(device)
+    inv = 1.0 / (10000 ** (torch.arange(0, D, 2, dtype=torch.float) / D))
+    fr = torch.einsum("i,j -> ij", torch.arange(4096, dtype=torch.float), inv)
+    cache = torch.cat((fr.cos(), fr.sin()), dim=-1).to(device)
+    sm_scale = 1.0 / (D ** 0.5)
+    indptr_d, perm_d, loc_d = indptr.to(device), perm.to(device), loc.to(device)
+
+    kb1, vb1 = k0.clone().to(device), v0.clone().to(device)
+    planes = ops.stream_linear_planes(x, w)
+    q1 = ops.rope_and_store_kv_planes(pos, planes, Hq, Hk, D, cache, kb1, vb1, loc_d)
+    o1 = torch.empty(B, Hq, D, dtype=dtype, device=device)
+    logits = torch.empty(B, Hq, waves, D + 1, dtype=torch.float32, device=device)
+    ops.decode_attention_fwd(q1.view(B, Hq, D), kb1, vb1, o1, indptr_d, perm_d, logits, waves, sm_scale, cap)
+
+    kb2, vb2 = k0.clone().to(device), v0.clone().to(device)
+    planes = ops.stream_linear_planes(x, w)
+    o2 = ops.decode_rope_attention_planes(pos, planes, Hq, Hk, D, cache, kb2, vb2, loc_d, indptr_d, perm_d, waves, sm_scale, cap)
+    torch.cuda.synchronize()
+    assert torch.equal(kb2.view(torch.uint8), kb1.view(torch.uint8)) and torch.equal(vb2.view(torch.uint8), vb1.view(torch.uint8))
+    assert torch.equal(o2.view(torch.int16), o1.view(B, Hq * D).view(torch.int16))
+    want = O.decode_attention(q1.view(B, Hq, D).cpu(), kb2.cpu().to(dtype), vb2.cpu().to(dtype), indptr, perm, sm_scale, cap)
+    _close(o2.view(B, Hq, D), want, dtype, rtol=2e-2, atol=4e-3 if dtype == torch.float16 else 1.5e-2)
+
+
+def test_decode_rope_attention_planes_refuses_what_it_cannot_do(ops, device):
+    assert not ops.decode_rope_attention_planes_supported(40, 1, 128, torch.bfloat16, torch.bfloat16)    # 40 q heads per kv head
+    assert not ops.decode_rope_attention_planes_supported(12, 12, 64, torch.bfloat16, torch.bfloat16)    # MHA: the shuffle kernel's
+    assert not ops.decode_rope_attention_planes_supported(32, 8, 96, torch.bfloat16, torch.bfloat16)     # head size
+    assert not ops.decode_rope_attention_planes_supported(32, 8, 128, torch.float32, torch.float32)
+    Hq, Hk, D, K, B = 8, 2, 128, 1024, 2
+    x = torch.randn(B, K, device=device).to(torch.bfloat16)
+    w = (torch.randn((Hq + 2 * Hk) * D, K, device=device) * 0.03).to(torch.bfloat16)
+    kb, vb = (torch.zeros(16, Hk, D, dtype=torch.bfloat16, device=device) for _ in range(2))
+    cache = torch.zeros(64, D, device=device)
+    pos = torch.zeros(B, dtype=torch.int64, device=device)
+    loc = torch.tensor([1, 2], dtype=torch.int64, device=device)
+    indptr = torch.tensor([0, 1, 2], dtype=torch.int32, device=device)
+    idx = torch.tensor([1, 2], dtype=torch.int32, device=device)
+    with pytest.raises(RuntimeError, match="waves"):
+        ops.decode_rope_attention_planes(pos, ops.stream_linear_planes(x, w), Hq, Hk, D, cache, kb, vb, loc, indptr, idx, 3, 0.1)
+
+
 # --------------------------------------------------------------------------- prefill-sized dense layers on a CU share
 def test_dense_gemm_with_measured_library_solution_matches_fp32(ops, device):
     """ops.dense_gemm = F.linear (UnquantizedLinearMethod.apply, layers/linear.py:165-172) through the hipBLASLt solution
