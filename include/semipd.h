@@ -383,8 +383,10 @@ size_t semipd_dense_gemm_report(char* buf, size_t len);
 int semipd_stream_linear_f32(float* out, const void* x, const void* weight, int64_t rows, int64_t n, int64_t k, int64_t ldx,
                              int dtype, void* stream);
 
-/* Dense layer of a decode batch: out[rows, n_out] = x[rows, k] . weight[n, k]^T, rows <= 64 (bf16 / f16, fp32
- * accumulate).  Weights are streamed once through LDS-DMA rings; the launch is (n / 128 row batches) x KS slices of K.
+/* Dense layer of a decode batch: out[rows, n_out] = x[rows, k] . weight[n, k]^T, rows <= 128 (bf16 / f16, fp32
+ * accumulate).  Weights are streamed once through LDS-DMA rings; the launch is (n / 128 row batches) x KS slices of K
+ * (up to 64 rows: eight waves of 16 weight rows, rings of three blocks; 65 .. 128 rows: four waves of 2 x 16 weight rows,
+ * rings of two blocks -- the activation block is 32 KB there).
  * KS is a function of the shape AND of the CU count declared with semipd_stream_linear_set_cus (whole rounds of that
  * many workgroups): the slices set the order of the fp32 partial sums, so two processes produce the same bits exactly
  * when they declare the same count -- every instance of the engine declares the DEVICE's CU count for that reason

@@ -1,4 +1,4 @@
-// Decode-instance dense layers on a CU share: out[m, n] = sum_k x[m, k] * W[n, k], m <= 64 rows.
+// Decode-instance dense layers on a CU share: out[m, n] = sum_k x[m, k] * W[n, k], m <= 128 rows.
 //
 // A decode step reads every weight once (16 GB for Llama-3-8B) and is bound by that stream, on whatever part
 // of the chip the decode instance owns.  The library GEMMs launch grids shaped for the whole device (two
@@ -60,11 +60,11 @@ enum { SL_PLAIN = 0, SL_SILU_MUL = 1 };
 //   * workgroup = NW waves x (NG x 16) weight rows over one K slice; the launch is n_row_batches x KS
 //     workgroups, KS chosen from the shape so that a half-chip share is filled by one round; KS > 1 writes fp32
 //     planes [KS][M][N] that splitk_planes_reduce below sums in slice order.
-template <int MT, int NG, int NW, int R>
+template <int MT, int NG, int NW, int R, int RX = R>
 struct SgLayout {
   static constexpr int kXStage = MT * 4096;                 // one activation block: MT x 16 rows x 256 B
   static constexpr int kWSlot = NG * 4096;                  // one weight block of a wave
-  static constexpr int kXRing = R * kXStage;
+  static constexpr int kXRing = RX * kXStage;               // (RX < R: the wide form, see the kernel's main loop)
   static constexpr int kBytes = kXRing + NW * R * kWSlot;
   static constexpr int kNX = (4 * MT + NW - 1) / NW;        // x DMA pieces per wave per block
   static constexpr int kPerBlock = kNX + 4 * NG;            // VMEM ops a wave issues per block
@@ -103,12 +103,13 @@ struct SgGroup {
   int num_valid, top_k_div, mul_routed_weight;
 };
 
-template <typename T, int MT, int NG, int NW, int R, int EPI, bool GR = false, bool ROT = true>
+template <typename T, int MT, int NG, int NW, int R, int EPI, bool GR = false, bool ROT = true, int RX = R>
 __global__ void __launch_bounds__(64 * NW)
 stream_gemm_glds_kernel(T* __restrict__ out, float* __restrict__ planes, const T* __restrict__ x,
                         const T* __restrict__ w, int M, int N, int K, int64_t ldx, int64_t ldo, int kb_per_slice,
                         int planes_only, SgGroup grp = SgGroup()) {
-  using L = SgLayout<MT, NG, NW, R>;
+  using L = SgLayout<MT, NG, NW, R, RX>;
+  static_assert(RX == R || (RX == 2 && R == 3), "activation ring: as deep as the weight rings, or two slots under three");
   extern __shared__ __attribute__((aligned(16))) char sg_smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -167,17 +168,25 @@ stream_gemm_glds_kernel(T* __restrict__ out, float* __restrict__ planes, const T
   // (not in the grouped form: its experts' fused and plain launches promise equal bits, tests/test_gpu_ops.py
   //  test_moe_stream_gemm_matches_fp32_per_expert, and its workgroups start at different experts' weights anyway)
   const int rot = (ROT && !GR) ? (int)(((uint32_t)(blockIdx.x + 1) * 0x9E3779B1u >> 16) % (uint32_t)nkb) : 0;
-  auto issue = [&](int kb) __attribute__((always_inline)) {   // block kb of this slice -> ring position kb % R
-    const int slot = kb % R;
+  auto issue_x = [&](int kb) __attribute__((always_inline)) {  // activation block kb of this slice -> ring position kb % RX
     int kk = kb + rot;
     if (kk >= nkb) kk -= nkb;
     const int64_t koff = (int64_t)kk * 128;
 #pragma unroll
-    for (int e = 0; e < L::kNX; ++e) SG_GLDS(xsrc[e] + koff, xring + slot * L::kXStage + xdst[e], 0);
+    for (int e = 0; e < L::kNX; ++e) SG_GLDS(xsrc[e] + koff, xring + (kb % RX) * L::kXStage + xdst[e], 0);
+  };
+  auto issue_w = [&](int kb) __attribute__((always_inline)) {  // this wave's weight block kb -> ring position kb % R
+    int kk = kb + rot;
+    if (kk >= nkb) kk -= nkb;
+    const int64_t koff = (int64_t)kk * 128;
 #pragma unroll
     for (int g = 0; g < NG; ++g)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) SG_GLDS(wsrc[g][j] + koff, wring + slot * L::kWSlot + g * 4096 + j * 1024, 2);
+      for (int j = 0; j < 4; ++j) SG_GLDS(wsrc[g][j] + koff, wring + (kb % R) * L::kWSlot + g * 4096 + j * 1024, 2);
+  };
+  auto issue = [&](int kb) __attribute__((always_inline)) {
+    issue_x(kb);
+    issue_w(kb);
   };
 
   sl_f32x4 acc[NG][MT];
@@ -191,19 +200,38 @@ stream_gemm_glds_kernel(T* __restrict__ out, float* __restrict__ planes, const T
 #pragma unroll
   for (int s = 0; s < 4; ++s) frag_off[s] = c16 * 256 + (((4 * s + q4) ^ c16) << 4);
 
+  if (RX == R) {
 #pragma unroll
-  for (int p = 0; p < R - 1; ++p)
-    if (p < nkb) issue(p);
+    for (int p = 0; p < R - 1; ++p)
+      if (p < nkb) issue(p);
+  } else {
+    // 65 .. 128 rows: an activation block is 24 / 32 KB and three slots of it do not fit next to the weight rings, but the
+    // activations come from L2 and the weights from HBM: TWO weight blocks stay in flight per wave, ONE activation block.
+    // Issue order w(0) x(0) w(1), then per block x(kb + 1) w(kb + 2): the counted wait below leaves exactly the youngest
+    // weight block outstanding.
+    issue_w(0);
+    issue_x(0);
+    if (1 < nkb) issue_w(1);
+  }
   for (int kb = 0; kb < nkb; ++kb) {
     // block kb landed (this wave's share); the R - 2 younger blocks stay in flight.  Near the end of the slice
     // fewer blocks are outstanding than the count assumes: drain.
-    if (kb + R - 1 <= nkb) sg_wait_vm<(R - 2) * L::kPerBlock>();
-    else sg_wait_vm<0>();
+    if (RX == R) {
+      if (kb + R - 1 <= nkb) sg_wait_vm<(R - 2) * L::kPerBlock>();
+      else sg_wait_vm<0>();
+    } else {
+      if (kb + 1 < nkb) sg_wait_vm<4 * NG>();
+      else sg_wait_vm<0>();
+    }
     __builtin_amdgcn_s_barrier();       // every wave's share of x(kb) landed; everybody is done with block kb - 1
     asm volatile("" ::: "memory");
-    if (kb + R - 1 < nkb) issue(kb + R - 1);                // into the ring position block kb - 1 just left
-    const int slot = kb % R;
-    const uint32_t xs = xring_addr + slot * L::kXStage, wsl = wring_addr + slot * L::kWSlot;
+    if (RX == R) {
+      if (kb + R - 1 < nkb) issue(kb + R - 1);              // into the ring position block kb - 1 just left
+    } else {
+      if (kb + 1 < nkb) issue_x(kb + 1);                    // both into the positions block kb - 1 just left
+      if (kb + 2 < nkb) issue_w(kb + 2);
+    }
+    const uint32_t xs = xring_addr + (kb % RX) * L::kXStage, wsl = wring_addr + (kb % R) * L::kWSlot;
     SlFrag a[2][NG], b[2][MT];
     auto read_step = [&](int buf, int s) __attribute__((always_inline)) {
 #pragma unroll
@@ -360,10 +388,10 @@ static int sg_pick_ksplit(int n_rb, int nkb, int M, int N, bool extra_reduce_lau
   return best;
 }
 
-template <typename T, int MT, int NG, int NW, int R, int EPI>
+template <typename T, int MT, int NG, int NW, int R, int EPI, int RX = R>
 static int sg_launch(T* out, float* planes, size_t planes_bytes, const T* x, const T* w, int M, int N, int K,
                      int64_t ldx, int64_t ldo, int force_ks, hipStream_t st, int* planes_only_ks = nullptr) {
-  using L = SgLayout<MT, NG, NW, R>;
+  using L = SgLayout<MT, NG, NW, R, RX>;
   const int rows_per_wg = (EPI == SL_SILU_MUL ? 16 : 16 * NG) * NW;
   const int n_rows = EPI == SL_SILU_MUL ? N / 2 : N;
   const int n_rb = (n_rows + rows_per_wg - 1) / rows_per_wg;
@@ -378,14 +406,14 @@ static int sg_launch(T* out, float* planes, size_t planes_bytes, const T* x, con
   static const bool rot_off = [] { const char* e = getenv("SEMIPD_SL_ROT"); return e && atoi(e) == 0; }();   // A/B knob
   if (rot_off) {
     static std::atomic<uint64_t> lds_ok0{0};
-    if (ensure_dynamic_lds((const void*)stream_gemm_glds_kernel<T, MT, NG, NW, R, EPI, false, false>, L::kBytes, lds_ok0, "stream_gemm_glds"))
+    if (ensure_dynamic_lds((const void*)stream_gemm_glds_kernel<T, MT, NG, NW, R, EPI, false, false, RX>, L::kBytes, lds_ok0, "stream_gemm_glds"))
       return 1;
-    hipLaunchKernelGGL((stream_gemm_glds_kernel<T, MT, NG, NW, R, EPI, false, false>), dim3(n_rb, ksp), dim3(64 * NW), L::kBytes, st,
+    hipLaunchKernelGGL((stream_gemm_glds_kernel<T, MT, NG, NW, R, EPI, false, false, RX>), dim3(n_rb, ksp), dim3(64 * NW), L::kBytes, st,
                        out, planes, x, w, M, N, K, ldx, ldo, per, planes_only_ks ? 1 : 0);
   } else {
-  if (ensure_dynamic_lds((const void*)stream_gemm_glds_kernel<T, MT, NG, NW, R, EPI>, L::kBytes, lds_ok, "stream_gemm_glds"))
+  if (ensure_dynamic_lds((const void*)stream_gemm_glds_kernel<T, MT, NG, NW, R, EPI, false, true, RX>, L::kBytes, lds_ok, "stream_gemm_glds"))
     return 1;
-  hipLaunchKernelGGL((stream_gemm_glds_kernel<T, MT, NG, NW, R, EPI>), dim3(n_rb, ksp), dim3(64 * NW), L::kBytes, st,
+  hipLaunchKernelGGL((stream_gemm_glds_kernel<T, MT, NG, NW, R, EPI, false, true, RX>), dim3(n_rb, ksp), dim3(64 * NW), L::kBytes, st,
                      out, planes, x, w, M, N, K, ldx, ldo, per, planes_only_ks ? 1 : 0);
   }
   int rc = launch_status("stream_gemm_glds");
@@ -451,8 +479,8 @@ int semipd_stream_linear(void* out, const void* x, const void* weight, void* wor
   SEMIPD_CHECK_ARG(rows >= 0 && n > 0 && k > 0 && ldx >= k, SEMIPD_EINVAL, "stream_linear: bad sizes");
   if (rows == 0) return 0;
   SEMIPD_CHECK_ARG(out && x && weight, SEMIPD_EINVAL, "stream_linear: null pointer");
-  SEMIPD_CHECK_ARG(rows <= 64, SEMIPD_ESHAPE, "stream_linear: %lld rows; this is the weight-streaming path for decode "
-                   "batches of at most 64 rows", (long long)rows);
+  SEMIPD_CHECK_ARG(rows <= 128, SEMIPD_ESHAPE, "stream_linear: %lld rows; this is the weight-streaming path for decode "
+                   "batches of at most 128 rows", (long long)rows);
   const int64_t n_out = fuse_silu_mul ? n / 2 : n;
   SEMIPD_CHECK_ARG(ldo >= n_out && (!fuse_silu_mul || n % 2 == 0), SEMIPD_EINVAL, "stream_linear: ldo < output width");
   SEMIPD_CHECK_ARG(k % 128 == 0 && ldx % 8 == 0 && n_out % 16 == 0 && ldo % 4 == 0 && aligned16(x) && aligned16(weight) &&
@@ -475,9 +503,17 @@ int semipd_stream_linear(void* out, const void* x, const void* weight, void* wor
 #define SL_GO(MTV, RV) \
   if (fuse_silu_mul) { SEMIPD_DISPATCH_HALF(dtype, T, rc = (sg_launch<T, MTV, 2, 4, RV, SL_SILU_MUL>((T*)out, planes, pb, (const T*)x, (const T*)weight, M, N, K, ldx, ldo, force_ks, st))); } \
   else { SEMIPD_DISPATCH_HALF(dtype, T, rc = (sg_launch<T, MTV, 1, 8, RV, SL_PLAIN>((T*)out, planes, pb, (const T*)x, (const T*)weight, M, N, K, ldx, ldo, force_ks, st))); }
+  // 65 .. 128 rows (SL_WIDE): two weight-row groups per wave (an activation fragment feeds two MFMAs: the LDS reads per
+  // weight byte of MT = 8 with one group would be the bound), four waves, weight rings of three slots and an activation
+  // ring of TWO -- a block of 128 rows is 32 KB: 64 + 96 KB is the CU's LDS to the byte
+#define SL_WIDE(MTV) \
+  if (fuse_silu_mul) { SEMIPD_DISPATCH_HALF(dtype, T, rc = (sg_launch<T, MTV, 2, 4, 3, SL_SILU_MUL, 2>((T*)out, planes, pb, (const T*)x, (const T*)weight, M, N, K, ldx, ldo, force_ks, st))); } \
+  else { SEMIPD_DISPATCH_HALF(dtype, T, rc = (sg_launch<T, MTV, 2, 4, 3, SL_PLAIN, 2>((T*)out, planes, pb, (const T*)x, (const T*)weight, M, N, K, ldx, ldo, force_ks, st))); }
   if (mt == 1) { if (deep) { SL_GO(1, 4) } else { SL_GO(1, 3) } }
   else if (mt == 2) { if (deep) { SL_GO(2, 4) } else { SL_GO(2, 3) } }
-  else if (mt == 3) { SL_GO(3, 3) } else { SL_GO(4, 3) }
+  else if (mt == 3) { SL_GO(3, 3) } else if (mt == 4) { SL_GO(4, 3) }
+  else if (mt <= 6) { SL_WIDE(6) } else { SL_WIDE(8) }
+#undef SL_WIDE
 #undef SL_GO
   return rc;
 }
@@ -486,7 +522,7 @@ int semipd_stream_linear(void* out, const void* x, const void* weight, void* wor
  * semipd_stream_linear_workspace bytes), for a consumer that sums them itself (semipd_fused_add_rmsnorm_planes). */
 int semipd_stream_linear_planes(float* planes, size_t planes_bytes, const void* x, const void* weight, int64_t rows,
                                 int64_t n, int64_t k, int64_t ldx, int dtype, int* ksplit, void* stream) {
-  SEMIPD_CHECK_ARG(rows > 0 && rows <= 64 && n > 0 && k > 0 && ldx >= k && ksplit, SEMIPD_EINVAL,
+  SEMIPD_CHECK_ARG(rows > 0 && rows <= 128 && n > 0 && k > 0 && ldx >= k && ksplit, SEMIPD_EINVAL,
                    "stream_linear_planes: bad sizes");
   SEMIPD_CHECK_ARG(planes && x && weight, SEMIPD_EINVAL, "stream_linear_planes: null pointer");
   SEMIPD_CHECK_ARG(k % 128 == 0 && ldx % 8 == 0 && n % 16 == 0 && aligned16(x) && aligned16(weight) && aligned16(planes) &&
@@ -500,9 +536,13 @@ int semipd_stream_linear_planes(float* planes, size_t planes_bytes, const void* 
   const bool deep = mt <= 2 && ring_knob >= 4;
 #define SL_GO(MTV, RV) \
   SEMIPD_DISPATCH_HALF(dtype, T, rc = (sg_launch<T, MTV, 1, 8, RV, SL_PLAIN>((T*)nullptr, planes, planes_bytes, (const T*)x, (const T*)weight, M, N, K, ldx, N, sl_env("SEMIPD_SL_KS", 0), st, ksplit)));
+#define SL_WIDE(MTV) \
+  SEMIPD_DISPATCH_HALF(dtype, T, rc = (sg_launch<T, MTV, 2, 4, 3, SL_PLAIN, 2>((T*)nullptr, planes, planes_bytes, (const T*)x, (const T*)weight, M, N, K, ldx, N, sl_env("SEMIPD_SL_KS", 0), st, ksplit)));
   if (mt == 1) { if (deep) { SL_GO(1, 4) } else { SL_GO(1, 3) } }
   else if (mt == 2) { if (deep) { SL_GO(2, 4) } else { SL_GO(2, 3) } }
-  else if (mt == 3) { SL_GO(3, 3) } else { SL_GO(4, 3) }
+  else if (mt == 3) { SL_GO(3, 3) } else if (mt == 4) { SL_GO(4, 3) }
+  else if (mt <= 6) { SL_WIDE(6) } else { SL_WIDE(8) }
+#undef SL_WIDE
 #undef SL_GO
   return rc;
 }

@@ -8,7 +8,7 @@ torch.nn.Module over the HIP operators (semi_pd_amd.ops).  Class names follow th
   LogitsProcessor             layers/logits_processor.py:220-445
   Sampler                     layers/sampler.py:29-171 (greedy branch)
 Dense GEMMs: hipBLASLt through F.linear (SURVEY §2.2 "TP linear") for prefill-sized calls, the persistent
-weight-streaming kernel (ops.stream_linear) for batches of at most 64 rows, i.e. every decode step.
+weight-streaming kernel (ops.stream_linear) for batches of at most 128 rows, i.e. every decode step.
 """
 from __future__ import annotations
 
@@ -196,7 +196,7 @@ def get_rope(head_size: int, rotary_dim: int, max_position: int, base: float, is
 
 
 # --------------------------------------------------------------------------- dense GEMM dispatch
-# Batches of at most 64 rows (decode steps, a short last chunk of a prefill) go through the LDS-DMA
+# Batches of at most 128 rows (decode steps, a short last chunk of a prefill) go through the LDS-DMA
 # weight-streaming kernel (csrc/stream_linear.hip); everything else stays on hipBLASLt (F.linear).
 _STREAM_LINEAR = {"enabled": False, "timing": None}
 
@@ -236,7 +236,7 @@ def dense_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """UnquantizedLinearMethod.apply (layers/linear.py:165-172).  `out`: a [rows, n] view with unit inner stride to write
     into (the token chunks of RowParallelLinear._forward_overlapped)."""
-    if (_STREAM_LINEAR["enabled"] and bias is None and x.dim() == 2 and x.shape[0] <= ops.STREAM_LINEAR_MAX_ROWS
+    if (_STREAM_LINEAR["enabled"] and bias is None and x.dim() == 2 and x.shape[0] <= ops.STREAM_LINEAR_DENSE_MAX_ROWS
             and ops.stream_linear_is_supported(x, weight)):
         return _timed_stream(lambda: ops.stream_linear(x, weight, out=out), x, weight, weight.shape[0], 2)
     if _STREAM_LINEAR["enabled"] and bias is None and x.dim() == 2 and _takes_tiled_gemm(x, weight):
@@ -265,7 +265,7 @@ _TALL_PLANES = os.environ.get("SEMIPD_TALL_PLANES", "0") == "1"
 def _takes_tiled_gemm(x: torch.Tensor, weight: torch.Tensor) -> bool:
     """dense_linear's two conditions for ops.gemm_tall, bias-free call."""
     rows = x.shape[0]
-    if ops.STREAM_LINEAR_MAX_ROWS < rows <= GEMM_TALL_MAX_ROWS:
+    if ops.STREAM_LINEAR_DENSE_MAX_ROWS < rows <= GEMM_TALL_MAX_ROWS:
         return not ops.dense_gemm_is_tuned(weight) and ops.gemm_tall_is_supported(x, weight)
     return rows > GEMM_TALL_MAX_ROWS and ops.tall_preferred(weight, rows) and ops.gemm_tall_is_supported(x, weight)
 
@@ -273,13 +273,13 @@ def _takes_tiled_gemm(x: torch.Tensor, weight: torch.Tensor) -> bool:
 def gate_up_silu(x: torch.Tensor, gate_up_proj: "MergedColumnParallelLinear", act_fn) -> torch.Tensor:
     """act_fn(gate_up_proj(x)) (models/llama.py:88-92); one launch for decode batches of a bf16 / f16 layer."""
     if (_STREAM_LINEAR["enabled"] and gate_up_proj.quant_config is None and gate_up_proj.bias is None
-            and isinstance(act_fn, SiluAndMul) and x.dim() == 2 and x.shape[0] <= ops.STREAM_LINEAR_MAX_ROWS
+            and isinstance(act_fn, SiluAndMul) and x.dim() == 2 and x.shape[0] <= ops.STREAM_LINEAR_DENSE_MAX_ROWS
             and ops.stream_linear_is_supported(x, gate_up_proj.weight, fuse_silu_mul=True)):
         w = gate_up_proj.weight
         return _timed_stream(lambda: ops.stream_linear(x, w, fuse_silu_mul=True), x, w, w.shape[0] // 2, 1)
     if (_STREAM_LINEAR["enabled"] and gate_up_proj.quant_config is None and gate_up_proj.bias is None
             and isinstance(act_fn, SiluAndMul) and x.dim() == 2
-            and ops.STREAM_LINEAR_MAX_ROWS < x.shape[0] <= GEMM_TALL_MAX_ROWS
+            and ops.STREAM_LINEAR_DENSE_MAX_ROWS < x.shape[0] <= GEMM_TALL_MAX_ROWS
             and not ops.dense_gemm_is_tuned(gate_up_proj.weight)
             and ops.gemm_tall_is_supported(x, gate_up_proj.weight, fuse_silu_mul=True)):
         return ops.gemm_tall(x, gate_up_proj.weight, fuse_silu_mul=True)   # SiLU * mul in the GEMM's epilogue
@@ -352,7 +352,7 @@ class ColumnParallelLinear(nn.Module):
         """Decode batches of an unquantised, bias-free layer: the K-slice planes of the streaming GEMM (ops.SplitKPlanes)
         for a consumer that sums them itself, or None when this call is not eligible."""
         if (_STREAM_LINEAR["enabled"] and self.quant_config is None and self.bias is None and x.dim() == 2
-                and x.shape[0] <= ops.STREAM_LINEAR_MAX_ROWS and self.weight.shape[0] % 8 == 0
+                and x.shape[0] <= ops.STREAM_LINEAR_DENSE_MAX_ROWS and self.weight.shape[0] % 8 == 0
                 and ops.stream_linear_is_supported(x, self.weight)):
             return _timed_stream(lambda: ops.stream_linear_planes(x, self.weight), x, self.weight, self.weight.shape[0], 1)
         return None
@@ -469,7 +469,7 @@ class RowParallelLinear(nn.Module):
         kernel does the reduction."""
         if (defer_reduce and _STREAM_LINEAR["enabled"] and self.quant_config is None and self.bias is None
                 and get_tensor_model_parallel_world_size() == 1 and x.dim() == 2
-                and x.shape[0] <= ops.STREAM_LINEAR_MAX_ROWS and self.weight.shape[0] % 8 == 0
+                and x.shape[0] <= ops.STREAM_LINEAR_DENSE_MAX_ROWS and self.weight.shape[0] % 8 == 0
                 and ops.stream_linear_is_supported(x, self.weight)):
             return _timed_stream(lambda: ops.stream_linear_planes(x, self.weight), x, self.weight, self.weight.shape[0], 1)
         if (defer_reduce and _TALL_PLANES and _STREAM_LINEAR["enabled"] and self.quant_config is None and self.bias is None

@@ -12,6 +12,7 @@ launches on torch's *current* stream and never synchronises.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -555,11 +556,14 @@ def dense_gemm(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tenso
     return out
 
 
-STREAM_LINEAR_MAX_ROWS = 64
+STREAM_LINEAR_MAX_ROWS = 64      # the fp32, fused lm_head and grouped (MoE) forms of the streaming kernel
+# dense layers (semipd_stream_linear / _planes): up to 128 rows -- four waves of 2 x 16 weight rows, an activation ring of two
+# blocks under weight rings of three (csrc/stream_linear.hip).  SEMIPD_SL_WIDE=0: 65+ rows go to the tiled GEMM as before.
+STREAM_LINEAR_DENSE_MAX_ROWS = 128 if os.environ.get("SEMIPD_SL_WIDE", "1") != "0" else 64
 
 
 def stream_linear_is_supported(x: torch.Tensor, weight: torch.Tensor, fuse_silu_mul: bool = False) -> bool:
-    if not (x.is_cuda and x.dim() == 2 and weight.dim() == 2 and 0 < x.shape[0] <= STREAM_LINEAR_MAX_ROWS
+    if not (x.is_cuda and x.dim() == 2 and weight.dim() == 2 and 0 < x.shape[0] <= STREAM_LINEAR_DENSE_MAX_ROWS
             and x.dtype == weight.dtype and x.dtype in (torch.bfloat16, torch.float16)
             and x.stride(1) == 1 and weight.is_contiguous() and x.shape[1] == weight.shape[1]):
         return False
@@ -571,7 +575,7 @@ def stream_linear_is_supported(x: torch.Tensor, weight: torch.Tensor, fuse_silu_
 
 def stream_linear(x: torch.Tensor, weight: torch.Tensor, fuse_silu_mul: bool = False,
                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """x @ weight.T for decode batches (at most 64 rows) with the LDS-DMA weight-streaming kernel; fuse_silu_mul:
+    """x @ weight.T for decode batches (at most 128 rows) with the LDS-DMA weight-streaming kernel; fuse_silu_mul:
     weight = merged [gate; up] and the result is SiluAndMul(x @ weight.T)
     (UnquantizedLinearMethod.apply layers/linear.py:165-172; LlamaMLP models/llama.py:88-92)."""
     if not stream_linear_is_supported(x, weight, fuse_silu_mul):

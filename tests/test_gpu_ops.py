@@ -1004,7 +1004,7 @@ def test_linear_strided_rows_and_f16(ops, device):
 
 
 # ----------------------------------------------------------------------------- decode batches: LDS-DMA streaming linear
-@pytest.mark.parametrize("M", [1, 7, 16, 17, 33, 48, 64])
+@pytest.mark.parametrize("M", [1, 7, 16, 17, 33, 48, 64, 65, 80, 96, 97, 128])   # 65+: the wide form (rings of 2 / 3 slots)
 @pytest.mark.parametrize("N,K", [(4096, 4096), (6144, 4096), (28672, 4096), (4096, 14336), (1008, 512), (16, 1024),
                                  # Llama-3-8B per rank at TP = 8 / TP = 4: qkv, o_proj, down_proj
                                  (768, 4096), (4096, 512), (4096, 1792), (1536, 4096), (4096, 1024), (4096, 3584)])
@@ -1020,7 +1020,7 @@ def test_stream_linear(ops, device, M, N, K):
     assert torch.equal(got, ops.stream_linear(x.to(device), w.to(device)))
 
 
-@pytest.mark.parametrize("M", [1, 16, 31, 64])
+@pytest.mark.parametrize("M", [1, 16, 31, 64, 66, 96, 128])
 @pytest.mark.parametrize("inter,K", [(14336, 4096), (1408, 2048), (48, 512), (1792, 4096), (3584, 4096)])   # last two: TP = 8 / 4
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_stream_linear_fused_silu_mul(ops, device, M, inter, K, dtype):
@@ -1050,14 +1050,15 @@ def test_stream_linear_strided_rows_and_limits(ops, device):
     x = big.to(device)[:, 512:]  # row stride 1024, 16-byte aligned start
     got = ops.stream_linear(x, w.to(device))
     torch.testing.assert_close(got.cpu().float(), big[:, 512:].float() @ w.float().T, rtol=2e-3, atol=2e-2)
-    assert not ops.stream_linear_is_supported(torch.randn(65, 512, device=device, dtype=torch.float16), w.to(device))
+    assert ops.stream_linear_is_supported(torch.randn(128, 512, device=device, dtype=torch.float16), w.to(device))
+    assert not ops.stream_linear_is_supported(torch.randn(129, 512, device=device, dtype=torch.float16), w.to(device))
     assert not ops.stream_linear_is_supported(torch.randn(8, 96, device=device, dtype=torch.float16),
                                               torch.randn(64, 96, device=device, dtype=torch.float16))  # k % 128
     with pytest.raises(RuntimeError):
-        ops.stream_linear(torch.randn(65, 512, device=device, dtype=torch.float16), w.to(device))
+        ops.stream_linear(torch.randn(129, 512, device=device, dtype=torch.float16), w.to(device))
 
 
-@pytest.mark.parametrize("M", [1, 16, 40, 64])
+@pytest.mark.parametrize("M", [1, 16, 40, 64, 72, 128])
 @pytest.mark.parametrize("N,K", [(4096, 4096), (4096, 14336), (2048, 1280), (512, 1024)])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_stream_linear_planes_into_fused_add_rmsnorm(ops, device, M, N, K, dtype):
