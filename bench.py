@@ -54,7 +54,9 @@ SLO_TPOT_P99_MS = 15.0
 # token check of the timed engines (bench_one_batch.py:16-41 `--correct` keeps a known-answer probe for the same purpose):
 # requests of these lengths, this many greedy tokens each, Semi-PD against the unified engine; they may part ways only at a
 # near-tie of the unified engine's own top-2 log-probabilities (tests/test_gpu_full_depth.py: same rule, same margin)
-TOKEN_CHECK_LENS = (64, 200, 1024, 7)
+# sixteen requests sent together: the decode batch reaches 16 requests, from where a Llama decode step takes the fused
+# RoPE + attention launch (layers/attention_backend.py: fused_decode_waves) -- the check must run what the timed waves ran
+TOKEN_CHECK_LENS = (64, 200, 1024, 7) * 4
 TOKEN_CHECK_STEPS = 8
 TOKEN_CHECK_MARGIN = 0.15
 
@@ -616,7 +618,7 @@ def main():
                 recs, dur = run_wave(engine, prompts, arrival_times(args.num_requests, 0.0, args.seed), args.output_len)
                 sm = summarize(recs, dur)
                 saturation = _rounded(sm)
-        # token check, first half: the engine that was just timed produces TOKEN_CHECK_STEPS tokens for four requests; the
+        # token check, first half: the engine that was just timed produces TOKEN_CHECK_STEPS tokens for sixteen requests; the
         # unified engine below is the reference they are compared with
         probes = {}
         want_token_check = (world == 1 and args.mode == "semi-pd" and not args.no_unified_wave and not args.no_token_check)
@@ -769,8 +771,15 @@ def main():
                     "event_pair_overhead_us": kt.get("_event_pair_overhead_us"),
                     "algorithmic_bytes_per_launch": int(k["bytes_per_launch"]), "launches_sampled": k["launches"]}
         if "decode_attention" in kt:
-            kname = ("mla_decode_kernel" if "Deepseek" in cfg.architectures[0] else "decode_mfma_kernel")
-            attn_line = hbm_line(kt["decode_attention"], kname + " + decode_stage2_kernel (one decode_attention call)")
+            if "Deepseek" in cfg.architectures[0]:
+                kname = "mla_decode_kernel + decode_stage2_kernel (one decode_attention call)"
+            elif os.environ.get("SEMIPD_FUSED_DECODE_ATTN", "1") != "0" and cfg.architectures[0] == "LlamaForCausalLM":
+                # csrc/decode_attention_fused.hip; batches under half a workgroup per CU keep the separate launches
+                kname = ("decode_rope_attn_kernel (qkv planes -> RoPE + KV store + paged attention + merge of the kv splits, "
+                         "ONE launch per layer; the separate launches below 16 requests)")
+            else:
+                kname = "decode_mfma_kernel + decode_stage2_kernel (one decode_attention call)"
+            attn_line = hbm_line(kt["decode_attention"], kname)
             if "stream_linear" in kt:
                 # the dominant kernel of the decode instance by GPU time is the weight-streaming GEMM
                 # (profiles/r02_bench_n1_decode_proc_kernel_stats_*.csv): qkv / o / gate_up + SiLU*mul / down of the

@@ -251,8 +251,10 @@ class HipAttnBackend(AttentionBackend):
         workgroups are (request, kv head) pairs with that many waves as kv splits (ops.decode_rope_attention_planes,
         csrc/decode_attention_fused.hip).  The fused form needs about one workgroup per two CUs to fill the chip;
         smaller batches keep the separate launches, whose split count is free (choose_kv_splits).
-        SEMIPD_FUSED_DECODE_ATTN=0 turns it off; a fixed --triton-attention-num-kv-splits keeps the reference's form."""
-        if self.is_mla or self.fixed_kv_splits or os.environ.get("SEMIPD_FUSED_DECODE_ATTN", "1") == "0":
+        SEMIPD_FUSED_DECODE_ATTN=0 turns it off, =2 takes it at every batch size (tests); a fixed
+        --triton-attention-num-kv-splits keeps the reference's form."""
+        knob = os.environ.get("SEMIPD_FUSED_DECODE_ATTN", "1")
+        if self.is_mla or self.fixed_kv_splits or knob == "0":
             return 0
         key = (head_dim,)
         ok = self._fused_decode_ok.get(key)
@@ -265,7 +267,7 @@ class HipAttnBackend(AttentionBackend):
         wgs, cus = bs * self.num_kv_head, max(1, self.num_cus)
         if wgs >= 2 * cus:
             return 4
-        return 8 if 2 * wgs >= cus else 0
+        return 8 if (2 * wgs >= cus or knob == "2") else 0
 
     def forward_decode_rope_planes(self, positions, qkv_planes, rotary_emb, layer, forward_batch: ForwardBatch, waves: int):
         md = self.forward_metadata

@@ -125,6 +125,39 @@ def test_unified_is_deterministic_and_graph_equals_eager(unified_llama):
         eager.shutdown()
 
 
+def test_fused_decode_launch_and_wide_decode_batches_match_oracle(unified_llama, monkeypatch):
+    """Two decode-step paths the small batches above never reach, engine tokens against the teacher-forced oracle:
+    (1) SEMIPD_FUSED_DECODE_ATTN=2 -- every Llama decode batch through the one-launch RoPE + KV store + attention + split
+        merge (csrc/decode_attention_fused.hip; by default only from about half a workgroup per CU up), eager and in graphs;
+    (2) 80 requests at once -- decode batches of 65+ rows: the streaming GEMM's wide form (csrc/stream_linear.hip) and, at
+        2 kv heads x 80 requests, the fused launch by its own rule."""
+    from semi_pd_amd.entrypoints.engine import Engine
+    from semi_pd_amd.managers.io_struct import SamplingParams
+    cfg, sd, prompts, outs, _ = unified_llama
+    oracle = OracleLlama(cfg, sd)
+    monkeypatch.setenv("SEMIPD_FUSED_DECODE_ATTN", "2")
+    for eager in (False, True):
+        eng = Engine(server_args(cfg, disable_cuda_graph=eager))
+        try:
+            assert eng.model_runner.attn_backend.fused_decode_waves(3, 128) == 8
+            got = eng.generate(prompts, SamplingParams(max_new_tokens=12, ignore_eos=True))
+        finally:
+            eng.shutdown()
+        if got != outs:   # other kv splits than the fixture's engine: only near-ties may flip
+            _explain_mismatch(oracle, prompts, got, outs)
+        check_against_oracle(oracle, prompts, got)
+    monkeypatch.delenv("SEMIPD_FUSED_DECODE_ATTN")
+    many = make_prompts(cfg.vocab_size, [5 + (7 * i) % 60 for i in range(80)], seed=11)
+    eng = Engine(server_args(cfg, max_running_requests=96, cuda_graph_max_bs=96, max_total_tokens=12000))
+    try:
+        assert eng.model_runner.attn_backend.fused_decode_waves(80, 128) == 8
+        got = eng.generate(many, SamplingParams(max_new_tokens=6, ignore_eos=True))
+    finally:
+        eng.shutdown()
+    assert all(len(o) == 6 for o in got)
+    check_against_oracle(oracle, many, got)
+
+
 def test_opt_matches_hf_weights(device):
     transformers = pytest.importorskip("transformers")
     from oracle.hf_convert import opt_from_hf, pad_vocab

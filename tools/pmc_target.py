@@ -1,5 +1,5 @@
 """One fixed launch shape of the dominant kernels, for rocprofv3 --pmc passes (HBM traffic check).
-Usage: python tools/pmc_target.py [decode|mla|fp8mm]"""
+Usage: python tools/pmc_target.py [decode|decode32|decode32_fused|mla|fp8mm|...]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "semi-pd_amd")]
@@ -38,6 +38,29 @@ elif which == "decode32":
         kb, vb = sets[i % 3]
         ops.decode_attention_fwd(q, kb, vb, o, indptr, idx, lg, splits, D ** -0.5)
     print("splits", splits, "algorithmic_bytes_per_launch", B * ctx * Hkv * 2 * D * 2 + 2 * B * Hq * D * 2)
+elif which == "decode32_fused":
+    # the same call through the fused decode launch (csrc/decode_attention_fused.hip): planes of a qkv GEMM in, RoPE + KV store +
+    # attention + split merge; 8 waves = 8 kv splits per (request, kv head)
+    B, ctx, Hq, Hkv, D, K = 32, 1100, 32, 8, 128, 4096
+    N = B * ctx + 1
+    sets = []
+    for _ in range(3):
+        sets.append((torch.randn(N, Hkv, D, device=dev, dtype=torch.bfloat16), torch.randn(N, Hkv, D, device=dev, dtype=torch.bfloat16)))
+    x = torch.randn(B, K, device=dev, dtype=torch.bfloat16)
+    w = torch.randn((Hq + 2 * Hkv) * D, K, device=dev, dtype=torch.bfloat16) * 0.02
+    indptr = torch.arange(B + 1, device=dev, dtype=torch.int32) * ctx
+    idx = (torch.randperm(N - 1, device=dev)[: B * ctx] + 1).to(torch.int32)
+    loc = idx[(indptr[1:] - 1).long()].to(torch.int64)
+    pos = torch.full((B,), ctx - 1, device=dev, dtype=torch.int64)
+    inv = 1.0 / (500000 ** (torch.arange(0, D, 2, dtype=torch.float) / D))
+    fr = torch.einsum("i,j -> ij", torch.arange(2048, dtype=torch.float), inv)
+    cache = torch.cat((fr.cos(), fr.sin()), dim=-1).to(dev)
+    for i in range(12):
+        kb, vb = sets[i % 3]
+        planes = ops.stream_linear_planes(x, w)
+        ops.decode_rope_attention_planes(pos, planes, Hq, Hkv, D, cache, kb, vb, loc, indptr, idx, 8, D ** -0.5)
+    print("planes", planes.ksplit, "algorithmic_bytes_per_launch",
+          B * ctx * Hkv * 2 * D * 2 + B * Hq * D * 2 + planes.ksplit * B * (Hq + 2 * Hkv) * D * 4 + 2 * B * Hkv * D * 2)
 elif which == "mla":
     B, ctx, H, splits = 128, 8192, 16, 4
     N = B * ctx + 1
