@@ -367,10 +367,10 @@ splitk_planes_reduce_kernel(T* __restrict__ out, const float* __restrict__ plane
 // process declares (semipd_stream_linear_set_cus); two processes that must produce the same bits declare the same.
 static std::atomic<int> g_sl_cus{128};
 
-static int sg_pick_ksplit(int n_rb, int nkb, int M, int N, bool extra_reduce_launch) {
-  const int cus = max(8, g_sl_cus.load(std::memory_order_relaxed));
+static int sg_pick_ksplit(int n_rb, int nkb, int M, int N, bool extra_reduce_launch, int wgs_per_cu = 1) {
+  const int cus = max(8, g_sl_cus.load(std::memory_order_relaxed)) * wgs_per_cu;
   const float t_block = 0.86f, t_round = 2.0f;
-  const float plane_us = 2.f * M * (float)N * 4.f / (cus * 37e3f);   // one plane written + read back
+  const float plane_us = 2.f * M * (float)N * 4.f / (cus / wgs_per_cu * 37e3f);   // one plane written + read back
   int best = 1;
   float best_cost = 1e30f;
   for (int ksp = 1; ksp <= 16; ++ksp) {
@@ -398,7 +398,9 @@ static int sg_launch(T* out, float* planes, size_t planes_bytes, const T* x, con
   const int nkb = K / 128;
   // (the separate-reduction charge applies to the SiLU epilogue only: a plain layer's planes are usually summed by its
   //  consumer, and its reducing and plane-returning forms must pick the SAME split to produce the same bits)
-  int ksp = force_ks > 0 ? force_ks : sg_pick_ksplit(n_rb, nkb, M, N, EPI == SL_SILU_MUL);
+  // (four-wave workgroups of the plain epilogue at <= 32 rows: 72 KB of LDS, two of them share a CU)
+  const int wgs_per_cu = (EPI == SL_PLAIN && NW == 4 && NG == 1 && RX == R && L::kBytes * 2 <= 160 * 1024) ? 2 : 1;
+  int ksp = force_ks > 0 ? force_ks : sg_pick_ksplit(n_rb, nkb, M, N, EPI == SL_SILU_MUL, wgs_per_cu);
   while (ksp > 1 && (size_t)ksp * M * N * 4 > planes_bytes) --ksp;
   const int per = (nkb + ksp - 1) / ksp;
   ksp = (nkb + per - 1) / per;
@@ -469,6 +471,21 @@ int semipd_stream_linear_set_cus(int cus) {
   return 0;
 }
 
+// Narrow workgroups (four waves = 64 weight rows, 72 KB of LDS: two per CU) for the plain epilogue at <= 32 rows of a SMALL
+// weight: o_proj of Llama-3-8B (4096 x 4096) is 32 workgroups of 128 rows per K slice -- with the four slices the cost rule
+// picks, a workgroup on half of the chip's CUs, and what a CU pulls from HBM is the limit this kernel runs into.  Measured
+// (profiles/r06_kbench_narrow_workgroups.txt, 32 rows, whole chip): o_proj 10.4 -> 8.5 us, the 70B TP = 8 rank's qkv (1280 x
+// 8192) 10.0 -> 7.7, its o_proj (8192 x 1024) 7.2 -> 6.1; no gain from 25 M weight elements up (qkv 8B, down_proj).
+// SEMIPD_SL_NW: 4 = always where it applies, 8 = never; otherwise weights of at most SEMIPD_SL_NARROW_MAX_NK elements (2^24).
+static bool sg_narrow(int mt, int N, int K, int fuse_silu_mul) {
+  if (fuse_silu_mul || mt > 2) return false;
+  const int knob = sl_env("SEMIPD_SL_NW", 0);
+  if (knob == 4) return true;
+  if (knob == 8) return false;
+  static const int64_t max_nk = [] { const char* e = getenv("SEMIPD_SL_NARROW_MAX_NK"); return e ? atoll(e) : (1ll << 24); }();
+  return (int64_t)N * K <= max_nk;
+}
+
 size_t semipd_stream_linear_workspace(int64_t max_n) {
   return (size_t)16 * 64 * (size_t)max_n * 4;   // 16 K slices of [64 rows, n] fp32
 }
@@ -509,7 +526,11 @@ int semipd_stream_linear(void* out, const void* x, const void* weight, void* wor
 #define SL_WIDE(MTV) \
   if (fuse_silu_mul) { SEMIPD_DISPATCH_HALF(dtype, T, rc = (sg_launch<T, MTV, 2, 4, 3, SL_SILU_MUL, 2>((T*)out, planes, pb, (const T*)x, (const T*)weight, M, N, K, ldx, ldo, force_ks, st))); } \
   else { SEMIPD_DISPATCH_HALF(dtype, T, rc = (sg_launch<T, MTV, 2, 4, 3, SL_PLAIN, 2>((T*)out, planes, pb, (const T*)x, (const T*)weight, M, N, K, ldx, ldo, force_ks, st))); }
-  if (mt == 1) { if (deep) { SL_GO(1, 4) } else { SL_GO(1, 3) } }
+  if (sg_narrow(mt, N, K, fuse_silu_mul)) {
+    if (mt == 1) { SEMIPD_DISPATCH_HALF(dtype, T, rc = (sg_launch<T, 1, 1, 4, 3, SL_PLAIN>((T*)out, planes, pb, (const T*)x, (const T*)weight, M, N, K, ldx, ldo, force_ks, st))); }
+    else { SEMIPD_DISPATCH_HALF(dtype, T, rc = (sg_launch<T, 2, 1, 4, 3, SL_PLAIN>((T*)out, planes, pb, (const T*)x, (const T*)weight, M, N, K, ldx, ldo, force_ks, st))); }
+  }
+  else if (mt == 1) { if (deep) { SL_GO(1, 4) } else { SL_GO(1, 3) } }
   else if (mt == 2) { if (deep) { SL_GO(2, 4) } else { SL_GO(2, 3) } }
   else if (mt == 3) { SL_GO(3, 3) } else if (mt == 4) { SL_GO(4, 3) }
   else if (mt <= 6) { SL_WIDE(6) } else { SL_WIDE(8) }
@@ -538,7 +559,11 @@ int semipd_stream_linear_planes(float* planes, size_t planes_bytes, const void* 
   SEMIPD_DISPATCH_HALF(dtype, T, rc = (sg_launch<T, MTV, 1, 8, RV, SL_PLAIN>((T*)nullptr, planes, planes_bytes, (const T*)x, (const T*)weight, M, N, K, ldx, N, sl_env("SEMIPD_SL_KS", 0), st, ksplit)));
 #define SL_WIDE(MTV) \
   SEMIPD_DISPATCH_HALF(dtype, T, rc = (sg_launch<T, MTV, 2, 4, 3, SL_PLAIN, 2>((T*)nullptr, planes, planes_bytes, (const T*)x, (const T*)weight, M, N, K, ldx, N, sl_env("SEMIPD_SL_KS", 0), st, ksplit)));
-  if (mt == 1) { if (deep) { SL_GO(1, 4) } else { SL_GO(1, 3) } }
+  if (sg_narrow(mt, N, K, 0)) {
+    if (mt == 1) { SEMIPD_DISPATCH_HALF(dtype, T, rc = (sg_launch<T, 1, 1, 4, 3, SL_PLAIN>((T*)nullptr, planes, planes_bytes, (const T*)x, (const T*)weight, M, N, K, ldx, N, sl_env("SEMIPD_SL_KS", 0), st, ksplit))); }
+    else { SEMIPD_DISPATCH_HALF(dtype, T, rc = (sg_launch<T, 2, 1, 4, 3, SL_PLAIN>((T*)nullptr, planes, planes_bytes, (const T*)x, (const T*)weight, M, N, K, ldx, N, sl_env("SEMIPD_SL_KS", 0), st, ksplit))); }
+  }
+  else if (mt == 1) { if (deep) { SL_GO(1, 4) } else { SL_GO(1, 3) } }
   else if (mt == 2) { if (deep) { SL_GO(2, 4) } else { SL_GO(2, 3) } }
   else if (mt == 3) { SL_GO(3, 3) } else if (mt == 4) { SL_GO(4, 3) }
   else if (mt <= 6) { SL_WIDE(6) } else { SL_WIDE(8) }
