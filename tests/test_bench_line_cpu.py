@@ -148,8 +148,10 @@ def test_the_bench_line_is_assembled_with_every_contract_field(monkeypatch, caps
         # the token check: both Semi-PD engines against the unified engine's tokens; the scripted near-tie is accepted as one
         tc = d["token_check"]
         assert tc["ok"] and [c["engine"] for c in tc["engines"]] == ["semi-pd", "semi-pd 50/50"]
-        assert tc["engines"][0]["equal_requests"] == 4 and tc["engines"][0]["near_tie_divergences"] == []
-        assert tc["engines"][1]["equal_requests"] == 3
+        n_check = len(bench.TOKEN_CHECK_LENS)      # sixteen requests: the decode batch reaches the fused decode launch
+        assert n_check == 16 and tc["prompt_lens"] == list(bench.TOKEN_CHECK_LENS)
+        assert tc["engines"][0]["equal_requests"] == n_check and tc["engines"][0]["near_tie_divergences"] == []
+        assert tc["engines"][1]["equal_requests"] == n_check - 1
         assert tc["engines"][1]["near_tie_divergences"] == [{"request": 1, "step": 2, "top2_logprob_gap": 0.02}]
         assert d["saturation"]["output_tokens"] == 6 * 4
         assert d["steps"] == 2 and d["warmup"] == 1

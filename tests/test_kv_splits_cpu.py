@@ -35,3 +35,36 @@ def test_mla_sixteen_heads_and_the_shared_tile_kernel():
     assert choose_kv_splits(32, 1, 8192, 256, 32, mla=True, mla_heads=128) == 8
     # ... below that the rule of the 16-head kernels
     assert choose_kv_splits(32, 1, 1100, 256, 32, mla=True, mla_heads=128) == choose_kv_splits(32, 1, 1100, 256, 32, mla=True, mla_heads=16)
+
+
+def test_fused_decode_launch_rule(monkeypatch):
+    """HipAttnBackend.fused_decode_waves: the one-launch RoPE + KV store + attention + split merge (csrc/decode_attention_fused.hip)
+    from about half a workgroup (= one (request, kv head)) per CU up -- below that the separate launches keep a free split
+    count --, four waves per workgroup from two workgroups per CU, never for MLA, one q head per kv head, a fixed
+    --triton-attention-num-kv-splits, or when switched off; SEMIPD_FUSED_DECODE_ATTN=2 takes it at every batch size."""
+    import types
+    import torch
+    from semi_pd_amd.layers.attention_backend import HipAttnBackend
+
+    def backend(heads, kv_heads, cus, kind="mha", fixed=None, kv_dtype=None):
+        mr = types.SimpleNamespace(device="cpu", num_attention_heads_local=heads, num_kv_heads_local=kv_heads, v_head_dim=128,
+                                   req_to_token_pool=types.SimpleNamespace(req_to_token=None), max_context_len=8192,
+                                   kv_geometry={"kind": kind}, num_kv_splits=fixed, num_cus_owned=cus, dtype=torch.bfloat16,
+                                   kv_cache_dtype=kv_dtype or torch.bfloat16)
+        return HipAttnBackend(mr)
+
+    monkeypatch.delenv("SEMIPD_FUSED_DECODE_ATTN", raising=False)
+    b = backend(32, 8, 256)                                   # Llama-3-8B on the whole chip
+    assert [b.fused_decode_waves(n, 128) for n in (1, 15, 16, 32, 63, 64, 256)] == [0, 0, 8, 8, 8, 4, 4]
+    assert backend(32, 8, 96).fused_decode_waves(6, 128) == 8           # a 96-CU share: from 6 requests
+    assert backend(8, 1, 256).fused_decode_waves(32, 128) == 0          # the 70B TP = 8 rank: 32 workgroups do not fill the chip
+    assert backend(8, 1, 256).fused_decode_waves(128, 128) == 8
+    assert backend(32, 8, 256, kv_dtype=torch.float8_e4m3fn).fused_decode_waves(32, 128) == 8   # fp8 pool rows
+    assert backend(32, 8, 256).fused_decode_waves(32, 96) == 0          # head size without an instantiation
+    assert backend(12, 12, 256).fused_decode_waves(64, 64) == 0         # MHA: the shuffle kernel's shape
+    assert backend(128, 1, 256, kind="mla").fused_decode_waves(64, 128) == 0
+    assert backend(32, 8, 256, fixed=16).fused_decode_waves(32, 128) == 0
+    monkeypatch.setenv("SEMIPD_FUSED_DECODE_ATTN", "0")
+    assert b.fused_decode_waves(32, 128) == 0
+    monkeypatch.setenv("SEMIPD_FUSED_DECODE_ATTN", "2")
+    assert b.fused_decode_waves(1, 128) == 8 and b.fused_decode_waves(256, 128) == 4

@@ -4,6 +4,7 @@ computation, scheduler-message broadcast, and the Semi-PD P<->D protocol with tw
 instance (rank 0 owns the sockets, rank 1 follows the broadcasts; semi_pd_prefill_scheduler.py:140-147,
 semi_pd_decode_scheduler.py:363-364)."""
 import multiprocessing as mp
+import io
 import os
 import socket
 import sys
@@ -30,7 +31,12 @@ def _run(rank, world, port, fn_name, q, paths):
         from semi_pd_amd import distributed as D
         D.init_distributed_environment(world, rank, f"tcp://127.0.0.1:{port}", backend="gloo")
         out = globals()[fn_name](rank, world)
-        q.put((rank, "ok", out))
+        # as bytes: a tensor on a multiprocessing queue travels as a file descriptor that the parent fetches from THIS
+        # process's resource sharer -- gone if the worker has exited before the parent unpickles (seen as a
+        # FileNotFoundError on the listener socket, one run in a few dozen)
+        buf = io.BytesIO()
+        torch.save(out, buf)
+        q.put((rank, "ok", buf.getvalue()))
         D.destroy_distributed_environment()
     except Exception:
         q.put((rank, "error", traceback.format_exc()))
@@ -49,7 +55,7 @@ def _spawn(fn_name, world=2, timeout=120):
     for _ in range(world):
         rank, status, out = q.get(timeout=timeout)
         assert status == "ok", f"rank {rank}:\n{out}"
-        results[rank] = out
+        results[rank] = torch.load(io.BytesIO(out), weights_only=False)
     for p in procs:
         p.join(30)
     return results
