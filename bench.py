@@ -53,11 +53,13 @@ SLO_ITL_P99_MS = 15.0
 SLO_TPOT_P99_MS = 15.0
 # token check of the timed engines (bench_one_batch.py:16-41 `--correct` keeps a known-answer probe for the same purpose):
 # requests of these lengths, this many greedy tokens each, Semi-PD against the unified engine; they may part ways only at a
-# near-tie of the unified engine's own top-2 log-probabilities (tests/test_gpu_full_depth.py: same rule, same margin)
+# near-tie among the unified engine's own best log-probabilities (tests/test_gpu_full_depth.py: same margin; here up to
+# TOKEN_CHECK_TOP-way: with flat random-weight logits and 128 steps per engine a three-way tie inside the margin was seen)
 # sixteen requests sent together: the decode batch reaches 16 requests, from where a Llama decode step takes the fused
 # RoPE + attention launch (layers/attention_backend.py: fused_decode_waves) -- the check must run what the timed waves ran
 TOKEN_CHECK_LENS = (64, 200, 1024, 7) * 4
 TOKEN_CHECK_STEPS = 8
+TOKEN_CHECK_TOP = 8     # log-probabilities the reference engine returns per step: a near-tie may be three- or four-way
 TOKEN_CHECK_MARGIN = 0.15
 
 HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
@@ -226,13 +228,13 @@ def token_probe(engine, vocab, seed, logprobs=False):
     prompts = [[int((o + j) % vocab) for j in range(n)] for o, n in zip(rs.randint(0, vocab, size=len(TOKEN_CHECK_LENS)), TOKEN_CHECK_LENS)]
     sp = SamplingParams(max_new_tokens=TOKEN_CHECK_STEPS, ignore_eos=True)
     if logprobs:
-        return engine.generate(prompts, sp, timeout=300, return_logprob=True, top_logprobs_num=2)
+        return engine.generate(prompts, sp, timeout=300, return_logprob=True, top_logprobs_num=TOKEN_CHECK_TOP)
     return engine.generate(prompts, sp, timeout=300), None
 
 
 def compare_tokens(name, got, ref, ref_lps):
-    """`got` (an engine under test) against `ref` (the unified engine, with its top-2 log-probabilities per step): equal, or
-    parting at a step where the other token is the reference's runner-up within TOKEN_CHECK_MARGIN."""
+    """`got` (an engine under test) against `ref` (the unified engine, with its TOKEN_CHECK_TOP best log-probabilities per step):
+    equal, or parting at a step where the other token is one the reference rates within TOKEN_CHECK_MARGIN of its own."""
     out = {"engine": name, "requests": len(ref), "tokens_per_request": TOKEN_CHECK_STEPS, "equal_requests": 0,
            "near_tie_divergences": [], "errors": []}
     for i, (a, b) in enumerate(zip(ref, got)):
@@ -244,16 +246,20 @@ def compare_tokens(name, got, ref, ref_lps):
             continue
         s = next(j for j in range(len(a)) if a[j] != b[j])
         try:
-            top = ref_lps[i]["top"][s]
-            (lp1, t1), (lp2, t2) = top[0][:2], top[1][:2]
-            gap = float(lp1) - float(lp2)
+            top = [(float(lp), int(t)) for lp, t in (e[:2] for e in ref_lps[i]["top"][s])]   # the reference's best tokens, best first
+            lp1, t1 = top[0]
         except Exception as e:   # no log-probabilities to judge the divergence by: it counts as an error
-            out["errors"].append(f"request {i} step {s}: {a[s]} vs {b[s]} and no top-2 log-probabilities ({e!r})")
+            out["errors"].append(f"request {i} step {s}: {a[s]} vs {b[s]} and no top log-probabilities ({e!r})")
             continue
-        if t1 == a[s] and b[s] == t2 and gap < TOKEN_CHECK_MARGIN:
-            out["near_tie_divergences"].append({"request": i, "step": s, "top2_logprob_gap": round(gap, 4)})
+        # the engine's token must be one the reference itself rates within the margin of its own choice (its runner-up, or
+        # -- flat random-weight logits, 128 steps per engine -- the third or fourth of a several-way near-tie)
+        rank = next((r for r, (_, t) in enumerate(top) if t == b[s]), None)
+        gap = lp1 - top[rank][0] if rank is not None else float("inf")
+        if t1 == a[s] and rank is not None and rank >= 1 and gap < TOKEN_CHECK_MARGIN:
+            out["near_tie_divergences"].append({"request": i, "step": s, "rank_in_reference": rank + 1, "logprob_gap": round(gap, 4)})
         else:
-            out["errors"].append(f"request {i} step {s}: unified {a[s]} (top-2 {t1}, {t2}, gap {gap:.4f}), {name} {b[s]}")
+            out["errors"].append(f"request {i} step {s}: unified {a[s]} (its top {len(top)}: "
+                                 + ", ".join(f"{t} {lp1 - lp:.4f}" for lp, t in top) + f"), {name} {b[s]}")
     out["ok"] = not out["errors"]
     return out
 
@@ -687,7 +693,7 @@ def main():
             if want_token_check:
                 ref, ref_lps = token_probe(eng5, cfg.vocab_size, args.seed, logprobs=True)
                 checks = [compare_tokens(name, got, ref, ref_lps) for name, got in probes.items()]
-                token_check = {"reference": "the unified engine's tokens and top-2 log-probabilities",
+                token_check = {"reference": f"the unified engine's tokens and top-{TOKEN_CHECK_TOP} log-probabilities",
                                "prompt_lens": list(TOKEN_CHECK_LENS), "margin": TOKEN_CHECK_MARGIN, "engines": checks,
                                "ok": all(c["ok"] for c in checks)}
         except Exception as e:
@@ -789,6 +795,17 @@ def main():
                 extra["decode_attention"] = attn_line
             else:
                 roofline = attn_line
+        if "prefill_gemm" in kt:
+            # the dominant kernels of the PREFILL instance by GPU time: the four dense layers of a sampled batch's first
+            # decoder layer, whatever serves them (layers/basic.py: _timed_gemm), flops = 2 rows n k
+            k = kt["prefill_gemm"]
+            extra["prefill_gemm"] = {"bound": "mfma", "kernel": "the dense layers of a prefill batch (qkv / o / gate_up / down of the "
+                                     "sampled batch's first layer): hipBLASLt solutions timed on the share, gemm8p / gemm4w where "
+                                     "they beat them (SiLU * mul in the epilogue there; the separate silu_and_mul is not in this "
+                                     "interval)", "achieved": round(k["tflops"], 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+                                     "unit": "TFLOP/s", "frac": round(k["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4),
+                                     "avg_launch_us": round(k["avg_us"], 1),
+                                     "flops_per_launch": int(k["flops_per_launch"]), "launches_sampled": k["launches"]}
         if "extend_attention" in kt:
             k = kt["extend_attention"]
             extra["extend_attention"] = {"bound": "mfma", "achieved": round(k["tflops"], 1),

@@ -229,6 +229,22 @@ def _timed_stream(fn, x: torch.Tensor, weight: torch.Tensor, n_out: int, n_kerne
     return out
 
 
+def _timed_gemm(fn, x: torch.Tensor, weight: torch.Tensor, n_out: int):
+    """The four dense layers of the first decoder layer of a sampled PREFILL batch (bench.py's roofline_extra.prefill_gemm):
+    whatever serves them -- a library solution timed on the share, the tiled GEMM, with or without the SiLU epilogue --
+    bracketed like the streaming GEMMs of a decode step; flops = 2 rows n k."""
+    kt = _STREAM_LINEAR["timing"]
+    if kt is None or not kt.active or kt.linear_budget <= 0 or x.dim() != 2 or x.shape[0] <= GEMM_TALL_MAX_ROWS:
+        return fn()
+    kt.linear_budget -= 1
+    t0 = kt.start()
+    out = fn()
+    es = weight.element_size()
+    kt.stop("prefill_gemm", t0, (weight.numel() + x.numel() + x.shape[0] * n_out) * es,
+            2.0 * x.shape[0] * weight.shape[0] * weight.shape[1], 1)
+    return out
+
+
 GEMM_TALL_MAX_ROWS = 256   # above: the library GEMM (prefill-sized; its solution timed on the share where that was asked for)
 
 
@@ -240,13 +256,13 @@ def dense_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
             and ops.stream_linear_is_supported(x, weight)):
         return _timed_stream(lambda: ops.stream_linear(x, weight, out=out), x, weight, weight.shape[0], 2)
     if _STREAM_LINEAR["enabled"] and bias is None and x.dim() == 2 and _takes_tiled_gemm(x, weight):
-        # the tiled ping-pong GEMM (csrc/gemm8p.hip): a tall decode batch (65 .. 256 rows) of an untuned layer, or a
+        # the tiled ping-pong GEMM (csrc/gemm8p.hip): a tall decode batch (129 .. 256 rows) of an untuned layer, or a
         # prefill-sized batch of a shape for which it beat the library's measured winner on this share
-        return ops.gemm_tall(x, weight, out=out)
+        return _timed_gemm(lambda: ops.gemm_tall(x, weight, out=out), x, weight, weight.shape[0])
     if x.dim() == 2 and x.shape[0] > 0 and ops.dense_gemm_is_tuned(weight) and x.stride(1) == 1:
         # prefill-sized batch of a layer whose library solutions were timed on this process's CU share at start-up
         # (ModelRunner.tune_dense_gemms): the measured winner instead of the library's whole-device heuristic
-        return ops.dense_gemm(x, weight, bias, out=out)
+        return _timed_gemm(lambda: ops.dense_gemm(x, weight, bias, out=out), x, weight, weight.shape[0])
     if out is None:
         return F.linear(x, weight, bias)
     # one rounding, like F.linear (mm + a separate add would round twice)
@@ -288,7 +304,8 @@ def gate_up_silu(x: torch.Tensor, gate_up_proj: "MergedColumnParallelLinear", ac
             and ops.tall_preferred(gate_up_proj.weight, x.shape[0], fuse_silu_mul=True)
             and ops.gemm_tall_is_supported(x, gate_up_proj.weight, fuse_silu_mul=True)):
         # prefill-sized batch: the tiled GEMM with the SiLU epilogue beat the library's winner + silu_and_mul on this share
-        return ops.gemm_tall(x, gate_up_proj.weight, fuse_silu_mul=True)
+        w = gate_up_proj.weight
+        return _timed_gemm(lambda: ops.gemm_tall(x, w, fuse_silu_mul=True), x, w, w.shape[0] // 2)
     return act_fn(gate_up_proj(x))
 
 

@@ -48,7 +48,9 @@ class FakeEngine:
             outs[i][st:] = [tok] * (n - st)
         if not return_logprob:
             return outs
-        lps = [{"token": [-0.1] * n, "top": [[(-0.10, o[j]), (-0.10 - FakeEngine.gap, 99)] for j in range(n)]} for o in outs]
+        # the reference's best tokens per step, best first: its own, then 98 and 99 at one and two gaps (a three-way near-tie)
+        lps = [{"token": [-0.1] * n, "top": [[(-0.10, o[j]), (-0.10 - FakeEngine.gap, 98), (-0.10 - 2 * FakeEngine.gap, 99)][:top_logprobs_num]
+                                             for j in range(n)]} for o in outs]
         return outs, lps
 
     def check_children(self):
@@ -67,7 +69,8 @@ class FakeEngine:
                  "t_output_s": 0.09, "kernel_timing": kt},
                 {"role": "PREFILL", "prefill_batches": 568, "prefill_tokens": 786432, "prefill_reqs": 768,
                  "t_wait_admission_s": 0.12, "t_forward_s": 16.9, "late_bound_launches": 287,
-                 "results_sent_from_layer_hook": 271, "kernel_timing": {}, "t_gpu_owned_s": 14.2,
+                 "results_sent_from_layer_hook": 271, "t_gpu_owned_s": 14.2,
+                 "kernel_timing": {"prefill_gemm": {"tflops": 1125.0, "avg_us": 131.0, "flops_per_launch": 147.4e9, "launches": 140}},
                  "step_gate": {"gates": 18176, "holds": 900, "held_ms": 1420.0, "timeouts": 0, "run_ahead_waits_ms": 9000.0,
                                "deadline_ms": 8.25, "deadline_range_ms": [8.0, 10.5], "deadline_trajectory": [[300, 8.25]],
                                "layer_ms_without_hold": 0.62, "layer_intervals_timed": 16276, "layer_ms_with_hold": 1.87,
@@ -121,6 +124,9 @@ def test_the_bench_line_is_assembled_with_every_contract_field(monkeypatch, caps
     assert pb["outside_layers"] == pytest.approx(25.0 - held - nl * 0.62, abs=0.02) and pb["pacer_wait_host"] > 0
     assert pb["step_gate"]["deadline_trajectory"] == [[300, 8.25]] and pb["step_gate"]["deadline_range_ms"] == [8.0, 10.5]
     assert d["roofline_extra"]["extend_attention"]["bound"] == "mfma"
+    pg = d["roofline_extra"]["prefill_gemm"]           # the prefill instance's dominant kernels: live HIP-event timing too
+    assert pg["bound"] == "mfma" and pg["unit"] == "TFLOP/s" and pg["peak"] == 2500.0 and pg["launches_sampled"] == 140
+    assert pg["frac"] == pytest.approx(1125.0 / 2500.0, abs=1e-4) and "hipBLASLt" in pg["kernel"]
     cfgd = d["config"]
     assert "workload" in cfgd and "model" not in cfgd and "CU-masked stream" in cfgd["workload"] and "50 / 50" in cfgd["workload"]
     assert cfgd["prefill_gemm"].startswith("library solutions timed on the prefill share") and "decode step" in cfgd["prefill_gemm"]
@@ -152,7 +158,8 @@ def test_the_bench_line_is_assembled_with_every_contract_field(monkeypatch, caps
         assert n_check == 16 and tc["prompt_lens"] == list(bench.TOKEN_CHECK_LENS)
         assert tc["engines"][0]["equal_requests"] == n_check and tc["engines"][0]["near_tie_divergences"] == []
         assert tc["engines"][1]["equal_requests"] == n_check - 1
-        assert tc["engines"][1]["near_tie_divergences"] == [{"request": 1, "step": 2, "top2_logprob_gap": 0.02}]
+        # (token 99 is the reference's THIRD choice there, 0.04 below its own: a several-way near-tie is accepted by its gap)
+        assert tc["engines"][1]["near_tie_divergences"] == [{"request": 1, "step": 2, "rank_in_reference": 3, "logprob_gap": 0.04}]
         assert d["saturation"]["output_tokens"] == 6 * 4
         assert d["steps"] == 2 and d["warmup"] == 1
     else:
