@@ -202,18 +202,20 @@ int semipd_decode_attention(void* out, const void* q, const void* k_buf, const v
  * semipd_stream_linear_planes; the rotated k and v of request b go to pool row loc[b], which must be the LAST row of the
  * request in kv_indices (the decode batch's new token); out [batch, o_stride] holds the merged attention output.
  * A workgroup = one (request, kv head) with 2 .. 16 q heads, its `waves` (4 or 8) waves are the kv splits and merge in
- * LDS: no attn_logits scratch, no stage-2 launch.  Meant for batch * Hkv >= about half the CUs; below that the separate calls with more
- * splits fill the chip better.  _supported() tells whether the shape is instantiated (1) or the caller must use the
- * separate calls (0).
+ * LDS: no attn_logits scratch, no stage-2 launch.  zsplits > 1 (batches that do not fill the chip with one workgroup per
+ * pair): zsplits workgroups per (request, kv head), waves * zsplits kv splits in all; each workgroup merges its own and
+ * writes ONE stage-1 partial to attn_logits fp32 [batch, Hq, zsplits, head + 1], and the stage-2 launch of
+ * semipd_decode_attention merges zsplits partials per head (two launches instead of three, tolerance instead of bits).
+ * _supported() tells whether the shape is instantiated (1) or the caller must use the separate calls (0).
  * replaces QKVParallelLinear's output write + RotaryEmbedding.forward_cuda + set_kv_buffer + decode_attention_fwd for
  *   decode batches (layers/linear.py:165-172; layers/rotary_embedding.py:143-169; mem_cache/memory_pool.py:316-346;
  *   layers/attention/triton_ops/decode_attention.py:625-670 with stage 1 :234-390 and stage 2 :476-531). */
 int semipd_decode_rope_attention_planes_supported(int num_q_heads, int num_kv_heads, int head_size, int dtype, int kv_dtype);
-int semipd_decode_rope_attention_planes(void* out, const float* planes, int n_planes, int64_t plane_elems, void* k_buf,
-                                        void* v_buf, const int64_t* loc, const float* cos_sin_cache,
+int semipd_decode_rope_attention_planes(void* out, float* attn_logits, const float* planes, int n_planes, int64_t plane_elems,
+                                        void* k_buf, void* v_buf, const int64_t* loc, const float* cos_sin_cache,
                                         const int64_t* positions, const int32_t* kv_indptr, const int32_t* kv_indices,
                                         int64_t batch, int num_q_heads, int num_kv_heads, int head_size, int64_t o_stride,
-                                        int64_t kbuf_stride, int64_t vbuf_stride, int waves, float sm_scale,
+                                        int64_t kbuf_stride, int64_t vbuf_stride, int waves, int zsplits, float sm_scale,
                                         float logit_cap, int dtype, int kv_dtype, void* stream);
 
 

@@ -393,6 +393,22 @@ decode_stage2_wave_kernel(T* __restrict__ out, const float* __restrict__ attn_lo
   stage2_merge<T>(out + (int64_t)b * o_stride + (int64_t)hq * Dv, base, n_valid, Dv, lane, 64);
 }
 
+template <typename T>
+static int launch_decode_stage2_t(T* out, const float* attn_logits, const int32_t* kv_indptr, int64_t batch, int num_q_heads,
+                                  int head_dim_v, int64_t o_stride, int num_kv_splits, hipStream_t st) {
+  if (head_dim_v >= 256 && batch * num_q_heads >= 4096) {
+    dim3 grid((unsigned)batch, (unsigned)((num_q_heads + 3) / 4));
+    hipLaunchKernelGGL((decode_stage2_wave_kernel<T>), grid, dim3(256), 0, st, out, attn_logits, kv_indptr,
+                       num_q_heads, head_dim_v, o_stride, num_kv_splits);
+  } else {
+    dim3 grid((unsigned)batch, (unsigned)num_q_heads);
+    const int threads = head_dim_v <= 64 ? 64 : head_dim_v <= 128 ? 128 : 256;
+    hipLaunchKernelGGL((decode_stage2_kernel<T>), grid, dim3(threads), 0, st, out, attn_logits, kv_indptr, num_q_heads,
+                       head_dim_v, o_stride, num_kv_splits);
+  }
+  return launch_status("decode_stage2");
+}
+
 template <typename T, int LPR, typename KV = T>
 static int launch_stage1(T* out, const T* q, const KV* k_buf, const KV* v_buf, const int32_t* kv_indptr,
                          const int32_t* kv_indices, float* attn_logits, int64_t batch, int Hq, int Hkv,
@@ -527,20 +543,16 @@ static int run_decode(void* out, const void* q, const void* k_buf, const void* v
                        o_stride, kbuf_stride, vbuf_stride, num_kv_splits, sm_scale, logit_cap);
     rc = launch_status("decode_stage1_generic");
   }
-  if (rc == 0 && num_kv_splits > 1) {
-    if (head_dim_v >= 256 && batch * num_q_heads >= 4096) {
-      dim3 grid((unsigned)batch, (unsigned)((num_q_heads + 3) / 4));
-      hipLaunchKernelGGL((decode_stage2_wave_kernel<T>), grid, dim3(256), 0, st, (T*)out, attn_logits, kv_indptr,
-                         num_q_heads, head_dim_v, o_stride, num_kv_splits);
-    } else {
-      dim3 grid((unsigned)batch, (unsigned)num_q_heads);
-      const int threads = head_dim_v <= 64 ? 64 : head_dim_v <= 128 ? 128 : 256;
-      hipLaunchKernelGGL((decode_stage2_kernel<T>), grid, dim3(threads), 0, st, (T*)out, attn_logits,
-                         kv_indptr, num_q_heads, head_dim_v, o_stride, num_kv_splits);
-    }
-    rc = launch_status("decode_stage2");
-  }
+  if (rc == 0 && num_kv_splits > 1)
+    rc = launch_decode_stage2_t<T>((T*)out, attn_logits, kv_indptr, batch, num_q_heads, head_dim_v, o_stride, num_kv_splits, st);
   return rc;
+}
+
+// stage 2 for the one-launch decode form with several workgroups per (request, kv head) (decode_attention_fused.hip)
+int launch_decode_stage2(void* out, const float* attn_logits, const int32_t* kv_indptr, int64_t batch, int num_q_heads,
+                         int head_dim_v, int64_t o_stride, int num_kv_splits, int dtype, hipStream_t st) {
+  SEMIPD_DISPATCH_HALF(dtype, T, return launch_decode_stage2_t<T>((T*)out, attn_logits, kv_indptr, batch, num_q_heads, head_dim_v, o_stride, num_kv_splits, st));
+  return 0;
 }
 
 }  // namespace semipd

@@ -8,7 +8,8 @@
 // they compute, and the split partials (8.7 MB per layer at 32 requests x 8 splits) made a round trip through HBM.
 //
 // A WORKGROUP owns one (request, kv head); its NW waves are the kv splits (same ranges as decode_mfma_kernel at
-// num_kv_splits = NW, walked by the same code: decode_mfma_walk.h).
+// num_kv_splits = NW, walked by the same code: decode_mfma_walk.h).  (Small batches: Z workgroups per pair, each merging
+// its NW splits into ONE stage-1 partial; decode_stage2_kernel then merges Z partials per head instead of NW * Z.)
 //   1. the lanes that rotate ask for their planes and cos / sin values, then every wave asks for its first tile of K / V
 //      rows and the K rows of the second (unless they hold the new token);
 //   2. the wave whose range ends with the new token sums the planes of k and v, rotates k and stores both pool rows
@@ -25,7 +26,8 @@ namespace semipd {
 
 template <typename T, int D, typename KV, int NW>
 __global__ void __launch_bounds__(NW * 64, 2)
-decode_rope_attn_kernel(T* __restrict__ out, const float* __restrict__ planes, int n_planes, int64_t plane_elems,
+decode_rope_attn_kernel(T* __restrict__ out, float* __restrict__ attn_logits, const float* __restrict__ planes, int n_planes,
+                        int64_t plane_elems,
                         int64_t row_elems, KV* __restrict__ k_buf, KV* __restrict__ v_buf, const int64_t* __restrict__ loc,
                         const float* __restrict__ cache, const int64_t* __restrict__ positions,
                         const int32_t* __restrict__ kv_indptr, const int32_t* __restrict__ kv_indices, int num_q_heads,
@@ -45,21 +47,27 @@ decode_rope_attn_kernel(T* __restrict__ out, const float* __restrict__ planes, i
   const int hq0 = hk * group;
   const bool head_ok = c16 < group;
 
+  // gridDim.y = Z workgroups per (request, kv head): NW * Z kv splits in all, workgroup z owns splits z * NW .. + NW - 1.
+  // Z = 1: the merged result is the output.  Z > 1 (batches too small to fill the chip with one workgroup per pair): the
+  // workgroup's merge is ONE partial of attn_logits[b, hq, z, :] for decode_stage2_kernel -- Z partials per head instead of
+  // NW * Z, and still no separate RoPE launch.
+  const int Z = gridDim.y, z = blockIdx.y;
   const int kv_start = kv_indptr[b];
   const int seq_len = kv_indptr[b + 1] - kv_start;
-  const int per_split = (seq_len + NW - 1) / NW;
-  const int s_begin = per_split * wave;
+  const int per_split = (seq_len + NW * Z - 1) / (NW * Z);
+  const int s_begin = per_split * (z * NW + wave);
   const int s_end = min(s_begin + per_split, seq_len);
   // The new token is the last one of the sequence.  The wave whose range ends with it rotates k, copies v and stores both
   // rows itself (its later loads of that row are ordered behind its own stores by a vmcnt(0)); the other waves rotate q
   // into LDS.  Nobody else reads the new rows, so the workgroup meets on the LDS writes only (a raw barrier: no wave
   // waits for its K / V rows in flight).  Tiles that cannot reach the new token are asked for before all that.
-  const int owner = seq_len > 0 ? (seq_len - 1) / per_split : NW - 1;
+  const int owner_g = seq_len > 0 ? (seq_len - 1) / per_split : NW * Z - 1;
+  const int owner = owner_g / NW == z ? owner_g - z * NW : -1;     // -1: the new token belongs to another workgroup
   constexpr int half = D / 2, IPH = half / V;                 // items of 8 pairs per head
   // a wave that rotates asks for its planes first and for its tiles after the barrier: loads return in order, and behind
   // the K / V rows of two tiles the planes would arrive a memory latency later -- with every wave of every CU of the
   // launch waiting at the same barrier.  The other waves have two tiles in flight by then.
-  const bool rotates = wave == owner || (wave < owner ? wave : wave - 1) * 64 < group * IPH;
+  const bool rotates = wave == owner || ((owner < 0 || wave < owner) ? wave : wave - 1) * 64 < group * IPH;
   const int early_tiles = rotates ? 0 : ((s_begin >= seq_len || s_begin + 64 < seq_len) ? 2 : (s_begin + 32 < seq_len ? 1 : 0));
 
   // ---- the rotation ----
@@ -69,7 +77,7 @@ decode_rope_attn_kernel(T* __restrict__ out, const float* __restrict__ planes, i
     if (lane < IPH) role = ROLE_K, i0 = lane * V;
     else if (lane < IPH + D / V) role = ROLE_V, i0 = (lane - IPH) * V;
   } else {
-    const int it = (wave < owner ? wave : wave - 1) * 64 + lane;   // 16 heads x 8 items <= 2 of the >= 3 other waves
+    const int it = ((owner < 0 || wave < owner) ? wave : wave - 1) * 64 + lane;   // 16 heads x 8 items <= 2 of the >= 3 other waves
     if (it < group * IPH) role = ROLE_Q, item_h = it / IPH, i0 = (it - item_h * IPH) * V;
   }
   const float* pa = planes + (int64_t)b * row_elems + i0 +
@@ -185,8 +193,9 @@ decode_rope_attn_kernel(T* __restrict__ out, const float* __restrict__ planes, i
   }
   __syncthreads();
 
-  // ---- merge (decode_stage2_kernel): splits [0, n_valid) are non-empty ----
-  const int n_valid = per_split > 0 ? min(NW, (seq_len + per_split - 1) / per_split) : 0;
+  // ---- merge (decode_stage2_kernel): this workgroup's splits [0, n_valid) are non-empty ----
+  const int first = z * NW * per_split;
+  const int n_valid = (per_split > 0 && first < seq_len) ? min(NW, (seq_len - first + per_split - 1) / per_split) : 0;
   for (int idx = tid; idx < group * D; idx += NW * 64) {
     const int h = idx / D, d = idx - h * D;
     float e_max = -INFINITY;
@@ -203,21 +212,29 @@ decode_rope_attn_kernel(T* __restrict__ out, const float* __restrict__ planes, i
 #pragma unroll
     for (int s = 0; s < NW; ++s)
       if (s < n_valid) acc = __builtin_fmaf(w[s], reinterpret_cast<const float*>(wave_lds[s])[h * PART_STRIDE + d], acc);
-    out[(int64_t)b * o_stride + (int64_t)(hq0 + h) * D + d] = Elem<T>::from_f(acc * inv);
+    if (Z == 1) {
+      out[(int64_t)b * o_stride + (int64_t)(hq0 + h) * D + d] = Elem<T>::from_f(acc * inv);
+    } else {
+      // a partial in stage 1's form: normalised row + log-sum-exp; an empty workgroup (fewer tokens than splits) leaves
+      // zeros and -inf, which stage 2 weighs with exp(-inf) = 0 wherever its own count of valid splits reaches it
+      float* dst = attn_logits + (((int64_t)b * num_q_heads + hq0 + h) * Z + z) * (D + 1);
+      dst[d] = acc * inv;
+      if (d == 0) dst[D] = n_valid > 0 ? e_max + __logf(e_sum) : -INFINITY;
+    }
   }
 }
 
 template <typename T, typename KV>
-static int launch_decode_rope_attn(void* out, const float* planes, int n_planes, int64_t plane_elems, void* k_buf, void* v_buf,
+static int launch_decode_rope_attn(void* out, float* attn_logits, int zsplits, const float* planes, int n_planes, int64_t plane_elems, void* k_buf, void* v_buf,
                                    const int64_t* loc, const float* cache, const int64_t* positions, const int32_t* kv_indptr,
                                    const int32_t* kv_indices, int64_t batch, int Hq, int Hkv, int D, int64_t o_stride,
                                    int64_t kbuf_stride, int64_t vbuf_stride, int waves, float sm_scale, float logit_cap,
                                    hipStream_t st) {
   const int group = Hq / Hkv;
   const int64_t row_elems = (int64_t)(Hq + 2 * Hkv) * D;
-  dim3 grid((unsigned)(batch * Hkv)), block((unsigned)(waves * 64));
+  dim3 grid((unsigned)(batch * Hkv), (unsigned)zsplits), block((unsigned)(waves * 64));
 #define DF(DD, NW)                                                                                                     \
-  hipLaunchKernelGGL((decode_rope_attn_kernel<T, DD, KV, NW>), grid, block, 0, st, (T*)out, planes, n_planes, plane_elems, \
+  hipLaunchKernelGGL((decode_rope_attn_kernel<T, DD, KV, NW>), grid, block, 0, st, (T*)out, attn_logits, planes, n_planes, plane_elems, \
                      row_elems, (KV*)k_buf, (KV*)v_buf, loc, cache, positions, kv_indptr, kv_indices, Hq, Hkv, group,      \
                      o_stride, kbuf_stride, vbuf_stride, sm_scale, logit_cap)
   if (D == 128 && waves == 8) DF(128, 8);
@@ -246,11 +263,11 @@ int semipd_decode_rope_attention_planes_supported(int num_q_heads, int num_kv_he
   return kv_dtype == dtype || kv_dtype == SEMIPD_F8E5M2 || kv_dtype == SEMIPD_F8E4M3;
 }
 
-int semipd_decode_rope_attention_planes(void* out, const float* planes, int n_planes, int64_t plane_elems, void* k_buf,
-                                        void* v_buf, const int64_t* loc, const float* cos_sin_cache,
+int semipd_decode_rope_attention_planes(void* out, float* attn_logits, const float* planes, int n_planes, int64_t plane_elems,
+                                        void* k_buf, void* v_buf, const int64_t* loc, const float* cos_sin_cache,
                                         const int64_t* positions, const int32_t* kv_indptr, const int32_t* kv_indices,
                                         int64_t batch, int num_q_heads, int num_kv_heads, int head_size, int64_t o_stride,
-                                        int64_t kbuf_stride, int64_t vbuf_stride, int waves, float sm_scale,
+                                        int64_t kbuf_stride, int64_t vbuf_stride, int waves, int zsplits, float sm_scale,
                                         float logit_cap, int dtype, int kv_dtype, void* stream) {
   SEMIPD_CHECK_ARG(batch >= 0 && n_planes >= 1 && head_size > 0 && num_q_heads > 0 && num_kv_heads > 0, SEMIPD_EINVAL,
                    "decode_rope_attention_planes: bad sizes");
@@ -262,7 +279,9 @@ int semipd_decode_rope_attention_planes(void* out, const float* planes, int n_pl
                    "decode_rope_attention_planes: needs Hq %% Hkv == 0, 2 .. 16 q heads per kv head, head size 64 / 128, "
                    "bf16 / f16 activations, pool rows in that type or fp8 (got Hq %d Hkv %d head %d dtype %d kv_dtype %d)",
                    num_q_heads, num_kv_heads, head_size, dtype, kv_dtype);
-  SEMIPD_CHECK_ARG(waves == 4 || waves == 8, SEMIPD_EINVAL, "decode_rope_attention_planes: waves (= kv splits) must be 4 or 8");
+  SEMIPD_CHECK_ARG(waves == 4 || waves == 8, SEMIPD_EINVAL, "decode_rope_attention_planes: waves (kv splits per workgroup) must be 4 or 8");
+  SEMIPD_CHECK_ARG(zsplits >= 1 && zsplits <= 64 && (zsplits == 1 || attn_logits), SEMIPD_EINVAL,
+                   "decode_rope_attention_planes: 1 .. 64 workgroups per (request, kv head); attn_logits scratch required above 1");
   SEMIPD_CHECK_ARG(batch * num_kv_heads < (1ll << 31), SEMIPD_EINVAL, "decode_rope_attention_planes: grid too large");
   const int64_t row_elems = (int64_t)(num_q_heads + 2 * num_kv_heads) * head_size;
   SEMIPD_CHECK_ARG(o_stride % 8 == 0 && kbuf_stride % 16 == 0 && vbuf_stride % 16 == 0 && plane_elems % 4 == 0 &&
@@ -270,8 +289,9 @@ int semipd_decode_rope_attention_planes(void* out, const float* planes, int n_pl
                        aligned16(v_buf),
                    SEMIPD_EALIGN, "decode_rope_attention_planes: 16-byte aligned rows required");
   hipStream_t st = as_stream(stream);
+  int rc = 0;
 #define GO(TT, KVT)                                                                                                       \
-  return launch_decode_rope_attn<TT, KVT>(out, planes, n_planes, plane_elems, k_buf, v_buf, loc, cos_sin_cache, positions, \
+  rc = launch_decode_rope_attn<TT, KVT>(out, attn_logits, zsplits, planes, n_planes, plane_elems, k_buf, v_buf, loc, cos_sin_cache, positions, \
                                           kv_indptr, kv_indices, batch, num_q_heads, num_kv_heads, head_size, o_stride,    \
                                           kbuf_stride, vbuf_stride, waves, sm_scale, logit_cap, st)
   SEMIPD_DISPATCH_HALF(dtype, T, {
@@ -280,7 +300,9 @@ int semipd_decode_rope_attention_planes(void* out, const float* planes, int n_pl
     else GO(T, f8e4m3_t);
   });
 #undef GO
-  return 0;
+  if (rc == 0 && zsplits > 1)
+    rc = launch_decode_stage2(out, attn_logits, kv_indptr, batch, num_q_heads, head_size, o_stride, zsplits, dtype, st);
+  return rc;
 }
 
 }  // extern "C"

@@ -50,6 +50,10 @@ template <int D, typename Raw> struct KRegs {
   Raw k[2][D / 32];
 };
 
+// decode_attention.hip: merge of `num_kv_splits` stage-1 partials per (request, head) (decode_stage2_kernel)
+int launch_decode_stage2(void* out, const float* attn_logits, const int32_t* kv_indptr, int64_t batch, int num_q_heads,
+                         int head_dim_v, int64_t o_stride, int num_kv_splits, int dtype, hipStream_t st);
+
 // bytes of the wave-private V tile in LDS and its row stride
 template <int D> struct DecodeWalkLds {
   static constexpr int PAD = ((D / 2) % 32 == 16) ? 0 : 64;  // row stride == 16 or 48 dwords (mod 64):

@@ -49,8 +49,8 @@ _SIGNATURES = {
     "semipd_decode_attention": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i64,
                                 _i64, _i64, _i64, _i32, _f32, _f32, _i32, _i32, _vp],
     "semipd_decode_rope_attention_planes_supported": [_i32, _i32, _i32, _i32, _i32],
-    "semipd_decode_rope_attention_planes": [_vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32,
-                                            _i64, _i64, _i64, _i32, _f32, _f32, _i32, _i32, _vp],
+    "semipd_decode_rope_attention_planes": [_vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32,
+                                            _i64, _i64, _i64, _i32, _i32, _f32, _f32, _i32, _i32, _vp],
     "semipd_extend_attention": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32,
                                 _i64, _i64, _i64, _i64, _i64, _i64, _i32, _f32, _f32, _i32, _i32, _vp],
     "semipd_extend_attention_masked": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32,

@@ -245,13 +245,15 @@ class HipAttnBackend(AttentionBackend):
 
 
     # ---- decode: RoPE + KV store + attention + split merge in one launch -------------------------
-    def fused_decode_waves(self, bs: int, head_dim: int) -> int:
+    def fused_decode_waves(self, bs: int, head_dim: int, num_kv_splits: int = 0) -> int:
         """How a decode batch of `bs` requests goes from the qkv GEMM's planes to o_proj's input: 0 = the separate
-        launches (rope_and_store_kv_planes, decode_attention_fwd: stage 1 + stage 2), 4 / 8 = ONE launch whose
+        launches (rope_and_store_kv_planes, decode_attention_fwd: stage 1 + stage 2), 4 / 8 = the launch whose
         workgroups are (request, kv head) pairs with that many waves as kv splits (ops.decode_rope_attention_planes,
-        csrc/decode_attention_fused.hip).  The fused form needs about one workgroup per two CUs to fill the chip;
-        smaller batches keep the separate launches, whose split count is free (choose_kv_splits).
-        SEMIPD_FUSED_DECODE_ATTN=0 turns it off, =2 takes it at every batch size (tests); a fixed
+        csrc/decode_attention_fused.hip).  From about half a workgroup per CU up that launch is the whole step between
+        the two GEMMs; a smaller batch gets several workgroups per pair (fused_decode_zsplits) and the stage-2 launch
+        behind them: two launches instead of three.
+        SEMIPD_FUSED_DECODE_ATTN: 0 = off; 2 = one workgroup per pair at every batch size (tests); 4 = only where one
+        workgroup per pair fills the chip (the form of the round's first measurements); a fixed
         --triton-attention-num-kv-splits keeps the reference's form."""
         knob = os.environ.get("SEMIPD_FUSED_DECODE_ATTN", "1")
         if self.is_mla or self.fixed_kv_splits or knob == "0":
@@ -267,19 +269,38 @@ class HipAttnBackend(AttentionBackend):
         wgs, cus = bs * self.num_kv_head, max(1, self.num_cus)
         if wgs >= 2 * cus:
             return 4
-        return 8 if (2 * wgs >= cus or knob == "2") else 0
+        if 2 * wgs >= cus or knob == "2":
+            return 8
+        # several workgroups per pair: worth it from about one workgroup per eight CUs (Llama-3-8B from one request: step
+        # alone 3.32 -> 3.25 ms, at 8 requests 3.65 -> 3.44; the 70B TP = 8 rank's single kv head at 1 .. 8 requests: 16 .. 32
+        # workgroups, 0.5-1 % slower than the separate launches, profiles/r06_decode_step_small_batches.txt)
+        z = max(1, min(64, (int(num_kv_splits or 32) + 7) // 8))
+        return 8 if (knob != "4" and 8 * wgs * z >= cus) else 0
+
+    def fused_decode_zsplits(self, bs: int, num_kv_splits: int) -> int:
+        """Workgroups per (request, kv head) of the fused launch: 1 where that fills the chip, otherwise what brings its
+        8-wave workgroups to the split count choose_kv_splits picked for this batch (its rule: about eight waves per CU,
+        no split shorter than 64 tokens)."""
+        wgs, cus = bs * self.num_kv_head, max(1, self.num_cus)
+        if 2 * wgs >= cus or os.environ.get("SEMIPD_FUSED_DECODE_ATTN", "1") == "2":
+            return 1
+        return max(1, min(64, (int(num_kv_splits) + 7) // 8))
 
     def forward_decode_rope_planes(self, positions, qkv_planes, rotary_emb, layer, forward_batch: ForwardBatch, waves: int):
         md = self.forward_metadata
         pool = forward_batch.token_to_kv_pool
+        zsplits = self.fused_decode_zsplits(qkv_planes.rows, md.num_kv_splits) if waves == 8 else 1
+        if zsplits > 1 and md.attn_logits is None:
+            zsplits = 1
         kt = self._timing()
         t0 = kt.start() if kt else None
         o = ops.decode_rope_attention_planes(
             positions, qkv_planes, layer.tp_q_head_num, layer.tp_k_head_num, layer.head_dim, rotary_emb.cos_sin_cache,
             pool.get_key_buffer(layer.layer_id), pool.get_value_buffer(layer.layer_id), forward_batch.out_cache_loc,
-            md.kv_indptr, md.kv_indices, waves, layer.scaling, layer.logit_cap)
+            md.kv_indptr, md.kv_indices, waves, layer.scaling, layer.logit_cap, zsplits=zsplits,
+            attn_logits=md.attn_logits if zsplits > 1 else None)
         if kt:
-            kt.stop("decode_attention", t0, *self._algo, n_kernels=1)
+            kt.stop("decode_attention", t0, *self._algo, n_kernels=2 if zsplits > 1 else 1)
         return o
 
 

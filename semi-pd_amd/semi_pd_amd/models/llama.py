@@ -84,7 +84,7 @@ class LlamaAttention(nn.Module):
             planes = self.qkv_proj.forward_planes(hidden_states)
             if planes is not None:
                 backend = forward_batch.attn_backend
-                waves = backend.fused_decode_waves(planes.rows, self.head_dim)
+                waves = backend.fused_decode_waves(planes.rows, self.head_dim, backend.forward_metadata.num_kv_splits)
                 if waves:
                     # ... and the same kernel walks the KV rows and merges its splits: one launch up to o_proj's input
                     attn_output = backend.forward_decode_rope_planes(positions, planes, self.rotary_emb, self.attn,

@@ -678,11 +678,13 @@ def decode_rope_attention_planes_supported(num_q_heads: int, num_kv_heads: int, 
 def decode_rope_attention_planes(positions: torch.Tensor, qkv: SplitKPlanes, num_q_heads: int, num_kv_heads: int,
                                  head_size: int, cos_sin_cache: torch.Tensor, k_buffer: torch.Tensor, v_buffer: torch.Tensor,
                                  loc: torch.Tensor, kv_indptr: torch.Tensor, kv_indices: torch.Tensor, waves: int,
-                                 sm_scale: float, logit_cap: float = 0.0) -> torch.Tensor:
+                                 sm_scale: float, logit_cap: float = 0.0, zsplits: int = 1,
+                                 attn_logits: Optional[torch.Tensor] = None) -> torch.Tensor:
     """rope_and_store_kv_planes + decode_attention_fwd (`waves` kv splits, both stages) in ONE launch: the qkv row is
     still the K-slice planes of the decode GEMM; rotated k and v go to the pool rows `loc` (the last row of each request
     in kv_indices); returns the attention output [tokens, Hq * head] (semipd_decode_rope_attention_planes).  Same bits
-    as the separate calls."""
+    as the separate calls.  zsplits > 1 (small batches): that many workgroups per (request, kv head), each writing one
+    merged partial to attn_logits fp32 [tokens, Hq, zsplits, head + 1]; stage 2 follows as a second launch."""
     if cos_sin_cache.dtype != torch.float32 or cos_sin_cache.shape[1] != head_size or not cos_sin_cache.is_contiguous():
         raise RuntimeError("decode_rope_attention_planes: contiguous fp32 cos / sin cache over the whole head expected")
     if qkv.n != (num_q_heads + 2 * num_kv_heads) * head_size:
@@ -701,12 +703,18 @@ def decode_rope_attention_planes(positions: torch.Tensor, qkv: SplitKPlanes, num
         raise RuntimeError("decode_rope_attention_planes: k_buffer / v_buffer dtype mismatch")
     if kv_indptr.dtype != torch.int32 or kv_indices.dtype != torch.int32 or qkv.rows > kv_indptr.shape[0] - 1:
         raise RuntimeError("decode_rope_attention_planes: int32 kv_indptr [tokens + 1] / kv_indices expected")
+    if zsplits > 1:
+        if (attn_logits is None or attn_logits.dtype != torch.float32 or not attn_logits.is_contiguous()
+                or attn_logits.numel() < qkv.rows * num_q_heads * zsplits * (head_size + 1)):
+            raise RuntimeError("decode_rope_attention_planes: contiguous fp32 attn_logits of at least "
+                               "[tokens, Hq, zsplits, head + 1] required when zsplits > 1")
     qkv.check_live("decode_rope_attention_planes")
     o = torch.empty((qkv.rows, num_q_heads * head_size), dtype=qkv.dtype, device=qkv.planes.device)
     check(_lib.load().semipd_decode_rope_attention_planes(
-        ptr(o), ptr(qkv.planes), qkv.ksplit, qkv.rows * qkv.n, ptr(k_buffer), ptr(v_buffer), ptr(loc), ptr(cos_sin_cache),
-        ptr(positions), ptr(kv_indptr), ptr(kv_indices), qkv.rows, num_q_heads, num_kv_heads, head_size, o.stride(0),
-        k_buffer.stride(0), v_buffer.stride(0), waves, sm_scale, logit_cap, dtype_code(qkv.dtype),
+        ptr(o), ptr(attn_logits) if zsplits > 1 else None, ptr(qkv.planes), qkv.ksplit, qkv.rows * qkv.n, ptr(k_buffer),
+        ptr(v_buffer), ptr(loc), ptr(cos_sin_cache), ptr(positions), ptr(kv_indptr), ptr(kv_indices), qkv.rows,
+        num_q_heads, num_kv_heads, head_size, o.stride(0), k_buffer.stride(0), v_buffer.stride(0), waves, int(zsplits),
+        sm_scale, logit_cap, dtype_code(qkv.dtype),
         _lib.kv_dtype_code(k_buffer.dtype), current_stream(o.device)), "decode_rope_attention_planes")
     return o
 

@@ -1317,6 +1317,60 @@ def test_decode_rope_attention_planes_has_the_bits_of_the_three_launches(ops, de
     _close(o2.view(B, Hq, D), want, dtype, rtol=2e-2, atol=4e-3 if dtype == torch.float16 else 1.5e-2)
 
 
+@pytest.mark.parametrize("lens", FUSED_DECODE_LENS + [[7], [3000, 40, 129]], ids=["three", "edges", "long", "one", "ragged"])
+@pytest.mark.parametrize("heads", [(32, 8, 128, 4096), (8, 1, 128, 8192), (32, 2, 64, 2048)],
+                         ids=["llama3_8b", "llama3_70b_tp8_rank", "g16_d64"])
+@pytest.mark.parametrize("zsplits", [2, 3, 4])
+@pytest.mark.parametrize("dtype,kv_dtype", [(torch.bfloat16, None), (torch.float16, torch.float8_e5m2)], ids=["bf16", "f16_fp8kv"])
+def test_decode_rope_attention_planes_with_several_workgroups_per_pair(ops, device, lens, heads, zsplits, dtype, kv_dtype):
+    """Small decode batches: `zsplits` workgroups per (request, kv head), each merging its 8 kv splits into one stage-1
+    partial, stage 2 behind them (two launches where the separate form takes three).  Pool rows: the bits of
+    rope_and_store_kv_planes; output: the oracle's attention over the pool it left behind, and the separate launches' result
+    to the same tolerance (the hierarchical merge rounds differently).  More splits than tokens, one-token requests and
+    requests whose new token sits in the first / last workgroup are in the length lists."""
+    Hq, Hk, D, K = heads
+    B = len(lens)
+    g = torch.Generator().manual_seed(sum(lens) + Hq + zsplits)
+    total = int(sum(lens))
+    slots = total + 13
+    perm = (torch.randperm(slots - 1, generator=g)[:total] + 1).to(torch.int32)
+    indptr = torch.zeros(B + 1, dtype=torch.int32)
+    indptr[1:] = torch.cumsum(torch.tensor(lens), 0)
+    loc = perm[(indptr[1:] - 1).long()].to(torch.int64)
+    pool_dtype = kv_dtype or dtype
+    k0 = torch.randn(slots, Hk, D, generator=g).to(dtype).to(pool_dtype)
+    v0 = torch.randn(slots, Hk, D, generator=g).to(dtype).to(pool_dtype)
+    x = torch.randn(B, K, generator=g).to(dtype).to(device)
+    w = (torch.randn((Hq + 2 * Hk) * D, K, generator=g) * 0.03).to(dtype).to(device)
+    pos = (torch.tensor(lens) - 1).to(torch.int64).to(device)
+    inv = 1.0 / (10000 ** (torch.arange(0, D, 2, dtype=torch.float) / D))
+    fr = torch.einsum("i,j -> ij", torch.arange(4096, dtype=torch.float), inv)
+    cache = torch.cat((fr.cos(), fr.sin()), dim=-1).to(device)
+    sm_scale = 1.0 / (D ** 0.5)
+    indptr_d, perm_d, loc_d = indptr.to(device), perm.to(device), loc.to(device)
+
+    kb1, vb1 = k0.clone().to(device), v0.clone().to(device)
+    q1 = ops.rope_and_store_kv_planes(pos, ops.stream_linear_planes(x, w), Hq, Hk, D, cache, kb1, vb1, loc_d)
+    o1 = torch.empty(B, Hq, D, dtype=dtype, device=device)
+    lg1 = torch.empty(B, Hq, 8 * zsplits, D + 1, dtype=torch.float32, device=device)
+    ops.decode_attention_fwd(q1.view(B, Hq, D), kb1, vb1, o1, indptr_d, perm_d, lg1, 8 * zsplits, sm_scale)
+
+    kb2, vb2 = k0.clone().to(device), v0.clone().to(device)
+    lg2 = torch.full((B, Hq, zsplits, D + 1), float("nan"), dtype=torch.float32, device=device)   # every partial must be written
+    o2 = ops.decode_rope_attention_planes(pos, ops.stream_linear_planes(x, w), Hq, Hk, D, cache, kb2, vb2, loc_d, indptr_d,
+                                          perm_d, 8, sm_scale, zsplits=zsplits, attn_logits=lg2)
+    torch.cuda.synchronize()
+    assert torch.equal(kb2.view(torch.uint8), kb1.view(torch.uint8)) and torch.equal(vb2.view(torch.uint8), vb1.view(torch.uint8))
+    assert not torch.isnan(lg2[..., :D]).any() and not torch.isnan(o2.float()).any()
+    tol = dict(rtol=2e-2, atol=4e-3 if dtype == torch.float16 else 1.5e-2)
+    want = O.decode_attention(q1.view(B, Hq, D).cpu(), kb2.cpu().to(dtype), vb2.cpu().to(dtype), indptr, perm, sm_scale)
+    _close(o2.view(B, Hq, D), want, dtype, **tol)
+    _close(o2.view(B, Hq, D), o1.float(), dtype, **tol)
+    with pytest.raises(RuntimeError, match="attn_logits"):
+        ops.decode_rope_attention_planes(pos, ops.stream_linear_planes(x, w), Hq, Hk, D, cache, kb2, vb2, loc_d, indptr_d, perm_d,
+                                         8, sm_scale, zsplits=zsplits)
+
+
 def test_decode_rope_attention_planes_refuses_what_it_cannot_do(ops, device):
     assert not ops.decode_rope_attention_planes_supported(40, 1, 128, torch.bfloat16, torch.bfloat16)    # 40 q heads per kv head
     assert not ops.decode_rope_attention_planes_supported(12, 12, 64, torch.bfloat16, torch.bfloat16)    # MHA: the shuffle kernel's

@@ -38,10 +38,10 @@ def test_mla_sixteen_heads_and_the_shared_tile_kernel():
 
 
 def test_fused_decode_launch_rule(monkeypatch):
-    """HipAttnBackend.fused_decode_waves: the one-launch RoPE + KV store + attention + split merge (csrc/decode_attention_fused.hip)
-    from about half a workgroup (= one (request, kv head)) per CU up -- below that the separate launches keep a free split
-    count --, four waves per workgroup from two workgroups per CU, never for MLA, one q head per kv head, a fixed
-    --triton-attention-num-kv-splits, or when switched off; SEMIPD_FUSED_DECODE_ATTN=2 takes it at every batch size."""
+    """HipAttnBackend.fused_decode_waves / fused_decode_zsplits: the RoPE + KV store + attention + split merge launch
+    (csrc/decode_attention_fused.hip): one workgroup per (request, kv head) from about half a workgroup per CU up, several
+    per pair (and stage 2 behind them) below that; four waves per workgroup from two workgroups per CU; never for MLA, one q
+    head per kv head, a fixed --triton-attention-num-kv-splits, or when switched off."""
     import types
     import torch
     from semi_pd_amd.layers.attention_backend import HipAttnBackend
@@ -55,10 +55,14 @@ def test_fused_decode_launch_rule(monkeypatch):
 
     monkeypatch.delenv("SEMIPD_FUSED_DECODE_ATTN", raising=False)
     b = backend(32, 8, 256)                                   # Llama-3-8B on the whole chip
-    assert [b.fused_decode_waves(n, 128) for n in (1, 15, 16, 32, 63, 64, 256)] == [0, 0, 8, 8, 8, 4, 4]
-    assert backend(32, 8, 96).fused_decode_waves(6, 128) == 8           # a 96-CU share: from 6 requests
-    assert backend(8, 1, 256).fused_decode_waves(32, 128) == 0          # the 70B TP = 8 rank: 32 workgroups do not fill the chip
-    assert backend(8, 1, 256).fused_decode_waves(128, 128) == 8
+    # 8 waves from the smallest batch (several workgroups per pair below 16 requests), 4 waves from two workgroups per CU
+    assert [b.fused_decode_waves(n, 128, 32) for n in (1, 15, 16, 32, 63, 64, 256)] == [8, 8, 8, 8, 8, 4, 4]
+    assert [b.fused_decode_zsplits(n, s) for n, s in ((1, 32), (8, 32), (8, 17), (15, 17), (16, 16), (32, 8))] == [4, 4, 3, 3, 1, 1]
+    assert backend(32, 8, 96).fused_decode_zsplits(6, 16) == 1           # a 96-CU share: one workgroup per pair from 6 requests
+    r70 = backend(8, 1, 256)                                             # the 70B TP = 8 rank: one kv head
+    assert r70.fused_decode_waves(32, 128, 32) == 8 and r70.fused_decode_zsplits(32, 32) == 4
+    assert [r70.fused_decode_waves(n, 128, 32) for n in (1, 4, 7, 8)] == [0, 0, 0, 8]   # under cus / 8 workgroups: the separate launches
+    assert backend(8, 1, 256).fused_decode_zsplits(128, 16) == 1
     assert backend(32, 8, 256, kv_dtype=torch.float8_e4m3fn).fused_decode_waves(32, 128) == 8   # fp8 pool rows
     assert backend(32, 8, 256).fused_decode_waves(32, 96) == 0          # head size without an instantiation
     assert backend(12, 12, 256).fused_decode_waves(64, 64) == 0         # MHA: the shuffle kernel's shape
@@ -66,5 +70,7 @@ def test_fused_decode_launch_rule(monkeypatch):
     assert backend(32, 8, 256, fixed=16).fused_decode_waves(32, 128) == 0
     monkeypatch.setenv("SEMIPD_FUSED_DECODE_ATTN", "0")
     assert b.fused_decode_waves(32, 128) == 0
-    monkeypatch.setenv("SEMIPD_FUSED_DECODE_ATTN", "2")
-    assert b.fused_decode_waves(1, 128) == 8 and b.fused_decode_waves(256, 128) == 4
+    monkeypatch.setenv("SEMIPD_FUSED_DECODE_ATTN", "2")                  # one workgroup per pair whatever the batch
+    assert b.fused_decode_waves(1, 128) == 8 and b.fused_decode_zsplits(1, 32) == 1 and b.fused_decode_waves(256, 128) == 4
+    monkeypatch.setenv("SEMIPD_FUSED_DECODE_ATTN", "4")                  # only where one workgroup per pair fills the chip
+    assert [b.fused_decode_waves(n, 128) for n in (1, 15, 16, 64)] == [0, 0, 8, 4]
