@@ -83,3 +83,7 @@ if __name__ == "__main__":
         results.append((name, json.load(open(path))))
         if k:
             compare(name, results[0][1], results[-1][1])
+    by_name = dict(results)
+    # the two engines on the SAME kernels (whether they are bit-identical depends on whether their batches were the same)
+    compare("Semi-PD vs unified, both round 6", by_name["all of round 6"], by_name["Semi-PD, all of round 6"])
+    compare("Semi-PD vs unified, both round 5", by_name["baseline"], by_name["Semi-PD, round-5 kernels"])
