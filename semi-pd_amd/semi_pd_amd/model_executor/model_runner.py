@@ -493,7 +493,10 @@ class ModelRunner:
         if os.environ.get("SEMIPD_TALL_PREFILL", "1") == "0":
             return ""
         seen, lines = set(), []
-        margin = float(os.environ.get("SEMIPD_TALL_MARGIN", "0.97"))   # the tiled kernel is taken below margin x the library's time
+        # the tiled kernel is taken below margin x the library's time.  SEMIPD_TALL_MARGIN_WIDE: the same for weights of 16 k
+        # rows and more (gate_up: the library's pick there is a persistent stream-K kernel)
+        margin = float(os.environ.get("SEMIPD_TALL_MARGIN", "0.97"))
+        margin_wide = float(os.environ.get("SEMIPD_TALL_MARGIN_WIDE", str(margin)))
 
         def timed(fn, iters=3):
             fn()
@@ -524,7 +527,7 @@ class ModelRunner:
                             continue
                         t_lib = timed((lambda: ops.silu_and_mul(ops.dense_gemm(x, w))) if silu else (lambda: ops.dense_gemm(x, w)))
                         t_tall = timed(lambda: ops.gemm_tall(x, w, fuse_silu_mul=silu))
-                        wins.append((r, t_tall < margin * t_lib))
+                        wins.append((r, t_tall < (margin_wide if w.shape[0] >= 16384 else margin) * t_lib))
                         lines.append(f"n={w.shape[0]} k={w.shape[1]} silu={int(silu)} rows={r}: library {t_lib:.1f} us, tiled {t_tall:.1f} us"
                                      f"{'  <- tiled' if wins[-1][1] else ''}")
                         del x
