@@ -75,6 +75,10 @@ def main():
         total_n = sum(r[1] for r in rows)
         total_t = sum(r[2] for r in rows)
         print(f"  {total_n} kernel launches, {total_t / 1e3:.3f} ms of kernel time in one step")
+        if total_n == 0:
+            print("  (torch's profiler sees no kernels of a hipGraph replay on this image: run the command without --kernels under\n"
+                  "   `rocprofv3 --kernel-trace --stats --output-format csv -d <dir> -- python tools/decode_step_bench.py ... --steps 200`\n"
+                  "   and read <dir>/**/*kernel_stats.csv with tools/stats_top.py -- profiles/r06_decode_step_*_kernel_stats.csv were made so)")
         for k, c, t in rows[:24]:
             print(f"  {c:5d} x {t / c:8.1f} us = {t / 1e3:7.3f} ms  {k[:100]}")
 
