@@ -471,14 +471,15 @@ int semipd_stream_linear_set_cus(int cus) {
   return 0;
 }
 
-// Narrow workgroups (four waves = 64 weight rows, 72 KB of LDS: two per CU) for the plain epilogue at <= 32 rows of a SMALL
-// weight: o_proj of Llama-3-8B (4096 x 4096) is 32 workgroups of 128 rows per K slice -- with the four slices the cost rule
+// Narrow workgroups (four waves = 64 weight rows; 72 KB of LDS up to 32 rows: two per CU) for the plain epilogue of a SMALL
+// weight at <= 64 rows: o_proj of Llama-3-8B (4096 x 4096) is 32 workgroups of 128 rows per K slice -- with the four slices the cost rule
 // picks, a workgroup on half of the chip's CUs, and what a CU pulls from HBM is the limit this kernel runs into.  Measured
 // (profiles/r06_kbench_narrow_workgroups.txt, 32 rows, whole chip): o_proj 10.4 -> 8.5 us, the 70B TP = 8 rank's qkv (1280 x
-// 8192) 10.0 -> 7.7, its o_proj (8192 x 1024) 7.2 -> 6.1; no gain from 25 M weight elements up (qkv 8B, down_proj).
+// 8192) 10.0 -> 7.7, its o_proj (8192 x 1024) 7.2 -> 6.1; at 64 rows 11.8 -> 9.6, 11.7 -> 9.0, 8.4 -> 6.9; no gain from 25 M
+// weight elements up (qkv 8B, down_proj).
 // SEMIPD_SL_NW: 4 = always where it applies, 8 = never; otherwise weights of at most SEMIPD_SL_NARROW_MAX_NK elements (2^24).
 static bool sg_narrow(int mt, int N, int K, int fuse_silu_mul) {
-  if (fuse_silu_mul || mt > 2) return false;
+  if (fuse_silu_mul || mt > 4) return false;   // (33 .. 64 rows: 84 / 96 KB of LDS, one workgroup per CU -- still a workgroup on every CU)
   const int knob = sl_env("SEMIPD_SL_NW", 0);
   if (knob == 4) return true;
   if (knob == 8) return false;
@@ -527,8 +528,9 @@ int semipd_stream_linear(void* out, const void* x, const void* weight, void* wor
   if (fuse_silu_mul) { SEMIPD_DISPATCH_HALF(dtype, T, rc = (sg_launch<T, MTV, 2, 4, 3, SL_SILU_MUL, 2>((T*)out, planes, pb, (const T*)x, (const T*)weight, M, N, K, ldx, ldo, force_ks, st))); } \
   else { SEMIPD_DISPATCH_HALF(dtype, T, rc = (sg_launch<T, MTV, 2, 4, 3, SL_PLAIN, 2>((T*)out, planes, pb, (const T*)x, (const T*)weight, M, N, K, ldx, ldo, force_ks, st))); }
   if (sg_narrow(mt, N, K, fuse_silu_mul)) {
-    if (mt == 1) { SEMIPD_DISPATCH_HALF(dtype, T, rc = (sg_launch<T, 1, 1, 4, 3, SL_PLAIN>((T*)out, planes, pb, (const T*)x, (const T*)weight, M, N, K, ldx, ldo, force_ks, st))); }
-    else { SEMIPD_DISPATCH_HALF(dtype, T, rc = (sg_launch<T, 2, 1, 4, 3, SL_PLAIN>((T*)out, planes, pb, (const T*)x, (const T*)weight, M, N, K, ldx, ldo, force_ks, st))); }
+#define SL_NARROW(MTV) SEMIPD_DISPATCH_HALF(dtype, T, rc = (sg_launch<T, MTV, 1, 4, 3, SL_PLAIN>((T*)out, planes, pb, (const T*)x, (const T*)weight, M, N, K, ldx, ldo, force_ks, st)));
+    if (mt == 1) { SL_NARROW(1) } else if (mt == 2) { SL_NARROW(2) } else if (mt == 3) { SL_NARROW(3) } else { SL_NARROW(4) }
+#undef SL_NARROW
   }
   else if (mt == 1) { if (deep) { SL_GO(1, 4) } else { SL_GO(1, 3) } }
   else if (mt == 2) { if (deep) { SL_GO(2, 4) } else { SL_GO(2, 3) } }
@@ -560,8 +562,9 @@ int semipd_stream_linear_planes(float* planes, size_t planes_bytes, const void* 
 #define SL_WIDE(MTV) \
   SEMIPD_DISPATCH_HALF(dtype, T, rc = (sg_launch<T, MTV, 2, 4, 3, SL_PLAIN, 2>((T*)nullptr, planes, planes_bytes, (const T*)x, (const T*)weight, M, N, K, ldx, N, sl_env("SEMIPD_SL_KS", 0), st, ksplit)));
   if (sg_narrow(mt, N, K, 0)) {
-    if (mt == 1) { SEMIPD_DISPATCH_HALF(dtype, T, rc = (sg_launch<T, 1, 1, 4, 3, SL_PLAIN>((T*)nullptr, planes, planes_bytes, (const T*)x, (const T*)weight, M, N, K, ldx, N, sl_env("SEMIPD_SL_KS", 0), st, ksplit))); }
-    else { SEMIPD_DISPATCH_HALF(dtype, T, rc = (sg_launch<T, 2, 1, 4, 3, SL_PLAIN>((T*)nullptr, planes, planes_bytes, (const T*)x, (const T*)weight, M, N, K, ldx, N, sl_env("SEMIPD_SL_KS", 0), st, ksplit))); }
+#define SL_NARROW(MTV) SEMIPD_DISPATCH_HALF(dtype, T, rc = (sg_launch<T, MTV, 1, 4, 3, SL_PLAIN>((T*)nullptr, planes, planes_bytes, (const T*)x, (const T*)weight, M, N, K, ldx, N, sl_env("SEMIPD_SL_KS", 0), st, ksplit)));
+    if (mt == 1) { SL_NARROW(1) } else if (mt == 2) { SL_NARROW(2) } else if (mt == 3) { SL_NARROW(3) } else { SL_NARROW(4) }
+#undef SL_NARROW
   }
   else if (mt == 1) { if (deep) { SL_GO(1, 4) } else { SL_GO(1, 3) } }
   else if (mt == 2) { if (deep) { SL_GO(2, 4) } else { SL_GO(2, 3) } }

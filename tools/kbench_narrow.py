@@ -39,9 +39,9 @@ print(f"# us per call (planes form, hipGraph of {REP}); columns: K slices " + " 
 for name, N, K in (("qkv", 6144, 4096), ("o_proj", 4096, 4096), ("down", 4096, 14336), ("qkv 70b/tp8", 1280, 8192),
                    ("o 70b/tp8", 8192, 1024), ("down 70b/tp8", 8192, 3584)):
     ws = [torch.randn(N, K, device=dev, dtype=torch.bfloat16) * 0.01 for _ in range(3)]   # rotate: not out of L2 / MALL
-    for M in (16, 32):
+    for M in [int(m) for m in os.environ.get("KBENCH_ROWS", "16,32").split(",")]:
         x = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
-        for nw in (8, 4):
+        for nw in [int(v) for v in os.environ.get("KBENCH_NW", "8,4").split(",")]:
             os.environ["SEMIPD_SL_NW"] = str(nw)
             row = []
             for ks in KS:
