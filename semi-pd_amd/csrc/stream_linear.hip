@@ -487,6 +487,17 @@ static bool sg_narrow(int mt, int N, int K, int fuse_silu_mul) {
   return (int64_t)N * K <= max_nk;
 }
 
+// The same idea at 65 .. 128 rows: one group of 16 weight rows per wave (64 rows per workgroup, 112 KB of LDS) instead of two.
+// Measured (profiles/r06_kbench_wide_rows_stream_vs_tiled.txt, second table; 80 / 128 rows): o_proj 17.5 -> 14.6 / 21.8 ->
+// 18.4 us, qkv (25 M elements) 20.2 -> 19.4 / 25.1 -> 23.1, down_proj (59 M) 29.8 -> 28.4 / 35.4 -> 36.9: weights of up to
+// 2^25 elements.  SEMIPD_SL_WIDE_NARROW: 2 = always, 0 = never.
+static bool sg_wide_narrow(int N, int K, int fuse_silu_mul) {
+  if (fuse_silu_mul) return false;
+  const int knob = sl_env("SEMIPD_SL_WIDE_NARROW", 1);
+  if (knob == 2) return true;
+  return knob == 1 && (int64_t)N * K <= (1ll << 25);
+}
+
 size_t semipd_stream_linear_workspace(int64_t max_n) {
   return (size_t)16 * 64 * (size_t)max_n * 4;   // 16 K slices of [64 rows, n] fp32
 }
@@ -535,6 +546,11 @@ int semipd_stream_linear(void* out, const void* x, const void* weight, void* wor
   else if (mt == 1) { if (deep) { SL_GO(1, 4) } else { SL_GO(1, 3) } }
   else if (mt == 2) { if (deep) { SL_GO(2, 4) } else { SL_GO(2, 3) } }
   else if (mt == 3) { SL_GO(3, 3) } else if (mt == 4) { SL_GO(4, 3) }
+  else if (sg_wide_narrow(N, K, fuse_silu_mul)) {
+#define SL_WN(MTV) SEMIPD_DISPATCH_HALF(dtype, T, rc = (sg_launch<T, MTV, 1, 4, 3, SL_PLAIN, 2>((T*)out, planes, pb, (const T*)x, (const T*)weight, M, N, K, ldx, ldo, force_ks, st)));
+    if (mt <= 6) { SL_WN(6) } else { SL_WN(8) }
+#undef SL_WN
+  }
   else if (mt <= 6) { SL_WIDE(6) } else { SL_WIDE(8) }
 #undef SL_WIDE
 #undef SL_GO
@@ -569,6 +585,11 @@ int semipd_stream_linear_planes(float* planes, size_t planes_bytes, const void* 
   else if (mt == 1) { if (deep) { SL_GO(1, 4) } else { SL_GO(1, 3) } }
   else if (mt == 2) { if (deep) { SL_GO(2, 4) } else { SL_GO(2, 3) } }
   else if (mt == 3) { SL_GO(3, 3) } else if (mt == 4) { SL_GO(4, 3) }
+  else if (sg_wide_narrow(N, K, 0)) {
+#define SL_WN(MTV) SEMIPD_DISPATCH_HALF(dtype, T, rc = (sg_launch<T, MTV, 1, 4, 3, SL_PLAIN, 2>((T*)nullptr, planes, planes_bytes, (const T*)x, (const T*)weight, M, N, K, ldx, N, sl_env("SEMIPD_SL_KS", 0), st, ksplit)));
+    if (mt <= 6) { SL_WN(6) } else { SL_WN(8) }
+#undef SL_WN
+  }
   else if (mt <= 6) { SL_WIDE(6) } else { SL_WIDE(8) }
 #undef SL_WIDE
 #undef SL_GO
